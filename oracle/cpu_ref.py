@@ -1,0 +1,773 @@
+"""CPU oracle for the ensemble-geometry hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy/SciPy restatement of the arithmetic of the reference
+(ntampellini/FIRECODE v2.0.4, paths relative to /root/reference) for the path
+named in BASELINE.json.  It is the *checker*: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it.  Nothing under ``firecode_amd/`` imports it, and the product never
+falls back to it.
+
+Parity status ("Oracle"):
+
+* PINNED -- functions whose body is in the reference tree.  They are restated
+  line by line here and checked in ``tests/test_oracle_golden.py`` against
+  golden vectors produced by the reference's own function objects
+  (``tests/golden/make_golden.py``):
+  ``align_vec_pair`` (firecode/algebra.py:28-49), ``count_clashes``
+  (algebra.py:52-54), ``cartesian_product`` (utils.py:219-221),
+  ``rotation_matrix_from_vectors`` (utils.py:224-249), ``polygonize``
+  (utils.py:252-312), ``compenetration_check`` (utils.py:507-575),
+  ``rmsd_similarity`` loop (utils.py:494-504), ``get_embed``
+  (embeds.py:808-817), ``torsion_comp_check`` (torsion_module.py:894-918),
+  ``tfd_similarity`` (torsion_module.py:1056-1067), the greedy loop of
+  ``prune_conformers_tfd`` (torsion_module.py:957-1043), ``fitness_check``
+  (optimization_methods.py:163-180, restated; module not importable),
+  ``Ensemble`` xyz text format (ensemble.py:58-98, 284-297).
+
+* PARITY UNPINNED -- functions whose arithmetic lives in the third-party
+  package ``prism_pruner`` (pinned 0.0.7 in pixi.lock:5054-5063), which is
+  neither vendored in the reference tree nor installed here.  They are restated
+  from its published algorithm and from the evidence in the reference tree
+  (call sites, the in-tree Kabsch twin ``align_vec_pair``, CHANGELOG.md:120,
+  188,198,206,256).  The reference's tests hold no numeric vector for them
+  (firecode/tests/test_suite.py asserts exit codes only), so they are checked
+  by property tests, not golden vectors: ``get_alignment_matrix``,
+  ``rmsd_and_max``, ``prune_by_rmsd``, ``prune_by_moment_of_inertia``,
+  ``get_inertia_moments``, ``align_structures``, ``rotate_dihedral``,
+  ``dihedral``, ``rot_mat_from_pointer``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+from scipy.spatial.distance import cdist
+
+# --------------------------------------------------------------------------
+# periodic table slice (prism_pruner.periodic_table MASSES_TABLE / INDEX_TABLE;
+# standard IUPAC atomic weights) -- enough for organic/organometallic inputs
+# --------------------------------------------------------------------------
+_ELEMENTS = (
+    "H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn Fe Co Ni Cu Zn "
+    "Ga Ge As Se Br Kr Rb Sr Y Zr Nb Mo Tc Ru Rh Pd Ag Cd In Sn Sb Te I Xe"
+).split()
+_MASSES = (
+    1.008, 4.002602, 6.94, 9.0121831, 10.81, 12.011, 14.007, 15.999, 18.998403163, 20.1797,
+    22.98976928, 24.305, 26.9815385, 28.085, 30.973761998, 32.06, 35.45, 39.948, 39.0983,
+    40.078, 44.955908, 47.867, 50.9415, 51.9961, 54.938044, 55.845, 58.933194, 58.6934,
+    63.546, 65.38, 69.723, 72.630, 74.921595, 78.971, 79.904, 83.798, 85.4678, 87.62,
+    88.90584, 91.224, 92.90637, 95.95, 97.0, 101.07, 102.90550, 106.42, 107.8682, 112.414,
+    114.818, 118.710, 121.760, 127.60, 126.90447, 131.293,
+)
+MASSES_TABLE = dict(zip(_ELEMENTS, _MASSES))
+INDEX_TABLE = {el: i + 1 for i, el in enumerate(_ELEMENTS)}
+
+# k-ladder shared by the in-tree TFD pruner (torsion_module.py:973) and the pruner
+LADDER = (500000, 200000, 100000, 50000, 20000, 10000, 5000, 2000, 1000, 500,
+          200, 100, 50, 20, 10, 5, 2, 1)
+
+
+# --------------------------------------------------------------------------
+# Kabsch / RMSD  (prism_pruner.rmsd -- parity unpinned; convention pinned to
+# the in-tree twin firecode/algebra.py:28-49)
+# --------------------------------------------------------------------------
+def align_vec_pair(ref, tgt):
+    """firecode/algebra.py:28-49, literal: B[i,k] = sum_j ref[j][i]*tgt[j][k];
+    u,s,vh = svd(B); det(u@vh) < 0 -> flip last column of u; return u@vh."""
+    B = np.zeros((3, 3))
+    for i in range(3):
+        for k in range(3):
+            tot = 0
+            for j in range(2):
+                tot += ref[j][i] * tgt[j][k]
+            B[i, k] = tot
+    u, s, vh = np.linalg.svd(B)
+    if np.linalg.det(u @ vh) < 0:
+        u[:, -1] = -u[:, -1]
+    return np.ascontiguousarray(np.dot(u, vh))
+
+
+def get_alignment_matrix(p, q):
+    """Rotation M (3,3) that, applied as ``(M @ q.T).T``, best superposes q
+    onto p (call site firecode/hypermolecule_class.py:77-84).  N-atom Kabsch
+    with exactly the convention of the in-tree twin (algebra.py:28-49):
+    covariance ``B = p.T @ q``, SVD, det-fix on the last column of u."""
+    p = np.asarray(p, dtype=np.float64)
+    q = np.asarray(q, dtype=np.float64)
+    B = p.T @ q
+    u, s, vh = np.linalg.svd(B)
+    if np.linalg.det(u @ vh) < 0:
+        u[:, -1] = -u[:, -1]
+    return np.ascontiguousarray(u @ vh)
+
+
+def rmsd_and_max(p, q, center=False):
+    """(rmsd, maxdev) after optimal rotation (call sites utils.py:499,
+    embedder.py:1784, ase_manipulations.py:1384).  ``center=True`` subtracts
+    each structure's centroid first (on copies)."""
+    p = np.array(p, dtype=np.float64)
+    q = np.array(q, dtype=np.float64)
+    if center:
+        p -= p.mean(axis=0)
+        q -= q.mean(axis=0)
+    M = get_alignment_matrix(p, q)
+    diff = p - (M @ q.T).T
+    sq = (diff * diff).sum(axis=1)
+    rmsd = np.sqrt(sq.sum() / len(diff))
+    maxdev = np.sqrt(sq).max()
+    return float(rmsd), float(maxdev)
+
+
+def rmsd_and_max_batch(P, Q, center=False):
+    """Vectorised ``rmsd_and_max`` over stacks P, Q of shape (K, A, 3) --
+    same arithmetic through NumPy's stacked SVD; used for the all-pairs
+    matrices the parity tests compare against."""
+    P = np.array(P, dtype=np.float64)
+    Q = np.array(Q, dtype=np.float64)
+    if center:
+        P -= P.mean(axis=1, keepdims=True)
+        Q -= Q.mean(axis=1, keepdims=True)
+    B = np.einsum("kai,kaj->kij", P, Q)
+    u, s, vh = np.linalg.svd(B)
+    flip = np.linalg.det(u @ vh) < 0
+    u[flip, :, -1] *= -1.0
+    M = u @ vh
+    diff = P - np.einsum("kij,kaj->kai", M, Q)
+    sq = (diff * diff).sum(axis=2)
+    return np.sqrt(sq.sum(axis=1) / P.shape[1]), np.sqrt(sq).max(axis=1)
+
+
+def rmsd_similarity(ref, structures, rmsd_thr=0.5):
+    """firecode/utils.py:494-504, literal."""
+    for structure in structures:
+        rmsd_value, maxdev_value = rmsd_and_max(ref, structure)
+        if rmsd_value < rmsd_thr and maxdev_value < 2 * rmsd_thr:
+            return True
+    return False
+
+
+def align_structures(structures, indices=None):
+    """Every conformer Kabsch-superposed on the first, optionally fitting only
+    the ``indices`` atoms (call sites embedder.py:1704,1910,2218,2300).
+    Restated: centre the fit subset of each structure, rotate the whole
+    structure, output expressed in the frame where the reference's fit subset
+    is centred at the origin."""
+    structures = np.asarray(structures, dtype=np.float64)
+    idx = np.arange(structures.shape[1]) if indices is None else np.asarray(indices, dtype=np.int64)
+    ref = structures[0]
+    ref_c = ref[idx].mean(axis=0)
+    out = np.empty_like(structures)
+    out[0] = ref - ref_c
+    for t in range(1, len(structures)):
+        tgt = structures[t]
+        tgt_c = tgt[idx].mean(axis=0)
+        M = get_alignment_matrix(ref[idx] - ref_c, tgt[idx] - tgt_c)
+        out[t] = (M @ (tgt - tgt_c).T).T
+    return out
+
+
+# --------------------------------------------------------------------------
+# greedy k-ladder pruner  (prism_pruner.pruner -- parity unpinned)
+# --------------------------------------------------------------------------
+def heavy_mask(atoms):
+    return np.asarray(atoms) != "H"
+
+
+def greedy_prune(n, similar, energies=None, max_dE=0.0, min_per_group=20, trace=None):
+    """Iterative subset pruning (CHANGELOG.md:120,188,198,206).
+
+    For each ladder value k with ``k == 1 or min_per_group*k < n_active`` the
+    structure array is cut into k contiguous chunks of ``n // k`` (last chunk
+    takes the remainder).  Inside a chunk a structure i that is active at the
+    start of the level is removed "at the first instance of a similar one":
+    as soon as an active j > i of the same chunk with ``similar(i, j)`` is
+    found.  Pairs found dissimilar are cached and never evaluated again.
+    With energies, structures are processed in ascending-energy order
+    (``np.argsort(energies)``), a pair further apart than ``max_dE`` is never
+    similar, and the mask is returned in the caller's order.
+
+    ``similar(i, j)`` receives indices into the caller's (unsorted) arrays.
+    Returns the boolean survivor mask (n,).
+    """
+    if energies is not None and len(energies) == n and n > 0:
+        energies = np.asarray(energies, dtype=np.float64)
+        order = np.argsort(energies)
+    else:
+        energies = None
+        order = np.arange(n)
+    mask = np.ones(n, dtype=bool)  # in processing (sorted) order
+    cache = set()
+    calls = 0
+    for k in LADDER:
+        if k == 1 or min_per_group * k < np.count_nonzero(mask):
+            chunk = n // k
+            out = np.ones(n, dtype=bool)
+            for c in range(k):
+                first = c * chunk
+                last = n if c == k - 1 else chunk * (c + 1)
+                for i in range(first, last):
+                    if not mask[i]:
+                        out[i] = False
+                        continue
+                    for j in range(i + 1, last):
+                        if not mask[j]:
+                            continue
+                        if (i, j) in cache:
+                            continue
+                        a, b = order[i], order[j]
+                        if energies is not None and abs(energies[a] - energies[b]) >= max_dE:
+                            sim = False
+                        else:
+                            sim = bool(similar(a, b))
+                            calls += 1
+                        if sim:
+                            out[i] = False
+                            break
+                        cache.add((i, j))
+            mask = out
+            if trace is not None:
+                trace.append((k, int(np.count_nonzero(mask))))
+    result = np.empty(n, dtype=bool)
+    result[order] = mask
+    return result
+
+
+def greedy_prune_from_matrix(S, energies=None, max_dE=0.0, min_per_group=20):
+    """Same result as ``greedy_prune`` when every pair's similarity is known
+    up front: S[a, b] (bool, indices in the caller's order, symmetric use of
+    the (min,max) processing pair).  A level reduces to
+    ``out[i] = in[i] and not any(in[j] and S[i,j] for j in chunk, j > i)``
+    because rejections inside a level never feed back into that level."""
+    n = S.shape[0]
+    if energies is not None and len(energies) == n and n > 0:
+        energies = np.asarray(energies, dtype=np.float64)
+        order = np.argsort(energies)
+        Ss = S[np.ix_(order, order)]
+        e = energies[order]
+        Ss = Ss & (np.abs(e[:, None] - e[None, :]) < max_dE)
+    else:
+        order = np.arange(n)
+        Ss = S
+    mask = np.ones(n, dtype=bool)
+    for k in LADDER:
+        if k == 1 or min_per_group * k < np.count_nonzero(mask):
+            chunk = n // k
+            out = mask.copy()
+            for c in range(k):
+                first = c * chunk
+                last = n if c == k - 1 else chunk * (c + 1)
+                sub = np.triu(Ss[first:last, first:last], 1) & mask[first:last][None, :]
+                out[first:last] &= ~sub.any(axis=1)
+            mask = out
+    result = np.empty(n, dtype=bool)
+    result[order] = mask
+    return result
+
+
+def prune_by_rmsd(structures, atoms, max_rmsd=0.25, max_dev=None, energies=None, max_dE=0.0):
+    """Heavy-atom Kabsch-RMSD pruning (call sites ensemble.py:230-235,
+    embedder.py:1472-1474).  Similar <=> ``rmsd < max_rmsd and maxdev <
+    max_dev`` with ``max_dev = 2*max_rmsd`` by default -- the rule of the
+    in-tree sibling utils.py:501.  Structures are centred on their heavy-atom
+    centroid.  Returns (structures[mask], mask)."""
+    structures = np.asarray(structures, dtype=np.float64)
+    if max_dev is None:
+        max_dev = 2 * max_rmsd
+    hv = heavy_mask(atoms)
+    X = structures[:, hv, :]
+    X = X - X.mean(axis=1, keepdims=True)
+
+    def similar(a, b):
+        r, m = rmsd_and_max(X[a], X[b])
+        return r < max_rmsd and m < max_dev
+
+    mask = greedy_prune(len(X), similar, energies=energies, max_dE=max_dE)
+    return structures[mask], mask
+
+
+def rmsd_similarity_matrix(structures, atoms, max_rmsd, max_dev=None, block=200000):
+    """All-pairs (N,N) boolean similarity + rmsd + maxdev matrices through the
+    vectorised Kabsch; upper triangle mirrored."""
+    structures = np.asarray(structures, dtype=np.float64)
+    if max_dev is None:
+        max_dev = 2 * max_rmsd
+    hv = heavy_mask(atoms)
+    X = structures[:, hv, :]
+    X = X - X.mean(axis=1, keepdims=True)
+    n = len(X)
+    iu, ju = np.triu_indices(n, 1)
+    R = np.zeros((n, n))
+    D = np.zeros((n, n))
+    for s in range(0, len(iu), block):
+        r, d = rmsd_and_max_batch(X[iu[s:s + block]], X[ju[s:s + block]])
+        R[iu[s:s + block], ju[s:s + block]] = r
+        D[iu[s:s + block], ju[s:s + block]] = d
+    R = R + R.T
+    D = D + D.T
+    S = (R < max_rmsd) & (D < max_dev)
+    np.fill_diagonal(S, False)
+    return S, R, D
+
+
+# --------------------------------------------------------------------------
+# moments of inertia  (prism_pruner.algebra.get_inertia_moments / pruner)
+# --------------------------------------------------------------------------
+def get_inertia_moments(coords, masses):
+    """Three principal moments of inertia, ascending (call sites
+    hypermolecule_class.py:66,72).  Coordinates are taken relative to the
+    centre of mass; tensor I = sum m (|r|^2 1 - r r^T)."""
+    coords = np.asarray(coords, dtype=np.float64)
+    masses = np.asarray(masses, dtype=np.float64)
+    com = (coords * masses[:, None]).sum(axis=0) / masses.sum()
+    r = coords - com
+    r2 = (r * r).sum(axis=1)
+    I = np.zeros((3, 3))
+    for i in range(3):
+        for j in range(3):
+            I[i, j] = (masses * ((r2 if i == j else 0.0) - r[:, i] * r[:, j])).sum()
+    return np.linalg.eigvalsh(I)
+
+
+def prune_by_moment_of_inertia(structures, atoms, max_deviation=0.01, energies=None, max_dE=0.0):
+    """MOI pruning (call sites ensemble.py:211-216, embedder.py:1452-1454):
+    same greedy scheme; similar <=> all three ``|I1_k - I2_k| / I1_k <
+    max_deviation`` (1 %: CHANGELOG.md:256), I1 being the earlier structure
+    of the pair in processing order."""
+    structures = np.asarray(structures, dtype=np.float64)
+    masses = np.array([MASSES_TABLE[a] for a in atoms])
+    moi = np.array([get_inertia_moments(s, masses) for s in structures])
+
+    def similar(a, b):
+        for k in range(3):
+            if abs(moi[a, k] - moi[b, k]) / moi[a, k] >= max_deviation:
+                return False
+        return True
+
+    mask = greedy_prune(len(structures), similar, energies=energies, max_dE=max_dE)
+    return structures[mask], mask
+
+
+# --------------------------------------------------------------------------
+# clash / compenetration checks  (in tree -- pinned)
+# --------------------------------------------------------------------------
+def count_clashes(coords):
+    """firecode/algebra.py:52-54, literal."""
+    return int(np.count_nonzero((cdist(coords, coords) < 0.5) & (cdist(coords, coords) > 0)))
+
+
+def compenetration_check(coords, graph_edges=None, ids=None, thresh=1.0, max_clashes=0):
+    """firecode/utils.py:507-575, literal.  ``graph_edges``: iterable of
+    undirected (i, j) bonds standing in for ``graph.edges`` membership."""
+    if ids is None:
+        if count_clashes(coords) > max_clashes:
+            return False
+        if graph_edges is None:
+            return True
+        edges = set()
+        for a, b in graph_edges:
+            edges.add((int(a), int(b)))
+            edges.add((int(b), int(a)))
+        clashes = 0
+        dist_mat = cdist(coords, coords)
+        for i1, i2 in np.argwhere(dist_mat < thresh):
+            if clashes > max_clashes:
+                return False
+            if i1 != i2 and (int(i1), int(i2)) not in edges:
+                clashes += 1
+        return True
+
+    if len(ids) == 2:
+        m1 = coords[0: ids[0]]
+        m2 = coords[ids[0]:]
+        return int(np.count_nonzero(cdist(m2, m1) < thresh)) <= max_clashes
+
+    clashes = 0
+    m1 = coords[0: ids[0]]
+    m2 = coords[ids[0]: ids[0] + ids[1]]
+    m3 = coords[ids[0] + ids[1]:]
+    clashes += int(np.count_nonzero(cdist(m2, m1) <= thresh))
+    if clashes > max_clashes:
+        return False
+    clashes += int(np.count_nonzero(cdist(m3, m2) <= thresh))
+    if clashes > max_clashes:
+        return False
+    clashes += int(np.count_nonzero(cdist(m1, m3) <= thresh))
+    if clashes > max_clashes:
+        return False
+    return True
+
+
+def fitness_check(coords, constraints, targets, threshold):
+    """firecode/optimization_methods.py:163-180, restated."""
+    error = 0.0
+    for (a, b), target in zip(constraints, targets):
+        if target is not None:
+            error += float(np.linalg.norm(coords[a] - coords[b]) - target)
+    return error < threshold
+
+
+# --------------------------------------------------------------------------
+# rigid roto-translation / embed  (in tree -- pinned) + 3P helpers
+# --------------------------------------------------------------------------
+def cartesian_product(*arrays):
+    """firecode/utils.py:219-221, literal."""
+    arrays_converted = [np.asarray(arr) for arr in arrays]
+    return np.stack(np.meshgrid(*arrays_converted), -1).reshape(-1, len(arrays))
+
+
+def rot_mat_from_pointer(pointer, angle):
+    """Proper rotation by ``angle`` degrees about ``pointer`` (need not be a
+    unit vector; call sites embeds.py:539,694).  prism_pruner.algebra, restated
+    from its published quaternion form (scalar-last quaternion
+    [sin(a/2) n, cos(a/2)] -> matrix)."""
+    pointer = np.asarray(pointer, dtype=np.float64)
+    angle_2 = angle / 2
+    angle_2 *= np.pi / 180
+    sin = np.sin(angle_2)
+    pointer = pointer / np.linalg.norm(pointer)
+    q1, q2, q3, q0 = sin * pointer[0], sin * pointer[1], sin * pointer[2], np.cos(angle_2)
+    return np.array(
+        [
+            [2 * (q0 * q0 + q1 * q1) - 1, 2 * (q1 * q2 - q0 * q3), 2 * (q1 * q3 + q0 * q2)],
+            [2 * (q1 * q2 + q0 * q3), 2 * (q0 * q0 + q2 * q2) - 1, 2 * (q2 * q3 - q0 * q1)],
+            [2 * (q1 * q3 - q0 * q2), 2 * (q2 * q3 + q0 * q1), 2 * (q0 * q0 + q3 * q3) - 1],
+        ]
+    )
+
+
+def rotation_matrix_from_vectors(vec1, vec2):
+    """firecode/utils.py:224-249, literal."""
+    assert vec1.shape == (3,)
+    assert vec2.shape == (3,)
+    a, b = (vec1 / np.linalg.norm(vec1)).reshape(3), (vec2 / np.linalg.norm(vec2)).reshape(3)
+    v = np.cross(a, b)
+    if np.linalg.norm(v) != 0:
+        c = np.dot(a, b)
+        s = np.linalg.norm(v)
+        kmat = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+        return np.eye(3) + kmat + kmat.dot(kmat) * ((1 - c) / (s**2))
+    if np.linalg.norm(a + b) == 0:
+        return rot_mat_from_pointer(np.array([0, 0, 1]), 180)
+    return np.eye(3)
+
+
+def polygonize(lengths):
+    """firecode/utils.py:252-312 (bimolecular branch literal; trimolecular
+    branch literal)."""
+    assert len(lengths) in (2, 3)
+    arr = np.zeros((len(lengths), 2, 3))
+    if len(lengths) == 2:
+        arr[0, 0] = np.array([-lengths[0] / 2, 0, 0])
+        arr[0, 1] = np.array([+lengths[0] / 2, 0, 0])
+        arr[1, 0] = np.array([-lengths[1] / 2, 0, 0])
+        arr[1, 1] = np.array([+lengths[1] / 2, 0, 0])
+        vertices_out = np.vstack(([arr], [arr]))
+        vertices_out[1, 1] *= -1
+    else:
+        if not all([lengths[i] < lengths[i - 1] + lengths[i - 2] for i in (0, 1, 2)]):
+            raise ValueError(f"Impossible to build a triangle with sides {lengths}")
+        arr[0, 1] = np.array([lengths[0], 0, 0])
+        arr[1, 0] = np.array([lengths[0], 0, 0])
+        a = np.power(lengths[0], 2)
+        b = np.power(lengths[1], 2)
+        c = np.power(lengths[2], 2)
+        x = (a - b + c) / (2 * a**0.5)
+        y = (c - x**2) ** 0.5
+        arr[1, 1] = np.array([x, y, 0])
+        arr[2, 0] = np.array([x, y, 0])
+        vertices_out = np.vstack(([arr], [arr], [arr], [arr], [arr], [arr], [arr], [arr]))
+        swaps = [(1, 2), (2, 1), (3, 1), (3, 2), (4, 0), (5, 0), (5, 1), (6, 0), (6, 2),
+                 (7, 0), (7, 1), (7, 2)]
+        for t, v in swaps:
+            vertices_out[t, v][[0, 1]] = vertices_out[t, v][[1, 0]]
+    return vertices_out
+
+
+def get_embed(coords_list, rotations, positions):
+    """firecode/embeds.py:808-817: concat of ``(R @ X.T).T + t`` per molecule."""
+    return np.concatenate(
+        [(R @ X.T).T + t for X, R, t in zip(coords_list, rotations, positions)]
+    )
+
+
+def rototranslate(X, R, t):
+    """One molecule of ``get_embed``: ``(R @ X.T).T + t``."""
+    return (np.asarray(R) @ np.asarray(X).T).T + np.asarray(t)
+
+
+def bimol_pose_transforms(c1, c2, reactive1, reactive2, pivot1, pivot2, angles, orientation):
+    """R, t of both molecules for one pose of the bimolecular cyclical embed
+    -- firecode/embeds.py:621-709 restated for one pivot per conformer.
+
+    c1, c2: (A,3) conformer coordinates; reactive*: index arrays (1 or 2
+    atoms); pivot* = (start, end) 3-vectors (Pivot.start/.end;
+    hypermolecule_class.py:329-333: ``pivot = start - end``,
+    ``meanpoint = mean((start, end))``); angles: (2,) degrees;
+    orientation: 0/1 index into ``polygonize(norms)``.
+    Returns (R1, t1, R2, t2)."""
+    mols = ((c1, reactive1, pivot1), (c2, reactive2, pivot2))
+    pvecs = [np.asarray(pv[0], float) - np.asarray(pv[1], float) for _, _, pv in mols]
+    means = [np.mean((np.asarray(pv[0], float), np.asarray(pv[1], float)), axis=0) for _, _, pv in mols]
+    norms = np.linalg.norm(np.array(pvecs), axis=1)
+    vecs = polygonize(norms)[orientation]
+    directions = np.array([[0, 1, 0], [0, -1, 0]])
+    out = []
+    for i, (coords, reactive, _) in enumerate(mols):
+        start, end = vecs[i]
+        angle = angles[i]
+        reactive_coords = coords[np.asarray(reactive)]
+        atomic_pivot_mean = np.mean(reactive_coords, axis=0)
+        mol_direction = means[i] - atomic_pivot_mean
+        if np.all(mol_direction == 0.0):
+            mol_direction = means[i]
+        alignment_rotation = align_vec_pair(
+            np.array([end - start, directions[i]]), np.array([pvecs[i], mol_direction])
+        )
+        if len(reactive_coords) == 2:
+            axis = alignment_rotation @ (reactive_coords[0] - reactive_coords[1])
+        else:
+            axis = alignment_rotation @ pvecs[i]
+        step_rotation = rot_mat_from_pointer(axis, angle)
+        center_of_rotation = alignment_rotation @ atomic_pivot_mean
+        R = step_rotation @ alignment_rotation
+        pos = np.mean(vecs[i], axis=0) - alignment_rotation @ means[i]
+        t = center_of_rotation - step_rotation @ center_of_rotation + pos
+        out.extend([R, t])
+    return tuple(out)
+
+
+# --------------------------------------------------------------------------
+# torsions  (rotate_dihedral / dihedral: 3P, unpinned; rest in tree, pinned)
+# --------------------------------------------------------------------------
+def rotate_dihedral(coords, torsion, angle, mask):
+    """Rotate ``coords[mask]`` by ``angle`` degrees about the i2-i3 bond
+    (call sites torsion_module.py:529,537,825,834).  Restated from
+    prism_pruner.utils: axis = coords[i2] - coords[i3], centre = coords[i3],
+    matrix = rot_mat_from_pointer(axis, angle).  Returns a new array."""
+    coords = np.array(coords, dtype=np.float64)
+    _, i2, i3, _ = torsion
+    mat = rot_mat_from_pointer(coords[i2] - coords[i3], angle)
+    center = coords[i3]
+    coords[mask] = (mat @ (coords[mask] - center).T).T + center
+    return coords
+
+
+def torsion_comp_check(coords, torsion, mask, thresh=1.5, max_clashes=0):
+    """firecode/torsion_module.py:894-918, literal."""
+    _, i2, i3, _ = torsion
+    antimask = ~mask
+    antimask[i2] = False
+    antimask[i3] = False
+    m1 = coords[mask]
+    m2 = coords[antimask]
+    return int(np.count_nonzero(cdist(m2, m1) < thresh)) <= max_clashes
+
+
+def torsion_scan(base, torsions, masks, angles, thresh=1.5, backoff=5):
+    """Inner loops of ``clustered_csearch`` for one starting point
+    (torsion_module.py:812-856): per angle-set apply the non-zero dihedral
+    rotations in order with the clash test and the 5-degree back-off.
+    Returns (coords (S,A,3), rotated_bonds (S,) int)."""
+    base = np.asarray(base, dtype=np.float64)
+    angles = np.asarray(angles)
+    S = len(angles)
+    out = np.empty((S,) + base.shape)
+    rot = np.zeros(S, dtype=np.int64)
+    for s, angle_set in enumerate(angles):
+        new_coords = np.copy(base)
+        rotated_bonds = 0
+        for t, torsion in enumerate(torsions):
+            angle = int(angle_set[t])
+            if angle != 0:
+                mask = np.asarray(masks[t], dtype=bool)
+                temp = rotate_dihedral(new_coords, torsion, angle, mask)
+                if not torsion_comp_check(temp, torsion, mask, thresh):
+                    for _ in range(angle // backoff):
+                        temp = rotate_dihedral(temp, torsion, -backoff, mask)
+                        if torsion_comp_check(temp, torsion, mask, thresh):
+                            rotated_bonds += 1
+                            break
+                else:
+                    rotated_bonds += 1
+                new_coords = temp
+        out[s] = new_coords
+        rot[s] = rotated_bonds
+    return out, rot
+
+
+def dihedral(p):
+    """Dihedral angle in degrees in (-180, 180] of four points
+    (prism_pruner.algebra.dihedral, call site torsion_module.py:1075);
+    restated from its published "praxeolitic" form: 1 sqrt, 1 cross product."""
+    p0, p1, p2, p3 = (np.asarray(x, dtype=np.float64) for x in p)
+    b0 = -1.0 * (p1 - p0)
+    b1 = p2 - p1
+    b2 = p3 - p2
+    b1 = b1 / np.linalg.norm(b1)
+    v = b0 - np.dot(b0, b1) * b1
+    w = b2 - np.dot(b2, b1) * b1
+    x = np.dot(v, w)
+    y = np.dot(np.cross(b1, v), w)
+    return float(np.degrees(np.arctan2(y, x)))
+
+
+def get_torsion_fingerprint(coords, quadruplets):
+    """firecode/torsion_module.py:1070-1076."""
+    out = np.zeros(len(quadruplets), dtype=float)
+    for i, q in enumerate(quadruplets):
+        i1, i2, i3, i4 = q
+        out[i] = dihedral([coords[i1], coords[i2], coords[i3], coords[i4]])
+    return out
+
+
+def get_tf_mat(structures, quadruplets):
+    """firecode/torsion_module.py:1046-1053."""
+    return np.array([get_torsion_fingerprint(s, quadruplets) for s in structures]).reshape(
+        len(structures), len(quadruplets)
+    )
+
+
+def tfd_similarity(tfp1, tfp2, thresh=10):
+    """firecode/torsion_module.py:1056-1067, literal."""
+    deltas = np.abs(tfp1 - tfp2)
+    deltas = np.abs(deltas - (deltas > 180) * 360)
+    if np.sum(deltas) < thresh:
+        return True
+    return False
+
+
+def prune_tfd_from_tf_mat(tf_mat, thresh=10):
+    """Greedy loop of ``prune_conformers_tfd`` (torsion_module.py:967-1043),
+    literal, given the fingerprint matrix.  Keeps ``group[0]`` of every
+    connected component of the first-match graph exactly as networkx hands it
+    out (subgraph-view node order)."""
+    from networkx import Graph, connected_components
+
+    n = tf_mat.shape[0]
+    cache_set = set()
+    final_mask = np.ones(n, dtype=bool)
+    for k in (5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1):
+        num_active_str = np.count_nonzero(final_mask)
+        if k == 1 or 5 * k < num_active_str:
+            d = int(n // k)
+            for step in range(int(k)):
+                if step == k - 1:
+                    _l = len(range(d * step, num_active_str))
+                else:
+                    _l = len(range(d * step, int(d * (step + 1))))
+                matches = set()
+                for i_rel in range(_l):
+                    for j_rel in range(i_rel + 1, _l):
+                        i_abs = i_rel + (d * step)
+                        j_abs = j_rel + (d * step)
+                        if (i_abs, j_abs) not in cache_set:
+                            if tfd_similarity(tf_mat[i_abs], tf_mat[j_abs], thresh=thresh):
+                                matches.add((i_rel, j_rel))
+                                break
+                            else:
+                                cache_set.add((i_abs, j_abs))
+                g = Graph(matches)
+                subgraphs = [g.subgraph(c) for c in connected_components(g)]
+                groups = [tuple(graph.nodes) for graph in subgraphs]
+                best_of_cluster = [group[0] for group in groups]
+                rejects_sets = [set(a) - {b} for a, b in zip(groups, best_of_cluster)]
+                for s in rejects_sets:
+                    for i in s:
+                        final_mask[i + d * step] = 0
+    return final_mask
+
+
+def prune_conformers_tfd(structures, quadruplets, thresh=10):
+    """firecode/torsion_module.py:957-1043."""
+    structures = np.asarray(structures, dtype=np.float64)
+    mask = prune_tfd_from_tf_mat(get_tf_mat(structures, quadruplets), thresh)
+    return structures[mask], mask
+
+
+# --------------------------------------------------------------------------
+# xyz wire format  (firecode/ensemble.py:58-98, 284-297 -- pinned)
+# --------------------------------------------------------------------------
+def ensemble_to_xyz_text(atoms, coords, basename=""):
+    """firecode/ensemble.py:284-297, literal (returns the text)."""
+
+    def to_xyz(c):
+        return (
+            f"{len(c)}\nExported from FIRECODE Ensemble ({basename})\n"
+            + "\n".join(
+                f"{atom} {x:15.8f} {y:15.8f} {z:15.8f}" for atom, (x, y, z) in zip(atoms, c)
+            )
+        )
+
+    return "\n".join(map(to_xyz, coords))
+
+
+def ensemble_from_xyz_text(text):
+    """firecode/ensemble.py:58-98, restated over a string (no energies)."""
+    lines = iter(text.split("\n"))
+    coords, atoms = [], []
+    for num in lines:
+        try:
+            if not num.strip():
+                continue
+            next(lines)
+            conf_atoms, conf_coords = [], []
+            for _ in range(int(num)):
+                atom, *xyz = next(lines).split()
+                conf_atoms.append(atom)
+                conf_coords.append([float(x) for x in xyz[0:3]])
+            atoms.append(conf_atoms)
+            coords.append(conf_coords)
+        except StopIteration:
+            pass
+    return np.array(atoms[0]), np.array(coords)
+
+
+# --------------------------------------------------------------------------
+# synthetic workloads -- shared by tests and bench
+# --------------------------------------------------------------------------
+def _random_rotation(rng):
+    q, r = np.linalg.qr(rng.normal(size=(3, 3)))
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def synthetic_skeleton(n_atoms, rng, bond=1.5, min_dist=1.2):
+    """Self-avoiding random walk, bond 1.5 A, no atom closer than 1.2 A."""
+    pts = [np.zeros(3)]
+    while len(pts) < n_atoms:
+        for _ in range(1000):
+            d = rng.normal(size=3)
+            cand = pts[-1] + bond * d / np.linalg.norm(d)
+            if np.min(np.linalg.norm(np.array(pts) - cand, axis=1)) >= min_dist:
+                pts.append(cand)
+                break
+        else:  # dead end: restart
+            pts = [np.zeros(3)]
+    return np.array(pts)
+
+
+def synthetic_ensemble(n_conf, n_atoms, seed, cluster_size=5, sigma_cluster=0.6, sigma_conf=0.03):
+    """Clustered synthetic ensemble of SURVEY.md section 8d: K = n_conf /
+    cluster_size cluster centres (skeleton + N(0, 0.6^2)), members = centre +
+    N(0, 0.03^2), shuffled, each given a random proper rotation and a
+    translation N(0, 5^2).  Returns (coords (N,A,3), atoms (A,) all 'C',
+    cluster id per conformer)."""
+    rng = np.random.default_rng(seed)
+    skel = synthetic_skeleton(n_atoms, rng)
+    K = max(1, n_conf // cluster_size)
+    centres = np.empty((K, n_atoms, 3))
+    for k in range(K):
+        while True:
+            c = skel + rng.normal(scale=sigma_cluster, size=skel.shape)
+            d = cdist(c, c)
+            d[np.diag_indices(n_atoms)] = 10.0
+            if d.min() >= 0.5:
+                centres[k] = c
+                break
+    assign = np.arange(n_conf) % K
+    rng.shuffle(assign)
+    coords = centres[assign] + rng.normal(scale=sigma_conf, size=(n_conf, n_atoms, 3))
+    for i in range(n_conf):
+        coords[i] = coords[i] @ _random_rotation(rng).T + rng.normal(scale=5.0, size=3)
+    return np.ascontiguousarray(coords), np.array(["C"] * n_atoms), assign
