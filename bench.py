@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""bench.py -- conformer-pair RMSD alignments/s (+ pruned ensembles/s) on MI355X.
+
+Workload (BASELINE.json configs[1]): synthetic 10 000-conformer
+x 50-atom float64 ensemble, all-pairs Kabsch RMSD + 0.5 A greedy prune.
+A step = one full pruning pass over the HBM-resident ensemble: all-pairs
+similarity bits (screen + exact refine) and the k-ladder replay -> survivor mask.
+
+N GPUs (weak scaling): every rank keeps the whole ensemble resident and owns a
+block-cyclic share of the bit-matrix rows; the conformer count grows as
+sqrt(N) so that the pairs per GPU stay constant; masks are exchanged with one
+RCCL all-gather per ladder level.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_CONF, N_ATOMS, MAX_RMSD = 10000, 50, 0.5
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(coords, budget_s=12.0):
+    """Oracle ('port' of the reference's per-pair NumPy path) on a bounded
+    sample: all pairs of the first n0 conformers, one core."""
+    from oracle import cpu_ref as o
+
+    n0 = 500
+    X = coords[:n0] - coords[:n0].mean(axis=1, keepdims=True)
+    iu, ju = np.triu_indices(n0, 1)
+    t0 = time.perf_counter()
+    done = 0
+    for a, b in zip(iu, ju):
+        o.rmsd_and_max(X[a], X[b])
+        done += 1
+        if (done & 1023) == 0 and time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "alignments/s", "cores": 1, "kind": "port",
+            "sample": f"{done} conformer pairs among the first {n0} conformers of the workload, "
+                      f"oracle rmsd_and_max (NumPy, LAPACK 3x3 SVD per pair), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run for --gpus > 1")
+        args.gpus = world
+
+    import firecode_amd as fc
+    from firecode_amd import dist as fdist
+    from firecode_amd import synthetic as syn
+
+    fc.init(local_rank)
+
+    allgather = None
+    tdist = None
+    if world > 1:
+        import torch
+        import torch.distributed as tdist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        allgather = fdist.torch_allgather(device=torch.device("cuda", local_rank))
+
+    n_conf = int(round(N_CONF * np.sqrt(world)))
+    coords, atoms, assign = syn.synthetic_ensemble(n_conf, N_ATOMS, seed=2)
+    ens = fc.DeviceEnsemble(coords, center=True)  # resident in HBM from here on
+    pairs_total = n_conf * (n_conf - 1) // 2
+
+    def barrier():
+        if world > 1:
+            import torch
+
+            torch.cuda.synchronize()
+            tdist.barrier()
+            torch.cuda.synchronize()
+
+    t_kernel_ms = None
+    if world == 1:
+        def step():
+            return ens.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=1, want_mask=False)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        tk = 0.0
+        for _ in range(args.steps):
+            k_ms, s_ms, _, stats = step()
+            tk += k_ms
+        elapsed = time.perf_counter() - t0
+        t_kernel_ms = tk / args.steps
+        _, _, mask, stats = ens.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=1, want_mask=True)
+    else:
+        def step():
+            return fdist.prune_by_rmsd_sharded(ens, MAX_RMSD, rank=rank, world=world, allgather_fn=allgather)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mask, stats = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    survivors = int(mask.sum())
+    expected = len(np.unique(assign))
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = pairs_total * args.steps / elapsed
+        bytes_per_alignment = 2 * N_ATOMS * 3 * 8 + 16
+        out = {
+            "metric": "conformer-pair RMSD alignments/s",
+            "value": value,
+            "unit": "alignments/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{n_conf}-conformer x {N_ATOMS}-atom ensemble, all-pairs Kabsch RMSD "
+                                   f"+ {MAX_RMSD} A prune (BASELINE configs[1]; conformers scale as sqrt(n_gpus))",
+                       "n_conformers": n_conf, "n_atoms": N_ATOMS, "max_rmsd": MAX_RMSD,
+                       "pairs_per_step": pairs_total, "sharding": f"block-cyclic rows x{world}"},
+            "pruned_ensembles_per_s": args.steps / elapsed,
+            "survivors": survivors,
+            "survivors_expected": expected,
+            "mask_ok": survivors == expected,
+        }
+        if t_kernel_ms is not None:
+            # dominant kernel: k_simbits_screen, HIP events on the library's stream
+            owned_pairs = pairs_total
+            achieved = owned_pairs * bytes_per_alignment / (t_kernel_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_simbits_screen", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel_ms": t_kernel_ms, "algorithmic_bytes_per_alignment": bytes_per_alignment,
+                "compulsory_bytes": n_conf * N_ATOMS * 24 + n_conf * ((n_conf + 63) // 64) * 8,
+            }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(coords)
+        print(json.dumps(out))
+    if world > 1:
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,23 @@
+"""firecode_amd -- MI355X (gfx950) implementation of FIRECODE's ensemble-geometry
+hot path behind the names FIRECODE imports.
+
+Python here is host glue only: argument normalisation, logging hooks and the
+reference's return conventions.  All arithmetic runs in hand-written HIP
+kernels inside ``libfc_hip.so`` (C ABI in ``include/fc_hip.h``); there is no
+NumPy fallback -- without the library or without a gfx950 device every compute
+call raises ``FirecodeHipError``.
+"""
+
+from firecode_amd._lib import (  # noqa: F401
+    DeviceEnsemble,
+    FirecodeHipDeviceError,
+    FirecodeHipError,
+    FirecodeHipInputError,
+    device_count,
+    device_info,
+    init,
+    shutdown,
+)
+from firecode_amd import algebra, embeds, ensemble, pruner, pt, rmsd, torsion_module, utils  # noqa: F401,E402
+
+__version__ = "0.1.0"

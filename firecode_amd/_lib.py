@@ -1,0 +1,266 @@
+"""ctypes binding of libfc_hip.so (include/fc_hip.h).
+
+The library is the product: there is no Python/NumPy fallback.  If the shared
+object is missing, or no gfx950 device is usable, the calls raise
+``FirecodeHipError`` -- loudly, never silently.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfc_hip.so")
+
+FC_OK = 0
+FC_E_INVALID, FC_E_NODEVICE, FC_E_HIP, FC_E_NOMEM, FC_E_LIMIT = -1, -2, -3, -4, -5
+
+
+class FirecodeHipError(RuntimeError):
+    """Any failure reported by libfc_hip.so (code in ``.code``)."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libfc_hip error {code}: {message}")
+        self.code = code
+
+
+class FirecodeHipInputError(FirecodeHipError, ValueError):
+    """FC_E_INVALID / FC_E_LIMIT: the arguments were rejected before any launch."""
+
+
+class FirecodeHipDeviceError(FirecodeHipError):
+    """FC_E_NODEVICE / FC_E_HIP / FC_E_NOMEM."""
+
+
+_lib = None
+
+_p_f64 = C.POINTER(C.c_double)
+_p_i64 = C.POINTER(C.c_int64)
+_p_u64 = C.POINTER(C.c_uint64)
+_p_u8 = C.POINTER(C.c_uint8)
+_i64 = C.c_int64
+_f64 = C.c_double
+_ens = C.c_void_p
+
+# name -> argtypes  (restype is always int unless noted)
+_SIGNATURES = {
+    "fc_abi_version": [],
+    "fc_device_count": [],
+    "fc_init": [C.c_int],
+    "fc_shutdown": [],
+    "fc_device_info": [C.c_char_p, _i64, _p_i64, _p_i64],
+    "fc_ensemble_create": [_p_f64, _i64, _i64, _p_u8, C.c_int, C.POINTER(_ens)],
+    "fc_ensemble_destroy": [_ens],
+    "fc_ensemble_shape": [_ens, _p_i64, _p_i64],
+    "fc_kabsch_rmsd_pairs": [_p_f64, _i64, _i64, _p_u8, _p_i64, _p_i64, _i64, C.c_int, _p_f64, _p_f64],
+    "fc_ensemble_rmsd_pairs": [_ens, _p_i64, _p_i64, _i64, _p_f64, _p_f64],
+    "fc_ensemble_rmsd_matrix": [_ens, _p_f64, _p_f64],
+    "fc_alignment_matrices": [_p_f64, _p_f64, _i64, _i64, _p_f64],
+    "fc_rmsd_simbits": [_ens, _f64, _f64, _p_f64, _f64, _i64, _i64, _p_u64, _p_i64],
+    "fc_prune_rmsd": [_ens, _f64, _f64, _p_f64, _f64, _i64, _p_u8, _p_i64],
+    "fc_greedy_prune_from_bits": [_p_u64, _i64, _i64, _p_u8],
+    "fc_prune_rmsd_begin": [_ens, _f64, _f64, _p_f64, _f64, _i64, _i64, _i64, _p_i64],
+    "fc_prune_level": [_ens, _i64, _p_u8, _p_u8],
+    "fc_inertia_moments": [_p_f64, _i64, _i64, _p_f64, _p_f64],
+    "fc_prune_moi": [_p_f64, _i64, _i64, _p_f64, _f64, _p_f64, _f64, _i64, _p_u8],
+    "fc_align_to_first": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64],
+    "fc_rototranslate": [_p_f64, _i64, _i64, _p_f64, _p_f64, _p_f64],
+    "fc_clash_self": [_p_f64, _i64, _i64, _f64, _f64, _p_i64],
+    "fc_clash_fragments": [_p_f64, _i64, _i64, _p_i64, _i64, _f64, _i64, _p_i64, _p_u8],
+    "fc_embed_poses_clash": [_p_f64, _i64, _i64, _p_f64, _i64, _i64, _p_i64, _p_i64, _p_f64, _p_f64,
+                             _p_f64, _p_f64, _i64, _f64, _i64, _p_i64, _p_u8, _p_f64],
+    "fc_torsion_scan": [_p_f64, _i64, _p_i64, _i64, _p_u8, _p_i64, _i64, _f64, _i64, _p_f64, _p_i64],
+    "fc_torsion_fingerprint": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64],
+    "fc_tfd_simbits": [_p_f64, _i64, _i64, _f64, _i64, _i64, _p_u64],
+    "fc_bench_prune_rmsd": [_ens, _f64, _f64, _i64, _p_f64, _p_f64, _p_u8, _p_i64],
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("fc_last_error",)
+
+
+def load():
+    """dlopen the library (no device is touched) and set the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FirecodeHipDeviceError(
+            FC_E_NODEVICE,
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C firecode_amd/csrc`; firecode_amd has no CPU fallback",
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.fc_last_error.argtypes = []
+    lib.fc_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == FC_OK:
+        return
+    msg = load().fc_last_error().decode("utf-8", "replace")
+    if rc in (FC_E_INVALID, FC_E_LIMIT):
+        raise FirecodeHipInputError(rc, msg)
+    raise FirecodeHipDeviceError(rc, msg)
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+# ---- array helpers ---------------------------------------------------------------
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def ptr(a, ctype):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def pf(a):
+    return ptr(a, C.c_double)
+
+
+def pi(a):
+    return ptr(a, C.c_int64)
+
+
+def pb(a):
+    return ptr(a, C.c_uint8)
+
+
+def pw(a):
+    return ptr(a, C.c_uint64)
+
+
+def init(device=0):
+    call("fc_init", int(device))
+
+
+def shutdown():
+    call("fc_shutdown")
+
+
+def device_count():
+    return int(load().fc_device_count())
+
+
+def device_info():
+    name = C.create_string_buffer(160)
+    ncu, hbm = C.c_int64(0), C.c_int64(0)
+    call("fc_device_info", name, 160, C.byref(ncu), C.byref(hbm))
+    return {"name": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": hbm.value}
+
+
+class DeviceEnsemble:
+    """HBM-resident prepared ensemble (fc_ensemble)."""
+
+    def __init__(self, coords, atom_mask=None, center=True):
+        coords = f64(coords)
+        if coords.ndim != 3 or coords.shape[2] != 3:
+            raise FirecodeHipInputError(FC_E_INVALID, f"coords must be (N, A, 3), got {coords.shape}")
+        self.N, self.A_all = int(coords.shape[0]), int(coords.shape[1])
+        m = None if atom_mask is None else u8(np.asarray(atom_mask, dtype=bool))
+        if m is not None and m.shape != (self.A_all,):
+            raise FirecodeHipInputError(FC_E_INVALID, "atom_mask must have one entry per atom")
+        self._h = _ens()
+        call("fc_ensemble_create", pf(coords), self.N, self.A_all, pb(m), int(bool(center)), C.byref(self._h))
+        self.W = (max(self.N, 1) + 63) // 64
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().fc_ensemble_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise FirecodeHipInputError(FC_E_INVALID, "ensemble already destroyed")
+        return self._h
+
+    def rmsd_pairs(self, pair_i, pair_j):
+        pi_, pj_ = i64(pair_i), i64(pair_j)
+        P = int(pi_.shape[0])
+        r, m = np.empty(P), np.empty(P)
+        call("fc_ensemble_rmsd_pairs", self.handle, pi(pi_), pi(pj_), P, pf(r), pf(m))
+        return r, m
+
+    def rmsd_matrix(self):
+        r = np.zeros((self.N, self.N))
+        m = np.zeros((self.N, self.N))
+        call("fc_ensemble_rmsd_matrix", self.handle, pf(r), pf(m))
+        return r, m
+
+    def simbits(self, max_rmsd, max_dev, energies=None, max_dE=0.0, row_begin=0, row_end=None):
+        row_end = self.N if row_end is None else int(row_end)
+        bits = np.zeros((row_end - row_begin, self.W), dtype=np.uint64)
+        grey = C.c_int64(0)
+        en = None if energies is None else f64(energies)
+        call("fc_rmsd_simbits", self.handle, float(max_rmsd), float(max_dev), pf(en), float(max_dE),
+             int(row_begin), row_end, pw(bits), C.byref(grey))
+        return bits, grey.value
+
+    def prune(self, max_rmsd, max_dev, energies=None, max_dE=0.0, min_per_group=20):
+        mask = np.zeros(self.N, dtype=np.uint8)
+        stats = np.zeros(6, dtype=np.int64)
+        en = None if energies is None else f64(energies)
+        call("fc_prune_rmsd", self.handle, float(max_rmsd), float(max_dev), pf(en), float(max_dE),
+             int(min_per_group), pb(mask), pi(stats))
+        return mask.astype(bool), stats
+
+    def prune_begin(self, max_rmsd, max_dev, rank, world, row_block=256, energies=None, max_dE=0.0):
+        stats = np.zeros(6, dtype=np.int64)
+        en = None if energies is None else f64(energies)
+        call("fc_prune_rmsd_begin", self.handle, float(max_rmsd), float(max_dev), pf(en), float(max_dE),
+             int(rank), int(world), int(row_block), pi(stats))
+        return stats
+
+    def prune_level(self, k, mask_in):
+        mi = u8(mask_in)
+        mo = np.zeros(self.N, dtype=np.uint8)
+        call("fc_prune_level", self.handle, int(k), pb(mi), pb(mo))
+        return mo
+
+    def bench_prune(self, max_rmsd, max_dev, reps=1, want_mask=True):
+        mask = np.zeros(self.N, dtype=np.uint8) if want_mask else None
+        stats = np.zeros(6, dtype=np.int64)
+        t_k, t_s = C.c_double(0), C.c_double(0)
+        call("fc_bench_prune_rmsd", self.handle, float(max_rmsd), float(max_dev), int(reps),
+             C.byref(t_k), C.byref(t_s), pb(mask), pi(stats))
+        return t_k.value, t_s.value, (None if mask is None else mask.astype(bool)), stats
+
+
+def unpack_bits(bits, n):
+    """(rows, W) uint64 words -> (rows, n) bool."""
+    b = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")
+    return b[:, :n].astype(bool)

@@ -1,0 +1,768 @@
+// fc_api.cpp -- the extern "C" surface of libfc_hip.so (include/fc_hip.h):
+// argument checks, host<->HBM staging, kernel sequencing.  No compute here.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "fc_common.h"
+
+namespace fc {
+
+// ---- launchers implemented in the .hip translation units --------------------
+int launch_prep(const double *, int64_t, int64_t, const int32_t *, int64_t, int, fc_ensemble *);
+int launch_pairs_exact(const fc_ensemble *, const int64_t *, const int64_t *, int64_t, double *,
+                       double *, double *);
+int launch_matrix_exact(const fc_ensemble *, double *, double *);
+int launch_simbits_screen(fc_ensemble *, double);
+int launch_simbits_refine(fc_ensemble *, double, double, const double *, double);
+int launch_align_to_first(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
+int launch_alignment_matrices(const double *, const double *, int64_t, int64_t, double *);
+int launch_pack_mask(const uint8_t *, int64_t, uint64_t *, int64_t, unsigned long long *);
+int launch_level(const uint64_t *, int64_t, const uint64_t *, const uint8_t *, uint8_t *, int64_t,
+                 int64_t, int64_t, int64_t, int64_t, int64_t);
+int launch_copy_bytes(const uint8_t *, uint8_t *, int64_t);
+int launch_inertia_moments(const double *, int64_t, int64_t, const double *, double *);
+int launch_moi_simbits(const double *, int64_t, double, const double *, double, uint64_t *, int64_t);
+int launch_tfd_simbits(const double *, int64_t, int64_t, double, int64_t, int64_t, uint64_t *,
+                       int64_t);
+int launch_clash_self(const double *, int64_t, int64_t, double, double, int64_t *);
+int launch_clash_fragments(const double *, int64_t, int64_t, const int64_t *, int64_t, double,
+                           int64_t, int64_t *, uint8_t *);
+int launch_rototranslate(const double *, int64_t, int64_t, const double *, const double *, double *);
+int launch_embed_poses_clash(const double *, int64_t, const double *, int64_t, const int64_t *,
+                             const int64_t *, const double *, const double *, const double *,
+                             const double *, int64_t, double, int64_t, int64_t *, uint8_t *,
+                             double *);
+int launch_torsion_scan(const double *, int64_t, const int64_t *, int64_t, const uint8_t *,
+                        const int16_t *, const int16_t *, const int32_t *, const int32_t *,
+                        const int64_t *, int64_t, double, int64_t, double *, int64_t *);
+int launch_torsion_fingerprint(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
+
+// ---- error state / context -----------------------------------------------------
+std::string &last_error() {
+  static thread_local std::string e;
+  return e;
+}
+
+int set_error(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+Context &ctx() {
+  static Context c;
+  return c;
+}
+
+static int do_init(int device) {
+  Context &c = ctx();
+  if (c.ready && c.device == device) return FC_OK;
+  if (c.ready) {
+    (void)hipStreamDestroy(c.stream);
+    c.ready = false;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return set_error(FC_E_NODEVICE, "no HIP device available (%s); libfc_hip has no CPU fallback",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device < 0 || device >= n)
+    return set_error(FC_E_INVALID, "device %d out of range (have %d)", device, n);
+  if (hipSetDevice(device) != hipSuccess)
+    return set_error(FC_E_NODEVICE, "hipSetDevice(%d) failed", device);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+    return set_error(FC_E_NODEVICE, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_error(FC_E_NODEVICE, "device %d is %s; this library is built for gfx950 only",
+                     device, prop.gcnArchName);
+  FC_HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  FC_HIP_TRY(hipEventCreate(&c.ev0));
+  FC_HIP_TRY(hipEventCreate(&c.ev1));
+  FC_HIP_TRY(hipEventCreate(&c.ev2));
+  FC_HIP_TRY(hipEventCreate(&c.ev3));
+  c.device = device;
+  c.n_cu = prop.multiProcessorCount;
+  c.hbm = prop.totalGlobalMem;
+  std::snprintf(c.name, sizeof c.name, "%s (%s)", prop.name, prop.gcnArchName);
+  c.ready = true;
+  return FC_OK;
+}
+
+int ensure_init() {
+  if (ctx().ready) {
+    // the calling thread may differ from the one that initialised
+    if (hipSetDevice(ctx().device) != hipSuccess)
+      return set_error(FC_E_NODEVICE, "hipSetDevice(%d) failed", ctx().device);
+    return FC_OK;
+  }
+  return do_init(0);
+}
+
+// upload helper: host array -> fresh device buffer
+template <class T>
+static int upload(DevBuf &b, const T *host, size_t count) {
+  FC_TRY(b.reserve(count * sizeof(T)));
+  return h2d(b.p, host, count * sizeof(T));
+}
+
+static int make_selection(const uint8_t *atom_mask, int64_t A_all, std::vector<int32_t> &sel) {
+  sel.clear();
+  for (int64_t a = 0; a < A_all; ++a)
+    if (atom_mask == nullptr || atom_mask[a]) sel.push_back((int32_t)a);
+  if (sel.empty()) return set_error(FC_E_INVALID, "atom_mask selects no atom");
+  return FC_OK;
+}
+
+static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const uint8_t *atom_mask,
+                          int center, fc_ensemble *e) {
+  std::vector<int32_t> sel;
+  FC_TRY(make_selection(atom_mask, A_all, sel));
+  e->N = N;
+  e->A = (int64_t)sel.size();
+  e->Npad = ceil_div(std::max<int64_t>(N, 1), 64) * 64;
+  e->W = e->Npad / 64;
+  FC_TRY(e->Xs.reserve((size_t)e->A * 3 * e->Npad * sizeof(double)));
+  FC_TRY(e->G.reserve((size_t)e->Npad * sizeof(double)));
+  FC_TRY(e->counters.reserve(8 * sizeof(uint64_t)));
+  DevBuf raw, dsel;
+  FC_TRY(upload(raw, coords, (size_t)N * A_all * 3));
+  FC_TRY(upload(dsel, sel.data(), sel.size()));
+  FC_TRY(launch_prep(raw.as<double>(), N, A_all, dsel.as<int32_t>(), e->A, center, e));
+  FC_TRY(sync());
+  return FC_OK;
+}
+
+// (re)shape the bit-matrix workspace for a given sharding
+static int ensemble_shard(fc_ensemble *e, int64_t rank, int64_t world, int64_t row_block) {
+  FC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world %lld/%lld", (long long)rank,
+             (long long)world);
+  FC_REQUIRE(row_block >= 32 && row_block % 32 == 0 && row_block <= 4096,
+             "row_block must be a multiple of 32 in [32, 4096]");
+  e->rank = rank;
+  e->world = world;
+  e->row_block = row_block;
+  const int64_t n_gblocks = ceil_div(e->N, row_block);
+  const int64_t n_lblocks = n_gblocks > rank ? (n_gblocks - rank + world - 1) / world : 0;
+  e->rows_local = n_lblocks * row_block;
+  FC_TRY(e->bits.reserve(std::max<size_t>((size_t)e->rows_local * e->W * sizeof(uint64_t), 8)));
+  FC_TRY(e->maskA.reserve((size_t)e->Npad));
+  FC_TRY(e->maskB.reserve((size_t)e->Npad));
+  FC_TRY(e->mbits.reserve((size_t)e->W * sizeof(uint64_t)));
+  e->bits_valid = false;
+  return FC_OK;
+}
+
+static const double kScreenMargin = 1e-6;  // A^2, added to max_rmsd^2 in the screen
+
+// similarity bits of this rank's rows: screen + exact refine; counters[1..3]
+static int simbits_local(fc_ensemble *e, double max_rmsd, double max_dev, const double *energies,
+                         double max_dE, bool zero_counters) {
+  const double *en_dev = nullptr;
+  if (energies != nullptr) {
+    FC_TRY(upload(e->energies, energies, (size_t)e->N));
+    en_dev = e->energies.as<double>();
+  }
+  if (zero_counters)
+    FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, 8 * sizeof(uint64_t), ctx().stream));
+  FC_TRY(launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin));
+  FC_TRY(launch_simbits_refine(e, max_rmsd, max_dev, en_dev, max_dE));
+  e->bits_valid = true;
+  return FC_OK;
+}
+
+static const int64_t kLadder[] = {500000, 200000, 100000, 50000, 20000, 10000, 5000, 2000, 1000,
+                                  500,    200,    100,    50,    20,    10,    5,    2,    1};
+
+// whole ladder on one device (world == 1): returns survivors, levels run
+static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_per_group,
+                         uint8_t *mask_out, int64_t *levels, int64_t *survivors) {
+  const int64_t N = e->N;
+  FC_HIP_TRY(hipMemsetAsync(e->maskA.p, 1, (size_t)N, ctx().stream));
+  uint8_t *cur = e->maskA.as<uint8_t>(), *nxt = e->maskB.as<uint8_t>();
+  auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
+  int64_t active = N, nlev = 0;
+  FC_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint64_t), ctx().stream));
+  FC_TRY(launch_pack_mask(cur, N, e->mbits.as<uint64_t>(), e->W, cnt));
+  const int64_t rows = ceil_div(N, e->row_block) * e->row_block;
+  for (int64_t k : kLadder) {
+    if (!(k == 1 || min_per_group * k < active)) continue;
+    FC_TRY(launch_level(bits_dev, e->W, e->mbits.as<uint64_t>(), cur, nxt, N, k, e->row_block, 0, 1,
+                        rows));
+    std::swap(cur, nxt);
+    ++nlev;
+    // survivors of this level decide which ladder values still apply
+    FC_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint64_t), ctx().stream));
+    FC_TRY(launch_pack_mask(cur, N, e->mbits.as<uint64_t>(), e->W, cnt));
+    unsigned long long c = 0;
+    FC_TRY(d2h(&c, cnt, sizeof c));
+    FC_TRY(sync());
+    active = (int64_t)c;
+  }
+  if (mask_out) {
+    FC_TRY(d2h(mask_out, cur, (size_t)N));
+    FC_TRY(sync());
+  }
+  if (levels) *levels = nlev;
+  if (survivors) *survivors = active;
+  return FC_OK;
+}
+
+}  // namespace fc
+
+using namespace fc;
+
+// =============================================================================
+extern "C" {
+
+int fc_abi_version(void) { return 1; }
+
+int fc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int fc_init(int device) { return do_init(device); }
+
+int fc_shutdown(void) {
+  Context &c = ctx();
+  if (c.ready) {
+    (void)hipStreamSynchronize(c.stream);
+    (void)hipEventDestroy(c.ev0);
+    (void)hipEventDestroy(c.ev1);
+    (void)hipEventDestroy(c.ev2);
+    (void)hipEventDestroy(c.ev3);
+    (void)hipStreamDestroy(c.stream);
+    c.ready = false;
+  }
+  return FC_OK;
+}
+
+const char *fc_last_error(void) { return last_error().c_str(); }
+
+int fc_device_info(char *name, int64_t name_len, int64_t *n_cu, int64_t *hbm_bytes) {
+  FC_TRY(ensure_init());
+  if (name && name_len > 0) std::snprintf(name, (size_t)name_len, "%s", ctx().name);
+  if (n_cu) *n_cu = ctx().n_cu;
+  if (hbm_bytes) *hbm_bytes = (int64_t)ctx().hbm;
+  return FC_OK;
+}
+
+// ---- ensemble ------------------------------------------------------------------
+int fc_ensemble_create(const double *coords, int64_t N, int64_t A, const uint8_t *atom_mask,
+                       int center, fc_ensemble **out) {
+  FC_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  FC_REQUIRE(coords != nullptr || N == 0, "coords is NULL");
+  FC_REQUIRE(N >= 0 && A >= 1, "bad shape N=%lld A=%lld", (long long)N, (long long)A);
+  FC_REQUIRE(A <= 32767, "A=%lld exceeds 32767 atoms", (long long)A);
+  FC_TRY(ensure_init());
+  std::unique_ptr<fc_ensemble> e(new (std::nothrow) fc_ensemble);
+  if (!e) return set_error(FC_E_NOMEM, "host allocation failed");
+  FC_TRY(ensemble_build(coords, N, A, atom_mask, center, e.get()));
+  *out = e.release();
+  return FC_OK;
+}
+
+int fc_ensemble_destroy(fc_ensemble *ens) {
+  delete ens;
+  return FC_OK;
+}
+
+int fc_ensemble_shape(const fc_ensemble *ens, int64_t *N, int64_t *A_selected) {
+  FC_REQUIRE(ens != nullptr, "ens is NULL");
+  if (N) *N = ens->N;
+  if (A_selected) *A_selected = ens->A;
+  return FC_OK;
+}
+
+// ---- a4 ------------------------------------------------------------------------
+int fc_ensemble_rmsd_pairs(fc_ensemble *ens, const int64_t *pair_i, const int64_t *pair_j,
+                           int64_t P, double *rmsd_out, double *maxdev_out) {
+  FC_REQUIRE(ens != nullptr, "ens is NULL");
+  FC_REQUIRE(P >= 0, "P < 0");
+  if (P == 0) return FC_OK;
+  FC_REQUIRE(pair_i && pair_j && rmsd_out && maxdev_out, "NULL pointer argument");
+  for (int64_t k = 0; k < P; ++k)
+    FC_REQUIRE(pair_i[k] >= 0 && pair_i[k] < ens->N && pair_j[k] >= 0 && pair_j[k] < ens->N,
+               "pair %lld = (%lld, %lld) out of range [0, %lld)", (long long)k,
+               (long long)pair_i[k], (long long)pair_j[k], (long long)ens->N);
+  FC_TRY(ensure_init());
+  DevBuf di, dj, dr, dm;
+  FC_TRY(upload(di, pair_i, (size_t)P));
+  FC_TRY(upload(dj, pair_j, (size_t)P));
+  FC_TRY(dr.reserve((size_t)P * sizeof(double)));
+  FC_TRY(dm.reserve((size_t)P * sizeof(double)));
+  FC_TRY(launch_pairs_exact(ens, di.as<int64_t>(), dj.as<int64_t>(), P, dr.as<double>(),
+                            dm.as<double>(), nullptr));
+  FC_TRY(d2h(rmsd_out, dr.p, (size_t)P * sizeof(double)));
+  FC_TRY(d2h(maxdev_out, dm.p, (size_t)P * sizeof(double)));
+  return sync();
+}
+
+int fc_kabsch_rmsd_pairs(const double *coords, int64_t N, int64_t A, const uint8_t *atom_mask,
+                         const int64_t *pair_i, const int64_t *pair_j, int64_t P, int center,
+                         double *rmsd_out, double *maxdev_out) {
+  fc_ensemble *e = nullptr;
+  FC_TRY(fc_ensemble_create(coords, N, A, atom_mask, center, &e));
+  const int rc = fc_ensemble_rmsd_pairs(e, pair_i, pair_j, P, rmsd_out, maxdev_out);
+  fc_ensemble_destroy(e);
+  return rc;
+}
+
+int fc_ensemble_rmsd_matrix(fc_ensemble *ens, double *rmsd_out, double *maxdev_out) {
+  FC_REQUIRE(ens && rmsd_out && maxdev_out, "NULL pointer argument");
+  FC_TRY(ensure_init());
+  const int64_t N = ens->N;
+  if (N == 0) return FC_OK;
+  DevBuf dr, dm;
+  const size_t bytes = (size_t)N * N * sizeof(double);
+  FC_TRY(dr.reserve(bytes));
+  FC_TRY(dm.reserve(bytes));
+  FC_HIP_TRY(hipMemsetAsync(dr.p, 0, bytes, ctx().stream));
+  FC_HIP_TRY(hipMemsetAsync(dm.p, 0, bytes, ctx().stream));
+  FC_TRY(launch_matrix_exact(ens, dr.as<double>(), dm.as<double>()));
+  FC_TRY(d2h(rmsd_out, dr.p, bytes));
+  FC_TRY(d2h(maxdev_out, dm.p, bytes));
+  FC_TRY(sync());
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t j = i + 1; j < N; ++j) {
+      rmsd_out[j * N + i] = rmsd_out[i * N + j];
+      maxdev_out[j * N + i] = maxdev_out[i * N + j];
+    }
+  return FC_OK;
+}
+
+int fc_alignment_matrices(const double *p, const double *q, int64_t n_pairs, int64_t A,
+                          double *M_out) {
+  FC_REQUIRE(n_pairs >= 0 && A >= 1, "bad shape");
+  if (n_pairs == 0) return FC_OK;
+  FC_REQUIRE(p && q && M_out, "NULL pointer argument");
+  FC_TRY(ensure_init());
+  DevBuf dp, dq, dM;
+  FC_TRY(upload(dp, p, (size_t)n_pairs * A * 3));
+  FC_TRY(upload(dq, q, (size_t)n_pairs * A * 3));
+  FC_TRY(dM.reserve((size_t)n_pairs * 9 * sizeof(double)));
+  FC_TRY(launch_alignment_matrices(dp.as<double>(), dq.as<double>(), n_pairs, A, dM.as<double>()));
+  FC_TRY(d2h(M_out, dM.p, (size_t)n_pairs * 9 * sizeof(double)));
+  return sync();
+}
+
+// ---- a5 ------------------------------------------------------------------------
+int fc_rmsd_simbits(fc_ensemble *ens, double max_rmsd, double max_dev, const double *energies,
+                    double max_dE, int64_t row_begin, int64_t row_end, uint64_t *bits_out,
+                    int64_t *n_grey) {
+  FC_REQUIRE(ens && bits_out, "NULL pointer argument");
+  FC_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= ens->N, "bad row range");
+  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
+  FC_TRY(ensure_init());
+  if (ens->N == 0) return FC_OK;
+  FC_TRY(ensemble_shard(ens, 0, 1, 64));
+  FC_TRY(simbits_local(ens, max_rmsd, max_dev, energies, max_dE, true));
+  const int64_t W = ens->W;
+  std::vector<uint64_t> all((size_t)ens->rows_local * W);
+  unsigned long long cnt[8];
+  FC_TRY(d2h(all.data(), ens->bits.p, all.size() * sizeof(uint64_t)));
+  FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
+  FC_TRY(sync());
+  // words at or below the diagonal were never produced: define them as 0
+  for (int64_t i = row_begin; i < row_end; ++i)
+    for (int64_t w = 0; w < W; ++w)
+      bits_out[(i - row_begin) * W + w] = (w * 64 + 63 > i) ? all[(size_t)i * W + w] : 0ull;
+  if (n_grey) *n_grey = (int64_t)cnt[3];
+  return FC_OK;
+}
+
+int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const double *energies,
+                  double max_dE, int64_t min_per_group, uint8_t *mask_out, int64_t *stats) {
+  FC_REQUIRE(ens && mask_out, "NULL pointer argument");
+  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
+  FC_REQUIRE(min_per_group >= 1, "min_per_group must be >= 1");
+  FC_TRY(ensure_init());
+  if (ens->N == 0) return FC_OK;
+  FC_TRY(ensemble_shard(ens, 0, 1, 256));
+  FC_TRY(simbits_local(ens, max_rmsd, max_dev, energies, max_dE, true));
+  unsigned long long cnt[8];
+  FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
+  FC_TRY(sync());
+  int64_t levels = 0, survivors = 0;
+  FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), min_per_group, mask_out, &levels, &survivors));
+  if (stats) {
+    stats[0] = ens->N * (ens->N - 1) / 2;
+    stats[1] = (int64_t)cnt[1];
+    stats[2] = (int64_t)cnt[2];
+    stats[3] = (int64_t)cnt[3];
+    stats[4] = levels;
+    stats[5] = survivors;
+  }
+  return FC_OK;
+}
+
+int fc_greedy_prune_from_bits(const uint64_t *bits, int64_t N, int64_t min_per_group,
+                              uint8_t *mask_out) {
+  FC_REQUIRE(N >= 0 && min_per_group >= 1, "bad arguments");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(bits && mask_out, "NULL pointer argument");
+  FC_TRY(ensure_init());
+  fc_ensemble e;
+  e.N = N;
+  e.Npad = ceil_div(N, 64) * 64;
+  e.W = e.Npad / 64;
+  e.row_block = 64;
+  FC_TRY(e.maskA.reserve((size_t)e.Npad));
+  FC_TRY(e.maskB.reserve((size_t)e.Npad));
+  FC_TRY(e.mbits.reserve((size_t)e.W * sizeof(uint64_t)));
+  FC_TRY(e.counters.reserve(8 * sizeof(uint64_t)));
+  // rows padded to a multiple of the row block so k_level's local row == global row
+  const int64_t rows = ceil_div(N, e.row_block) * e.row_block;
+  FC_TRY(e.bits.reserve((size_t)rows * e.W * sizeof(uint64_t)));
+  FC_TRY(h2d(e.bits.p, bits, (size_t)N * e.W * sizeof(uint64_t)));
+  return ladder_single(&e, e.bits.as<uint64_t>(), min_per_group, mask_out, nullptr, nullptr);
+}
+
+int fc_prune_rmsd_begin(fc_ensemble *ens, double max_rmsd, double max_dev, const double *energies,
+                        double max_dE, int64_t rank, int64_t world, int64_t row_block,
+                        int64_t *stats) {
+  FC_REQUIRE(ens != nullptr, "ens is NULL");
+  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
+  FC_TRY(ensure_init());
+  FC_TRY(ensemble_shard(ens, rank, world, row_block));
+  if (ens->N == 0) return FC_OK;
+  FC_TRY(simbits_local(ens, max_rmsd, max_dev, energies, max_dE, true));
+  unsigned long long cnt[8];
+  FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
+  FC_TRY(sync());
+  if (stats) {
+    stats[0] = 0;  // pairs owned by this rank: rows i owned, columns j > i
+    const int64_t nb = ceil_div(ens->N, row_block);
+    for (int64_t b = rank; b < nb; b += world)
+      for (int64_t i = b * row_block; i < std::min(ens->N, (b + 1) * row_block); ++i)
+        stats[0] += ens->N - 1 - i;
+    stats[1] = (int64_t)cnt[1];
+    stats[2] = (int64_t)cnt[2];
+    stats[3] = (int64_t)cnt[3];
+    stats[4] = 0;
+    stats[5] = 0;
+  }
+  return FC_OK;
+}
+
+int fc_prune_level(fc_ensemble *ens, int64_t k, const uint8_t *mask_in, uint8_t *mask_out) {
+  FC_REQUIRE(ens && mask_in && mask_out, "NULL pointer argument");
+  FC_REQUIRE(ens->bits_valid, "fc_prune_rmsd_begin has not been called on this ensemble");
+  FC_REQUIRE(k >= 1, "k must be >= 1");
+  FC_TRY(ensure_init());
+  const int64_t N = ens->N;
+  if (N == 0) return FC_OK;
+  auto *cnt = reinterpret_cast<unsigned long long *>(ens->counters.p);
+  FC_TRY(h2d(ens->maskA.p, mask_in, (size_t)N));
+  FC_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint64_t), ctx().stream));
+  FC_TRY(launch_pack_mask(ens->maskA.as<uint8_t>(), N, ens->mbits.as<uint64_t>(), ens->W, cnt));
+  FC_TRY(launch_copy_bytes(ens->maskA.as<uint8_t>(), ens->maskB.as<uint8_t>(), N));
+  FC_TRY(launch_level(ens->bits.as<uint64_t>(), ens->W, ens->mbits.as<uint64_t>(),
+                      ens->maskA.as<uint8_t>(), ens->maskB.as<uint8_t>(), N, k, ens->row_block,
+                      ens->rank, ens->world, ens->rows_local));
+  FC_TRY(d2h(mask_out, ens->maskB.p, (size_t)N));
+  return sync();
+}
+
+// ---- a6 ------------------------------------------------------------------------
+int fc_inertia_moments(const double *coords, int64_t N, int64_t A, const double *masses,
+                       double *moments_out) {
+  FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(coords && masses && moments_out, "NULL pointer argument");
+  FC_TRY(ensure_init());
+  DevBuf dc, dm, dout;
+  FC_TRY(upload(dc, coords, (size_t)N * A * 3));
+  FC_TRY(upload(dm, masses, (size_t)A));
+  FC_TRY(dout.reserve((size_t)N * 3 * sizeof(double)));
+  FC_TRY(launch_inertia_moments(dc.as<double>(), N, A, dm.as<double>(), dout.as<double>()));
+  FC_TRY(d2h(moments_out, dout.p, (size_t)N * 3 * sizeof(double)));
+  return sync();
+}
+
+int fc_prune_moi(const double *coords, int64_t N, int64_t A, const double *masses,
+                 double max_deviation, const double *energies, double max_dE,
+                 int64_t min_per_group, uint8_t *mask_out) {
+  FC_REQUIRE(N >= 0 && A >= 1 && min_per_group >= 1, "bad arguments");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(coords && masses && mask_out, "NULL pointer argument");
+  FC_TRY(ensure_init());
+  fc_ensemble e;
+  e.N = N;
+  e.Npad = ceil_div(N, 64) * 64;
+  e.W = e.Npad / 64;
+  e.row_block = 64;
+  FC_TRY(e.maskA.reserve((size_t)e.Npad));
+  FC_TRY(e.maskB.reserve((size_t)e.Npad));
+  FC_TRY(e.mbits.reserve((size_t)e.W * sizeof(uint64_t)));
+  FC_TRY(e.counters.reserve(8 * sizeof(uint64_t)));
+  const int64_t rows = ceil_div(N, e.row_block) * e.row_block;
+  FC_TRY(e.bits.reserve((size_t)rows * e.W * sizeof(uint64_t)));
+  DevBuf dc, dm, dmom;
+  FC_TRY(upload(dc, coords, (size_t)N * A * 3));
+  FC_TRY(upload(dm, masses, (size_t)A));
+  FC_TRY(dmom.reserve((size_t)N * 3 * sizeof(double)));
+  const double *en_dev = nullptr;
+  if (energies) {
+    FC_TRY(upload(e.energies, energies, (size_t)N));
+    en_dev = e.energies.as<double>();
+  }
+  FC_TRY(launch_inertia_moments(dc.as<double>(), N, A, dm.as<double>(), dmom.as<double>()));
+  FC_TRY(launch_moi_simbits(dmom.as<double>(), N, max_deviation, en_dev, max_dE,
+                            e.bits.as<uint64_t>(), e.W));
+  return ladder_single(&e, e.bits.as<uint64_t>(), min_per_group, mask_out, nullptr, nullptr);
+}
+
+// ---- a8 / a13 --------------------------------------------------------------------
+int fc_align_to_first(const double *coords, int64_t N, int64_t A, const int64_t *idx,
+                      int64_t n_idx, double *out) {
+  FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(coords && out, "NULL pointer argument");
+  if (idx == nullptr) n_idx = A;
+  FC_REQUIRE(n_idx >= 1, "n_idx must be >= 1");
+  if (idx)
+    for (int64_t k = 0; k < n_idx; ++k)
+      FC_REQUIRE(idx[k] >= 0 && idx[k] < A, "idx[%lld] out of range", (long long)k);
+  FC_TRY(ensure_init());
+  DevBuf dc, di, dout;
+  FC_TRY(upload(dc, coords, (size_t)N * A * 3));
+  if (idx) FC_TRY(upload(di, idx, (size_t)n_idx));
+  FC_TRY(dout.reserve((size_t)N * A * 3 * sizeof(double)));
+  FC_TRY(launch_align_to_first(dc.as<double>(), N, A, idx ? di.as<int64_t>() : nullptr, n_idx,
+                               dout.as<double>()));
+  FC_TRY(d2h(out, dout.p, (size_t)N * A * 3 * sizeof(double)));
+  return sync();
+}
+
+int fc_rototranslate(const double *coords, int64_t n, int64_t A, const double *R, const double *t,
+                     double *out) {
+  FC_REQUIRE(n >= 0 && A >= 1, "bad shape");
+  if (n == 0) return FC_OK;
+  FC_REQUIRE(coords && R && t && out, "NULL pointer argument");
+  FC_TRY(ensure_init());
+  DevBuf dc, dR, dt, dout;
+  FC_TRY(upload(dc, coords, (size_t)n * A * 3));
+  FC_TRY(upload(dR, R, (size_t)n * 9));
+  FC_TRY(upload(dt, t, (size_t)n * 3));
+  FC_TRY(dout.reserve((size_t)n * A * 3 * sizeof(double)));
+  FC_TRY(launch_rototranslate(dc.as<double>(), n, A, dR.as<double>(), dt.as<double>(),
+                              dout.as<double>()));
+  FC_TRY(d2h(out, dout.p, (size_t)n * A * 3 * sizeof(double)));
+  return sync();
+}
+
+// ---- a11 / a12 ---------------------------------------------------------------------
+static const int64_t kMaxLdsAtoms = 160 * 1024 / 24;  // one structure per wavefront in LDS
+
+int fc_clash_self(const double *coords, int64_t N, int64_t A, double lo, double hi,
+                  int64_t *counts_out) {
+  FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(coords && counts_out, "NULL pointer argument");
+  if (A > kMaxLdsAtoms) return set_error(FC_E_LIMIT, "A=%lld exceeds %lld atoms", (long long)A, (long long)kMaxLdsAtoms);
+  FC_TRY(ensure_init());
+  DevBuf dc, dn;
+  FC_TRY(upload(dc, coords, (size_t)N * A * 3));
+  FC_TRY(dn.reserve((size_t)N * sizeof(int64_t)));
+  FC_TRY(launch_clash_self(dc.as<double>(), N, A, lo, hi, dn.as<int64_t>()));
+  FC_TRY(d2h(counts_out, dn.p, (size_t)N * sizeof(int64_t)));
+  return sync();
+}
+
+int fc_clash_fragments(const double *coords, int64_t N, int64_t A, const int64_t *ids,
+                       int64_t n_ids, double thresh, int64_t max_clashes, int64_t *counts_out,
+                       uint8_t *pass_out) {
+  FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
+  FC_REQUIRE(ids != nullptr && (n_ids == 2 || n_ids == 3), "ids must hold 2 or 3 fragment lengths");
+  int64_t tot = 0;
+  for (int64_t k = 0; k < n_ids; ++k) {
+    FC_REQUIRE(ids[k] >= 0, "negative fragment length");
+    tot += ids[k];
+  }
+  // reference slices m_last = coords[sum(ids[:-1]):] -- the last fragment takes the rest
+  FC_REQUIRE(tot - ids[n_ids - 1] <= A, "fragment lengths exceed A");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(coords && (counts_out || pass_out), "NULL pointer argument");
+  if (A > kMaxLdsAtoms) return set_error(FC_E_LIMIT, "A=%lld exceeds %lld atoms", (long long)A, (long long)kMaxLdsAtoms);
+  FC_TRY(ensure_init());
+  DevBuf dc, dn, dp;
+  FC_TRY(upload(dc, coords, (size_t)N * A * 3));
+  FC_TRY(dn.reserve((size_t)N * sizeof(int64_t)));
+  FC_TRY(dp.reserve((size_t)N));
+  FC_TRY(launch_clash_fragments(dc.as<double>(), N, A, ids, n_ids, thresh, max_clashes,
+                                dn.as<int64_t>(), dp.as<uint8_t>()));
+  if (counts_out) FC_TRY(d2h(counts_out, dn.p, (size_t)N * sizeof(int64_t)));
+  if (pass_out) FC_TRY(d2h(pass_out, dp.p, (size_t)N));
+  return sync();
+}
+
+// ---- a14 -------------------------------------------------------------------------
+int fc_embed_poses_clash(const double *m1, int64_t n1, int64_t A1, const double *m2, int64_t n2,
+                         int64_t A2, const int64_t *c1, const int64_t *c2, const double *R1,
+                         const double *t1, const double *R2, const double *t2, int64_t P,
+                         double thresh, int64_t max_clashes, int64_t *counts_out,
+                         uint8_t *pass_out, double *poses_out) {
+  FC_REQUIRE(n1 >= 1 && n2 >= 1 && A1 >= 1 && A2 >= 1 && P >= 0, "bad shape");
+  if (P == 0) return FC_OK;
+  FC_REQUIRE(m1 && m2 && c1 && c2 && R1 && t1 && R2 && t2, "NULL pointer argument");
+  FC_REQUIRE(counts_out || pass_out || poses_out, "no output requested");
+  if (4 * A1 * 24 > 160 * 1024) return set_error(FC_E_LIMIT, "A1=%lld too large for the LDS slice", (long long)A1);
+  for (int64_t k = 0; k < P; ++k)
+    FC_REQUIRE(c1[k] >= 0 && c1[k] < n1 && c2[k] >= 0 && c2[k] < n2, "conformer id out of range at pose %lld", (long long)k);
+  FC_TRY(ensure_init());
+  DevBuf dm1, dm2, dc1, dc2, dR1, dt1, dR2, dt2, dn, dp, dposes;
+  FC_TRY(upload(dm1, m1, (size_t)n1 * A1 * 3));
+  FC_TRY(upload(dm2, m2, (size_t)n2 * A2 * 3));
+  FC_TRY(upload(dc1, c1, (size_t)P));
+  FC_TRY(upload(dc2, c2, (size_t)P));
+  FC_TRY(upload(dR1, R1, (size_t)P * 9));
+  FC_TRY(upload(dt1, t1, (size_t)P * 3));
+  FC_TRY(upload(dR2, R2, (size_t)P * 9));
+  FC_TRY(upload(dt2, t2, (size_t)P * 3));
+  FC_TRY(dn.reserve((size_t)P * sizeof(int64_t)));
+  FC_TRY(dp.reserve((size_t)P));
+  if (poses_out) FC_TRY(dposes.reserve((size_t)P * (A1 + A2) * 3 * sizeof(double)));
+  FC_TRY(launch_embed_poses_clash(dm1.as<double>(), A1, dm2.as<double>(), A2, dc1.as<int64_t>(),
+                                  dc2.as<int64_t>(), dR1.as<double>(), dt1.as<double>(),
+                                  dR2.as<double>(), dt2.as<double>(), P, thresh, max_clashes,
+                                  dn.as<int64_t>(), dp.as<uint8_t>(),
+                                  poses_out ? dposes.as<double>() : nullptr));
+  if (counts_out) FC_TRY(d2h(counts_out, dn.p, (size_t)P * sizeof(int64_t)));
+  if (pass_out) FC_TRY(d2h(pass_out, dp.p, (size_t)P));
+  if (poses_out) FC_TRY(d2h(poses_out, dposes.p, (size_t)P * (A1 + A2) * 3 * sizeof(double)));
+  return sync();
+}
+
+// ---- a17-a20 -----------------------------------------------------------------------
+int fc_torsion_scan(const double *base, int64_t A, const int64_t *torsions, int64_t T,
+                    const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
+                    int64_t backoff_deg, double *coords_out, int64_t *rotated_bonds_out) {
+  FC_REQUIRE(A >= 2 && T >= 1 && S >= 0, "bad shape");
+  FC_REQUIRE(backoff_deg != 0, "backoff_deg must be non-zero");
+  if (S == 0) return FC_OK;
+  FC_REQUIRE(base && torsions && rotmasks && angles && coords_out && rotated_bonds_out,
+             "NULL pointer argument");
+  if (4 * A * 24 > 160 * 1024 || A > 32767)
+    return set_error(FC_E_LIMIT, "A=%lld too large for the LDS slice", (long long)A);
+  // moving / rest index lists per torsion (torsion_module.py:907-915)
+  std::vector<int16_t> mv((size_t)T * A, 0), rs((size_t)T * A, 0);
+  std::vector<int32_t> nmv((size_t)T, 0), nrs((size_t)T, 0);
+  for (int64_t t = 0; t < T; ++t) {
+    for (int k = 0; k < 4; ++k)
+      FC_REQUIRE(torsions[t * 4 + k] >= 0 && torsions[t * 4 + k] < A, "torsion %lld index out of range", (long long)t);
+    const int64_t i2 = torsions[t * 4 + 1], i3 = torsions[t * 4 + 2];
+    for (int64_t a = 0; a < A; ++a) {
+      if (rotmasks[t * A + a]) mv[(size_t)t * A + nmv[t]++] = (int16_t)a;
+      else if (a != i2 && a != i3) rs[(size_t)t * A + nrs[t]++] = (int16_t)a;
+    }
+  }
+  FC_TRY(ensure_init());
+  DevBuf db, dt, dmk, dmv, drs, dnm, dnr, da, dout, drot;
+  FC_TRY(upload(db, base, (size_t)A * 3));
+  FC_TRY(upload(dt, torsions, (size_t)T * 4));
+  FC_TRY(upload(dmk, rotmasks, (size_t)T * A));
+  FC_TRY(upload(dmv, mv.data(), mv.size()));
+  FC_TRY(upload(drs, rs.data(), rs.size()));
+  FC_TRY(upload(dnm, nmv.data(), nmv.size()));
+  FC_TRY(upload(dnr, nrs.data(), nrs.size()));
+  FC_TRY(upload(da, angles, (size_t)S * T));
+  FC_TRY(dout.reserve((size_t)S * A * 3 * sizeof(double)));
+  FC_TRY(drot.reserve((size_t)S * sizeof(int64_t)));
+  FC_TRY(launch_torsion_scan(db.as<double>(), A, dt.as<int64_t>(), T, dmk.as<uint8_t>(),
+                             dmv.as<int16_t>(), drs.as<int16_t>(), dnm.as<int32_t>(),
+                             dnr.as<int32_t>(), da.as<int64_t>(), S, thresh, backoff_deg,
+                             dout.as<double>(), drot.as<int64_t>()));
+  FC_TRY(d2h(coords_out, dout.p, (size_t)S * A * 3 * sizeof(double)));
+  FC_TRY(d2h(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t)));
+  return sync();
+}
+
+int fc_torsion_fingerprint(const double *coords, int64_t N, int64_t A, const int64_t *quads,
+                           int64_t Q, double *tf_out) {
+  FC_REQUIRE(N >= 0 && A >= 1 && Q >= 0, "bad shape");
+  if (N == 0 || Q == 0) return FC_OK;
+  FC_REQUIRE(coords && quads && tf_out, "NULL pointer argument");
+  for (int64_t k = 0; k < Q * 4; ++k) FC_REQUIRE(quads[k] >= 0 && quads[k] < A, "quadruplet index out of range");
+  FC_TRY(ensure_init());
+  DevBuf dc, dq, dtf;
+  FC_TRY(upload(dc, coords, (size_t)N * A * 3));
+  FC_TRY(upload(dq, quads, (size_t)Q * 4));
+  FC_TRY(dtf.reserve((size_t)N * Q * sizeof(double)));
+  FC_TRY(launch_torsion_fingerprint(dc.as<double>(), N, A, dq.as<int64_t>(), Q, dtf.as<double>()));
+  FC_TRY(d2h(tf_out, dtf.p, (size_t)N * Q * sizeof(double)));
+  return sync();
+}
+
+int fc_tfd_simbits(const double *tf, int64_t N, int64_t Q, double thresh, int64_t row_begin,
+                   int64_t row_end, uint64_t *bits_out) {
+  FC_REQUIRE(N >= 0 && Q >= 0, "bad shape");
+  FC_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= N, "bad row range");
+  if (row_end == row_begin) return FC_OK;
+  FC_REQUIRE(bits_out && (tf || Q == 0), "NULL pointer argument");
+  FC_TRY(ensure_init());
+  const int64_t W = ceil_div(N, 64);
+  DevBuf dtf, dbits;
+  FC_TRY(upload(dtf, tf, (size_t)N * Q));
+  const size_t bytes = (size_t)(row_end - row_begin) * W * sizeof(uint64_t);
+  FC_TRY(dbits.reserve(bytes));
+  FC_TRY(launch_tfd_simbits(dtf.as<double>(), N, Q, thresh, row_begin, row_end,
+                            dbits.as<uint64_t>(), W));
+  FC_TRY(d2h(bits_out, dbits.p, bytes));
+  return sync();
+}
+
+// ---- bench hook ----------------------------------------------------------------------
+int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
+                        double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
+                        int64_t *stats) {
+  FC_REQUIRE(ens && reps >= 1, "bad arguments");
+  FC_TRY(ensure_init());
+  FC_TRY(ensemble_shard(ens, 0, 1, 256));
+  Context &c = ctx();
+  double t_kernel = 0.0, t_step = 0.0;
+  int64_t levels = 0, survivors = 0;
+  unsigned long long cnt[8] = {0};
+  for (int64_t r = 0; r < reps; ++r) {
+    FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 8 * sizeof(uint64_t), c.stream));
+    FC_HIP_TRY(hipEventRecord(c.ev0, c.stream));
+    FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
+    FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
+    FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
+    ens->bits_valid = true;
+    FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
+    FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, nullptr, &levels, &survivors));
+    FC_HIP_TRY(hipEventRecord(c.ev2, c.stream));
+    FC_HIP_TRY(hipEventSynchronize(c.ev2));
+    float a = 0.f, b = 0.f;
+    FC_HIP_TRY(hipEventElapsedTime(&a, c.ev0, c.ev1));
+    FC_HIP_TRY(hipEventElapsedTime(&b, c.ev0, c.ev2));
+    t_kernel += a;
+    t_step += b;
+  }
+  if (ms_simbits_kernel) *ms_simbits_kernel = t_kernel / (double)reps;
+  if (ms_step) *ms_step = t_step / (double)reps;
+  if (mask_out) {
+    // ladder_single left the final mask in maskA or maskB; rerun the cheap ladder to export it
+    FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, mask_out, &levels, &survivors));
+  }
+  if (stats) {
+    stats[0] = ens->N * (ens->N - 1) / 2;
+    stats[1] = (int64_t)cnt[1];
+    stats[2] = (int64_t)cnt[2];
+    stats[3] = (int64_t)cnt[3];
+    stats[4] = levels;
+    stats[5] = survivors;
+  }
+  return FC_OK;
+}
+
+}  // extern "C"

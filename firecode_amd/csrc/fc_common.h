@@ -1,0 +1,126 @@
+// fc_common.h -- context, error plumbing and device buffers shared by the
+// translation units of libfc_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fc_hip.h"
+
+namespace fc {
+
+// ---- error state (per thread) ---------------------------------------------
+std::string &last_error();
+int set_error(int code, const char *fmt, ...);
+
+#define FC_HIP_TRY(expr)                                                              \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess)                                                             \
+      return ::fc::set_error(_e == hipErrorOutOfMemory ? FC_E_NOMEM : FC_E_HIP,       \
+                             "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                             __FILE__, __LINE__);                                     \
+  } while (0)
+
+#define FC_TRY(expr)           \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc != FC_OK) return _rc; \
+  } while (0)
+
+#define FC_REQUIRE(cond, ...)                                  \
+  do {                                                         \
+    if (!(cond)) return ::fc::set_error(FC_E_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// ---- context ----------------------------------------------------------------
+struct Context {
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  int n_cu = 0;
+  size_t hbm = 0;
+  char name[128] = {0};
+};
+Context &ctx();
+int ensure_init();  // lazy init on device 0 (or the one given to fc_init)
+
+// ---- RAII device buffer -------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  // grow-only allocation; contents are NOT preserved
+  int reserve(size_t n) {
+    if (n <= bytes && p) return FC_OK;
+    release();
+    if (n == 0) n = 8;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return set_error(FC_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    }
+    bytes = n;
+    return FC_OK;
+  }
+  template <class T>
+  T *as() const { return static_cast<T *>(p); }
+};
+
+inline int h2d(void *dst, const void *src, size_t n) {
+  if (n == 0) return FC_OK;
+  FC_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, ctx().stream));
+  return FC_OK;
+}
+inline int d2h(void *dst, const void *src, size_t n) {
+  if (n == 0) return FC_OK;
+  FC_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, ctx().stream));
+  return FC_OK;
+}
+inline int sync() {
+  FC_HIP_TRY(hipStreamSynchronize(ctx().stream));
+  return FC_OK;
+}
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(FC_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return FC_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace fc
+
+// ---- resident ensemble -----------------------------------------------------------
+struct fc_ensemble {
+  int64_t N = 0, A = 0;        // conformers, selected atoms
+  int64_t Npad = 0, W = 0;     // N rounded up to 64; words per bit row
+  fc::DevBuf Xs;               // [(a*3+c)*Npad + n] doubles, zero padded
+  fc::DevBuf G;                // [Npad] sum of squares per conformer
+  // prune workspace (allocated on first use, kept for later calls)
+  fc::DevBuf bits;             // rows_local * W uint64
+  fc::DevBuf energies;         // N doubles (optional)
+  fc::DevBuf maskA, maskB;     // N bytes each
+  fc::DevBuf mbits;            // W uint64 active-flag words
+  fc::DevBuf counters;         // 8 x uint64
+  // sharding of the bit matrix rows (block-cyclic)
+  int64_t rank = 0, world = 1, row_block = 64;
+  int64_t rows_local = 0;
+  bool bits_valid = false;
+};

@@ -1,0 +1,188 @@
+// fc_kabsch_math.h -- per-lane float64 3x3 / 4x4 algebra for the Kabsch
+// superposition (register resident, no LDS, no MFMA: SURVEY.md section 7).
+//
+// Convention (pinned to the in-tree twin firecode/algebra.py:28-49 and the
+// call site hypermolecule_class.py:77-84): B[x][y] = sum_a p_a[x] * q_a[y];
+// the rotation R returned maximises tr(R^T B) over SO(3), i.e. R rotates q
+// onto p and is applied as  q' = R q  ( == (M @ q.T).T row-wise ).
+// LAPACK's  u, s, vh = svd(B);  det-fix;  R = u @ vh  gives the same matrix;
+// here it is obtained as the dominant eigenvector of Horn's 4x4 quaternion
+// matrix by cyclic Jacobi, which never leaves SO(3) and needs no det-fix.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fc {
+
+// One Jacobi rotation on the (P,Q) plane of a symmetric 4x4 `a`, accumulated
+// into the eigenvector matrix `v` (columns).  All indices are compile time,
+// so both arrays live in VGPRs.
+template <int P, int Q>
+__host__ __device__ __forceinline__ void jacobi_rot(double (&a)[4][4], double (&v)[4][4], bool late) {
+  const double apq = a[P][Q];
+  const double g = 100.0 * fabs(apq);
+  const double app = a[P][P], aqq = a[Q][Q];
+  if (late && (fabs(app) + g == fabs(app)) && (fabs(aqq) + g == fabs(aqq))) {
+    a[P][Q] = 0.0;
+    a[Q][P] = 0.0;
+    return;
+  }
+  if (apq == 0.0) return;
+  const double h = aqq - app;
+  double t;
+  if (fabs(h) + g == fabs(h)) {
+    t = apq / h;
+  } else {
+    const double theta = 0.5 * h / apq;
+    t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+    if (theta < 0.0) t = -t;
+  }
+  const double c = 1.0 / sqrt(1.0 + t * t);
+  const double s = t * c;
+  const double tau = s / (1.0 + c);
+  const double hh = t * apq;
+  a[P][P] = app - hh;
+  a[Q][Q] = aqq + hh;
+  a[P][Q] = 0.0;
+  a[Q][P] = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (r != P && r != Q) {
+      const double arp = a[r][P], arq = a[r][Q];
+      const double np_ = arp - s * (arq + arp * tau);
+      const double nq_ = arq + s * (arp - arq * tau);
+      a[r][P] = np_;
+      a[P][r] = np_;
+      a[r][Q] = nq_;
+      a[Q][r] = nq_;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double vrp = v[r][P], vrq = v[r][Q];
+    v[r][P] = vrp - s * (vrq + vrp * tau);
+    v[r][Q] = vrq + s * (vrp - vrq * tau);
+  }
+}
+
+// Optimal rotation (row-major R[9]) from the covariance B (row-major 3x3).
+// Returns the largest eigenvalue of the quaternion matrix
+// (= s1 + s2 +/- s3 of B).
+__host__ __device__ __forceinline__ double kabsch_rotation(const double (&B)[9], double (&R)[9]) {
+  // Horn's matrix for rotating the q-structure onto the p-structure:
+  // S_xy = sum q_x p_y = B[y][x]
+  const double Sxx = B[0], Sxy = B[3], Sxz = B[6];
+  const double Syx = B[1], Syy = B[4], Syz = B[7];
+  const double Szx = B[2], Szy = B[5], Szz = B[8];
+  double a[4][4], v[4][4];
+  a[0][0] = Sxx + Syy + Szz;
+  a[0][1] = Syz - Szy;
+  a[0][2] = Szx - Sxz;
+  a[0][3] = Sxy - Syx;
+  a[1][1] = Sxx - Syy - Szz;
+  a[1][2] = Sxy + Syx;
+  a[1][3] = Szx + Sxz;
+  a[2][2] = -Sxx + Syy - Szz;
+  a[2][3] = Syz + Szy;
+  a[3][3] = -Sxx - Syy + Szz;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < i; ++j) a[i][j] = a[j][i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[0][3]) + fabs(a[1][2]) +
+                       fabs(a[1][3]) + fabs(a[2][3]);
+    if (off == 0.0) break;
+    const bool late = sweep > 3;
+    jacobi_rot<0, 1>(a, v, late);
+    jacobi_rot<0, 2>(a, v, late);
+    jacobi_rot<0, 3>(a, v, late);
+    jacobi_rot<1, 2>(a, v, late);
+    jacobi_rot<1, 3>(a, v, late);
+    jacobi_rot<2, 3>(a, v, late);
+  }
+  // dominant eigenpair (select with compile-time indices only)
+  double lam = a[0][0];
+  double q0 = v[0][0], q1 = v[1][0], q2 = v[2][0], q3 = v[3][0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const bool better = a[k][k] > lam;
+    lam = better ? a[k][k] : lam;
+    q0 = better ? v[0][k] : q0;
+    q1 = better ? v[1][k] : q1;
+    q2 = better ? v[2][k] : q2;
+    q3 = better ? v[3][k] : q3;
+  }
+  const double nrm = 1.0 / sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+  q0 *= nrm;
+  q1 *= nrm;
+  q2 *= nrm;
+  q3 *= nrm;
+  R[0] = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3;
+  R[1] = 2.0 * (q1 * q2 - q0 * q3);
+  R[2] = 2.0 * (q1 * q3 + q0 * q2);
+  R[3] = 2.0 * (q1 * q2 + q0 * q3);
+  R[4] = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3;
+  R[5] = 2.0 * (q2 * q3 - q0 * q1);
+  R[6] = 2.0 * (q1 * q3 - q0 * q2);
+  R[7] = 2.0 * (q2 * q3 + q0 * q1);
+  R[8] = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
+  return lam;
+}
+
+// Division-free screen used by the all-pairs kernel.  With
+// L = (Gp + Gq - A*thr2)/2 the pair has  msd < thr2  iff the largest root of
+// the quaternion characteristic polynomial
+//     P(x) = x^4 + C2 x^2 + C1 x + C0,
+//     C2 = -2 |B|_F^2,  C1 = -8 det B,  C0 = det K
+// exceeds L.  All roots are real, so by Budan-Fourier no root exceeds L iff
+// P, P', P'', P''' are all >= 0 at L.  Returns true when the pair MAY be
+// similar (it is then re-evaluated exactly); false only when it provably
+// (with a 1e-12 relative guard on P) is not.
+__host__ __device__ __forceinline__ bool kabsch_may_be_below(const double (&B)[9], double GpGq,
+                                                     double A_thr2) {
+  const double s = 0.5 * GpGq;
+  const double L = s - 0.5 * A_thr2;
+  if (!(A_thr2 < 0.5 * s)) return true;  // tiny structure w.r.t. threshold
+  const double Sxx = B[0], Sxy = B[1], Sxz = B[2];
+  const double Syx = B[3], Syy = B[4], Syz = B[5];
+  const double Szx = B[6], Szy = B[7], Szz = B[8];
+  const double n2 = Sxx * Sxx + Sxy * Sxy + Sxz * Sxz + Syx * Syx + Syy * Syy + Syz * Syz +
+                    Szx * Szx + Szy * Szy + Szz * Szz;
+  const double C2 = -2.0 * n2;
+  const double L2 = L * L;
+  const double P2 = 12.0 * L2 + 2.0 * C2;
+  if (P2 < 0.0) return true;
+  const double detB = Sxx * (Syy * Szz - Syz * Szy) - Sxy * (Syx * Szz - Syz * Szx) +
+                      Sxz * (Syx * Szy - Syy * Szx);
+  const double C1 = -8.0 * detB;
+  const double P1 = (4.0 * L2 + 2.0 * C2) * L + C1;
+  if (P1 < 0.0) return true;
+  // det K by Laplace expansion over the first two rows
+  const double a00 = Sxx + Syy + Szz, a01 = Syz - Szy, a02 = Szx - Sxz, a03 = Sxy - Syx;
+  const double a11 = Sxx - Syy - Szz, a12 = Sxy + Syx, a13 = Szx + Sxz;
+  const double a22 = -Sxx + Syy - Szz, a23 = Syz + Szy;
+  const double a33 = -Sxx - Syy + Szz;
+  const double s0 = a00 * a11 - a01 * a01;
+  const double s1 = a00 * a12 - a01 * a02;
+  const double s2 = a00 * a13 - a01 * a03;
+  const double s3 = a01 * a12 - a11 * a02;
+  const double s4 = a01 * a13 - a11 * a03;
+  const double s5 = a02 * a13 - a12 * a03;
+  const double c5 = a22 * a33 - a23 * a23;
+  const double c4 = a12 * a33 - a13 * a23;
+  const double c3 = a12 * a23 - a13 * a22;
+  const double c2 = a02 * a33 - a03 * a23;
+  const double c1 = a02 * a23 - a03 * a22;
+  const double c0 = a02 * a13 - a03 * a12;
+  const double C0 = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+  const double P0 = ((L2 + C2) * L + C1) * L + C0;
+  const double eps = 1e-12 * (s * s) * (s * s);
+  return !(P0 > eps);
+}
+
+}  // namespace fc

@@ -1,0 +1,283 @@
+// fc_prune.hip -- greedy k-ladder replay over similarity bits, moment-of-
+// inertia similarity, torsion-fingerprint similarity (gfx950, wave64).
+//
+// Reference semantics (prism_pruner.pruner as evidenced by
+// /root/reference/CHANGELOG.md:120,188,198,206 and the in-tree sibling
+// firecode/torsion_module.py:973-992): for every ladder value k the array is
+// cut in k contiguous chunks of N//k (last chunk takes the remainder); a
+// structure active at the start of the level is removed "at the first
+// instance of a similar one", i.e. iff an active j > i of its chunk is
+// similar.  Rejections inside a level do not feed back into that level, so a
+// level is a data-parallel map over rows of the bit matrix:
+//     out[i] = in[i] && !any_{i<j<last(i)} ( in[j] && sim[i][j] )
+#include "fc_common.h"
+#include "fc_kabsch_math.h"
+
+namespace fc {
+
+// bytes -> active-flag words + population count (counters[0])
+__global__ void __launch_bounds__(256)
+k_pack_mask(const uint8_t *__restrict__ mask, int64_t N, uint64_t *__restrict__ mbits, int64_t W,
+            unsigned long long *__restrict__ counters) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= W) return;
+  const int64_t i = w * 64 + lane;
+  const bool on = (i < N) && mask[i];
+  const uint64_t word = __ballot(on);
+  if (lane == 0) {
+    mbits[w] = word;
+    if (word) atomicAdd(&counters[0], (unsigned long long)__popcll(word));
+  }
+}
+
+// one wavefront per owned row; lanes stride over the row's words (coalesced)
+__global__ void __launch_bounds__(256)
+k_level(const uint64_t *__restrict__ bits, int64_t W, const uint64_t *__restrict__ mbits,
+        const uint8_t *__restrict__ mask_in, uint8_t *__restrict__ mask_out, int64_t N, int64_t k,
+        int IB, int64_t rank, int64_t world, int64_t rows_local) {
+  const int lane = threadIdx.x & 63;
+  const int64_t lrow = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (lrow >= rows_local) return;
+  const int64_t lb = lrow / IB;
+  const int64_t i = (lb * world + rank) * IB + (lrow % IB);
+  if (i >= N) return;
+  if (!mask_in[i]) {
+    if (lane == 0) mask_out[i] = 0;
+    return;
+  }
+  const int64_t chunk = N / k;
+  int64_t c = chunk > 0 ? i / chunk : 0;
+  if (c > k - 1) c = k - 1;
+  const int64_t last = (c == k - 1) ? N : chunk * (c + 1);  // exclusive
+  // columns j in (i, last)
+  const int64_t w0 = (i + 1) >> 6;
+  const int64_t w1 = (last - 1) >> 6;  // inclusive; last >= i+1 always
+  bool hit = false;
+  const uint64_t *row = bits + lrow * W;
+  for (int64_t w = w0 + lane; w <= w1; w += 64) {
+    uint64_t x = row[w] & mbits[w];
+    if (w == w0) {
+      const int s = (int)((i + 1) & 63);
+      x &= (~0ull) << s;
+    }
+    if (w == w1) {
+      const int e = (int)((last - 1) & 63);  // keep bits 0..e
+      x &= (e == 63) ? ~0ull : ((1ull << (e + 1)) - 1ull);
+    }
+    hit |= (x != 0);
+  }
+  const bool any = __any(hit);
+  if (lane == 0) mask_out[i] = any ? 0 : 1;
+}
+
+// copy for rows a rank does not own (sharded levels)
+__global__ void __launch_bounds__(256)
+k_copy_bytes(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
+// moments of inertia: one lane per conformer; 3x3 symmetric eigenvalues by
+// cyclic Jacobi (same rotation as the 4x4 case), sorted ascending.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void sym3_eigvals(double a00, double a01, double a02, double a11,
+                                             double a12, double a22, double (&w)[3]) {
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    const double off = fabs(a01) + fabs(a02) + fabs(a12);
+    if (off == 0.0) break;
+    const bool late = sweep > 3;
+    // (0,1)
+    {
+      const double g = 100.0 * fabs(a01);
+      if (late && fabs(a00) + g == fabs(a00) && fabs(a11) + g == fabs(a11)) a01 = 0.0;
+      else if (a01 != 0.0) {
+        const double h = a11 - a00;
+        double t;
+        if (fabs(h) + g == fabs(h)) t = a01 / h;
+        else { const double th = 0.5 * h / a01; t = 1.0 / (fabs(th) + sqrt(1.0 + th * th)); if (th < 0.0) t = -t; }
+        const double c = 1.0 / sqrt(1.0 + t * t), s = t * c, tau = s / (1.0 + c), hh = t * a01;
+        a00 -= hh; a11 += hh; a01 = 0.0;
+        const double p = a02, q = a12;
+        a02 = p - s * (q + p * tau);
+        a12 = q + s * (p - q * tau);
+      }
+    }
+    // (0,2)
+    {
+      const double g = 100.0 * fabs(a02);
+      if (late && fabs(a00) + g == fabs(a00) && fabs(a22) + g == fabs(a22)) a02 = 0.0;
+      else if (a02 != 0.0) {
+        const double h = a22 - a00;
+        double t;
+        if (fabs(h) + g == fabs(h)) t = a02 / h;
+        else { const double th = 0.5 * h / a02; t = 1.0 / (fabs(th) + sqrt(1.0 + th * th)); if (th < 0.0) t = -t; }
+        const double c = 1.0 / sqrt(1.0 + t * t), s = t * c, tau = s / (1.0 + c), hh = t * a02;
+        a00 -= hh; a22 += hh; a02 = 0.0;
+        const double p = a01, q = a12;  // a[1][0], a[1][2]
+        a01 = p - s * (q + p * tau);
+        a12 = q + s * (p - q * tau);
+      }
+    }
+    // (1,2)
+    {
+      const double g = 100.0 * fabs(a12);
+      if (late && fabs(a11) + g == fabs(a11) && fabs(a22) + g == fabs(a22)) a12 = 0.0;
+      else if (a12 != 0.0) {
+        const double h = a22 - a11;
+        double t;
+        if (fabs(h) + g == fabs(h)) t = a12 / h;
+        else { const double th = 0.5 * h / a12; t = 1.0 / (fabs(th) + sqrt(1.0 + th * th)); if (th < 0.0) t = -t; }
+        const double c = 1.0 / sqrt(1.0 + t * t), s = t * c, tau = s / (1.0 + c), hh = t * a12;
+        a11 -= hh; a22 += hh; a12 = 0.0;
+        const double p = a01, q = a02;  // a[0][1], a[0][2]
+        a01 = p - s * (q + p * tau);
+        a02 = q + s * (p - q * tau);
+      }
+    }
+  }
+  double x = a00, y = a11, z = a22, t;
+  if (x > y) { t = x; x = y; y = t; }
+  if (y > z) { t = y; y = z; z = t; }
+  if (x > y) { t = x; x = y; y = t; }
+  w[0] = x; w[1] = y; w[2] = z;
+}
+
+__global__ void __launch_bounds__(256)
+k_inertia_moments(const double *__restrict__ coords, int64_t N, int64_t A,
+                  const double *__restrict__ masses, double *__restrict__ moments) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const double *x = coords + n * A * 3;
+  double mt = 0.0, cx = 0.0, cy = 0.0, cz = 0.0;
+  for (int64_t a = 0; a < A; ++a) {
+    const double m = masses[a];
+    mt += m;
+    cx += x[a * 3] * m;
+    cy += x[a * 3 + 1] * m;
+    cz += x[a * 3 + 2] * m;
+  }
+  cx /= mt; cy /= mt; cz /= mt;
+  double ixx = 0, iyy = 0, izz = 0, ixy = 0, ixz = 0, iyz = 0;
+  for (int64_t a = 0; a < A; ++a) {
+    const double m = masses[a];
+    const double rx = x[a * 3] - cx, ry = x[a * 3 + 1] - cy, rz = x[a * 3 + 2] - cz;
+    const double r2 = rx * rx + ry * ry + rz * rz;
+    ixx += m * (r2 - rx * rx);
+    iyy += m * (r2 - ry * ry);
+    izz += m * (r2 - rz * rz);
+    ixy += m * (0.0 - rx * ry);
+    ixz += m * (0.0 - rx * rz);
+    iyz += m * (0.0 - ry * rz);
+  }
+  double w[3];
+  sym3_eigvals(ixx, ixy, ixz, iyy, iyz, izz, w);
+  moments[n * 3 + 0] = w[0];
+  moments[n * 3 + 1] = w[1];
+  moments[n * 3 + 2] = w[2];
+}
+
+// MOI similarity bits: bit j of row i (j > i) = all_k |I_i[k]-I_j[k]| / I_i[k] < tol
+// [&& |E_i - E_j| < max_dE].  One wavefront per (row, 64-column word).
+__global__ void __launch_bounds__(256)
+k_moi_simbits(const double *__restrict__ moments, int64_t N, double tol,
+              const double *__restrict__ energies, double max_dE, uint64_t *__restrict__ bits,
+              int64_t W) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t i = wave / W, jt = wave % W;
+  if (i >= N) return;
+  if (jt * 64 + 63 <= i) return;
+  const int64_t j = jt * 64 + lane;
+  bool sim = false;
+  if (j < N && j > i) {
+    const double a0 = moments[i * 3], a1 = moments[i * 3 + 1], a2 = moments[i * 3 + 2];
+    const double b0 = moments[j * 3], b1 = moments[j * 3 + 1], b2 = moments[j * 3 + 2];
+    sim = (fabs(a0 - b0) / a0 < tol) && (fabs(a1 - b1) / a1 < tol) && (fabs(a2 - b2) / a2 < tol);
+    if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
+  }
+  const uint64_t word = __ballot(sim);
+  if (lane == 0) bits[i * W + jt] = word;
+}
+
+// TFD similarity bits over all j != i (firecode/torsion_module.py:1056-1067):
+// deltas = |tf_i - tf_j|; deltas = |deltas - (deltas > 180)*360|; sum < thresh.
+// Same left-to-right summation order as np.sum over Q <= 8 elements.
+__global__ void __launch_bounds__(256)
+k_tfd_simbits(const double *__restrict__ tf, int64_t N, int Q, double thresh, int64_t row_begin,
+              int64_t row_end, uint64_t *__restrict__ bits, int64_t W) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t r = wave / W, jt = wave % W;
+  const int64_t i = row_begin + r;
+  if (i >= row_end) return;
+  const int64_t j = jt * 64 + lane;
+  bool sim = false;
+  if (j < N && j != i) {
+    double sum = 0.0;
+    for (int q = 0; q < Q; ++q) {
+      double d = fabs(tf[i * Q + q] - tf[j * Q + q]);
+      d = fabs(d - (d > 180.0 ? 360.0 : 0.0));
+      sum += d;
+    }
+    sim = sum < thresh;
+  }
+  const uint64_t word = __ballot(sim);
+  if (lane == 0) bits[r * W + jt] = word;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+int launch_pack_mask(const uint8_t *mask_dev, int64_t N, uint64_t *mbits_dev, int64_t W,
+                     unsigned long long *counters_dev) {
+  hipLaunchKernelGGL(k_pack_mask, dim3((unsigned)ceil_div(W, 4)), dim3(256), 0, ctx().stream,
+                     mask_dev, N, mbits_dev, W, counters_dev);
+  return check_launch("k_pack_mask");
+}
+
+int launch_level(const uint64_t *bits_dev, int64_t W, const uint64_t *mbits_dev,
+                 const uint8_t *mask_in, uint8_t *mask_out, int64_t N, int64_t k, int64_t IB,
+                 int64_t rank, int64_t world, int64_t rows_local) {
+  if (rows_local == 0) return FC_OK;
+  hipLaunchKernelGGL(k_level, dim3((unsigned)ceil_div(rows_local, 4)), dim3(256), 0, ctx().stream,
+                     bits_dev, W, mbits_dev, mask_in, mask_out, N, k, (int)IB, rank, world,
+                     rows_local);
+  return check_launch("k_level");
+}
+
+int launch_copy_bytes(const uint8_t *src, uint8_t *dst, int64_t n) {
+  if (n == 0) return FC_OK;
+  hipLaunchKernelGGL(k_copy_bytes, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream,
+                     src, dst, n);
+  return check_launch("k_copy_bytes");
+}
+
+int launch_inertia_moments(const double *coords_dev, int64_t N, int64_t A, const double *masses_dev,
+                           double *moments_dev) {
+  if (N == 0) return FC_OK;
+  hipLaunchKernelGGL(k_inertia_moments, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0,
+                     ctx().stream, coords_dev, N, A, masses_dev, moments_dev);
+  return check_launch("k_inertia_moments");
+}
+
+int launch_moi_simbits(const double *moments_dev, int64_t N, double tol, const double *energies_dev,
+                       double max_dE, uint64_t *bits_dev, int64_t W) {
+  const int64_t waves = N * W;
+  if (waves == 0) return FC_OK;
+  hipLaunchKernelGGL(k_moi_simbits, dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, ctx().stream,
+                     moments_dev, N, tol, energies_dev, max_dE, bits_dev, W);
+  return check_launch("k_moi_simbits");
+}
+
+int launch_tfd_simbits(const double *tf_dev, int64_t N, int64_t Q, double thresh, int64_t row_begin,
+                       int64_t row_end, uint64_t *bits_dev, int64_t W) {
+  const int64_t waves = (row_end - row_begin) * W;
+  if (waves <= 0) return FC_OK;
+  hipLaunchKernelGGL(k_tfd_simbits, dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, ctx().stream,
+                     tf_dev, N, (int)Q, thresh, row_begin, row_end, bits_dev, W);
+  return check_launch("k_tfd_simbits");
+}
+
+}  // namespace fc

@@ -1,0 +1,183 @@
+// fc_torsion.hip -- torsion-scan conformer generation and torsion
+// fingerprints for gfx950 (wave64, float64).
+//
+// Replaces the inner loops of clustered_csearch / random_csearch
+// (firecode/torsion_module.py:812-856, 514-556): per angle-set apply the
+// non-zero dihedral rotations in order -- rotate_dihedral (prism_pruner.utils:
+// axis = x[i2]-x[i3], centre x[i3], matrix rot_mat_from_pointer(axis, angle))
+// -- test torsion_comp_check (torsion_module.py:894-918: any pair between the
+// rotating side `mask` and the rest minus {i2,i3} closer than thresh) and
+// back off in -5 degree steps, at most angle//5 times.
+//
+// One wavefront per angle-set: the conformer lives in the wave's LDS slice
+// (A*3 doubles); a rotation is lane-per-atom; a clash test flattens the
+// (rest x moving) rectangle over the 64 lanes and reduces with a ballot.
+#include "fc_common.h"
+
+namespace fc {
+
+double sq_threshold_lt(double t);  // fc_clash.hip
+
+// rot_mat_from_pointer: scalar-last quaternion [sin(a/2) n, cos(a/2)] -> matrix
+__device__ __forceinline__ void rot_from_axis_angle(double ax, double ay, double az,
+                                                    double angle_deg, double (&M)[9]) {
+  double a2 = angle_deg / 2.0;
+  a2 *= 3.141592653589793 / 180.0;
+  double sn, cs;
+  sincos(a2, &sn, &cs);
+  const double nrm = sqrt((ax * ax + ay * ay) + az * az);
+  const double q1 = sn * (ax / nrm), q2 = sn * (ay / nrm), q3 = sn * (az / nrm), q0 = cs;
+  M[0] = 2.0 * (q0 * q0 + q1 * q1) - 1.0;
+  M[1] = 2.0 * (q1 * q2 - q0 * q3);
+  M[2] = 2.0 * (q1 * q3 + q0 * q2);
+  M[3] = 2.0 * (q1 * q2 + q0 * q3);
+  M[4] = 2.0 * (q0 * q0 + q2 * q2) - 1.0;
+  M[5] = 2.0 * (q2 * q3 - q0 * q1);
+  M[6] = 2.0 * (q1 * q3 - q0 * q2);
+  M[7] = 2.0 * (q2 * q3 + q0 * q1);
+  M[8] = 2.0 * (q0 * q0 + q3 * q3) - 1.0;
+}
+
+// rotate the atoms flagged in `mv` (bit per atom, up to 4 words = 256 atoms)
+__device__ __forceinline__ void rotate_masked(double *x, int A, const uint8_t *mask, int i2, int i3,
+                                              double angle, int lane) {
+  const double cx = x[i3 * 3], cy = x[i3 * 3 + 1], cz = x[i3 * 3 + 2];
+  double M[9];
+  rot_from_axis_angle(x[i2 * 3] - cx, x[i2 * 3 + 1] - cy, x[i2 * 3 + 2] - cz, angle, M);
+  __builtin_amdgcn_wave_barrier();
+  for (int a = lane; a < A; a += 64) {
+    if (mask[a]) {
+      const double px = x[a * 3] - cx, py = x[a * 3 + 1] - cy, pz = x[a * 3 + 2] - cz;
+      x[a * 3] = ((M[0] * px + M[1] * py) + M[2] * pz) + cx;
+      x[a * 3 + 1] = ((M[3] * px + M[4] * py) + M[5] * pz) + cy;
+      x[a * 3 + 2] = ((M[6] * px + M[7] * py) + M[8] * pz) + cz;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// true when no (rest, moving) pair is closer than thresh (max_clashes = 0 is
+// the only value the reference ever passes: torsion_module.py:827,838)
+__device__ __forceinline__ bool comp_check(const double *x, const int16_t *mv, int nmv,
+                                           const int16_t *rs, int nrs, double thr2, int lane) {
+  bool hit = false;
+  const int total = nmv * nrs;
+  for (int p0 = 0; p0 < total; p0 += 64) {
+    const int p = p0 + lane;
+    if (p < total) {
+      const int r = rs[p / nmv], m = mv[p % nmv];
+      const double dx = x[r * 3] - x[m * 3], dy = x[r * 3 + 1] - x[m * 3 + 1],
+                   dz = x[r * 3 + 2] - x[m * 3 + 2];
+      const double d2 = ((dx * dx) + dy * dy) + dz * dz;
+      hit = hit || (d2 < thr2);
+    }
+    if (__any(hit)) return false;
+  }
+  return true;
+}
+
+
+__global__ void __launch_bounds__(256)
+k_torsion_scan(const double *__restrict__ base, int A, const int64_t *__restrict__ torsions, int T,
+               const uint8_t *__restrict__ rotmasks, const int16_t *__restrict__ mv_idx,
+               const int16_t *__restrict__ rs_idx, const int32_t *__restrict__ n_mv,
+               const int32_t *__restrict__ n_rs, const int64_t *__restrict__ angles, int64_t S,
+               double thr2, int backoff, double *__restrict__ out, int64_t *__restrict__ rotated) {
+  extern __shared__ double s[];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  double *x = s + (size_t)wv * A * 3;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t sidx = wave0; sidx < S; sidx += nwaves) {
+    for (int k = lane; k < A * 3; k += 64) x[k] = base[k];
+    __builtin_amdgcn_wave_barrier();
+    int rot = 0;
+    for (int t = 0; t < T; ++t) {
+      const int angle = (int)angles[sidx * T + t];
+      if (angle == 0) continue;
+      const int i2 = (int)torsions[t * 4 + 1], i3 = (int)torsions[t * 4 + 2];
+      const uint8_t *mask = rotmasks + (size_t)t * A;
+      const int16_t *mv = mv_idx + (size_t)t * A;
+      const int16_t *rs = rs_idx + (size_t)t * A;
+      const int nm = n_mv[t], nr = n_rs[t];
+      rotate_masked(x, A, mask, i2, i3, (double)angle, lane);
+      if (!comp_check(x, mv, nm, rs, nr, thr2, lane)) {
+        // Python floor division: range(angle // backoff)
+        int steps = angle / backoff;
+        if ((angle % backoff != 0) && ((angle < 0) != (backoff < 0))) --steps;
+        for (int b = 0; b < steps; ++b) {
+          rotate_masked(x, A, mask, i2, i3, (double)(-backoff), lane);
+          if (comp_check(x, mv, nm, rs, nr, thr2, lane)) {
+            ++rot;
+            break;
+          }
+        }
+      } else {
+        ++rot;
+      }
+    }
+    double *o = out + sidx * (int64_t)A * 3;
+    for (int k = lane; k < A * 3; k += 64) o[k] = x[k];
+    if (lane == 0) rotated[sidx] = rot;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// dihedral (prism_pruner.algebra.dihedral, "praxeolitic" form) per lane
+__device__ __forceinline__ double dihedral_deg(const double *p0, const double *p1, const double *p2,
+                                               const double *p3) {
+  const double b0x = -1.0 * (p1[0] - p0[0]), b0y = -1.0 * (p1[1] - p0[1]), b0z = -1.0 * (p1[2] - p0[2]);
+  double b1x = p2[0] - p1[0], b1y = p2[1] - p1[1], b1z = p2[2] - p1[2];
+  const double b2x = p3[0] - p2[0], b2y = p3[1] - p2[1], b2z = p3[2] - p2[2];
+  const double n1 = sqrt((b1x * b1x + b1y * b1y) + b1z * b1z);
+  b1x /= n1; b1y /= n1; b1z /= n1;
+  const double d0 = (b0x * b1x + b0y * b1y) + b0z * b1z;
+  const double d2 = (b2x * b1x + b2y * b1y) + b2z * b1z;
+  const double vx = b0x - d0 * b1x, vy = b0y - d0 * b1y, vz = b0z - d0 * b1z;
+  const double wx = b2x - d2 * b1x, wy = b2y - d2 * b1y, wz = b2z - d2 * b1z;
+  const double xx = (vx * wx + vy * wy) + vz * wz;
+  const double cx = b1y * vz - b1z * vy, cy = b1z * vx - b1x * vz, cz = b1x * vy - b1y * vx;
+  const double yy = (cx * wx + cy * wy) + cz * wz;
+  return atan2(yy, xx) * (180.0 / 3.141592653589793);
+}
+
+__global__ void __launch_bounds__(256)
+k_torsion_fingerprint(const double *__restrict__ coords, int64_t N, int64_t A,
+                      const int64_t *__restrict__ quads, int Q, double *__restrict__ tf) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N * Q) return;
+  const int64_t n = g / Q;
+  const int q = (int)(g % Q);
+  const double *x = coords + n * A * 3;
+  tf[g] = dihedral_deg(x + quads[q * 4] * 3, x + quads[q * 4 + 1] * 3, x + quads[q * 4 + 2] * 3,
+                       x + quads[q * 4 + 3] * 3);
+}
+
+// ---------------------------------------------------------------------------
+int launch_torsion_scan(const double *base_dev, int64_t A, const int64_t *torsions_dev, int64_t T,
+                        const uint8_t *rotmasks_dev, const int16_t *mv_dev, const int16_t *rs_dev,
+                        const int32_t *nmv_dev, const int32_t *nrs_dev, const int64_t *angles_dev,
+                        int64_t S, double thresh, int64_t backoff, double *out_dev,
+                        int64_t *rot_dev) {
+  if (S == 0) return FC_OK;
+  const double thr2 = sq_threshold_lt(thresh);
+  int64_t blocks = ceil_div(S, 4);
+  const int64_t cap = (int64_t)ctx().n_cu * 32;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_torsion_scan, dim3((unsigned)blocks), dim3(256),
+                     (size_t)4 * A * 3 * sizeof(double), ctx().stream, base_dev, (int)A,
+                     torsions_dev, (int)T, rotmasks_dev, mv_dev, rs_dev, nmv_dev, nrs_dev,
+                     angles_dev, S, thr2, (int)backoff, out_dev, rot_dev);
+  return check_launch("k_torsion_scan");
+}
+
+int launch_torsion_fingerprint(const double *coords_dev, int64_t N, int64_t A,
+                               const int64_t *quads_dev, int64_t Q, double *tf_dev) {
+  if (N * Q == 0) return FC_OK;
+  hipLaunchKernelGGL(k_torsion_fingerprint, dim3((unsigned)ceil_div(N * Q, 256)), dim3(256), 0,
+                     ctx().stream, coords_dev, N, A, quads_dev, (int)Q, tf_dev);
+  return check_launch("k_torsion_fingerprint");
+}
+
+}  // namespace fc

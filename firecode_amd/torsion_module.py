@@ -1,0 +1,107 @@
+"""Drop-in for the numeric names of ``firecode.torsion_module``."""
+
+import numpy as np
+
+from firecode_amd import _lib as L
+
+
+def torsion_scan(base, torsions, masks, angles, thresh=1.5, backoff=5):
+    """Inner loops of ``clustered_csearch`` (firecode/torsion_module.py:812-856)
+    for one starting structure: every row of ``angles`` (S, T) is applied to
+    ``base`` (A, 3) with the clash test and the 5-degree back-off.
+    Returns (coords (S, A, 3), rotated_bonds (S,))."""
+    base = L.f64(base)
+    tors = L.i64(torsions).reshape(-1, 4)
+    msk = L.u8(np.asarray(masks, dtype=bool)).reshape(tors.shape[0], -1)
+    ang = L.i64(angles).reshape(-1, tors.shape[0])
+    A, T, S = base.shape[0], tors.shape[0], ang.shape[0]
+    if base.ndim != 2 or base.shape[1] != 3 or msk.shape[1] != A:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "base must be (A, 3) and masks (T, A)")
+    out = np.empty((S, A, 3))
+    rot = np.zeros(S, dtype=np.int64)
+    L.call("fc_torsion_scan", L.pf(base), A, L.pi(tors), T, L.pb(msk), L.pi(ang), S, float(thresh),
+           int(backoff), L.pf(out), L.pi(rot))
+    return out, rot
+
+
+def torsion_comp_check(coords, torsion, mask, thresh=1.5, max_clashes=0):
+    """firecode/torsion_module.py:894-918: rest-vs-moving clash count <= max_clashes."""
+    X = L.f64(coords)
+    mask = np.asarray(mask, dtype=bool)
+    _, i2, i3, _ = torsion
+    anti = ~mask
+    anti[i2] = False
+    anti[i3] = False
+    # fragment form: [moving | rest] contiguous, bimolecular strict-< count
+    packed = np.concatenate([X[mask], X[anti]])[None]
+    if packed.shape[1] == 0 or mask.sum() == 0 or anti.sum() == 0:
+        return True
+    ok = np.zeros(1, dtype=np.uint8)
+    ids = np.array([int(mask.sum()), int(anti.sum())], dtype=np.int64)
+    L.call("fc_clash_fragments", L.pf(L.f64(packed)), 1, packed.shape[1], L.pi(ids), 2, float(thresh),
+           int(max_clashes), None, L.pb(ok))
+    return bool(ok[0])
+
+
+def get_tf_mat(structures, quadruplets):
+    """firecode/torsion_module.py:1046-1053 (``_get_tf_mat``), batched."""
+    X = L.f64(structures)
+    quads = L.i64(quadruplets).reshape(-1, 4)
+    out = np.zeros((X.shape[0], quads.shape[0]))
+    L.call("fc_torsion_fingerprint", L.pf(X), X.shape[0], X.shape[1], L.pi(quads), quads.shape[0], L.pf(out))
+    return out
+
+
+def get_torsion_fingerprint(coords, quadruplets):
+    """firecode/torsion_module.py:1070-1076."""
+    return get_tf_mat(L.f64(coords)[None], quadruplets)[0]
+
+
+def tfd_simbits(tf_mat, thresh=10, row_begin=0, row_end=None):
+    tf = L.f64(tf_mat)
+    N, Q = tf.shape
+    row_end = N if row_end is None else row_end
+    W = (N + 63) // 64
+    bits = np.zeros((row_end - row_begin, W), dtype=np.uint64)
+    L.call("fc_tfd_simbits", L.pf(tf), N, Q, float(thresh), row_begin, row_end, L.pw(bits))
+    return bits
+
+
+def tfd_similarity(tfp1, tfp2, thresh=10):
+    """firecode/torsion_module.py:1056-1067."""
+    tf = np.stack([L.f64(tfp1), L.f64(tfp2)])
+    bits = tfd_simbits(tf, thresh, 0, 1)
+    return bool((int(bits[0, 0]) >> 1) & 1)
+
+
+def prune_conformers_tfd(structures, quadruplets, thresh=10, verbose=False):
+    """firecode/torsion_module.py:957-1043.  Fingerprints and the N x N TFD
+    similarity bits are computed on the GPU; the first-match / connected-
+    component bookkeeping of the reference (networkx, `group[0]` kept) is
+    replayed on the host over the bit rows."""
+    from networkx import Graph, connected_components
+
+    structures = L.f64(structures)
+    n = structures.shape[0]
+    tf_mat = get_tf_mat(structures, quadruplets)
+    sim = L.unpack_bits(tfd_simbits(tf_mat, thresh), n) if n else np.zeros((0, 0), dtype=bool)
+    final_mask = np.ones(n, dtype=bool)
+    for k in (5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1):
+        num_active_str = np.count_nonzero(final_mask)
+        if k == 1 or 5 * k < num_active_str:
+            d = int(n // k)
+            for step in range(int(k)):
+                lo = d * step
+                _l = len(range(lo, num_active_str)) if step == k - 1 else len(range(lo, int(d * (step + 1))))
+                if _l <= 1:
+                    continue
+                sub = np.triu(sim[lo:lo + _l, lo:lo + _l], 1)
+                rows = np.flatnonzero(sub.any(axis=1))
+                # first similar j > i per row (the cache only skips known-dissimilar pairs)
+                matches = set((int(i), int(sub[i].argmax())) for i in rows)
+                g = Graph(matches)
+                for c in connected_components(g):
+                    group = tuple(g.subgraph(c).nodes)
+                    for i in set(group) - {group[0]}:
+                        final_mask[i + lo] = 0
+    return structures[final_mask], final_mask

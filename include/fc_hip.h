@@ -1,0 +1,188 @@
+/* fc_hip.h -- C ABI of libfc_hip.so: the MI355X (gfx950) ensemble-geometry
+ * hot path of FIRECODE behind plain pointers and sizes.
+ *
+ * The reference (ntampellini/FIRECODE v2.0.4, paths relative to
+ * /root/reference) has no FFI: its hot path is NumPy/SciPy calls made from
+ * Python.  Each entry point below names the reference call it replaces; the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md and lives
+ * in firecode_amd/_lib.py.
+ *
+ * Conventions
+ *   - every pointer is a HOST pointer to a caller-owned buffer unless the
+ *     parameter name ends in _dev; coordinates are float64, C-order
+ *     (N, A, 3) -- firecode/typing_.py:6-8; masks are 1 byte per element
+ *     (np.bool_, typing_.py:12); index arrays are int64.
+ *   - return value: 0 = OK, < 0 = error (FC_E_*); the message is kept per
+ *     thread and read with fc_last_error().  No exceptions, no callbacks and
+ *     no stdout writes cross this boundary.  Calls block until results are in
+ *     the output buffers.
+ *   - the HIP context is created lazily, per process, on the first call
+ *     (the reference may call from spawn()ed pool workers, embedder.py:116).
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute
+ *     entry point returns FC_E_NODEVICE.
+ */
+#ifndef FC_HIP_H
+#define FC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FC_OK 0
+#define FC_E_INVALID (-1)   /* bad argument (shape, NULL, range)              */
+#define FC_E_NODEVICE (-2)  /* no HIP device / HIP runtime error at init      */
+#define FC_E_HIP (-3)       /* HIP runtime error (message has the hipError)   */
+#define FC_E_NOMEM (-4)     /* device allocation failed                       */
+#define FC_E_LIMIT (-5)     /* size outside what a kernel supports            */
+
+/* ---- lifecycle --------------------------------------------------------- */
+int fc_abi_version(void);
+int fc_device_count(void);
+int fc_init(int device);
+int fc_shutdown(void);
+const char *fc_last_error(void);
+/* name, CU count and bytes of HBM of the active device (diagnostics) */
+int fc_device_info(char *name, int64_t name_len, int64_t *n_cu, int64_t *hbm_bytes);
+
+/* ---- resident ensemble -------------------------------------------------
+ * Uploads (N, A, 3) coordinates once and keeps the prepared layout in HBM:
+ * the atoms selected by atom_mask (NULL = all; the "heavy atoms" of
+ * prism_pruner's RMSD pruner), optionally centred on their centroid, stored
+ * conformer-minor  Xs[(a*3+c)*Npad + n]  so that a wavefront reads 64
+ * conformers of one coordinate with one coalesced 512-byte load, plus
+ * G[n] = sum |x|^2.  Everything below that takes an fc_ensemble works on
+ * HBM-resident data only. */
+typedef struct fc_ensemble fc_ensemble;
+int fc_ensemble_create(const double *coords, int64_t N, int64_t A, const uint8_t *atom_mask,
+                       int center, fc_ensemble **out);
+int fc_ensemble_destroy(fc_ensemble *ens);
+int fc_ensemble_shape(const fc_ensemble *ens, int64_t *N, int64_t *A_selected);
+
+/* ---- a4: rmsd_and_max(p, q, center) -- prism_pruner.rmsd; call sites
+ * firecode/utils.py:499, embedder.py:1784, ase_manipulations.py:1384.
+ * P pairs (pair_i[k], pair_j[k]) of one coordinate block. */
+int fc_kabsch_rmsd_pairs(const double *coords, int64_t N, int64_t A, const uint8_t *atom_mask,
+                         const int64_t *pair_i, const int64_t *pair_j, int64_t P, int center,
+                         double *rmsd_out, double *maxdev_out);
+/* same over a resident ensemble */
+int fc_ensemble_rmsd_pairs(fc_ensemble *ens, const int64_t *pair_i, const int64_t *pair_j,
+                           int64_t P, double *rmsd_out, double *maxdev_out);
+/* all pairs: rmsd_out / maxdev_out are (N, N) row-major, symmetric, 0 diagonal */
+int fc_ensemble_rmsd_matrix(fc_ensemble *ens, double *rmsd_out, double *maxdev_out);
+/* a9: get_alignment_matrix(p, q) -- prism_pruner.rmsd; call site
+ * hypermolecule_class.py:77.  M (3,3) row-major, applied as (M @ q.T).T */
+int fc_alignment_matrices(const double *p, const double *q, int64_t n_pairs, int64_t A,
+                          double *M_out);
+
+/* ---- a5: prune_by_rmsd(structures, atoms, max_rmsd, energies=, max_dE=)
+ * -- prism_pruner.pruner; call sites firecode/ensemble.py:230-235,
+ * embedder.py:1472-1474, operators.py:619-624.
+ *
+ * fc_rmsd_simbits: similarity bits of rows [row_begin,row_end) against all
+ * later conformers: bit j of row i (j > i) = rmsd(i,j) < max_rmsd &&
+ * maxdev(i,j) < max_dev [&& |E_i-E_j| < max_dE when energies != NULL].
+ * bits_out: (row_end-row_begin) rows of W = ceil(N/64) uint64 words.
+ * n_grey (may be NULL): pairs within 1e-9 of either threshold.
+ *
+ * fc_prune_rmsd: the whole stage on the GPU -- similarity bits, then the
+ * k-ladder greedy replay -- conformers taken in the order given (the host
+ * pre-sorts by energy as the reference does).  mask_out: N bytes.
+ * stats (may be NULL): [0]=pairs evaluated, [1]=candidate pairs refined,
+ * [2]=similar pairs, [3]=grey pairs, [4]=ladder levels run, [5]=survivors. */
+int fc_rmsd_simbits(fc_ensemble *ens, double max_rmsd, double max_dev, const double *energies,
+                    double max_dE, int64_t row_begin, int64_t row_end, uint64_t *bits_out,
+                    int64_t *n_grey);
+int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const double *energies,
+                  double max_dE, int64_t min_per_group, uint8_t *mask_out, int64_t *stats);
+/* greedy k-ladder replay over caller-supplied bits (N rows x ceil(N/64) words) */
+int fc_greedy_prune_from_bits(const uint64_t *bits, int64_t N, int64_t min_per_group,
+                              uint8_t *mask_out);
+
+/* sharded form (conformer rows dealt block-cyclically to ranks):
+ * fc_prune_rmsd_begin computes this rank's rows of the bit matrix;
+ * fc_prune_level applies one ladder level to this rank's rows given the
+ * GLOBAL mask of the previous level (mask_in, N bytes) and returns the rows'
+ * new flags in mask_out (N bytes, only owned rows written, others copied
+ * from mask_in) -- the caller all-gathers between levels. */
+int fc_prune_rmsd_begin(fc_ensemble *ens, double max_rmsd, double max_dev,
+                        const double *energies, double max_dE, int64_t rank, int64_t world,
+                        int64_t row_block, int64_t *stats);
+int fc_prune_level(fc_ensemble *ens, int64_t k, const uint8_t *mask_in, uint8_t *mask_out);
+
+/* ---- a6: prune_by_moment_of_inertia -- prism_pruner.pruner; call sites
+ * firecode/ensemble.py:211-216, embedder.py:1452-1454.
+ * fc_inertia_moments: get_inertia_moments(coords, masses) for N conformers,
+ * moments_out (N,3) ascending. */
+int fc_inertia_moments(const double *coords, int64_t N, int64_t A, const double *masses,
+                       double *moments_out);
+int fc_prune_moi(const double *coords, int64_t N, int64_t A, const double *masses,
+                 double max_deviation, const double *energies, double max_dE,
+                 int64_t min_per_group, uint8_t *mask_out);
+
+/* ---- a8: align_structures(structures, indices) -- prism_pruner.utils;
+ * call sites embedder.py:1704,1910,2218,2300; operators.py:262.
+ * out (N,A,3): every conformer superposed on conformer 0 using the n_idx
+ * atoms in idx (NULL = all). */
+int fc_align_to_first(const double *coords, int64_t N, int64_t A, const int64_t *idx,
+                      int64_t n_idx, double *out);
+
+/* ---- a13: get_embed -- firecode/embeds.py:808-817: out[k] = (R_k @ X_k.T).T + t_k
+ * for n blocks of A atoms (R (n,3,3), t (n,3)). */
+int fc_rototranslate(const double *coords, int64_t n, int64_t A, const double *R,
+                     const double *t, double *out);
+
+/* ---- a11/a12: count_clashes (firecode/algebra.py:52-54) and
+ * compenetration_check (firecode/utils.py:507-575), batched over N structures.
+ * fc_clash_self: ordered pairs with lo < d < hi (reference: 0 < d < 0.5).
+ * fc_clash_fragments: ids = fragment lengths (2 or 3 entries); bimolecular
+ * counts d < thresh, trimolecular counts d <= thresh cumulatively over
+ * (m2,m1),(m3,m2),(m1,m3); pass_out[n] = 1 when within max_clashes. */
+int fc_clash_self(const double *coords, int64_t N, int64_t A, double lo, double hi,
+                  int64_t *counts_out);
+int fc_clash_fragments(const double *coords, int64_t N, int64_t A, const int64_t *ids,
+                       int64_t n_ids, double thresh, int64_t max_clashes,
+                       int64_t *counts_out, uint8_t *pass_out);
+
+/* ---- a14: bimolecular rigid embed poses -- firecode/embeds.py:713-722:
+ * pose k uses conformer c1[k] of m1 (n1,A1,3) moved by (R1[k], t1[k]) and
+ * conformer c2[k] of m2 (n2,A2,3) moved by (R2[k], t2[k]); counts atom pairs
+ * closer than thresh (strict <) without materialising the pose;
+ * pass_out[k] = count <= max_clashes.  poses_out (may be NULL): (P, A1+A2, 3). */
+int fc_embed_poses_clash(const double *m1, int64_t n1, int64_t A1, const double *m2,
+                         int64_t n2, int64_t A2, const int64_t *c1, const int64_t *c2,
+                         const double *R1, const double *t1, const double *R2,
+                         const double *t2, int64_t P, double thresh, int64_t max_clashes,
+                         int64_t *counts_out, uint8_t *pass_out, double *poses_out);
+
+/* ---- a17-a19: torsion scan -- firecode/torsion_module.py:812-856
+ * (clustered_csearch inner loops) with rotate_dihedral (prism_pruner.utils)
+ * and torsion_comp_check (torsion_module.py:894-918).
+ * base (A,3); torsions (T,4) int64; rotmasks (T,A) bytes; angles (S,T) int64
+ * degrees.  coords_out (S,A,3); rotated_bonds_out (S) int64. */
+int fc_torsion_scan(const double *base, int64_t A, const int64_t *torsions, int64_t T,
+                    const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
+                    int64_t backoff_deg, double *coords_out, int64_t *rotated_bonds_out);
+
+/* ---- a20: torsion fingerprints and TFD similarity bits --
+ * firecode/torsion_module.py:1046-1076.
+ * tf_out (N,Q) degrees in (-180,180].  fc_tfd_simbits: bit j of row i (all
+ * j != i) = sum |wrap(tf_i - tf_j)| < thresh; rows [row_begin,row_end). */
+int fc_torsion_fingerprint(const double *coords, int64_t N, int64_t A, const int64_t *quads,
+                           int64_t Q, double *tf_out);
+int fc_tfd_simbits(const double *tf, int64_t N, int64_t Q, double thresh, int64_t row_begin,
+                   int64_t row_end, uint64_t *bits_out);
+
+/* ---- bench / profiling hooks (resident data, device-side timing) --------
+ * Runs the all-pairs similarity stage + greedy replay `reps` times on the
+ * resident ensemble and returns HIP-event times (ms, per rep) of the
+ * dominant kernel and of the whole step measured on the library's stream. */
+int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
+                        double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
+                        int64_t *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FC_HIP_H */

@@ -719,55 +719,3 @@ def ensemble_from_xyz_text(text):
         except StopIteration:
             pass
     return np.array(atoms[0]), np.array(coords)
-
-
-# --------------------------------------------------------------------------
-# synthetic workloads -- shared by tests and bench
-# --------------------------------------------------------------------------
-def _random_rotation(rng):
-    q, r = np.linalg.qr(rng.normal(size=(3, 3)))
-    q = q * np.sign(np.diag(r))
-    if np.linalg.det(q) < 0:
-        q[:, 0] = -q[:, 0]
-    return q
-
-
-def synthetic_skeleton(n_atoms, rng, bond=1.5, min_dist=1.2):
-    """Self-avoiding random walk, bond 1.5 A, no atom closer than 1.2 A."""
-    pts = [np.zeros(3)]
-    while len(pts) < n_atoms:
-        for _ in range(1000):
-            d = rng.normal(size=3)
-            cand = pts[-1] + bond * d / np.linalg.norm(d)
-            if np.min(np.linalg.norm(np.array(pts) - cand, axis=1)) >= min_dist:
-                pts.append(cand)
-                break
-        else:  # dead end: restart
-            pts = [np.zeros(3)]
-    return np.array(pts)
-
-
-def synthetic_ensemble(n_conf, n_atoms, seed, cluster_size=5, sigma_cluster=0.6, sigma_conf=0.03):
-    """Clustered synthetic ensemble of SURVEY.md section 8d: K = n_conf /
-    cluster_size cluster centres (skeleton + N(0, 0.6^2)), members = centre +
-    N(0, 0.03^2), shuffled, each given a random proper rotation and a
-    translation N(0, 5^2).  Returns (coords (N,A,3), atoms (A,) all 'C',
-    cluster id per conformer)."""
-    rng = np.random.default_rng(seed)
-    skel = synthetic_skeleton(n_atoms, rng)
-    K = max(1, n_conf // cluster_size)
-    centres = np.empty((K, n_atoms, 3))
-    for k in range(K):
-        while True:
-            c = skel + rng.normal(scale=sigma_cluster, size=skel.shape)
-            d = cdist(c, c)
-            d[np.diag_indices(n_atoms)] = 10.0
-            if d.min() >= 0.5:
-                centres[k] = c
-                break
-    assign = np.arange(n_conf) % K
-    rng.shuffle(assign)
-    coords = centres[assign] + rng.normal(scale=sigma_conf, size=(n_conf, n_atoms, 3))
-    for i in range(n_conf):
-        coords[i] = coords[i] @ _random_rotation(rng).T + rng.normal(scale=5.0, size=3)
-    return np.ascontiguousarray(coords), np.array(["C"] * n_atoms), assign

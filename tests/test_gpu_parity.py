@@ -1,0 +1,336 @@
+"""GPU parity tests: every HIP path against the oracle on the same seeded
+inputs, through the C ABI (firecode_amd -> ctypes -> libfc_hip.so).
+
+Bars (BASELINE.json north_star): integer / boolean results bit-exact;
+RMSD, max deviation and coordinates within 1e-10.
+"""
+
+import numpy as np
+import pytest
+
+from firecode_amd import synthetic as syn
+from oracle import cpu_ref as o
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def _rot(rng):
+    return syn.random_rotation(rng)
+
+
+# ---------------------------------------------------------------- a4 / a9
+def test_rmsd_and_max_pairs(fc):
+    X, atoms, _ = syn.synthetic_ensemble(120, 50, seed=3)
+    iu, ju = np.triu_indices(len(X), 1)
+    r, m = fc.rmsd.rmsd_and_max_batch(X, iu, ju, center=True)
+    r0, m0 = o.rmsd_and_max_batch(X[iu], X[ju], center=True)
+    assert np.abs(r - r0).max() < TOL
+    # similar pairs have a well-conditioned optimum: max deviation to 1e-10
+    close = r0 < 1.0
+    assert close.sum() > 50
+    assert np.abs(m - m0)[close].max() < TOL
+    assert np.abs(m - m0).max() < 1e-8
+
+
+def test_rmsd_and_max_single_no_center(fc):
+    rng = np.random.default_rng(5)
+    p = rng.normal(size=(33, 3))
+    q = p @ _rot(rng).T + 0.01 * rng.normal(size=p.shape)
+    for center in (False, True):
+        r, m = fc.rmsd.rmsd_and_max(p, q, center=center)
+        r0, m0 = o.rmsd_and_max(p, q, center=center)
+        assert abs(r - r0) < TOL and abs(m - m0) < TOL
+    # identical structures, pure rotation about the origin
+    r, m = fc.rmsd.rmsd_and_max(p, p @ _rot(rng).T)
+    assert r < 1e-12 and m < 1e-12
+
+
+def test_rmsd_matrix(fc):
+    X, atoms, _ = syn.synthetic_ensemble(200, 30, seed=4)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        R, D = ens.rmsd_matrix()
+    S0, R0, D0 = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    assert np.abs(R - R0).max() < TOL
+    assert np.allclose(R, R.T) and np.all(np.diag(R) == 0)
+    assert np.abs(D - D0)[R0 < 1.0].max() < TOL
+
+
+def test_heavy_atom_mask(fc):
+    X, _, _ = syn.synthetic_ensemble(40, 24, seed=6)
+    atoms = np.array(["C", "H", "H", "O"] * 6)
+    hv = atoms != "H"
+    iu, ju = np.triu_indices(len(X), 1)
+    r, m = fc.rmsd.rmsd_and_max_batch(X, iu, ju, center=True, atom_mask=hv)
+    r0, m0 = o.rmsd_and_max_batch(X[iu][:, hv], X[ju][:, hv], center=True)
+    assert np.abs(r - r0).max() < TOL
+
+
+def test_alignment_matrix_and_align_vec_pair(fc, golden):
+    rng = np.random.default_rng(8)
+    P = rng.normal(size=(50, 20, 3))
+    Q = np.array([p @ _rot(rng).T for p in P]) + 0.05 * rng.normal(size=P.shape)
+    M = fc.rmsd.get_alignment_matrices(P, Q)
+    M0 = np.array([o.get_alignment_matrix(p, q) for p, q in zip(P, Q)])
+    assert np.abs(M - M0).max() < TOL
+    assert np.abs(np.linalg.det(M) - 1).max() < 1e-12
+    # in-tree twin, against the reference's own outputs (rank-2 cases)
+    out = fc.algebra.align_vec_pair_batch(golden["avp_ref"], golden["avp_tgt"])
+    ok = np.ones(len(out), dtype=bool)
+    ok[8:12] = False  # rank-1 covariance: rotation not unique
+    assert np.abs(out - golden["avp_out"])[ok].max() < TOL
+    one = fc.algebra.align_vec_pair(golden["avp_ref"][20], golden["avp_tgt"][20])
+    assert np.abs(one - golden["avp_out"][20]).max() < TOL
+
+
+def test_align_structures(fc):
+    X, atoms, _ = syn.synthetic_ensemble(30, 25, seed=9)
+    out = fc.utils.align_structures(X)
+    assert np.abs(out - o.align_structures(X)).max() < TOL
+    idx = np.array([0, 3, 5, 8, 13, 21])
+    out = fc.utils.align_structures(X, idx)
+    assert np.abs(out - o.align_structures(X, idx)).max() < TOL
+
+
+# ---------------------------------------------------------------- a5 / a6
+@pytest.mark.parametrize("n,a,seed", [(64, 12, 1), (257, 30, 2), (600, 50, 3), (1000, 17, 4)])
+def test_prune_by_rmsd_mask_bit_exact(fc, n, a, seed):
+    X, atoms, asg = syn.synthetic_ensemble(n, a, seed=seed)
+    S0, R0, D0 = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    assert np.abs(R0[R0 > 0] - 0.5).min() > 1e-6  # generator keeps pairs off the threshold
+    ref_mask = o.greedy_prune_from_matrix(S0)
+    pruned, mask = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    assert mask.dtype == np.bool_ and mask.shape == (n,)
+    assert np.array_equal(mask, ref_mask)
+    assert np.array_equal(pruned, X[mask])
+    assert mask.sum() == len(np.unique(asg))
+
+
+def test_prune_by_rmsd_literal_oracle_small(fc):
+    """against the literal (sequential, cached) restatement, not the matrix form"""
+    X, atoms, _ = syn.synthetic_ensemble(150, 20, seed=12)
+    _, ref = o.prune_by_rmsd(X, atoms, 0.5)
+    _, mask = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    assert np.array_equal(mask, ref)
+
+
+def test_simbits_match_oracle_matrix(fc):
+    X, atoms, _ = syn.synthetic_ensemble(300, 40, seed=13)
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        bits, grey = ens.simbits(0.5, 1.0)
+    from firecode_amd._lib import unpack_bits
+
+    S = unpack_bits(bits, len(X))
+    assert np.array_equal(S, np.triu(S0, 1))
+    assert grey == 0
+
+
+def test_prune_with_energies(fc):
+    X, atoms, _ = syn.synthetic_ensemble(300, 20, seed=14)
+    rng = np.random.default_rng(14)
+    en = rng.uniform(0, 3, size=len(X))
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0, energies=en, max_dE=1.0)
+    _, mask = fc.pruner.prune_by_rmsd(X, atoms, 0.5, energies=en, max_dE=1.0)
+    assert np.array_equal(mask, ref)
+
+
+def test_prune_edge_cases(fc):
+    atoms = np.array(["C"] * 7)
+    # empty ensemble
+    p, m = fc.pruner.prune_by_rmsd(np.zeros((0, 7, 3)), atoms, 0.5)
+    assert p.shape == (0, 7, 3) and m.shape == (0,)
+    # single structure
+    X = np.random.default_rng(0).normal(size=(1, 7, 3))
+    p, m = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    assert m.tolist() == [True]
+    # all identical up to rigid motion: the last one survives
+    rng = np.random.default_rng(1)
+    base = rng.normal(scale=2.0, size=(7, 3))
+    X = np.array([base @ _rot(rng).T + rng.normal(size=3) for _ in range(70)])
+    _, m = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    _, ref = o.prune_by_rmsd(X, atoms, 0.5)
+    assert np.array_equal(m, ref) and m.sum() == 1 and m[-1]
+    # all distinct
+    X = rng.normal(scale=3.0, size=(65, 7, 3))
+    _, m = fc.pruner.prune_by_rmsd(X, atoms, 0.05)
+    assert m.all()
+
+
+def test_greedy_from_bits(fc):
+    rng = np.random.default_rng(3)
+    n = 700
+    S = np.triu(rng.random((n, n)) < 0.002, 1)
+    W = (n + 63) // 64
+    padded = np.zeros((n, W * 64), dtype=np.uint8)
+    padded[:, :n] = S
+    bits = np.packbits(padded, axis=1, bitorder="little").view(np.uint64)
+    mask = fc.pruner.greedy_prune_from_bits(bits, n)
+    assert np.array_equal(mask, o.greedy_prune_from_matrix(S | S.T))
+
+
+def test_moments_and_moi_prune(fc):
+    X, atoms, _ = syn.synthetic_ensemble(260, 22, seed=15)
+    atoms = np.array((["C", "H", "N", "O", "H"] * 5)[:22])
+    masses = np.array([o.MASSES_TABLE[a] for a in atoms])
+    mom = fc.algebra.get_inertia_moments_batch(X, masses)
+    mom0 = np.array([o.get_inertia_moments(x, masses) for x in X])
+    assert np.abs(mom - mom0).max() < 1e-9 * mom0.max()
+    _, ref = o.prune_by_moment_of_inertia(X, atoms)
+    _, mask = fc.pruner.prune_by_moment_of_inertia(X, atoms)
+    assert np.array_equal(mask, ref)
+    assert 0 < mask.sum() < len(mask)
+
+
+# ---------------------------------------------------------------- a11 / a12 / a13
+def test_count_clashes_golden(fc, golden):
+    out = fc.algebra.count_clashes_batch(golden["cc_in"])
+    assert np.array_equal(out, golden["cc_out"])
+    assert fc.algebra.count_clashes(golden["cc_in"][0]) == golden["cc_out"][0]
+
+
+def test_compenetration_check_golden(fc, golden):
+    cp = golden["cp_in"]
+    assert np.array_equal(fc.utils.compenetration_check_batch(cp), golden["cp_none"])
+    assert np.array_equal(fc.utils.compenetration_check_batch(cp, max_clashes=2), golden["cp_none_mc2"])
+    for thr in (1.0, 1.5):
+        for mc in (0, 3):
+            bi = fc.utils.compenetration_check_batch(cp, ids=[20, 16], thresh=thr, max_clashes=mc)
+            tri = fc.utils.compenetration_check_batch(cp, ids=[12, 14, 10], thresh=thr, max_clashes=mc)
+            assert np.array_equal(bi, golden[f"cp_bi_{thr}_{mc}"])
+            assert np.array_equal(tri, golden[f"cp_tri_{thr}_{mc}"])
+    assert fc.utils.compenetration_check(cp[3], ids=[20, 16], thresh=1.5) == bool(golden["cp_bi_1.5_0"][3])
+
+
+def test_clash_threshold_ties(fc):
+    """distances exactly at / next to the threshold decide like cdist does"""
+    thr = 1.5
+    xs = [thr, np.nextafter(thr, 0), np.nextafter(thr, 9), 0.3 * 5, 1.4999999999999998]
+    coords = np.array([[[0, 0, 0], [x, 0, 0]] for x in xs] +
+                      [[[0.1, 0.2, 0.3], [0.1 + x / np.sqrt(3), 0.2 + x / np.sqrt(3), 0.3 + x / np.sqrt(3)]] for x in xs])
+    for ids, kw in (([1, 1], {}),):
+        got = fc.utils.compenetration_check_batch(coords, ids=ids, thresh=thr)
+        ref = [o.compenetration_check(c, ids=ids, thresh=thr) for c in coords]
+        assert np.array_equal(got, ref)
+    tri = np.concatenate([coords, coords[:, :1] + 50.0], axis=1)
+    got = fc.utils.compenetration_check_batch(tri, ids=[1, 1, 1], thresh=thr)
+    ref = [o.compenetration_check(c, ids=[1, 1, 1], thresh=thr) for c in tri]
+    assert np.array_equal(got, ref)
+
+
+def test_get_embed_and_rototranslate(fc, golden):
+    class Mol:
+        pass
+
+    m1, m2 = Mol(), Mol()
+    m1.coords, m2.coords = golden["ge_c1"], golden["ge_c2"]
+    for R, t, ids, exp in zip(golden["ge_R"], golden["ge_t"], golden["ge_ids"], golden["ge_out"]):
+        m1.rotation, m1.position = R[0], t[0]
+        m2.rotation, m2.position = R[1], t[1]
+        out = fc.embeds.get_embed([m1, m2], ids)
+        assert np.abs(out - exp).max() < TOL
+
+
+def test_embed_poses_clash(fc):
+    rng = np.random.default_rng(21)
+    m1 = rng.normal(scale=2.0, size=(6, 40, 3))
+    m2 = rng.normal(scale=2.0, size=(5, 37, 3))
+    P = 500
+    c1, c2 = rng.integers(0, 6, P), rng.integers(0, 5, P)
+    R1 = np.array([_rot(rng) for _ in range(P)])
+    R2 = np.array([_rot(rng) for _ in range(P)])
+    t1 = rng.normal(scale=1.0, size=(P, 3))
+    t2 = t1 + rng.normal(scale=4.0, size=(P, 3))
+    ok, counts, poses = fc.embeds.embed_poses_clash(m1, m2, c1, c2, R1, t1, R2, t2, thresh=1.5,
+                                                    max_clashes=0, return_poses=True)
+    ref_pose = np.array([o.get_embed([m1[a], m2[b]], [ra, rb], [ta, tb])
+                         for a, b, ra, rb, ta, tb in zip(c1, c2, R1, R2, t1, t2)])
+    assert np.abs(poses - ref_pose).max() < TOL
+    ref_ok = np.array([o.compenetration_check(p, ids=[40, 37], thresh=1.5) for p in ref_pose])
+    assert np.array_equal(ok, ref_ok)
+    assert 0 < ok.sum() < P
+    ok2, counts2 = fc.embeds.embed_poses_clash(m1, m2, c1, c2, R1, t1, R2, t2, thresh=1.5, max_clashes=4)
+    ref_ok2 = np.array([o.compenetration_check(p, ids=[40, 37], thresh=1.5, max_clashes=4) for p in ref_pose])
+    assert np.array_equal(ok2, ref_ok2) and np.array_equal(counts, counts2)
+
+
+# ---------------------------------------------------------------- a17 - a20
+def _chain_case(n_atoms, n_tors, seed):
+    """zig-zag chain with side atoms; torsions about backbone bonds, mask = the
+    atoms after the bond (what _get_rotation_mask returns for a chain)."""
+    rng = np.random.default_rng(seed)
+    skel = syn.synthetic_skeleton(n_atoms, rng)
+    centres = np.linspace(2, n_atoms - 4, n_tors).astype(int)
+    torsions, masks = [], []
+    for c in centres:
+        torsions.append((c - 1, c, c + 1, c + 2))
+        m = np.zeros(n_atoms, dtype=bool)
+        m[c + 2:] = True
+        masks.append(m)
+    return skel, np.array(torsions), np.array(masks)
+
+
+def test_torsion_scan_vs_oracle(fc):
+    base, tors, masks = _chain_case(30, 4, seed=31)
+    angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 4)[::5]
+    out, rot = fc.torsion_module.torsion_scan(base, tors, masks, angles, thresh=1.5)
+    out0, rot0 = o.torsion_scan(base, tors, masks, angles, thresh=1.5)
+    assert np.array_equal(rot, rot0)
+    assert np.abs(out - out0).max() < TOL
+    assert (rot0 < (angles != 0).sum(axis=1)).any()  # some back-off / failed rotations happened
+
+
+def test_rotate_dihedral_and_comp_check(fc, golden):
+    base, tors, masks = _chain_case(20, 2, seed=32)
+    new = fc.utils.rotate_dihedral(base, tors[0], 120, mask=masks[0])
+    assert np.abs(new - o.rotate_dihedral(base, tors[0], 120, masks[0])).max() < TOL
+    out = [fc.torsion_module.torsion_comp_check(c, tuple(t), m.copy()) for c, t, m in
+           zip(golden["tc_in"], golden["tc_tors"], golden["tc_mask"])]
+    assert np.array_equal(out, golden["tc_out"])
+    out = [fc.torsion_module.torsion_comp_check(c, tuple(t), m.copy(), max_clashes=2) for c, t, m in
+           zip(golden["tc_in"][:20], golden["tc_tors"][:20], golden["tc_mask"][:20])]
+    assert np.array_equal(out, golden["tc_out_mc2"][:20])
+
+
+def test_fingerprints_and_tfd(fc, golden):
+    rng = np.random.default_rng(33)
+    X = rng.normal(scale=2.0, size=(50, 16, 3))
+    quads = np.array([rng.choice(16, 4, replace=False) for _ in range(7)])
+    tf = fc.torsion_module.get_tf_mat(X, quads)
+    tf0 = o.get_tf_mat(X, quads)
+    assert np.abs(tf - tf0).max() < TOL
+    assert abs(fc.algebra.dihedral(X[0][quads[0]]) - tf0[0, 0]) < TOL
+    out = [fc.torsion_module.tfd_similarity(a, b) for a, b in zip(golden["tfd_a"], golden["tfd_b"])]
+    assert np.array_equal(out, golden["tfd_out"])
+
+
+@pytest.mark.parametrize("name", ["tfdp_small", "tfdp_mid", "tfdp_big", "tfdp_dense"])
+def test_tfd_bits_and_prune_golden(fc, golden, name, monkeypatch):
+    """TFD similarity bits on the GPU + the reference's bookkeeping = the
+    mask the reference's own prune_conformers_tfd produced."""
+    tf = golden[name + "_tf"]
+    n = len(tf)
+    from firecode_amd import torsion_module as tm
+
+    monkeypatch.setattr(tm, "get_tf_mat", lambda s, q: tf)
+    _, mask = tm.prune_conformers_tfd(np.zeros((n, 4, 3)), np.zeros((tf.shape[1], 4), dtype=int), thresh=10)
+    assert np.array_equal(mask, golden[name + "_mask"])
+
+
+# ---------------------------------------------------------------- Ensemble driver
+def test_ensemble_similarity_pruning_cfg1(fc, tmp_path):
+    """BASELINE config 1: 200 x 30 written to .xyz (8 decimals), re-read, pruned."""
+    X, atoms, asg = syn.synthetic_ensemble(200, 30, seed=1)
+    ens = fc.ensemble.Ensemble(atoms=atoms, coords=X, basename="cfg1", logfunction=None)
+    path = tmp_path / "cfg1.xyz"
+    ens.to_xyz(path)
+    assert path.read_text() == o.ensemble_to_xyz_text(atoms, X, "cfg1")
+    back = fc.ensemble.Ensemble.from_xyz(path)
+    back.logfunction = None
+    Xr = back.coords.copy()
+    back.similarity_pruning(moi=False, rmsd=True, max_rmsd=0.5)
+    _, ref = o.prune_by_rmsd(Xr, atoms, 0.5)
+    assert np.array_equal(back.coords, Xr[ref])
+    assert len(back.coords) == len(np.unique(asg))
