@@ -28,12 +28,12 @@ N_CONF, N_ATOMS, MAX_RMSD = 10000, 50, 0.5
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(coords, budget_s=12.0):
+def cpu_baseline(coords, budget_s=20.0):
     """Oracle ('port' of the reference's per-pair NumPy path) on a bounded
     sample: all pairs of the first n0 conformers, one core."""
     from oracle import cpu_ref as o
 
-    n0 = 500
+    n0 = 1400
     X = coords[:n0] - coords[:n0].mean(axis=1, keepdims=True)
     iu, ju = np.triu_indices(n0, 1)
     t0 = time.perf_counter()

@@ -2,6 +2,7 @@
 // argument checks, host<->HBM staging, kernel sequencing.  No compute here.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 #include "fc_common.h"
@@ -21,6 +22,9 @@ int launch_pack_mask(const uint8_t *, int64_t, uint64_t *, int64_t, unsigned lon
 int launch_level(const uint64_t *, int64_t, const uint64_t *, const uint8_t *, uint8_t *, int64_t,
                  int64_t, int64_t, int64_t, int64_t, int64_t);
 int launch_copy_bytes(const uint8_t *, uint8_t *, int64_t);
+int launch_mask_init(uint64_t *, int64_t, int64_t);
+int launch_level_fused(const uint64_t *, int64_t, const uint64_t *, uint64_t *, int64_t, int64_t,
+                       int64_t, unsigned long long *);
 int launch_inertia_moments(const double *, int64_t, int64_t, const double *, double *);
 int launch_moi_simbits(const double *, int64_t, double, const double *, double, uint64_t *, int64_t);
 int launch_tfd_simbits(const double *, int64_t, int64_t, double, int64_t, int64_t, uint64_t *,
@@ -127,7 +131,7 @@ static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const 
   e->A = (int64_t)sel.size();
   e->Npad = ceil_div(std::max<int64_t>(N, 1), 64) * 64;
   e->W = e->Npad / 64;
-  FC_TRY(e->Xs.reserve((size_t)e->A * 3 * e->Npad * sizeof(double)));
+  FC_TRY(e->Xs.reserve((size_t)((e->A + 3) / 4 * 4) * 3 * e->Npad * sizeof(double)));
   FC_TRY(e->G.reserve((size_t)e->Npad * sizeof(double)));
   FC_TRY(e->counters.reserve(8 * sizeof(uint64_t)));
   DevBuf raw, dsel;
@@ -150,7 +154,18 @@ static int ensemble_shard(fc_ensemble *e, int64_t rank, int64_t world, int64_t r
   const int64_t n_gblocks = ceil_div(e->N, row_block);
   const int64_t n_lblocks = n_gblocks > rank ? (n_gblocks - rank + world - 1) / world : 0;
   e->rows_local = n_lblocks * row_block;
+  if ((uint64_t)e->rows_local * (uint64_t)e->W >= (1ull << 32))
+    return set_error(FC_E_LIMIT, "bit matrix of %lld x %lld words exceeds the 32-bit word index",
+                     (long long)e->rows_local, (long long)e->W);
   FC_TRY(e->bits.reserve(std::max<size_t>((size_t)e->rows_local * e->W * sizeof(uint64_t), 8)));
+  FC_TRY(e->cand.reserve(std::max<size_t>((size_t)e->rows_local * e->W * sizeof(uint32_t), 8)));
+  // candidate-pair queue: 256 entries per conformer, 1M..64M entries
+  e->pairq_cap = std::min<int64_t>(std::max<int64_t>(256 * e->N, 1 << 20), 1 << 26);
+  if (const char *v = getenv("FC_PAIRQ_CAP")) {  // test knob: force the word-queue fallback
+    const long long c = std::strtoll(v, nullptr, 10);
+    if (c >= 1 && c <= (1ll << 26)) e->pairq_cap = c;
+  }
+  FC_TRY(e->pairq.reserve((size_t)e->pairq_cap * sizeof(uint64_t)));
   FC_TRY(e->maskA.reserve((size_t)e->Npad));
   FC_TRY(e->maskB.reserve((size_t)e->Npad));
   FC_TRY(e->mbits.reserve((size_t)e->W * sizeof(uint64_t)));
@@ -159,6 +174,16 @@ static int ensemble_shard(fc_ensemble *e, int64_t rank, int64_t world, int64_t r
 }
 
 static const double kScreenMargin = 1e-6;  // A^2, added to max_rmsd^2 in the screen
+
+// rows of the bit matrix per workgroup (tuning knob FC_ROW_BLOCK, multiple of 128)
+static int64_t default_row_block() {
+  const char *v = getenv("FC_ROW_BLOCK");
+  if (v) {
+    const long r = std::strtol(v, nullptr, 10);
+    if (r >= 128 && r <= 4096 && r % 128 == 0) return r;
+  }
+  return 256;
+}
 
 // similarity bits of this rank's rows: screen + exact refine; counters[1..3]
 static int simbits_local(fc_ensemble *e, double max_rmsd, double max_dev, const double *energies,
@@ -179,37 +204,39 @@ static int simbits_local(fc_ensemble *e, double max_rmsd, double max_dev, const 
 static const int64_t kLadder[] = {500000, 200000, 100000, 50000, 20000, 10000, 5000, 2000, 1000,
                                   500,    200,    100,    50,    20,    10,    5,    2,    1};
 
-// whole ladder on one device (world == 1): returns survivors, levels run
+// whole ladder on one device (world == 1), enqueued without host round trips:
+// one fused launch per ladder value that can still apply (the first ones are
+// ruled out on the host from N alone), one sync at the end.
 static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_per_group,
                          uint8_t *mask_out, int64_t *levels, int64_t *survivors) {
-  const int64_t N = e->N;
-  FC_HIP_TRY(hipMemsetAsync(e->maskA.p, 1, (size_t)N, ctx().stream));
-  uint8_t *cur = e->maskA.as<uint8_t>(), *nxt = e->maskB.as<uint8_t>();
+  const int64_t N = e->N, W = e->W;
+  const int n_ladder = (int)(sizeof(kLadder) / sizeof(kLadder[0]));
+  FC_TRY(e->ladder.reserve((size_t)(n_ladder + 1) * W * sizeof(uint64_t)));
+  uint64_t *mb = e->ladder.as<uint64_t>();
   auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
-  int64_t active = N, nlev = 0;
-  FC_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint64_t), ctx().stream));
-  FC_TRY(launch_pack_mask(cur, N, e->mbits.as<uint64_t>(), e->W, cnt));
-  const int64_t rows = ceil_div(N, e->row_block) * e->row_block;
+  FC_HIP_TRY(hipMemsetAsync(mb, 0, (size_t)(n_ladder + 1) * W * sizeof(uint64_t), ctx().stream));
+  FC_HIP_TRY(hipMemsetAsync(cnt + 5, 0, sizeof(uint64_t), ctx().stream));
+  FC_TRY(launch_mask_init(mb, N, W));
+  int cur = 0;
   for (int64_t k : kLadder) {
-    if (!(k == 1 || min_per_group * k < active)) continue;
-    FC_TRY(launch_level(bits_dev, e->W, e->mbits.as<uint64_t>(), cur, nxt, N, k, e->row_block, 0, 1,
-                        rows));
-    std::swap(cur, nxt);
-    ++nlev;
-    // survivors of this level decide which ladder values still apply
-    FC_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint64_t), ctx().stream));
-    FC_TRY(launch_pack_mask(cur, N, e->mbits.as<uint64_t>(), e->W, cnt));
-    unsigned long long c = 0;
-    FC_TRY(d2h(&c, cnt, sizeof c));
-    FC_TRY(sync());
-    active = (int64_t)c;
+    if (!(k == 1 || min_per_group * k < N)) continue;  // can never run: n_active <= N
+    FC_TRY(launch_level_fused(bits_dev, W, mb + (size_t)cur * W, mb + (size_t)(cur + 1) * W, N, k,
+                              min_per_group, cnt));
+    ++cur;
   }
-  if (mask_out) {
-    FC_TRY(d2h(mask_out, cur, (size_t)N));
-    FC_TRY(sync());
+  std::vector<uint64_t> words((size_t)W);
+  unsigned long long nlev = 0;
+  FC_TRY(d2h(words.data(), mb + (size_t)cur * W, (size_t)W * sizeof(uint64_t)));
+  FC_TRY(d2h(&nlev, cnt + 5, sizeof nlev));
+  FC_TRY(sync());
+  int64_t alive = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    const uint8_t b = (uint8_t)((words[(size_t)(i >> 6)] >> (i & 63)) & 1ull);
+    alive += b;
+    if (mask_out) mask_out[i] = b;
   }
-  if (levels) *levels = nlev;
-  if (survivors) *survivors = active;
+  if (levels) *levels = (int64_t)nlev;
+  if (survivors) *survivors = alive;
   return FC_OK;
 }
 
@@ -363,7 +390,7 @@ int fc_rmsd_simbits(fc_ensemble *ens, double max_rmsd, double max_dev, const dou
   FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
   FC_TRY(ensure_init());
   if (ens->N == 0) return FC_OK;
-  FC_TRY(ensemble_shard(ens, 0, 1, 64));
+  FC_TRY(ensemble_shard(ens, 0, 1, default_row_block()));
   FC_TRY(simbits_local(ens, max_rmsd, max_dev, energies, max_dE, true));
   const int64_t W = ens->W;
   std::vector<uint64_t> all((size_t)ens->rows_local * W);
@@ -386,7 +413,7 @@ int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const doubl
   FC_REQUIRE(min_per_group >= 1, "min_per_group must be >= 1");
   FC_TRY(ensure_init());
   if (ens->N == 0) return FC_OK;
-  FC_TRY(ensemble_shard(ens, 0, 1, 256));
+  FC_TRY(ensemble_shard(ens, 0, 1, default_row_block()));
   FC_TRY(simbits_local(ens, max_rmsd, max_dev, energies, max_dE, true));
   unsigned long long cnt[8];
   FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
@@ -726,7 +753,7 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
                         int64_t *stats) {
   FC_REQUIRE(ens && reps >= 1, "bad arguments");
   FC_TRY(ensure_init());
-  FC_TRY(ensemble_shard(ens, 0, 1, 256));
+  FC_TRY(ensemble_shard(ens, 0, 1, default_row_block()));
   Context &c = ctx();
   double t_kernel = 0.0, t_step = 0.0;
   int64_t levels = 0, survivors = 0;

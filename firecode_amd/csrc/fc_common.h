@@ -115,9 +115,13 @@ struct fc_ensemble {
   fc::DevBuf G;                // [Npad] sum of squares per conformer
   // prune workspace (allocated on first use, kept for later calls)
   fc::DevBuf bits;             // rows_local * W uint64
+  fc::DevBuf cand;             // rows_local * W uint32: queue of words to refine
+  fc::DevBuf pairq;            // pairq_cap x uint64: queue of candidate pairs (i<<32 | j)
+  int64_t pairq_cap = 0;
   fc::DevBuf energies;         // N doubles (optional)
   fc::DevBuf maskA, maskB;     // N bytes each
   fc::DevBuf mbits;            // W uint64 active-flag words
+  fc::DevBuf ladder;           // (levels+1) x W mask words of the fused single-GPU ladder
   fc::DevBuf counters;         // 8 x uint64
   // sharding of the bit matrix rows (block-cyclic)
   int64_t rank = 0, world = 1, row_block = 64;

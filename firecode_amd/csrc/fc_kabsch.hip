@@ -14,6 +14,8 @@
 #include "fc_common.h"
 #include "fc_kabsch_math.h"
 
+#include <cstdlib>
+
 namespace fc {
 
 // ---------------------------------------------------------------------------
@@ -27,6 +29,13 @@ k_prep(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_
        int64_t A, int center, int64_t Npad, double *__restrict__ Xs, double *__restrict__ G) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= Npad) return;
+  // atom rows A .. A4-1 (A4 = A rounded up to 4) are zero: the MFMA K loop
+  // runs over whole groups of 4 atoms without a bounds test
+  for (int64_t a = A; a < ((A + 3) & ~(int64_t)3); ++a) {
+    Xs[(a * 3 + 0) * Npad + n] = 0.0;
+    Xs[(a * 3 + 1) * Npad + n] = 0.0;
+    Xs[(a * 3 + 2) * Npad + n] = 0.0;
+  }
   if (n >= N) {  // zero padding keeps every later load in bounds and finite
     for (int64_t a = 0; a < A; ++a) {
       Xs[(a * 3 + 0) * Npad + n] = 0.0;
@@ -106,6 +115,52 @@ __device__ __forceinline__ void pair_exact(const double *__restrict__ Xs, int64_
   }
 }
 
+// Same evaluation with the whole wavefront on ONE pair: lane = atom (strided),
+// the nine covariance sums and the deviation sum / max are reduced across the
+// wave with xor shuffles; the 4x4 eigen-solve runs redundantly in every lane.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ void pair_exact_wave(const double *__restrict__ Xs, int64_t Npad, int A,
+                                                int64_t i, int64_t j, int lane, double &rmsd,
+                                                double &maxdev) {
+  double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int a = lane; a < A; a += 64) {
+    const double *pa = Xs + (int64_t)(a * 3) * Npad;
+    const double px = pa[i], py = pa[Npad + i], pz = pa[2 * Npad + i];
+    const double qx = pa[j], qy = pa[Npad + j], qz = pa[2 * Npad + j];
+    B[0] = fma(px, qx, B[0]); B[1] = fma(px, qy, B[1]); B[2] = fma(px, qz, B[2]);
+    B[3] = fma(py, qx, B[3]); B[4] = fma(py, qy, B[4]); B[5] = fma(py, qz, B[5]);
+    B[6] = fma(pz, qx, B[6]); B[7] = fma(pz, qy, B[7]); B[8] = fma(pz, qz, B[8]);
+  }
+#pragma unroll
+  for (int e = 0; e < 9; ++e) B[e] = wave_sum_f64(B[e]);
+  double R[9];
+  (void)kabsch_rotation(B, R);
+  double ssq = 0.0, mx = 0.0;
+  for (int a = lane; a < A; a += 64) {
+    const double *pa = Xs + (int64_t)(a * 3) * Npad;
+    const double px = pa[i], py = pa[Npad + i], pz = pa[2 * Npad + i];
+    const double qx = pa[j], qy = pa[Npad + j], qz = pa[2 * Npad + j];
+    const double dx = px - (R[0] * qx + R[1] * qy + R[2] * qz);
+    const double dy = py - (R[3] * qx + R[4] * qy + R[5] * qz);
+    const double dz = pz - (R[6] * qx + R[7] * qy + R[8] * qz);
+    const double s = dx * dx + dy * dy + dz * dz;
+    ssq += s;
+    mx = fmax(mx, s);
+  }
+  rmsd = sqrt(wave_sum_f64(ssq) / (double)A);
+  maxdev = sqrt(wave_max_f64(mx));
+}
+
 __global__ void __launch_bounds__(256)
 k_pairs_exact(const double *__restrict__ Xs, int64_t Npad, int A, const int64_t *__restrict__ pi,
               const int64_t *__restrict__ pj, int64_t P, double *__restrict__ rmsd,
@@ -138,6 +193,24 @@ k_matrix_exact(const double *__restrict__ Xs, int64_t N, int64_t Npad, int A,
   maxdev[i * N + j] = m;
 }
 
+// Candidate pairs found by a screen kernel are also appended to a pair queue
+// ((i << 32) | j, global indices) so that the exact re-evaluation can give
+// every lane its own pair.  counters[6] counts ALL candidates, also those
+// beyond the queue capacity Q -- the refine kernel then falls back to the
+// (always complete) word queue.
+__device__ __forceinline__ void push_pairs(uint64_t m, bool may, unsigned i, unsigned j,
+                                           uint64_t *__restrict__ pairq, unsigned long long Q,
+                                           unsigned long long *__restrict__ counters, int lane) {
+  if (m == 0) return;  // wave-uniform
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(&counters[6], (unsigned long long)__popcll(m));
+  base = __shfl(base, 0);
+  if (may) {
+    const unsigned long long slot = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+    if (slot < Q) pairq[slot] = ((uint64_t)i << 32) | (uint64_t)j;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // k_simbits_screen -- the dominant kernel of the pruning stage.
 //
@@ -152,13 +225,13 @@ k_matrix_exact(const double *__restrict__ Xs, int64_t N, int64_t Npad, int A,
 // = one uint64 word of the bit matrix, written by lane 0 (no atomics).
 // Pairs that pass the screen are re-evaluated exactly by k_simbits_refine.
 // ---------------------------------------------------------------------------
-constexpr int TI = 8;
-
-template <bool USE_LDS>
-__global__ void __launch_bounds__(256)
+template <bool USE_LDS, int TI, int NW>
+__global__ void __launch_bounds__(NW * 64)
 k_simbits_screen(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N,
                  int64_t Npad, int A, double A_thr2, int IB, int64_t rank, int64_t world,
-                 uint64_t *__restrict__ bits, int64_t W) {
+                 uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
+                 unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
+                 unsigned long long Q) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -173,7 +246,7 @@ k_simbits_screen(const double *__restrict__ Xs, const double *__restrict__ G, in
 
   if (USE_LDS) {
     const int total = A * 3 * 64;
-    for (int idx = tid; idx < total; idx += 256) {
+    for (int idx = tid; idx < total; idx += NW * 64) {
       const int ac = idx >> 6, l = idx & 63;
       lds[idx] = Xs[(int64_t)ac * Npad + jt * 64 + l];
     }
@@ -182,7 +255,7 @@ k_simbits_screen(const double *__restrict__ Xs, const double *__restrict__ G, in
   const double Gq = G[j];
   const double *__restrict__ xq = Xs + jt * 64 + lane;
 
-  for (int it = wv; it * TI < IB; it += 4) {
+  for (int it = wv; it * TI < IB; it += NW) {
     const int64_t ib = i0 + (int64_t)it * TI;    // first row of this 8-row tile
     if (ib >= N) break;
     if (jt * 64 + 63 <= ib) break;               // later tiles are further below
@@ -229,9 +302,186 @@ k_simbits_screen(const double *__restrict__ Xs, const double *__restrict__ G, in
       bool may = kabsch_may_be_below(acc[k], Gp + Gq, A_thr2);
       may = may && (j > i) && (j < N) && (i < N);
       const uint64_t word = __ballot(may);
+      push_pairs(word, may, (unsigned)i, (unsigned)j, pairq, Q, counters, lane);
       if (lane == 0 && i < N) {
         const int64_t lrow = (int64_t)(lb * IB) + (int64_t)it * TI + k;
         bits[lrow * W + jt] = word;
+        if (word) {  // queue the word for exact re-evaluation (k_simbits_refine)
+          const unsigned long long slot = atomicAdd(&counters[4], 1ull);
+          cand[slot] = (uint32_t)(lrow * W + jt);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_simbits_screen_mfma -- same screen, covariance on the fp64 matrix pipe.
+//
+// The 9 covariance entries of ALL pairs of a (16-row x 16-column) tile are 9
+// small GEMMs  C_xy[r][c] = sum_a Px[r][a] * Qy[c][a]  with K = atoms: exactly
+// v_mfma_f64_16x16x4_f64 (A: lane l holds row l&15, k = l>>4; B: column l&15,
+// k = l>>4; D: column l&15, row (l>>4)+4*reg).  After the K loop a lane owns
+// the full 3x3 covariance of 4 pairs per tile, so the polynomial screen runs
+// per lane exactly as in the VALU kernel.  Measured on MI355X
+// (tools/ubench_f64.hip): v_fma_f64 reaches 38/52/65 TFLOP/s at 1/2/4 waves
+// per SIMD, the f64 MFMA 71/76/78 -- and the VALU kernel additionally starves
+// on scalar-cache misses for its wave-uniform operand (profiles/, round 1),
+// which is why the matrix pipe is the default for this contraction.
+//
+// Workgroup = NW waves = (one 64-column tile) x (IB rows).  Column tile in LDS,
+// k-grouped and half-swizzled so that the four k-slices a ds_read_b64 touches
+// fall on disjoint banks:  [(s*3+c)][k>>1][cs][k&1][16].  Row operands stream
+// from L2 one k-step ahead (3 doubles per lane).  A wave takes 16 rows at a
+// time against two 16-column sub-tiles (18 accumulators of 4 doubles).
+// ---------------------------------------------------------------------------
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2)
+k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N,
+                      int64_t Npad, int A, double A_thr2, int IB, int64_t rank, int64_t world,
+                      uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
+                      unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
+                      unsigned long long Q) {
+  extern __shared__ double lds[];
+  constexpr int TC = 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KS = (A + 3) >> 2;
+  const int64_t jt = blockIdx.x;
+  const int64_t j0 = jt * TC;
+  const int64_t lb = blockIdx.y;
+  const int64_t i0 = (lb * world + rank) * IB;
+  if (i0 >= N) return;
+  if (j0 + TC - 1 <= i0) return;
+
+  {  // stage the column tile, zero-padded to a multiple of 4 atoms
+    const int total = KS * 4 * 3 * TC;
+    for (int idx = tid; idx < total; idx += NW * 64) {
+      const int col = idx & (TC - 1);
+      const int ac = idx >> 6;  // a*3 + c
+      const int a = ac / 3, c = ac - a * 3;
+      const int sgrp = a >> 2, k = a & 3;
+      const double v = Xs[(int64_t)ac * Npad + j0 + col];
+      lds[(sgrp * 3 + c) * (4 * TC) + (k >> 1) * (2 * TC) + (col >> 4) * 32 + (k & 1) * 16 + (col & 15)] = v;
+    }
+    __syncthreads();
+  }
+  const int kq = lane >> 4, l15 = lane & 15;
+  const int boff = (kq >> 1) * (2 * TC) + (kq & 1) * 16 + l15;
+  uint16_t *bits16 = reinterpret_cast<uint16_t *>(bits);
+
+  for (int it = wv; it * 16 < IB; it += NW) {
+    const int64_t ib = i0 + (int64_t)it * 16;
+    if (ib >= N) break;
+    if (j0 + TC - 1 <= ib) break;
+    const int64_t lrow0 = lb * IB + (int64_t)it * 16;
+    unsigned nz0 = 0, nz1 = 0, nz2 = 0, nz3 = 0;
+    // per-lane element offsets of the lane's row operand inside one k-step
+    // (fits 32 bits: checked by the launcher)
+    unsigned voff[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) voff[c] = (unsigned)((int64_t)(kq * 3 + c) * Npad + ib + l15);
+
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      const int cs0 = half * 2;
+      if (j0 + (cs0 + 2) * 16 - 1 <= ib) {  // both sub-tiles at or below the diagonal
+        if (lane < 4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t row = ib + lane + 4 * r;
+            if (row < N) {
+              bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs0] = 0;
+              bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs0 + 1] = 0;
+            }
+          }
+        }
+        continue;
+      }
+      d4_t acc[2][9];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc[t][e] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+      // operands of k-step s+1 are fetched (rows: L2 -> VGPR, columns: LDS -> VGPR)
+      // before the 18 MFMAs of k-step s are issued
+      double a_cur[3], a_nxt[3], b_cur[2][3], b_nxt[2][3];
+      // addresses = wave-uniform k-step base (SGPR) + per-lane 32-bit offset
+      const double *__restrict__ lb0 = lds + cs0 * 32 + boff;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a_cur[c] = Xs[voff[c]];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b_cur[t][c] = lb0[c * (4 * TC) + t * 32];
+      for (int sgrp = 0; sgrp < KS; ++sgrp) {
+        const int sn = (sgrp + 1 < KS) ? sgrp + 1 : sgrp;  // last step re-reads itself
+        const double *__restrict__ xs_s = Xs + (int64_t)sn * 12 * Npad;  // uniform
+        const double *__restrict__ lb_s = lb0 + sn * (12 * TC);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a_nxt[c] = xs_s[voff[c]];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) b_nxt[t][c] = lb_s[c * (4 * TC) + t * 32];
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+          for (int y = 0; y < 3; ++y)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              acc[t][x * 3 + y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[x], b_cur[t][y],
+                                                                       acc[t][x * 3 + y], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a_cur[c] = a_nxt[c];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) b_cur[t][c] = b_nxt[t][c];
+      }
+      // epilogue: lane owns pairs (ib + kq + 4r, j0 + cs*16 + l15), r = 0..3
+      const int n32 = (int)N, ib32 = (int)ib;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int cs = cs0 + t;
+        const int j = (int)j0 + cs * 16 + l15;
+        const double Gq = G[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ib32 + kq + 4 * r;
+          const double Gp = G[i];
+          double B9[9];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
+          bool may = kabsch_may_be_below(B9, Gp + Gq, A_thr2);
+          may = may && (j > i) && (j < n32) && (i < n32);
+          const uint64_t m = __ballot(may);
+          push_pairs(m, may, (unsigned)i, (unsigned)j, pairq, Q, counters, lane);
+          if (lane < 4) {
+            const unsigned piece = (unsigned)((m >> (16 * lane)) & 0xffffull);
+            if (ib32 + lane + 4 * r < n32) {
+              bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs] = (uint16_t)piece;
+              if (r == 0) nz0 |= piece;
+              if (r == 1) nz1 |= piece;
+              if (r == 2) nz2 |= piece;
+              if (r == 3) nz3 |= piece;
+            }
+          }
+        }
+      }
+    }
+    if (lane < 4) {  // queue the non-empty words of this row tile for the exact refine
+      const unsigned nz[4] = {nz0, nz1, nz2, nz3};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (nz[r]) {
+          const unsigned long long slot = atomicAdd(&counters[4], 1ull);
+          cand[slot] = (uint32_t)((lrow0 + lane + 4 * r) * W + jt);
+        }
       }
     }
   }
@@ -248,35 +498,88 @@ __global__ void __launch_bounds__(256)
 k_simbits_refine(const double *__restrict__ Xs, int64_t N, int64_t Npad, int A, double max_rmsd,
                  double max_dev, const double *__restrict__ energies, double max_dE, int IB,
                  int64_t rank, int64_t world, int64_t rows_local, uint64_t *__restrict__ bits,
-                 int64_t W, unsigned long long *__restrict__ counters) {
+                 int64_t W, const uint32_t *__restrict__ cand,
+                 unsigned long long *__restrict__ counters, const uint64_t *__restrict__ pairq,
+                 unsigned long long Q) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t lrow = wave / W;
-  const int64_t jt = wave % W;
-  if (lrow >= rows_local) return;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const unsigned long long n_pairs = counters[6];
+  if (n_pairs <= Q) {
+    // pair mode: the queue is complete -> one lane per candidate pair; a pair
+    // that is not similar has its screen bit cleared
+    for (int64_t base = wave0 * 64; base < (int64_t)n_pairs; base += nwaves * 64) {
+      const int64_t p = base + lane;
+      const bool on = p < (int64_t)n_pairs;
+      bool sim = false, grey = false;
+      if (on) {
+        const uint64_t e = pairq[p];
+        const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
+        double r, m;
+        pair_exact(Xs, Npad, A, i, j, r, m);
+        sim = (r < max_rmsd) && (m < max_dev);
+        grey = (fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9);
+        if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
+        if (!sim) {
+          const int64_t lrow = ((i / IB) / world) * IB + (i % IB);
+          atomicAnd(reinterpret_cast<unsigned long long *>(&bits[lrow * W + (j >> 6)]),
+                    ~(1ull << (j & 63)));
+        }
+      }
+      const uint64_t mo = __ballot(on), ms = __ballot(sim), mg = __ballot(grey);
+      if (lane == 0) {
+        atomicAdd(&counters[1], (unsigned long long)__popcll(mo));
+        if (ms) atomicAdd(&counters[2], (unsigned long long)__popcll(ms));
+        if (mg) atomicAdd(&counters[3], (unsigned long long)__popcll(mg));
+      }
+    }
+    return;
+  }
+  const int64_t n_cand = (int64_t)counters[4];
+  for (int64_t c = wave0; c < n_cand; c += nwaves) {
+  const int64_t widx = cand[c];
+  const int64_t lrow = widx / W;
+  const int64_t jt = widx % W;
   const int64_t lb = lrow / IB;
   const int64_t i = (lb * world + rank) * IB + (lrow % IB);
-  if (i >= N) return;
-  if (jt * 64 + 63 <= i) return;
   const uint64_t word = bits[lrow * W + jt];
-  if (word == 0) return;
-  const int64_t j = jt * 64 + lane;
-  const bool cand = (word >> lane) & 1ull;
-  bool sim = false, grey = false;
-  if (cand) {
-    double r, m;
-    pair_exact(Xs, Npad, A, i, j, r, m);
-    sim = (r < max_rmsd) && (m < max_dev);
-    grey = (fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9);
-    if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
+  uint64_t out = 0, g = 0;
+  if (__popcll(word) < 8) {
+    // sparse word (the usual case): the whole wave works on one pair at a time
+    uint64_t rest = word;
+    while (rest) {
+      const int b = __ffsll((unsigned long long)rest) - 1;
+      rest &= rest - 1;
+      const int64_t j = jt * 64 + b;
+      double r, m;
+      pair_exact_wave(Xs, Npad, A, i, j, lane, r, m);
+      bool sim = (r < max_rmsd) && (m < max_dev);
+      const bool grey = (fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9);
+      if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
+      if (sim) out |= 1ull << b;
+      if (grey) g |= 1ull << b;
+    }
+  } else {
+    // dense word: one lane per pair
+    const int64_t j = jt * 64 + lane;
+    const bool cand = (word >> lane) & 1ull;
+    bool sim = false, grey = false;
+    if (cand) {
+      double r, m;
+      pair_exact(Xs, Npad, A, i, j, r, m);
+      sim = (r < max_rmsd) && (m < max_dev);
+      grey = (fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9);
+      if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
+    }
+    out = __ballot(sim);
+    g = __ballot(grey);
   }
-  const uint64_t out = __ballot(sim);
-  const uint64_t g = __ballot(grey);
   if (lane == 0) {
     bits[lrow * W + jt] = out;
     atomicAdd(&counters[1], (unsigned long long)__popcll(word));
     atomicAdd(&counters[2], (unsigned long long)__popcll(out));
     if (g) atomicAdd(&counters[3], (unsigned long long)__popcll(g));
+  }
   }
 }
 
@@ -386,34 +689,76 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   const double A_thr2 = (double)e->A * thr2_margin;
   const size_t lds = (size_t)e->A * 3 * 64 * sizeof(double);
   dim3 grid((unsigned)NT, (unsigned)n_lblocks);
+  // tuning / evidence knob: "mfma" (default), "valu8x4", "valu4x8"
+  const char *cfg = getenv("FC_SCREEN_CFG");
+  const bool want_valu = cfg && std::strncmp(cfg, "valu", 4) == 0;
+  const bool alt = cfg && std::strcmp(cfg, "valu4x8") == 0;
+  {
+    const size_t lds_m = (size_t)((e->A + 3) / 4) * 4 * 3 * 64 * sizeof(double);
+    const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32);
+    if (!want_valu && fits32 && lds_m <= kLdsLimit && e->row_block % 128 == 0) {
+      auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
+      const bool two_blocks = 2 * lds_m <= kLdsLimit;
+      const void *fn = two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4>)
+                                  : reinterpret_cast<const void *>(k_simbits_screen_mfma<8>);
+      if (lds_m > 64 * 1024) {
+        hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+        if (err != hipSuccess)
+          return set_error(FC_E_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", lds_m,
+                           hipGetErrorString(err));
+      }
+      if (two_blocks)
+        hipLaunchKernelGGL(k_simbits_screen_mfma<4>, grid, dim3(256), lds_m, ctx().stream,
+                           e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
+                           (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
+                           e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
+                           (unsigned long long)e->pairq_cap);
+      else
+        hipLaunchKernelGGL(k_simbits_screen_mfma<8>, grid, dim3(512), lds_m, ctx().stream,
+                           e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
+                           (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
+                           e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
+                           (unsigned long long)e->pairq_cap);
+      return check_launch("k_simbits_screen_mfma");
+    }
+  }
+#define FC_LAUNCH_SCREEN(LDSFLAG, TI_, NW_, SMEM)                                                   \
+  hipLaunchKernelGGL((k_simbits_screen<LDSFLAG, TI_, NW_>), grid, dim3(NW_ * 64), SMEM,            \
+                     ctx().stream, e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad,           \
+                     (int)e->A, A_thr2, (int)e->row_block, e->rank, e->world,                      \
+                     e->bits.as<uint64_t>(), e->W, e->cand.as<uint32_t>(),                         \
+                     reinterpret_cast<unsigned long long *>(e->counters.p),                        \
+                     e->pairq.as<uint64_t>(), (unsigned long long)e->pairq_cap)
   if (lds <= kLdsLimit) {
+    const void *fn = alt ? reinterpret_cast<const void *>(k_simbits_screen<true, 4, 8>)
+                         : reinterpret_cast<const void *>(k_simbits_screen<true, 8, 4>);
     if (lds > 64 * 1024) {
-      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_simbits_screen<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (err != hipSuccess)
         return set_error(FC_E_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", lds,
                          hipGetErrorString(err));
     }
-    hipLaunchKernelGGL(k_simbits_screen<true>, grid, dim3(256), lds, ctx().stream,
-                       e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
-                       (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W);
+    if (alt) FC_LAUNCH_SCREEN(true, 4, 8, lds);
+    else FC_LAUNCH_SCREEN(true, 8, 4, lds);
   } else {
-    hipLaunchKernelGGL(k_simbits_screen<false>, grid, dim3(256), 0, ctx().stream,
-                       e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
-                       (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W);
+    if (alt) FC_LAUNCH_SCREEN(false, 4, 8, 0);
+    else FC_LAUNCH_SCREEN(false, 8, 4, 0);
   }
+#undef FC_LAUNCH_SCREEN
   return check_launch("k_simbits_screen");
 }
 
 int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const double *energies_dev,
                           double max_dE) {
-  const int64_t waves = e->rows_local * e->W;
-  if (waves == 0) return FC_OK;
-  hipLaunchKernelGGL(k_simbits_refine, dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0,
+  if (e->rows_local * e->W == 0) return FC_OK;
+  // persistent-style grid: wavefronts stride over the candidate queue whose
+  // length the screen kernel left in counters[4] (same stream, no host sync)
+  hipLaunchKernelGGL(k_simbits_refine, dim3((unsigned)(ctx().n_cu * 8)), dim3(256), 0,
                      ctx().stream, e->Xs.as<double>(), e->N, e->Npad, (int)e->A, max_rmsd, max_dev,
                      energies_dev, max_dE, (int)e->row_block, e->rank, e->world, e->rows_local,
-                     e->bits.as<uint64_t>(), e->W,
-                     reinterpret_cast<unsigned long long *>(e->counters.p));
+                     e->bits.as<uint64_t>(), e->W, e->cand.as<uint32_t>(),
+                     reinterpret_cast<unsigned long long *>(e->counters.p), e->pairq.as<uint64_t>(),
+                     (unsigned long long)e->pairq_cap);
   return check_launch("k_simbits_refine");
 }
 

@@ -145,6 +145,9 @@ __host__ __device__ __forceinline__ double kabsch_rotation(const double (&B)[9],
 // (with a 1e-12 relative guard on P) is not.
 __host__ __device__ __forceinline__ bool kabsch_may_be_below(const double (&B)[9], double GpGq,
                                                      double A_thr2) {
+  // the screen has a 1e-6 A^2 margin and a 1e-12 relative guard: fused
+  // multiply-adds are welcome here (the file is otherwise built contract=off)
+#pragma clang fp contract(fast)
   const double s = 0.5 * GpGq;
   const double L = s - 0.5 * A_thr2;
   if (!(A_thr2 < 0.5 * s)) return true;  // tiny structure w.r.t. threshold
@@ -157,29 +160,21 @@ __host__ __device__ __forceinline__ bool kabsch_may_be_below(const double (&B)[9
   const double L2 = L * L;
   const double P2 = 12.0 * L2 + 2.0 * C2;
   if (P2 < 0.0) return true;
-  const double detB = Sxx * (Syy * Szz - Syz * Szy) - Sxy * (Syx * Szz - Syz * Szx) +
-                      Sxz * (Syx * Szy - Syy * Szx);
+  // cofactors of B: det B = row 0 . cofactor row 0, and with s_i the singular
+  // values of B the eigenvalues of K are (+-s1 +- s2 +- s3) with an even number
+  // of minus signs (s3 signed by det B), whose product is
+  //   C0 = det K = (s1^2+s2^2+s3^2)^2 - 4 (s1^2 s2^2 + s2^2 s3^2 + s3^2 s1^2)
+  //             = n2^2 - 4 |cof B|_F^2
+  const double c00 = Syy * Szz - Syz * Szy, c01 = Syz * Szx - Syx * Szz, c02 = Syx * Szy - Syy * Szx;
+  const double c10 = Sxz * Szy - Sxy * Szz, c11 = Sxx * Szz - Sxz * Szx, c12 = Sxy * Szx - Sxx * Szy;
+  const double c20 = Sxy * Syz - Sxz * Syy, c21 = Sxz * Syx - Sxx * Syz, c22 = Sxx * Syy - Sxy * Syx;
+  const double detB = Sxx * c00 + Sxy * c01 + Sxz * c02;
   const double C1 = -8.0 * detB;
   const double P1 = (4.0 * L2 + 2.0 * C2) * L + C1;
   if (P1 < 0.0) return true;
-  // det K by Laplace expansion over the first two rows
-  const double a00 = Sxx + Syy + Szz, a01 = Syz - Szy, a02 = Szx - Sxz, a03 = Sxy - Syx;
-  const double a11 = Sxx - Syy - Szz, a12 = Sxy + Syx, a13 = Szx + Sxz;
-  const double a22 = -Sxx + Syy - Szz, a23 = Syz + Szy;
-  const double a33 = -Sxx - Syy + Szz;
-  const double s0 = a00 * a11 - a01 * a01;
-  const double s1 = a00 * a12 - a01 * a02;
-  const double s2 = a00 * a13 - a01 * a03;
-  const double s3 = a01 * a12 - a11 * a02;
-  const double s4 = a01 * a13 - a11 * a03;
-  const double s5 = a02 * a13 - a12 * a03;
-  const double c5 = a22 * a33 - a23 * a23;
-  const double c4 = a12 * a33 - a13 * a23;
-  const double c3 = a12 * a23 - a13 * a22;
-  const double c2 = a02 * a33 - a03 * a23;
-  const double c1 = a02 * a23 - a03 * a22;
-  const double c0 = a02 * a13 - a03 * a12;
-  const double C0 = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+  const double e2 = c00 * c00 + c01 * c01 + c02 * c02 + c10 * c10 + c11 * c11 + c12 * c12 +
+                    c20 * c20 + c21 * c21 + c22 * c22;
+  const double C0 = n2 * n2 - 4.0 * e2;
   const double P0 = ((L2 + C2) * L + C1) * L + C0;
   const double eps = 1e-12 * (s * s) * (s * s);
   return !(P0 > eps);

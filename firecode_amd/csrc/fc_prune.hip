@@ -71,6 +71,72 @@ k_level(const uint64_t *__restrict__ bits, int64_t W, const uint64_t *__restrict
   if (lane == 0) mask_out[i] = any ? 0 : 1;
 }
 
+// ---------------------------------------------------------------------------
+// Single-GPU ladder without host round trips: every level is ONE launch that
+// decides on the device whether the reference would run it
+// (k == 1 or min_per_group * k < n_active), so the host can enqueue the whole
+// ladder behind the similarity kernels and synchronise once.
+// mask words: mb_in (read), mb_out (zeroed beforehand, survivors OR their bit).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_mask_init(uint64_t *__restrict__ mb, int64_t N, int64_t W) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  const int64_t lo = w * 64;
+  uint64_t v = 0;
+  if (lo + 64 <= N) v = ~0ull;
+  else if (lo < N) v = (1ull << (N - lo)) - 1ull;
+  mb[w] = v;
+}
+
+__global__ void __launch_bounds__(256)
+k_level_fused(const uint64_t *__restrict__ bits, int64_t W, const uint64_t *__restrict__ mb_in,
+              uint64_t *__restrict__ mb_out, int64_t N, int64_t k, int64_t min_per_group,
+              unsigned long long *__restrict__ counters) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= N) return;
+  const bool active = (mb_in[i >> 6] >> (i & 63)) & 1ull;
+  if (!active) return;  // wave-uniform
+  // every wave recounts the active set (W words: a few coalesced loads per lane)
+  // and learns whether its row is the first active one (it reports the level)
+  int cnt = 0;
+  bool before = false;
+  for (int64_t w = lane; w < W; w += 64) {
+    const uint64_t m = mb_in[w];
+    cnt += __popcll(m);
+    if (w < (i >> 6)) before |= (m != 0);
+    else if (w == (i >> 6)) before |= ((m & ((1ull << (i & 63)) - 1ull)) != 0);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  const bool first = !__any(before);
+  const bool run = (k == 1) || (min_per_group * k < (int64_t)cnt);
+  bool hit = false;
+  if (run) {
+    const int64_t chunk = N / k;
+    int64_t c = chunk > 0 ? i / chunk : 0;
+    if (c > k - 1) c = k - 1;
+    const int64_t last = (c == k - 1) ? N : chunk * (c + 1);
+    const int64_t w0 = (i + 1) >> 6, w1 = (last - 1) >> 6;
+    const uint64_t *row = bits + i * W;
+    for (int64_t w = w0 + lane; w <= w1; w += 64) {
+      uint64_t x = row[w] & mb_in[w];
+      if (w == w0) x &= (~0ull) << (int)((i + 1) & 63);
+      if (w == w1) {
+        const int e = (int)((last - 1) & 63);
+        x &= (e == 63) ? ~0ull : ((1ull << (e + 1)) - 1ull);
+      }
+      hit |= (x != 0);
+    }
+  }
+  const bool any = __any(hit);
+  if (lane == 0) {
+    if (!any) atomicOr(reinterpret_cast<unsigned long long *>(&mb_out[i >> 6]), 1ull << (i & 63));
+    if (run && first && counters != nullptr) atomicAdd(&counters[5], 1ull);
+  }
+}
+
 // copy for rows a rank does not own (sharded levels)
 __global__ void __launch_bounds__(256)
 k_copy_bytes(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t n) {
@@ -245,6 +311,19 @@ int launch_level(const uint64_t *bits_dev, int64_t W, const uint64_t *mbits_dev,
                      bits_dev, W, mbits_dev, mask_in, mask_out, N, k, (int)IB, rank, world,
                      rows_local);
   return check_launch("k_level");
+}
+
+int launch_mask_init(uint64_t *mb_dev, int64_t N, int64_t W) {
+  hipLaunchKernelGGL(k_mask_init, dim3((unsigned)ceil_div(W, 256)), dim3(256), 0, ctx().stream,
+                     mb_dev, N, W);
+  return check_launch("k_mask_init");
+}
+
+int launch_level_fused(const uint64_t *bits_dev, int64_t W, const uint64_t *mb_in, uint64_t *mb_out,
+                       int64_t N, int64_t k, int64_t min_per_group, unsigned long long *counters) {
+  hipLaunchKernelGGL(k_level_fused, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, ctx().stream,
+                     bits_dev, W, mb_in, mb_out, N, k, min_per_group, counters);
+  return check_launch("k_level_fused");
 }
 
 int launch_copy_bytes(const uint8_t *src, uint8_t *dst, int64_t n) {

@@ -127,6 +127,24 @@ def test_simbits_match_oracle_matrix(fc):
     assert grey == 0
 
 
+def test_refine_word_queue_fallback(fc, monkeypatch):
+    """pair queue too small -> the refine kernel must fall back to the word
+    queue (sparse words: wave per pair; dense words: lane per pair)"""
+    monkeypatch.setenv("FC_PAIRQ_CAP", "4")
+    X, atoms, _ = syn.synthetic_ensemble(300, 20, seed=16)  # sparse words
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    _, mask = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    assert np.array_equal(mask, o.greedy_prune_from_matrix(S0))
+    X, atoms, _ = syn.synthetic_ensemble(256, 15, seed=17, cluster_size=64)  # dense words
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        bits, _ = ens.simbits(0.5, 1.0)
+    from firecode_amd._lib import unpack_bits
+
+    assert np.array_equal(unpack_bits(bits, len(X)), np.triu(S0, 1))
+    assert np.triu(S0, 1).sum() > 4000
+
+
 def test_prune_with_energies(fc):
     X, atoms, _ = syn.synthetic_ensemble(300, 20, seed=14)
     rng = np.random.default_rng(14)
