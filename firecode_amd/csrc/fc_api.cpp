@@ -152,7 +152,7 @@ static int ensemble_shard(fc_ensemble *e, int64_t rank, int64_t world, int64_t r
   e->world = world;
   e->row_block = row_block;
   const int64_t n_gblocks = ceil_div(e->N, row_block);
-  const int64_t n_lblocks = n_gblocks > rank ? (n_gblocks - rank + world - 1) / world : 0;
+  const int64_t n_lblocks = local_block_count(n_gblocks, rank, world);
   e->rows_local = n_lblocks * row_block;
   if ((uint64_t)e->rows_local * (uint64_t)e->W >= (1ull << 32))
     return set_error(FC_E_LIMIT, "bit matrix of %lld x %lld words exceeds the 32-bit word index",
@@ -468,7 +468,7 @@ int fc_prune_rmsd_begin(fc_ensemble *ens, double max_rmsd, double max_dev, const
   if (stats) {
     stats[0] = 0;  // pairs owned by this rank: rows i owned, columns j > i
     const int64_t nb = ceil_div(ens->N, row_block);
-    for (int64_t b = rank; b < nb; b += world)
+    for (int64_t lb = 0, b = rank; (b = global_block(lb, rank, world)) < nb; ++lb)
       for (int64_t i = b * row_block; i < std::min(ens->N, (b + 1) * row_block); ++i)
         stats[0] += ens->N - 1 - i;
     stats[1] = (int64_t)cnt[1];

@@ -105,6 +105,18 @@ inline int check_launch(const char *what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Row blocks of the bit matrix are dealt to ranks in snake order (0..W-1,
+// W-1..0, 0..W-1, ...): the work of a row block falls linearly with its index,
+// so pairs of consecutive cycles carry equal work on every rank.
+__host__ __device__ inline int64_t global_block(int64_t local_block, int64_t rank, int64_t world) {
+  return local_block * world + ((local_block & 1) ? (world - 1 - rank) : rank);
+}
+inline int64_t local_block_count(int64_t n_gblocks, int64_t rank, int64_t world) {
+  int64_t n = 0;
+  while (global_block(n, rank, world) < n_gblocks) ++n;  // strictly increasing in n
+  return n;
+}
+
 }  // namespace fc
 
 // ---- resident ensemble -----------------------------------------------------------

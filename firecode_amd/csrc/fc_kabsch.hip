@@ -238,7 +238,7 @@ k_simbits_screen(const double *__restrict__ Xs, const double *__restrict__ G, in
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t jt = blockIdx.x;
   const int64_t lb = blockIdx.y;                 // local row block
-  const int64_t gb = lb * world + rank;          // global row block
+  const int64_t gb = global_block(lb, rank, world);  // global row block
   const int64_t i0 = gb * IB;
   if (i0 >= N) return;
   if (jt * 64 + 63 <= i0) return;                // nothing above the diagonal here
@@ -353,7 +353,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
   const int64_t jt = blockIdx.x;
   const int64_t j0 = jt * TC;
   const int64_t lb = blockIdx.y;
-  const int64_t i0 = (lb * world + rank) * IB;
+  const int64_t i0 = global_block(lb, rank, world) * IB;
   if (i0 >= N) return;
   if (j0 + TC - 1 <= i0) return;
 
@@ -541,7 +541,7 @@ k_simbits_refine(const double *__restrict__ Xs, int64_t N, int64_t Npad, int A, 
   const int64_t lrow = widx / W;
   const int64_t jt = widx % W;
   const int64_t lb = lrow / IB;
-  const int64_t i = (lb * world + rank) * IB + (lrow % IB);
+  const int64_t i = global_block(lb, rank, world) * IB + (lrow % IB);
   const uint64_t word = bits[lrow * W + jt];
   uint64_t out = 0, g = 0;
   if (__popcll(word) < 8) {
@@ -684,7 +684,7 @@ static constexpr size_t kLdsLimit = 160 * 1024;
 int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   const int64_t NT = e->Npad >> 6;
   const int64_t n_gblocks = ceil_div(e->N, e->row_block);
-  const int64_t n_lblocks = (n_gblocks - e->rank + e->world - 1) / e->world;
+  const int64_t n_lblocks = local_block_count(n_gblocks, e->rank, e->world);
   if (n_lblocks <= 0 || NT == 0) return FC_OK;
   const double A_thr2 = (double)e->A * thr2_margin;
   const size_t lds = (size_t)e->A * 3 * 64 * sizeof(double);

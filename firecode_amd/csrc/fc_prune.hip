@@ -40,7 +40,7 @@ k_level(const uint64_t *__restrict__ bits, int64_t W, const uint64_t *__restrict
   const int64_t lrow = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (lrow >= rows_local) return;
   const int64_t lb = lrow / IB;
-  const int64_t i = (lb * world + rank) * IB + (lrow % IB);
+  const int64_t i = global_block(lb, rank, world) * IB + (lrow % IB);
   if (i >= N) return;
   if (!mask_in[i]) {
     if (lane == 0) mask_out[i] = 0;

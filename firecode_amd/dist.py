@@ -1,8 +1,8 @@
 """Conformer-sharded RMSD pruning over the GPUs of one node.
 
-Every rank holds the whole (small) ensemble in its own HBM and owns the rows
-``i`` of the similarity bit matrix with ``(i // row_block) % world == rank``
-(block-cyclic: balances the triangular work).  The similarity stage needs no
+Every rank holds the whole (small) ensemble in its own HBM and owns the row
+blocks of the similarity bit matrix dealt in snake order (``owner_of_rows``:
+balances the triangular work).  The similarity stage needs no
 communication.  The greedy k-ladder needs the *global* survivor mask of the
 previous level, so after every level the ranks exchange their rows' new flags
 with ONE all-gather of (N,) uint8 (RCCL on GPUs -- ``backend="nccl"`` of
@@ -20,7 +20,12 @@ LADDER = (500000, 200000, 100000, 50000, 20000, 10000, 5000, 2000, 1000, 500,
 
 
 def owner_of_rows(n, world, row_block):
-    return (np.arange(n) // row_block) % world
+    """Rank owning each row: row blocks are dealt in snake order (0..W-1, W-1..0,
+    ...) because the work of a row block falls linearly with its index -- the
+    same map as ``global_block`` in csrc/fc_common.h."""
+    block = np.arange(n) // row_block
+    cycle, pos = block // world, block % world
+    return np.where(cycle % 2 == 0, pos, world - 1 - pos)
 
 
 def run_ladder(n, level_fn, allgather_fn, min_per_group=20, trace=None):
@@ -50,9 +55,9 @@ def torch_allgather(group=None, device=None):
         t = torch.from_numpy(np.ascontiguousarray(mask_u8))
         if device is not None:
             t = t.to(device)
-        out = torch.empty((world, t.numel()), dtype=torch.uint8, device=t.device)
-        dist.all_gather_into_tensor(out, t, group=group)
-        return out.cpu().numpy()
+        out = torch.empty(world * t.numel(), dtype=torch.uint8, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=group)  # rank-major concatenation
+        return out.view(world, t.numel()).cpu().numpy()
 
     return fn
 

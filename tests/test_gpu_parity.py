@@ -352,3 +352,29 @@ def test_ensemble_similarity_pruning_cfg1(fc, tmp_path):
     _, ref = o.prune_by_rmsd(Xr, atoms, 0.5)
     assert np.array_equal(back.coords, Xr[ref])
     assert len(back.coords) == len(np.unique(asg))
+
+
+# ---------------------------------------------------------------- sharded ladder on one GPU
+@pytest.mark.parametrize("world,row_block", [(2, 128), (3, 128), (4, 256)])
+def test_sharded_prune_all_ranks_on_one_gpu(fc, world, row_block):
+    """every 'rank' is a DeviceEnsemble on this GPU; the all-gather is an
+    in-process stack -- exercises fc_prune_rmsd_begin / fc_prune_level and the
+    snake row ownership on the real kernels"""
+    from firecode_amd import dist as fdist
+
+    X, atoms, asg = syn.synthetic_ensemble(1100, 24, seed=50 + world)
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    ranks = [fc.DeviceEnsemble(X, center=True) for _ in range(world)]
+    pairs = 0
+    for r, ens in enumerate(ranks):
+        stats = ens.prune_begin(0.5, 1.0, r, world, row_block=row_block)
+        pairs += int(stats[0])
+    assert pairs == len(X) * (len(X) - 1) // 2  # every pair has exactly one owner
+    mask = np.ones(len(X), dtype=np.uint8)
+    for k in fdist.LADDER:
+        if k == 1 or 20 * k < int(mask.sum()):
+            mask = np.stack([ens.prune_level(k, mask) for ens in ranks]).min(axis=0)
+    for ens in ranks:
+        ens.close()
+    assert np.array_equal(mask.astype(bool), ref)
