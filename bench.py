@@ -165,6 +165,13 @@ def main():
                 "kernel_ms": t_kernel_ms, "algorithmic_bytes_per_alignment": bytes_per_alignment,
                 "compulsory_bytes": n_conf * N_ATOMS * 24 + n_conf * ((n_conf + 63) // 64) * 8,
             }
+            # the bound that actually binds: executed fp64 MFMA flops of the screen kernel
+            # (9 covariance entries x K = atoms padded to 4) against the 78.6 TFLOP/s fp64 peak
+            a4 = (N_ATOMS + 3) // 4 * 4
+            tflops = owned_pairs * 2.0 * 9 * a4 / (t_kernel_ms * 1e-3) / 1e12
+            out["roofline_fp64"] = {"bound": "mfma", "kernel": "k_simbits_screen_mfma", "achieved": tflops,
+                                    "peak": 78.6, "unit": "TFLOP/s", "frac": tflops / 78.6,
+                                    "flops_per_alignment": 2 * 9 * a4}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(coords)
         print(json.dumps(out))
