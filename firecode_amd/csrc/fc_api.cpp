@@ -98,6 +98,18 @@ static int do_init(int device) {
   return FC_OK;
 }
 
+int pinned_reserve(size_t bytes) {
+  Context &c = ctx();
+  if (bytes <= c.pinned_bytes) return FC_OK;
+  if (c.pinned) (void)hipHostFree(c.pinned);
+  c.pinned = nullptr;
+  c.pinned_bytes = 0;
+  const size_t want = std::max<size_t>(bytes, 1 << 20);
+  FC_HIP_TRY(hipHostMalloc(&c.pinned, want, hipHostMallocDefault));
+  c.pinned_bytes = want;
+  return FC_OK;
+}
+
 int ensure_init() {
   if (ctx().ready) {
     // the calling thread may differ from the one that initialised
@@ -133,6 +145,7 @@ static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const 
   e->W = e->Npad / 64;
   FC_TRY(e->Xs.reserve((size_t)((e->A + 3) / 4 * 4) * 3 * e->Npad * sizeof(double)));
   FC_TRY(e->G.reserve((size_t)e->Npad * sizeof(double)));
+  FC_TRY(e->Xa.reserve((size_t)std::max<int64_t>(N, 1) * e->A * 3 * sizeof(double)));
   FC_TRY(e->counters.reserve(8 * sizeof(uint64_t)));
   DevBuf raw, dsel;
   FC_TRY(upload(raw, coords, (size_t)N * A_all * 3));
@@ -208,10 +221,12 @@ static const int64_t kLadder[] = {500000, 200000, 100000, 50000, 20000, 10000, 5
 // one fused launch per ladder value that can still apply (the first ones are
 // ruled out on the host from N alone), one sync at the end.
 static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_per_group,
-                         uint8_t *mask_out, int64_t *levels, int64_t *survivors) {
+                         uint8_t *mask_out, int64_t *levels, int64_t *survivors,
+                         unsigned long long *counters_out = nullptr) {
   const int64_t N = e->N, W = e->W;
   const int n_ladder = (int)(sizeof(kLadder) / sizeof(kLadder[0]));
   FC_TRY(e->ladder.reserve((size_t)(n_ladder + 1) * W * sizeof(uint64_t)));
+  FC_TRY(pinned_reserve((size_t)(W + 8) * sizeof(uint64_t)));
   uint64_t *mb = e->ladder.as<uint64_t>();
   auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
   FC_HIP_TRY(hipMemsetAsync(mb, 0, (size_t)(n_ladder + 1) * W * sizeof(uint64_t), ctx().stream));
@@ -224,19 +239,20 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
                               min_per_group, cnt));
     ++cur;
   }
-  std::vector<uint64_t> words((size_t)W);
-  unsigned long long nlev = 0;
-  FC_TRY(d2h(words.data(), mb + (size_t)cur * W, (size_t)W * sizeof(uint64_t)));
-  FC_TRY(d2h(&nlev, cnt + 5, sizeof nlev));
+  // results land in pinned memory: both copies are asynchronous, one sync for the whole stage
+  uint64_t *words = static_cast<uint64_t *>(ctx().pinned);
+  uint64_t *cnt_host = words + W;
+  FC_TRY(d2h(words, mb + (size_t)cur * W, (size_t)W * sizeof(uint64_t)));
+  FC_TRY(d2h(cnt_host, cnt, 8 * sizeof(uint64_t)));
   FC_TRY(sync());
   int64_t alive = 0;
-  for (int64_t i = 0; i < N; ++i) {
-    const uint8_t b = (uint8_t)((words[(size_t)(i >> 6)] >> (i & 63)) & 1ull);
-    alive += b;
-    if (mask_out) mask_out[i] = b;
-  }
-  if (levels) *levels = (int64_t)nlev;
+  for (int64_t w = 0; w < W; ++w) alive += __builtin_popcountll(words[w]);
+  if (mask_out)
+    for (int64_t i = 0; i < N; ++i) mask_out[i] = (uint8_t)((words[(size_t)(i >> 6)] >> (i & 63)) & 1ull);
+  if (levels) *levels = (int64_t)cnt_host[5];
   if (survivors) *survivors = alive;
+  if (counters_out)
+    for (int k = 0; k < 8; ++k) counters_out[k] = cnt_host[k];
   return FC_OK;
 }
 
@@ -266,6 +282,9 @@ int fc_shutdown(void) {
     (void)hipEventDestroy(c.ev2);
     (void)hipEventDestroy(c.ev3);
     (void)hipStreamDestroy(c.stream);
+    if (c.pinned) (void)hipHostFree(c.pinned);
+    c.pinned = nullptr;
+    c.pinned_bytes = 0;
     c.ready = false;
   }
   return FC_OK;
@@ -416,10 +435,8 @@ int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const doubl
   FC_TRY(ensemble_shard(ens, 0, 1, default_row_block()));
   FC_TRY(simbits_local(ens, max_rmsd, max_dev, energies, max_dE, true));
   unsigned long long cnt[8];
-  FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
-  FC_TRY(sync());
   int64_t levels = 0, survivors = 0;
-  FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), min_per_group, mask_out, &levels, &survivors));
+  FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), min_per_group, mask_out, &levels, &survivors, cnt));
   if (stats) {
     stats[0] = ens->N * (ens->N - 1) / 2;
     stats[1] = (int64_t)cnt[1];
@@ -765,8 +782,8 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
     FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
     FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
     ens->bits_valid = true;
-    FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
-    FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, nullptr, &levels, &survivors));
+    FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, r + 1 == reps ? mask_out : nullptr, &levels,
+                         &survivors, cnt));
     FC_HIP_TRY(hipEventRecord(c.ev2, c.stream));
     FC_HIP_TRY(hipEventSynchronize(c.ev2));
     float a = 0.f, b = 0.f;
@@ -777,10 +794,6 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
   }
   if (ms_simbits_kernel) *ms_simbits_kernel = t_kernel / (double)reps;
   if (ms_step) *ms_step = t_step / (double)reps;
-  if (mask_out) {
-    // ladder_single left the final mask in maskA or maskB; rerun the cheap ladder to export it
-    FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, mask_out, &levels, &survivors));
-  }
   if (stats) {
     stats[0] = ens->N * (ens->N - 1) / 2;
     stats[1] = (int64_t)cnt[1];

@@ -49,7 +49,11 @@ struct Context {
   int n_cu = 0;
   size_t hbm = 0;
   char name[128] = {0};
+  // pinned host staging for small device->host results (truly asynchronous copies)
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
 };
+int pinned_reserve(size_t bytes);  // grows ctx().pinned
 Context &ctx();
 int ensure_init();  // lazy init on device 0 (or the one given to fc_init)
 
@@ -124,6 +128,7 @@ struct fc_ensemble {
   int64_t N = 0, A = 0;        // conformers, selected atoms
   int64_t Npad = 0, W = 0;     // N rounded up to 64; words per bit row
   fc::DevBuf Xs;               // [(a*3+c)*Npad + n] doubles, zero padded
+  fc::DevBuf Xa;               // [n][a][c] doubles: same (centred, selected) atoms, conformer-major
   fc::DevBuf G;                // [Npad] sum of squares per conformer
   // prune workspace (allocated on first use, kept for later calls)
   fc::DevBuf bits;             // rows_local * W uint64

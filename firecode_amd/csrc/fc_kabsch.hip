@@ -14,6 +14,7 @@
 #include "fc_common.h"
 #include "fc_kabsch_math.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace fc {
@@ -26,7 +27,8 @@ namespace fc {
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_prep(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_t *__restrict__ sel,
-       int64_t A, int center, int64_t Npad, double *__restrict__ Xs, double *__restrict__ G) {
+       int64_t A, int center, int64_t Npad, double *__restrict__ Xs, double *__restrict__ G,
+       double *__restrict__ Xa) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= Npad) return;
   // atom rows A .. A4-1 (A4 = A rounded up to 4) are zero: the MFMA K loop
@@ -66,6 +68,9 @@ k_prep(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_
     Xs[(a * 3 + 0) * Npad + n] = x;
     Xs[(a * 3 + 1) * Npad + n] = y;
     Xs[(a * 3 + 2) * Npad + n] = z;
+    Xa[(n * A + a) * 3 + 0] = x;
+    Xa[(n * A + a) * 3 + 1] = y;
+    Xa[(n * A + a) * 3 + 2] = z;
     g += x * x + y * y + z * z;
   }
   G[n] = g;
@@ -100,6 +105,43 @@ __device__ __forceinline__ void pair_exact(const double *__restrict__ Xs, int64_
     const double *pa = Xs + (int64_t)(a * 3) * Npad;
     const double px = pa[i], py = pa[Npad + i], pz = pa[2 * Npad + i];
     const double qx = pa[j], qy = pa[Npad + j], qz = pa[2 * Npad + j];
+    const double dx = px - (R[0] * qx + R[1] * qy + R[2] * qz);
+    const double dy = py - (R[3] * qx + R[4] * qy + R[5] * qz);
+    const double dz = pz - (R[6] * qx + R[7] * qy + R[8] * qz);
+    const double s = dx * dx + dy * dy + dz * dz;
+    ssq += s;
+    mx = fmax(mx, s);
+  }
+  rmsd = sqrt(ssq / (double)A);
+  maxdev = sqrt(mx);
+  if (R_out) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R_out[k] = R[k];
+  }
+}
+
+// Same evaluation from the conformer-major copy Xa: a lane that owns one pair
+// streams two contiguous A*24-byte blocks instead of gathering 6*A strided
+// doubles -- used wherever lanes of a wave hold unrelated pairs.
+__device__ __forceinline__ void pair_exact_aos(const double *__restrict__ Xa, int A, int64_t i,
+                                               int64_t j, double &rmsd, double &maxdev,
+                                               double *R_out = nullptr) {
+  const double *__restrict__ p = Xa + i * (int64_t)A * 3;
+  const double *__restrict__ q = Xa + j * (int64_t)A * 3;
+  double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int a = 0; a < A; ++a) {
+    const double px = p[a * 3], py = p[a * 3 + 1], pz = p[a * 3 + 2];
+    const double qx = q[a * 3], qy = q[a * 3 + 1], qz = q[a * 3 + 2];
+    B[0] = fma(px, qx, B[0]); B[1] = fma(px, qy, B[1]); B[2] = fma(px, qz, B[2]);
+    B[3] = fma(py, qx, B[3]); B[4] = fma(py, qy, B[4]); B[5] = fma(py, qz, B[5]);
+    B[6] = fma(pz, qx, B[6]); B[7] = fma(pz, qy, B[7]); B[8] = fma(pz, qz, B[8]);
+  }
+  double R[9];
+  (void)kabsch_rotation(B, R);
+  double ssq = 0.0, mx = 0.0;
+  for (int a = 0; a < A; ++a) {
+    const double px = p[a * 3], py = p[a * 3 + 1], pz = p[a * 3 + 2];
+    const double qx = q[a * 3], qy = q[a * 3 + 1], qz = q[a * 3 + 2];
     const double dx = px - (R[0] * qx + R[1] * qy + R[2] * qz);
     const double dy = py - (R[3] * qx + R[4] * qy + R[5] * qz);
     const double dz = pz - (R[6] * qx + R[7] * qy + R[8] * qz);
@@ -162,13 +204,13 @@ __device__ __forceinline__ void pair_exact_wave(const double *__restrict__ Xs, i
 }
 
 __global__ void __launch_bounds__(256)
-k_pairs_exact(const double *__restrict__ Xs, int64_t Npad, int A, const int64_t *__restrict__ pi,
+k_pairs_exact(const double *__restrict__ Xa, int A, const int64_t *__restrict__ pi,
               const int64_t *__restrict__ pj, int64_t P, double *__restrict__ rmsd,
               double *__restrict__ maxdev, double *__restrict__ Rout) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   double r, m;
-  pair_exact(Xs, Npad, A, pi[p], pj[p], r, m, Rout ? Rout + p * 9 : nullptr);
+  pair_exact_aos(Xa, A, pi[p], pj[p], r, m, Rout ? Rout + p * 9 : nullptr);
   rmsd[p] = r;
   maxdev[p] = m;
 }
@@ -343,29 +385,62 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
                       int64_t Npad, int A, double A_thr2, int IB, int64_t rank, int64_t world,
                       uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
                       unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
-                      unsigned long long Q) {
+                      unsigned long long Q, int compact) {
   extern __shared__ double lds[];
   constexpr int TC = 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int KS = (A + 3) >> 2;
-  const int64_t jt = blockIdx.x;
+  int64_t jt, lb;
+  if (compact) {
+    // 1-D grid over the blocks that touch the upper triangle only (world == 1):
+    // row block lb owns NT - r*lb column tiles (r = IB/64), so the blocks before
+    // it number C(lb) = lb*NT - r*lb*(lb-1)/2; invert with one sqrt and fix up.
+    const int64_t NT = Npad >> 6, r = IB >> 6, b = blockIdx.x;
+    const double t = (double)(2 * NT + r);
+    int64_t l = (int64_t)((t - sqrt(t * t - 8.0 * (double)r * (double)b)) / (2.0 * (double)r));
+    if (l < 0) l = 0;
+    while (l > 0 && l * NT - r * l * (l - 1) / 2 > b) --l;
+    while ((l + 1) * NT - r * (l + 1) * l / 2 <= b) ++l;
+    lb = l;
+    jt = r * l + (b - (l * NT - r * l * (l - 1) / 2));
+  } else {
+    jt = blockIdx.x;
+    lb = blockIdx.y;
+  }
   const int64_t j0 = jt * TC;
-  const int64_t lb = blockIdx.y;
   const int64_t i0 = global_block(lb, rank, world) * IB;
   if (i0 >= N) return;
   if (j0 + TC - 1 <= i0) return;
 
-  {  // stage the column tile, zero-padded to a multiple of 4 atoms
-    const int total = KS * 4 * 3 * TC;
-    for (int idx = tid; idx < total; idx += NW * 64) {
-      const int col = idx & (TC - 1);
-      const int ac = idx >> 6;  // a*3 + c
-      const int a = ac / 3, c = ac - a * 3;
-      const int sgrp = a >> 2, k = a & 3;
-      const double v = Xs[(int64_t)ac * Npad + j0 + col];
-      lds[(sgrp * 3 + c) * (4 * TC) + (k >> 1) * (2 * TC) + (col >> 4) * 32 + (k & 1) * 16 + (col & 15)] = v;
+  {  // stage the column tile: 16-byte loads, UNR of them in flight per lane
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const int total2 = KS * 4 * 3 * (TC / 2);  // pairs of adjacent columns
+    constexpr int UNR = 5;
+    for (int base = tid; base < total2; base += NW * 64 * UNR) {
+      d2_t v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = base + u * NW * 64;
+        const int col = (idx & (TC / 2 - 1)) * 2;
+        const int ac = idx >> 5;  // a*3 + c   (TC/2 = 32 pairs per row)
+        v[u] = (idx < total2)
+                   ? *reinterpret_cast<const d2_t *>(Xs + (int64_t)ac * Npad + j0 + col)
+                   : d2_t{0.0, 0.0};
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = base + u * NW * 64;
+        if (idx < total2) {
+          const int col = (idx & (TC / 2 - 1)) * 2;
+          const int ac = idx >> 5;
+          const int a = ac / 3, c = ac - a * 3;
+          const int sgrp = a >> 2, k = a & 3;
+          *reinterpret_cast<d2_t *>(lds + (sgrp * 3 + c) * (4 * TC) + (k >> 1) * (2 * TC) +
+                                    (col >> 4) * 32 + (k & 1) * 16 + (col & 15)) = v[u];
+        }
+      }
     }
     __syncthreads();
   }
@@ -407,42 +482,58 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 #pragma unroll
         for (int e = 0; e < 9; ++e) acc[t][e] = d4_t{0.0, 0.0, 0.0, 0.0};
 
-      // operands of k-step s+1 are fetched (rows: L2 -> VGPR, columns: LDS -> VGPR)
-      // before the 18 MFMAs of k-step s are issued
-      double a_cur[3], a_nxt[3], b_cur[2][3], b_nxt[2][3];
-      // addresses = wave-uniform k-step base (SGPR) + per-lane 32-bit offset
+      // Operand sets rotate through the K loop so that no register copies are
+      // needed: row operands (L2 / Infinity Cache, ~1 us under load) in three
+      // sets -- the set consumed by k-step s is refilled with k-step s+3 right
+      // after its 18 MFMAs have issued, two full k-steps ahead of its use --
+      // column operands (LDS) in two sets, one k-step ahead.
       const double *__restrict__ lb0 = lds + cs0 * 32 + boff;
+      double a0[3], a1[3], a2[3], b0[2][3], b1[2][3];
+      const int KSe = KS;
+      auto fetch_a = [&](double (&a)[3], int sx) {
+        const int sl = sx < KS ? sx : KS - 1;  // past the end: harmless re-read
+        const double *__restrict__ xs_s = Xs + (int64_t)sl * 12 * Npad;  // wave-uniform base
 #pragma unroll
-      for (int c = 0; c < 3; ++c) a_cur[c] = Xs[voff[c]];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) b_cur[t][c] = lb0[c * (4 * TC) + t * 32];
-      for (int sgrp = 0; sgrp < KS; ++sgrp) {
-        const int sn = (sgrp + 1 < KS) ? sgrp + 1 : sgrp;  // last step re-reads itself
-        const double *__restrict__ xs_s = Xs + (int64_t)sn * 12 * Npad;  // uniform
-        const double *__restrict__ lb_s = lb0 + sn * (12 * TC);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) a_nxt[c] = xs_s[voff[c]];
+        for (int c = 0; c < 3; ++c) a[c] = xs_s[voff[c]];
+      };
+      auto fetch_b = [&](double (&b)[2][3], int sx) {
+        const int sl = sx < KS ? sx : KS - 1;
+        const double *__restrict__ lb_s = lb0 + sl * (12 * TC);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) b_nxt[t][c] = lb_s[c * (4 * TC) + t * 32];
+          for (int c = 0; c < 3; ++c) b[t][c] = lb_s[c * (4 * TC) + t * 32];
+      };
+      auto mma = [&](const double (&a)[3], const double (&b)[2][3]) {
 #pragma unroll
         for (int x = 0; x < 3; ++x)
 #pragma unroll
           for (int y = 0; y < 3; ++y)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-              acc[t][x * 3 + y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[x], b_cur[t][y],
-                                                                       acc[t][x * 3 + y], 0, 0, 0);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) a_cur[c] = a_nxt[c];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) b_cur[t][c] = b_nxt[t][c];
+              acc[t][x * 3 + y] =
+                  __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[t][y], acc[t][x * 3 + y], 0, 0, 0);
+      };
+      fetch_a(a0, 0);
+      fetch_a(a1, 1);
+      fetch_a(a2, 2);
+      fetch_b(b0, 0);
+      fetch_b(b1, 1);
+#define FC_KSTEP(AX, BX, U)             \
+  if (sgrp + (U) < KSe) {               \
+    mma(AX, BX);                        \
+    fetch_a(AX, sgrp + (U) + 3);        \
+    fetch_b(BX, sgrp + (U) + 2);        \
+  }
+      for (int sgrp = 0; sgrp < KSe; sgrp += 6) {
+        FC_KSTEP(a0, b0, 0)
+        FC_KSTEP(a1, b1, 1)
+        FC_KSTEP(a2, b0, 2)
+        FC_KSTEP(a0, b1, 3)
+        FC_KSTEP(a1, b0, 4)
+        FC_KSTEP(a2, b1, 5)
       }
+#undef FC_KSTEP
       // epilogue: lane owns pairs (ib + kq + 4r, j0 + cs*16 + l15), r = 0..3
       const int n32 = (int)N, ib32 = (int)ib;
 #pragma unroll
@@ -495,7 +586,8 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 // [3] += pairs within 1e-9 of a threshold ("grey").
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_simbits_refine(const double *__restrict__ Xs, int64_t N, int64_t Npad, int A, double max_rmsd,
+k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, int64_t N,
+                 int64_t Npad, int A, double max_rmsd,
                  double max_dev, const double *__restrict__ energies, double max_dE, int IB,
                  int64_t rank, int64_t world, int64_t rows_local, uint64_t *__restrict__ bits,
                  int64_t W, const uint32_t *__restrict__ cand,
@@ -516,7 +608,7 @@ k_simbits_refine(const double *__restrict__ Xs, int64_t N, int64_t Npad, int A, 
         const uint64_t e = pairq[p];
         const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
         double r, m;
-        pair_exact(Xs, Npad, A, i, j, r, m);
+        pair_exact_aos(Xa, A, i, j, r, m);
         sim = (r < max_rmsd) && (m < max_dev);
         grey = (fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9);
         if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
@@ -656,7 +748,8 @@ int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_
                 int64_t A, int center, fc_ensemble *e) {
   const int64_t blocks = ceil_div(e->Npad, 256);
   hipLaunchKernelGGL(k_prep, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, coords_dev, N,
-                     A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>());
+                     A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
+                     e->Xa.as<double>());
   return check_launch("k_prep");
 }
 
@@ -664,8 +757,7 @@ int launch_pairs_exact(const fc_ensemble *e, const int64_t *pi_dev, const int64_
                        int64_t P, double *rmsd_dev, double *maxdev_dev, double *R_dev) {
   if (P == 0) return FC_OK;
   hipLaunchKernelGGL(k_pairs_exact, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, ctx().stream,
-                     e->Xs.as<double>(), e->Npad, (int)e->A, pi_dev, pj_dev, P, rmsd_dev,
-                     maxdev_dev, R_dev);
+                     e->Xa.as<double>(), (int)e->A, pi_dev, pj_dev, P, rmsd_dev, maxdev_dev, R_dev);
   return check_launch("k_pairs_exact");
 }
 
@@ -707,18 +799,35 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
           return set_error(FC_E_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", lds_m,
                            hipGetErrorString(err));
       }
+      if (getenv("FC_DEBUG")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, two_blocks ? 256 : 512, lds_m);
+        fprintf(stderr, "[fc] screen_mfma<%d>: LDS %zu B, occupancy API says %d blocks/CU\n",
+                two_blocks ? 4 : 8, lds_m, nb);
+      }
+      int compact = 0;
+      dim3 mgrid = grid;
+      if (e->world == 1 && e->row_block % 64 == 0) {
+        const int64_t r = e->row_block / 64;
+        int64_t nvalid = 0;
+        for (int64_t l = 0; l < n_lblocks; ++l) nvalid += std::max<int64_t>(NT - r * l, 0);
+        if (nvalid > 0 && nvalid < (1ll << 31) && NT - r * (n_lblocks - 1) > 0) {
+          compact = 1;
+          mgrid = dim3((unsigned)nvalid);
+        }
+      }
       if (two_blocks)
-        hipLaunchKernelGGL(k_simbits_screen_mfma<4>, grid, dim3(256), lds_m, ctx().stream,
+        hipLaunchKernelGGL(k_simbits_screen_mfma<4>, mgrid, dim3(256), lds_m, ctx().stream,
                            e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
                            (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                            e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
-                           (unsigned long long)e->pairq_cap);
+                           (unsigned long long)e->pairq_cap, compact);
       else
-        hipLaunchKernelGGL(k_simbits_screen_mfma<8>, grid, dim3(512), lds_m, ctx().stream,
+        hipLaunchKernelGGL(k_simbits_screen_mfma<8>, mgrid, dim3(512), lds_m, ctx().stream,
                            e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
                            (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                            e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
-                           (unsigned long long)e->pairq_cap);
+                           (unsigned long long)e->pairq_cap, compact);
       return check_launch("k_simbits_screen_mfma");
     }
   }
@@ -754,8 +863,9 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
   // persistent-style grid: wavefronts stride over the candidate queue whose
   // length the screen kernel left in counters[4] (same stream, no host sync)
   hipLaunchKernelGGL(k_simbits_refine, dim3((unsigned)(ctx().n_cu * 8)), dim3(256), 0,
-                     ctx().stream, e->Xs.as<double>(), e->N, e->Npad, (int)e->A, max_rmsd, max_dev,
-                     energies_dev, max_dE, (int)e->row_block, e->rank, e->world, e->rows_local,
+                     ctx().stream, e->Xs.as<double>(), e->Xa.as<double>(), e->N, e->Npad, (int)e->A,
+                     max_rmsd, max_dev, energies_dev, max_dE, (int)e->row_block, e->rank, e->world,
+                     e->rows_local,
                      e->bits.as<uint64_t>(), e->W, e->cand.as<uint32_t>(),
                      reinterpret_cast<unsigned long long *>(e->counters.p), e->pairq.as<uint64_t>(),
                      (unsigned long long)e->pairq_cap);

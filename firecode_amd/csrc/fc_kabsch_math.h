@@ -180,4 +180,5 @@ __host__ __device__ __forceinline__ bool kabsch_may_be_below(const double (&B)[9
   return !(P0 > eps);
 }
 
+
 }  // namespace fc
