@@ -41,6 +41,12 @@ int launch_torsion_scan(const double *, int64_t, const int64_t *, int64_t, const
                         const int16_t *, const int16_t *, const int32_t *, const int32_t *,
                         const int64_t *, int64_t, double, int64_t, double *, int64_t *);
 int launch_torsion_fingerprint(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
+int launch_embed_mol_transforms(const double *, int64_t, int64_t, const int64_t *, int, const double *,
+                                const double *, int, const double *, int64_t, double *, double *);
+int launch_embed_pretransform(const double *, int64_t, int64_t, int64_t, const double *,
+                              const double *, int, int64_t, double *);
+int launch_embed_grid_clash(const double *, int64_t, int64_t, int64_t, const double *, int64_t, int64_t,
+                            int64_t, int64_t, double, int64_t, uint8_t *, int32_t *);
 
 // ---- error state / context -----------------------------------------------------
 std::string &last_error() {
@@ -684,6 +690,97 @@ int fc_embed_poses_clash(const double *m1, int64_t n1, int64_t A1, const double 
   if (pass_out) FC_TRY(d2h(pass_out, dp.p, (size_t)P));
   if (poses_out) FC_TRY(d2h(poses_out, dposes.p, (size_t)P * (A1 + A2) * 3 * sizeof(double)));
   return sync();
+}
+
+static int check_embed_mol(const double *m, int64_t n, int64_t A, const int64_t *reactive, int64_t nr,
+                           const double *ps, const double *pe, const double *angles, int64_t na) {
+  FC_REQUIRE(m && reactive && ps && pe && angles, "NULL pointer argument");
+  FC_REQUIRE(n >= 1 && A >= 1 && na >= 1, "bad shape");
+  FC_REQUIRE(nr == 1 || nr == 2, "a molecule has 1 or 2 reactive atoms");
+  for (int64_t k = 0; k < nr; ++k) FC_REQUIRE(reactive[k] >= 0 && reactive[k] < A, "reactive index out of range");
+  return FC_OK;
+}
+
+int fc_embed_mol_transforms(const double *coords, int64_t n, int64_t A, const int64_t *reactive,
+                            int64_t nr, const double *pivot_start, const double *pivot_end,
+                            int64_t mol, const double *angles, int64_t na, double *R_out,
+                            double *t_out) {
+  FC_TRY(check_embed_mol(coords, n, A, reactive, nr, pivot_start, pivot_end, angles, na));
+  FC_REQUIRE((mol == 0 || mol == 1) && R_out && t_out, "bad arguments");
+  FC_TRY(ensure_init());
+  DevBuf dc, dr, dps, dpe, da, dR, dt;
+  FC_TRY(upload(dc, coords, (size_t)n * A * 3));
+  FC_TRY(upload(dr, reactive, (size_t)nr));
+  FC_TRY(upload(dps, pivot_start, (size_t)n * 3));
+  FC_TRY(upload(dpe, pivot_end, (size_t)n * 3));
+  FC_TRY(upload(da, angles, (size_t)na));
+  const size_t G = (size_t)n * 2 * na;
+  FC_TRY(dR.reserve(G * 9 * sizeof(double)));
+  FC_TRY(dt.reserve(G * 3 * sizeof(double)));
+  FC_TRY(launch_embed_mol_transforms(dc.as<double>(), n, A, dr.as<int64_t>(), (int)nr, dps.as<double>(),
+                                     dpe.as<double>(), (int)mol, da.as<double>(), na, dR.as<double>(),
+                                     dt.as<double>()));
+  FC_TRY(d2h(R_out, dR.p, G * 9 * sizeof(double)));
+  FC_TRY(d2h(t_out, dt.p, G * 3 * sizeof(double)));
+  return sync();
+}
+
+int fc_embed_grid_clash(const double *m1, int64_t n1, int64_t A1, const int64_t *reactive1,
+                        int64_t nr1, const double *ps1, const double *pe1, const double *m2,
+                        int64_t n2, int64_t A2, const int64_t *reactive2, int64_t nr2,
+                        const double *ps2, const double *pe2, const double *angles1, int64_t na1,
+                        const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
+                        uint8_t *pass_out, int32_t *counts_out, double *ms_kernel) {
+  FC_TRY(check_embed_mol(m1, n1, A1, reactive1, nr1, ps1, pe1, angles1, na1));
+  FC_TRY(check_embed_mol(m2, n2, A2, reactive2, nr2, ps2, pe2, angles2, na2));
+  FC_REQUIRE(pass_out != nullptr && max_clashes >= 0, "bad arguments");
+  if (A1 * 24 > 64 * 1024) return set_error(FC_E_LIMIT, "A1=%lld too large for the LDS stage", (long long)A1);
+  FC_TRY(ensure_init());
+  Context &c = ctx();
+  const int64_t P = n1 * n2 * 2 * na1 * na2;
+  const int64_t S2 = ceil_div(n2 * na2, 64) * 64;
+  DevBuf d1, d2, r1, r2, s1, e1, s2, e2, a1, a2, R1, t1, R2, t2, X1, X2s, dpass, dcnt;
+  FC_TRY(upload(d1, m1, (size_t)n1 * A1 * 3));
+  FC_TRY(upload(d2, m2, (size_t)n2 * A2 * 3));
+  FC_TRY(upload(r1, reactive1, (size_t)nr1));
+  FC_TRY(upload(r2, reactive2, (size_t)nr2));
+  FC_TRY(upload(s1, ps1, (size_t)n1 * 3));
+  FC_TRY(upload(e1, pe1, (size_t)n1 * 3));
+  FC_TRY(upload(s2, ps2, (size_t)n2 * 3));
+  FC_TRY(upload(e2, pe2, (size_t)n2 * 3));
+  FC_TRY(upload(a1, angles1, (size_t)na1));
+  FC_TRY(upload(a2, angles2, (size_t)na2));
+  const size_t G1 = (size_t)n1 * 2 * na1, G2 = (size_t)n2 * 2 * na2;
+  FC_TRY(R1.reserve(G1 * 9 * sizeof(double)));
+  FC_TRY(t1.reserve(G1 * 3 * sizeof(double)));
+  FC_TRY(R2.reserve(G2 * 9 * sizeof(double)));
+  FC_TRY(t2.reserve(G2 * 3 * sizeof(double)));
+  FC_TRY(X1.reserve(G1 * A1 * 3 * sizeof(double)));
+  FC_TRY(X2s.reserve((size_t)2 * A2 * 3 * S2 * sizeof(double)));
+  FC_TRY(dpass.reserve((size_t)P));
+  if (counts_out) FC_TRY(dcnt.reserve((size_t)P * sizeof(int32_t)));
+  FC_HIP_TRY(hipMemsetAsync(X2s.p, 0, (size_t)2 * A2 * 3 * S2 * sizeof(double), c.stream));
+  FC_TRY(launch_embed_mol_transforms(d1.as<double>(), n1, A1, r1.as<int64_t>(), (int)nr1, s1.as<double>(),
+                                     e1.as<double>(), 0, a1.as<double>(), na1, R1.as<double>(), t1.as<double>()));
+  FC_TRY(launch_embed_mol_transforms(d2.as<double>(), n2, A2, r2.as<int64_t>(), (int)nr2, s2.as<double>(),
+                                     e2.as<double>(), 1, a2.as<double>(), na2, R2.as<double>(), t2.as<double>()));
+  FC_TRY(launch_embed_pretransform(d1.as<double>(), n1, A1, na1, R1.as<double>(), t1.as<double>(), 1, 0,
+                                   X1.as<double>()));
+  FC_TRY(launch_embed_pretransform(d2.as<double>(), n2, A2, na2, R2.as<double>(), t2.as<double>(), 0, S2,
+                                   X2s.as<double>()));
+  FC_HIP_TRY(hipEventRecord(c.ev0, c.stream));
+  FC_TRY(launch_embed_grid_clash(X1.as<double>(), n1, A1, na1, X2s.as<double>(), n2, A2, na2, S2, thresh,
+                                 max_clashes, dpass.as<uint8_t>(), counts_out ? dcnt.as<int32_t>() : nullptr));
+  FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
+  FC_TRY(d2h(pass_out, dpass.p, (size_t)P));
+  if (counts_out) FC_TRY(d2h(counts_out, dcnt.p, (size_t)P * sizeof(int32_t)));
+  FC_TRY(sync());
+  if (ms_kernel) {
+    float ms = 0.f;
+    FC_HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    *ms_kernel = ms;
+  }
+  return FC_OK;
 }
 
 // ---- a17-a20 -----------------------------------------------------------------------

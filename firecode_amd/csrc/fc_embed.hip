@@ -1,0 +1,254 @@
+// fc_embed.hip -- bimolecular rigid ("cyclical") embed on gfx950: pose
+// transforms, pre-transformed conformer tables and the all-pose clash grid.
+//
+// Replaces the pose loop of firecode/embeds.py:597-727
+// (_fast_bimol_rigid_cyclical_embed) up to and including the
+// compenetration_check of embeds.py:718.
+//
+// Observation that shapes the kernels: for molecule i the rigid transform of a
+// pose depends only on (conformer c, orientation o, own step angle) --
+// polygonize() places a segment of the molecule's OWN pivot length on the x
+// axis (firecode/utils.py:265-272), align_vec_pair sees only that molecule's
+// vectors (embeds.py:677-680) and mean(vec_pair) is the origin.  So the
+// n1*n2*2*na1*na2 poses are the cross product of two small tables of
+// pre-transformed structures (n_i * 2 * na_i each), and the clash test is an
+// all-pairs distance count between the tables, restricted to equal o.
+#include "fc_common.h"
+#include "fc_kabsch_math.h"
+
+#include <algorithm>
+
+namespace fc {
+
+double sq_threshold_lt(double t);  // fc_clash.hip
+
+// rot_mat_from_pointer (prism_pruner.algebra): scalar-last quaternion -> matrix
+__device__ __forceinline__ void rot_axis_angle(double ax, double ay, double az, double angle_deg,
+                                               double (&M)[9]) {
+  double a2 = angle_deg / 2.0;
+  a2 *= 3.141592653589793 / 180.0;
+  double sn, cs;
+  sincos(a2, &sn, &cs);
+  const double nrm = sqrt((ax * ax + ay * ay) + az * az);
+  const double q1 = sn * (ax / nrm), q2 = sn * (ay / nrm), q3 = sn * (az / nrm), q0 = cs;
+  M[0] = 2.0 * (q0 * q0 + q1 * q1) - 1.0;
+  M[1] = 2.0 * (q1 * q2 - q0 * q3);
+  M[2] = 2.0 * (q1 * q3 + q0 * q2);
+  M[3] = 2.0 * (q1 * q2 + q0 * q3);
+  M[4] = 2.0 * (q0 * q0 + q2 * q2) - 1.0;
+  M[5] = 2.0 * (q2 * q3 - q0 * q1);
+  M[6] = 2.0 * (q1 * q3 - q0 * q2);
+  M[7] = 2.0 * (q2 * q3 + q0 * q1);
+  M[8] = 2.0 * (q0 * q0 + q3 * q3) - 1.0;
+}
+
+__device__ __forceinline__ void mat_vec(const double (&M)[9], double x, double y, double z,
+                                        double &ox, double &oy, double &oz) {
+  ox = (M[0] * x + M[1] * y) + M[2] * z;
+  oy = (M[3] * x + M[4] * y) + M[5] * z;
+  oz = (M[6] * x + M[7] * y) + M[8] * z;
+}
+
+// one lane per (conformer c, orientation o, angle index ai) of molecule `mol`
+// (0 or 1): R (9) and t (3) exactly as embeds.py:649-709 builds them.
+__global__ void __launch_bounds__(64)
+k_embed_mol_transforms(const double *__restrict__ coords, int64_t n, int64_t A,
+                       const int64_t *__restrict__ reactive, int nr,
+                       const double *__restrict__ piv_start, const double *__restrict__ piv_end,
+                       int mol, const double *__restrict__ angles, int64_t na,
+                       double *__restrict__ R_out, double *__restrict__ t_out) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n * 2 * na) return;
+  const int64_t ai = g % na;
+  const int o = (int)((g / na) % 2);
+  const int64_t c = g / (2 * na);
+  const double *x = coords + c * A * 3;
+  const double sx = piv_start[c * 3], sy = piv_start[c * 3 + 1], sz = piv_start[c * 3 + 2];
+  const double ex = piv_end[c * 3], ey = piv_end[c * 3 + 1], ez = piv_end[c * 3 + 2];
+  // Pivot.pivot = start - end, Pivot.meanpoint = mean((start, end))  (hypermolecule_class.py:329-333)
+  const double pvx = sx - ex, pvy = sy - ey, pvz = sz - ez;
+  const double mx = (sx + ex) / 2.0, my = (sy + ey) / 2.0, mz = (sz + ez) / 2.0;
+  const double norm = sqrt((pvx * pvx + pvy * pvy) + pvz * pvz);
+  // polygonize(): segment (-norm/2,0,0) -> (+norm/2,0,0); orientation 1 flips molecule 1
+  const double sgn = (o == 1 && mol == 1) ? -1.0 : 1.0;
+  const double esx = sgn * norm;  // end - start, x component (y = z = 0)
+  const double diry = (mol == 0) ? 1.0 : -1.0;
+  // mean position of the reactive atoms
+  double ax = 0.0, ay = 0.0, az = 0.0;
+  for (int k = 0; k < nr; ++k) {
+    const int64_t r = reactive[k];
+    ax += x[r * 3];
+    ay += x[r * 3 + 1];
+    az += x[r * 3 + 2];
+  }
+  ax /= (double)nr;
+  ay /= (double)nr;
+  az /= (double)nr;
+  double dx = mx - ax, dy = my - ay, dz = mz - az;
+  if (dx == 0.0 && dy == 0.0 && dz == 0.0) {
+    dx = mx;
+    dy = my;
+    dz = mz;
+  }
+  // align_vec_pair(ref = [end-start, direction], tgt = [pivot, mol_direction])
+  double B[9];
+  // B[x][y] = sum_j ref[j][x] * tgt[j][y] with ref = [(esx,0,0), (0,diry,0)]
+  B[0] = esx * pvx;  B[1] = esx * pvy;  B[2] = esx * pvz;
+  B[3] = diry * dx;  B[4] = diry * dy;  B[5] = diry * dz;
+  B[6] = 0.0;        B[7] = 0.0;        B[8] = 0.0;
+  double Al[9];
+  (void)kabsch_rotation(B, Al);
+  // axis of the step rotation
+  double ux, uy, uz;
+  if (nr == 2) {
+    const int64_t r0 = reactive[0], r1 = reactive[1];
+    mat_vec(Al, x[r0 * 3] - x[r1 * 3], x[r0 * 3 + 1] - x[r1 * 3 + 1], x[r0 * 3 + 2] - x[r1 * 3 + 2],
+            ux, uy, uz);
+  } else {
+    mat_vec(Al, pvx, pvy, pvz, ux, uy, uz);
+  }
+  double St[9];
+  rot_axis_angle(ux, uy, uz, angles[ai], St);
+  double cx, cy, cz;
+  mat_vec(Al, ax, ay, az, cx, cy, cz);  // center_of_rotation
+  double R[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      R[r * 3 + q] = (St[r * 3] * Al[q] + St[r * 3 + 1] * Al[3 + q]) + St[r * 3 + 2] * Al[6 + q];
+  double px, py, pz;
+  mat_vec(Al, mx, my, mz, px, py, pz);  // pos = mean(vec_pair) - Al @ meanpoint = 0 - ...
+  double scx, scy, scz;
+  mat_vec(St, cx, cy, cz, scx, scy, scz);
+  double *Ro = R_out + g * 9, *to = t_out + g * 3;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Ro[k] = R[k];
+  to[0] = (cx - scx) + (0.0 - px);
+  to[1] = (cy - scy) + (0.0 - py);
+  to[2] = (cz - scz) + (0.0 - pz);
+}
+
+// table of pre-transformed structures: out[g][a] = (R_g @ x_a) + t_g, g = (c, o, ai)
+// aos != 0: out[g][a][3];  else conformer-minor per orientation:
+// out[((o*A + a)*3 + k)*S + (c*na + ai)],  S = n*na rounded up to 64
+__global__ void __launch_bounds__(256)
+k_embed_pretransform(const double *__restrict__ coords, int64_t n, int64_t A, int64_t na,
+                     const double *__restrict__ R, const double *__restrict__ t, int aos,
+                     int64_t S, double *__restrict__ out) {
+  const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tix >= n * 2 * na * A) return;
+  const int64_t a = tix % A;
+  const int64_t g = tix / A;
+  const int64_t ai = g % na;
+  const int o = (int)((g / na) % 2);
+  const int64_t c = g / (2 * na);
+  const double *x = coords + (c * A + a) * 3;
+  const double *r = R + g * 9, *tt = t + g * 3;
+  const double ox = ((r[0] * x[0] + r[1] * x[1]) + r[2] * x[2]) + tt[0];
+  const double oy = ((r[3] * x[0] + r[4] * x[1]) + r[5] * x[2]) + tt[1];
+  const double oz = ((r[6] * x[0] + r[7] * x[1]) + r[8] * x[2]) + tt[2];
+  if (aos) {
+    out[(g * A + a) * 3] = ox;
+    out[(g * A + a) * 3 + 1] = oy;
+    out[(g * A + a) * 3 + 2] = oz;
+  } else {
+    const int64_t s = c * na + ai;
+    out[((o * A + a) * 3 + 0) * S + s] = ox;
+    out[((o * A + a) * 3 + 1) * S + s] = oy;
+    out[((o * A + a) * 3 + 2) * S + s] = oz;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_embed_grid_clash: all poses.  Workgroup = one pre-transformed structure of
+// molecule 1 (c1, o, a1) staged in LDS x a strip of molecule-2 structures of
+// the same orientation; lane = one molecule-2 structure (conformer-minor
+// layout: coalesced 512-byte loads per atom coordinate), atoms of molecule 1
+// arrive as LDS broadcasts.  A lane stops counting once it exceeds max_clashes.
+// pose index (reference loop order, embeds.py:597-647 with cartesian_product's
+// "second argument slowest" order):
+//   p = ((c2*n1 + c1)*2 + o) * (na1*na2) + (a2*na1 + a1)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_embed_grid_clash(const double *__restrict__ X1, int64_t n1, int A1, int64_t na1,
+                   const double *__restrict__ X2s, int64_t n2, int A2, int64_t na2, int64_t S2,
+                   double thr2, int max_clashes, int strips, uint8_t *__restrict__ pass,
+                   int32_t *__restrict__ counts) {
+  extern __shared__ double s[];
+  const int tid = threadIdx.x;
+  const int64_t g1 = blockIdx.x;  // (c1, o, a1)
+  const int64_t a1 = g1 % na1;
+  const int o = (int)((g1 / na1) % 2);
+  const int64_t c1 = g1 / (2 * na1);
+  for (int k = tid; k < A1 * 3; k += 256) s[k] = X1[g1 * (int64_t)A1 * 3 + k];
+  __syncthreads();
+  const int64_t n_s2 = n2 * na2;
+  const double *__restrict__ base2 = X2s + (int64_t)o * A2 * 3 * S2;
+  for (int64_t s2 = (int64_t)blockIdx.y * 256 + tid; s2 < S2; s2 += (int64_t)strips * 256) {
+    const bool on = s2 < n_s2;
+    int cnt = 0;
+    for (int b = 0; b < A2; ++b) {
+      const double bx = base2[(int64_t)(b * 3 + 0) * S2 + s2];
+      const double by = base2[(int64_t)(b * 3 + 1) * S2 + s2];
+      const double bz = base2[(int64_t)(b * 3 + 2) * S2 + s2];
+      if (cnt <= max_clashes) {
+        for (int a = 0; a < A1; ++a) {
+          const double dx = bx - s[a * 3], dy = by - s[a * 3 + 1], dz = bz - s[a * 3 + 2];
+          const double d2 = ((dx * dx) + dy * dy) + dz * dz;
+          cnt += (d2 < thr2) ? 1 : 0;
+        }
+      }
+      // whole wave past the limit: nothing left to learn
+      if (__all(cnt > max_clashes || !on)) break;
+    }
+    if (on) {
+      const int64_t c2 = s2 / na2, a2 = s2 % na2;
+      const int64_t p = ((c2 * n1 + c1) * 2 + o) * (na1 * na2) + (a2 * na1 + a1);
+      pass[p] = (cnt <= max_clashes) ? 1 : 0;
+      if (counts) counts[p] = cnt;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+int launch_embed_mol_transforms(const double *coords_dev, int64_t n, int64_t A,
+                                const int64_t *reactive_dev, int nr, const double *ps_dev,
+                                const double *pe_dev, int mol, const double *angles_dev, int64_t na,
+                                double *R_dev, double *t_dev) {
+  const int64_t total = n * 2 * na;
+  if (total == 0) return FC_OK;
+  hipLaunchKernelGGL(k_embed_mol_transforms, dim3((unsigned)ceil_div(total, 64)), dim3(64), 0,
+                     ctx().stream, coords_dev, n, A, reactive_dev, nr, ps_dev, pe_dev, mol,
+                     angles_dev, na, R_dev, t_dev);
+  return check_launch("k_embed_mol_transforms");
+}
+
+int launch_embed_pretransform(const double *coords_dev, int64_t n, int64_t A, int64_t na,
+                              const double *R_dev, const double *t_dev, int aos, int64_t S,
+                              double *out_dev) {
+  const int64_t total = n * 2 * na * A;
+  if (total == 0) return FC_OK;
+  hipLaunchKernelGGL(k_embed_pretransform, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
+                     ctx().stream, coords_dev, n, A, na, R_dev, t_dev, aos, S, out_dev);
+  return check_launch("k_embed_pretransform");
+}
+
+int launch_embed_grid_clash(const double *X1_dev, int64_t n1, int64_t A1, int64_t na1,
+                            const double *X2s_dev, int64_t n2, int64_t A2, int64_t na2, int64_t S2,
+                            double thresh, int64_t max_clashes, uint8_t *pass_dev,
+                            int32_t *counts_dev) {
+  const int64_t g1 = n1 * 2 * na1;
+  if (g1 == 0 || n2 * na2 == 0) return FC_OK;
+  const double thr2 = sq_threshold_lt(thresh);
+  int64_t strips = ceil_div(S2, 256);
+  // enough workgroups to fill the chip, few enough that the LDS stage is amortised
+  const int64_t want = ceil_div((int64_t)ctx().n_cu * 16, g1);
+  if (strips > want) strips = std::max<int64_t>(want, 1);
+  hipLaunchKernelGGL(k_embed_grid_clash, dim3((unsigned)g1, (unsigned)strips), dim3(256),
+                     (size_t)A1 * 3 * sizeof(double), ctx().stream, X1_dev, n1, (int)A1, na1, X2s_dev,
+                     n2, (int)A2, na2, S2, thr2, (int)max_clashes, (int)strips, pass_dev, counts_dev);
+  return check_launch("k_embed_grid_clash");
+}
+
+}  // namespace fc

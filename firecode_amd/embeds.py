@@ -45,3 +45,51 @@ def embed_poses_clash(m1, m2, c1, c2, R1, t1, R2, t2, thresh=1.5, max_clashes=0,
     if return_poses:
         return ok.astype(bool), counts, poses
     return ok.astype(bool), counts
+
+
+def _mol_args(coords, reactive, pivots):
+    X = L.f64(coords)
+    r = L.i64(reactive).reshape(-1)
+    pv = L.f64(pivots)
+    if X.ndim != 3 or X.shape[2] != 3 or pv.shape != (X.shape[0], 2, 3) or r.shape[0] not in (1, 2):
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "coords (n, A, 3), reactive (1|2,), pivots (n, 2, 3) expected")
+    return X, r, np.ascontiguousarray(pv[:, 0]), np.ascontiguousarray(pv[:, 1])
+
+
+def embed_mol_transforms(coords, reactive, pivots, mol, angles):
+    """Per-molecule pose transforms of the bimolecular cyclical embed
+    (embeds.py:649-709): R (n, 2, na, 3, 3), t (n, 2, na, 3) over (conformer,
+    orientation, step angle).  pivots[c] = (start, end) of the conformer's pivot."""
+    X, r, ps, pe = _mol_args(coords, reactive, pivots)
+    ang = L.f64(angles).reshape(-1)
+    n, na = X.shape[0], ang.shape[0]
+    R = np.empty((n, 2, na, 3, 3))
+    t = np.empty((n, 2, na, 3))
+    L.call("fc_embed_mol_transforms", L.pf(X), n, X.shape[1], L.pi(r), r.shape[0], L.pf(ps), L.pf(pe),
+           int(mol), L.pf(ang), na, L.pf(R), L.pf(t))
+    return R, t
+
+
+def embed_grid_clash(m1, reactive1, pivots1, m2, reactive2, pivots2, angles1, angles2=None,
+                     thresh=1.5, max_clashes=0, return_counts=False):
+    """Every pose of the bimolecular rigid embed at once (the loop of
+    embeds.py:597-722 for one pivot per conformer, up to the clash test).
+    Returns pass (n2, n1, 2, na2, na1) bool -- index [c2, c1, o, a2, a1], the
+    reference's iteration order flattened -- and the kernel time in ms."""
+    import ctypes as C
+
+    X1, r1, ps1, pe1 = _mol_args(m1, reactive1, pivots1)
+    X2, r2, ps2, pe2 = _mol_args(m2, reactive2, pivots2)
+    a1 = L.f64(angles1).reshape(-1)
+    a2 = a1 if angles2 is None else L.f64(angles2).reshape(-1)
+    shape = (X2.shape[0], X1.shape[0], 2, a2.shape[0], a1.shape[0])
+    ok = np.zeros(shape, dtype=np.uint8)
+    counts = np.zeros(shape, dtype=np.int32) if return_counts else None
+    ms = C.c_double(0)
+    L.call("fc_embed_grid_clash", L.pf(X1), X1.shape[0], X1.shape[1], L.pi(r1), r1.shape[0], L.pf(ps1), L.pf(pe1),
+           L.pf(X2), X2.shape[0], X2.shape[1], L.pi(r2), r2.shape[0], L.pf(ps2), L.pf(pe2),
+           L.pf(a1), a1.shape[0], L.pf(a2), a2.shape[0], float(thresh), int(max_clashes), L.pb(ok),
+           None if counts is None else counts.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms))
+    if return_counts:
+        return ok.astype(bool), counts, ms.value
+    return ok.astype(bool), ms.value

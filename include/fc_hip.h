@@ -156,6 +156,26 @@ int fc_embed_poses_clash(const double *m1, int64_t n1, int64_t A1, const double 
                          const double *t2, int64_t P, double thresh, int64_t max_clashes,
                          int64_t *counts_out, uint8_t *pass_out, double *poses_out);
 
+/* Whole bimolecular rigid-embed grid (embeds.py:597-722 for one pivot per
+ * conformer): molecule i has n_i conformers of A_i atoms, nr_i (1 or 2)
+ * reactive atom indices, one pivot (start, end 3-vectors) per conformer and
+ * na_i step angles (degrees).  fc_embed_mol_transforms returns the per-
+ * molecule tables R (n,2,na,3,3), t (n,2,na,3) over (conformer, orientation,
+ * angle); fc_embed_grid_clash tests every pose
+ *   p = ((c2*n1 + c1)*2 + o)*(na1*na2) + (a2*na1 + a1)
+ * (the reference's loop order) and writes pass_out[p] = count(d < thresh) <=
+ * max_clashes; counts_out (may be NULL) saturates just above max_clashes. */
+int fc_embed_mol_transforms(const double *coords, int64_t n, int64_t A, const int64_t *reactive,
+                            int64_t nr, const double *pivot_start, const double *pivot_end,
+                            int64_t mol, const double *angles, int64_t na, double *R_out,
+                            double *t_out);
+int fc_embed_grid_clash(const double *m1, int64_t n1, int64_t A1, const int64_t *reactive1,
+                        int64_t nr1, const double *ps1, const double *pe1, const double *m2,
+                        int64_t n2, int64_t A2, const int64_t *reactive2, int64_t nr2,
+                        const double *ps2, const double *pe2, const double *angles1, int64_t na1,
+                        const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
+                        uint8_t *pass_out, int32_t *counts_out, double *ms_kernel);
+
 /* ---- a17-a19: torsion scan -- firecode/torsion_module.py:812-856
  * (clustered_csearch inner loops) with rotate_dihedral (prism_pruner.utils)
  * and torsion_comp_check (torsion_module.py:894-918).

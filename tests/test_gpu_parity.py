@@ -378,3 +378,66 @@ def test_sharded_prune_all_ranks_on_one_gpu(fc, world, row_block):
     for ens in ranks:
         ens.close()
     assert np.array_equal(mask.astype(bool), ref)
+
+
+# ---------------------------------------------------------------- a14: bimolecular embed grid
+def _embed_case(seed, n1=3, n2=4, A1=14, A2=11, nr1=2, nr2=1):
+    rng = np.random.default_rng(seed)
+    m1 = rng.normal(scale=1.8, size=(n1, A1, 3))
+    m2 = rng.normal(scale=1.8, size=(n2, A2, 3))
+    r1 = rng.choice(A1, nr1, replace=False)
+    r2 = rng.choice(A2, nr2, replace=False)
+    # pivots: two pseudo-orbital centres near the reactive atoms, pushed outwards
+    def pivots(m, r):
+        out = np.empty((len(m), 2, 3))
+        for c, x in enumerate(m):
+            ra = x[r[0]]
+            rb = x[r[-1]]
+            out[c, 0] = ra * 1.6 + rng.normal(scale=0.3, size=3)
+            out[c, 1] = rb * 1.6 + rng.normal(scale=0.3, size=3) + (0 if len(r) == 2 else 1.2)
+        return out
+    return m1, r1, pivots(m1, r1), m2, r2, pivots(m2, r2)
+
+
+@pytest.mark.parametrize("seed,nr1,nr2", [(61, 2, 1), (62, 1, 1), (63, 2, 2)])
+def test_embed_grid_vs_oracle(fc, seed, nr1, nr2):
+    m1, r1, pv1, m2, r2, pv2 = _embed_case(seed, nr1=nr1, nr2=nr2)
+    steps, rr = 3, 45.0
+    angles = np.arange(steps + 1) * 2 * rr / steps - rr
+    R1, t1 = fc.embeds.embed_mol_transforms(m1, r1, pv1, 0, angles)
+    R2, t2 = fc.embeds.embed_mol_transforms(m2, r2, pv2, 1, angles)
+    ok, counts, ms = fc.embeds.embed_grid_clash(m1, r1, pv1, m2, r2, pv2, angles, thresh=1.5,
+                                                max_clashes=0, return_counts=True)
+    assert ok.shape == (len(m2), len(m1), 2, len(angles), len(angles))
+    # the reference's loop order: conf pairs (second molecule slowest), orientation, angle pairs
+    conf_ids = o.cartesian_product(range(len(m1)), range(len(m2)))
+    ang_ids = o.cartesian_product(range(steps + 1), range(steps + 1))
+    ref_ok = np.zeros_like(ok)
+    ref_cnt = np.zeros(ok.shape, dtype=np.int64)
+    worst_R = worst_t = 0.0
+    for c1, c2 in conf_ids:
+        for ori in (0, 1):
+            for i1, i2 in ang_ids:
+                Ra, ta, Rb, tb = o.bimol_pose_transforms(m1[c1], m2[c2], r1, r2, pv1[c1], pv2[c2],
+                                                         (angles[i1], angles[i2]), ori)
+                worst_R = max(worst_R, np.abs(Ra - R1[c1, ori, i1]).max(), np.abs(Rb - R2[c2, ori, i2]).max())
+                worst_t = max(worst_t, np.abs(ta - t1[c1, ori, i1]).max(), np.abs(tb - t2[c2, ori, i2]).max())
+                pose = o.get_embed([m1[c1], m2[c2]], [Ra, Rb], [ta, tb])
+                ref_ok[c2, c1, ori, i2, i1] = o.compenetration_check(pose, ids=[m1.shape[1], m2.shape[1]],
+                                                                     thresh=1.5)
+                from scipy.spatial.distance import cdist
+                ref_cnt[c2, c1, ori, i2, i1] = np.count_nonzero(cdist(pose[m1.shape[1]:], pose[:m1.shape[1]]) < 1.5)
+    assert worst_R < TOL and worst_t < TOL
+    assert np.array_equal(ok, ref_ok)
+    assert 0 < ok.sum() < ok.size
+    # flattened index == reference iteration order
+    flat = ok.reshape(-1)
+    k = 0
+    for c1, c2 in conf_ids[:3]:
+        for ori in (0, 1):
+            for i1, i2 in ang_ids:
+                assert flat[((c2 * len(m1) + c1) * 2 + ori) * len(ang_ids) + (i2 * (steps + 1) + i1)] == \
+                    ref_ok[c2, c1, ori, i2, i1]
+    ok3, _ = fc.embeds.embed_grid_clash(m1, r1, pv1, m2, r2, pv2, angles, thresh=1.5, max_clashes=3)
+    assert np.array_equal(ok3, ref_cnt <= 3) and ok3.sum() > ok.sum()
+    assert np.array_equal(np.minimum(counts, 1), np.minimum(ref_cnt, 1))  # counts saturate past max_clashes
