@@ -70,6 +70,8 @@ _SIGNATURES = {
     "fc_rototranslate": [_p_f64, _i64, _i64, _p_f64, _p_f64, _p_f64],
     "fc_clash_self": [_p_f64, _i64, _i64, _f64, _f64, _p_i64],
     "fc_clash_fragments": [_p_f64, _i64, _i64, _p_i64, _i64, _f64, _i64, _p_i64, _p_u8],
+    "fc_clash_graph": [_p_f64, _i64, _i64, _p_u8, _f64, _p_i64],
+    "fc_fitness_check": [_p_f64, _i64, _i64, _p_i64, _p_f64, _i64, _f64, _p_f64, _p_u8],
     "fc_embed_poses_clash": [_p_f64, _i64, _i64, _p_f64, _i64, _i64, _p_i64, _p_i64, _p_f64, _p_f64,
                              _p_f64, _p_f64, _i64, _f64, _i64, _p_i64, _p_u8, _p_f64],
     "fc_embed_mol_transforms": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64, _p_f64, _i64, _p_f64, _i64, _p_f64, _p_f64],

@@ -33,6 +33,9 @@ int launch_clash_self(const double *, int64_t, int64_t, double, double, int64_t 
 int launch_clash_fragments(const double *, int64_t, int64_t, const int64_t *, int64_t, double,
                            int64_t, int64_t *, uint8_t *);
 int launch_rototranslate(const double *, int64_t, int64_t, const double *, const double *, double *);
+int launch_clash_graph(const double *, int64_t, int64_t, const uint8_t *, double, int64_t *);
+int launch_fitness(const double *, int64_t, int64_t, const int64_t *, const double *, int64_t, double,
+                   double *, uint8_t *);
 int launch_embed_poses_clash(const double *, int64_t, const double *, int64_t, const int64_t *,
                              const int64_t *, const double *, const double *, const double *,
                              const double *, int64_t, double, int64_t, int64_t *, uint8_t *,
@@ -652,6 +655,44 @@ int fc_clash_fragments(const double *coords, int64_t N, int64_t A, const int64_t
                                 dn.as<int64_t>(), dp.as<uint8_t>()));
   if (counts_out) FC_TRY(d2h(counts_out, dn.p, (size_t)N * sizeof(int64_t)));
   if (pass_out) FC_TRY(d2h(pass_out, dp.p, (size_t)N));
+  return sync();
+}
+
+int fc_clash_graph(const double *coords, int64_t N, int64_t A, const uint8_t *adj, double thresh,
+                   int64_t *counts_out) {
+  FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(coords && adj && counts_out, "NULL pointer argument");
+  FC_REQUIRE(thresh > 0.0, "thresh must be positive");
+  if (A > kMaxLdsAtoms) return set_error(FC_E_LIMIT, "A=%lld exceeds %lld atoms", (long long)A, (long long)kMaxLdsAtoms);
+  FC_TRY(ensure_init());
+  DevBuf dc, da, dn;
+  FC_TRY(upload(dc, coords, (size_t)N * A * 3));
+  FC_TRY(upload(da, adj, (size_t)A * A));
+  FC_TRY(dn.reserve((size_t)N * sizeof(int64_t)));
+  FC_TRY(launch_clash_graph(dc.as<double>(), N, A, da.as<uint8_t>(), thresh, dn.as<int64_t>()));
+  FC_TRY(d2h(counts_out, dn.p, (size_t)N * sizeof(int64_t)));
+  return sync();
+}
+
+int fc_fitness_check(const double *coords, int64_t N, int64_t A, const int64_t *pairs,
+                     const double *targets, int64_t C, double threshold, double *error_out,
+                     uint8_t *pass_out) {
+  FC_REQUIRE(N >= 0 && A >= 1 && C >= 0, "bad shape");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(coords && pass_out && (C == 0 || (pairs && targets)), "NULL pointer argument");
+  for (int64_t k = 0; k < N * C * 2; ++k) FC_REQUIRE(pairs[k] >= 0 && pairs[k] < A, "constraint index out of range");
+  FC_TRY(ensure_init());
+  DevBuf dc, dp, dt, de, dm;
+  FC_TRY(upload(dc, coords, (size_t)N * A * 3));
+  FC_TRY(upload(dp, pairs, (size_t)N * C * 2));
+  FC_TRY(upload(dt, targets, (size_t)N * C));
+  FC_TRY(de.reserve((size_t)N * sizeof(double)));
+  FC_TRY(dm.reserve((size_t)N));
+  FC_TRY(launch_fitness(dc.as<double>(), N, A, dp.as<int64_t>(), dt.as<double>(), C, threshold,
+                        de.as<double>(), dm.as<uint8_t>()));
+  if (error_out) FC_TRY(d2h(error_out, de.p, (size_t)N * sizeof(double)));
+  FC_TRY(d2h(pass_out, dm.p, (size_t)N));
   return sync();
 }
 

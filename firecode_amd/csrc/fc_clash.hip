@@ -118,6 +118,59 @@ k_clash_fragments(const double *__restrict__ coords, int64_t N, int A, int n0, i
 }
 
 // ---------------------------------------------------------------------------
+// compenetration_check(graph=...) -- firecode/utils.py:528-542.  The
+// reference walks argwhere(dist < thresh) in row-major order, tests
+// `clashes > max_clashes` BEFORE looking at a pair and counts ordered,
+// non-bonded, off-diagonal pairs.  The list always ends with the diagonal
+// element (A-1, A-1) (distance 0 < thresh), which is never counted, so the
+// early-exit test is reached once more after the last counted pair: the
+// function returns  count <= max_clashes  -- no off-by-one survives.
+// adj: A x A bytes, adj[i*A + j] != 0 when i-j is a bond.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_clash_graph(const double *__restrict__ coords, int64_t N, int A, const uint8_t *__restrict__ adj,
+              double thr2, int64_t *__restrict__ counts) {
+  extern __shared__ double s[];
+  const int64_t n = blockIdx.x;
+  const int lane = threadIdx.x;
+  const double *x = coords + n * (int64_t)A * 3;
+  for (int k = lane; k < A * 3; k += 64) s[k] = x[k];
+  __syncthreads();
+  int cnt = 0;
+  for (int a = lane; a < A; a += 64) {
+    const double ax = s[a * 3], ay = s[a * 3 + 1], az = s[a * 3 + 2];
+    for (int b = a + 1; b < A; ++b) {
+      const double d2 = dist2(ax, ay, az, s[b * 3], s[b * 3 + 1], s[b * 3 + 2]);
+      cnt += (d2 < thr2 && !adj[a * A + b]) ? 1 : 0;
+    }
+  }
+  cnt = wave_sum(cnt);
+  if (lane == 0) counts[n] = 2 * (int64_t)cnt;  // (i1,i2) and (i2,i1) are both visited
+}
+
+// fitness_check (firecode/optimization_methods.py:163-180): sum over constraints
+// of (|x_a - x_b| - target) < threshold; one lane per structure.
+// pairs (N, C, 2) int64, targets (N, C) with NaN = "None" (skipped).
+__global__ void __launch_bounds__(256)
+k_fitness(const double *__restrict__ coords, int64_t N, int64_t A, const int64_t *__restrict__ pairs,
+          const double *__restrict__ targets, int64_t C, double threshold,
+          double *__restrict__ error_out, uint8_t *__restrict__ pass) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const double *x = coords + n * A * 3;
+  double err = 0.0;
+  for (int64_t c = 0; c < C; ++c) {
+    const double tgt = targets[n * C + c];
+    if (tgt != tgt) continue;  // NaN: no target for this constraint
+    const int64_t a = pairs[(n * C + c) * 2], b = pairs[(n * C + c) * 2 + 1];
+    const double dx = x[a * 3] - x[b * 3], dy = x[a * 3 + 1] - x[b * 3 + 1], dz = x[a * 3 + 2] - x[b * 3 + 2];
+    err += sqrt((dx * dx + dy * dy) + dz * dz) - tgt;
+  }
+  if (error_out) error_out[n] = err;
+  pass[n] = (err < threshold) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
 // get_embed: out[k][a] = ((R0*x + R1*y) + R2*z) + t  -- one lane per atom,
 // R/t of a block are wave-uniform.
 // ---------------------------------------------------------------------------
@@ -232,6 +285,23 @@ int launch_clash_fragments(const double *coords_dev, int64_t N, int64_t A, const
                      (int)ids[0], (int)ids[1], n_ids == 3 ? (int)ids[2] : 0, (int)n_ids, thr2,
                      max_clashes, counts_dev, pass_dev);
   return check_launch("k_clash_fragments");
+}
+
+int launch_clash_graph(const double *coords_dev, int64_t N, int64_t A, const uint8_t *adj_dev,
+                       double thresh, int64_t *counts_dev) {
+  if (N == 0) return FC_OK;
+  hipLaunchKernelGGL(k_clash_graph, dim3((unsigned)N), dim3(64), (size_t)A * 3 * sizeof(double),
+                     ctx().stream, coords_dev, N, (int)A, adj_dev, sq_threshold_lt(thresh), counts_dev);
+  return check_launch("k_clash_graph");
+}
+
+int launch_fitness(const double *coords_dev, int64_t N, int64_t A, const int64_t *pairs_dev,
+                   const double *targets_dev, int64_t C, double threshold, double *err_dev,
+                   uint8_t *pass_dev) {
+  if (N == 0) return FC_OK;
+  hipLaunchKernelGGL(k_fitness, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx().stream,
+                     coords_dev, N, A, pairs_dev, targets_dev, C, threshold, err_dev, pass_dev);
+  return check_launch("k_fitness");
 }
 
 int launch_rototranslate(const double *coords_dev, int64_t n, int64_t A, const double *R_dev,

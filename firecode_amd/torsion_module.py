@@ -105,3 +105,38 @@ def prune_conformers_tfd(structures, quadruplets, thresh=10, verbose=False):
                     for i in set(group) - {group[0]}:
                         final_mask[i + lo] = 0
     return structures[final_mask], final_mask
+
+
+def most_diverse_conformers(n, structures, seed=None):
+    """firecode/torsion_module.py:574-586: a RANDOM subsample of n structures
+    (with replacement, sorted indices).  The reference draws from the global,
+    unseeded NumPy RNG; pass ``seed`` for a reproducible draw."""
+    rng = np.random if seed is None else np.random.RandomState(seed)
+    indices = np.sort(rng.choice(len(structures), size=n))
+    return [structures[i] for i in indices]
+
+
+def clustered_csearch(coords, torsions, rotation_masks, n_out=100, thresh=1.5, seed=None, logfunction=None):
+    """Numeric core of ``clustered_csearch`` (torsion_module.py:726-891) for one
+    torsion group: ``torsions`` = sequence of (i1, i2, i3, i4, n_fold),
+    ``rotation_masks`` = the matching ``_get_rotation_mask`` arrays (graph
+    perception stays with the caller).  Generates the n-fold angle grid in the
+    reference's ``cartesian_product`` order, scans it on the GPU, keeps the
+    starting structure plus every conformer with at least one rotated bond,
+    TFD-prunes on the torsion quadruplets and subsamples to ``n_out``."""
+    from firecode_amd.utils import cartesian_product
+
+    n_fold_angles = {2: (0, 180), 3: (0, 120, 240), 4: (0, 90, 180, 270), 6: (0, 60, 120, 180, 240, 300)}
+    quads = np.array([t[:4] for t in torsions], dtype=np.int64)
+    angles = cartesian_product(*[n_fold_angles[int(t[4])] for t in torsions])
+    base = L.f64(coords)
+    out, rot = torsion_scan(base, quads, rotation_masks, angles, thresh=thresh)
+    new_structures = np.concatenate([base[None], out[rot != 0]])
+    if logfunction is not None:
+        logfunction(f"> Group 1/1 - {len(torsions)} bonds, {[int(t[4]) for t in torsions]} n-folds, "
+                    f"1 starting point = {len(angles)} conformers")
+    pruned, _ = prune_conformers_tfd(new_structures, quads)
+    output = list(pruned)
+    if len(new_structures) > n_out:
+        output = most_diverse_conformers(n_out, output, seed=seed)
+    return np.array(output)

@@ -40,13 +40,30 @@ def rmsd_similarity(ref, structures, rmsd_thr=0.5):
     return bool(np.any((r < rmsd_thr) & (m < 2 * rmsd_thr)))
 
 
-def compenetration_check_batch(structures, ids=None, thresh=1.0, max_clashes=0):
-    """Per-structure ``compenetration_check`` (no graph) -> bool (N,)."""
+def _adjacency(graph, n_atoms):
+    """(A, A) byte adjacency from a networkx graph or an iterable of (i, j) bonds."""
+    adj = np.zeros((n_atoms, n_atoms), dtype=np.uint8)
+    edges = graph.edges if hasattr(graph, "edges") else graph
+    for i, j in edges:
+        adj[int(i), int(j)] = 1
+        adj[int(j), int(i)] = 1
+    return adj
+
+
+def compenetration_check_batch(structures, graph=None, ids=None, thresh=1.0, max_clashes=0):
+    """Per-structure ``compenetration_check`` -> bool (N,).  ``graph``: networkx
+    graph or iterable of bonds, used only when ``ids`` is None (utils.py:522-542)."""
     X = L.f64(structures)
     if X.ndim != 3 or X.shape[2] != 3:
         raise L.FirecodeHipInputError(L.FC_E_INVALID, f"structures must be (N, A, 3), got {X.shape}")
     if ids is None:
-        return count_clashes_batch(X) <= max_clashes
+        ok = count_clashes_batch(X) <= max_clashes
+        if graph is None:
+            return ok
+        counts = np.zeros(X.shape[0], dtype=np.int64)
+        adj = _adjacency(graph, X.shape[1])
+        L.call("fc_clash_graph", L.pf(X), X.shape[0], X.shape[1], L.pb(adj), float(thresh), L.pi(counts))
+        return ok & (counts <= max_clashes)
     ids = L.i64(ids)
     if ids.shape[0] not in (2, 3):
         raise L.FirecodeHipInputError(L.FC_E_INVALID, "ids must list 2 or 3 fragment lengths")
@@ -57,13 +74,35 @@ def compenetration_check_batch(structures, ids=None, thresh=1.0, max_clashes=0):
 
 
 def compenetration_check(coords, graph=None, ids=None, thresh=1.0, max_clashes=0):
-    """firecode/utils.py:507-575.  Fragment modes and the graph-less mode run on
-    the GPU; the graph mode (bond list filtering, utils.py:533-542) is outside
-    the round-1 scope and raises."""
-    if ids is None and graph is not None:
-        raise NotImplementedError("compenetration_check(graph=...) is not part of the GPU path yet")
-    return bool(compenetration_check_batch(L.f64(coords)[None], ids=ids, thresh=thresh,
+    """firecode/utils.py:507-575 -- all three modes on the GPU."""
+    return bool(compenetration_check_batch(L.f64(coords)[None], graph=graph, ids=ids, thresh=thresh,
                                            max_clashes=max_clashes)[0])
+
+
+def fitness_check_batch(structures, constraints, targets, threshold):
+    """``fitness_check`` (optimization_methods.py:163-180) for N structures:
+    constraints (N, C, 2) or (C, 2); targets (N, C) or (C,), ``None``/NaN = no
+    target.  Returns (pass (N,) bool, error (N,))."""
+    X = L.f64(structures)
+    N = X.shape[0]
+    cons = L.i64(constraints)
+    if cons.ndim == 2:
+        cons = np.ascontiguousarray(np.broadcast_to(cons, (N,) + cons.shape))
+    tg = np.array([[np.nan if t is None else t for t in row] for row in np.atleast_2d(np.asarray(targets, dtype=object))],
+                  dtype=np.float64)
+    if tg.shape[0] == 1 and N != 1:
+        tg = np.broadcast_to(tg, (N, tg.shape[1]))
+    tg = np.ascontiguousarray(tg)
+    C = cons.shape[1]
+    ok = np.zeros(N, dtype=np.uint8)
+    err = np.zeros(N)
+    L.call("fc_fitness_check", L.pf(X), N, X.shape[1], L.pi(cons), L.pf(tg), C, float(threshold), L.pf(err), L.pb(ok))
+    return ok.astype(bool), err
+
+
+def fitness_check(coords, constraints, targets, threshold):
+    ok, _ = fitness_check_batch(L.f64(coords)[None], L.i64(constraints).reshape(-1, 2), [list(targets)], threshold)
+    return bool(ok[0])
 
 
 def rotate_dihedral(coords, dihedral, angle, mask=None, indices_to_be_moved=None):

@@ -145,6 +145,17 @@ int fc_clash_fragments(const double *coords, int64_t N, int64_t A, const int64_t
                        int64_t n_ids, double thresh, int64_t max_clashes,
                        int64_t *counts_out, uint8_t *pass_out);
 
+/* graph mode of compenetration_check (utils.py:528-542): ordered, off-diagonal,
+ * NON-BONDED pairs with d < thresh; adj is an (A, A) byte adjacency matrix. */
+int fc_clash_graph(const double *coords, int64_t N, int64_t A, const uint8_t *adj, double thresh,
+                   int64_t *counts_out);
+/* a21: fitness_check (optimization_methods.py:163-180) for N structures with C
+ * constraints each: pairs (N, C, 2), targets (N, C) (NaN = no target);
+ * pass_out[n] = sum(|x_a - x_b| - target) < threshold; error_out may be NULL. */
+int fc_fitness_check(const double *coords, int64_t N, int64_t A, const int64_t *pairs,
+                     const double *targets, int64_t C, double threshold, double *error_out,
+                     uint8_t *pass_out);
+
 /* ---- a14: bimolecular rigid embed poses -- firecode/embeds.py:713-722:
  * pose k uses conformer c1[k] of m1 (n1,A1,3) moved by (R1[k], t1[k]) and
  * conformer c2[k] of m2 (n2,A2,3) moved by (R2[k], t2[k]); counts atom pairs

@@ -441,3 +441,59 @@ def test_embed_grid_vs_oracle(fc, seed, nr1, nr2):
     ok3, _ = fc.embeds.embed_grid_clash(m1, r1, pv1, m2, r2, pv2, angles, thresh=1.5, max_clashes=3)
     assert np.array_equal(ok3, ref_cnt <= 3) and ok3.sum() > ok.sum()
     assert np.array_equal(np.minimum(counts, 1), np.minimum(ref_cnt, 1))  # counts saturate past max_clashes
+
+
+# ---------------------------------------------------------------- graph clash, fitness, drivers
+def test_compenetration_graph_mode_golden(fc, golden):
+    edges = golden["cp_graph_edges"]
+    for mc in (0, 2):
+        out = fc.utils.compenetration_check_batch(golden["cpg_in"], graph=edges, thresh=1.2, max_clashes=mc)
+        assert np.array_equal(out, golden[f"cp_graph_{mc}"])
+    import networkx as nx
+
+    g = nx.Graph([tuple(e) for e in edges])
+    assert fc.utils.compenetration_check(golden["cpg_in"][5], graph=g, thresh=1.2) == bool(golden["cp_graph_0"][5])
+
+
+def test_fitness_check(fc):
+    rng = np.random.default_rng(71)
+    X = rng.normal(scale=2.0, size=(40, 12, 3))
+    cons = np.array([[0, 5], [3, 7], [2, 11]])
+    targets = [2.0, None, 1.5]
+    ok, err = fc.utils.fitness_check_batch(X, cons, [targets], threshold=3.0)
+    ref = np.array([o.fitness_check(x, cons, targets, 3.0) for x in X])
+    assert np.array_equal(ok, ref) and 0 < ok.sum() < len(ok)
+    assert fc.utils.fitness_check(X[0], cons, targets, 3.0) == bool(ref[0])
+    m = fc.refining.fitness_refining(X, cons, [targets], threshold=3.0)
+    assert np.array_equal(m, ref)
+
+
+def test_refining_drivers(fc, golden):
+    X, atoms, asg = syn.synthetic_ensemble(400, 18, seed=72)
+    logs = []
+    mask = fc.refining.similarity_refining(X, atoms, rmsd_thr=0.5, moi=True, rmsd=True, logfunction=logs.append)
+    _, m1 = o.prune_by_moment_of_inertia(X, atoms)
+    _, m2 = o.prune_by_rmsd(X[m1], atoms, 0.5)
+    ref = np.zeros(len(X), dtype=bool)
+    ref[np.flatnonzero(m1)[m2]] = True
+    assert np.array_equal(mask, ref)
+    assert any("RMSD similarity" in s or "MOI similarity" in s for s in logs)
+    cm = fc.refining.compenetration_refining(golden["cp_in"], ids=[20, 16], clash_thresh=1.5, max_clashes=0)
+    assert np.array_equal(cm, golden["cp_bi_1.5_0"])
+    em = fc.refining.energy_pruning(golden["enp_energies"], 10.0)
+    assert em.sum() == int(golden["enp_kept10"])
+    assert fc.refining.dynamic_energy_thr(golden["enp_energies"], 0.5) == float(golden["enp_thr0p5"])
+
+
+def test_clustered_csearch_driver(fc):
+    base, tors, masks = _chain_case(26, 3, seed=73)
+    torsions = [tuple(t) + (6,) for t in tors]
+    out = fc.torsion_module.clustered_csearch(base, torsions, masks, n_out=10_000)
+    # oracle pipeline: scan -> keep rotated -> TFD prune
+    angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 3)
+    sc, rot = o.torsion_scan(base, tors, masks, angles)
+    new = np.concatenate([base[None], sc[rot != 0]])
+    ref, _ = o.prune_conformers_tfd(new, tors)
+    assert out.shape == ref.shape and np.abs(out - ref).max() < TOL
+    sub = fc.torsion_module.most_diverse_conformers(5, list(ref), seed=1)
+    assert len(sub) == 5
