@@ -64,6 +64,8 @@ _SIGNATURES = {
     "fc_greedy_prune_from_bits": [_p_u64, _i64, _i64, _p_u8],
     "fc_prune_rmsd_begin": [_ens, _f64, _f64, _p_f64, _f64, _i64, _i64, _i64, _p_i64],
     "fc_prune_level": [_ens, _i64, _p_u8, _p_u8],
+    "fc_prune_similar_pairs": [_ens, _p_u64, _i64, _p_i64],
+    "fc_prune_from_pairs": [_ens, _p_u64, _i64, _i64, _p_u8],
     "fc_inertia_moments": [_p_f64, _i64, _i64, _p_f64, _p_f64],
     "fc_prune_moi": [_p_f64, _i64, _i64, _p_f64, _f64, _p_f64, _f64, _i64, _p_u8],
     "fc_align_to_first": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64],
@@ -256,6 +258,22 @@ class DeviceEnsemble:
         mo = np.zeros(self.N, dtype=np.uint8)
         call("fc_prune_level", self.handle, int(k), pb(mi), pb(mo))
         return mo
+
+    def similar_pairs(self):
+        """This rank's exactly-similar pairs after ``prune_begin`` as uint64
+        ``(i << 32) | j``; raises FirecodeHipInputError (FC_E_LIMIT) when the
+        candidate queue overflowed (dense similarity: use ``prune_level``)."""
+        n = C.c_int64(0)
+        call("fc_prune_similar_pairs", self.handle, None, 0, C.byref(n))
+        out = np.zeros(n.value, dtype=np.uint64)
+        call("fc_prune_similar_pairs", self.handle, pw(out), n.value, C.byref(n))
+        return out
+
+    def prune_from_pairs(self, pairs, min_per_group=20):
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint64)
+        mask = np.zeros(self.N, dtype=np.uint8)
+        call("fc_prune_from_pairs", self.handle, pw(pairs), int(pairs.shape[0]), int(min_per_group), pb(mask))
+        return mask.astype(bool)
 
     def bench_prune(self, max_rmsd, max_dev, reps=1, want_mask=True):
         mask = np.zeros(self.N, dtype=np.uint8) if want_mask else None

@@ -23,6 +23,7 @@ int launch_level(const uint64_t *, int64_t, const uint64_t *, const uint8_t *, u
                  int64_t, int64_t, int64_t, int64_t, int64_t);
 int launch_copy_bytes(const uint8_t *, uint8_t *, int64_t);
 int launch_mask_init(uint64_t *, int64_t, int64_t);
+int launch_scatter_pairs(const uint64_t *, int64_t, int64_t, int64_t, uint64_t *);
 int launch_level_fused(const uint64_t *, int64_t, const uint64_t *, uint64_t *, int64_t, int64_t,
                        int64_t, unsigned long long *);
 int launch_inertia_moments(const double *, int64_t, int64_t, const double *, double *);
@@ -188,6 +189,7 @@ static int ensemble_shard(fc_ensemble *e, int64_t rank, int64_t world, int64_t r
     if (c >= 1 && c <= (1ll << 26)) e->pairq_cap = c;
   }
   FC_TRY(e->pairq.reserve((size_t)e->pairq_cap * sizeof(uint64_t)));
+  FC_TRY(e->simq.reserve((size_t)e->pairq_cap * sizeof(uint64_t)));
   FC_TRY(e->maskA.reserve((size_t)e->Npad));
   FC_TRY(e->maskB.reserve((size_t)e->Npad));
   FC_TRY(e->mbits.reserve((size_t)e->W * sizeof(uint64_t)));
@@ -523,6 +525,43 @@ int fc_prune_level(fc_ensemble *ens, int64_t k, const uint8_t *mask_in, uint8_t 
                       ens->rank, ens->world, ens->rows_local));
   FC_TRY(d2h(mask_out, ens->maskB.p, (size_t)N));
   return sync();
+}
+
+int fc_prune_similar_pairs(fc_ensemble *ens, uint64_t *pairs_out, int64_t capacity, int64_t *n_out) {
+  FC_REQUIRE(ens && n_out, "NULL pointer argument");
+  FC_REQUIRE(ens->bits_valid, "fc_prune_rmsd_begin has not been called on this ensemble");
+  FC_TRY(ensure_init());
+  *n_out = 0;
+  if (ens->N == 0) return FC_OK;
+  unsigned long long cnt[8];
+  FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
+  FC_TRY(sync());
+  if ((int64_t)cnt[6] > ens->pairq_cap)
+    return set_error(FC_E_LIMIT, "candidate queue overflow (%llu > %lld): similar-pair list unavailable",
+                     cnt[6], (long long)ens->pairq_cap);
+  *n_out = (int64_t)cnt[2];
+  if (pairs_out == nullptr) return FC_OK;  // size query
+  FC_REQUIRE(capacity >= (int64_t)cnt[2], "pairs_out holds %lld entries, %llu needed", (long long)capacity, cnt[2]);
+  FC_TRY(d2h(pairs_out, ens->simq.p, (size_t)cnt[2] * sizeof(uint64_t)));
+  return sync();
+}
+
+int fc_prune_from_pairs(fc_ensemble *ens, const uint64_t *pairs, int64_t n_pairs,
+                        int64_t min_per_group, uint8_t *mask_out) {
+  FC_REQUIRE(ens && mask_out && (pairs || n_pairs == 0), "NULL pointer argument");
+  FC_REQUIRE(n_pairs >= 0 && min_per_group >= 1, "bad arguments");
+  FC_TRY(ensure_init());
+  const int64_t N = ens->N, W = ens->W;
+  if (N == 0) return FC_OK;
+  // rows padded like ladder_single expects (local row == global row)
+  const int64_t rb = ens->row_block > 0 ? ens->row_block : 64;
+  const size_t bytes = (size_t)(ceil_div(N, rb) * rb) * W * sizeof(uint64_t);
+  FC_TRY(ens->bits_full.reserve(bytes));
+  FC_HIP_TRY(hipMemsetAsync(ens->bits_full.p, 0, bytes, ctx().stream));
+  DevBuf dp;
+  FC_TRY(upload(dp, pairs, (size_t)n_pairs));
+  FC_TRY(launch_scatter_pairs(dp.as<uint64_t>(), n_pairs, N, W, ens->bits_full.as<uint64_t>()));
+  return ladder_single(ens, ens->bits_full.as<uint64_t>(), min_per_group, mask_out, nullptr, nullptr);
 }
 
 // ---- a6 ------------------------------------------------------------------------

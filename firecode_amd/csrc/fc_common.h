@@ -135,6 +135,8 @@ struct fc_ensemble {
   fc::DevBuf cand;             // rows_local * W uint32: queue of words to refine
   fc::DevBuf pairq;            // pairq_cap x uint64: queue of candidate pairs (i<<32 | j)
   int64_t pairq_cap = 0;
+  fc::DevBuf simq;             // pairq_cap x uint64: exactly-similar pairs found by the refine
+  fc::DevBuf bits_full;        // N x W uint64: whole bit matrix rebuilt from gathered pairs
   fc::DevBuf energies;         // N doubles (optional)
   fc::DevBuf maskA, maskB;     // N bytes each
   fc::DevBuf mbits;            // W uint64 active-flag words

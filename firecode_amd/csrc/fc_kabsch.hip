@@ -592,7 +592,7 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
                  int64_t rank, int64_t world, int64_t rows_local, uint64_t *__restrict__ bits,
                  int64_t W, const uint32_t *__restrict__ cand,
                  unsigned long long *__restrict__ counters, const uint64_t *__restrict__ pairq,
-                 unsigned long long Q) {
+                 unsigned long long Q, uint64_t *__restrict__ simq) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -619,11 +619,16 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
         }
       }
       const uint64_t mo = __ballot(on), ms = __ballot(sim), mg = __ballot(grey);
+      unsigned long long sbase = 0;
       if (lane == 0) {
         atomicAdd(&counters[1], (unsigned long long)__popcll(mo));
-        if (ms) atomicAdd(&counters[2], (unsigned long long)__popcll(ms));
+        if (ms) sbase = atomicAdd(&counters[2], (unsigned long long)__popcll(ms));
         if (mg) atomicAdd(&counters[3], (unsigned long long)__popcll(mg));
       }
+      // list of exactly-similar pairs (same capacity as the candidate queue):
+      // what a rank contributes to the multi-GPU exchange
+      sbase = __shfl(sbase, 0);
+      if (sim) simq[sbase + (unsigned long long)__popcll(ms & ((1ull << lane) - 1ull))] = pairq[p];
     }
     return;
   }
@@ -739,6 +744,27 @@ k_alignment_matrices(const double *__restrict__ p, const double *__restrict__ q,
   double R[9];
   (void)kabsch_rotation(B, R);
   for (int e = 0; e < 9; ++e) M[k * 9 + e] = R[e];
+}
+
+// full bit matrix from a list of similar pairs ((i << 32) | j, i < j): the
+// receiving side of the multi-GPU exchange
+__global__ void __launch_bounds__(256)
+k_scatter_pairs(const uint64_t *__restrict__ pairs, int64_t n_pairs, int64_t N, int64_t W,
+                uint64_t *__restrict__ bits) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  const uint64_t e = pairs[p];
+  const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
+  if (i < 0 || j <= i || j >= N) return;  // padding / malformed entries are ignored
+  atomicOr(reinterpret_cast<unsigned long long *>(&bits[i * W + (j >> 6)]), 1ull << (j & 63));
+}
+
+int launch_scatter_pairs(const uint64_t *pairs_dev, int64_t n_pairs, int64_t N, int64_t W,
+                         uint64_t *bits_dev) {
+  if (n_pairs == 0) return FC_OK;
+  hipLaunchKernelGGL(k_scatter_pairs, dim3((unsigned)ceil_div(n_pairs, 256)), dim3(256), 0,
+                     ctx().stream, pairs_dev, n_pairs, N, W, bits_dev);
+  return check_launch("k_scatter_pairs");
 }
 
 // ---------------------------------------------------------------------------
@@ -868,7 +894,7 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
                      e->rows_local,
                      e->bits.as<uint64_t>(), e->W, e->cand.as<uint32_t>(),
                      reinterpret_cast<unsigned long long *>(e->counters.p), e->pairq.as<uint64_t>(),
-                     (unsigned long long)e->pairq_cap);
+                     (unsigned long long)e->pairq_cap, e->simq.as<uint64_t>());
   return check_launch("k_simbits_refine");
 }
 

@@ -62,10 +62,35 @@ def torch_allgather(group=None, device=None):
     return fn
 
 
+PAD = np.uint64(0xFFFFFFFFFFFFFFFF)  # (i = 2^32-1): ignored by the scatter kernel
+
+
+def gather_pairs(pairs, allgather_fn):
+    """Variable-length all-gather of uint64 pair lists with two fixed-size
+    collectives: the counts, then the lists padded to the longest."""
+    count = np.array([pairs.shape[0]], dtype=np.int64)
+    counts = allgather_fn(count.view(np.uint8)).view(np.int64).reshape(-1)
+    longest = int(counts.max())
+    if longest == 0:
+        return np.zeros(0, dtype=np.uint64)
+    padded = np.full(longest, PAD, dtype=np.uint64)
+    padded[: pairs.shape[0]] = pairs
+    rows = allgather_fn(padded.view(np.uint8)).view(np.uint64).reshape(len(counts), longest)
+    return np.concatenate([rows[r, : counts[r]] for r in range(len(counts))])
+
+
 def prune_by_rmsd_sharded(ens, max_rmsd, max_dev=None, rank=0, world=1, allgather_fn=None,
-                          row_block=256, min_per_group=20, trace=None):
+                          row_block=256, min_per_group=20, trace=None, mode="auto"):
     """``ens``: a ``DeviceEnsemble`` holding the whole ensemble on this rank's
-    GPU.  Returns (mask (N,) bool, stats of this rank's similarity stage)."""
+    GPU.  Each rank computes the similarity of its own row blocks, then
+
+    * ``pairs`` (default when available): ONE variable-length all-gather of the
+      ranks' exactly-similar pair lists (a few hundred kB), after which every
+      rank replays the whole k-ladder locally -- no further communication;
+    * ``levels``: one (N,) uint8 mask all-gather per ladder level (used when a
+      rank's candidate queue overflowed, i.e. similarity is dense).
+
+    Returns (mask (N,) bool, stats of this rank's similarity stage)."""
     if max_dev is None:
         max_dev = 2 * max_rmsd
     if allgather_fn is None:
@@ -73,5 +98,18 @@ def prune_by_rmsd_sharded(ens, max_rmsd, max_dev=None, rank=0, world=1, allgathe
             raise ValueError("allgather_fn is required when world > 1")
         allgather_fn = lambda m: m[None]  # noqa: E731
     stats = ens.prune_begin(max_rmsd, max_dev, rank, world, row_block=row_block)
+    pairs = None
+    if mode in ("auto", "pairs") and hasattr(ens, "similar_pairs"):
+        try:
+            pairs = ens.similar_pairs()
+        except ValueError:  # FirecodeHipInputError(FC_E_LIMIT): queue overflow on this rank
+            if mode == "pairs":
+                raise
+    # every rank must take the same branch: agree with one tiny all-gather
+    have = allgather_fn(np.array([pairs is not None], dtype=np.uint8)).reshape(-1)
+    if have.all():
+        all_pairs = gather_pairs(pairs, allgather_fn)
+        mask = ens.prune_from_pairs(all_pairs, min_per_group=min_per_group)
+        return mask, stats
     mask = run_ladder(ens.N, ens.prune_level, allgather_fn, min_per_group=min_per_group, trace=trace)
     return mask, stats

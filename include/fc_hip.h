@@ -110,6 +110,15 @@ int fc_prune_rmsd_begin(fc_ensemble *ens, double max_rmsd, double max_dev,
                         const double *energies, double max_dE, int64_t rank, int64_t world,
                         int64_t row_block, int64_t *stats);
 int fc_prune_level(fc_ensemble *ens, int64_t k, const uint8_t *mask_in, uint8_t *mask_out);
+/* Preferred exchange when similar pairs are sparse (the usual case): after
+ * fc_prune_rmsd_begin, fc_prune_similar_pairs returns this rank's exactly-
+ * similar pairs as (i << 32) | j in processing order indices (n_out = count;
+ * FC_E_LIMIT when the candidate queue overflowed -- use fc_prune_level then).
+ * The ranks all-gather the lists ONCE and every rank replays the whole ladder
+ * locally with fc_prune_from_pairs (pairs from all ranks, any order). */
+int fc_prune_similar_pairs(fc_ensemble *ens, uint64_t *pairs_out, int64_t capacity, int64_t *n_out);
+int fc_prune_from_pairs(fc_ensemble *ens, const uint64_t *pairs, int64_t n_pairs,
+                        int64_t min_per_group, uint8_t *mask_out);
 
 /* ---- a6: prune_by_moment_of_inertia -- prism_pruner.pruner; call sites
  * firecode/ensemble.py:211-216, embedder.py:1452-1454.

@@ -41,6 +41,20 @@ class OracleShard:
         return out.astype(np.uint8)
 
 
+class OraclePairShard(OracleShard):
+    """adds the similar-pair exchange (fc_prune_similar_pairs / fc_prune_from_pairs)"""
+
+    def similar_pairs(self):
+        i, j = np.nonzero(self.S & self.own[:, None])
+        return (i.astype(np.uint64) << np.uint64(32)) | j.astype(np.uint64)
+
+    def prune_from_pairs(self, pairs, min_per_group=20):
+        S = np.zeros((self.N, self.N), dtype=bool)
+        ok = pairs != fdist.PAD
+        S[(pairs[ok] >> np.uint64(32)).astype(np.int64), (pairs[ok] & np.uint64(0xFFFFFFFF)).astype(np.int64)] = True
+        return o.greedy_prune_from_matrix(S | S.T, min_per_group=min_per_group)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -49,13 +63,13 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, a, seed, row_block, out_dir):
+def _worker(rank, world, port, n, a, seed, row_block, out_dir, pairs_mode=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     X, atoms, _ = syn.synthetic_ensemble(n, a, seed=seed)
     S, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
-    shard = OracleShard(S, rank, world, row_block)
+    shard = (OraclePairShard if pairs_mode else OracleShard)(S, rank, world, row_block)
     trace = []
     mask, _ = fdist.prune_by_rmsd_sharded(shard, 0.5, rank=rank, world=world,
                                           allgather_fn=fdist.torch_allgather(), row_block=row_block,
@@ -79,6 +93,42 @@ def test_sharded_ladder_matches_single(tmp_path, world, n, row_block):
     ref_trace = []
     o.greedy_prune(n, lambda i, j: S[i, j], trace=ref_trace)
     assert np.array_equal(np.load(tmp_path / "trace_0.npy"), np.array(ref_trace))
+
+
+@pytest.mark.parametrize("world,n", [(2, 600), (3, 333)])
+def test_sharded_pairs_exchange_matches_single(tmp_path, world, n):
+    a, seed, row_block = 10, 60 + world, 64
+    mp.spawn(_worker, args=(world, _free_port(), n, a, seed, row_block, str(tmp_path), True), nprocs=world, join=True)
+    X, atoms, _ = syn.synthetic_ensemble(n, a, seed=seed)
+    S, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"mask_{r}.npy"), ref)
+
+
+def test_gather_pairs_variable_length():
+    lists = [np.arange(5, dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.arange(100, 103, dtype=np.uint64)]
+    # emulate 3 ranks in-process: the all-gather stacks what each rank would send
+    sent = {}
+
+    def make(rank):
+        def fn(buf):
+            sent.setdefault(len(buf), {})[rank] = buf.copy()
+            return None
+        return fn
+
+    # two passes: first record every rank's buffers, then answer from the record
+    def run(rank, answers):
+        it = iter(answers)
+        return fdist.gather_pairs(lists[rank], lambda buf: next(it))
+
+    counts = np.stack([np.array([len(l)], dtype=np.int64).view(np.uint8) for l in lists])
+    longest = max(len(l) for l in lists)
+    padded = np.stack([np.concatenate([l, np.full(longest - len(l), fdist.PAD, dtype=np.uint64)]).view(np.uint8)
+                       for l in lists])
+    for rank in range(3):
+        out = run(rank, [counts, padded])
+        assert np.array_equal(out, np.concatenate(lists))
 
 
 def test_owner_of_rows_balances_triangle():

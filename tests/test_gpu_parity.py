@@ -497,3 +497,24 @@ def test_clustered_csearch_driver(fc):
     assert out.shape == ref.shape and np.abs(out - ref).max() < TOL
     sub = fc.torsion_module.most_diverse_conformers(5, list(ref), seed=1)
     assert len(sub) == 5
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pairs_exchange_on_one_gpu(fc, world):
+    """the one-all-gather path: every rank contributes its similar pairs, every
+    rank replays the ladder from the union"""
+    from firecode_amd import dist as fdist
+
+    X, atoms, asg = syn.synthetic_ensemble(900, 20, seed=80 + world)
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    ranks = [fc.DeviceEnsemble(X, center=True) for _ in range(world)]
+    lists = []
+    for r, ens in enumerate(ranks):
+        ens.prune_begin(0.5, 1.0, r, world, row_block=128)
+        lists.append(ens.similar_pairs())
+    assert sum(len(l) for l in lists) == np.triu(S0, 1).sum()
+    union = np.concatenate(lists + [np.full(7, fdist.PAD, dtype=np.uint64)])  # padding is ignored
+    for ens in ranks:
+        assert np.array_equal(ens.prune_from_pairs(union), ref)
+        ens.close()
