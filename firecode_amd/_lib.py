@@ -83,6 +83,11 @@ _SIGNATURES = {
     "fc_torsion_scan": [_p_f64, _i64, _p_i64, _i64, _p_u8, _p_i64, _i64, _f64, _i64, _p_f64, _p_i64],
     "fc_torsion_fingerprint": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64],
     "fc_tfd_simbits": [_p_f64, _i64, _i64, _f64, _i64, _i64, _p_u64],
+    "fc_tfd_first_match": [_p_f64, _i64, _i64, _f64, _p_i64],
+    "fc_tfd_ladder_from_first_match": [_p_i64, _i64, _p_u8],
+    "fc_tfd_prune": [_p_f64, _i64, _i64, _f64, _p_u8],
+    "fc_debug_pyset_order_ints": [_p_i64, _i64, _p_i64, _p_i64],
+    "fc_debug_pyset_order_pairs": [_p_i64, _i64, _p_i64, _p_i64],
     "fc_bench_prune_rmsd": [_ens, _f64, _f64, _i64, _p_f64, _p_f64, _p_u8, _p_i64],
 }
 

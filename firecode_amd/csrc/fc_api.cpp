@@ -45,6 +45,10 @@ int launch_torsion_scan(const double *, int64_t, const int64_t *, int64_t, const
                         const int16_t *, const int16_t *, const int32_t *, const int32_t *,
                         const int64_t *, int64_t, double, int64_t, double *, int64_t *);
 int launch_torsion_fingerprint(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
+int launch_tfd_first_match(const double *, int64_t, int64_t, int64_t, double, int64_t *);
+int tfd_ladder_from_first_match(const int64_t *, int64_t, uint8_t *);
+void pyset_order_ints(const int64_t *, int64_t, std::vector<int64_t> &);
+void pyset_order_pairs(const int64_t *, int64_t, std::vector<int64_t> &);
 int launch_embed_mol_transforms(const double *, int64_t, int64_t, const int64_t *, int, const double *,
                                 const double *, int, const double *, int64_t, double *, double *);
 int launch_embed_pretransform(const double *, int64_t, int64_t, int64_t, const double *,
@@ -939,6 +943,62 @@ int fc_tfd_simbits(const double *tf, int64_t N, int64_t Q, double thresh, int64_
                             dbits.as<uint64_t>(), W));
   FC_TRY(d2h(bits_out, dbits.p, bytes));
   return sync();
+}
+
+int fc_tfd_first_match(const double *tf, int64_t N, int64_t Q, double thresh, int64_t *first_out) {
+  FC_REQUIRE(N >= 0 && Q >= 0, "bad shape");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(first_out && (tf || Q == 0), "NULL pointer argument");
+  if (Q > 128) return set_error(FC_E_LIMIT, "Q=%lld fingerprints exceed 128 (NumPy's summation order changes there)", (long long)Q);
+  FC_TRY(ensure_init());
+  const int64_t Npad = ceil_div(N, 64) * 64;
+  // fingerprint-major copy so that consecutive columns are contiguous
+  std::vector<double> tfT((size_t)std::max<int64_t>(Q, 1) * Npad, 0.0);
+  for (int64_t n = 0; n < N; ++n)
+    for (int64_t q = 0; q < Q; ++q) tfT[(size_t)q * Npad + n] = tf[n * Q + q];
+  DevBuf dT, dfm;
+  FC_TRY(upload(dT, tfT.data(), tfT.size()));
+  FC_TRY(dfm.reserve((size_t)N * sizeof(int64_t)));
+  FC_TRY(launch_tfd_first_match(dT.as<double>(), N, Npad, Q, thresh, dfm.as<int64_t>()));
+  FC_TRY(d2h(first_out, dfm.p, (size_t)N * sizeof(int64_t)));
+  return sync();
+}
+
+int fc_tfd_ladder_from_first_match(const int64_t *first_match, int64_t N, uint8_t *mask_out) {
+  FC_REQUIRE(N >= 0, "bad shape");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(first_match && mask_out, "NULL pointer argument");
+  for (int64_t i = 0; i < N; ++i)
+    FC_REQUIRE(first_match[i] == -1 || (first_match[i] > i && first_match[i] < N), "first_match[%lld] invalid", (long long)i);
+  return tfd_ladder_from_first_match(first_match, N, mask_out);
+}
+
+int fc_tfd_prune(const double *tf, int64_t N, int64_t Q, double thresh, uint8_t *mask_out) {
+  FC_REQUIRE(N >= 0 && Q >= 0, "bad shape");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(mask_out != nullptr, "NULL pointer argument");
+  std::vector<int64_t> fm((size_t)N);
+  FC_TRY(fc_tfd_first_match(tf, N, Q, thresh, fm.data()));
+  return tfd_ladder_from_first_match(fm.data(), N, mask_out);
+}
+
+int fc_debug_pyset_order_ints(const int64_t *keys, int64_t n, int64_t *order_out, int64_t *n_out) {
+  FC_REQUIRE(n >= 0 && (keys || n == 0) && order_out && n_out, "bad arguments");
+  for (int64_t k = 0; k < n; ++k) FC_REQUIRE(keys[k] >= 0, "keys must be non-negative");
+  std::vector<int64_t> o;
+  pyset_order_ints(keys, n, o);
+  for (size_t k = 0; k < o.size(); ++k) order_out[k] = o[k];
+  *n_out = (int64_t)o.size();
+  return FC_OK;
+}
+
+int fc_debug_pyset_order_pairs(const int64_t *pairs, int64_t n, int64_t *order_out, int64_t *n_out) {
+  FC_REQUIRE(n >= 0 && (pairs || n == 0) && order_out && n_out, "bad arguments");
+  std::vector<int64_t> o;
+  pyset_order_pairs(pairs, n, o);
+  for (size_t k = 0; k < o.size(); ++k) order_out[k] = o[k];
+  *n_out = (int64_t)o.size();
+  return FC_OK;
 }
 
 // ---- bench hook ----------------------------------------------------------------------

@@ -267,9 +267,41 @@ k_moi_simbits(const double *__restrict__ moments, int64_t N, double tol,
   if (lane == 0) bits[i * W + jt] = word;
 }
 
-// TFD similarity bits over all j != i (firecode/torsion_module.py:1056-1067):
-// deltas = |tf_i - tf_j|; deltas = |deltas - (deltas > 180)*360|; sum < thresh.
-// Same left-to-right summation order as np.sum over Q <= 8 elements.
+// TFD similarity (firecode/torsion_module.py:1056-1067):
+//   deltas = |tf_i - tf_j|; deltas = |deltas - (deltas > 180)*360|; np.sum(deltas) < thresh
+// np.sum adds a contiguous float64 vector in its "pairwise" order: plain
+// left-to-right below 8 elements, otherwise 8 running lanes r[k] += a[8m+k]
+// combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the n%8 tail added one
+// by one (verified against np.sum bit for bit for n <= 128; the launcher
+// refuses Q > 128, where NumPy starts to recurse).
+__device__ __forceinline__ double tfd_delta(const double *__restrict__ ti, const double *__restrict__ tj,
+                                            int q, int64_t si, int64_t sj) {
+  double d = fabs(ti[q * si] - tj[q * sj]);
+  return fabs(d - (d > 180.0 ? 360.0 : 0.0));
+}
+
+// ti / tj: fingerprint of one structure with element stride si / sj
+__device__ __forceinline__ double tfd_sum(const double *__restrict__ ti, int64_t si,
+                                          const double *__restrict__ tj, int64_t sj, int Q) {
+  if (Q < 8) {
+    double res = 0.0;
+    for (int q = 0; q < Q; ++q) res += tfd_delta(ti, tj, q, si, sj);
+    return res;
+  }
+  double r[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = tfd_delta(ti, tj, k, si, sj);
+  int i = 8;
+  for (; i < Q - (Q % 8); i += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] += tfd_delta(ti, tj, i + k, si, sj);
+  }
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < Q; ++i) res += tfd_delta(ti, tj, i, si, sj);
+  return res;
+}
+
+// bits over all j != i, rows [row_begin, row_end): one wavefront per (row, word)
 __global__ void __launch_bounds__(256)
 k_tfd_simbits(const double *__restrict__ tf, int64_t N, int Q, double thresh, int64_t row_begin,
               int64_t row_end, uint64_t *__restrict__ bits, int64_t W) {
@@ -280,17 +312,62 @@ k_tfd_simbits(const double *__restrict__ tf, int64_t N, int Q, double thresh, in
   if (i >= row_end) return;
   const int64_t j = jt * 64 + lane;
   bool sim = false;
-  if (j < N && j != i) {
-    double sum = 0.0;
-    for (int q = 0; q < Q; ++q) {
-      double d = fabs(tf[i * Q + q] - tf[j * Q + q]);
-      d = fabs(d - (d > 180.0 ? 360.0 : 0.0));
-      sum += d;
-    }
-    sim = sum < thresh;
-  }
+  if (j < N && j != i) sim = tfd_sum(tf + i * Q, 1, tf + j * Q, 1, Q) < thresh;
   const uint64_t word = __ballot(sim);
   if (lane == 0) bits[r * W + jt] = word;
+}
+
+// first_match[i] = min{ j > i : tfd_similar(i, j) } (or -1): everything the
+// k-ladder of prune_conformers_tfd needs, in N integers instead of N^2 bits.
+// tfT is fingerprint-major (tfT[q*Npad + n]) so that lanes owning consecutive
+// columns load coalesced.  Workgroup = 64 rows (fingerprints in LDS) x a
+// running window of 256 columns; a row retires at its first hit and the
+// workgroup stops when all its rows have.
+template <int QT>  // QT > 0: fingerprint length known at compile time (column kept in VGPRs)
+__global__ void __launch_bounds__(256)
+k_tfd_first_match(const double *__restrict__ tfT, int64_t N, int64_t Npad, int Qrt, double thresh,
+                  int64_t *__restrict__ first_match) {
+  const int Q = QT > 0 ? QT : Qrt;
+  extern __shared__ double rows[];              // [64][Q]
+  __shared__ long long best[64];
+  __shared__ int n_open;
+  const int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * 64;
+  for (int k = tid; k < 64 * Q; k += 256) {
+    const int r = k / Q, q = k % Q;
+    rows[k] = (i0 + r < N) ? tfT[(int64_t)q * Npad + i0 + r] : 0.0;
+  }
+  if (tid < 64) best[tid] = (i0 + tid < N) ? (long long)N : -2;  // N = none yet, -2 = no such row
+  if (tid == 0) n_open = (int)((N - i0 < 64) ? (N - i0) : 64);
+  __syncthreads();
+  for (int64_t jb = i0 + 1; jb < N; jb += 256) {
+    const int64_t j = jb + tid;
+    if (j < N) {
+      double cj[QT > 0 ? QT : 1];
+      if (QT > 0) {
+#pragma unroll
+        for (int q = 0; q < QT; ++q) cj[q] = tfT[(int64_t)q * Npad + j];
+      }
+      for (int r = 0; r < 64; ++r) {
+        const int64_t i = i0 + r;
+        // rows are retired in increasing-column windows: a hit in an earlier
+        // window is final, a hit in this window is resolved with atomicMin
+        if (i >= N || j <= i || best[r] < jb) continue;
+        const double sum = (QT > 0) ? tfd_sum(rows + r * Q, 1, cj, 1, QT)
+                                    : tfd_sum(rows + r * Q, 1, tfT + j, Npad, Q);
+        if (sum < thresh) atomicMin(&best[r], (long long)j);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int open = 0;
+      for (int r = 0; r < 64; ++r) open += (best[r] == (long long)N) ? 1 : 0;
+      n_open = open;
+    }
+    __syncthreads();
+    if (n_open == 0) break;
+  }
+  if (tid < 64 && i0 + tid < N) first_match[i0 + tid] = (best[tid] >= (long long)N) ? -1 : best[tid];
 }
 
 // ---------------------------------------------------------------------------
@@ -348,6 +425,27 @@ int launch_moi_simbits(const double *moments_dev, int64_t N, double tol, const d
   hipLaunchKernelGGL(k_moi_simbits, dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, ctx().stream,
                      moments_dev, N, tol, energies_dev, max_dE, bits_dev, W);
   return check_launch("k_moi_simbits");
+}
+
+int launch_tfd_first_match(const double *tfT_dev, int64_t N, int64_t Npad, int64_t Q, double thresh,
+                           int64_t *fm_dev) {
+  if (N == 0) return FC_OK;
+  const dim3 grid((unsigned)ceil_div(N, 64)), block(256);
+  const size_t lds = (size_t)64 * Q * sizeof(double);
+#define FC_FM(QT)                                                                                  \
+  case QT:                                                                                         \
+    hipLaunchKernelGGL(k_tfd_first_match<QT>, grid, block, lds, ctx().stream, tfT_dev, N, Npad,    \
+                       (int)Q, thresh, fm_dev);                                                    \
+    break;
+  switch (Q) {
+    FC_FM(1) FC_FM(2) FC_FM(3) FC_FM(4) FC_FM(5) FC_FM(6) FC_FM(7) FC_FM(8) FC_FM(9) FC_FM(10)
+    FC_FM(11) FC_FM(12) FC_FM(13) FC_FM(14) FC_FM(15) FC_FM(16)
+    default:
+      hipLaunchKernelGGL(k_tfd_first_match<0>, grid, block, lds, ctx().stream, tfT_dev, N, Npad, (int)Q,
+                         thresh, fm_dev);
+  }
+#undef FC_FM
+  return check_launch("k_tfd_first_match");
 }
 
 int launch_tfd_simbits(const double *tf_dev, int64_t N, int64_t Q, double thresh, int64_t row_begin,

@@ -67,9 +67,12 @@ PAD = np.uint64(0xFFFFFFFFFFFFFFFF)  # (i = 2^32-1): ignored by the scatter kern
 
 def gather_pairs(pairs, allgather_fn):
     """Variable-length all-gather of uint64 pair lists with two fixed-size
-    collectives: the counts, then the lists padded to the longest."""
-    count = np.array([pairs.shape[0]], dtype=np.int64)
+    collectives: the counts (-1 = "this rank has no list"), then the lists
+    padded to the longest.  Returns None when any rank has no list."""
+    count = np.array([-1 if pairs is None else pairs.shape[0]], dtype=np.int64)
     counts = allgather_fn(count.view(np.uint8)).view(np.int64).reshape(-1)
+    if (counts < 0).any():
+        return None
     longest = int(counts.max())
     if longest == 0:
         return np.zeros(0, dtype=np.uint64)
@@ -105,10 +108,9 @@ def prune_by_rmsd_sharded(ens, max_rmsd, max_dev=None, rank=0, world=1, allgathe
         except ValueError:  # FirecodeHipInputError(FC_E_LIMIT): queue overflow on this rank
             if mode == "pairs":
                 raise
-    # every rank must take the same branch: agree with one tiny all-gather
-    have = allgather_fn(np.array([pairs is not None], dtype=np.uint8)).reshape(-1)
-    if have.all():
-        all_pairs = gather_pairs(pairs, allgather_fn)
+    # every rank takes the same branch: the count exchange doubles as the vote
+    all_pairs = gather_pairs(pairs, allgather_fn)
+    if all_pairs is not None:
         mask = ens.prune_from_pairs(all_pairs, min_per_group=min_per_group)
         return mask, stats
     mask = run_ladder(ens.N, ens.prune_level, allgather_fn, min_per_group=min_per_group, trace=trace)

@@ -74,37 +74,26 @@ def tfd_similarity(tfp1, tfp2, thresh=10):
     return bool((int(bits[0, 0]) >> 1) & 1)
 
 
-def prune_conformers_tfd(structures, quadruplets, thresh=10, verbose=False):
-    """firecode/torsion_module.py:957-1043.  Fingerprints and the N x N TFD
-    similarity bits are computed on the GPU; the first-match / connected-
-    component bookkeeping of the reference (networkx, `group[0]` kept) is
-    replayed on the host over the bit rows."""
-    from networkx import Graph, connected_components
+def prune_tfd_from_tf_mat(tf_mat, thresh=10):
+    """The k-ladder of ``prune_conformers_tfd`` given the fingerprint matrix:
+    the GPU finds, for every structure, its first TFD-similar successor
+    (O(N^2) comparisons, N integers out); the reference's per-chunk
+    match-graph / "keep group[0]" bookkeeping is replayed from that array in
+    C++ (csrc/fc_tfd_host.cpp), reproducing CPython's set order so that the
+    mask equals the reference's bit for bit."""
+    tf = L.f64(tf_mat)
+    if tf.ndim != 2:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "tf_mat must be (N, Q)")
+    mask = np.zeros(tf.shape[0], dtype=np.uint8)
+    L.call("fc_tfd_prune", L.pf(tf), tf.shape[0], tf.shape[1], float(thresh), L.pb(mask))
+    return mask.astype(bool)
 
+
+def prune_conformers_tfd(structures, quadruplets, thresh=10, verbose=False):
+    """firecode/torsion_module.py:957-1043 -> (structures[mask], mask)."""
     structures = L.f64(structures)
-    n = structures.shape[0]
-    tf_mat = get_tf_mat(structures, quadruplets)
-    sim = L.unpack_bits(tfd_simbits(tf_mat, thresh), n) if n else np.zeros((0, 0), dtype=bool)
-    final_mask = np.ones(n, dtype=bool)
-    for k in (5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1):
-        num_active_str = np.count_nonzero(final_mask)
-        if k == 1 or 5 * k < num_active_str:
-            d = int(n // k)
-            for step in range(int(k)):
-                lo = d * step
-                _l = len(range(lo, num_active_str)) if step == k - 1 else len(range(lo, int(d * (step + 1))))
-                if _l <= 1:
-                    continue
-                sub = np.triu(sim[lo:lo + _l, lo:lo + _l], 1)
-                rows = np.flatnonzero(sub.any(axis=1))
-                # first similar j > i per row (the cache only skips known-dissimilar pairs)
-                matches = set((int(i), int(sub[i].argmax())) for i in rows)
-                g = Graph(matches)
-                for c in connected_components(g):
-                    group = tuple(g.subgraph(c).nodes)
-                    for i in set(group) - {group[0]}:
-                        final_mask[i + lo] = 0
-    return structures[final_mask], final_mask
+    mask = prune_tfd_from_tf_mat(get_tf_mat(structures, quadruplets), thresh)
+    return structures[mask], mask
 
 
 def most_diverse_conformers(n, structures, seed=None):

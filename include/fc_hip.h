@@ -214,6 +214,22 @@ int fc_torsion_fingerprint(const double *coords, int64_t N, int64_t A, const int
 int fc_tfd_simbits(const double *tf, int64_t N, int64_t Q, double thresh, int64_t row_begin,
                    int64_t row_end, uint64_t *bits_out);
 
+/* prune_conformers_tfd at any N (firecode/torsion_module.py:957-1043):
+ * fc_tfd_first_match: first_out[i] = min{ j > i : TFD-similar(i, j) } or -1 (GPU);
+ * fc_tfd_ladder_from_first_match: the reference's k-ladder / match-graph /
+ * "keep group[0]" bookkeeping replayed on the host from that array -- pure
+ * host code (no device needed), bit-identical to the reference under CPython
+ * >= 3.8 + networkx 3.x because it reproduces their set iteration order;
+ * fc_tfd_prune = both. */
+int fc_tfd_first_match(const double *tf, int64_t N, int64_t Q, double thresh, int64_t *first_out);
+int fc_tfd_ladder_from_first_match(const int64_t *first_match, int64_t N, uint8_t *mask_out);
+int fc_tfd_prune(const double *tf, int64_t N, int64_t Q, double thresh, uint8_t *mask_out);
+/* test hooks for the CPython set-order emulation used by the ladder: iteration
+ * order of set(keys) (non-negative ints inserted in the given order) and of a
+ * set of 2-tuples (returned as indices into the input) */
+int fc_debug_pyset_order_ints(const int64_t *keys, int64_t n, int64_t *order_out, int64_t *n_out);
+int fc_debug_pyset_order_pairs(const int64_t *pairs, int64_t n, int64_t *order_out, int64_t *n_out);
+
 /* ---- bench / profiling hooks (resident data, device-side timing) --------
  * Runs the all-pairs similarity stage + greedy replay `reps` times on the
  * resident ensemble and returns HIP-event times (ms, per rep) of the

@@ -145,6 +145,11 @@ tf_b[::3] = rng.uniform(-180, 180, size=tf_b[::3].shape)
 tf_b[1] = tf_a[1] + [359.0, 0, 0, 0, 0, 0]  # wrap-around
 G["tfd_a"], G["tfd_b"] = tf_a, tf_b
 G["tfd_out"] = np.array([ft.tfd_similarity(a, b, thresh=10) for a, b in zip(tf_a, tf_b)])
+# long fingerprints: np.sum switches to its 8-lane pairwise order at Q >= 8
+tfl_a = rng.uniform(-180, 180, size=(400, 17))
+tfl_b = tfl_a + rng.normal(scale=0.72, size=tfl_a.shape)   # sums straddle the threshold
+G["tfdl_a"], G["tfdl_b"] = tfl_a, tfl_b
+G["tfdl_out"] = np.array([ft.tfd_similarity(a, b, thresh=10) for a, b in zip(tfl_a, tfl_b)])
 
 
 def _tfd_case(n, q, n_clusters, noise, seed):
@@ -159,6 +164,9 @@ for name, (n, q, k, noise, seed) in {
     "tfdp_mid": (333, 5, 40, 1.0, 2),
     "tfdp_big": (1500, 6, 200, 0.9, 3),
     "tfdp_dense": (400, 3, 6, 1.5, 4),
+    "tfdp_q8": (500, 8, 60, 0.55, 5),
+    "tfdp_q11": (300, 11, 40, 0.45, 6),
+    "tfdp_q19": (200, 19, 25, 0.26, 7),
 }.items():
     tf = _tfd_case(n, q, k, noise, seed)
     saved = ft._get_tf_mat

@@ -324,7 +324,15 @@ def test_fingerprints_and_tfd(fc, golden):
     assert np.array_equal(out, golden["tfd_out"])
 
 
-@pytest.mark.parametrize("name", ["tfdp_small", "tfdp_mid", "tfdp_big", "tfdp_dense"])
+def test_tfd_long_fingerprints_numpy_sum_order(fc, golden):
+    """Q >= 8: np.sum's 8-lane pairwise order decides sums that straddle the threshold"""
+    a, b = golden["tfdl_a"], golden["tfdl_b"]
+    out = [fc.torsion_module.tfd_similarity(x, y) for x, y in zip(a[:120], b[:120])]
+    assert np.array_equal(out, golden["tfdl_out"][:120])
+    assert 20 < golden["tfdl_out"][:120].sum() < 100
+
+
+@pytest.mark.parametrize("name", ["tfdp_small", "tfdp_mid", "tfdp_big", "tfdp_dense", "tfdp_q8", "tfdp_q11", "tfdp_q19"])
 def test_tfd_bits_and_prune_golden(fc, golden, name, monkeypatch):
     """TFD similarity bits on the GPU + the reference's bookkeeping = the
     mask the reference's own prune_conformers_tfd produced."""
