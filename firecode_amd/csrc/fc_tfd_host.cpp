@@ -17,7 +17,8 @@
 // tests/test_pyset_emulation.py checks both against the running interpreter.
 #include <cstdint>
 #include <cstring>
-#include <unordered_map>
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "fc_common.h"
@@ -34,6 +35,11 @@ struct PySetEmu {
   std::vector<Entry> table;
   size_t mask = 7, fill = 0, used_n = 0;
   PySetEmu() : table(8) {}
+  void reset() {  // back to an empty 8-slot set; keeps the allocation
+    table.assign(8, Entry{});
+    mask = 7;
+    fill = used_n = 0;
+  }
 
   static void insert_clean(std::vector<Entry> &t, size_t mask, int64_t key, int64_t hash) {
     size_t perturb = (size_t)hash;
@@ -154,84 +160,141 @@ void pyset_order_pairs(const int64_t *pairs, int64_t n, std::vector<int64_t> &ou
 }
 
 // ---- one chunk: matches (i_rel ascending) -> relative indices to reject -------
+// Scratch that survives across the ~10^5 chunks of a fine ladder level.
+struct ChunkScratch {
+  PySetEmu edge_set, comp, view;
+  std::vector<int64_t> order, nodes, members, level, next, adj_head, adj_next, adj_to, adj_tail;
+  std::vector<int64_t> pos_of;     // relative index -> position in `nodes` (valid when stamp matches)
+  std::vector<int64_t> stamp;
+  std::vector<char> seen;
+  int64_t generation = 0;
+};
+
 // edges[k] = (i_rel, j_rel) in the order the reference adds them to `matches`.
-static void chunk_rejects(const std::vector<int64_t> &edges, std::vector<int64_t> &rejects) {
+static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, ChunkScratch &w,
+                          std::vector<int64_t> &rejects) {
   rejects.clear();
   const int64_t m = (int64_t)edges.size() / 2;
   if (m == 0) return;
   // (1) Graph(matches): edges arrive in the iteration order of the set of tuples
-  std::vector<int64_t> order;
-  pyset_order_pairs(edges.data(), m, order);
-  std::vector<int64_t> nodes;                      // insertion order of g._node
-  std::unordered_map<int64_t, int64_t> idx;        // node value -> position in `nodes`
-  std::vector<std::vector<int64_t>> adj;           // neighbour lists in insertion order
+  w.edge_set.reset();
+  {
+    const int64_t *pairs = edges.data();
+    auto eq = [&](int64_t x, int64_t y) {
+      return pairs[x * 2] == pairs[y * 2] && pairs[x * 2 + 1] == pairs[y * 2 + 1];
+    };
+    for (int64_t k = 0; k < m; ++k) w.edge_set.add(k, py_tuple2_hash(pairs[k * 2], pairs[k * 2 + 1]), eq);
+    w.order.clear();
+    w.edge_set.for_each([&](int64_t key) { w.order.push_back(key); });
+  }
+  if ((int64_t)w.pos_of.size() < chunk_len) {
+    w.pos_of.resize((size_t)chunk_len);
+    w.stamp.resize((size_t)chunk_len, -1);
+  }
+  const int64_t gen = ++w.generation;
+  w.nodes.clear();
+  w.adj_head.clear();  // per node: first adjacency record (-1 = none); records form insertion-ordered lists
+  w.adj_tail.clear();
+  w.adj_next.clear();
+  w.adj_to.clear();
   auto node_of = [&](int64_t v) {
-    auto it = idx.find(v);
-    if (it != idx.end()) return it->second;
-    const int64_t p = (int64_t)nodes.size();
-    idx.emplace(v, p);
-    nodes.push_back(v);
-    adj.emplace_back();
+    if (w.stamp[(size_t)v] == gen) return w.pos_of[(size_t)v];
+    const int64_t p = (int64_t)w.nodes.size();
+    w.stamp[(size_t)v] = gen;
+    w.pos_of[(size_t)v] = p;
+    w.nodes.push_back(v);
+    w.adj_head.push_back(-1);
+    w.adj_tail.push_back(-1);
     return p;
   };
-  for (int64_t e : order) {
-    const int64_t u = edges[e * 2], v = edges[e * 2 + 1];
-    const int64_t pu = node_of(u), pv = node_of(v);
-    // dict semantics: re-adding an existing neighbour keeps its position
-    bool have = false;
-    for (int64_t w : adj[pu]) have = have || (w == pv);
-    if (!have) adj[pu].push_back(pv);
-    have = false;
-    for (int64_t w : adj[pv]) have = have || (w == pu);
-    if (!have) adj[pv].push_back(pu);
+  auto link = [&](int64_t from, int64_t to) {  // matches are unique pairs: no duplicate neighbours
+    const int64_t rec = (int64_t)w.adj_to.size();
+    w.adj_to.push_back(to);
+    w.adj_next.push_back(-1);
+    if (w.adj_head[(size_t)from] < 0) w.adj_head[(size_t)from] = rec;
+    else w.adj_next[(size_t)w.adj_tail[(size_t)from]] = rec;
+    w.adj_tail[(size_t)from] = rec;
+  };
+  for (int64_t e : w.order) {
+    const int64_t pu = node_of(edges[e * 2]);
+    const int64_t pv = node_of(edges[e * 2 + 1]);
+    link(pu, pv);
+    link(pv, pu);
   }
-  const int64_t n_nodes = (int64_t)nodes.size();
-  std::vector<char> seen_all(n_nodes, 0);
+  const int64_t n_nodes = (int64_t)w.nodes.size();
+  w.seen.assign((size_t)n_nodes, 0);
   int64_t n_seen = 0;
   for (int64_t src = 0; src < n_nodes; ++src) {
-    if (seen_all[src]) continue;
+    if (w.seen[(size_t)src]) continue;
     // (2) networkx _plain_bfs: `seen` is a Python set filled in BFS order
-    PySetEmu comp;
-    std::vector<int64_t> members;  // BFS discovery order (positions)
+    w.comp.reset();
+    w.members.clear();
     const int64_t limit = n_nodes - n_seen;
-    comp.add(nodes[src], nodes[src], int_eq);
-    members.push_back(src);
-    seen_all[src] = 1;
-    std::vector<int64_t> level{src}, next;
-    bool full = (int64_t)members.size() == limit;
-    while (!level.empty() && !full) {
-      next.clear();
-      for (int64_t v : level) {
-        for (int64_t w : adj[v]) {
-          if (!seen_all[w]) {
-            seen_all[w] = 1;
-            comp.add(nodes[w], nodes[w], int_eq);
-            members.push_back(w);
-            next.push_back(w);
+    w.comp.add(w.nodes[(size_t)src], w.nodes[(size_t)src], int_eq);
+    w.members.push_back(src);
+    w.seen[(size_t)src] = 1;
+    w.level.assign(1, src);
+    bool full = (int64_t)w.members.size() == limit;
+    while (!w.level.empty() && !full) {
+      w.next.clear();
+      for (int64_t v : w.level) {
+        for (int64_t rec = w.adj_head[(size_t)v]; rec >= 0; rec = w.adj_next[(size_t)rec]) {
+          const int64_t x = w.adj_to[(size_t)rec];
+          if (!w.seen[(size_t)x]) {
+            w.seen[(size_t)x] = 1;
+            w.comp.add(w.nodes[(size_t)x], w.nodes[(size_t)x], int_eq);
+            w.members.push_back(x);
+            w.next.push_back(x);
           }
         }
-        if ((int64_t)members.size() == limit) {
+        if ((int64_t)w.members.size() == limit) {
           full = true;
           break;
         }
       }
-      level.swap(next);
+      w.level.swap(w.next);
     }
-    n_seen += (int64_t)members.size();
+    n_seen += (int64_t)w.members.size();
     // (3) group[0] of tuple(g.subgraph(c).nodes)
     int64_t first;
-    if (2 * (int64_t)members.size() < n_nodes) {
-      PySetEmu view;  // show_nodes.nodes = set(nbunch_iter(c)): rebuilt in c's iteration order
-      comp.for_each([&](int64_t key) { view.add(key, key, int_eq); });
+    if (2 * (int64_t)w.members.size() < n_nodes) {
+      w.view.reset();  // show_nodes.nodes = set(nbunch_iter(c)): rebuilt in c's iteration order
+      w.comp.for_each([&](int64_t key) { w.view.add(key, key, int_eq); });
       first = -1;
-      view.for_each([&](int64_t key) {
+      w.view.for_each([&](int64_t key) {
         if (first < 0) first = key;
       });
     } else {
-      first = nodes[src];  // atlas order: the BFS source is the component's earliest node
+      first = w.nodes[(size_t)src];  // atlas order: the BFS source is the component's earliest node
     }
-    for (int64_t p : members)
-      if (nodes[p] != first) rejects.push_back(nodes[p]);
+    for (int64_t p : w.members)
+      if (w.nodes[(size_t)p] != first) rejects.push_back(w.nodes[(size_t)p]);
+  }
+}
+
+// chunks [step_begin, step_end) of one ladder level; chunks are independent
+static void level_chunks(const int64_t *fm, int64_t N, int64_t k, int64_t d, int64_t num_active,
+                         int64_t step_begin, int64_t step_end, uint8_t *mask_out) {
+  std::vector<int64_t> edges, rejects;
+  ChunkScratch scratch;
+  for (int64_t step = step_begin; step < step_end; ++step) {
+    const int64_t lo = d * step;
+    // torsion_module.py:987-990: the LAST chunk ends at num_active_str, not at N
+    const int64_t len = (step == k - 1) ? (num_active - lo) : (d * (step + 1) - lo);
+    if (len <= 1) continue;
+    if (lo >= N) break;
+    edges.clear();
+    const int64_t hi = lo + len;  // exclusive; <= N because num_active <= N
+    for (int64_t i = lo; i < hi && i < N; ++i) {
+      const int64_t j = fm[i];
+      if (j >= 0 && j < hi) {
+        edges.push_back(i - lo);
+        edges.push_back(j - lo);
+      }
+    }
+    if (edges.empty()) continue;
+    chunk_rejects(edges, len, scratch, rejects);
+    for (int64_t r : rejects) mask_out[r + lo] = 0;  // chunks own disjoint row ranges
   }
 }
 
@@ -239,31 +302,28 @@ static void chunk_rejects(const std::vector<int64_t> &edges, std::vector<int64_t
 int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out) {
   static const double kl[] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};
   for (int64_t i = 0; i < N; ++i) mask_out[i] = 1;
-  std::vector<int64_t> edges, rejects;
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 1;
+  if (hw > 16) hw = 16;
   for (double kd : kl) {
     const int64_t k = (int64_t)kd;
     int64_t num_active = 0;
     for (int64_t i = 0; i < N; ++i) num_active += mask_out[i];
     if (!(k == 1 || 5 * k < num_active)) continue;
     const int64_t d = N / k;
-    for (int64_t step = 0; step < k; ++step) {
-      const int64_t lo = d * step;
-      // torsion_module.py:987-990: the LAST chunk ends at num_active_str, not at N
-      int64_t len = (step == k - 1) ? (num_active - lo) : (d * (step + 1) - lo);
-      if (len <= 1) continue;
-      if (lo >= N) break;
-      edges.clear();
-      const int64_t hi = lo + len;  // exclusive; may exceed N only through num_active <= N: never
-      for (int64_t i = lo; i < hi && i < N; ++i) {
-        const int64_t j = fm[i];
-        if (j >= 0 && j < hi) {
-          edges.push_back(i - lo);
-          edges.push_back(j - lo);
-        }
+    // fine levels: many independent chunks -> host threads; coarse levels: one thread
+    const int64_t nthreads = (k >= 64 && N >= 100000) ? (int64_t)hw : 1;
+    if (nthreads == 1) {
+      level_chunks(fm, N, k, d, num_active, 0, k, mask_out);
+    } else {
+      std::vector<std::thread> pool;
+      const int64_t per = (k + nthreads - 1) / nthreads;
+      for (int64_t t = 0; t < nthreads; ++t) {
+        const int64_t b = t * per, e = std::min<int64_t>(k, (t + 1) * per);
+        if (b >= e) break;
+        pool.emplace_back(level_chunks, fm, N, k, d, num_active, b, e, mask_out);
       }
-      if (edges.empty()) continue;
-      chunk_rejects(edges, rejects);
-      for (int64_t r : rejects) mask_out[r + lo] = 0;
+      for (auto &th : pool) th.join();
     }
   }
   return FC_OK;

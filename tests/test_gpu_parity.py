@@ -526,3 +526,29 @@ def test_sharded_pairs_exchange_on_one_gpu(fc, world):
     for ens in ranks:
         assert np.array_equal(ens.prune_from_pairs(union), ref)
         ens.close()
+
+
+# ---------------------------------------------------------------- screen-kernel variants / odd shapes
+@pytest.mark.parametrize("n,a", [(2, 1), (3, 2), (70, 3), (130, 5), (200, 80), (150, 104), (140, 110), (90, 130)])
+def test_prune_odd_shapes_and_all_screen_variants(fc, n, a):
+    """A <= 53: mfma<4>; 54..104: mfma<8> (one workgroup per CU); > 104: VALU screen
+    without LDS staging; plus tiny atom counts (K padded to 4) and tiny N"""
+    X, atoms, asg = syn.synthetic_ensemble(n, a, seed=90 + a, cluster_size=3)
+    S0, R0, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    _, mask = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    assert np.array_equal(mask, ref)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        bits, grey = ens.simbits(0.5, 1.0)
+    from firecode_amd._lib import unpack_bits
+
+    assert np.array_equal(unpack_bits(bits, n), np.triu(S0, 1))
+
+
+@pytest.mark.parametrize("cfg", ["valu8x4", "valu4x8"])
+def test_valu_screen_kernels_still_agree(fc, cfg, monkeypatch):
+    monkeypatch.setenv("FC_SCREEN_CFG", cfg)
+    X, atoms, _ = syn.synthetic_ensemble(500, 33, seed=97)
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    _, mask = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    assert np.array_equal(mask, o.greedy_prune_from_matrix(S0))
