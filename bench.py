@@ -171,9 +171,16 @@ def main():
             # dominant kernel: k_simbits_screen, HIP events on the library's stream
             owned_pairs = pairs_total
             achieved = owned_pairs * bytes_per_alignment / (t_kernel_ms * 1e-3) / 1e9
+            # fabric-side bytes per launch of the same kernel on the same workload, from the
+            # committed PMC passes (rocprofv3 cannot run inside this process)
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_screen_final.json")
+            if n_conf == N_CONF and os.path.exists(pmc):
+                traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+                traffic_src = "profiles/r01_pmc_screen_final.json"
             out["roofline"] = {
-                "bound": "hbm", "kernel": "k_simbits_screen", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bound": "hbm", "kernel": "k_simbits_screen_mfma", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms": t_kernel_ms, "algorithmic_bytes_per_alignment": bytes_per_alignment,
                 "compulsory_bytes": n_conf * N_ATOMS * 24 + n_conf * ((n_conf + 63) // 64) * 8,
             }
