@@ -22,7 +22,10 @@ int launch_pack_mask(const uint8_t *, int64_t, uint64_t *, int64_t, unsigned lon
 int launch_level(const uint64_t *, int64_t, const uint64_t *, const uint8_t *, uint8_t *, int64_t,
                  int64_t, int64_t, int64_t, int64_t, int64_t);
 int launch_copy_bytes(const uint8_t *, uint8_t *, int64_t);
-int launch_mask_init(uint64_t *, int64_t, int64_t);
+int launch_mask_init(uint64_t *, int64_t, int64_t, int64_t);
+int launch_ladder_pairs(const uint64_t *, const unsigned long long *, const unsigned long long *,
+                        unsigned long long, unsigned long long, int64_t, int64_t, int64_t, const int64_t *,
+                        int, uint64_t *, unsigned long long *);
 int launch_scatter_pairs(const uint64_t *, int64_t, int64_t, int64_t, uint64_t *);
 int launch_level_fused(const uint64_t *, int64_t, const uint64_t *, uint64_t *, int64_t, int64_t,
                        int64_t, unsigned long long *);
@@ -160,7 +163,7 @@ static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const 
   FC_TRY(e->Xs.reserve((size_t)((e->A + 3) / 4 * 4) * 3 * e->Npad * sizeof(double)));
   FC_TRY(e->G.reserve((size_t)e->Npad * sizeof(double)));
   FC_TRY(e->Xa.reserve((size_t)std::max<int64_t>(N, 1) * e->A * 3 * sizeof(double)));
-  FC_TRY(e->counters.reserve(8 * sizeof(uint64_t)));
+  FC_TRY(e->counters.reserve(16 * sizeof(uint64_t)));
   DevBuf raw, dsel;
   FC_TRY(upload(raw, coords, (size_t)N * A_all * 3));
   FC_TRY(upload(dsel, sel.data(), sel.size()));
@@ -235,36 +238,69 @@ static const int64_t kLadder[] = {500000, 200000, 100000, 50000, 20000, 10000, 5
 // whole ladder on one device (world == 1), enqueued without host round trips:
 // one fused launch per ladder value that can still apply (the first ones are
 // ruled out on the host from N alone), one sync at the end.
+// pairs_dev != nullptr: a device list of the exactly-similar pairs whose length is the device
+// counter counters[2] (refine output; complete iff counters[6] <= pairq_cap) or, with
+// pairs_are_final, counters[2] alone (list uploaded by the caller).  Then the one-launch
+// k_ladder_pairs runs first and the bit-matrix levels behind it return at once.
+static const unsigned long long kPairLadderCap = 1ull << 20;
+
 static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_per_group,
                          uint8_t *mask_out, int64_t *levels, int64_t *survivors,
-                         unsigned long long *counters_out = nullptr) {
+                         unsigned long long *counters_out = nullptr, const uint64_t *pairs_dev = nullptr,
+                         bool pairs_are_final = false) {
   const int64_t N = e->N, W = e->W;
   const int n_ladder = (int)(sizeof(kLadder) / sizeof(kLadder[0]));
   FC_TRY(e->ladder.reserve((size_t)(n_ladder + 1) * W * sizeof(uint64_t)));
-  FC_TRY(pinned_reserve((size_t)(W + 8) * sizeof(uint64_t)));
+  FC_TRY(pinned_reserve((size_t)(W + 16) * sizeof(uint64_t)));
   uint64_t *mb = e->ladder.as<uint64_t>();
   auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
-  FC_HIP_TRY(hipMemsetAsync(mb, 0, (size_t)(n_ladder + 1) * W * sizeof(uint64_t), ctx().stream));
-  FC_HIP_TRY(hipMemsetAsync(cnt + 5, 0, sizeof(uint64_t), ctx().stream));
-  FC_TRY(launch_mask_init(mb, N, W));
-  int cur = 0;
-  for (int64_t k : kLadder) {
-    if (!(k == 1 || min_per_group * k < N)) continue;  // can never run: n_active <= N
-    FC_TRY(launch_level_fused(bits_dev, W, mb + (size_t)cur * W, mb + (size_t)(cur + 1) * W, N, k,
-                              min_per_group, cnt));
-    ++cur;
-  }
-  // results land in pinned memory: both copies are asynchronous, one sync for the whole stage
+  // ladder values that can ever run (n_active <= N) -- decided here, the rest on the device
+  std::vector<int64_t> ks;
+  for (int64_t k : kLadder)
+    if (k == 1 || min_per_group * k < N) ks.push_back(k);
+  const int n_lv = (int)ks.size();
+  // counters[8] = levels run, counters[9] = "k_ladder_pairs produced the mask"
+  FC_HIP_TRY(hipMemsetAsync(cnt + 8, 0, 2 * sizeof(uint64_t), ctx().stream));
   uint64_t *words = static_cast<uint64_t *>(ctx().pinned);
   uint64_t *cnt_host = words + W;
-  FC_TRY(d2h(words, mb + (size_t)cur * W, (size_t)W * sizeof(uint64_t)));
-  FC_TRY(d2h(cnt_host, cnt, 8 * sizeof(uint64_t)));
-  FC_TRY(sync());
+  bool have_mask = false;
+  const bool lds_ok = (size_t)2 * W * sizeof(uint64_t) <= 60 * 1024;
+  if (pairs_dev != nullptr && lds_ok) {
+    // sparse similarity (the usual case): the whole ladder is ONE launch over the pair list
+    if (e->ladder_k_n != n_lv || e->ladder_k_mpg != min_per_group) {
+      FC_TRY(e->ladder_k.reserve(ks.size() * sizeof(int64_t)));
+      FC_TRY(h2d(e->ladder_k.p, ks.data(), ks.size() * sizeof(int64_t)));
+      FC_TRY(sync());  // ks is a local: the copy must finish before it goes out of scope
+      e->ladder_k_n = n_lv;
+      e->ladder_k_mpg = min_per_group;
+    }
+    FC_TRY(launch_ladder_pairs(pairs_dev, cnt + 2, pairs_are_final ? nullptr : cnt + 6,
+                               (unsigned long long)e->pairq_cap, kPairLadderCap, N, W, min_per_group,
+                               e->ladder_k.as<int64_t>(), n_lv, mb + (size_t)n_lv * W, cnt));
+    FC_TRY(d2h(words, mb + (size_t)n_lv * W, (size_t)W * sizeof(uint64_t)));
+    FC_TRY(d2h(cnt_host, cnt, 16 * sizeof(uint64_t)));
+    FC_TRY(sync());
+    have_mask = cnt_host[9] != 0;
+  }
+  if (!have_mask) {
+    // dense similarity / no pair list: one fused launch per level over the bit matrix
+    if (bits_dev == nullptr) return set_error(FC_E_LIMIT, "pair list too long for the one-launch ladder and no bit matrix given");
+    FC_TRY(launch_mask_init(mb, N, W, (int64_t)(n_lv + 1) * W));
+    int cur = 0;
+    for (int64_t k : ks) {
+      FC_TRY(launch_level_fused(bits_dev, W, mb + (size_t)cur * W, mb + (size_t)(cur + 1) * W, N, k,
+                                min_per_group, cnt));
+      ++cur;
+    }
+    FC_TRY(d2h(words, mb + (size_t)n_lv * W, (size_t)W * sizeof(uint64_t)));
+    FC_TRY(d2h(cnt_host, cnt, 16 * sizeof(uint64_t)));
+    FC_TRY(sync());
+  }
   int64_t alive = 0;
   for (int64_t w = 0; w < W; ++w) alive += __builtin_popcountll(words[w]);
   if (mask_out)
     for (int64_t i = 0; i < N; ++i) mask_out[i] = (uint8_t)((words[(size_t)(i >> 6)] >> (i & 63)) & 1ull);
-  if (levels) *levels = (int64_t)cnt_host[5];
+  if (levels) *levels = (int64_t)cnt_host[8];
   if (survivors) *survivors = alive;
   if (counters_out)
     for (int k = 0; k < 8; ++k) counters_out[k] = cnt_host[k];
@@ -451,7 +487,8 @@ int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const doubl
   FC_TRY(simbits_local(ens, max_rmsd, max_dev, energies, max_dE, true));
   unsigned long long cnt[8];
   int64_t levels = 0, survivors = 0;
-  FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), min_per_group, mask_out, &levels, &survivors, cnt));
+  FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), min_per_group, mask_out, &levels, &survivors, cnt,
+                       ens->simq.as<uint64_t>()));
   if (stats) {
     stats[0] = ens->N * (ens->N - 1) / 2;
     stats[1] = (int64_t)cnt[1];
@@ -477,7 +514,7 @@ int fc_greedy_prune_from_bits(const uint64_t *bits, int64_t N, int64_t min_per_g
   FC_TRY(e.maskA.reserve((size_t)e.Npad));
   FC_TRY(e.maskB.reserve((size_t)e.Npad));
   FC_TRY(e.mbits.reserve((size_t)e.W * sizeof(uint64_t)));
-  FC_TRY(e.counters.reserve(8 * sizeof(uint64_t)));
+  FC_TRY(e.counters.reserve(16 * sizeof(uint64_t)));
   // rows padded to a multiple of the row block so k_level's local row == global row
   const int64_t rows = ceil_div(N, e.row_block) * e.row_block;
   FC_TRY(e.bits.reserve((size_t)rows * e.W * sizeof(uint64_t)));
@@ -557,13 +594,21 @@ int fc_prune_from_pairs(fc_ensemble *ens, const uint64_t *pairs, int64_t n_pairs
   FC_TRY(ensure_init());
   const int64_t N = ens->N, W = ens->W;
   if (N == 0) return FC_OK;
-  // rows padded like ladder_single expects (local row == global row)
+  FC_TRY(ens->counters.reserve(16 * sizeof(uint64_t)));
+  auto *cnt = reinterpret_cast<unsigned long long *>(ens->counters.p);
+  DevBuf dp;
+  FC_TRY(upload(dp, pairs, (size_t)n_pairs));
+  const unsigned long long np = (unsigned long long)n_pairs;
+  FC_TRY(h2d(cnt + 2, &np, sizeof np));  // k_ladder_pairs reads the list length from counters[2]
+  const bool sparse = np <= kPairLadderCap && (size_t)2 * W * sizeof(uint64_t) <= 60 * 1024;
+  if (sparse)  // one launch over the pair list; no bit matrix needed
+    return ladder_single(ens, nullptr, min_per_group, mask_out, nullptr, nullptr, nullptr,
+                         dp.as<uint64_t>(), true);
+  // dense: rebuild the whole bit matrix (rows padded like ladder_single expects) and run the levels
   const int64_t rb = ens->row_block > 0 ? ens->row_block : 64;
   const size_t bytes = (size_t)(ceil_div(N, rb) * rb) * W * sizeof(uint64_t);
   FC_TRY(ens->bits_full.reserve(bytes));
   FC_HIP_TRY(hipMemsetAsync(ens->bits_full.p, 0, bytes, ctx().stream));
-  DevBuf dp;
-  FC_TRY(upload(dp, pairs, (size_t)n_pairs));
   FC_TRY(launch_scatter_pairs(dp.as<uint64_t>(), n_pairs, N, W, ens->bits_full.as<uint64_t>()));
   return ladder_single(ens, ens->bits_full.as<uint64_t>(), min_per_group, mask_out, nullptr, nullptr);
 }
@@ -599,7 +644,7 @@ int fc_prune_moi(const double *coords, int64_t N, int64_t A, const double *masse
   FC_TRY(e.maskA.reserve((size_t)e.Npad));
   FC_TRY(e.maskB.reserve((size_t)e.Npad));
   FC_TRY(e.mbits.reserve((size_t)e.W * sizeof(uint64_t)));
-  FC_TRY(e.counters.reserve(8 * sizeof(uint64_t)));
+  FC_TRY(e.counters.reserve(16 * sizeof(uint64_t)));
   const int64_t rows = ceil_div(N, e.row_block) * e.row_block;
   FC_TRY(e.bits.reserve((size_t)rows * e.W * sizeof(uint64_t)));
   DevBuf dc, dm, dmom;
@@ -1020,7 +1065,7 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
     FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
     ens->bits_valid = true;
     FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, r + 1 == reps ? mask_out : nullptr, &levels,
-                         &survivors, cnt));
+                         &survivors, cnt, ens->simq.as<uint64_t>()));
     FC_HIP_TRY(hipEventRecord(c.ev2, c.stream));
     FC_HIP_TRY(hipEventSynchronize(c.ev2));
     float a = 0.f, b = 0.f;

@@ -141,6 +141,9 @@ struct fc_ensemble {
   fc::DevBuf maskA, maskB;     // N bytes each
   fc::DevBuf mbits;            // W uint64 active-flag words
   fc::DevBuf ladder;           // (levels+1) x W mask words of the fused single-GPU ladder
+  fc::DevBuf ladder_k;         // the ladder values that can apply at this N (int64), for k_ladder_pairs
+  int ladder_k_n = -1;
+  int64_t ladder_k_mpg = -1;
   fc::DevBuf counters;         // 8 x uint64
   // sharding of the bit matrix rows (block-cyclic)
   int64_t rank = 0, world = 1, row_block = 64;

@@ -157,6 +157,55 @@ __device__ __forceinline__ void pair_exact_aos(const double *__restrict__ Xa, in
   }
 }
 
+// Same evaluation with EIGHT lanes per pair (sub-lane s = lane & 7 takes atoms
+// s, s+8, ...; 8 consecutive atoms are 192 contiguous bytes of Xa): the atom
+// loops shrink eightfold and the partial sums meet through three xor-shuffles
+// that never leave the 8-lane group.  Cuts the latency of the sparse refine,
+// whose few hundred pairs cannot fill the chip anyway.
+__device__ __forceinline__ double group8_sum(double v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  return v;
+}
+__device__ __forceinline__ double group8_max(double v) {
+  v = fmax(v, __shfl_xor(v, 1));
+  v = fmax(v, __shfl_xor(v, 2));
+  v = fmax(v, __shfl_xor(v, 4));
+  return v;
+}
+
+__device__ __forceinline__ void pair_exact_group8(const double *__restrict__ Xa, int A, int64_t i,
+                                                  int64_t j, int sub, double &rmsd, double &maxdev) {
+  const double *__restrict__ p = Xa + i * (int64_t)A * 3;
+  const double *__restrict__ q = Xa + j * (int64_t)A * 3;
+  double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int a = sub; a < A; a += 8) {
+    const double px = p[a * 3], py = p[a * 3 + 1], pz = p[a * 3 + 2];
+    const double qx = q[a * 3], qy = q[a * 3 + 1], qz = q[a * 3 + 2];
+    B[0] = fma(px, qx, B[0]); B[1] = fma(px, qy, B[1]); B[2] = fma(px, qz, B[2]);
+    B[3] = fma(py, qx, B[3]); B[4] = fma(py, qy, B[4]); B[5] = fma(py, qz, B[5]);
+    B[6] = fma(pz, qx, B[6]); B[7] = fma(pz, qy, B[7]); B[8] = fma(pz, qz, B[8]);
+  }
+#pragma unroll
+  for (int e = 0; e < 9; ++e) B[e] = group8_sum(B[e]);
+  double R[9];
+  (void)kabsch_rotation(B, R);  // identical in the 8 lanes of the group
+  double ssq = 0.0, mx = 0.0;
+  for (int a = sub; a < A; a += 8) {
+    const double px = p[a * 3], py = p[a * 3 + 1], pz = p[a * 3 + 2];
+    const double qx = q[a * 3], qy = q[a * 3 + 1], qz = q[a * 3 + 2];
+    const double dx = px - (R[0] * qx + R[1] * qy + R[2] * qz);
+    const double dy = py - (R[3] * qx + R[4] * qy + R[5] * qz);
+    const double dz = pz - (R[6] * qx + R[7] * qy + R[8] * qz);
+    const double s = dx * dx + dy * dy + dz * dz;
+    ssq += s;
+    mx = fmax(mx, s);
+  }
+  rmsd = sqrt(group8_sum(ssq) / (double)A);
+  maxdev = sqrt(group8_max(mx));
+}
+
 // Same evaluation with the whole wavefront on ONE pair: lane = atom (strided),
 // the nine covariance sums and the deviation sum / max are reduced across the
 // wave with xor shuffles; the 4x4 eigen-solve runs redundantly in every lane.
@@ -598,27 +647,31 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const unsigned long long n_pairs = counters[6];
   if (n_pairs <= Q) {
-    // pair mode: the queue is complete -> one lane per candidate pair; a pair
-    // that is not similar has its screen bit cleared
-    for (int64_t base = wave0 * 64; base < (int64_t)n_pairs; base += nwaves * 64) {
-      const int64_t p = base + lane;
+    // pair mode: the queue is complete -> eight lanes per candidate pair (8 pairs
+    // per wavefront); a pair that is not similar has its screen bit cleared
+    const int sub = lane & 7, slot = lane >> 3;
+    for (int64_t base = wave0 * 8; base < (int64_t)n_pairs; base += nwaves * 8) {
+      const int64_t p = base + slot;
       const bool on = p < (int64_t)n_pairs;
       bool sim = false, grey = false;
-      if (on) {
-        const uint64_t e = pairq[p];
+      uint64_t e = 0;
+      if (on) {  // uniform inside each 8-lane group
+        e = pairq[p];
         const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
         double r, m;
-        pair_exact_aos(Xa, A, i, j, r, m);
+        pair_exact_group8(Xa, A, i, j, sub, r, m);
         sim = (r < max_rmsd) && (m < max_dev);
         grey = (fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9);
         if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
-        if (!sim) {
+        if (!sim && sub == 0) {
           const int64_t lrow = ((i / IB) / world) * IB + (i % IB);
           atomicAnd(reinterpret_cast<unsigned long long *>(&bits[lrow * W + (j >> 6)]),
                     ~(1ull << (j & 63)));
         }
       }
-      const uint64_t mo = __ballot(on), ms = __ballot(sim), mg = __ballot(grey);
+      // one representative lane per pair in the ballots
+      const bool rep = on && sub == 0;
+      const uint64_t mo = __ballot(rep), ms = __ballot(rep && sim), mg = __ballot(rep && grey);
       unsigned long long sbase = 0;
       if (lane == 0) {
         atomicAdd(&counters[1], (unsigned long long)__popcll(mo));
@@ -626,9 +679,9 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
         if (mg) atomicAdd(&counters[3], (unsigned long long)__popcll(mg));
       }
       // list of exactly-similar pairs (same capacity as the candidate queue):
-      // what a rank contributes to the multi-GPU exchange
+      // what the one-launch ladder and the multi-GPU exchange consume
       sbase = __shfl(sbase, 0);
-      if (sim) simq[sbase + (unsigned long long)__popcll(ms & ((1ull << lane) - 1ull))] = pairq[p];
+      if (rep && sim) simq[sbase + (unsigned long long)__popcll(ms & ((1ull << lane) - 1ull))] = e;
     }
     return;
   }
@@ -888,7 +941,7 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
   if (e->rows_local * e->W == 0) return FC_OK;
   // persistent-style grid: wavefronts stride over the candidate queue whose
   // length the screen kernel left in counters[4] (same stream, no host sync)
-  hipLaunchKernelGGL(k_simbits_refine, dim3((unsigned)(ctx().n_cu * 8)), dim3(256), 0,
+  hipLaunchKernelGGL(k_simbits_refine, dim3((unsigned)(ctx().n_cu * 16)), dim3(256), 0,
                      ctx().stream, e->Xs.as<double>(), e->Xa.as<double>(), e->N, e->Npad, (int)e->A,
                      max_rmsd, max_dev, energies_dev, max_dE, (int)e->row_block, e->rank, e->world,
                      e->rows_local,

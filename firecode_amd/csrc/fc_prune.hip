@@ -79,9 +79,13 @@ k_level(const uint64_t *__restrict__ bits, int64_t W, const uint64_t *__restrict
 // mask words: mb_in (read), mb_out (zeroed beforehand, survivors OR their bit).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_mask_init(uint64_t *__restrict__ mb, int64_t N, int64_t W) {
+k_mask_init(uint64_t *__restrict__ mb, int64_t N, int64_t W, int64_t total_words) {
   const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= W) return;
+  if (w >= total_words) return;
+  if (w >= W) {  // the level outputs start from zero (survivors OR their bit in)
+    mb[w] = 0;
+    return;
+  }
   const int64_t lo = w * 64;
   uint64_t v = 0;
   if (lo + 64 <= N) v = ~0ull;
@@ -133,7 +137,80 @@ k_level_fused(const uint64_t *__restrict__ bits, int64_t W, const uint64_t *__re
   const bool any = __any(hit);
   if (lane == 0) {
     if (!any) atomicOr(reinterpret_cast<unsigned long long *>(&mb_out[i >> 6]), 1ull << (i & 63));
-    if (run && first && counters != nullptr) atomicAdd(&counters[5], 1ull);
+    if (run && first && counters != nullptr) atomicAdd(&counters[8], 1ull);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_ladder_pairs: the WHOLE k-ladder in one launch when similarity is sparse.
+// With the exactly-similar pairs as a list (i < j), a level is
+//     for every pair: in[i] && in[j] && chunk_k(i) == chunk_k(j)  ->  out[i] = 0
+// so one 1024-thread workgroup keeps the mask words in LDS, walks the pair list
+// once per level and separates levels with __syncthreads(): no grid barrier, no
+// host round trip, ~1 us per level.  `n_pairs_ptr`/`n_cand_ptr` are device
+// counters (the refine kernel's outputs); the kernel does nothing -- and leaves
+// counters[9] = 0 -- when the list is incomplete (candidate queue overflow) or
+// longer than `cap`, in which case the bit-matrix levels launched behind it do
+// the work (the host sees the flag with the results and launches them only then);
+// otherwise it sets counters[9] = 1.  counters[8] = levels that ran.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_ladder_pairs(const uint64_t *__restrict__ pairs, const unsigned long long *__restrict__ n_pairs_ptr,
+               const unsigned long long *__restrict__ n_cand_ptr, unsigned long long cand_cap,
+               unsigned long long cap, int64_t N, int64_t W, int64_t min_per_group,
+               const int64_t *__restrict__ ladder, int n_ladder, uint64_t *__restrict__ mask_out,
+               unsigned long long *__restrict__ counters) {
+  extern __shared__ unsigned long long lm[];  // cur[W] | nxt[W]
+  __shared__ int s_count;
+  const int tid = threadIdx.x;
+  const unsigned long long P = *n_pairs_ptr;
+  if ((n_cand_ptr != nullptr && *n_cand_ptr > cand_cap) || P > cap) {
+    if (tid == 0) counters[9] = 0;
+    return;
+  }
+  unsigned long long *cur = lm, *nxt = lm + W;
+  for (int64_t w = tid; w < W; w += 1024) {
+    const int64_t lo = w * 64;
+    cur[w] = (lo + 64 <= N) ? ~0ull : ((lo < N) ? ((1ull << (N - lo)) - 1ull) : 0ull);
+  }
+  __syncthreads();
+  int levels = 0;
+  for (int l = 0; l < n_ladder; ++l) {
+    const int64_t k = ladder[l];
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    int c = 0;
+    for (int64_t w = tid; w < W; w += 1024) c += __popcll(cur[w]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((tid & 63) == 0 && c) atomicAdd(&s_count, c);
+    __syncthreads();
+    const bool run = (k == 1) || (min_per_group * k < (int64_t)s_count);
+    if (!run) continue;  // block-uniform
+    ++levels;
+    for (int64_t w = tid; w < W; w += 1024) nxt[w] = cur[w];
+    __syncthreads();
+    // indices fit 32 bits (pairs are packed as two 32-bit halves): 32-bit divisions
+    const uint32_t chunk = (uint32_t)(N / k), kmax = (uint32_t)(k - 1), n32 = (uint32_t)N;
+    for (unsigned long long p = tid; p < P; p += 1024) {
+      const uint64_t e = pairs[p];
+      const uint32_t i = (uint32_t)(e >> 32), j = (uint32_t)(e & 0xffffffffull);
+      if (j <= i || j >= n32) continue;  // padding
+      if (!((cur[i >> 6] >> (i & 63)) & 1ull) || !((cur[j >> 6] >> (j & 63)) & 1ull)) continue;
+      uint32_t ci = i / chunk, cj = j / chunk;
+      if (ci > kmax) ci = kmax;
+      if (cj > kmax) cj = kmax;
+      if (ci == cj) atomicAnd(&nxt[i >> 6], ~(1ull << (i & 63)));
+    }
+    __syncthreads();
+    unsigned long long *t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  for (int64_t w = tid; w < W; w += 1024) mask_out[w] = cur[w];
+  if (tid == 0) {
+    counters[8] = (unsigned long long)levels;
+    counters[9] = 1;
   }
 }
 
@@ -390,9 +467,9 @@ int launch_level(const uint64_t *bits_dev, int64_t W, const uint64_t *mbits_dev,
   return check_launch("k_level");
 }
 
-int launch_mask_init(uint64_t *mb_dev, int64_t N, int64_t W) {
-  hipLaunchKernelGGL(k_mask_init, dim3((unsigned)ceil_div(W, 256)), dim3(256), 0, ctx().stream,
-                     mb_dev, N, W);
+int launch_mask_init(uint64_t *mb_dev, int64_t N, int64_t W, int64_t total_words) {
+  hipLaunchKernelGGL(k_mask_init, dim3((unsigned)ceil_div(total_words, 256)), dim3(256), 0, ctx().stream,
+                     mb_dev, N, W, total_words);
   return check_launch("k_mask_init");
 }
 
@@ -401,6 +478,18 @@ int launch_level_fused(const uint64_t *bits_dev, int64_t W, const uint64_t *mb_i
   hipLaunchKernelGGL(k_level_fused, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, ctx().stream,
                      bits_dev, W, mb_in, mb_out, N, k, min_per_group, counters);
   return check_launch("k_level_fused");
+}
+
+int launch_ladder_pairs(const uint64_t *pairs_dev, const unsigned long long *n_pairs_dev,
+                        const unsigned long long *n_cand_dev, unsigned long long cand_cap,
+                        unsigned long long cap, int64_t N, int64_t W, int64_t min_per_group,
+                        const int64_t *ladder_dev, int n_ladder, uint64_t *mask_out_dev,
+                        unsigned long long *counters_dev) {
+  const size_t lds = (size_t)2 * W * sizeof(uint64_t);
+  hipLaunchKernelGGL(k_ladder_pairs, dim3(1), dim3(1024), lds, ctx().stream, pairs_dev, n_pairs_dev,
+                     n_cand_dev, cand_cap, cap, N, W, min_per_group, ladder_dev, n_ladder, mask_out_dev,
+                     counters_dev);
+  return check_launch("k_ladder_pairs");
 }
 
 int launch_copy_bytes(const uint8_t *src, uint8_t *dst, int64_t n) {
