@@ -23,7 +23,7 @@ int launch_level(const uint64_t *, int64_t, const uint64_t *, const uint8_t *, u
                  int64_t, int64_t, int64_t, int64_t, int64_t);
 int launch_copy_bytes(const uint8_t *, uint8_t *, int64_t);
 int launch_mask_init(uint64_t *, int64_t, int64_t, int64_t);
-int launch_ladder_pairs(const uint64_t *, const unsigned long long *, const unsigned long long *,
+int launch_ladder_pairs(const uint64_t *, uint32_t *, const unsigned long long *, const unsigned long long *,
                         unsigned long long, unsigned long long, int64_t, int64_t, int64_t, const int64_t *,
                         int, uint64_t *, unsigned long long *);
 int launch_scatter_pairs(const uint64_t *, int64_t, int64_t, int64_t, uint64_t *);
@@ -274,7 +274,9 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
       e->ladder_k_n = n_lv;
       e->ladder_k_mpg = min_per_group;
     }
-    FC_TRY(launch_ladder_pairs(pairs_dev, cnt + 2, pairs_are_final ? nullptr : cnt + 6,
+    FC_TRY(e->levelmask.reserve((size_t)kPairLadderCap * sizeof(uint32_t)));
+    FC_TRY(launch_ladder_pairs(pairs_dev, e->levelmask.as<uint32_t>(), cnt + 2,
+                               pairs_are_final ? nullptr : cnt + 6,
                                (unsigned long long)e->pairq_cap, kPairLadderCap, N, W, min_per_group,
                                e->ladder_k.as<int64_t>(), n_lv, mb + (size_t)n_lv * W, cnt));
     FC_TRY(d2h(words, mb + (size_t)n_lv * W, (size_t)W * sizeof(uint64_t)));

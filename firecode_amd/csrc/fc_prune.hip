@@ -141,6 +141,37 @@ k_level_fused(const uint64_t *__restrict__ bits, int64_t W, const uint64_t *__re
   }
 }
 
+// per similar pair: bit l set when i and j share a chunk at ladder value ladder[l]
+// (the only levels at which the pair can act).  Massively parallel, so the
+// 2 x n_ladder integer divisions per pair cost nothing; the one-workgroup ladder
+// kernel below then touches a pair only at the levels where it matters.
+__global__ void __launch_bounds__(256)
+k_pair_levelmask(const uint64_t *__restrict__ pairs, const unsigned long long *__restrict__ n_pairs_ptr,
+                 unsigned long long cap, int64_t N, const int64_t *__restrict__ ladder, int n_ladder,
+                 uint32_t *__restrict__ levelmask) {
+  const unsigned long long P = *n_pairs_ptr;
+  if (P > cap) return;
+  const uint32_t n32 = (uint32_t)N;
+  for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < P;
+       p += (unsigned long long)gridDim.x * blockDim.x) {
+    const uint64_t e = pairs[p];
+    const uint32_t i = (uint32_t)(e >> 32), j = (uint32_t)(e & 0xffffffffull);
+    uint32_t m = 0;
+    if (j > i && j < n32) {
+      for (int l = 0; l < n_ladder; ++l) {
+        const uint32_t k = (uint32_t)ladder[l];
+        const uint32_t chunk = n32 / k;
+        if (chunk == 0) continue;  // k > N: the level can never run
+        uint32_t ci = i / chunk, cj = j / chunk;
+        if (ci > k - 1) ci = k - 1;
+        if (cj > k - 1) cj = k - 1;
+        if (ci == cj) m |= 1u << l;
+      }
+    }
+    levelmask[p] = m;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // k_ladder_pairs: the WHOLE k-ladder in one launch when similarity is sparse.
 // With the exactly-similar pairs as a list (i < j), a level is
@@ -155,7 +186,8 @@ k_level_fused(const uint64_t *__restrict__ bits, int64_t W, const uint64_t *__re
 // otherwise it sets counters[9] = 1.  counters[8] = levels that ran.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-k_ladder_pairs(const uint64_t *__restrict__ pairs, const unsigned long long *__restrict__ n_pairs_ptr,
+k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ levelmask,
+               const unsigned long long *__restrict__ n_pairs_ptr,
                const unsigned long long *__restrict__ n_cand_ptr, unsigned long long cand_cap,
                unsigned long long cap, int64_t N, int64_t W, int64_t min_per_group,
                const int64_t *__restrict__ ladder, int n_ladder, uint64_t *__restrict__ mask_out,
@@ -173,6 +205,7 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const unsigned long long *__r
     const int64_t lo = w * 64;
     cur[w] = (lo + 64 <= N) ? ~0ull : ((lo < N) ? ((1ull << (N - lo)) - 1ull) : 0ull);
   }
+  const uint32_t n32 = (uint32_t)N;
   __syncthreads();
   int levels = 0;
   for (int l = 0; l < n_ladder; ++l) {
@@ -190,17 +223,27 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const unsigned long long *__r
     ++levels;
     for (int64_t w = tid; w < W; w += 1024) nxt[w] = cur[w];
     __syncthreads();
-    // indices fit 32 bits (pairs are packed as two 32-bit halves): 32-bit divisions
-    const uint32_t chunk = (uint32_t)(N / k), kmax = (uint32_t)(k - 1), n32 = (uint32_t)N;
-    for (unsigned long long p = tid; p < P; p += 1024) {
-      const uint64_t e = pairs[p];
-      const uint32_t i = (uint32_t)(e >> 32), j = (uint32_t)(e & 0xffffffffull);
-      if (j <= i || j >= n32) continue;  // padding
-      if (!((cur[i >> 6] >> (i & 63)) & 1ull) || !((cur[j >> 6] >> (j & 63)) & 1ull)) continue;
-      uint32_t ci = i / chunk, cj = j / chunk;
-      if (ci > kmax) ci = kmax;
-      if (cj > kmax) cj = kmax;
-      if (ci == cj) atomicAnd(&nxt[i >> 6], ~(1ull << (i & 63)));
+    // eight independent (mask, pair) loads in flight per lane: a single workgroup
+    // cannot hide one L2 round trip per pair behind other waves
+    constexpr int U = 8;
+    for (unsigned long long p0 = tid; p0 < P; p0 += 1024ull * U) {
+      uint32_t lmv[U];
+      uint64_t ev[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned long long p = p0 + 1024ull * u;
+        const bool ok = p < P;
+        lmv[u] = ok ? levelmask[p] : 0u;
+        ev[u] = ok ? pairs[p] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if ((lmv[u] >> l) & 1u) {  // the pair shares a chunk at this level (never set for padding)
+          const uint32_t i = (uint32_t)(ev[u] >> 32), j = (uint32_t)(ev[u] & 0xffffffffull);
+          if (((cur[i >> 6] >> (i & 63)) & 1ull) && ((cur[j >> 6] >> (j & 63)) & 1ull))
+            atomicAnd(&nxt[i >> 6], ~(1ull << (i & 63)));
+        }
+      }
     }
     __syncthreads();
     unsigned long long *t = cur;
@@ -480,15 +523,18 @@ int launch_level_fused(const uint64_t *bits_dev, int64_t W, const uint64_t *mb_i
   return check_launch("k_level_fused");
 }
 
-int launch_ladder_pairs(const uint64_t *pairs_dev, const unsigned long long *n_pairs_dev,
-                        const unsigned long long *n_cand_dev, unsigned long long cand_cap,
-                        unsigned long long cap, int64_t N, int64_t W, int64_t min_per_group,
-                        const int64_t *ladder_dev, int n_ladder, uint64_t *mask_out_dev,
-                        unsigned long long *counters_dev) {
+int launch_ladder_pairs(const uint64_t *pairs_dev, uint32_t *levelmask_dev,
+                        const unsigned long long *n_pairs_dev, const unsigned long long *n_cand_dev,
+                        unsigned long long cand_cap, unsigned long long cap, int64_t N, int64_t W,
+                        int64_t min_per_group, const int64_t *ladder_dev, int n_ladder,
+                        uint64_t *mask_out_dev, unsigned long long *counters_dev) {
+  hipLaunchKernelGGL(k_pair_levelmask, dim3((unsigned)(ctx().n_cu * 2)), dim3(256), 0, ctx().stream,
+                     pairs_dev, n_pairs_dev, cap, N, ladder_dev, n_ladder, levelmask_dev);
+  FC_TRY(check_launch("k_pair_levelmask"));
   const size_t lds = (size_t)2 * W * sizeof(uint64_t);
-  hipLaunchKernelGGL(k_ladder_pairs, dim3(1), dim3(1024), lds, ctx().stream, pairs_dev, n_pairs_dev,
-                     n_cand_dev, cand_cap, cap, N, W, min_per_group, ladder_dev, n_ladder, mask_out_dev,
-                     counters_dev);
+  hipLaunchKernelGGL(k_ladder_pairs, dim3(1), dim3(1024), lds, ctx().stream, pairs_dev, levelmask_dev,
+                     n_pairs_dev, n_cand_dev, cand_cap, cap, N, W, min_per_group, ladder_dev, n_ladder,
+                     mask_out_dev, counters_dev);
   return check_launch("k_ladder_pairs");
 }
 
