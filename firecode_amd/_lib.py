@@ -80,6 +80,8 @@ _SIGNATURES = {
     "fc_embed_grid_clash": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64, _p_f64, _p_f64, _i64, _i64, _p_i64, _i64,
                             _p_f64, _p_f64, _p_f64, _i64, _p_f64, _i64, _f64, _i64, _p_u8,
                             C.POINTER(C.c_int32), _p_f64],
+    "fc_embed_grid_dedupe": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64, _p_f64, _p_f64, _i64, _i64, _p_i64, _i64,
+                             _p_f64, _p_f64, _p_f64, _i64, _p_f64, _i64, _f64, _i64, _f64, _p_u8, _p_u8],
     "fc_torsion_scan": [_p_f64, _i64, _p_i64, _i64, _p_u8, _p_i64, _i64, _f64, _i64, _p_f64, _p_i64],
     "fc_torsion_fingerprint": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64],
     "fc_tfd_simbits": [_p_f64, _i64, _i64, _f64, _i64, _i64, _p_u64],

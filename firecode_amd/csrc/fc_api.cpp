@@ -58,6 +58,8 @@ int launch_embed_pretransform(const double *, int64_t, int64_t, int64_t, const d
                               const double *, int, int64_t, double *);
 int launch_embed_grid_clash(const double *, int64_t, int64_t, int64_t, const double *, int64_t, int64_t,
                             int64_t, int64_t, double, int64_t, uint8_t *, int32_t *);
+int launch_embed_group_dedupe(const double *, int64_t, int64_t, int64_t, const double *, int64_t, int64_t,
+                              int64_t, double, const uint8_t *, uint8_t *);
 
 // ---- error state / context -----------------------------------------------------
 std::string &last_error() {
@@ -856,12 +858,13 @@ int fc_embed_mol_transforms(const double *coords, int64_t n, int64_t A, const in
   return sync();
 }
 
-int fc_embed_grid_clash(const double *m1, int64_t n1, int64_t A1, const int64_t *reactive1,
-                        int64_t nr1, const double *ps1, const double *pe1, const double *m2,
-                        int64_t n2, int64_t A2, const int64_t *reactive2, int64_t nr2,
-                        const double *ps2, const double *pe2, const double *angles1, int64_t na1,
-                        const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
-                        uint8_t *pass_out, int32_t *counts_out, double *ms_kernel) {
+static int embed_grid(const double *m1, int64_t n1, int64_t A1, const int64_t *reactive1,
+                      int64_t nr1, const double *ps1, const double *pe1, const double *m2,
+                      int64_t n2, int64_t A2, const int64_t *reactive2, int64_t nr2,
+                      const double *ps2, const double *pe2, const double *angles1, int64_t na1,
+                      const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
+                      uint8_t *pass_out, int32_t *counts_out, double *ms_kernel, double rmsd_thr,
+                      uint8_t *accept_out) {
   FC_TRY(check_embed_mol(m1, n1, A1, reactive1, nr1, ps1, pe1, angles1, na1));
   FC_TRY(check_embed_mol(m2, n2, A2, reactive2, nr2, ps2, pe2, angles2, na2));
   FC_REQUIRE(pass_out != nullptr && max_clashes >= 0, "bad arguments");
@@ -903,6 +906,18 @@ int fc_embed_grid_clash(const double *m1, int64_t n1, int64_t A1, const int64_t 
   FC_TRY(launch_embed_grid_clash(X1.as<double>(), n1, A1, na1, X2s.as<double>(), n2, A2, na2, S2, thresh,
                                  max_clashes, dpass.as<uint8_t>(), counts_out ? dcnt.as<int32_t>() : nullptr));
   FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
+  DevBuf X2a, dacc;
+  if (accept_out != nullptr) {
+    FC_REQUIRE(rmsd_thr > 0.0, "rmsd_thr must be positive");
+    FC_REQUIRE(na1 * na2 * 4 * (int64_t)sizeof(int) <= 64 * 1024, "too many angle pairs per group for the LDS list");
+    FC_TRY(X2a.reserve(G2 * A2 * 3 * sizeof(double)));
+    FC_TRY(dacc.reserve((size_t)P));
+    FC_TRY(launch_embed_pretransform(d2.as<double>(), n2, A2, na2, R2.as<double>(), t2.as<double>(), 1, 0,
+                                     X2a.as<double>()));
+    FC_TRY(launch_embed_group_dedupe(X1.as<double>(), n1, A1, na1, X2a.as<double>(), n2, A2, na2, rmsd_thr,
+                                     dpass.as<uint8_t>(), dacc.as<uint8_t>()));
+    FC_TRY(d2h(accept_out, dacc.p, (size_t)P));
+  }
   FC_TRY(d2h(pass_out, dpass.p, (size_t)P));
   if (counts_out) FC_TRY(d2h(counts_out, dcnt.p, (size_t)P * sizeof(int32_t)));
   FC_TRY(sync());
@@ -912,6 +927,27 @@ int fc_embed_grid_clash(const double *m1, int64_t n1, int64_t A1, const int64_t 
     *ms_kernel = ms;
   }
   return FC_OK;
+}
+
+int fc_embed_grid_clash(const double *m1, int64_t n1, int64_t A1, const int64_t *reactive1,
+                        int64_t nr1, const double *ps1, const double *pe1, const double *m2,
+                        int64_t n2, int64_t A2, const int64_t *reactive2, int64_t nr2,
+                        const double *ps2, const double *pe2, const double *angles1, int64_t na1,
+                        const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
+                        uint8_t *pass_out, int32_t *counts_out, double *ms_kernel) {
+  return embed_grid(m1, n1, A1, reactive1, nr1, ps1, pe1, m2, n2, A2, reactive2, nr2, ps2, pe2, angles1,
+                    na1, angles2, na2, thresh, max_clashes, pass_out, counts_out, ms_kernel, 0.0, nullptr);
+}
+
+int fc_embed_grid_dedupe(const double *m1, int64_t n1, int64_t A1, const int64_t *reactive1,
+                         int64_t nr1, const double *ps1, const double *pe1, const double *m2,
+                         int64_t n2, int64_t A2, const int64_t *reactive2, int64_t nr2,
+                         const double *ps2, const double *pe2, const double *angles1, int64_t na1,
+                         const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
+                         double rmsd_thr, uint8_t *pass_out, uint8_t *accept_out) {
+  FC_REQUIRE(accept_out != nullptr, "accept_out is NULL");
+  return embed_grid(m1, n1, A1, reactive1, nr1, ps1, pe1, m2, n2, A2, reactive2, nr2, ps2, pe2, angles1,
+                    na1, angles2, na2, thresh, max_clashes, pass_out, nullptr, nullptr, rmsd_thr, accept_out);
 }
 
 // ---- a17-a20 -----------------------------------------------------------------------

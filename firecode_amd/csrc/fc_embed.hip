@@ -212,6 +212,113 @@ k_embed_grid_clash(const double *__restrict__ X1, int64_t n1, int A1, int64_t na
 }
 
 // ---------------------------------------------------------------------------
+// k_embed_group_dedupe: the `rmsd_similarity(embedded_structure, angular_poses,
+// rmsd_thr=1)` filter of embeds.py:723 -- inside one (conformer pair,
+// orientation) group the poses are visited in angle order and a clash-free pose
+// is kept only if no previously kept pose of the group has
+// rmsd < thr and maxdev < 2*thr to it (Kabsch without centring, utils.py:494).
+// One wavefront per group; the sequential walk over the <= na1*na2 poses stays
+// in the wave, the comparison against the poses kept so far is lane-parallel
+// (lane = kept pose).  A pose is the concatenation of one pre-transformed
+// structure of each molecule, so the 3x3 covariance of two poses is the sum of
+// the two per-molecule covariances -- no pose is materialised.
+// X1a / X2a: AoS tables [g][atom][3], g = (c*2 + o)*na + a.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void accumulate_cov(const double *__restrict__ p, const double *__restrict__ q,
+                                               int A, double (&B)[9]) {
+  for (int a = 0; a < A; ++a) {
+    const double px = p[a * 3], py = p[a * 3 + 1], pz = p[a * 3 + 2];
+    const double qx = q[a * 3], qy = q[a * 3 + 1], qz = q[a * 3 + 2];
+    B[0] = fma(px, qx, B[0]); B[1] = fma(px, qy, B[1]); B[2] = fma(px, qz, B[2]);
+    B[3] = fma(py, qx, B[3]); B[4] = fma(py, qy, B[4]); B[5] = fma(py, qz, B[5]);
+    B[6] = fma(pz, qx, B[6]); B[7] = fma(pz, qy, B[7]); B[8] = fma(pz, qz, B[8]);
+  }
+}
+__device__ __forceinline__ void accumulate_dev(const double *__restrict__ p, const double *__restrict__ q,
+                                               int A, const double (&R)[9], double &ssq, double &mx) {
+  for (int a = 0; a < A; ++a) {
+    const double qx = q[a * 3], qy = q[a * 3 + 1], qz = q[a * 3 + 2];
+    const double dx = p[a * 3] - (R[0] * qx + R[1] * qy + R[2] * qz);
+    const double dy = p[a * 3 + 1] - (R[3] * qx + R[4] * qy + R[5] * qz);
+    const double dz = p[a * 3 + 2] - (R[6] * qx + R[7] * qy + R[8] * qz);
+    const double s = dx * dx + dy * dy + dz * dz;
+    ssq += s;
+    mx = fmax(mx, s);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_embed_group_dedupe(const double *__restrict__ X1a, int64_t n1, int A1, int64_t na1,
+                     const double *__restrict__ X2a, int64_t n2, int A2, int64_t na2, double thr,
+                     const uint8_t *__restrict__ pass, uint8_t *__restrict__ accept) {
+  extern __shared__ int kept_all[];  // per wave: indices (angle pair) of the poses kept so far
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t n_ang = na1 * na2;
+  int *kept = kept_all + (size_t)wv * n_ang;
+  const int64_t n_groups = n1 * n2 * 2;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < n_groups; grp += (int64_t)gridDim.x * 4) {
+    const int o = (int)(grp & 1);
+    const int64_t ci = grp >> 1;            // = c2*n1 + c1
+    const int64_t c1 = ci % n1, c2 = ci / n1;
+    const int64_t pbase = grp * n_ang;
+    int n_kept = 0;
+    for (int64_t ai = 0; ai < n_ang; ++ai) {
+      const int64_t p = pbase + ai;
+      if (!pass[p]) {  // wave-uniform
+        if (lane == 0) accept[p] = 0;
+        continue;
+      }
+      const int64_t a1 = ai % na1, a2 = ai / na1;
+      const double *p1 = X1a + (((c1 * 2 + o) * na1 + a1) * (int64_t)A1) * 3;
+      const double *p2 = X2a + (((c2 * 2 + o) * na2 + a2) * (int64_t)A2) * 3;
+      bool similar = false;
+      for (int k0 = 0; k0 < n_kept && !similar; k0 += 64) {
+        const int kk = k0 + lane;
+        bool hit = false;
+        if (kk < n_kept) {
+          const int64_t bi = kept[kk];
+          const int64_t b1 = bi % na1, b2 = bi / na1;
+          const double *q1 = X1a + (((c1 * 2 + o) * na1 + b1) * (int64_t)A1) * 3;
+          const double *q2 = X2a + (((c2 * 2 + o) * na2 + b2) * (int64_t)A2) * 3;
+          double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+          accumulate_cov(p1, q1, A1, B);
+          accumulate_cov(p2, q2, A2, B);
+          double R[9];
+          (void)kabsch_rotation(B, R);
+          double ssq = 0.0, mx = 0.0;
+          accumulate_dev(p1, q1, A1, R, ssq, mx);
+          accumulate_dev(p2, q2, A2, R, ssq, mx);
+          const double rmsd = sqrt(ssq / (double)(A1 + A2)), maxdev = sqrt(mx);
+          hit = (rmsd < thr) && (maxdev < 2.0 * thr);
+        }
+        similar = __any(hit);
+      }
+      if (!similar) {
+        if (lane == 0) kept[n_kept] = (int)ai;
+        ++n_kept;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+      }
+      if (lane == 0) accept[p] = similar ? 0 : 1;
+    }
+  }
+}
+
+int launch_embed_group_dedupe(const double *X1a, int64_t n1, int64_t A1, int64_t na1, const double *X2a,
+                              int64_t n2, int64_t A2, int64_t na2, double thr, const uint8_t *pass_dev,
+                              uint8_t *accept_dev) {
+  const int64_t groups = n1 * n2 * 2;
+  if (groups == 0) return FC_OK;
+  int64_t blocks = ceil_div(groups, 4);
+  const int64_t cap = (int64_t)ctx().n_cu * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_embed_group_dedupe, dim3((unsigned)blocks), dim3(256),
+                     (size_t)4 * na1 * na2 * sizeof(int), ctx().stream, X1a, n1, (int)A1, na1, X2a, n2,
+                     (int)A2, na2, thr, pass_dev, accept_dev);
+  return check_launch("k_embed_group_dedupe");
+}
+
+// ---------------------------------------------------------------------------
 int launch_embed_mol_transforms(const double *coords_dev, int64_t n, int64_t A,
                                 const int64_t *reactive_dev, int nr, const double *ps_dev,
                                 const double *pe_dev, int mol, const double *angles_dev, int64_t na,

@@ -93,3 +93,24 @@ def embed_grid_clash(m1, reactive1, pivots1, m2, reactive2, pivots2, angles1, an
     if return_counts:
         return ok.astype(bool), counts, ms.value
     return ok.astype(bool), ms.value
+
+
+def embed_grid_poses(m1, reactive1, pivots1, m2, reactive2, pivots2, angles1, angles2=None,
+                     thresh=1.5, max_clashes=0, rmsd_thr=1.0):
+    """The pose selection of ``_fast_bimol_rigid_cyclical_embed`` (embeds.py:597-727,
+    one pivot per conformer): clash test, then -- inside every (conformer pair,
+    orientation) group, in angle order -- ``rmsd_similarity`` against the poses of
+    the group kept so far.  Returns (accept, clash_pass), both (n2, n1, 2, na2, na1)
+    bool; ``accept.reshape(-1)`` is in the reference's iteration order."""
+    X1, r1, ps1, pe1 = _mol_args(m1, reactive1, pivots1)
+    X2, r2, ps2, pe2 = _mol_args(m2, reactive2, pivots2)
+    a1 = L.f64(angles1).reshape(-1)
+    a2 = a1 if angles2 is None else L.f64(angles2).reshape(-1)
+    shape = (X2.shape[0], X1.shape[0], 2, a2.shape[0], a1.shape[0])
+    ok = np.zeros(shape, dtype=np.uint8)
+    acc = np.zeros(shape, dtype=np.uint8)
+    L.call("fc_embed_grid_dedupe", L.pf(X1), X1.shape[0], X1.shape[1], L.pi(r1), r1.shape[0], L.pf(ps1), L.pf(pe1),
+           L.pf(X2), X2.shape[0], X2.shape[1], L.pi(r2), r2.shape[0], L.pf(ps2), L.pf(pe2),
+           L.pf(a1), a1.shape[0], L.pf(a2), a2.shape[0], float(thresh), int(max_clashes), float(rmsd_thr),
+           L.pb(ok), L.pb(acc))
+    return acc.astype(bool), ok.astype(bool)

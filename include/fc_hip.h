@@ -195,6 +195,15 @@ int fc_embed_grid_clash(const double *m1, int64_t n1, int64_t A1, const int64_t 
                         const double *ps2, const double *pe2, const double *angles1, int64_t na1,
                         const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
                         uint8_t *pass_out, int32_t *counts_out, double *ms_kernel);
+/* same grid followed by the in-group de-duplication of embeds.py:723
+ * (rmsd_similarity(pose, poses kept so far in this (conformer pair, orientation)
+ * group, rmsd_thr)): accept_out[p] = pass[p] && the pose is new. */
+int fc_embed_grid_dedupe(const double *m1, int64_t n1, int64_t A1, const int64_t *reactive1,
+                         int64_t nr1, const double *ps1, const double *pe1, const double *m2,
+                         int64_t n2, int64_t A2, const int64_t *reactive2, int64_t nr2,
+                         const double *ps2, const double *pe2, const double *angles1, int64_t na1,
+                         const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
+                         double rmsd_thr, uint8_t *pass_out, uint8_t *accept_out);
 
 /* ---- a17-a19: torsion scan -- firecode/torsion_module.py:812-856
  * (clustered_csearch inner loops) with rotate_dihedral (prism_pruner.utils)

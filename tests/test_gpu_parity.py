@@ -552,3 +552,36 @@ def test_valu_screen_kernels_still_agree(fc, cfg, monkeypatch):
     S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
     _, mask = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
     assert np.array_equal(mask, o.greedy_prune_from_matrix(S0))
+
+
+@pytest.mark.parametrize("seed,nr1,nr2,scale", [(66, 2, 1, 1.8), (67, 1, 2, 1.25), (68, 2, 2, 1.0)])
+def test_embed_grid_dedupe_vs_oracle(fc, seed, nr1, nr2, scale):
+    """clash test + the sequential in-group rmsd_similarity filter (embeds.py:713-727)"""
+    m1, r1, pv1, m2, r2, pv2 = _embed_case(seed, n1=2, n2=3, A1=9, A2=8, nr1=nr1, nr2=nr2)
+    # spread the molecules so that a good share of the poses is clash free
+    pv1 = pv1 * scale
+    pv2 = pv2 * scale
+    steps, rr = 5, 45.0
+    angles = np.arange(steps + 1) * 2 * rr / steps - rr
+    acc, ok = fc.embeds.embed_grid_poses(m1, r1, pv1, m2, r2, pv2, angles, thresh=(1.2 if scale > 1.5 else 3.0), rmsd_thr=1.0)
+    conf_ids = o.cartesian_product(range(len(m1)), range(len(m2)))
+    ang_ids = o.cartesian_product(range(steps + 1), range(steps + 1))
+    ref_acc = np.zeros_like(acc)
+    ref_ok = np.zeros_like(ok)
+    for c1, c2 in conf_ids:
+        for ori in (0, 1):
+            angular_poses = []
+            for i1, i2 in ang_ids:
+                Ra, ta, Rb, tb = o.bimol_pose_transforms(m1[c1], m2[c2], r1, r2, pv1[c1], pv2[c2],
+                                                         (angles[i1], angles[i2]), ori)
+                pose = o.get_embed([m1[c1], m2[c2]], [Ra, Rb], [ta, tb])
+                if o.compenetration_check(pose, ids=[m1.shape[1], m2.shape[1]], thresh=(1.2 if scale > 1.5 else 3.0)):
+                    ref_ok[c2, c1, ori, i2, i1] = True
+                    if not o.rmsd_similarity(pose, np.array(angular_poses), rmsd_thr=1):
+                        angular_poses.append(pose)
+                        ref_acc[c2, c1, ori, i2, i1] = True
+    assert np.array_equal(ok, ref_ok)
+    assert np.array_equal(acc, ref_acc)
+    assert 0 < acc.sum() < ok.sum() <= ok.size
+    if scale < 1.5:
+        assert ok.sum() < ok.size  # some poses clash
