@@ -90,6 +90,9 @@ _SIGNATURES = {
     "fc_tfd_prune": [_p_f64, _i64, _i64, _f64, _p_u8],
     "fc_debug_pyset_order_ints": [_p_i64, _i64, _p_i64, _p_i64],
     "fc_debug_pyset_order_pairs": [_p_i64, _i64, _p_i64, _p_i64],
+    "fc_xyz_write": [C.c_char_p, C.POINTER(C.c_char_p), _i64, _p_f64, _i64, C.c_char_p, C.c_int],
+    "fc_xyz_scan": [C.c_char_p, _p_i64, _p_i64],
+    "fc_xyz_read": [C.c_char_p, _i64, _i64, C.c_char_p, _p_f64],
     "fc_bench_prune_rmsd": [_ens, _f64, _f64, _i64, _p_f64, _p_f64, _p_u8, _p_i64],
 }
 
@@ -295,3 +298,27 @@ def unpack_bits(bits, n):
     """(rows, W) uint64 words -> (rows, n) bool."""
     b = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")
     return b[:, :n].astype(bool)
+
+
+# ---- .xyz wire format (host code of the library) --------------------------------------
+def xyz_write(path, atoms, coords, label="", mode=0):
+    """mode 0: Ensemble.to_xyz text (label = basename); mode 1: utils.write_xyz text per conformer."""
+    X = f64(coords)
+    if X.ndim == 2:
+        X = X[None]
+    syms = [str(a).encode() for a in atoms]
+    arr = (C.c_char_p * len(syms))(*syms)
+    call("fc_xyz_write", os.fsencode(str(path)), arr, len(syms), pf(X), X.shape[0], str(label).encode(), int(mode))
+
+
+def xyz_read(path):
+    """-> (atoms (A,) str array of the first conformer, coords (N, A, 3))"""
+    n, a = C.c_int64(0), C.c_int64(0)
+    p = os.fsencode(str(path))
+    call("fc_xyz_scan", p, C.byref(n), C.byref(a))
+    coords = np.empty((n.value, a.value, 3))
+    buf = C.create_string_buffer(max(a.value, 1) * 8)
+    if n.value:
+        call("fc_xyz_read", p, n.value, a.value, buf, pf(coords))
+    atoms = np.array([buf.raw[i * 8:(i + 1) * 8].split(b"\0", 1)[0].decode() for i in range(a.value)])
+    return atoms, coords

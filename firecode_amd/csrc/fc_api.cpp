@@ -52,6 +52,8 @@ int launch_tfd_first_match(const double *, int64_t, int64_t, int64_t, double, in
 int tfd_ladder_from_first_match(const int64_t *, int64_t, uint8_t *);
 void pyset_order_ints(const int64_t *, int64_t, std::vector<int64_t> &);
 void pyset_order_pairs(const int64_t *, int64_t, std::vector<int64_t> &);
+int xyz_write(const char *, const char *const *, int64_t, const double *, int64_t, const char *, int);
+int xyz_read(const char *, int64_t *, int64_t *, char *, double *);
 int launch_embed_mol_transforms(const double *, int64_t, int64_t, const int64_t *, int, const double *,
                                 const double *, int, const double *, int64_t, double *, double *);
 int launch_embed_pretransform(const double *, int64_t, int64_t, int64_t, const double *,
@@ -1082,6 +1084,25 @@ int fc_debug_pyset_order_pairs(const int64_t *pairs, int64_t n, int64_t *order_o
   for (size_t k = 0; k < o.size(); ++k) order_out[k] = o[k];
   *n_out = (int64_t)o.size();
   return FC_OK;
+}
+
+int fc_xyz_write(const char *path, const char *const *atoms, int64_t A, const double *coords,
+                 int64_t N, const char *label, int mode) {
+  FC_REQUIRE(path && atoms && label && (coords || N == 0), "NULL pointer argument");
+  FC_REQUIRE(A >= 1 && N >= 0 && (mode == 0 || mode == 1), "bad arguments");
+  for (int64_t a = 0; a < A; ++a) FC_REQUIRE(atoms[a] != nullptr, "atoms[%lld] is NULL", (long long)a);
+  return xyz_write(path, atoms, A, coords, N, label, mode);
+}
+
+int fc_xyz_scan(const char *path, int64_t *N_out, int64_t *A_out) {
+  FC_REQUIRE(path && N_out && A_out, "NULL pointer argument");
+  return xyz_read(path, N_out, A_out, nullptr, nullptr);
+}
+
+int fc_xyz_read(const char *path, int64_t N, int64_t A, char *atoms_out, double *coords_out) {
+  FC_REQUIRE(path && atoms_out && coords_out, "NULL pointer argument");
+  FC_REQUIRE(N >= 0 && A >= 0, "bad shape");
+  return xyz_read(path, &N, &A, atoms_out, coords_out);
 }
 
 // ---- bench hook ----------------------------------------------------------------------

@@ -27,44 +27,39 @@ class Ensemble:
 
     @classmethod
     def from_xyz(cls, file, read_energies=False):
-        """firecode/ensemble.py:58-98 (same text format, same float() parse)."""
-        coords, atoms, energies = [], [], []
-        with Path(file).open() as f:
-            for num in f:
-                try:
-                    if not num.strip():
-                        continue
-                    if read_energies:
+        """firecode/ensemble.py:58-98.  Coordinates are parsed by the library's
+        C++ reader (same text rules, same values as float()); the energy regex
+        of ``read_energies=True`` stays in Python (one line per conformer)."""
+        from firecode_amd._lib import xyz_read
+
+        atoms, coords = xyz_read(file)
+        energies = []
+        if read_energies:
+            with Path(file).open() as f:
+                for num in f:
+                    try:
+                        if not num.strip():
+                            continue
                         energies.append(float(next(re.finditer(r"-*\d+\.\d+", next(f))).group()))
-                    else:
-                        next(f)
-                    conf_atoms, conf_coords = [], []
-                    for _ in range(int(num)):
-                        atom, *xyz = next(f).split()
-                        conf_atoms.append(atom)
-                        conf_coords.append([float(x) for x in xyz[0:3]])
-                    atoms.append(conf_atoms)
-                    coords.append(conf_coords)
-                except StopIteration:
-                    pass
+                        for _ in range(int(num)):
+                            next(f)
+                    except StopIteration:
+                        pass
+            energies = energies[: len(coords)]
         return cls(
-            atoms=np.array(atoms[0]),
-            coords=np.array(coords),
+            atoms=atoms,
+            coords=coords,
             filename=str(file),
             basename=Path(str(file)).stem,
-            atomnos=np.array([pt.number(letter) for letter in atoms[0]]),
+            atomnos=np.array([pt.number(letter) for letter in atoms]),
             energies=np.array(energies),
         )
 
     def to_xyz(self, file):
-        """firecode/ensemble.py:284-297."""
+        """firecode/ensemble.py:284-297 -- byte-identical text, written by the library."""
+        from firecode_amd._lib import xyz_write
 
-        def to_xyz(c):
-            return (f"{len(c)}\nExported from FIRECODE Ensemble ({self.basename})\n"
-                    + "\n".join(f"{atom} {x:15.8f} {y:15.8f} {z:15.8f}" for atom, (x, y, z) in zip(self.atoms, c)))
-
-        with Path(file).open("w") as f:
-            f.write("\n".join(map(to_xyz, self.coords)))
+        xyz_write(file, self.atoms, self.coords, label=self.basename, mode=0)
 
     @property
     def rel_energies(self):

@@ -122,3 +122,12 @@ def rotate_dihedral(coords, dihedral, angle, mask=None, indices_to_be_moved=None
     # thresh=0 -> the clash test can never fail, so exactly one rotation is applied
     out, _ = torsion_scan(X, [dihedral], [mask], [[int(angle)]], thresh=0.0)
     return out[0]
+
+
+def write_xyz(atoms, coords, output, title="temp"):
+    """firecode/utils.py:105-116 for one structure or a whole (N, A, 3) block:
+    ``output`` is a path (the reference takes an open text file; a path lets the
+    library stream millions of conformers without Python string work)."""
+    from firecode_amd._lib import xyz_write
+
+    xyz_write(output, atoms, coords, label=title, mode=1)

@@ -239,6 +239,18 @@ int fc_tfd_prune(const double *tf, int64_t N, int64_t Q, double thresh, uint8_t 
 int fc_debug_pyset_order_ints(const int64_t *keys, int64_t n, int64_t *order_out, int64_t *n_out);
 int fc_debug_pyset_order_pairs(const int64_t *pairs, int64_t n, int64_t *order_out, int64_t *n_out);
 
+/* ---- a1: the .xyz wire format (host code; firecode/ensemble.py:58-98, 284-297;
+ * firecode/utils.py:105-116).  atoms: A C strings.  mode 0 = Ensemble.to_xyz text
+ * (label = basename), mode 1 = utils.write_xyz text repeated per conformer
+ * (label = title).  Byte-identical to the Python writers.
+ * fc_xyz_scan: conformer count and atoms per conformer of a file;
+ * fc_xyz_read: atoms_out A x 8 bytes (NUL padded symbols of the first conformer),
+ * coords_out (N, A, 3) parsed exactly like Python's float(). */
+int fc_xyz_write(const char *path, const char *const *atoms, int64_t A, const double *coords,
+                 int64_t N, const char *label, int mode);
+int fc_xyz_scan(const char *path, int64_t *N_out, int64_t *A_out);
+int fc_xyz_read(const char *path, int64_t N, int64_t A, char *atoms_out, double *coords_out);
+
 /* ---- bench / profiling hooks (resident data, device-side timing) --------
  * Runs the all-pairs similarity stage + greedy replay `reps` times on the
  * resident ensemble and returns HIP-event times (ms, per rep) of the
