@@ -156,26 +156,22 @@ __host__ __device__ __forceinline__ bool kabsch_may_be_below(const double (&B)[9
   const double Szx = B[6], Szy = B[7], Szz = B[8];
   const double n2 = Sxx * Sxx + Sxy * Sxy + Sxz * Sxz + Syx * Syx + Syy * Syy + Syz * Syz +
                     Szx * Szx + Szy * Szy + Szz * Szz;
-  const double C2 = -2.0 * n2;
+  // with u = L^2 - n2 the three values to test are
+  //   P''/4 = 2 L^2 + u,   P'/4 = u L - 2 det B,   P = u^2 - 4 (|cof B|_F^2 + 2 L det B)
+  // (C2 = -2 n2, C1 = -8 det B, C0 = n2^2 - 4 |cof B|_F^2: with s_i the singular values of B
+  // the eigenvalues of K are (+-s1 +- s2 +- s3) with an even number of minus signs, s3 signed
+  // by det B, whose product is (s1^2+s2^2+s3^2)^2 - 4 (s1^2 s2^2 + s2^2 s3^2 + s3^2 s1^2))
   const double L2 = L * L;
-  const double P2 = 12.0 * L2 + 2.0 * C2;
-  if (P2 < 0.0) return true;
-  // cofactors of B: det B = row 0 . cofactor row 0, and with s_i the singular
-  // values of B the eigenvalues of K are (+-s1 +- s2 +- s3) with an even number
-  // of minus signs (s3 signed by det B), whose product is
-  //   C0 = det K = (s1^2+s2^2+s3^2)^2 - 4 (s1^2 s2^2 + s2^2 s3^2 + s3^2 s1^2)
-  //             = n2^2 - 4 |cof B|_F^2
+  const double u = L2 - n2;
+  if (2.0 * L2 + u < 0.0) return true;
   const double c00 = Syy * Szz - Syz * Szy, c01 = Syz * Szx - Syx * Szz, c02 = Syx * Szy - Syy * Szx;
   const double c10 = Sxz * Szy - Sxy * Szz, c11 = Sxx * Szz - Sxz * Szx, c12 = Sxy * Szx - Sxx * Szy;
   const double c20 = Sxy * Syz - Sxz * Syy, c21 = Sxz * Syx - Sxx * Syz, c22 = Sxx * Syy - Sxy * Syx;
   const double detB = Sxx * c00 + Sxy * c01 + Sxz * c02;
-  const double C1 = -8.0 * detB;
-  const double P1 = (4.0 * L2 + 2.0 * C2) * L + C1;
-  if (P1 < 0.0) return true;
+  if (u * L - 2.0 * detB < 0.0) return true;
   const double e2 = c00 * c00 + c01 * c01 + c02 * c02 + c10 * c10 + c11 * c11 + c12 * c12 +
                     c20 * c20 + c21 * c21 + c22 * c22;
-  const double C0 = n2 * n2 - 4.0 * e2;
-  const double P0 = ((L2 + C2) * L + C1) * L + C0;
+  const double P0 = u * u - 4.0 * (e2 + 2.0 * L * detB);
   const double eps = 1e-12 * (s * s) * (s * s);
   return !(P0 > eps);
 }
