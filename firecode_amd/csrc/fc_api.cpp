@@ -230,10 +230,20 @@ static int simbits_local(fc_ensemble *e, double max_rmsd, double max_dev, const 
   }
   if (zero_counters)
     FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, 8 * sizeof(uint64_t), ctx().stream));
+  // HIP events bracket the screen kernel (the dominant one) on the library's stream
+  FC_HIP_TRY(hipEventRecord(ctx().ev2, ctx().stream));
   FC_TRY(launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin));
+  FC_HIP_TRY(hipEventRecord(ctx().ev3, ctx().stream));
   FC_TRY(launch_simbits_refine(e, max_rmsd, max_dev, en_dev, max_dE));
   e->bits_valid = true;
   return FC_OK;
+}
+
+// duration of the last screen kernel enqueued by simbits_local, after a sync
+static int64_t last_screen_ns() {
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, ctx().ev2, ctx().ev3) != hipSuccess) return 0;
+  return (int64_t)(ms * 1e6);
 }
 
 static const int64_t kLadder[] = {500000, 200000, 100000, 50000, 20000, 10000, 5000, 2000, 1000,
@@ -549,7 +559,7 @@ int fc_prune_rmsd_begin(fc_ensemble *ens, double max_rmsd, double max_dev, const
     stats[1] = (int64_t)cnt[1];
     stats[2] = (int64_t)cnt[2];
     stats[3] = (int64_t)cnt[3];
-    stats[4] = 0;
+    stats[4] = last_screen_ns();  // screen-kernel duration (ns) of this rank
     stats[5] = 0;
   }
   return FC_OK;

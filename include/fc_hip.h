@@ -106,6 +106,8 @@ int fc_greedy_prune_from_bits(const uint64_t *bits, int64_t N, int64_t min_per_g
  * GLOBAL mask of the previous level (mask_in, N bytes) and returns the rows'
  * new flags in mask_out (N bytes, only owned rows written, others copied
  * from mask_in) -- the caller all-gathers between levels. */
+/* stats of fc_prune_rmsd_begin: [0] pairs owned by this rank, [1] refined, [2] similar,
+ * [3] grey, [4] duration of this rank's screen kernel in ns (HIP events), [5] 0 */
 int fc_prune_rmsd_begin(fc_ensemble *ens, double max_rmsd, double max_dev,
                         const double *energies, double max_dE, int64_t rank, int64_t world,
                         int64_t row_block, int64_t *stats);
