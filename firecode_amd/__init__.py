@@ -18,6 +18,8 @@ from firecode_amd._lib import (  # noqa: F401
     init,
     shutdown,
 )
-from firecode_amd import algebra, embeds, ensemble, pruner, pt, refining, rmsd, torsion_module, utils  # noqa: F401,E402
+from firecode_amd import (  # noqa: F401,E402
+    algebra, embeds, ensemble, host_helpers, pruner, pt, refining, rmsd, torsion_module, utils,
+)
 
 __version__ = "0.1.0"
