@@ -82,6 +82,8 @@ _SIGNATURES = {
                             C.POINTER(C.c_int32), _p_f64],
     "fc_embed_grid_dedupe": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64, _p_f64, _p_f64, _i64, _i64, _p_i64, _i64,
                              _p_f64, _p_f64, _p_f64, _i64, _p_f64, _i64, _f64, _i64, _f64, _p_u8, _p_u8],
+    "fc_string_embed": [_p_f64, _i64, _i64, _p_f64, _p_f64, _i64, _p_f64, _i64, _i64, _p_f64, _p_f64, _i64, _p_f64, _i64,
+                        _p_i64, _i64, _f64, _i64, _f64, _p_u8, _p_u8, _p_f64, _p_f64],
     "fc_torsion_scan": [_p_f64, _i64, _p_i64, _i64, _p_u8, _p_i64, _i64, _f64, _i64, _p_f64, _p_i64],
     "fc_torsion_fingerprint": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64],
     "fc_tfd_simbits": [_p_f64, _i64, _i64, _f64, _i64, _i64, _p_u64],

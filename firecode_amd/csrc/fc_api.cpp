@@ -60,6 +60,13 @@ int launch_embed_pretransform(const double *, int64_t, int64_t, int64_t, const d
                               const double *, int, int64_t, double *);
 int launch_embed_grid_clash(const double *, int64_t, int64_t, int64_t, const double *, int64_t, int64_t,
                             int64_t, int64_t, double, int64_t, uint8_t *, int32_t *);
+int launch_string_transforms(const double *, const double *, int64_t, int64_t, const double *, const double *,
+                             int64_t, int64_t, const double *, int64_t, double *, double *, int64_t *, int64_t *);
+int launch_pose_fingerprints(const double *, int64_t, const double *, int64_t, const int64_t *, const int64_t *,
+                             const double *, const double *, int64_t, const int64_t *, int64_t, const uint8_t *,
+                             double *);
+int launch_leader_chunk(const double *, int64_t, int64_t, int64_t, const uint8_t *, double *, int64_t,
+                        unsigned long long *, double, uint8_t *, uint8_t *);
 int launch_embed_group_dedupe(const double *, int64_t, int64_t, int64_t, const double *, int64_t, int64_t,
                               int64_t, double, const uint8_t *, uint8_t *);
 
@@ -960,6 +967,62 @@ int fc_embed_grid_dedupe(const double *m1, int64_t n1, int64_t A1, const int64_t
   FC_REQUIRE(accept_out != nullptr, "accept_out is NULL");
   return embed_grid(m1, n1, A1, reactive1, nr1, ps1, pe1, m2, n2, A2, reactive2, nr2, ps2, pe2, angles1,
                     na1, angles2, na2, thresh, max_clashes, pass_out, nullptr, nullptr, rmsd_thr, accept_out);
+}
+
+int fc_string_embed(const double *m1, int64_t n1, int64_t A1, const double *centers1,
+                    const double *orbvecs1, int64_t K1, const double *m2, int64_t n2, int64_t A2,
+                    const double *centers2, const double *orbvecs2, int64_t K2,
+                    const double *angles, int64_t nA, const int64_t *quads, int64_t Q,
+                    double thresh, int64_t max_clashes, double tfd_thresh, uint8_t *pass_out,
+                    uint8_t *accept_out, double *R2_out, double *t2_out) {
+  FC_REQUIRE(m1 && m2 && centers1 && orbvecs1 && centers2 && orbvecs2 && angles && pass_out && accept_out,
+             "NULL pointer argument");
+  FC_REQUIRE(n1 >= 1 && n2 >= 1 && A1 >= 1 && A2 >= 1 && K1 >= 1 && K2 >= 1 && nA >= 1 && Q >= 0, "bad shape");
+  FC_REQUIRE(quads || Q == 0, "quads is NULL");
+  if (Q > 128) return set_error(FC_E_LIMIT, "Q=%lld fingerprints exceed 128", (long long)Q);
+  for (int64_t k = 0; k < Q * 4; ++k) FC_REQUIRE(quads[k] >= 0 && quads[k] < A1 + A2, "quadruplet index out of range");
+  if (4 * A1 * 24 > 160 * 1024) return set_error(FC_E_LIMIT, "A1=%lld too large for the LDS slice", (long long)A1);
+  FC_TRY(ensure_init());
+  const int64_t P = n1 * n2 * K1 * K2 * nA;
+  DevBuf d1, d2, dc1, dv1, dc2, dv2, da, dq, dR, dt, di1, di2, dpass, dacc, drej, dtf, daccT, dn;
+  FC_TRY(upload(d1, m1, (size_t)n1 * A1 * 3));
+  FC_TRY(upload(d2, m2, (size_t)n2 * A2 * 3));
+  FC_TRY(upload(dc1, centers1, (size_t)n1 * K1 * 3));
+  FC_TRY(upload(dv1, orbvecs1, (size_t)n1 * K1 * 3));
+  FC_TRY(upload(dc2, centers2, (size_t)n2 * K2 * 3));
+  FC_TRY(upload(dv2, orbvecs2, (size_t)n2 * K2 * 3));
+  FC_TRY(upload(da, angles, (size_t)nA));
+  FC_TRY(upload(dq, quads, (size_t)Q * 4));
+  FC_TRY(dR.reserve((size_t)P * 9 * sizeof(double)));
+  FC_TRY(dt.reserve((size_t)P * 3 * sizeof(double)));
+  FC_TRY(di1.reserve((size_t)P * sizeof(int64_t)));
+  FC_TRY(di2.reserve((size_t)P * sizeof(int64_t)));
+  FC_TRY(dpass.reserve((size_t)P));
+  FC_TRY(dacc.reserve((size_t)P));
+  FC_TRY(drej.reserve(256));
+  FC_TRY(dtf.reserve((size_t)P * std::max<int64_t>(Q, 1) * sizeof(double)));
+  FC_TRY(daccT.reserve((size_t)P * std::max<int64_t>(Q, 1) * sizeof(double)));
+  FC_TRY(dn.reserve(sizeof(uint64_t)));
+  FC_HIP_TRY(hipMemsetAsync(dn.p, 0, sizeof(uint64_t), ctx().stream));
+  FC_HIP_TRY(hipMemsetAsync(drej.p, 0, 256, ctx().stream));
+  FC_TRY(launch_string_transforms(dc1.as<double>(), dv1.as<double>(), n1, K1, dc2.as<double>(), dv2.as<double>(),
+                                  n2, K2, da.as<double>(), nA, dR.as<double>(), dt.as<double>(),
+                                  di1.as<int64_t>(), di2.as<int64_t>()));
+  FC_TRY(launch_embed_poses_clash(d1.as<double>(), A1, d2.as<double>(), A2, di1.as<int64_t>(), di2.as<int64_t>(),
+                                  nullptr, nullptr, dR.as<double>(), dt.as<double>(), P, thresh, max_clashes,
+                                  nullptr, dpass.as<uint8_t>(), nullptr));
+  FC_TRY(launch_pose_fingerprints(d1.as<double>(), A1, d2.as<double>(), A2, di1.as<int64_t>(), di2.as<int64_t>(),
+                                  dR.as<double>(), dt.as<double>(), P, dq.as<int64_t>(), Q, dpass.as<uint8_t>(),
+                                  dtf.as<double>()));
+  for (int64_t c0 = 0; c0 < P; c0 += 256)
+    FC_TRY(launch_leader_chunk(dtf.as<double>(), Q, c0, P, dpass.as<uint8_t>(), daccT.as<double>(), P,
+                               reinterpret_cast<unsigned long long *>(dn.p), tfd_thresh, drej.as<uint8_t>(),
+                               dacc.as<uint8_t>()));
+  FC_TRY(d2h(pass_out, dpass.p, (size_t)P));
+  FC_TRY(d2h(accept_out, dacc.p, (size_t)P));
+  if (R2_out) FC_TRY(d2h(R2_out, dR.p, (size_t)P * 9 * sizeof(double)));
+  if (t2_out) FC_TRY(d2h(t2_out, dt.p, (size_t)P * 3 * sizeof(double)));
+  return sync();
 }
 
 // ---- a17-a20 -----------------------------------------------------------------------

@@ -212,8 +212,11 @@ k_embed_poses_clash(const double *__restrict__ m1, int A1, const double *__restr
   for (int64_t k = wave0; k < P; k += nwaves) {
     const double *x1 = m1 + c1[k] * (int64_t)A1 * 3;
     const double *x2 = m2 + c2[k] * (int64_t)A2 * 3;
-    const double *r1 = R1 + k * 9, *r2 = R2 + k * 9;
-    const double *u1 = t1 + k * 3, *u2 = t2 + k * 3;
+    static const double kEye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, kZero[3] = {0, 0, 0};
+    // R1 == nullptr: molecule 1 is not moved (string embed); the identity goes through
+    // the same expression and reproduces x exactly
+    const double *r1 = R1 ? R1 + k * 9 : kEye, *r2 = R2 + k * 9;
+    const double *u1 = t1 ? t1 + k * 3 : kZero, *u2 = t2 + k * 3;
     double *po = poses ? poses + k * (int64_t)(A1 + A2) * 3 : nullptr;
     for (int a = lane; a < A1; a += 64) {
       const double x = x1[a * 3], y = x1[a * 3 + 1], z = x1[a * 3 + 2];

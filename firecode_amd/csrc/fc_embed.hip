@@ -212,6 +212,148 @@ k_embed_grid_clash(const double *__restrict__ X1, int64_t n1, int A1, int64_t na
 }
 
 // ---------------------------------------------------------------------------
+// String embed (firecode/embeds.py:51-158): molecule 1 stays put, molecule 2 is
+// rotated so that its orbital vector opposes molecule 1's and spun about that
+// axis.  One lane per pose builds (R2, t2):
+//   R = rotation_matrix_from_vectors(mol_vec, -ref_vec)        (utils.py:224-249)
+//   if angle != 0: R = rot_mat_from_pointer(ref_vec, angle) @ R
+//   t = p1 - R @ p2
+// pose index (reference loop order; cartesian_product: second argument slowest):
+//   p = ((c2*n1 + c1) * (K1*K2) + (k2*K1 + k1)) * nA + ia
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_string_transforms(const double *__restrict__ cen1, const double *__restrict__ vec1, int64_t n1,
+                    int64_t K1, const double *__restrict__ cen2, const double *__restrict__ vec2,
+                    int64_t n2, int64_t K2, const double *__restrict__ angles, int64_t nA,
+                    double *__restrict__ R_out, double *__restrict__ t_out, int64_t *__restrict__ c1_out,
+                    int64_t *__restrict__ c2_out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t P = n1 * n2 * K1 * K2 * nA;
+  if (p >= P) return;
+  const int64_t ia = p % nA;
+  const int64_t ki = (p / nA) % (K1 * K2);
+  const int64_t ci = p / (nA * K1 * K2);
+  const int64_t c1 = ci % n1, c2 = ci / n1, k1 = ki % K1, k2 = ki / K1;
+  const double *p1 = cen1 + (c1 * K1 + k1) * 3, *rv = vec1 + (c1 * K1 + k1) * 3;
+  const double *p2 = cen2 + (c2 * K2 + k2) * 3, *mv = vec2 + (c2 * K2 + k2) * 3;
+  // a = mol_vec / |mol_vec|,  b = -ref_vec / |ref_vec|
+  const double na = sqrt((mv[0] * mv[0] + mv[1] * mv[1]) + mv[2] * mv[2]);
+  const double nb = sqrt((rv[0] * rv[0] + rv[1] * rv[1]) + rv[2] * rv[2]);
+  const double ax = mv[0] / na, ay = mv[1] / na, az = mv[2] / na;
+  const double bx = -rv[0] / nb, by = -rv[1] / nb, bz = -rv[2] / nb;
+  const double vx = ay * bz - az * by, vy = az * bx - ax * bz, vz = ax * by - ay * bx;
+  const double nv = sqrt((vx * vx + vy * vy) + vz * vz);
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (nv != 0.0) {
+    const double c = (ax * bx + ay * by) + az * bz;
+    const double f = (1.0 - c) / (nv * nv);
+    // kmat = [[0,-vz,vy],[vz,0,-vx],[-vy,vx,0]];  R = I + kmat + kmat@kmat * f
+    const double k2m[9] = {(0.0 * 0.0 + -vz * vz) + vy * -vy, (0.0 * -vz + -vz * 0.0) + vy * vx, (0.0 * vy + -vz * -vx) + vy * 0.0,
+                           (vz * 0.0 + 0.0 * vz) + -vx * -vy, (vz * -vz + 0.0 * 0.0) + -vx * vx, (vz * vy + 0.0 * -vx) + -vx * 0.0,
+                           (-vy * 0.0 + vx * vz) + 0.0 * -vy, (-vy * -vz + vx * 0.0) + 0.0 * vx, (-vy * vy + vx * -vx) + 0.0 * 0.0};
+    const double km[9] = {0.0, -vz, vy, vz, 0.0, -vx, -vy, vx, 0.0};
+#pragma unroll
+    for (int e = 0; e < 9; ++e) R[e] = (R[e] + km[e]) + k2m[e] * f;
+  } else {
+    const double sx = ax + bx, sy = ay + by, sz = az + bz;
+    if (sqrt((sx * sx + sy * sy) + sz * sz) == 0.0) rot_axis_angle(0.0, 0.0, 1.0, 180.0, R);
+  }
+  const double angle = angles[ia];
+  if (angle != 0.0) {
+    double D[9], RR[9];
+    rot_axis_angle(rv[0], rv[1], rv[2], angle, D);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        RR[r * 3 + q] = (D[r * 3] * R[q] + D[r * 3 + 1] * R[3 + q]) + D[r * 3 + 2] * R[6 + q];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) R[e] = RR[e];
+  }
+  double rx, ry, rz;
+  mat_vec(R, p2[0], p2[1], p2[2], rx, ry, rz);
+#pragma unroll
+  for (int e = 0; e < 9; ++e) R_out[p * 9 + e] = R[e];
+  t_out[p * 3 + 0] = p1[0] - rx;
+  t_out[p * 3 + 1] = p1[1] - ry;
+  t_out[p * 3 + 2] = p1[2] - rz;
+  c1_out[p] = c1;
+  c2_out[p] = c2;
+}
+
+// torsion fingerprint of a pose that is never materialised: atoms below A1 come
+// from molecule 1 as they are, the others from molecule 2 through (R2, t2)
+__device__ __forceinline__ double dihedral4(const double (&p)[4][3]) {
+  const double b0x = -1.0 * (p[1][0] - p[0][0]), b0y = -1.0 * (p[1][1] - p[0][1]), b0z = -1.0 * (p[1][2] - p[0][2]);
+  double b1x = p[2][0] - p[1][0], b1y = p[2][1] - p[1][1], b1z = p[2][2] - p[1][2];
+  const double b2x = p[3][0] - p[2][0], b2y = p[3][1] - p[2][1], b2z = p[3][2] - p[2][2];
+  const double n1 = sqrt((b1x * b1x + b1y * b1y) + b1z * b1z);
+  b1x /= n1; b1y /= n1; b1z /= n1;
+  const double d0 = (b0x * b1x + b0y * b1y) + b0z * b1z;
+  const double d2 = (b2x * b1x + b2y * b1y) + b2z * b1z;
+  const double vx = b0x - d0 * b1x, vy = b0y - d0 * b1y, vz = b0z - d0 * b1z;
+  const double wx = b2x - d2 * b1x, wy = b2y - d2 * b1y, wz = b2z - d2 * b1z;
+  const double xx = (vx * wx + vy * wy) + vz * wz;
+  const double cx = b1y * vz - b1z * vy, cy = b1z * vx - b1x * vz, cz = b1x * vy - b1y * vx;
+  const double yy = (cx * wx + cy * wy) + cz * wz;
+  return atan2(yy, xx) * (180.0 / 3.141592653589793);
+}
+
+__global__ void __launch_bounds__(256)
+k_pose_fingerprints(const double *__restrict__ m1, int64_t A1, const double *__restrict__ m2, int64_t A2,
+                    const int64_t *__restrict__ c1, const int64_t *__restrict__ c2,
+                    const double *__restrict__ R2, const double *__restrict__ t2, int64_t P,
+                    const int64_t *__restrict__ quads, int Q, const uint8_t *__restrict__ pass,
+                    double *__restrict__ tf) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P * Q) return;
+  const int64_t p = g / Q;
+  const int q = (int)(g % Q);
+  if (pass != nullptr && !pass[p]) {
+    tf[g] = 0.0;
+    return;
+  }
+  const double *x1 = m1 + c1[p] * A1 * 3, *x2 = m2 + c2[p] * A2 * 3;
+  const double *r = R2 + p * 9, *t = t2 + p * 3;
+  double pts[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t a = quads[q * 4 + k];
+    if (a < A1) {
+      pts[k][0] = x1[a * 3];
+      pts[k][1] = x1[a * 3 + 1];
+      pts[k][2] = x1[a * 3 + 2];
+    } else {
+      const double *x = x2 + (a - A1) * 3;
+      pts[k][0] = ((r[0] * x[0] + r[1] * x[1]) + r[2] * x[2]) + t[0];
+      pts[k][1] = ((r[3] * x[0] + r[4] * x[1]) + r[5] * x[2]) + t[1];
+      pts[k][2] = ((r[6] * x[0] + r[7] * x[1]) + r[8] * x[2]) + t[2];
+    }
+  }
+  tf[g] = dihedral4(pts);
+}
+
+int launch_string_transforms(const double *cen1, const double *vec1, int64_t n1, int64_t K1,
+                             const double *cen2, const double *vec2, int64_t n2, int64_t K2,
+                             const double *angles, int64_t nA, double *R_dev, double *t_dev,
+                             int64_t *c1_dev, int64_t *c2_dev) {
+  const int64_t P = n1 * n2 * K1 * K2 * nA;
+  if (P == 0) return FC_OK;
+  hipLaunchKernelGGL(k_string_transforms, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, ctx().stream,
+                     cen1, vec1, n1, K1, cen2, vec2, n2, K2, angles, nA, R_dev, t_dev, c1_dev, c2_dev);
+  return check_launch("k_string_transforms");
+}
+
+int launch_pose_fingerprints(const double *m1, int64_t A1, const double *m2, int64_t A2, const int64_t *c1,
+                             const int64_t *c2, const double *R2, const double *t2, int64_t P,
+                             const int64_t *quads, int64_t Q, const uint8_t *pass, double *tf) {
+  if (P * Q == 0) return FC_OK;
+  hipLaunchKernelGGL(k_pose_fingerprints, dim3((unsigned)ceil_div(P * Q, 256)), dim3(256), 0, ctx().stream,
+                     m1, A1, m2, A2, c1, c2, R2, t2, P, quads, (int)Q, pass, tf);
+  return check_launch("k_pose_fingerprints");
+}
+
+// ---------------------------------------------------------------------------
 // k_embed_group_dedupe: the `rmsd_similarity(embedded_structure, angular_poses,
 // rmsd_thr=1)` filter of embeds.py:723 -- inside one (conformer pair,
 // orientation) group the poses are visited in angle order and a clash-free pose

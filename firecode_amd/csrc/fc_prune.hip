@@ -491,6 +491,84 @@ k_tfd_first_match(const double *__restrict__ tfT, int64_t N, int64_t Npad, int Q
 }
 
 // ---------------------------------------------------------------------------
+// Sequential "is_new_structure" filter of string_embed (embeds.py:59-84): a pose
+// that passed the clash test is kept iff its fingerprint is not TFD-similar to
+// any fingerprint KEPT so far (the cache is never trimmed).  Exact, chunked:
+// for the next 256 poses (in order) (1) every pose is compared with all
+// fingerprints kept before the chunk -- one workgroup per pose, lanes stride
+// the kept list; (2) one wavefront walks the chunk in order and compares each
+// still-alive pose with the ones kept inside the chunk.  accT: kept fingerprints,
+// fingerprint-major with stride cap.  n_acc: device counter.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_leader_vs_kept(const double *__restrict__ tf, int Q, int64_t chunk0, int64_t P,
+                 const uint8_t *__restrict__ pass, const double *__restrict__ accT, int64_t cap,
+                 const unsigned long long *__restrict__ n_acc, double thresh,
+                 uint8_t *__restrict__ rejected) {
+  __shared__ int found;
+  const int64_t p = chunk0 + blockIdx.x;
+  if (p >= P) return;
+  if (threadIdx.x == 0) found = 0;
+  __syncthreads();
+  if (!pass[p]) return;
+  const int64_t n = (int64_t)*n_acc;
+  const double *ti = tf + p * Q;
+  for (int64_t j0 = 0; j0 < n; j0 += 256) {
+    const int64_t j = j0 + threadIdx.x;
+    if (j < n && tfd_sum(ti, 1, accT + j, cap, Q) < thresh) found = 1;
+    __syncthreads();
+    if (found) break;
+  }
+  if (threadIdx.x == 0) rejected[blockIdx.x] = (uint8_t)found;
+}
+
+__global__ void __launch_bounds__(64)
+k_leader_within_chunk(const double *__restrict__ tf, int Q, int64_t chunk0, int64_t P,
+                      const uint8_t *__restrict__ pass, const uint8_t *__restrict__ rejected,
+                      double *__restrict__ accT, int64_t cap, unsigned long long *__restrict__ n_acc,
+                      double thresh, uint8_t *__restrict__ accept) {
+  __shared__ int kept[256];
+  const int lane = threadIdx.x;
+  int n_kept = 0;
+  unsigned long long base = *n_acc;
+  const int64_t n_in = (P - chunk0 < 256) ? (P - chunk0) : 256;
+  for (int c = 0; c < (int)n_in; ++c) {
+    const int64_t p = chunk0 + c;
+    bool ok = pass[p] && !rejected[c];  // wave-uniform
+    if (ok) {
+      bool hit = false;
+      for (int k0 = 0; k0 < n_kept; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < n_kept && tfd_sum(tf + p * Q, 1, tf + (chunk0 + kept[k]) * Q, 1, Q) < thresh) hit = true;
+      }
+      ok = !__any(hit);
+    }
+    if (ok) {
+      if (lane == 0) kept[n_kept] = c;
+      for (int q = lane; q < Q; q += 64) accT[(int64_t)q * cap + (int64_t)(base + n_kept)] = tf[p * Q + q];
+      ++n_kept;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+    if (lane == 0) accept[p] = ok ? 1 : 0;
+  }
+  if (lane == 0) *n_acc = base + (unsigned long long)n_kept;
+}
+
+int launch_leader_chunk(const double *tf_dev, int64_t Q, int64_t chunk0, int64_t P, const uint8_t *pass_dev,
+                        double *accT_dev, int64_t cap, unsigned long long *n_acc_dev, double thresh,
+                        uint8_t *rejected_dev, uint8_t *accept_dev) {
+  const int64_t n_in = (P - chunk0 < 256) ? (P - chunk0) : 256;
+  if (n_in <= 0) return FC_OK;
+  hipLaunchKernelGGL(k_leader_vs_kept, dim3((unsigned)n_in), dim3(256), 0, ctx().stream, tf_dev, (int)Q, chunk0,
+                     P, pass_dev, accT_dev, cap, n_acc_dev, thresh, rejected_dev);
+  FC_TRY(check_launch("k_leader_vs_kept"));
+  hipLaunchKernelGGL(k_leader_within_chunk, dim3(1), dim3(64), 0, ctx().stream, tf_dev, (int)Q, chunk0, P,
+                     pass_dev, rejected_dev, accT_dev, cap, n_acc_dev, thresh, accept_dev);
+  return check_launch("k_leader_within_chunk");
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 int launch_pack_mask(const uint8_t *mask_dev, int64_t N, uint64_t *mbits_dev, int64_t W,

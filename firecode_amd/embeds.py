@@ -114,3 +114,34 @@ def embed_grid_poses(m1, reactive1, pivots1, m2, reactive2, pivots2, angles1, an
            L.pf(a1), a1.shape[0], L.pf(a2), a2.shape[0], float(thresh), int(max_clashes), float(rmsd_thr),
            L.pb(ok), L.pb(acc))
     return acc.astype(bool), ok.astype(bool)
+
+
+def string_embed(m1, centers1, orbvecs1, m2, centers2, orbvecs2, angles, quadruplets,
+                 thresh=1.5, max_clashes=0, tfd_thresh=10):
+    """Pose loop of ``string_embed`` (firecode/embeds.py:51-158): molecule 1 fixed,
+    molecule 2 oriented orbital-against-orbital and spun by every angle; clash
+    test; sequential torsion-fingerprint novelty filter.  centers*/orbvecs*:
+    (n_conf, K, 3) orbital centres / vectors of the reactive atom.
+    Returns (poses (n_accepted, A1+A2, 3), accept (P,) bool, clash_pass (P,) bool),
+    P in the reference's iteration order."""
+    X1, X2 = L.f64(m1), L.f64(m2)
+    c1, v1, c2, v2 = (L.f64(a) for a in (centers1, orbvecs1, centers2, orbvecs2))
+    ang = L.f64(angles).reshape(-1)
+    quads = L.i64(quadruplets).reshape(-1, 4)
+    n1, n2, K1, K2, nA = X1.shape[0], X2.shape[0], c1.shape[1], c2.shape[1], ang.shape[0]
+    if c1.shape != (n1, K1, 3) or v1.shape != c1.shape or c2.shape != (n2, K2, 3) or v2.shape != c2.shape:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "centers/orbvecs must be (n_conf, K, 3)")
+    P = n1 * n2 * K1 * K2 * nA
+    ok = np.zeros(P, dtype=np.uint8)
+    acc = np.zeros(P, dtype=np.uint8)
+    R2 = np.empty((P, 3, 3))
+    t2 = np.empty((P, 3))
+    L.call("fc_string_embed", L.pf(X1), n1, X1.shape[1], L.pf(c1), L.pf(v1), K1, L.pf(X2), n2, X2.shape[1],
+           L.pf(c2), L.pf(v2), K2, L.pf(ang), nA, L.pi(quads), quads.shape[0], float(thresh), int(max_clashes),
+           float(tfd_thresh), L.pb(ok), L.pb(acc), L.pf(R2), L.pf(t2))
+    acc = acc.astype(bool)
+    sel = np.flatnonzero(acc)
+    ci = sel // (K1 * K2 * nA)
+    moved = rototranslate(X2[ci // n1], R2[sel], t2[sel]) if len(sel) else np.zeros((0, X2.shape[1], 3))
+    poses = np.concatenate([X1[ci % n1], moved], axis=1)
+    return poses, acc, ok.astype(bool)

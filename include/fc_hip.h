@@ -207,6 +207,22 @@ int fc_embed_grid_dedupe(const double *m1, int64_t n1, int64_t A1, const int64_t
                          const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
                          double rmsd_thr, uint8_t *pass_out, uint8_t *accept_out);
 
+/* String embed (firecode/embeds.py:51-158) for two molecules with one reactive atom
+ * each: molecule i has n_i conformers, K_i orbital centres per conformer
+ * (centers_i, orbvecs_i: (n_i, K_i, 3) -- RAtom.center / .orb_vecs) and the run
+ * has nA rotation angles.  Pose p = ((c2*n1 + c1)*(K1*K2) + (k2*K1 + k1))*nA + ia
+ * (the reference's loop order).  pass_out[p]: compenetration_check of the pose;
+ * accept_out[p]: passed AND its torsion fingerprint over quads (Q,4; atom indices
+ * in the concatenated pose) is not TFD-similar (tfd_thresh) to any pose accepted
+ * before it.  R2_out (P,3,3) / t2_out (P,3) (may be NULL): molecule 2's transform
+ * (molecule 1 is not moved). */
+int fc_string_embed(const double *m1, int64_t n1, int64_t A1, const double *centers1,
+                    const double *orbvecs1, int64_t K1, const double *m2, int64_t n2, int64_t A2,
+                    const double *centers2, const double *orbvecs2, int64_t K2,
+                    const double *angles, int64_t nA, const int64_t *quads, int64_t Q,
+                    double thresh, int64_t max_clashes, double tfd_thresh, uint8_t *pass_out,
+                    uint8_t *accept_out, double *R2_out, double *t2_out);
+
 /* ---- a17-a19: torsion scan -- firecode/torsion_module.py:812-856
  * (clustered_csearch inner loops) with rotate_dihedral (prism_pruner.utils)
  * and torsion_comp_check (torsion_module.py:894-918).

@@ -719,3 +719,45 @@ def ensemble_from_xyz_text(text):
         except StopIteration:
             pass
     return np.array(atoms[0]), np.array(coords)
+
+
+# --------------------------------------------------------------------------
+# string embed  (firecode/embeds.py:51-158; rot_mat_from_pointer / dihedral are 3P)
+# --------------------------------------------------------------------------
+def string_embed(m1, m2, centers1, orbvecs1, centers2, orbvecs2, angles, quadruplets,
+                 thresh=1.5, max_clashes=0, tfd_thresh=10):
+    """Literal pose loop of ``string_embed`` for duck-typed inputs: molecule 1 is
+    never moved; molecule 2 gets ``R = [rot(ref_vec, angle) @]
+    rotation_matrix_from_vectors(mol_vec, -ref_vec)``, ``t = p1 - R @ p2``; a pose
+    is kept if it passes ``compenetration_check`` and its torsion fingerprint is
+    not TFD-similar to ANY fingerprint kept so far (the 5-entry "LRU" of
+    embeds.py:80-82 is never trimmed: the slice only rebinds a local name).
+    centers*/orbvecs*: (n_conf, K, 3).  Returns (pass, accept) flat over the
+    reference's loop order, plus the list of accepted poses."""
+    n1, n2 = len(m1), len(m2)
+    K1, K2 = centers1.shape[1], centers2.shape[1]
+    A1 = m1.shape[1]
+    conf_indices = cartesian_product(np.arange(n1), np.arange(n2))
+    center_indices = cartesian_product(np.arange(K1), np.arange(K2))
+    ok, acc, poses, cache = [], [], [], []
+    for c1, c2 in conf_indices:
+        for ai1, ai2 in center_indices:
+            for angle in angles:
+                p1, p2 = centers1[c1, ai1], centers2[c2, ai2]
+                ref_vec, mol_vec = orbvecs1[c1, ai1], orbvecs2[c2, ai2]
+                R = rotation_matrix_from_vectors(mol_vec, -ref_vec)
+                if angle != 0:
+                    R = rot_mat_from_pointer(ref_vec, angle) @ R
+                t = p1 - R @ p2
+                pose = np.concatenate([m1[c1], (R @ m2[c2].T).T + t])
+                good = compenetration_check(pose, ids=[A1, m2.shape[1]], thresh=thresh, max_clashes=max_clashes)
+                new = False
+                if good:
+                    tfp = get_torsion_fingerprint(pose, quadruplets)
+                    new = not any(tfd_similarity(tfp, ref, thresh=tfd_thresh) for ref in cache)
+                    if new:
+                        cache.append(tfp)
+                        poses.append(pose)
+                ok.append(good)
+                acc.append(new)
+    return np.array(ok), np.array(acc), np.array(poses)

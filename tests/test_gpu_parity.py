@@ -585,3 +585,28 @@ def test_embed_grid_dedupe_vs_oracle(fc, seed, nr1, nr2, scale):
     assert 0 < acc.sum() < ok.sum() <= ok.size
     if scale < 1.5:
         assert ok.sum() < ok.size  # some poses clash
+
+
+# ---------------------------------------------------------------- a14: string embed
+@pytest.mark.parametrize("seed,thresh", [(75, 1.2), (76, 2.2)])
+def test_string_embed_vs_oracle(fc, seed, thresh):
+    rng = np.random.default_rng(seed)
+    m1 = rng.normal(scale=1.5, size=(3, 9, 3))
+    m2 = rng.normal(scale=1.5, size=(2, 7, 3))
+    r1, r2 = 2, 4
+    c1 = m1[:, [r1]] * 1.7 + rng.normal(scale=0.2, size=(3, 1, 3))
+    v1 = c1 - m1[:, [r1]]
+    c2 = np.concatenate([m2[:, [r2]] * 1.7, m2[:, [r2]] * -0.9 + 0.3], axis=1)
+    v2 = c2 - m2[:, [r2]]
+    v2[0, 1] = -v1[0, 0] * 2.0     # already anti-parallel to ref_vec of conformer 0: the identity branch
+    v2[1, 0] = v1[1, 0] * 0.5      # exactly parallel to ref_vec: the 180-degree-about-z branch
+    angles = np.arange(12) * 30.0
+    quads = np.array([[0, 1, r1, 9 + r2], [1, r1, 9 + r2, 9 + 5], [r1, 9 + r2, 9 + 5, 9 + 6]])
+    poses, acc, ok = fc.embeds.string_embed(m1, c1, v1, m2, c2, v2, angles, quads, thresh=thresh)
+    ok0, acc0, poses0 = o.string_embed(m1, m2, c1, v1, c2, v2, angles, quads, thresh=thresh)
+    assert np.array_equal(ok, ok0)
+    assert np.array_equal(acc, acc0)
+    assert poses.shape == poses0.shape and np.abs(poses - poses0).max() < TOL
+    assert 0 < acc.sum() <= ok.sum() <= len(ok)
+    if thresh > 2:
+        assert ok.sum() < len(ok) and acc.sum() < ok.sum()
