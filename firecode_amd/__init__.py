@@ -8,6 +8,7 @@ NumPy fallback -- without the library or without a gfx950 device every compute
 call raises ``FirecodeHipError``.
 """
 
+from firecode_amd import _lib  # noqa: F401
 from firecode_amd._lib import (  # noqa: F401
     DeviceEnsemble,
     FirecodeHipDeviceError,
@@ -19,7 +20,7 @@ from firecode_amd._lib import (  # noqa: F401
     shutdown,
 )
 from firecode_amd import (  # noqa: F401,E402
-    algebra, embeds, ensemble, host_helpers, pruner, pt, refining, rmsd, torsion_module, utils,
+    algebra, embeds, ensemble, host_helpers, operators, pruner, pt, refining, rmsd, torsion_module, utils,
 )
 
 __version__ = "0.1.0"

@@ -610,3 +610,25 @@ def test_string_embed_vs_oracle(fc, seed, thresh):
     assert 0 < acc.sum() <= ok.sum() <= len(ok)
     if thresh > 2:
         assert ok.sum() < len(ok) and acc.sum() < ok.sum()
+
+
+def test_gpu_prune_operator(fc, tmp_path, monkeypatch):
+    """operator contract: f(filename, embedder) -> output .xyz name"""
+    from types import SimpleNamespace
+
+    from firecode_amd import operators as ops
+
+    monkeypatch.chdir(tmp_path)
+    X, atoms, asg = syn.synthetic_ensemble(300, 14, seed=77)
+    logs = []
+    emb = SimpleNamespace(mols={"mol.xyz": SimpleNamespace(coords=X, atoms=atoms, basename="mol")},
+                          options=SimpleNamespace(rmsd=0.5, dryrun=False), log=logs.append, debuglog=None)
+    out = ops.operate("mol.xyz", "gpu_prune", emb)
+    assert out == "mol_gpu_pruned.xyz"
+    a, c = fc._lib.xyz_read(tmp_path / out)
+    _, m1 = o.prune_by_moment_of_inertia(X, atoms)
+    _, m2 = o.prune_by_rmsd(X[m1], atoms, 0.5)
+    assert len(c) == m2.sum() and np.abs(c - np.round(X[m1][m2], 6)).max() < 1e-6
+    assert any("Discarded" in s for s in logs)
+    emb.options.dryrun = True
+    assert ops.operate("mol.xyz", "gpu_prune", emb) == "mol.xyz"
