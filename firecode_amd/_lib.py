@@ -271,15 +271,18 @@ class DeviceEnsemble:
         call("fc_prune_level", self.handle, int(k), pb(mi), pb(mo))
         return mo
 
-    def similar_pairs(self):
+    def similar_pairs(self, count_hint=None):
         """This rank's exactly-similar pairs after ``prune_begin`` as uint64
         ``(i << 32) | j``; raises FirecodeHipInputError (FC_E_LIMIT) when the
-        candidate queue overflowed (dense similarity: use ``prune_level``)."""
+        candidate queue overflowed (dense similarity: use ``prune_level``).
+        ``count_hint``: ``stats[2]`` of ``prune_begin`` saves the size query."""
         n = C.c_int64(0)
-        call("fc_prune_similar_pairs", self.handle, None, 0, C.byref(n))
-        out = np.zeros(n.value, dtype=np.uint64)
-        call("fc_prune_similar_pairs", self.handle, pw(out), n.value, C.byref(n))
-        return out
+        if count_hint is None:
+            call("fc_prune_similar_pairs", self.handle, None, 0, C.byref(n))
+            count_hint = n.value
+        out = np.zeros(int(count_hint), dtype=np.uint64)
+        call("fc_prune_similar_pairs", self.handle, pw(out), out.shape[0], C.byref(n))
+        return out[: n.value]
 
     def prune_from_pairs(self, pairs, min_per_group=20):
         pairs = np.ascontiguousarray(pairs, dtype=np.uint64)

@@ -65,21 +65,34 @@ def torch_allgather(group=None, device=None):
 PAD = np.uint64(0xFFFFFFFFFFFFFFFF)  # (i = 2^32-1): ignored by the scatter kernel
 
 
-def gather_pairs(pairs, allgather_fn):
-    """Variable-length all-gather of uint64 pair lists with two fixed-size
-    collectives: the counts (-1 = "this rank has no list"), then the lists
-    padded to the longest.  Returns None when any rank has no list."""
-    count = np.array([-1 if pairs is None else pairs.shape[0]], dtype=np.int64)
-    counts = allgather_fn(count.view(np.uint8)).view(np.int64).reshape(-1)
-    if (counts < 0).any():
+NONE = np.uint64(0xFFFFFFFFFFFFFFFE)  # header value of a rank that has no list
+
+
+def gather_pairs(pairs, allgather_fn, cap=0):
+    """Variable-length all-gather of the ranks' uint64 pair lists.
+
+    One collective in the usual case: every rank sends ``cap + 1`` words --
+    its count, then its pairs, padded.  Only when some list is longer than
+    ``cap`` a second collective (padded to the longest list) follows.
+    ``pairs is None`` = "this rank has no list"; then None is returned on every
+    rank (the header doubles as the vote for the exchange mode)."""
+    n = 0 if pairs is None else int(pairs.shape[0])
+    buf = np.full(cap + 1, PAD, dtype=np.uint64)
+    buf[0] = NONE if pairs is None else np.uint64(n)
+    if n:
+        buf[1: 1 + min(n, cap)] = pairs[:cap]
+    rows = allgather_fn(buf.view(np.uint8)).view(np.uint64).reshape(-1, cap + 1)
+    counts = rows[:, 0]
+    if (counts == NONE).any():
         return None
+    counts = counts.astype(np.int64)
+    if (counts <= cap).all():
+        return np.concatenate([rows[r, 1: 1 + counts[r]] for r in range(len(counts))])
     longest = int(counts.max())
-    if longest == 0:
-        return np.zeros(0, dtype=np.uint64)
     padded = np.full(longest, PAD, dtype=np.uint64)
-    padded[: pairs.shape[0]] = pairs
-    rows = allgather_fn(padded.view(np.uint8)).view(np.uint64).reshape(len(counts), longest)
-    return np.concatenate([rows[r, : counts[r]] for r in range(len(counts))])
+    padded[:n] = pairs
+    full = allgather_fn(padded.view(np.uint8)).view(np.uint64).reshape(len(counts), longest)
+    return np.concatenate([full[r, : counts[r]] for r in range(len(counts))])
 
 
 def prune_by_rmsd_sharded(ens, max_rmsd, max_dev=None, rank=0, world=1, allgather_fn=None,
@@ -104,12 +117,14 @@ def prune_by_rmsd_sharded(ens, max_rmsd, max_dev=None, rank=0, world=1, allgathe
     pairs = None
     if mode in ("auto", "pairs") and hasattr(ens, "similar_pairs"):
         try:
-            pairs = ens.similar_pairs()
+            pairs = ens.similar_pairs(int(stats[2]))
         except ValueError:  # FirecodeHipInputError(FC_E_LIMIT): queue overflow on this rank
             if mode == "pairs":
                 raise
-    # every rank takes the same branch: the count exchange doubles as the vote
-    all_pairs = gather_pairs(pairs, allgather_fn)
+    # every rank takes the same branch: the count header doubles as the vote; the
+    # capacity (same on every rank) makes the exchange ONE collective unless similarity is
+    # much denser than a handful of duplicates per conformer
+    all_pairs = gather_pairs(pairs, allgather_fn, cap=1024 + 4 * ens.N // max(world, 1))
     if all_pairs is not None:
         mask = ens.prune_from_pairs(all_pairs, min_per_group=min_per_group)
         return mask, stats

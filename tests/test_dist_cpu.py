@@ -44,7 +44,7 @@ class OracleShard:
 class OraclePairShard(OracleShard):
     """adds the similar-pair exchange (fc_prune_similar_pairs / fc_prune_from_pairs)"""
 
-    def similar_pairs(self):
+    def similar_pairs(self, count_hint=None):
         i, j = np.nonzero(self.S & self.own[:, None])
         return (i.astype(np.uint64) << np.uint64(32)) | j.astype(np.uint64)
 
@@ -107,28 +107,45 @@ def test_sharded_pairs_exchange_matches_single(tmp_path, world, n):
 
 
 def test_gather_pairs_variable_length():
+    """3 ranks emulated in-process: one collective when every list fits the capacity,
+    a second one when a list is longer; None when a rank has no list"""
     lists = [np.arange(5, dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.arange(100, 103, dtype=np.uint64)]
-    # emulate 3 ranks in-process: the all-gather stacks what each rank would send
-    sent = {}
 
-    def make(rank):
-        def fn(buf):
-            sent.setdefault(len(buf), {})[rank] = buf.copy()
-            return None
-        return fn
-
-    # two passes: first record every rank's buffers, then answer from the record
-    def run(rank, answers):
-        it = iter(answers)
-        return fdist.gather_pairs(lists[rank], lambda buf: next(it))
-
-    counts = np.stack([np.array([len(l)], dtype=np.int64).view(np.uint8) for l in lists])
-    longest = max(len(l) for l in lists)
-    padded = np.stack([np.concatenate([l, np.full(longest - len(l), fdist.PAD, dtype=np.uint64)]).view(np.uint8)
-                       for l in lists])
-    for rank in range(3):
-        out = run(rank, [counts, padded])
-        assert np.array_equal(out, np.concatenate(lists))
+    for cap in (8, 3):
+        outs = []
+        n_coll = []
+        for r in range(3):
+            # build the replies exactly as an all-gather would: stack every rank's buffer
+            def first(l):
+                buf = np.full(cap + 1, fdist.PAD, dtype=np.uint64)
+                buf[0] = fdist.NONE if l is None else np.uint64(len(l))
+                if l is not None and len(l):
+                    buf[1:1 + min(len(l), cap)] = l[:cap]
+                return buf.view(np.uint8)
+            longest = max(len(l) for l in lists)
+            def second(l):
+                buf = np.full(longest, fdist.PAD, dtype=np.uint64)
+                buf[:len(l)] = l
+                return buf.view(np.uint8)
+            replies = [np.stack([first(l) for l in lists]), np.stack([second(l) for l in lists])]
+            used = []
+            def fn(buf):
+                used.append(1)
+                return replies[len(used) - 1]
+            outs.append(fdist.gather_pairs(lists[r], fn, cap))
+            n_coll.append(len(used))
+        for out in outs:
+            assert np.array_equal(out, np.concatenate(lists))
+        assert n_coll == ([1, 1, 1] if cap >= 5 else [2, 2, 2])
+    # a rank without a list: everybody gets None
+    def fn_none(buf):
+        rows = []
+        for l in (lists[0], None, lists[2]):
+            b = np.full(9, fdist.PAD, dtype=np.uint64)
+            b[0] = fdist.NONE if l is None else np.uint64(len(l))
+            rows.append(b.view(np.uint8))
+        return np.stack(rows)
+    assert fdist.gather_pairs(lists[0], fn_none, 8) is None
 
 
 def test_owner_of_rows_balances_triangle():
