@@ -58,6 +58,7 @@ _SIGNATURES = {
     "fc_kabsch_rmsd_pairs": [_p_f64, _i64, _i64, _p_u8, _p_i64, _p_i64, _i64, C.c_int, _p_f64, _p_f64],
     "fc_ensemble_rmsd_pairs": [_ens, _p_i64, _p_i64, _i64, _p_f64, _p_f64],
     "fc_ensemble_rmsd_matrix": [_ens, _p_f64, _p_f64],
+    "fc_ensemble_rmsd_values": [_ens, _p_f64, _p_f64],
     "fc_alignment_matrices": [_p_f64, _p_f64, _i64, _i64, _p_f64],
     "fc_rmsd_simbits": [_ens, _f64, _f64, _p_f64, _f64, _i64, _i64, _p_u64, _p_i64],
     "fc_prune_rmsd": [_ens, _f64, _f64, _p_f64, _f64, _i64, _p_u8, _p_i64],
@@ -240,6 +241,14 @@ class DeviceEnsemble:
         m = np.zeros((self.N, self.N))
         call("fc_ensemble_rmsd_matrix", self.handle, pf(r), pf(m))
         return r, m
+
+    def rmsd_values(self, want_matrix=True):
+        """All-pairs RMSD values (no max deviation) on the matrix pipe:
+        (matrix (N, N) or None, kernel ms)."""
+        r = np.zeros((self.N, self.N)) if want_matrix else None
+        ms = C.c_double(0)
+        call("fc_ensemble_rmsd_values", self.handle, pf(r), C.byref(ms))
+        return r, ms.value
 
     def simbits(self, max_rmsd, max_dev, energies=None, max_dE=0.0, row_begin=0, row_end=None):
         row_end = self.N if row_end is None else int(row_end)

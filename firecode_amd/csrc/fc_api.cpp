@@ -14,6 +14,7 @@ int launch_prep(const double *, int64_t, int64_t, const int32_t *, int64_t, int,
 int launch_pairs_exact(const fc_ensemble *, const int64_t *, const int64_t *, int64_t, double *,
                        double *, double *);
 int launch_matrix_exact(const fc_ensemble *, double *, double *);
+int launch_rmsd_values(fc_ensemble *, double, double *);
 int launch_simbits_screen(fc_ensemble *, double);
 int launch_simbits_refine(fc_ensemble *, double, double, const double *, double);
 int launch_align_to_first(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
@@ -456,6 +457,39 @@ int fc_ensemble_rmsd_matrix(fc_ensemble *ens, double *rmsd_out, double *maxdev_o
       rmsd_out[j * N + i] = rmsd_out[i * N + j];
       maxdev_out[j * N + i] = maxdev_out[i * N + j];
     }
+  return FC_OK;
+}
+
+int fc_ensemble_rmsd_values(fc_ensemble *ens, double *rmsd_out, double *ms_kernel) {
+  FC_REQUIRE(ens != nullptr, "ens is NULL");
+  FC_TRY(ensure_init());
+  const int64_t N = ens->N;
+  if (N == 0) return FC_OK;
+  FC_TRY(ensemble_shard(ens, 0, 1, 256));  // sizes the pair queue
+  Context &c = ctx();
+  DevBuf dr;
+  const size_t bytes = (size_t)N * N * sizeof(double);
+  FC_TRY(dr.reserve(bytes));
+  FC_HIP_TRY(hipMemsetAsync(dr.p, 0, bytes, c.stream));
+  FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 16 * sizeof(uint64_t), c.stream));
+  FC_HIP_TRY(hipEventRecord(c.ev0, c.stream));
+  FC_TRY(launch_rmsd_values(ens, 0.02, dr.as<double>()));
+  FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
+  unsigned long long cnt[16];
+  FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
+  if (rmsd_out) FC_TRY(d2h(rmsd_out, dr.p, bytes));
+  FC_TRY(sync());
+  if (cnt[6] > (unsigned long long)ens->pairq_cap)
+    return set_error(FC_E_LIMIT, "%llu pairs closer than 0.02 A exceed the fix-up queue (%lld): "
+                     "use fc_ensemble_rmsd_matrix", cnt[6], (long long)ens->pairq_cap);
+  if (ms_kernel) {
+    float ms = 0.f;
+    FC_HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    *ms_kernel = ms;
+  }
+  if (rmsd_out)
+    for (int64_t i = 0; i < N; ++i)
+      for (int64_t j = i + 1; j < N; ++j) rmsd_out[j * N + i] = rmsd_out[i * N + j];
   return FC_OK;
 }
 

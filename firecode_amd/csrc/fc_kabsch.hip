@@ -19,6 +19,9 @@
 
 namespace fc {
 
+// LDS budget: a column tile is A*3*64*8 bytes; 160 KiB per CU on gfx950
+static constexpr size_t kLdsLimit = 160 * 1024;
+
 // ---------------------------------------------------------------------------
 // k_prep: AoS (N, A_all, 3) -> conformer-minor SoA of the selected atoms,
 // optional centring on the centroid of the selection, G[n].
@@ -428,13 +431,17 @@ k_simbits_screen(const double *__restrict__ Xs, const double *__restrict__ G, in
 // ---------------------------------------------------------------------------
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-template <int NW>
+// VALUES = true: same tiling, but the epilogue solves for the largest quaternion
+// eigenvalue (Newton) and stores rmsd(i, j) into a dense (N, N) matrix instead of
+// screening; pairs with rmsd below `A_thr2` (reused as the small-rmsd^2 * A limit)
+// are queued for the exact explicit-difference evaluation.
+template <int NW, bool VALUES = false>
 __global__ void __launch_bounds__(NW * 64, 2)
 k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N,
                       int64_t Npad, int A, double A_thr2, int IB, int64_t rank, int64_t world,
                       uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
                       unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
-                      unsigned long long Q, int compact) {
+                      unsigned long long Q, int compact, double *__restrict__ rmsd_out = nullptr) {
   extern __shared__ double lds[];
   constexpr int TC = 64;
   const int tid = threadIdx.x;
@@ -513,7 +520,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
     for (int half = 0; half < 2; ++half) {
       const int cs0 = half * 2;
       if (j0 + (cs0 + 2) * 16 - 1 <= ib) {  // both sub-tiles at or below the diagonal
-        if (lane < 4) {
+        if (!VALUES && lane < 4) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int64_t row = ib + lane + 4 * r;
@@ -597,6 +604,15 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
           double B9[9];
 #pragma unroll
           for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
+          if (VALUES) {
+            const double lam = kabsch_lambda_max(B9, Gp + Gq);
+            const double msdA = (Gp + Gq) - 2.0 * lam;
+            const bool in = (j > i) && (j < n32) && (i < n32);
+            if (in) rmsd_out[(int64_t)i * N + j] = sqrt(fmax(msdA, 0.0) / (double)A);
+            const bool redo = in && (msdA < A_thr2);
+            push_pairs(__ballot(redo), redo, (unsigned)i, (unsigned)j, pairq, Q, counters, lane);
+            continue;
+          }
           bool may = kabsch_may_be_below(B9, Gp + Gq, A_thr2);
           may = may && (j > i) && (j < n32) && (i < n32);
           const uint64_t m = __ballot(may);
@@ -614,7 +630,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
         }
       }
     }
-    if (lane < 4) {  // queue the non-empty words of this row tile for the exact refine
+    if (!VALUES && lane < 4) {  // queue the non-empty words of this row tile for the exact refine
       const unsigned nz[4] = {nz0, nz1, nz2, nz3};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -799,6 +815,29 @@ k_alignment_matrices(const double *__restrict__ p, const double *__restrict__ q,
   for (int e = 0; e < 9; ++e) M[k * 9 + e] = R[e];
 }
 
+// exact (explicit rotated difference) rmsd for the queued small-rmsd pairs of the
+// VALUES kernel: eight lanes per pair, overwrites the Newton value
+__global__ void __launch_bounds__(256)
+k_rmsd_fix_small(const double *__restrict__ Xa, int A, int64_t N, const uint64_t *__restrict__ pairq,
+                 const unsigned long long *__restrict__ counters, unsigned long long Q,
+                 double *__restrict__ rmsd_out) {
+  const int lane = threadIdx.x & 63, sub = lane & 7, slot = lane >> 3;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  unsigned long long n = counters[6];
+  if (n > Q) n = Q;  // overflow is reported by the host wrapper
+  for (int64_t base = wave0 * 8; base < (int64_t)n; base += nwaves * 8) {
+    const int64_t p = base + slot;
+    if (p < (int64_t)n) {
+      const uint64_t e = pairq[p];
+      const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
+      double r, m;
+      pair_exact_group8(Xa, A, i, j, sub, r, m);
+      if (sub == 0) rmsd_out[i * N + j] = r;
+    }
+  }
+}
+
 // full bit matrix from a list of similar pairs ((i << 32) | j, i < j): the
 // receiving side of the multi-GPU exchange
 __global__ void __launch_bounds__(256)
@@ -810,6 +849,43 @@ k_scatter_pairs(const uint64_t *__restrict__ pairs, int64_t n_pairs, int64_t N, 
   const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
   if (i < 0 || j <= i || j >= N) return;  // padding / malformed entries are ignored
   atomicOr(reinterpret_cast<unsigned long long *>(&bits[i * W + (j >> 6)]), 1ull << (j & 63));
+}
+
+// all-pairs RMSD values on the matrix pipe (world == 1 layout); rmsd_dev: (N, N), pre-zeroed
+int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev) {
+  const int64_t NT = e->Npad >> 6;
+  const int64_t rb = 256;
+  const int64_t n_lblocks = ceil_div(e->N, rb);
+  const size_t lds_m = (size_t)((e->A + 3) / 4) * 4 * 3 * 64 * sizeof(double);
+  if (lds_m > kLdsLimit || NT == 0)
+    return set_error(FC_E_LIMIT, "A=%lld atoms exceed the LDS column tile of the value kernel", (long long)e->A);
+  const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32);
+  if (!fits32) return set_error(FC_E_LIMIT, "ensemble too large for 32-bit operand offsets");
+  auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
+  const bool two_blocks = 2 * lds_m <= kLdsLimit;
+  const void *fn = two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4, true>)
+                              : reinterpret_cast<const void *>(k_simbits_screen_mfma<8, true>);
+  if (lds_m > 64 * 1024) {
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+    if (err != hipSuccess) return set_error(FC_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
+  }
+  const dim3 grid((unsigned)NT, (unsigned)n_lblocks);
+  const double A_small = (double)e->A * small_rmsd * small_rmsd;
+  if (two_blocks)
+    hipLaunchKernelGGL((k_simbits_screen_mfma<4, true>), grid, dim3(256), lds_m, ctx().stream,
+                       e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,
+                       (int64_t)0, (int64_t)1, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),
+                       (unsigned long long)e->pairq_cap, 0, rmsd_dev);
+  else
+    hipLaunchKernelGGL((k_simbits_screen_mfma<8, true>), grid, dim3(512), lds_m, ctx().stream,
+                       e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,
+                       (int64_t)0, (int64_t)1, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),
+                       (unsigned long long)e->pairq_cap, 0, rmsd_dev);
+  FC_TRY(check_launch("k_simbits_screen_mfma<values>"));
+  hipLaunchKernelGGL(k_rmsd_fix_small, dim3((unsigned)(ctx().n_cu * 4)), dim3(256), 0, ctx().stream,
+                     e->Xa.as<double>(), (int)e->A, e->N, e->pairq.as<uint64_t>(), cnt,
+                     (unsigned long long)e->pairq_cap, rmsd_dev);
+  return check_launch("k_rmsd_fix_small");
 }
 
 int launch_scatter_pairs(const uint64_t *pairs_dev, int64_t n_pairs, int64_t N, int64_t W,
@@ -849,8 +925,6 @@ int launch_matrix_exact(const fc_ensemble *e, double *rmsd_dev, double *maxdev_d
   return check_launch("k_matrix_exact");
 }
 
-// LDS budget: a column tile is A*3*64*8 bytes; 160 KiB per CU on gfx950
-static constexpr size_t kLdsLimit = 160 * 1024;
 
 int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   const int64_t NT = e->Npad >> 6;

@@ -177,4 +177,38 @@ __host__ __device__ __forceinline__ bool kabsch_may_be_below(const double (&B)[9
 }
 
 
+
+// Largest eigenvalue of the quaternion matrix by Newton's iteration on its
+// characteristic polynomial, started from the upper bound (Gp+Gq)/2 (monotone
+// convergence from above; Theobald's QCP).  rmsd^2 = (Gp + Gq - 2 lambda) / A.
+// Used for all-pairs RMSD *values*: no eigenvector, no rotation.  The caller
+// re-evaluates pairs with a tiny rmsd exactly (cancellation in Gp+Gq-2*lambda).
+__host__ __device__ __forceinline__ double kabsch_lambda_max(const double (&B)[9], double GpGq) {
+#pragma clang fp contract(fast)
+  const double Sxx = B[0], Sxy = B[1], Sxz = B[2];
+  const double Syx = B[3], Syy = B[4], Syz = B[5];
+  const double Szx = B[6], Szy = B[7], Szz = B[8];
+  const double n2 = Sxx * Sxx + Sxy * Sxy + Sxz * Sxz + Syx * Syx + Syy * Syy + Syz * Syz +
+                    Szx * Szx + Szy * Szy + Szz * Szz;
+  const double c00 = Syy * Szz - Syz * Szy, c01 = Syz * Szx - Syx * Szz, c02 = Syx * Szy - Syy * Szx;
+  const double c10 = Sxz * Szy - Sxy * Szz, c11 = Sxx * Szz - Sxz * Szx, c12 = Sxy * Szx - Sxx * Szy;
+  const double c20 = Sxy * Syz - Sxz * Syy, c21 = Sxz * Syx - Sxx * Syz, c22 = Sxx * Syy - Sxy * Syx;
+  const double detB = Sxx * c00 + Sxy * c01 + Sxz * c02;
+  const double e2 = c00 * c00 + c01 * c01 + c02 * c02 + c10 * c10 + c11 * c11 + c12 * c12 +
+                    c20 * c20 + c21 * c21 + c22 * c22;
+  const double C2 = -2.0 * n2, C1 = -8.0 * detB, C0 = n2 * n2 - 4.0 * e2;
+  double x = 0.5 * GpGq;
+  for (int it = 0; it < 64; ++it) {
+    const double x2 = x * x;
+    const double b = (x2 + C2) * x;
+    const double a = b + C1;
+    const double den = 2.0 * x2 * x + b + a;
+    if (den == 0.0) break;
+    const double delta = (a * x + C0) / den;
+    x -= delta;
+    if (fabs(delta) <= 4e-16 * fabs(x)) break;
+  }
+  return x;
+}
+
 }  // namespace fc

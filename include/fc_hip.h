@@ -71,6 +71,13 @@ int fc_ensemble_rmsd_pairs(fc_ensemble *ens, const int64_t *pair_i, const int64_
                            int64_t P, double *rmsd_out, double *maxdev_out);
 /* all pairs: rmsd_out / maxdev_out are (N, N) row-major, symmetric, 0 diagonal */
 int fc_ensemble_rmsd_matrix(fc_ensemble *ens, double *rmsd_out, double *maxdev_out);
+/* all-pairs RMSD VALUES on the fp64 matrix pipe: covariance by MFMA, largest
+ * quaternion eigenvalue by Newton (QCP), rmsd = sqrt((Gp+Gq-2*lambda)/A); pairs
+ * below 0.02 A are re-evaluated with the explicit rotated difference.  No max
+ * deviation (that needs the rotation: fc_ensemble_rmsd_matrix).  rmsd_out (N, N)
+ * symmetric, may be NULL (timing only); ms_kernel (may be NULL) = HIP-event time
+ * of the two kernels. */
+int fc_ensemble_rmsd_values(fc_ensemble *ens, double *rmsd_out, double *ms_kernel);
 /* a9: get_alignment_matrix(p, q) -- prism_pruner.rmsd; call site
  * hypermolecule_class.py:77.  M (3,3) row-major, applied as (M @ q.T).T */
 int fc_alignment_matrices(const double *p, const double *q, int64_t n_pairs, int64_t A,

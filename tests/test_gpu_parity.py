@@ -632,3 +632,23 @@ def test_gpu_prune_operator(fc, tmp_path, monkeypatch):
     assert any("Discarded" in s for s in logs)
     emb.options.dryrun = True
     assert ops.operate("mol.xyz", "gpu_prune", emb) == "mol.xyz"
+
+
+def test_rmsd_values_matrix(fc):
+    """all-pairs RMSD values from the Newton / MFMA kernel (+ exact fix-up of tiny rmsd)"""
+    X, atoms, asg = syn.synthetic_ensemble(700, 50, seed=81)
+    X[5] = X[4] @ syn.random_rotation(np.random.default_rng(1)).T + 2.0        # identical up to a rigid motion
+    X[9] = X[8] + 1e-6 * np.random.default_rng(2).normal(size=X[8].shape)      # almost identical
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        R, ms = ens.rmsd_values()
+    _, R0, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    assert np.abs(R - R0).max() < TOL
+    assert R[4, 5] < 1e-12 and abs(R[8, 9] - R0[8, 9]) < 1e-13 and ms > 0
+    # random, unrelated structures (no cluster structure at all), odd sizes
+    rng = np.random.default_rng(3)
+    Y = rng.normal(scale=2.5, size=(150, 23, 3))
+    with fc.DeviceEnsemble(Y, center=True) as ens:
+        R, _ = ens.rmsd_values()
+    iu, ju = np.triu_indices(150, 1)
+    r0, _ = o.rmsd_and_max_batch(Y[iu], Y[ju], center=True)
+    assert np.abs(R[iu, ju] - r0).max() < TOL
