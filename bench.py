@@ -168,7 +168,7 @@ def main():
                                    f"+ {MAX_RMSD} A prune (BASELINE configs[1]; conformers scale as sqrt(n_gpus))",
                        "n_conformers": n_conf, "n_atoms": N_ATOMS, "max_rmsd": MAX_RMSD,
                        "pairs_per_step": pairs_total,
-                       "sharding": f"row blocks of 256 dealt in snake order over {world} rank(s); one all-gather "
+                       "sharding": f"row blocks of 128 dealt in snake order over {world} rank(s); one all-gather "
                                    "of similar-pair lists, ladder replayed on every rank"},
             "pruned_ensembles_per_s": args.steps / elapsed,
             "rmsd_values_per_s": (pairs_total / (values_ms * 1e-3)) if world == 1 else None,

@@ -267,7 +267,7 @@ class DeviceEnsemble:
              int(min_per_group), pb(mask), pi(stats))
         return mask.astype(bool), stats
 
-    def prune_begin(self, max_rmsd, max_dev, rank, world, row_block=256, energies=None, max_dE=0.0):
+    def prune_begin(self, max_rmsd, max_dev, rank, world, row_block=128, energies=None, max_dE=0.0):
         stats = np.zeros(6, dtype=np.int64)
         en = None if energies is None else f64(energies)
         call("fc_prune_rmsd_begin", self.handle, float(max_rmsd), float(max_dev), pf(en), float(max_dE),

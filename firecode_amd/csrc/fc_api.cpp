@@ -223,9 +223,9 @@ static int64_t default_row_block() {
   const char *v = getenv("FC_ROW_BLOCK");
   if (v) {
     const long r = std::strtol(v, nullptr, 10);
-    if (r >= 128 && r <= 4096 && r % 128 == 0) return r;
+    if (r >= 64 && r <= 4096 && r % 64 == 0) return r;
   }
-  return 256;
+  return 128;  // measured best on cfg2 (tail and balance beat the extra LDS fills)
 }
 
 // similarity bits of this rank's rows: screen + exact refine; counters[1..3]

@@ -941,7 +941,8 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   {
     const size_t lds_m = (size_t)((e->A + 3) / 4) * 4 * 3 * 64 * sizeof(double);
     const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32);
-    if (!want_valu && fits32 && lds_m <= kLdsLimit && e->row_block % 128 == 0) {
+    const bool two_blocks_fit = 2 * lds_m <= kLdsLimit;
+    if (!want_valu && fits32 && lds_m <= kLdsLimit && e->row_block % (two_blocks_fit ? 64 : 128) == 0) {
       auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
       const bool two_blocks = 2 * lds_m <= kLdsLimit;
       const void *fn = two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4>)

@@ -96,7 +96,7 @@ def gather_pairs(pairs, allgather_fn, cap=0):
 
 
 def prune_by_rmsd_sharded(ens, max_rmsd, max_dev=None, rank=0, world=1, allgather_fn=None,
-                          row_block=256, min_per_group=20, trace=None, mode="auto"):
+                          row_block=128, min_per_group=20, trace=None, mode="auto"):
     """``ens``: a ``DeviceEnsemble`` holding the whole ensemble on this rank's
     GPU.  Each rank computes the similarity of its own row blocks, then
 
