@@ -77,7 +77,16 @@ def main():
 
     allgather = None
     tdist = None
-    if world > 1:
+    # FC_BENCH_FORCE_SHARDED=1: take the multi-GPU code path (RCCL group of one rank) on a
+    # single GPU -- measures what the exchange costs over the resident single-GPU step
+    sharded = world > 1 or os.environ.get("FC_BENCH_FORCE_SHARDED") == "1"
+    stdout_fd = None
+    if sharded:
+        # RCCL writes a version banner to fd 1 when the communicator is created; the contract
+        # is ONE JSON line on stdout, so everything but that line goes to stderr
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch
         import torch.distributed as tdist
 
@@ -87,7 +96,11 @@ def main():
             allgather = fdist.torch_allgather()
         else:
             torch.cuda.set_device(local_rank)
-            tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            if world == 1 and "RANK" not in os.environ:
+                tdist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29655", rank=0,
+                                         world_size=1, device_id=torch.device("cuda", local_rank))
+            else:
+                tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
             allgather = fdist.torch_allgather(device=torch.device("cuda", local_rank))
 
     n_conf = int(round(N_CONF * np.sqrt(world)))
@@ -96,7 +109,7 @@ def main():
     pairs_total = n_conf * (n_conf - 1) // 2
 
     def barrier():
-        if world > 1:
+        if sharded:
             import torch
 
             if backend != "gloo":
@@ -106,7 +119,7 @@ def main():
                 torch.cuda.synchronize()
 
     t_kernel_ms = None
-    if world == 1:
+    if not sharded:
         def step():
             return ens.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=1, want_mask=False)
         for _ in range(args.warmup):
@@ -124,8 +137,13 @@ def main():
         ens.rmsd_values(want_matrix=False)
         values_ms = min(ens.rmsd_values(want_matrix=False)[1] for _ in range(3))
     else:
-        def step():
-            return fdist.prune_by_rmsd_sharded(ens, MAX_RMSD, rank=rank, world=world, allgather_fn=allgather)
+        if backend == "gloo":  # rehearsal: host exchange through gloo
+            def step():
+                return fdist.prune_by_rmsd_sharded(ens, MAX_RMSD, rank=rank, world=world, allgather_fn=allgather)
+        else:  # everything between the screen and the mask stays in HBM, one RCCL all-gather
+            def step():
+                return fdist.prune_by_rmsd_sharded_device(ens, MAX_RMSD, rank=rank, world=world,
+                                                          device=torch.device("cuda", local_rank))
         for _ in range(args.warmup):
             step()
         barrier()
@@ -169,16 +187,20 @@ def main():
                        "n_conformers": n_conf, "n_atoms": N_ATOMS, "max_rmsd": MAX_RMSD,
                        "pairs_per_step": pairs_total,
                        "sharding": f"row blocks of 128 dealt in snake order over {world} rank(s); one all-gather "
-                                   "of similar-pair lists, ladder replayed on every rank"},
+                                   "of similar-pair lists, ladder replayed on every rank",
+                       "exchange": ("none (single GPU, resident step)" if not sharded else
+                                    "host lists through gloo" if backend == "gloo" else
+                                    "device-resident: export kernel -> RCCL all_gather_into_tensor -> ladder, "
+                                    "one stream, one host sync")},
             "pruned_ensembles_per_s": args.steps / elapsed,
-            "rmsd_values_per_s": (pairs_total / (values_ms * 1e-3)) if world == 1 else None,
+            "rmsd_values_per_s": (pairs_total / (values_ms * 1e-3)) if not sharded else None,
             "survivors": survivors,
             "survivors_expected": expected,
             "mask_ok": survivors == expected,
         }
         if t_kernel_ms is not None:
             # dominant kernel: k_simbits_screen, HIP events on the library's stream
-            owned_pairs = pairs_total if world == 1 else owned_pairs_rank0  # pairs of the timed launch
+            owned_pairs = pairs_total if not sharded else owned_pairs_rank0  # pairs of the timed launch
             achieved = owned_pairs * bytes_per_alignment / (t_kernel_ms * 1e-3) / 1e9
             # fabric-side bytes per launch of the same kernel on the same workload, from the
             # committed PMC passes (rocprofv3 cannot run inside this process)
@@ -209,8 +231,13 @@ def main():
             }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(coords)
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        if stdout_fd is not None:
+            os.dup2(stdout_fd, 1)
+        print(json.dumps(out), flush=True)
+        if stdout_fd is not None:
+            os.dup2(2, 1)
+    if sharded:
         tdist.destroy_process_group()
 
 

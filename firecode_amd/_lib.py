@@ -67,6 +67,10 @@ _SIGNATURES = {
     "fc_prune_level": [_ens, _i64, _p_u8, _p_u8],
     "fc_prune_similar_pairs": [_ens, _p_u64, _i64, _p_i64],
     "fc_prune_from_pairs": [_ens, _p_u64, _i64, _i64, _p_u8],
+    "fc_prune_rmsd_begin_async": [_ens, _f64, _f64, _i64, _i64, _i64],
+    "fc_prune_export_pairs_dev": [_ens, C.c_void_p, _i64],
+    "fc_prune_from_gathered_dev": [_ens, C.c_void_p, _i64, _i64, _i64, _p_u8, _p_i64],
+    "fc_stream_set": [C.c_void_p],
     "fc_inertia_moments": [_p_f64, _i64, _i64, _p_f64, _p_f64],
     "fc_prune_moi": [_p_f64, _i64, _i64, _p_f64, _f64, _p_f64, _f64, _i64, _p_u8],
     "fc_align_to_first": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64],
@@ -102,11 +106,38 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("fc_last_error",)
 
 
+def _share_torch_hip_runtime():
+    """PyTorch's ROCm wheels carry their own libamdhip64.so / libhsa-runtime64.so, and two HIP
+    runtimes in one process cannot both own the GPU: whichever initialises second reports
+    "no HIP GPUs".  libfc_hip.so asks for ``libamdhip64.so.7`` by soname, so when torch's copy
+    (same soname) is mapped first both sides share ONE runtime, one device context and
+    compatible streams -- which the RCCL exchange in ``firecode_amd.dist`` needs.  torch
+    itself is not imported here.  ``FC_HIP_RUNTIME=system`` keeps the ROCm install's runtime
+    (torch.cuda is then unusable in this process)."""
+    import importlib.util
+    import sys
+
+    if os.environ.get("FC_HIP_RUNTIME", "auto") == "system" or "torch" in sys.modules:
+        return None
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return path
+
+
 def load():
     """dlopen the library (no device is touched) and set the prototypes."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise FirecodeHipDeviceError(
             FC_E_NODEVICE,
@@ -178,6 +209,12 @@ def init(device=0):
 
 def shutdown():
     call("fc_shutdown")
+
+
+def stream_set(hip_stream):
+    """Enqueue on the caller's HIP stream (integer handle, e.g. ``torch.cuda.Stream().cuda_stream``);
+    None / 0 switches back to the library's own stream."""
+    call("fc_stream_set", C.c_void_p(int(hip_stream) if hip_stream else None))
 
 
 def device_count():
@@ -298,6 +335,21 @@ class DeviceEnsemble:
         mask = np.zeros(self.N, dtype=np.uint8)
         call("fc_prune_from_pairs", self.handle, pw(pairs), int(pairs.shape[0]), int(min_per_group), pb(mask))
         return mask.astype(bool)
+
+    # device-resident exchange: device pointers are plain integers (e.g. torch's data_ptr())
+    def prune_begin_async(self, max_rmsd, max_dev, rank, world, row_block=128):
+        call("fc_prune_rmsd_begin_async", self.handle, float(max_rmsd), float(max_dev), int(rank), int(world),
+             int(row_block))
+
+    def export_pairs_dev(self, dev_ptr, cap):
+        call("fc_prune_export_pairs_dev", self.handle, C.c_void_p(int(dev_ptr)), int(cap))
+
+    def prune_from_gathered_dev(self, dev_ptr, world, cap, min_per_group=20):
+        mask = np.zeros(self.N, dtype=np.uint8)
+        stats = np.zeros(6, dtype=np.int64)
+        call("fc_prune_from_gathered_dev", self.handle, C.c_void_p(int(dev_ptr)), int(world), int(cap),
+             int(min_per_group), pb(mask), pi(stats))
+        return mask.astype(bool), stats
 
     def bench_prune(self, max_rmsd, max_dev, reps=1, want_mask=True):
         mask = np.zeros(self.N, dtype=np.uint8) if want_mask else None

@@ -28,6 +28,8 @@ int launch_ladder_pairs(const uint64_t *, uint32_t *, const unsigned long long *
                         unsigned long long, unsigned long long, int64_t, int64_t, int64_t, const int64_t *,
                         int, uint64_t *, unsigned long long *);
 int launch_scatter_pairs(const uint64_t *, int64_t, int64_t, int64_t, uint64_t *);
+int launch_export_pairs(const uint64_t *, const unsigned long long *, unsigned long long, int64_t, uint64_t *);
+int launch_compact_gathered(const uint64_t *, int, int64_t, uint64_t *, unsigned long long *);
 int launch_level_fused(const uint64_t *, int64_t, const uint64_t *, uint64_t *, int64_t, int64_t,
                        int64_t, unsigned long long *);
 int launch_inertia_moments(const double *, int64_t, int64_t, const double *, double *);
@@ -96,7 +98,7 @@ static int do_init(int device) {
   Context &c = ctx();
   if (c.ready && c.device == device) return FC_OK;
   if (c.ready) {
-    (void)hipStreamDestroy(c.stream);
+    (void)hipStreamDestroy(c.own_stream);
     c.ready = false;
   }
   int n = 0;
@@ -114,7 +116,8 @@ static int do_init(int device) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return set_error(FC_E_NODEVICE, "device %d is %s; this library is built for gfx950 only",
                      device, prop.gcnArchName);
-  FC_HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  FC_HIP_TRY(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+  c.stream = c.own_stream;
   FC_HIP_TRY(hipEventCreate(&c.ev0));
   FC_HIP_TRY(hipEventCreate(&c.ev1));
   FC_HIP_TRY(hipEventCreate(&c.ev2));
@@ -356,7 +359,8 @@ int fc_shutdown(void) {
     (void)hipEventDestroy(c.ev1);
     (void)hipEventDestroy(c.ev2);
     (void)hipEventDestroy(c.ev3);
-    (void)hipStreamDestroy(c.stream);
+    (void)hipStreamDestroy(c.own_stream);
+    c.stream = c.own_stream = nullptr;
     if (c.pinned) (void)hipHostFree(c.pinned);
     c.pinned = nullptr;
     c.pinned_bytes = 0;
@@ -366,6 +370,14 @@ int fc_shutdown(void) {
 }
 
 const char *fc_last_error(void) { return last_error().c_str(); }
+
+int fc_stream_set(void *hip_stream) {
+  FC_TRY(ensure_init());
+  Context &c = ctx();
+  FC_HIP_TRY(hipStreamSynchronize(c.stream));  // nothing of ours may still be queued on the old one
+  c.stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c.own_stream;
+  return FC_OK;
+}
 
 int fc_device_info(char *name, int64_t name_len, int64_t *n_cu, int64_t *hbm_bytes) {
   FC_TRY(ensure_init());
@@ -668,6 +680,66 @@ int fc_prune_from_pairs(fc_ensemble *ens, const uint64_t *pairs, int64_t n_pairs
   FC_HIP_TRY(hipMemsetAsync(ens->bits_full.p, 0, bytes, ctx().stream));
   FC_TRY(launch_scatter_pairs(dp.as<uint64_t>(), n_pairs, N, W, ens->bits_full.as<uint64_t>()));
   return ladder_single(ens, ens->bits_full.as<uint64_t>(), min_per_group, mask_out, nullptr, nullptr);
+}
+
+// ---- device-resident exchange (no host round trip between screen and mask) --------------
+int fc_prune_rmsd_begin_async(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t rank,
+                              int64_t world, int64_t row_block) {
+  FC_REQUIRE(ens != nullptr, "ens is NULL");
+  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
+  FC_TRY(ensure_init());
+  FC_TRY(ensemble_shard(ens, rank, world, row_block));
+  if (ens->N == 0) return FC_OK;
+  return simbits_local(ens, max_rmsd, max_dev, nullptr, 0.0, true);
+}
+
+int fc_prune_export_pairs_dev(fc_ensemble *ens, uint64_t *dev_out, int64_t cap) {
+  FC_REQUIRE(ens && dev_out, "NULL pointer argument");
+  FC_REQUIRE(cap >= 0, "cap must be >= 0");
+  FC_REQUIRE(ens->bits_valid, "fc_prune_rmsd_begin has not been called on this ensemble");
+  FC_TRY(ensure_init());
+  return launch_export_pairs(ens->simq.as<uint64_t>(),
+                             reinterpret_cast<const unsigned long long *>(ens->counters.p),
+                             (unsigned long long)ens->pairq_cap, cap, dev_out);
+}
+
+int fc_prune_from_gathered_dev(fc_ensemble *ens, const uint64_t *dev_gathered, int64_t world, int64_t cap,
+                               int64_t min_per_group, uint8_t *mask_out, int64_t *stats) {
+  FC_REQUIRE(ens && dev_gathered && mask_out, "NULL pointer argument");
+  FC_REQUIRE(world >= 1 && world <= 64 && cap >= 0 && min_per_group >= 1, "bad arguments");
+  FC_TRY(ensure_init());
+  const int64_t N = ens->N, W = ens->W;
+  if (N == 0) return FC_OK;
+  if ((uint64_t)world * (uint64_t)cap > kPairLadderCap || (size_t)2 * W * sizeof(uint64_t) > 60 * 1024)
+    return set_error(FC_E_LIMIT, "exchange too large for the one-launch ladder (world*cap = %lld, N = %lld)",
+                     (long long)(world * cap), (long long)N);
+  FC_TRY(ens->counters.reserve(16 * sizeof(uint64_t)));
+  FC_TRY(ens->gathered.reserve((size_t)std::max<int64_t>(world * cap, 1) * sizeof(uint64_t)));
+  auto *cnt = reinterpret_cast<unsigned long long *>(ens->counters.p);
+  unsigned long long local[8];
+  FC_TRY(pinned_reserve((size_t)(W + 32) * sizeof(uint64_t)));
+  // this rank's own counters (candidates, similar, grey) before counters[2] becomes the global length
+  unsigned long long *local_host = static_cast<unsigned long long *>(ctx().pinned) + W + 16;
+  FC_TRY(d2h(local_host, cnt, 8 * sizeof(uint64_t)));
+  FC_TRY(launch_compact_gathered(dev_gathered, (int)world, cap, ens->gathered.as<uint64_t>(), cnt));
+  int64_t survivors = 0;
+  const int rc = ladder_single(ens, nullptr, min_per_group, mask_out, nullptr, &survivors, nullptr,
+                               ens->gathered.as<uint64_t>(), true);
+  if (rc != FC_OK) return rc;  // FC_E_LIMIT: some rank's list was missing or longer than cap
+  for (int k = 0; k < 8; ++k) local[k] = local_host[k];
+  if (stats) {
+    stats[0] = 0;
+    const int64_t nb = ceil_div(N, ens->row_block);
+    for (int64_t lb = 0, b; (b = global_block(lb, ens->rank, ens->world)) < nb; ++lb)
+      for (int64_t i = b * ens->row_block; i < std::min(N, (b + 1) * ens->row_block); ++i)
+        stats[0] += N - 1 - i;
+    stats[1] = (int64_t)local[1];
+    stats[2] = (int64_t)local[2];
+    stats[3] = (int64_t)local[3];
+    stats[4] = last_screen_ns();
+    stats[5] = survivors;
+  }
+  return FC_OK;
 }
 
 // ---- a6 ------------------------------------------------------------------------

@@ -44,7 +44,8 @@ int set_error(int code, const char *fmt, ...);
 struct Context {
   bool ready = false;
   int device = -1;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // the stream every launch and copy goes to
+  hipStream_t own_stream = nullptr;  // the library's own; `stream` differs after fc_stream_set
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   int n_cu = 0;
   size_t hbm = 0;
@@ -137,6 +138,7 @@ struct fc_ensemble {
   int64_t pairq_cap = 0;
   fc::DevBuf simq;             // pairq_cap x uint64: exactly-similar pairs found by the refine
   fc::DevBuf bits_full;        // N x W uint64: whole bit matrix rebuilt from gathered pairs
+  fc::DevBuf gathered;         // world x cap uint64: all ranks' similar pairs, compacted (device exchange)
   fc::DevBuf energies;         // N doubles (optional)
   fc::DevBuf maskA, maskB;     // N bytes each
   fc::DevBuf mbits;            // W uint64 active-flag words

@@ -257,6 +257,61 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Device-resident exchange of the sharded prune (fc_prune_export_pairs_dev /
+// fc_prune_from_gathered_dev): a rank's message is cap+1 words -- its count
+// (kPairsNone when its candidate queue overflowed), its exactly-similar pairs,
+// padding -- written straight into the caller's collective buffer; the
+// gathered world*(cap+1) words are compacted into one list whose length goes
+// to counters[2].  A message that is missing or longer than cap makes the
+// length ~0, so the ladder kernel behind declines (counters[9] = 0) and the
+// caller takes the host path.
+// ---------------------------------------------------------------------------
+constexpr unsigned long long kPairsNone = 0xFFFFFFFFFFFFFFFEull;
+constexpr unsigned long long kPairsPad = 0xFFFFFFFFFFFFFFFFull;
+
+__global__ void __launch_bounds__(256)
+k_export_pairs(const uint64_t *__restrict__ simq, const unsigned long long *__restrict__ counters,
+               unsigned long long cand_cap, int64_t cap, uint64_t *__restrict__ out) {
+  const unsigned long long n = counters[2];
+  const bool overflow = counters[6] > cand_cap;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) out[0] = overflow ? kPairsNone : n;
+  for (int64_t p = t; p < cap; p += stride)
+    out[1 + p] = (!overflow && (unsigned long long)p < n) ? simq[p] : kPairsPad;
+}
+
+__global__ void __launch_bounds__(1024)
+k_compact_gathered(const uint64_t *__restrict__ gathered, int world, int64_t cap,
+                   uint64_t *__restrict__ list, unsigned long long *__restrict__ counters) {
+  __shared__ unsigned long long s_off[65];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    unsigned long long off = 0;
+    int bad = 0;
+    for (int r = 0; r < world; ++r) {
+      const unsigned long long c = gathered[(int64_t)r * (cap + 1)];
+      if (c > (unsigned long long)cap) bad = 1;  // includes kPairsNone
+      s_off[r] = off;
+      off += bad ? 0ull : c;
+    }
+    s_off[world] = off;
+    s_bad = bad;
+    counters[2] = bad ? ~0ull : off;
+    counters[10] = (unsigned long long)bad;
+  }
+  __syncthreads();
+  if (s_bad) return;
+  for (int r = 0; r < world; ++r) {
+    const uint64_t *src = gathered + (int64_t)r * (cap + 1) + 1;
+    const unsigned long long c = s_off[r + 1] - s_off[r];
+    uint64_t *dst = list + s_off[r];
+    for (unsigned long long p = tid; p < c; p += 1024) dst[p] = src[p];
+  }
+}
+
 // copy for rows a rank does not own (sharded levels)
 __global__ void __launch_bounds__(256)
 k_copy_bytes(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t n) {
@@ -614,6 +669,21 @@ int launch_ladder_pairs(const uint64_t *pairs_dev, uint32_t *levelmask_dev,
                      n_pairs_dev, n_cand_dev, cand_cap, cap, N, W, min_per_group, ladder_dev, n_ladder,
                      mask_out_dev, counters_dev);
   return check_launch("k_ladder_pairs");
+}
+
+int launch_export_pairs(const uint64_t *simq_dev, const unsigned long long *counters_dev,
+                        unsigned long long cand_cap, int64_t cap, uint64_t *out_dev) {
+  const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(cap, 256), 64));
+  hipLaunchKernelGGL(k_export_pairs, dim3(blocks), dim3(256), 0, ctx().stream, simq_dev, counters_dev,
+                     cand_cap, cap, out_dev);
+  return check_launch("k_export_pairs");
+}
+
+int launch_compact_gathered(const uint64_t *gathered_dev, int world, int64_t cap, uint64_t *list_dev,
+                            unsigned long long *counters_dev) {
+  hipLaunchKernelGGL(k_compact_gathered, dim3(1), dim3(1024), 0, ctx().stream, gathered_dev, world, cap,
+                     list_dev, counters_dev);
+  return check_launch("k_compact_gathered");
 }
 
 int launch_copy_bytes(const uint8_t *src, uint8_t *dst, int64_t n) {

@@ -95,6 +95,68 @@ def gather_pairs(pairs, allgather_fn, cap=0):
     return np.concatenate([full[r, : counts[r]] for r in range(len(counts))])
 
 
+def exchange_cap(n, world):
+    """Pairs a rank can send in the single fixed-size collective (same on every rank)."""
+    return 1024 + 4 * n // max(world, 1)
+
+
+_streams = {}
+_buffers = {}
+
+
+def prune_by_rmsd_sharded_device(ens, max_rmsd, max_dev=None, rank=0, world=1, group=None, device=None,
+                                 row_block=128, min_per_group=20, gather_fn=None):
+    """The sharded prune with the exchange kept in HBM: screen + refine of the own row
+    blocks, the rank's similar-pair list written by a kernel into the collective's send
+    buffer, ONE ``all_gather_into_tensor`` (RCCL) and the ladder replay are all enqueued
+    on one HIP stream -- RCCL orders itself against it -- and the host waits once, for
+    the mask.  ``gather_fn(send, recv)`` replaces the collective in single-process tests.
+
+    When some rank's list does not fit the fixed message (or its candidate queue
+    overflowed) every rank sees that in the gathered headers and all of them redo the
+    exchange through ``prune_by_rmsd_sharded``'s host path together (rare: it repeats
+    the similarity stage)."""
+    import torch
+    import torch.distributed as tdist
+
+    from firecode_amd import _lib
+
+    if max_dev is None:
+        max_dev = 2 * max_rmsd
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    stream = _streams.get(device)
+    if stream is None:
+        stream = _streams[device] = torch.cuda.Stream(device=device)
+    cap = exchange_cap(ens.N, world)
+    with torch.cuda.stream(stream):
+        _lib.stream_set(stream.cuda_stream)
+        try:
+            key = (device, world, cap)
+            if key not in _buffers:  # the collective's buffers are kept: same size every step
+                _buffers.clear()
+                _buffers[key] = (torch.empty(cap + 1, dtype=torch.int64, device=device),
+                                 torch.empty(world * (cap + 1), dtype=torch.int64, device=device))
+            send, recv = _buffers[key]
+            ens.prune_begin_async(max_rmsd, max_dev, rank, world, row_block=row_block)
+            ens.export_pairs_dev(send.data_ptr(), cap)
+            if gather_fn is not None:
+                gather_fn(send, recv)
+            elif world == 1 and group is None and not tdist.is_initialized():
+                recv.copy_(send)
+            else:
+                tdist.all_gather_into_tensor(recv, send, group=group)
+            try:
+                return ens.prune_from_gathered_dev(recv.data_ptr(), world, cap, min_per_group=min_per_group)
+            except _lib.FirecodeHipInputError as e:
+                if e.code != _lib.FC_E_LIMIT:  # FC_E_LIMIT comes identically on every rank
+                    raise
+        finally:
+            _lib.stream_set(None)
+    allgather = torch_allgather(group=group, device=device) if (world > 1 or tdist.is_initialized()) else None
+    return prune_by_rmsd_sharded(ens, max_rmsd, max_dev, rank=rank, world=world, allgather_fn=allgather,
+                                 row_block=row_block, min_per_group=min_per_group)
+
+
 def prune_by_rmsd_sharded(ens, max_rmsd, max_dev=None, rank=0, world=1, allgather_fn=None,
                           row_block=128, min_per_group=20, trace=None, mode="auto"):
     """``ens``: a ``DeviceEnsemble`` holding the whole ensemble on this rank's
@@ -124,7 +186,7 @@ def prune_by_rmsd_sharded(ens, max_rmsd, max_dev=None, rank=0, world=1, allgathe
     # every rank takes the same branch: the count header doubles as the vote; the
     # capacity (same on every rank) makes the exchange ONE collective unless similarity is
     # much denser than a handful of duplicates per conformer
-    all_pairs = gather_pairs(pairs, allgather_fn, cap=1024 + 4 * ens.N // max(world, 1))
+    all_pairs = gather_pairs(pairs, allgather_fn, cap=exchange_cap(ens.N, world))
     if all_pairs is not None:
         mask = ens.prune_from_pairs(all_pairs, min_per_group=min_per_group)
         return mask, stats

@@ -43,6 +43,11 @@ int fc_device_count(void);
 int fc_init(int device);
 int fc_shutdown(void);
 const char *fc_last_error(void);
+/* Enqueue everything on the caller's HIP stream (a hipStream_t, e.g. the stream a
+ * collective library orders itself against) instead of the library's own non-blocking
+ * stream; NULL switches back.  The previous stream is drained first.  The legacy null
+ * stream cannot be named this way (NULL means "own stream"). */
+int fc_stream_set(void *hip_stream);
 /* name, CU count and bytes of HBM of the active device (diagnostics) */
 int fc_device_info(char *name, int64_t name_len, int64_t *n_cu, int64_t *hbm_bytes);
 
@@ -128,6 +133,23 @@ int fc_prune_level(fc_ensemble *ens, int64_t k, const uint8_t *mask_in, uint8_t 
 int fc_prune_similar_pairs(fc_ensemble *ens, uint64_t *pairs_out, int64_t capacity, int64_t *n_out);
 int fc_prune_from_pairs(fc_ensemble *ens, const uint64_t *pairs, int64_t n_pairs,
                         int64_t min_per_group, uint8_t *mask_out);
+/* The same exchange without leaving the device (multi-GPU path of bench.py):
+ *   fc_prune_rmsd_begin_async   enqueue screen + refine of this rank's row blocks, no sync;
+ *   fc_prune_export_pairs_dev   write this rank's message into a CALLER-OWNED DEVICE buffer of
+ *                               cap+1 words: [count | pairs ... | padding]; count is
+ *                               0xFFFFFFFFFFFFFFFE when the candidate queue overflowed;
+ *   (caller: one all-gather of the cap+1 words -- RCCL on the stream given to fc_stream_set)
+ *   fc_prune_from_gathered_dev  compact the world*(cap+1) gathered words (device pointer), replay
+ *                               the whole ladder, ONE sync, mask to the host.  FC_E_LIMIT when a
+ *                               rank's list was missing or longer than cap: every rank sees the same
+ *                               words, so every rank falls back to the host exchange above together.
+ * stats (6): [0] pairs owned, [1] refined, [2] similar (this rank), [3] grey, [4] screen ns,
+ * [5] survivors. */
+int fc_prune_rmsd_begin_async(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t rank,
+                              int64_t world, int64_t row_block);
+int fc_prune_export_pairs_dev(fc_ensemble *ens, uint64_t *dev_out, int64_t cap);
+int fc_prune_from_gathered_dev(fc_ensemble *ens, const uint64_t *dev_gathered, int64_t world,
+                               int64_t cap, int64_t min_per_group, uint8_t *mask_out, int64_t *stats);
 
 /* ---- a6: prune_by_moment_of_inertia -- prism_pruner.pruner; call sites
  * firecode/ensemble.py:211-216, embedder.py:1452-1454.

@@ -528,6 +528,88 @@ def test_sharded_pairs_exchange_on_one_gpu(fc, world):
         ens.close()
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_device_resident_exchange_logical_ranks(fc, world):
+    """fc_prune_export_pairs_dev / fc_prune_from_gathered_dev: the messages of `world`
+    logical ranks are written by kernels into one torch buffer (standing in for the
+    all-gather's output), the ladder is replayed from it -- all on a torch stream"""
+    import torch
+
+    from firecode_amd import _lib
+    from firecode_amd import dist as fdist
+
+    X, atoms, asg = syn.synthetic_ensemble(1100, 24, seed=180 + world)
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    cap = fdist.exchange_cap(len(X), world)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with fc.DeviceEnsemble(X, center=True) as ens, torch.cuda.stream(stream):
+        _lib.stream_set(stream.cuda_stream)
+        try:
+            recv = torch.zeros(world * (cap + 1), dtype=torch.int64, device=dev)
+            for r in range(world):
+                ens.prune_begin_async(0.5, 1.0, r, world, row_block=128)
+                ens.export_pairs_dev(recv.data_ptr() + 8 * r * (cap + 1), cap)
+            mask, stats = ens.prune_from_gathered_dev(recv.data_ptr(), world, cap)
+            host = recv.cpu().numpy().view(np.uint64).reshape(world, cap + 1)
+        finally:
+            _lib.stream_set(None)
+    assert np.array_equal(mask, ref)
+    assert int(host[:, 0].sum()) == int(np.triu(S0, 1).sum())
+    for r in range(world):  # message layout: count, pairs, padding
+        c = int(host[r, 0])
+        assert (host[r, 1 + c:] == fdist.PAD).all() and (host[r, 1: 1 + c] != fdist.PAD).all()
+    assert stats[5] == ref.sum() and stats[4] > 0
+
+
+def test_device_resident_exchange_driver_and_fallback(fc, monkeypatch):
+    """prune_by_rmsd_sharded_device on one rank (copy instead of the collective); then with a
+    4-entry candidate queue: the message header says "no list", the device ladder declines
+    (FC_E_LIMIT) and the driver repeats the exchange on the host path -- same mask"""
+    from firecode_amd import dist as fdist
+
+    X, atoms, asg = syn.synthetic_ensemble(700, 20, seed=191)
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        mask, stats = fdist.prune_by_rmsd_sharded_device(ens, 0.5)
+        assert np.array_equal(mask, ref) and stats[2] == np.triu(S0, 1).sum()
+    monkeypatch.setenv("FC_PAIRQ_CAP", "4")
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        mask, stats = fdist.prune_by_rmsd_sharded_device(ens, 0.5)
+        assert np.array_equal(mask, ref)
+    # a message longer than the fixed capacity takes the same way out
+    monkeypatch.delenv("FC_PAIRQ_CAP")
+    monkeypatch.setattr(fdist, "exchange_cap", lambda n, world: 16)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        mask, stats = fdist.prune_by_rmsd_sharded_device(ens, 0.5)
+        assert np.array_equal(mask, ref)
+
+
+def test_device_resident_exchange_over_rccl_single_rank(fc):
+    """the real collective (torch.distributed nccl = RCCL) on a 1-rank group: stream ordering
+    between the library's kernels and RCCL's stream, no host synchronisation in between"""
+    import torch
+    import torch.distributed as tdist
+
+    from firecode_amd import dist as fdist
+
+    X, atoms, asg = syn.synthetic_ensemble(1500, 30, seed=195)
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    torch.cuda.set_device(0)
+    tdist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1,
+                             device_id=torch.device("cuda", 0))
+    try:
+        with fc.DeviceEnsemble(X, center=True) as ens:
+            for _ in range(3):
+                mask, stats = fdist.prune_by_rmsd_sharded_device(ens, 0.5, rank=0, world=1)
+                assert np.array_equal(mask, ref)
+    finally:
+        tdist.destroy_process_group()
+
+
 # ---------------------------------------------------------------- screen-kernel variants / odd shapes
 @pytest.mark.parametrize("n,a", [(2, 1), (3, 2), (70, 3), (130, 5), (200, 80), (150, 104), (140, 110), (90, 130)])
 def test_prune_odd_shapes_and_all_screen_variants(fc, n, a):
