@@ -470,6 +470,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
   if (i0 >= N) return;
   if (j0 + TC - 1 <= i0) return;
 
+  double *__restrict__ ldsG = lds + KS * 12 * TC;  // [TC column sums | IB row sums]
   {  // stage the column tile: 16-byte loads, UNR of them in flight per lane
     typedef double d2_t __attribute__((ext_vector_type(2)));
     const int total2 = KS * 4 * 3 * (TC / 2);  // pairs of adjacent columns
@@ -498,11 +499,35 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
         }
       }
     }
+    // sums of squares of the tile's columns and of the block's rows: the epilogue reads them
+    // from LDS (lgkmcnt) so that it never waits on vmcnt behind the row-operand prefetch
+    for (int idx = tid; idx < TC + IB; idx += NW * 64) {
+      const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
+      ldsG[idx] = g < Npad ? G[g] : 0.0;
+    }
     __syncthreads();
   }
   const int kq = lane >> 4, l15 = lane & 15;
   const int boff = (kq >> 1) * (2 * TC) + (kq & 1) * 16 + l15;
   uint16_t *bits16 = reinterpret_cast<uint16_t *>(bits);
+
+  // Row operands of the first three k-steps of the NEXT unit (same rows for the second
+  // half, the wave's next 16-row tile after it) are requested right after the last MFMA
+  // of a unit has issued, so their L2 latency passes under the polynomial epilogue
+  // instead of in front of the next K loop.  pre_it = row tile those registers hold.
+  double a0[3], a1[3], a2[3];
+  int pre_it = -1;
+  auto row_offsets = [&](int it_, unsigned (&vo)[3]) {
+    const int64_t ib_ = i0 + (int64_t)it_ * 16;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vo[c] = (unsigned)((int64_t)(kq * 3 + c) * Npad + ib_ + l15);
+  };
+  auto fetch_a_at = [&](double (&a)[3], const unsigned (&vo)[3], int sx) {
+    const int sl = sx < KS ? sx : KS - 1;  // fewer than 3 k-steps: harmless re-read
+    const double *__restrict__ xs_s = Xs + (int64_t)sl * 12 * Npad;  // wave-uniform base
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[c] = xs_s[vo[c]];
+  };
 
   for (int it = wv; it * 16 < IB; it += NW) {
     const int64_t ib = i0 + (int64_t)it * 16;
@@ -513,8 +538,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
     // per-lane element offsets of the lane's row operand inside one k-step
     // (fits 32 bits: checked by the launcher)
     unsigned voff[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) voff[c] = (unsigned)((int64_t)(kq * 3 + c) * Npad + ib + l15);
+    row_offsets(it, voff);
 
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
@@ -544,13 +568,10 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
       // after its 18 MFMAs have issued, two full k-steps ahead of its use --
       // column operands (LDS) in two sets, one k-step ahead.
       const double *__restrict__ lb0 = lds + cs0 * 32 + boff;
-      double a0[3], a1[3], a2[3], b0[2][3], b1[2][3];
+      double b0[2][3], b1[2][3];
       const int KSe = KS;
       auto fetch_a = [&](double (&a)[3], int sx) {
-        const int sl = sx < KS ? sx : KS - 1;  // past the end: harmless re-read
-        const double *__restrict__ xs_s = Xs + (int64_t)sl * 12 * Npad;  // wave-uniform base
-#pragma unroll
-        for (int c = 0; c < 3; ++c) a[c] = xs_s[voff[c]];
+        fetch_a_at(a, voff, sx);  // past the end: harmless re-read, replaced by the prefetch below
       };
       auto fetch_b = [&](double (&b)[2][3], int sx) {
         const int sl = sx < KS ? sx : KS - 1;
@@ -570,9 +591,11 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
               acc[t][x * 3 + y] =
                   __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[t][y], acc[t][x * 3 + y], 0, 0, 0);
       };
-      fetch_a(a0, 0);
-      fetch_a(a1, 1);
-      fetch_a(a2, 2);
+      if (pre_it != it) {  // first unit of the wave, or the prediction below missed
+        fetch_a_at(a0, voff, 0);
+        fetch_a_at(a1, voff, 1);
+        fetch_a_at(a2, voff, 2);
+      }
       fetch_b(b0, 0);
       fetch_b(b1, 1);
 #define FC_KSTEP(AX, BX, U)             \
@@ -590,17 +613,32 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
         FC_KSTEP(a2, b1, 5)
       }
 #undef FC_KSTEP
+      {  // request the next unit's first three k-steps now; they land during the epilogue
+        const int nit = half == 0 ? it : it + NW;
+        const bool more = half == 0 || ((nit * 16 < IB) && (i0 + (int64_t)nit * 16 < N) &&
+                                        !(j0 + TC - 1 <= i0 + (int64_t)nit * 16));
+        if (more) {
+          unsigned vn[3];
+          row_offsets(nit, vn);
+          fetch_a_at(a0, vn, 0);
+          fetch_a_at(a1, vn, 1);
+          fetch_a_at(a2, vn, 2);
+          pre_it = nit;
+        } else {
+          pre_it = -1;
+        }
+      }
       // epilogue: lane owns pairs (ib + kq + 4r, j0 + cs*16 + l15), r = 0..3
       const int n32 = (int)N, ib32 = (int)ib;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int cs = cs0 + t;
         const int j = (int)j0 + cs * 16 + l15;
-        const double Gq = G[j];
+        const double Gq = ldsG[cs * 16 + l15];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = ib32 + kq + 4 * r;
-          const double Gp = G[i];
+          const double Gp = ldsG[TC + it * 16 + kq + 4 * r];
           double B9[9];
 #pragma unroll
           for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
@@ -854,9 +892,9 @@ k_scatter_pairs(const uint64_t *__restrict__ pairs, int64_t n_pairs, int64_t N, 
 // all-pairs RMSD values on the matrix pipe (world == 1 layout); rmsd_dev: (N, N), pre-zeroed
 int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev) {
   const int64_t NT = e->Npad >> 6;
-  const int64_t rb = 256;
+  const int64_t rb = 128;
   const int64_t n_lblocks = ceil_div(e->N, rb);
-  const size_t lds_m = (size_t)((e->A + 3) / 4) * 4 * 3 * 64 * sizeof(double);
+  const size_t lds_m = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)rb) * sizeof(double);
   if (lds_m > kLdsLimit || NT == 0)
     return set_error(FC_E_LIMIT, "A=%lld atoms exceed the LDS column tile of the value kernel", (long long)e->A);
   const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32);
@@ -939,7 +977,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   const bool want_valu = cfg && std::strncmp(cfg, "valu", 4) == 0;
   const bool alt = cfg && std::strcmp(cfg, "valu4x8") == 0;
   {
-    const size_t lds_m = (size_t)((e->A + 3) / 4) * 4 * 3 * 64 * sizeof(double);
+    const size_t lds_m = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)e->row_block) * sizeof(double);
     const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32);
     const bool two_blocks_fit = 2 * lds_m <= kLdsLimit;
     if (!want_valu && fits32 && lds_m <= kLdsLimit && e->row_block % (two_blocks_fit ? 64 : 128) == 0) {
