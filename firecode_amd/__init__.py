@@ -20,7 +20,8 @@ from firecode_amd._lib import (  # noqa: F401
     shutdown,
 )
 from firecode_amd import (  # noqa: F401,E402
-    algebra, embeds, ensemble, host_helpers, operators, pruner, pt, refining, rmsd, torsion_module, utils,
+    algebra, embeds, ensemble, host_helpers, hypermolecule_class, operators, pruner, pt, refining, rmsd,
+    torsion_module, utils,
 )
 
 __version__ = "0.1.0"

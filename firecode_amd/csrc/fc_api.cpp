@@ -28,6 +28,9 @@ int launch_ladder_pairs(const uint64_t *, uint32_t *, const unsigned long long *
                         unsigned long long, unsigned long long, int64_t, int64_t, int64_t, const int64_t *,
                         int, uint64_t *, unsigned long long *);
 int launch_scatter_pairs(const uint64_t *, int64_t, int64_t, int64_t, uint64_t *);
+int launch_center_structures(const double *, int64_t, int64_t, double *);
+int launch_moi_diag_pairs(const double *, int64_t, double *, double *);
+int launch_set_identity(double *);
 int launch_export_pairs(const uint64_t *, const unsigned long long *, unsigned long long, int64_t, uint64_t *);
 int launch_compact_gathered(const uint64_t *, int, int64_t, uint64_t *, unsigned long long *);
 int launch_level_fused(const uint64_t *, int64_t, const uint64_t *, uint64_t *, int64_t, int64_t,
@@ -517,6 +520,33 @@ int fc_alignment_matrices(const double *p, const double *q, int64_t n_pairs, int
   FC_TRY(dM.reserve((size_t)n_pairs * 9 * sizeof(double)));
   FC_TRY(launch_alignment_matrices(dp.as<double>(), dq.as<double>(), n_pairs, A, dM.as<double>()));
   FC_TRY(d2h(M_out, dM.p, (size_t)n_pairs * 9 * sizeof(double)));
+  return sync();
+}
+
+// ---- a9: align_by_moi (firecode/hypermolecule_class.py:45-86) ------------------------------
+int fc_align_by_moi(const double *coords, int64_t N, int64_t A, const double *masses, double *out) {
+  FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(coords && masses && out, "NULL pointer argument");
+  FC_TRY(ensure_init());
+  DevBuf dc, dm, dcen, dmom, dP, dQ, dM, dt, dout;
+  FC_TRY(upload(dc, coords, (size_t)N * A * 3));
+  FC_TRY(upload(dm, masses, (size_t)A));
+  FC_TRY(dcen.reserve((size_t)N * A * 3 * sizeof(double)));
+  FC_TRY(dmom.reserve((size_t)N * 3 * sizeof(double)));
+  FC_TRY(dP.reserve((size_t)N * 9 * sizeof(double)));
+  FC_TRY(dQ.reserve((size_t)N * 9 * sizeof(double)));
+  FC_TRY(dM.reserve((size_t)N * 9 * sizeof(double)));
+  FC_TRY(dt.reserve((size_t)N * 3 * sizeof(double)));
+  FC_TRY(dout.reserve((size_t)N * A * 3 * sizeof(double)));
+  FC_TRY(launch_center_structures(dc.as<double>(), N, A, dcen.as<double>()));
+  FC_TRY(launch_inertia_moments(dcen.as<double>(), N, A, dm.as<double>(), dmom.as<double>()));
+  FC_TRY(launch_moi_diag_pairs(dmom.as<double>(), N, dP.as<double>(), dQ.as<double>()));
+  FC_TRY(launch_alignment_matrices(dP.as<double>(), dQ.as<double>(), N, 3, dM.as<double>()));
+  FC_TRY(launch_set_identity(dM.as<double>()));
+  FC_HIP_TRY(hipMemsetAsync(dt.p, 0, (size_t)N * 3 * sizeof(double), ctx().stream));
+  FC_TRY(launch_rototranslate(dcen.as<double>(), N, A, dM.as<double>(), dt.as<double>(), dout.as<double>()));
+  FC_TRY(d2h(out, dout.p, (size_t)N * A * 3 * sizeof(double)));
   return sync();
 }
 

@@ -189,6 +189,41 @@ k_rototranslate(const double *__restrict__ coords, int64_t n, int64_t A,
   out[g * 3 + 2] = ((r[6] * x + r[7] * y) + r[8] * z) + tt[2];
 }
 
+// align_by_moi helpers (hypermolecule_class.py:45-86): centre every structure on its plain
+// mean (rows added in order, like np.mean(axis=0)); build the "moment vector" arrays
+// diag(I_ref), diag(I_n) the reference feeds to get_alignment_matrix.
+__global__ void __launch_bounds__(256)
+k_center_structures(const double *__restrict__ coords, int64_t N, int64_t A, double *__restrict__ out) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (structure, component)
+  if (g >= N * 3) return;
+  const int64_t n = g / 3;
+  const int c = (int)(g - n * 3);
+  const double *x = coords + n * A * 3 + c;
+  double s = 0.0;
+  for (int64_t a = 0; a < A; ++a) s += x[a * 3];
+  const double m = s / (double)A;
+  double *o = out + n * A * 3 + c;
+  for (int64_t a = 0; a < A; ++a) o[a * 3] = x[a * 3] - m;
+}
+
+__global__ void __launch_bounds__(256)
+k_moi_diag_pairs(const double *__restrict__ moments, int64_t N, double *__restrict__ P,
+                 double *__restrict__ Q) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const bool d = (e == 0 || e == 4 || e == 8);
+    P[n * 9 + e] = d ? moments[e / 4] : 0.0;
+    Q[n * 9 + e] = d ? moments[n * 3 + e / 4] : 0.0;
+  }
+}
+
+// the first structure is copied, not rotated (hypermolecule_class.py:60-61)
+__global__ void k_set_identity(double *__restrict__ M) {
+  if (threadIdx.x < 9) M[threadIdx.x] = (threadIdx.x % 4 == 0) ? 1.0 : 0.0;
+}
+
 // ---------------------------------------------------------------------------
 // Rigid-embed poses: transform + clash count fused, pose never written unless
 // asked for.  One wavefront per pose (4 per workgroup): molecule 1 of the pose
@@ -313,6 +348,25 @@ int launch_rototranslate(const double *coords_dev, int64_t n, int64_t A, const d
   hipLaunchKernelGGL(k_rototranslate, dim3((unsigned)ceil_div(n * A, 256)), dim3(256), 0,
                      ctx().stream, coords_dev, n, A, R_dev, t_dev, out_dev);
   return check_launch("k_rototranslate");
+}
+
+int launch_center_structures(const double *coords_dev, int64_t N, int64_t A, double *out_dev) {
+  if (N == 0) return FC_OK;
+  hipLaunchKernelGGL(k_center_structures, dim3((unsigned)ceil_div(N * 3, 256)), dim3(256), 0, ctx().stream,
+                     coords_dev, N, A, out_dev);
+  return check_launch("k_center_structures");
+}
+
+int launch_moi_diag_pairs(const double *moments_dev, int64_t N, double *P_dev, double *Q_dev) {
+  if (N == 0) return FC_OK;
+  hipLaunchKernelGGL(k_moi_diag_pairs, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx().stream,
+                     moments_dev, N, P_dev, Q_dev);
+  return check_launch("k_moi_diag_pairs");
+}
+
+int launch_set_identity(double *M_dev) {
+  hipLaunchKernelGGL(k_set_identity, dim3(1), dim3(64), 0, ctx().stream, M_dev);
+  return check_launch("k_set_identity");
 }
 
 int launch_embed_poses_clash(const double *m1_dev, int64_t A1, const double *m2_dev, int64_t A2,

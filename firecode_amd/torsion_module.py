@@ -129,3 +129,51 @@ def clustered_csearch(coords, torsions, rotation_masks, n_out=100, thresh=1.5, s
     if len(new_structures) > n_out:
         output = most_diverse_conformers(n_out, output, seed=seed)
     return np.array(output)
+
+
+N_FOLD_ANGLES = {2: (0, 180), 3: (0, 120, 240), 4: (0, 90, 180, 270), 6: (0, 60, 120, 180, 240, 300)}
+
+
+def random_csearch(coords, torsions, rotation_masks, n_out=100, max_tries=10000, rotations=None, thresh=1.5,
+                   seed=None, order=None, return_indices=False):
+    """Numeric core of ``random_csearch`` (torsion_module.py:436-571): the n-fold angle grid
+    in ``cartesian_product`` order, optionally only the sets with exactly ``rotations``
+    non-zero angles, SHUFFLED, then the same per-set dihedral scan as the clustered search;
+    the first ``n_out`` sets that rotated at least one bond are returned, in shuffled order.
+
+    The reference shuffles with the global unseeded NumPy RNG; here ``order`` (a permutation
+    of the filtered grid) or ``seed`` (``RandomState(seed).shuffle``) fixes it -- with the same
+    permutation the output is the reference's.  The stop rule is the reference's, quirk
+    included: the loop ends only ON a kept set, when ``n_out`` are collected or that set's
+    index equals ``max_tries``.  The grid is scanned on the GPU in chunks of shuffled sets
+    until the stop rule fires."""
+    from firecode_amd.utils import cartesian_product
+
+    quads = np.array([t[:4] for t in torsions], dtype=np.int64)
+    angles = cartesian_product(*[N_FOLD_ANGLES[int(t[4])] for t in torsions])
+    if rotations is not None:
+        angles = angles[np.count_nonzero(angles, axis=1) == rotations]
+    if order is not None:
+        angles = angles[np.asarray(order, dtype=np.int64)]
+    else:
+        rng = np.random if seed is None else np.random.RandomState(seed)
+        rng.shuffle(angles)
+    base = L.f64(coords)
+    kept, kept_idx = [], []
+    chunk = max(4 * int(n_out), 4096)
+    done = False
+    for lo in range(0, len(angles), chunk):
+        out, rot = torsion_scan(base, quads, rotation_masks, angles[lo: lo + chunk], thresh=thresh)
+        for s in np.nonzero(rot != 0)[0]:
+            a = lo + int(s)
+            kept.append(out[s])
+            kept_idx.append(a)
+            if len(kept) == n_out or a == max_tries:
+                done = True
+                break
+        if done:
+            break
+    structures = np.array(kept) if kept else np.empty((0,) + base.shape)
+    if return_indices:
+        return structures, np.array(kept_idx, dtype=np.int64)
+    return structures

@@ -151,6 +151,11 @@ int fc_prune_export_pairs_dev(fc_ensemble *ens, uint64_t *dev_out, int64_t cap);
 int fc_prune_from_gathered_dev(fc_ensemble *ens, const uint64_t *dev_gathered, int64_t world,
                                int64_t cap, int64_t min_per_group, uint8_t *mask_out, int64_t *stats);
 
+/* ---- a9: align_by_moi(atoms, structures) -- firecode/hypermolecule_class.py:45-86.
+ * Every structure centred on its plain mean; M = get_alignment_matrix(diag(I_ref), diag(I_n))
+ * applied as (M @ X.T).T; structure 0 is copied unrotated.  masses (A,), out (N, A, 3). */
+int fc_align_by_moi(const double *coords, int64_t N, int64_t A, const double *masses, double *out);
+
 /* ---- a6: prune_by_moment_of_inertia -- prism_pruner.pruner; call sites
  * firecode/ensemble.py:211-216, embedder.py:1452-1454.
  * fc_inertia_moments: get_inertia_moments(coords, masses) for N conformers,

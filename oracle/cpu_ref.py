@@ -327,6 +327,26 @@ def get_inertia_moments(coords, masses):
     return np.linalg.eigvalsh(I)
 
 
+def align_by_moi(masses, structures):
+    """``align_by_moi`` (hypermolecule_class.py:45-86): every structure is centred on its
+    plain (unweighted) mean; the "moment vectors" are diag(I1, I2, I3) for reference and
+    target; ``get_alignment_matrix`` of those two 3x3 arrays (rows as points) gives the
+    matrix applied as ``(M @ target.T).T``.  (Both arrays are positive diagonal, so the
+    Kabsch rotation is the identity whenever the moments are distinct and non-zero -- the
+    restatement keeps the literal computation.)  Returns the (N, A, 3) output array."""
+    structures = np.array(structures, dtype=np.float64)
+    out = np.zeros(structures.shape)
+    ref = structures[0] - structures[0].mean(axis=0)
+    out[0] = ref
+    ref_v = np.diag(get_inertia_moments(ref, masses))
+    for t in range(1, len(structures)):
+        tgt = structures[t] - structures[t].mean(axis=0)
+        tgt_v = np.diag(get_inertia_moments(tgt, masses))
+        M = get_alignment_matrix(ref_v, tgt_v)
+        out[t] = (M @ tgt.T).T
+    return out
+
+
 def prune_by_moment_of_inertia(structures, atoms, max_deviation=0.01, energies=None, max_dE=0.0):
     """MOI pruning (call sites ensemble.py:211-216, embedder.py:1452-1454):
     same greedy scheme; similar <=> all three ``|I1_k - I2_k| / I1_k <
@@ -592,6 +612,25 @@ def torsion_scan(base, torsions, masks, angles, thresh=1.5, backoff=5):
         out[s] = new_coords
         rot[s] = rotated_bonds
     return out, rot
+
+
+def random_csearch(base, torsions, masks, shuffled_angles, n_out=100, max_tries=10000, thresh=1.5):
+    """Numeric core of ``random_csearch`` (torsion_module.py:499-560) given the angle
+    sets ALREADY in the order ``np.random.shuffle`` left them: same per-set scan as
+    ``torsion_scan``; a set is kept when at least one bond rotated; the loop stops --
+    only on a kept set -- when ``n_out`` are collected or the set's index equals
+    ``max_tries`` (so an unlucky index ``max_tries`` does not stop it: reference quirk,
+    :556-558).  Returns (structures (K, A, 3), indices (K,) into shuffled_angles)."""
+    keep, idx = [], []
+    for a, angle_set in enumerate(np.asarray(shuffled_angles)):
+        out, rot = torsion_scan(base, torsions, masks, angle_set[None], thresh=thresh)
+        if rot[0] != 0:
+            keep.append(out[0])
+            idx.append(a)
+            if len(keep) == n_out or a == max_tries:
+                break
+    base = np.asarray(base, dtype=np.float64)
+    return (np.array(keep) if keep else np.empty((0,) + base.shape)), np.array(idx, dtype=np.int64)
 
 
 def dihedral(p):

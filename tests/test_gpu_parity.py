@@ -300,6 +300,44 @@ def test_torsion_scan_vs_oracle(fc):
     assert (rot0 < (angles != 0).sum(axis=1)).any()  # some back-off / failed rotations happened
 
 
+def test_random_csearch_vs_oracle(fc):
+    """random_csearch (torsion_module.py:436-571) with the shuffle fixed: same kept sets, same
+    coordinates, including the max_tries quirk (the stop is only evaluated on a kept set)"""
+    base, tors, masks = _chain_case(28, 4, seed=41)
+    tors5 = [tuple(t) + (n,) for t, n in zip(tors, (6, 3, 6, 2))]
+    grid = o.cartesian_product((0, 60, 120, 180, 240, 300), (0, 120, 240), (0, 60, 120, 180, 240, 300), (0, 180))
+    order = np.random.RandomState(5).permutation(len(grid))
+    for n_out, max_tries, rotations in ((25, 10000, None), (1000, 37, None), (12, 10000, 2)):
+        g = grid if rotations is None else grid[np.count_nonzero(grid, axis=1) == rotations]
+        od = order[order < len(g)] if rotations is not None else order
+        ref, ref_idx = o.random_csearch(base, tors, masks, g[od], n_out=n_out, max_tries=max_tries)
+        out, idx = fc.torsion_module.random_csearch(base, tors5, masks, n_out=n_out, max_tries=max_tries,
+                                                    rotations=rotations, order=od, return_indices=True)
+        assert np.array_equal(idx, ref_idx) and len(idx) > 0
+        assert np.abs(out - ref).max() < TOL
+    # seeded shuffle = RandomState(seed).shuffle of the grid
+    out = fc.torsion_module.random_csearch(base, tors5, masks, n_out=10, seed=3)
+    g = grid.copy()
+    np.random.RandomState(3).shuffle(g)
+    ref, _ = o.random_csearch(base, tors, masks, g, n_out=10)
+    assert np.abs(out - ref).max() < TOL
+
+
+def test_align_by_moi_vs_oracle(fc):
+    """align_by_moi (hypermolecule_class.py:45-86): centring in place + the literal
+    get_alignment_matrix of the two diagonal moment arrays"""
+    rng = np.random.default_rng(43)
+    X = rng.normal(scale=2.5, size=(9, 21, 3)) + rng.normal(scale=4.0, size=(9, 1, 3))
+    atoms = np.array(list("CHONCHHCCOHHNCCHHHOCH"))
+    masses = np.array([fc.pt.pt.mass(a) for a in atoms])
+    ref = o.align_by_moi(masses, X.copy())
+    mine = X.copy()
+    out = fc.hypermolecule_class.align_by_moi(atoms, mine)
+    assert np.abs(out - ref).max() < TOL
+    assert np.abs(mine.mean(axis=1)).max() < 1e-12  # centred in place like the reference
+    assert np.abs(out[0] - (X[0] - X[0].mean(axis=0))).max() < 1e-12
+
+
 def test_rotate_dihedral_and_comp_check(fc, golden):
     base, tors, masks = _chain_case(20, 2, seed=32)
     new = fc.utils.rotate_dihedral(base, tors[0], 120, mask=masks[0])

@@ -135,3 +135,28 @@ def test_align_structures_superposes_on_first():
     out = o.align_structures(X)
     for t in range(1, 10):
         assert np.sqrt(((out[t] - out[0]) ** 2).sum() / 9) < 0.15
+
+
+def test_random_csearch_stop_rule_and_align_by_moi_identity():
+    """random_csearch (torsion_module.py:556-558): the stop is evaluated only on a kept set;
+    align_by_moi (hypermolecule_class.py:45-86): two positive diagonal arrays -> identity"""
+    rng = np.random.default_rng(7)
+    base = np.cumsum(rng.normal(scale=1.0, size=(12, 3)) + [1.5, 0, 0], axis=0)
+    tors = np.array([[2, 3, 4, 5], [6, 7, 8, 9]])
+    masks = np.zeros((2, 12), dtype=bool)
+    masks[0, 5:] = True
+    masks[1, 9:] = True
+    grid = o.cartesian_product((0, 120, 240), (0, 120, 240))
+    order = np.array([0, 3, 1, 0, 4, 8, 2, 5])  # index 0 = all-zero set: never kept
+    S, idx = o.random_csearch(base, tors, masks, grid[order], n_out=100, max_tries=3)
+    full, rot = o.torsion_scan(base, tors, masks, grid[order])
+    kept_all = np.nonzero(rot)[0]
+    assert 3 not in kept_all and len(idx) == len(kept_all)  # index 3 is not kept -> no stop at max_tries
+    S2, idx2 = o.random_csearch(base, tors, masks, grid[order], n_out=100, max_tries=int(kept_all[1]))
+    assert list(idx2) == list(kept_all[:2])
+    S3, idx3 = o.random_csearch(base, tors, masks, grid[order], n_out=3)
+    assert list(idx3) == list(kept_all[:3]) and np.array_equal(S3, full[kept_all[:3]])
+
+    X = rng.normal(scale=2.0, size=(5, 12, 3)) + 3.0
+    out = o.align_by_moi(rng.uniform(1, 16, size=12), X)
+    assert np.abs(out - (X - X.mean(axis=1, keepdims=True))).max() < 1e-13
