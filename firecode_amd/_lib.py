@@ -83,6 +83,9 @@ _SIGNATURES = {
     "fc_embed_poses_clash": [_p_f64, _i64, _i64, _p_f64, _i64, _i64, _p_i64, _p_i64, _p_f64, _p_f64,
                              _p_f64, _p_f64, _i64, _f64, _i64, _p_i64, _p_u8, _p_f64],
     "fc_embed_mol_transforms": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64, _p_f64, _i64, _p_f64, _i64, _p_f64, _p_f64],
+    "fc_embed_trimolecular": [C.POINTER(_p_f64), _p_i64, _p_i64, C.POINTER(_p_i64), _p_i64, _i64, _p_i64, _p_f64,
+                              _p_f64, _p_f64, _p_f64, _p_u8, _p_i64, _p_f64, _p_f64, _i64, C.POINTER(C.c_int32),
+                              _i64, _f64, _i64, _f64, _p_f64, _p_f64, _p_u8, _p_u8],
     "fc_embed_grid_clash": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64, _p_f64, _p_f64, _i64, _i64, _p_i64, _i64,
                             _p_f64, _p_f64, _p_f64, _i64, _p_f64, _i64, _f64, _i64, _p_u8,
                             C.POINTER(C.c_int32), _p_f64],

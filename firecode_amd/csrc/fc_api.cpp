@@ -31,6 +31,11 @@ int launch_scatter_pairs(const uint64_t *, int64_t, int64_t, int64_t, uint64_t *
 int launch_center_structures(const double *, int64_t, int64_t, double *);
 int launch_moi_diag_pairs(const double *, int64_t, double *, double *);
 int launch_set_identity(double *);
+size_t tri_group_lds_bytes(int64_t, int, int);
+int launch_tri_embed(const double *const[3], const int64_t *const[3], const int64_t[3], const int64_t[3], int64_t,
+                     const int64_t *, const double *, const double *, const double *, const double *,
+                     const uint8_t *, const int64_t *, const double *, const double *, int, const int32_t *, int,
+                     double, int, double, double *, double *, uint8_t *, uint8_t *);
 int launch_export_pairs(const uint64_t *, const unsigned long long *, unsigned long long, int64_t, uint64_t *);
 int launch_compact_gathered(const uint64_t *, int, int64_t, uint64_t *, unsigned long long *);
 int launch_level_fused(const uint64_t *, int64_t, const uint64_t *, uint64_t *, int64_t, int64_t,
@@ -1103,6 +1108,84 @@ int fc_embed_grid_dedupe(const double *m1, int64_t n1, int64_t A1, const int64_t
   FC_REQUIRE(accept_out != nullptr, "accept_out is NULL");
   return embed_grid(m1, n1, A1, reactive1, nr1, ps1, pe1, m2, n2, A2, reactive2, nr2, ps2, pe2, angles1,
                     na1, angles2, na2, thresh, max_clashes, pass_out, nullptr, nullptr, rmsd_thr, accept_out);
+}
+
+// ---- a14, three molecules: cyclical_embed (firecode/embeds.py:409-585) -----------------------
+int fc_embed_trimolecular(const double *const coords[3], const int64_t n_conf[3], const int64_t n_atoms[3],
+                          const int64_t *const reactive[3], const int64_t n_reactive[3], int64_t J,
+                          const int64_t *conf, const double *piv_start, const double *piv_end,
+                          const double *vecs, const double *dirs0, const uint8_t *run, const int64_t *rtab,
+                          const double *norms, const double *ua, int64_t U, const int32_t *aidx, int64_t S,
+                          double thresh, int64_t max_clashes, double rmsd_thr, double *dirs_out,
+                          double *Rt_out, uint8_t *pass_out, uint8_t *accept_out) {
+  FC_REQUIRE(coords && n_conf && n_atoms && reactive && n_reactive, "NULL pointer argument");
+  FC_REQUIRE(J >= 0 && U >= 1 && S >= 1, "bad shape");
+  if (J == 0) return FC_OK;
+  FC_REQUIRE(conf && piv_start && piv_end && vecs && dirs0 && run && rtab && norms && ua && aidx && dirs_out &&
+                 Rt_out && pass_out && accept_out,
+             "NULL pointer argument");
+  FC_REQUIRE(thresh > 0.0 && rmsd_thr > 0.0 && max_clashes >= 0, "thresholds must be positive");
+  int64_t Atot = 0;
+  for (int i = 0; i < 3; ++i) {
+    FC_REQUIRE(coords[i] && reactive[i] && n_conf[i] >= 1 && n_atoms[i] >= 1, "bad molecule %d", i);
+    FC_REQUIRE(n_reactive[i] >= 1 && n_reactive[i] <= 2, "molecule %d: 1 or 2 reactive atoms expected", i);
+    for (int64_t r = 0; r < n_reactive[i]; ++r)
+      FC_REQUIRE(reactive[i][r] >= 0 && reactive[i][r] < n_atoms[i], "reactive index out of range");
+    Atot += n_atoms[i];
+  }
+  // every index a kernel dereferences is checked here
+  for (int64_t j = 0; j < J; ++j)
+    for (int i = 0; i < 3; ++i) {
+      FC_REQUIRE(conf[j * 3 + i] >= 0 && conf[j * 3 + i] < n_conf[i], "conformer index out of range (job %lld)",
+                 (long long)j);
+      for (int v = 0; v < 8; ++v)
+        for (int k = 0; k < 3; ++k) {
+          const int64_t r = rtab[((j * 8 + v) * 3 + i) * 3 + k];
+          FC_REQUIRE(r >= 0 && r < n_atoms[i], "reactive-pair table entry out of range (job %lld)", (long long)j);
+        }
+    }
+  for (int64_t s = 0; s < S * 3; ++s) FC_REQUIRE(aidx[s] >= 0 && aidx[s] < U, "angle index out of range");
+  if (3 * U > 256) return set_error(FC_E_LIMIT, "U=%lld distinct step angles per molecule exceed 85", (long long)U);
+  if (J * 8 * S >= (1ll << 31)) return set_error(FC_E_LIMIT, "too many poses in one call: split the jobs");
+  const size_t lds = tri_group_lds_bytes(Atot, (int)U, (int)S);
+  if (lds > 160 * 1024)
+    return set_error(FC_E_LIMIT, "%zu bytes of LDS per group (atoms %lld x angles %lld, %lld poses) exceed 160 KB",
+                     lds, (long long)Atot, (long long)U, (long long)S);
+  FC_TRY(ensure_init());
+  DevBuf dc[3], dr[3], dconf, dps, dpe, dvecs, dd0, drun, drt, dn, dua, daidx, ddirs, dRt, dpass, dacc;
+  const double *cdev[3];
+  const int64_t *rdev[3];
+  for (int i = 0; i < 3; ++i) {
+    FC_TRY(upload(dc[i], coords[i], (size_t)n_conf[i] * n_atoms[i] * 3));
+    FC_TRY(upload(dr[i], reactive[i], (size_t)n_reactive[i]));
+    cdev[i] = dc[i].as<double>();
+    rdev[i] = dr[i].as<int64_t>();
+  }
+  FC_TRY(upload(dconf, conf, (size_t)J * 3));
+  FC_TRY(upload(dps, piv_start, (size_t)J * 9));
+  FC_TRY(upload(dpe, piv_end, (size_t)J * 9));
+  FC_TRY(upload(dvecs, vecs, (size_t)J * 8 * 18));
+  FC_TRY(upload(dd0, dirs0, (size_t)J * 9));
+  FC_TRY(upload(drun, run, (size_t)J * 8));
+  FC_TRY(upload(drt, rtab, (size_t)J * 8 * 9));
+  FC_TRY(upload(dn, norms, (size_t)J * 3));
+  FC_TRY(upload(dua, ua, (size_t)3 * U));
+  FC_TRY(upload(daidx, aidx, (size_t)S * 3));
+  FC_TRY(ddirs.reserve((size_t)J * 8 * 9 * sizeof(double)));
+  FC_TRY(dRt.reserve((size_t)J * 8 * 3 * U * 12 * sizeof(double)));
+  FC_TRY(dpass.reserve((size_t)J * 8 * S));
+  FC_TRY(dacc.reserve((size_t)J * 8 * S));
+  FC_HIP_TRY(hipMemsetAsync(dRt.p, 0, (size_t)J * 8 * 3 * U * 12 * sizeof(double), ctx().stream));
+  FC_TRY(launch_tri_embed(cdev, rdev, n_atoms, n_reactive, J, dconf.as<int64_t>(), dps.as<double>(),
+                          dpe.as<double>(), dvecs.as<double>(), dd0.as<double>(), drun.as<uint8_t>(),
+                          drt.as<int64_t>(), dn.as<double>(), dua.as<double>(), (int)U, daidx.as<int32_t>(),
+                          (int)S, thresh, (int)max_clashes, rmsd_thr, ddirs.as<double>(), dRt.as<double>(),
+                          dpass.as<uint8_t>(), dacc.as<uint8_t>()));
+  FC_TRY(d2h(dirs_out, ddirs.p, (size_t)J * 8 * 9 * sizeof(double)));
+  FC_TRY(d2h(Rt_out, dRt.p, (size_t)J * 8 * 3 * U * 12 * sizeof(double)));
+  FC_TRY(d2h(pass_out, dpass.p, (size_t)J * 8 * S));
+  FC_TRY(d2h(accept_out, dacc.p, (size_t)J * 8 * S));
+  return sync();
 }
 
 int fc_string_embed(const double *m1, int64_t n1, int64_t A1, const double *centers1,

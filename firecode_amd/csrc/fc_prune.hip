@@ -151,7 +151,6 @@ k_pair_levelmask(const uint64_t *__restrict__ pairs, const unsigned long long *_
                  uint32_t *__restrict__ levelmask) {
   const unsigned long long P = *n_pairs_ptr;
   if (P > cap) return;
-  const uint32_t n32 = (uint32_t)N;
   for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < P;
        p += (unsigned long long)gridDim.x * blockDim.x) {
     const uint64_t e = pairs[p];

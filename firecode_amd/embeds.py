@@ -145,3 +145,121 @@ def string_embed(m1, centers1, orbvecs1, m2, centers2, orbvecs2, angles, quadrup
     moved = rototranslate(X2[ci // n1], R2[sel], t2[sel]) if len(sel) else np.zeros((0, X2.shape[1], 3))
     poses = np.concatenate([X1[ci % n1], moved], axis=1)
     return poses, acc, ok.astype(bool)
+
+
+def _tri_mol(m):
+    get = m.get if isinstance(m, dict) else (lambda k: getattr(m, k))
+    return (L.f64(get("coords")), L.i64(get("reactive_indices")), get("pivots"), dict(get("reactive_cumnums")))
+
+
+def cyclical_embed_trimolecular(mols, systematic_angles, pairings_table=None, internal_constraints=(),
+                                clash_thresh=1.5, max_clashes=0, rmsd_thr=1.0, return_details=False):
+    """``cyclical_embed`` for three molecules (firecode/embeds.py:409-585).
+
+    ``mols``: three objects (or dicts) with ``coords`` (n_conf, A, 3), ``reactive_indices``
+    (two atom indices), ``pivots[conf]`` = list of ``(start_xyz, end_xyz, start_cumnum,
+    end_cumnum)`` (FIRECODE's Pivot: orbital centres and the cumulative numbers of their
+    atoms) and ``reactive_cumnums`` = {atom index: cumnum} (``reactive_atoms_classes_dict[0]``).
+    ``systematic_angles``: (S, 3) step angles in degrees (``embedder.systematic_angles``).
+
+    The host enumerates (conformer triple, pivot triple) jobs in the reference's order and
+    computes their O(1) set-up (norms, ``polygonize``, ``_get_directions``, the pairings
+    filter, the reactive-pair table); ``_adjust_directions``, the S poses of each of the 8
+    orientations, their clash test and the sequential ``rmsd_similarity`` filter run on the
+    GPU (``fc_embed_trimolecular``).  Returns ``(poses (P, A1+A2+A3, 3), constrained_indices
+    (P, 3, 2))`` in the reference's order; with ``return_details`` also a dict with the
+    per-group ``jobs``, ``directions``, ``passed`` and ``accepted`` arrays."""
+    import ctypes as C
+
+    from firecode_amd import host_helpers as hh
+    from firecode_amd.utils import cartesian_product
+
+    if len(mols) != 3:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "three molecules expected")
+    coords, reactive, pivots, cumnums = zip(*[_tri_mol(m) for m in mols])
+    ang = L.f64(systematic_angles).reshape(-1, 3)
+    S = ang.shape[0]
+    cum2atom = {}
+    for m in range(3):
+        for index, cumnum in cumnums[m].items():
+            cum2atom[int(cumnum)] = (m, int(index))
+    wanted = list(pairings_table.values()) if pairings_table else []
+    internal = [tuple(c) for c in np.asarray(internal_constraints).tolist()] if len(internal_constraints) else []
+
+    jobs, conf, ps, pe, vecs, dirs0, run, rtab, norms_all, ids_all = [], [], [], [], [], [], [], [], [], []
+    conf_indices = cartesian_product(*[np.arange(len(c)) for c in coords])
+    for conf_ids in conf_indices:
+        piv_idx = cartesian_product(*[np.arange(len(pivots[i][conf_ids[i]])) for i in range(3)])
+        for pi in piv_idx:
+            piv = [pivots[i][conf_ids[i]][pi[i]] for i in range(3)]
+            start = np.array([np.asarray(p[0], float) for p in piv])
+            end = np.array([np.asarray(p[1], float) for p in piv])
+            norms = np.linalg.norm(start - end, axis=1)
+            if not all(norms[i] < norms[i - 1] + norms[i - 2] for i in (0, 1, 2)):
+                continue  # no triangle with these pivots (embeds.py:455-458)
+            polygon = hh.polygonize(norms)
+            d0 = hh.triangle_directions(norms)  # may nudge norms[0], as the reference does
+            cum_ids = [(int(p[2]), int(p[3])) for p in piv]
+            run_j, rt_j, ids_j = np.zeros(8, np.uint8), np.zeros((8, 3, 3), np.int64), []
+            for v in range(8):
+                ids = hh.cyclical_reactive_indices_tri(cum_ids, v)
+                ids_j.append(ids)
+                ok = (not wanted) or all((tuple(p) in ids) or (tuple(p) in internal) for p in wanted)
+                run_j[v] = ok
+                if ok:  # r[m, k]: reactive atom of molecule m that faces molecule k (:338-352)
+                    for c0, c1 in ids:
+                        (ma, ia), (mb, ib) = cum2atom[c0], cum2atom[c1]
+                        rt_j[v, ma, mb] = ia
+                        rt_j[v, mb, ma] = ib
+            jobs.append((tuple(int(c) for c in conf_ids), tuple(int(p) for p in pi)))
+            conf.append(conf_ids)
+            ps.append(start)
+            pe.append(end)
+            vecs.append(polygon)
+            dirs0.append(d0)
+            run.append(run_j)
+            rtab.append(rt_j)
+            norms_all.append(norms)
+            ids_all.append(ids_j)
+    A = [c.shape[1] for c in coords]
+    n_atoms = sum(A)
+    J = len(jobs)
+    if J == 0:
+        empty = (np.empty((0, n_atoms, 3)), np.empty((0, 3, 2), dtype=np.int64))
+        return empty + ({"jobs": []},) if return_details else empty
+    # distinct step angles per molecule
+    uniq = [np.unique(ang[:, i], return_inverse=True) for i in range(3)]
+    U = max(len(u[0]) for u in uniq)
+    ua = np.zeros((3, U))
+    for i in range(3):
+        ua[i, : len(uniq[i][0])] = uniq[i][0]
+    aidx = np.ascontiguousarray(np.stack([u[1] for u in uniq], axis=1).astype(np.int32))
+    conf_a, ps_a, pe_a = L.i64(np.array(conf)), L.f64(np.array(ps)), L.f64(np.array(pe))
+    vecs_a, d0_a, run_a = L.f64(np.array(vecs)), L.f64(np.array(dirs0)), L.u8(np.array(run))
+    rt_a, nm_a = L.i64(np.array(rtab)), L.f64(np.array(norms_all))
+    dirs_out = np.empty((J, 8, 3, 3))
+    Rt = np.empty((J, 8, 3, U, 12))
+    passed = np.zeros((J, 8, S), dtype=np.uint8)
+    accepted = np.zeros((J, 8, S), dtype=np.uint8)
+    cptr = (C.POINTER(C.c_double) * 3)(*[L.pf(c) for c in coords])
+    rptr = (C.POINTER(C.c_int64) * 3)(*[L.pi(r) for r in reactive])
+    nconf = L.i64([len(c) for c in coords])
+    natm = L.i64(A)
+    nreact = L.i64([len(r) for r in reactive])
+    L.call("fc_embed_trimolecular", cptr, L.pi(nconf), L.pi(natm), rptr, L.pi(nreact), J, L.pi(conf_a),
+           L.pf(ps_a), L.pf(pe_a), L.pf(vecs_a), L.pf(d0_a), L.pb(run_a), L.pi(rt_a), L.pf(nm_a), L.pf(ua), U,
+           aidx.ctypes.data_as(C.POINTER(C.c_int32)), S, float(clash_thresh), int(max_clashes), float(rmsd_thr),
+           L.pf(dirs_out), L.pf(Rt), L.pb(passed), L.pb(accepted))
+    # accepted poses, in loop order: molecule i = R x + t with (R, t) of its step angle
+    jj, vv, ss = np.nonzero(accepted)
+    parts = []
+    for i in range(3):
+        rt = Rt[jj, vv, i, aidx[ss, i]]
+        parts.append(rototranslate(coords[i][conf_a[jj, i]], rt[:, :9].reshape(-1, 3, 3), rt[:, 9:])
+                     if len(jj) else np.empty((0, A[i], 3)))
+    poses = np.concatenate(parts, axis=1)
+    constrained = np.array([ids_all[j][v] for j, v in zip(jj, vv)], dtype=np.int64).reshape(-1, 3, 2)
+    if return_details:
+        return poses, constrained, {"jobs": jobs, "directions": dirs_out, "passed": passed.astype(bool),
+                                    "accepted": accepted.astype(bool), "run": np.array(run).astype(bool)}
+    return poses, constrained

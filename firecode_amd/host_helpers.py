@@ -82,3 +82,50 @@ def cyclical_reactive_indices(cum_ids_1, cum_ids_2, orientation):
     o1 = list(reversed(cum_ids_1)) if swaps[orientation][0] else list(cum_ids_1)
     o2 = list(reversed(cum_ids_2)) if swaps[orientation][1] else list(cum_ids_2)
     return [(o1[0], o2[0]), (o1[1], o2[1])]
+
+
+def _vec_angle(v1, v2):
+    """prism_pruner.algebra.vec_angle: degrees between two vectors."""
+    u1, u2 = np.asarray(v1, float), np.asarray(v2, float)
+    u1, u2 = u1 / np.linalg.norm(u1), u2 / np.linalg.norm(u2)
+    return float(np.degrees(np.arccos(np.clip(np.dot(u1, u2), -1.0, 1.0))))
+
+
+def triangle_directions(norms):
+    """``_get_directions`` of ``cyclical_embed`` for three molecules (embeds.py:187-260):
+    unit vectors, in the plane of the pivot triangle, from the middle of each side towards
+    the circumcentre (sign flipped for the two sides adjacent to an obtuse angle's opposite
+    vertex, as the reference does).  May nudge ``norms[0]`` by 1e-5 in place for a right
+    triangle (:236), like the reference -- the caller's later uses see the nudged value."""
+    n0 = norms[0]
+    a, b, c = n0**2, norms[1] ** 2, norms[2] ** 2
+    x = (a - b + c) / (2 * a**0.5)
+    y = (c - x**2) ** 0.5
+    v0, v1, v2 = np.zeros(2), np.array([n0, 0.0]), np.array([x, y])
+    # circumcentre of (0,0), (n0,0), (x,y)
+    cc = np.array([n0 / 2, (x**2 + y**2 - n0 * x) / (2 * y)])
+    dirs = [cc - np.mean((v0, v1), axis=0), cc - np.mean((v1, v2), axis=0), cc - np.mean((v2, v0), axis=0)]
+    if any(np.all(d == 0) for d in dirs):
+        norms[0] += 1e-5
+        dirs = [t[:-1] for t in triangle_directions(norms)]
+    obtuse0 = _vec_angle(v1 - v0, v2 - v0) > 90
+    obtuse1 = _vec_angle(v0 - v1, v2 - v1) > 90
+    obtuse2 = _vec_angle(v0 - v2, v1 - v2) > 90
+    flips = (obtuse2, obtuse0, obtuse1)
+    out = np.zeros((3, 3))
+    for k in range(3):
+        d = -dirs[k] if flips[k] else dirs[k]
+        d3 = np.array([d[0], d[1], 0.0])
+        out[k] = d3 / np.linalg.norm(d3)
+    return out
+
+
+_TRI_SWAPS = ((0, 0, 0), (0, 0, 1), (0, 1, 0), (0, 1, 1), (1, 0, 0), (1, 1, 0), (1, 0, 1), (1, 1, 1))
+
+
+def cyclical_reactive_indices_tri(cum_ids, orientation):
+    """``_get_cyclical_reactive_indices`` (embeds.py:753-784), trimolecular branch:
+    ``cum_ids`` = three (start, end) cumulative atom numbers -> three sorted couples."""
+    oriented = [tuple(reversed(ids)) if _TRI_SWAPS[orientation][i] else tuple(ids) for i, ids in enumerate(cum_ids)]
+    couples = ((oriented[0][1], oriented[1][0]), (oriented[1][1], oriented[2][0]), (oriented[2][1], oriented[0][0]))
+    return [tuple(sorted(int(x) for x in c)) for c in couples]

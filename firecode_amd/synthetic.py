@@ -56,3 +56,36 @@ def synthetic_ensemble(n_conf, n_atoms, seed, cluster_size=5, sigma_cluster=0.6,
     q[neg, :, 0] *= -1.0
     coords = np.einsum("nij,naj->nai", q, coords) + rng.normal(scale=5.0, size=(n_conf, 1, 3))
     return np.ascontiguousarray(coords), np.array(["C"] * n_atoms), assign
+
+
+def synthetic_trimolecular(n_conf=(2, 2, 2), n_atoms=(9, 11, 8), seed=0, pivots_per_conf=(1, 2, 1), sep=(3, 4, 3)):
+    """Three small molecules for the trimolecular cyclical embed: per molecule ``coords``
+    (n, A, 3) (conformers = jittered copies of a random skeleton), two reactive atoms
+    ``sep`` bonds apart, and per conformer a list of pivots (start xyz, end xyz, start
+    cumnum, end cumnum): orbital centres 0.8-1.2 A off the reactive atoms, as FIRECODE's
+    Pivot objects hold them.  cumnum = atom index + atoms of the preceding molecules.
+    Returns a list of three dicts (coords, reactive_indices, pivots, reactive_cumnums)."""
+    rng = np.random.default_rng(seed)
+    mols, offset = [], 0
+    for m in range(3):
+        A = n_atoms[m]
+        skel = synthetic_skeleton(A, rng)
+        r0 = int(rng.integers(0, A - sep[m]))
+        r1 = r0 + sep[m]
+        coords = skel[None] + rng.normal(scale=0.08, size=(n_conf[m], A, 3))
+        coords = np.array([c @ random_rotation(rng).T + rng.normal(scale=2.0, size=3) for c in coords])
+        pivots = []
+        for c in range(n_conf[m]):
+            centre = coords[c].mean(axis=0)
+            plist = []
+            for _ in range(pivots_per_conf[m]):
+                off0 = coords[c, r0] - centre + rng.normal(scale=0.5, size=3)
+                off1 = coords[c, r1] - centre + rng.normal(scale=0.5, size=3)
+                start = coords[c, r0] + rng.uniform(0.8, 1.2) * off0 / np.linalg.norm(off0)
+                end = coords[c, r1] + rng.uniform(0.8, 1.2) * off1 / np.linalg.norm(off1)
+                plist.append((start, end, r0 + offset, r1 + offset))
+            pivots.append(plist)
+        mols.append({"coords": coords, "reactive_indices": np.array([r0, r1]), "pivots": pivots,
+                     "reactive_cumnums": {r0: r0 + offset, r1: r1 + offset}})
+        offset += A
+    return mols

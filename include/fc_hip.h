@@ -241,6 +241,29 @@ int fc_embed_grid_dedupe(const double *m1, int64_t n1, int64_t A1, const int64_t
                          const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
                          double rmsd_thr, uint8_t *pass_out, uint8_t *accept_out);
 
+/* ---- a14, three molecules: the body of cyclical_embed, firecode/embeds.py:409-585.
+ * A "job" is one (conformer triple, pivot triple); the host enumerates jobs in the reference's
+ * loop order and supplies, per job: conf (J,3); the three pivots' start / end points
+ * (J,3,3 each; Pivot.pivot = start - end); polygonize(norms) as vecs (J,8,3,2,3);
+ * _get_directions(norms) as dirs0 (J,3,3); run (J,8) = the orientation passes the pairings filter
+ * (:471-475); rtab (J,8,3,3): atom index of molecule m's reactive atom facing molecule k
+ * (the r table of :338-352); norms (J,3).  ua (3,U): distinct step angles (degrees) per molecule,
+ * aidx (S,3) int32: pose s of embedder.systematic_angles -> indices into ua.
+ * Per job the 8 orientations run in order: _adjust_directions (:262-407, 343 candidates, first
+ * minimum) whose result also seeds the next orientation; then the S poses: R, t per molecule
+ * (:488-546), trimolecular compenetration_check (utils.py:556-575, d <= thresh, sum over the three
+ * fragment pairs <= max_clashes) and the rmsd_similarity(rmsd_thr) filter against the poses
+ * already accepted in the group (:553-566).
+ * Out: dirs_out (J,8,3,3) directions used by each orientation; Rt_out (J,8,3,U,12): R (9, row
+ * major) and t (3) of molecule i at step angle u; pass_out / accept_out (J,8,S) uint8. */
+int fc_embed_trimolecular(const double *const coords[3], const int64_t n_conf[3], const int64_t n_atoms[3],
+                          const int64_t *const reactive[3], const int64_t n_reactive[3], int64_t J,
+                          const int64_t *conf, const double *piv_start, const double *piv_end,
+                          const double *vecs, const double *dirs0, const uint8_t *run, const int64_t *rtab,
+                          const double *norms, const double *ua, int64_t U, const int32_t *aidx, int64_t S,
+                          double thresh, int64_t max_clashes, double rmsd_thr, double *dirs_out,
+                          double *Rt_out, uint8_t *pass_out, uint8_t *accept_out);
+
 /* String embed (firecode/embeds.py:51-158) for two molecules with one reactive atom
  * each: molecule i has n_i conformers, K_i orbital centres per conformer
  * (centers_i, orbvecs_i: (n_i, K_i, 3) -- RAtom.center / .orb_vecs) and the run

@@ -648,6 +648,54 @@ def test_device_resident_exchange_over_rccl_single_rank(fc):
         tdist.destroy_process_group()
 
 
+def _tri_objects(mols):
+    from oracle import cyclical_ref as cy
+
+    return [cy.Mol(m["coords"], m["reactive_indices"], [[cy.Pivot(*p) for p in pl] for pl in m["pivots"]],
+                   m["reactive_cumnums"]) for m in mols]
+
+
+@pytest.mark.parametrize("seed,thresh,pairing", [(2, 1.5, False), (5, 0.9, False), (7, 1.1, True)])
+def test_trimolecular_cyclical_embed_vs_oracle(fc, seed, thresh, pairing):
+    """cyclical_embed for three molecules (embeds.py:409-585): adjusted directions, clash pass
+    flags, the sequential accept filter, the poses and the constrained indices, group by group"""
+    from oracle import cyclical_ref as cy
+
+    mols = syn.synthetic_trimolecular(n_conf=(2, 1, 2), n_atoms=(9, 12, 8), seed=seed, pivots_per_conf=(1, 2, 1))
+    angles = o.cartesian_product(*[range(6)] * 3) * 2 * 45 / 5 - 45
+    table = None
+    if pairing:  # a pairing only some orientations realise
+        cum = [list(m["reactive_cumnums"].values()) for m in mols]
+        table = {"a": tuple(sorted((cum[0][1], cum[1][0])))}
+    trace = []
+    ref_poses, ref_ci = cy.cyclical_embed_trimolecular(_tri_objects(mols), angles, pairings_table=table,
+                                                       clash_thresh=thresh, trace=trace)
+    poses, ci, det = fc.embeds.cyclical_embed_trimolecular(mols, angles, pairings_table=table, clash_thresh=thresh,
+                                                          return_details=True)
+    groups = {(g[0], g[1], g[2]): g for g in trace}
+    n_run = 0
+    for j, (conf_ids, piv_ids) in enumerate(det["jobs"]):
+        for v in range(8):
+            key = (conf_ids, piv_ids, v)
+            assert det["run"][j, v] == (key in groups)
+            if key not in groups:
+                assert not det["accepted"][j, v].any()
+                continue
+            n_run += 1
+            _, _, _, d_ref, p_ref, a_ref = groups[key]
+            assert np.abs(det["directions"][j, v] - d_ref).max() < 1e-9
+            assert np.array_equal(det["passed"][j, v], p_ref)
+            assert np.array_equal(det["accepted"][j, v], a_ref)
+    assert n_run == len(trace) and n_run > 0
+    if pairing:
+        assert 0 < n_run < 8 * len(det["jobs"])
+    assert poses.shape == ref_poses.shape and len(poses) > 0
+    assert np.abs(poses - ref_poses).max() < 1e-9
+    assert np.array_equal(ci, ref_ci)
+    if thresh < 1.0:  # the accept filter had something to reject
+        assert det["passed"].sum() > det["accepted"].sum()
+
+
 # ---------------------------------------------------------------- screen-kernel variants / odd shapes
 @pytest.mark.parametrize("n,a", [(2, 1), (3, 2), (70, 3), (130, 5), (200, 80), (150, 104), (140, 110), (90, 130)])
 def test_prune_odd_shapes_and_all_screen_variants(fc, n, a):

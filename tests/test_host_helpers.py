@@ -23,3 +23,36 @@ def test_rot_mat_and_angles():
     assert np.array_equal(np.unique(ref), ang) and len(ang) == 6
     assert hh.cyclical_reactive_indices([3, 9], [20, 25], 0) == [(3, 20), (9, 25)]
     assert hh.cyclical_reactive_indices([3, 9], [20, 25], 1) == [(3, 25), (9, 20)]
+
+
+def test_triangle_helpers_against_the_restatement():
+    """triangle_directions / cyclical_reactive_indices_tri (product host code) against the
+    oracle's literal _get_directions / _get_cyclical_reactive_indices; geometric sanity"""
+    from oracle import cyclical_ref as cy
+
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        n = rng.uniform(1.5, 4.0, size=3)
+        if not all(n[i] < n[i - 1] + n[i - 2] for i in (0, 1, 2)):
+            continue
+        d = hh.triangle_directions(n.copy())
+        assert np.array_equal(d, cy.get_directions(n.copy()))
+        assert np.allclose(np.linalg.norm(d, axis=1), 1.0) and np.all(d[:, 2] == 0)
+    # acute triangle: every direction points from the side's midpoint to the circumcentre
+    n = np.array([3.0, 3.2, 2.9])
+    d = hh.triangle_directions(n.copy())
+    poly = hh.polygonize(n)[0]
+    mids = poly.mean(axis=1)
+    # lines mid_k + t d_k meet in one point
+    A = np.array([[d[0, 0], -d[1, 0]], [d[0, 1], -d[1, 1]]])
+    t = np.linalg.solve(A, (mids[1] - mids[0])[:2])
+    centre = mids[0][:2] + t[0] * d[0][:2]
+    verts = poly[:, 0, :2]
+    assert np.allclose(np.linalg.norm(verts - centre, axis=1), np.linalg.norm(verts[0] - centre))
+    # right triangle: the reference nudges norms[0]
+    n = np.array([3.0, 4.0, 5.0])
+    d = hh.triangle_directions(n)
+    assert n[0] == 3.0 + 1e-5 and np.isfinite(d).all()
+    piv = [cy.Pivot(np.zeros(3), np.ones(3), a, b) for a, b in ((2, 7), (13, 19), (25, 31))]
+    for v in range(8):
+        assert hh.cyclical_reactive_indices_tri([(2, 7), (13, 19), (25, 31)], v) == cy.get_cyclical_reactive_indices(piv, v)

@@ -141,7 +141,23 @@ def values():
     }))
 
 
+def tri():
+    """trimolecular cyclical embed: 12 x 12 x 12 conformer triples x 8 orientations x 216 poses"""
+    mols = syn.synthetic_trimolecular(n_conf=(12, 12, 12), n_atoms=(30, 34, 28), seed=9, pivots_per_conf=(1, 1, 1),
+                                      sep=(4, 5, 4))
+    angles = fc.utils.cartesian_product(*[range(6)] * 3) * 2 * 45 / 5 - 45
+    fc.embeds.cyclical_embed_trimolecular(mols, angles, clash_thresh=1.2)  # warm-up
+    t0 = time.perf_counter()
+    poses, ci, det = fc.embeds.cyclical_embed_trimolecular(mols, angles, clash_thresh=1.2, return_details=True)
+    dt = time.perf_counter() - t0
+    n_poses = int(det["run"].sum()) * len(angles)
+    print(json.dumps({"workload": "trimolecular cyclical embed, 12x12x12 conformers (30+34+28 atoms), 8 orientations, "
+                                  "216 step-angle triples; host set-up + adjust + clash + accept filter + pose build",
+                      "jobs": len(det["jobs"]), "poses": n_poses, "passed": int(det["passed"].sum()),
+                      "accepted": int(len(poses)), "seconds": dt, "poses_per_s": n_poses / dt}))
+
+
 if __name__ == "__main__":
     fc.init(0)
     for w in sys.argv[1:] or ["embed", "csearch", "prune80"]:
-        {"embed": embed, "csearch": csearch, "prune80": prune80, "pcie": pcie, "values": values}[w]()
+        {"embed": embed, "csearch": csearch, "prune80": prune80, "pcie": pcie, "values": values, "tri": tri}[w]()
