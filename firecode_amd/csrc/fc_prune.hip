@@ -151,6 +151,7 @@ k_pair_levelmask(const uint64_t *__restrict__ pairs, const unsigned long long *_
                  uint32_t *__restrict__ levelmask) {
   const unsigned long long P = *n_pairs_ptr;
   if (P > cap) return;
+  const uint32_t n32 = (uint32_t)N;
   for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < P;
        p += (unsigned long long)gridDim.x * blockDim.x) {
     const uint64_t e = pairs[p];
@@ -204,7 +205,6 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ 
     const int64_t lo = w * 64;
     cur[w] = (lo + 64 <= N) ? ~0ull : ((lo < N) ? ((1ull << (N - lo)) - 1ull) : 0ull);
   }
-  const uint32_t n32 = (uint32_t)N;
   __syncthreads();
   int levels = 0;
   for (int l = 0; l < n_ladder; ++l) {
