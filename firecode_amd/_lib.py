@@ -72,6 +72,8 @@ _SIGNATURES = {
     "fc_prune_from_gathered_dev": [_ens, C.c_void_p, _i64, _i64, _i64, _p_u8, _p_i64],
     "fc_stream_set": [C.c_void_p],
     "fc_inertia_moments": [_p_f64, _i64, _i64, _p_f64, _p_f64],
+    "fc_prune_rmsd_rot_corr": [_p_f64, _i64, _i64, _p_u8, _p_i64, _i64, _p_u8, _p_f64, C.POINTER(C.c_int32), _i64,
+                               _f64, _f64, _p_f64, _f64, _i64, _p_u8, _p_u64],
     "fc_align_by_moi": [_p_f64, _i64, _i64, _p_f64, _p_f64],
     "fc_prune_moi": [_p_f64, _i64, _i64, _p_f64, _f64, _p_f64, _f64, _i64, _p_u8],
     "fc_align_to_first": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64],

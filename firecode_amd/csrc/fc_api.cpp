@@ -28,6 +28,9 @@ int launch_ladder_pairs(const uint64_t *, uint32_t *, const unsigned long long *
                         unsigned long long, unsigned long long, int64_t, int64_t, int64_t, const int64_t *,
                         int, uint64_t *, unsigned long long *);
 int launch_scatter_pairs(const uint64_t *, int64_t, int64_t, int64_t, uint64_t *);
+int launch_rotcorr_simbits(const double *, int64_t, int64_t, const uint8_t *, const int64_t *, int64_t,
+                           const uint8_t *, const double *, const int32_t *, int, double, double, const double *,
+                           double, uint64_t *, int64_t);
 int launch_center_structures(const double *, int64_t, int64_t, double *);
 int launch_moi_diag_pairs(const double *, int64_t, double *, double *);
 int launch_set_identity(double *);
@@ -823,6 +826,64 @@ int fc_prune_moi(const double *coords, int64_t N, int64_t A, const double *masse
   FC_TRY(launch_inertia_moments(dc.as<double>(), N, A, dm.as<double>(), dmom.as<double>()));
   FC_TRY(launch_moi_simbits(dmom.as<double>(), N, max_deviation, en_dev, max_dE,
                             e.bits.as<uint64_t>(), e.W));
+  return ladder_single(&e, e.bits.as<uint64_t>(), min_per_group, mask_out, nullptr, nullptr);
+}
+
+// ---- a7: prune_by_rmsd_rot_corr (prism_pruner.pruner; firecode/ensemble.py:253-260) ----------
+int fc_prune_rmsd_rot_corr(const double *coords, int64_t N, int64_t A, const uint8_t *heavy_mask,
+                           const int64_t *torsions, int64_t T, const uint8_t *rotation_masks,
+                           const double *angles, const int32_t *n_angles, int64_t max_angles,
+                           double max_rmsd, double max_dev, const double *energies, double max_dE,
+                           int64_t min_per_group, uint8_t *mask_out, uint64_t *bits_out) {
+  FC_REQUIRE(N >= 0 && A >= 1 && T >= 0 && min_per_group >= 1, "bad arguments");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(coords && heavy_mask && mask_out, "NULL pointer argument");
+  FC_REQUIRE(T == 0 || (torsions && rotation_masks && angles && n_angles), "NULL torsion arrays");
+  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
+  FC_REQUIRE(max_angles >= 1 && max_angles <= 64, "1..64 trial angles per torsion");
+  int64_t n_heavy = 0;
+  for (int64_t a = 0; a < A; ++a) n_heavy += heavy_mask[a] ? 1 : 0;
+  FC_REQUIRE(n_heavy >= 1, "the heavy-atom mask selects no atom");
+  for (int64_t t = 0; t < T; ++t) {
+    for (int k = 0; k < 4; ++k)
+      FC_REQUIRE(torsions[t * 4 + k] >= 0 && torsions[t * 4 + k] < A, "torsion %lld: atom index out of range", (long long)t);
+    FC_REQUIRE(n_angles[t] >= 1 && n_angles[t] <= max_angles, "torsion %lld: bad angle count", (long long)t);
+  }
+  if ((size_t)4 * A * 24 > 160 * 1024) return set_error(FC_E_LIMIT, "A=%lld too large for the LDS slice", (long long)A);
+  FC_TRY(ensure_init());
+  fc_ensemble e;
+  e.N = N;
+  e.Npad = ceil_div(N, 64) * 64;
+  e.W = e.Npad / 64;
+  e.row_block = 64;
+  FC_TRY(e.maskA.reserve((size_t)e.Npad));
+  FC_TRY(e.maskB.reserve((size_t)e.Npad));
+  FC_TRY(e.mbits.reserve((size_t)e.W * sizeof(uint64_t)));
+  FC_TRY(e.counters.reserve(16 * sizeof(uint64_t)));
+  const int64_t rows = ceil_div(N, e.row_block) * e.row_block;
+  const size_t bits_bytes = (size_t)rows * e.W * sizeof(uint64_t);
+  FC_TRY(e.bits.reserve(bits_bytes));
+  FC_HIP_TRY(hipMemsetAsync(e.bits.p, 0, bits_bytes, ctx().stream));
+  DevBuf dc, dcen, dh, dt, dm, da, dn;
+  FC_TRY(upload(dc, coords, (size_t)N * A * 3));
+  FC_TRY(dcen.reserve((size_t)N * A * 3 * sizeof(double)));
+  FC_TRY(upload(dh, heavy_mask, (size_t)A));
+  if (T > 0) {
+    FC_TRY(upload(dt, torsions, (size_t)T * 4));
+    FC_TRY(upload(dm, rotation_masks, (size_t)T * A));
+    FC_TRY(upload(da, angles, (size_t)T * max_angles));
+    FC_TRY(upload(dn, n_angles, (size_t)T));
+  }
+  const double *en_dev = nullptr;
+  if (energies) {
+    FC_TRY(upload(e.energies, energies, (size_t)N));
+    en_dev = e.energies.as<double>();
+  }
+  FC_TRY(launch_center_structures(dc.as<double>(), N, A, dcen.as<double>()));
+  FC_TRY(launch_rotcorr_simbits(dcen.as<double>(), N, A, dh.as<uint8_t>(), dt.as<int64_t>(), T, dm.as<uint8_t>(),
+                                da.as<double>(), dn.as<int32_t>(), (int)max_angles, max_rmsd, max_dev, en_dev,
+                                max_dE, e.bits.as<uint64_t>(), e.W));
+  if (bits_out) FC_TRY(d2h(bits_out, e.bits.p, (size_t)N * e.W * sizeof(uint64_t)));
   return ladder_single(&e, e.bits.as<uint64_t>(), min_per_group, mask_out, nullptr, nullptr);
 }
 

@@ -13,6 +13,7 @@
 // (A*3 doubles); a rotation is lane-per-atom; a clash test flattens the
 // (rest x moving) rectangle over the 64 lanes and reduces with a ballot.
 #include "fc_common.h"
+#include "fc_kabsch_math.h"
 
 namespace fc {
 
@@ -124,6 +125,138 @@ k_torsion_scan(const double *__restrict__ base, int A, const int64_t *__restrict
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_rotcorr_simbits: similarity bits of prune_by_rmsd_rot_corr (a7,
+// prism_pruner.pruner; call sites firecode/ensemble.py:253-260,
+// embedder.py:1489-1496).  The third-party source is not in the tree; restated
+// after the predecessor's published routine (TSCoDe,
+// rotationally_corrected_rmsd_and_max) -- PARITY UNPINNED:
+//   for every locally symmetric torsion t (in order), for every angle of its
+//   n-fold set (0 first): rotate ONLY atom i4 of the second structure about the
+//   i2-i3 bond and take the Kabsch RMSD of the four torsion atoms against the
+//   first structure; the first angle with the smallest local RMSD is then
+//   applied to the whole rotating side (rotation mask); finally
+//   rmsd_and_max over the heavy atoms decides: rmsd < max_rmsd && maxdev < max_dev.
+// One wavefront per pair (i, j > i): the second structure lives in the wave's
+// LDS slice, lanes = trial angles for the local fit, lanes = atoms for the
+// rotations and the final superposition.  X is centred (N, A, 3).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rotcorr_simbits(const double *__restrict__ X, int64_t N, int A, const uint8_t *__restrict__ heavy,
+                  const int64_t *__restrict__ torsions, int T, const uint8_t *__restrict__ rotmasks,
+                  const double *__restrict__ angles, const int32_t *__restrict__ n_angles, int max_angles,
+                  double max_rmsd, double max_dev, const double *__restrict__ energies, double max_dE,
+                  unsigned long long *__restrict__ bits, int64_t W) {
+  extern __shared__ double s[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t i = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * 4 + wv;
+  if (j <= i || j >= N) return;
+  if (energies != nullptr && !(fabs(energies[i] - energies[j]) < max_dE)) return;
+  double *x = s + (size_t)wv * A * 3;
+  const double *ref = X + i * (int64_t)A * 3;
+  const double *src = X + j * (int64_t)A * 3;
+  for (int k = lane; k < A * 3; k += 64) x[k] = src[k];
+  __builtin_amdgcn_wave_barrier();
+  for (int t = 0; t < T; ++t) {
+    const int i1 = (int)torsions[t * 4], i2 = (int)torsions[t * 4 + 1], i3 = (int)torsions[t * 4 + 2],
+              i4 = (int)torsions[t * 4 + 3];
+    const int na = n_angles[t];
+    double local = 1.0e300;
+    double my_angle = 0.0;
+    if (lane < na) {
+      my_angle = angles[(size_t)t * max_angles + lane];
+      const int id[4] = {i1, i2, i3, i4};
+      double p[4][3], q[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          p[k][c] = ref[id[k] * 3 + c];
+          q[k][c] = x[id[k] * 3 + c];
+        }
+      double M[9];
+      rot_from_axis_angle(q[1][0] - q[2][0], q[1][1] - q[2][1], q[1][2] - q[2][2], my_angle, M);
+      const double rx = q[3][0] - q[2][0], ry = q[3][1] - q[2][1], rz = q[3][2] - q[2][2];
+      q[3][0] = ((M[0] * rx + M[1] * ry) + M[2] * rz) + q[2][0];
+      q[3][1] = ((M[3] * rx + M[4] * ry) + M[5] * rz) + q[2][1];
+      q[3][2] = ((M[6] * rx + M[7] * ry) + M[8] * rz) + q[2][2];
+      double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) B[a * 3 + b] = fma(p[k][a], q[k][b], B[a * 3 + b]);
+      double R[9];
+      (void)kabsch_rotation(B, R);
+      double ssq = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double dx = p[k][0] - (R[0] * q[k][0] + R[1] * q[k][1] + R[2] * q[k][2]);
+        const double dy = p[k][1] - (R[3] * q[k][0] + R[4] * q[k][1] + R[5] * q[k][2]);
+        const double dz = p[k][2] - (R[6] * q[k][0] + R[7] * q[k][1] + R[8] * q[k][2]);
+        ssq += dx * dx + dy * dy + dz * dz;
+      }
+      local = sqrt(ssq / 4.0);
+    }
+    // first angle with the smallest local RMSD (the reference compares with a strict <)
+    int best_lane = lane;
+    double best = local;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off);
+      const int ol = __shfl_xor(best_lane, off);
+      if (ob < best || (ob == best && ol < best_lane)) {
+        best = ob;
+        best_lane = ol;
+      }
+    }
+    const double corr = __shfl(my_angle, best_lane);
+    if (corr != 0.0) rotate_masked(x, A, rotmasks + (size_t)t * A, i2, i3, corr, lane);
+  }
+  // rmsd_and_max(ref[heavy], x[heavy]) -- Kabsch without centring
+  double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int nh = 0;
+  for (int a = lane; a < A; a += 64) {
+    if (heavy[a]) {
+      ++nh;
+      const double px = ref[a * 3], py = ref[a * 3 + 1], pz = ref[a * 3 + 2];
+      const double qx = x[a * 3], qy = x[a * 3 + 1], qz = x[a * 3 + 2];
+      B[0] = fma(px, qx, B[0]); B[1] = fma(px, qy, B[1]); B[2] = fma(px, qz, B[2]);
+      B[3] = fma(py, qx, B[3]); B[4] = fma(py, qy, B[4]); B[5] = fma(py, qz, B[5]);
+      B[6] = fma(pz, qx, B[6]); B[7] = fma(pz, qy, B[7]); B[8] = fma(pz, qz, B[8]);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) B[e] += __shfl_xor(B[e], off);
+    nh += __shfl_xor(nh, off);
+  }
+  double R[9];
+  (void)kabsch_rotation(B, R);
+  double ssq = 0.0, mx = 0.0;
+  for (int a = lane; a < A; a += 64) {
+    if (heavy[a]) {
+      const double qx = x[a * 3], qy = x[a * 3 + 1], qz = x[a * 3 + 2];
+      const double dx = ref[a * 3] - (R[0] * qx + R[1] * qy + R[2] * qz);
+      const double dy = ref[a * 3 + 1] - (R[3] * qx + R[4] * qy + R[5] * qz);
+      const double dz = ref[a * 3 + 2] - (R[6] * qx + R[7] * qy + R[8] * qz);
+      const double d = dx * dx + dy * dy + dz * dz;
+      ssq += d;
+      mx = fmax(mx, d);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ssq += __shfl_xor(ssq, off);
+    mx = fmax(mx, __shfl_xor(mx, off));
+  }
+  const double rmsd = sqrt(ssq / (double)nh), maxdev = sqrt(mx);
+  if (lane == 0 && rmsd < max_rmsd && maxdev < max_dev) atomicOr(&bits[i * W + (j >> 6)], 1ull << (j & 63));
+}
+
 // dihedral (prism_pruner.algebra.dihedral, "praxeolitic" form) per lane
 __device__ __forceinline__ double dihedral_deg(const double *p0, const double *p1, const double *p2,
                                                const double *p3) {
@@ -170,6 +303,19 @@ int launch_torsion_scan(const double *base_dev, int64_t A, const int64_t *torsio
                      torsions_dev, (int)T, rotmasks_dev, mv_dev, rs_dev, nmv_dev, nrs_dev,
                      angles_dev, S, thr2, (int)backoff, out_dev, rot_dev);
   return check_launch("k_torsion_scan");
+}
+
+int launch_rotcorr_simbits(const double *X_dev, int64_t N, int64_t A, const uint8_t *heavy_dev,
+                           const int64_t *tors_dev, int64_t T, const uint8_t *rotmasks_dev,
+                           const double *angles_dev, const int32_t *n_angles_dev, int max_angles,
+                           double max_rmsd, double max_dev, const double *energies_dev, double max_dE,
+                           uint64_t *bits_dev, int64_t W) {
+  if (N < 2) return FC_OK;
+  hipLaunchKernelGGL(k_rotcorr_simbits, dim3((unsigned)ceil_div(N, 4), (unsigned)N), dim3(256),
+                     (size_t)4 * A * 3 * sizeof(double), ctx().stream, X_dev, N, (int)A, heavy_dev, tors_dev,
+                     (int)T, rotmasks_dev, angles_dev, n_angles_dev, max_angles, max_rmsd, max_dev, energies_dev,
+                     max_dE, reinterpret_cast<unsigned long long *>(bits_dev), W);
+  return check_launch("k_rotcorr_simbits");
 }
 
 int launch_torsion_fingerprint(const double *coords_dev, int64_t N, int64_t A,

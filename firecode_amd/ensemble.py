@@ -103,10 +103,15 @@ class Ensemble:
         self.energies = self.energies[order]
         self.coords = self.coords[order]
 
-    def similarity_pruning(self, moi=True, rmsd=True, rmsd_rot_corr=False, verbose=True, max_rmsd=0.25):
-        """firecode/ensemble.py:185-276: MOI prune then RMSD prune, masks
-        propagated to ``energies``; same log lines.  ``max_rmsd`` is explicit
-        here (the reference relies on prism_pruner's default)."""
+    def similarity_pruning(self, moi=True, rmsd=True, rmsd_rot_corr=False, verbose=True, max_rmsd=0.25,
+                           symmetric_torsions=None, graph=None, rotation_masks=None):
+        """firecode/ensemble.py:185-276: MOI prune, RMSD prune, then (``rmsd_rot_corr``, at
+        most 1000 structures, :246-270) the symmetry-corrected RMSD prune; masks propagated to
+        ``energies``; same log lines.  ``max_rmsd`` is explicit here (the reference relies on
+        prism_pruner's default).  The rot-corr stage needs the locally symmetric torsions
+        ``(i1, i2, i3, i4, n_fold)`` and ``graph`` (or ``rotation_masks``): the reference
+        perceives them inside prism_pruner from ``graphize(atoms, coords[0])``; that graph work
+        is the caller's here."""
         log = self.logfunction if verbose else None
         if log is not None:
             log("--> Similarity Processing")
@@ -129,8 +134,21 @@ class Ensemble:
             if n0 > len(self.coords) and log is not None:
                 log(f"Discarded {n0 - len(self.coords)} candidates for RMSD similarity "
                     f"({len(self.coords)} left, {perf_counter() - t0:.3f} s)")
-            if rmsd_rot_corr and log is not None:
-                log("Skipped rotationally-corrected RMSD pruning (not on the GPU path yet)")
+            if rmsd_rot_corr:
+                if len(self.coords) <= 1e3:
+                    from firecode_amd.pruner import prune_by_rmsd_rot_corr
+
+                    n0, t0 = len(self.coords), perf_counter()
+                    self.coords, mask = prune_by_rmsd_rot_corr(
+                        self.coords, self.atoms, graph, max_rmsd=max_rmsd,
+                        energies=self.energies if use_en else None, max_dE=max_dE, torsions=symmetric_torsions,
+                        rotation_masks=rotation_masks)
+                    self.apply_mask(("energies",), mask)
+                    if n0 > len(self.coords) and log is not None:
+                        log(f"Discarded {n0 - len(self.coords)} candidates for symmetry-corrected RMSD similarity "
+                            f"({len(self.coords)} left, {perf_counter() - t0:.3f} s)")
+                elif log is not None:
+                    log("Skipped rotationally-corrected RMSD pruning (>1k structures)")
         if len(self.coords) == before and log is not None:
             log(f"All structures passed the similarity check.{' ' * 15}")
         if log is not None:

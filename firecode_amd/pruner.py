@@ -64,6 +64,91 @@ def prune_by_rmsd(structures, atoms, max_rmsd=0.25, max_dev=None, energies=None,
     return structures[mask], mask
 
 
+def rotation_mask(graph, torsion, n_atoms=None):
+    """``_get_rotation_mask`` (firecode/torsion_module.py:354-382): the atoms that rotate
+    with i4 -- reachable from i4 once the i2-i3 edge is removed -- with i3 excluded."""
+    import networkx as nx
+
+    _, i2, i3, i4 = (int(t) for t in torsion)
+    n = graph.number_of_nodes() if n_atoms is None else n_atoms
+    had = graph.has_edge(i2, i3)
+    if had:
+        graph.remove_edge(i2, i3)
+    try:
+        reach = nx.node_connected_component(graph, i4)
+    finally:
+        if had:
+            graph.add_edge(i2, i3)
+    mask = np.zeros(n, dtype=bool)
+    mask[list(reach)] = True
+    mask[i3] = False
+    return mask
+
+
+def prune_by_rmsd_rot_corr(structures, atoms, graph=None, max_rmsd=0.25, max_dev=None, energies=None, max_dE=0.0,
+                           logfunction=None, debugfunction=None, torsions=None, rotation_masks=None,
+                           min_per_group=20, return_bits=False):
+    """``prune_by_rmsd_rot_corr`` (prism_pruner.pruner; ensemble.py:253-260): RMSD pruning
+    that is invariant to rotations of locally symmetric groups (tBu, Ph, NMe2 ...).
+
+    ``torsions``: the locally symmetric torsions as ``(i1, i2, i3, i4, n_fold)`` -- what the
+    reference's own perception (``_get_torsions(..., mode="symmetry")`` filtered to dummy
+    rotations) yields; perceiving them is graph work that stays with the caller.
+    ``rotation_masks`` (T, A) may be given, or are derived from ``graph`` like
+    ``_get_rotation_mask`` does.  With no torsions this is a plain heavy-atom RMSD prune of
+    the mean-centred structures.  PARITY UNPINNED (third-party algorithm restated, see
+    include/fc_hip.h)."""
+    from firecode_amd.torsion_module import N_FOLD_ANGLES
+
+    t0 = perf_counter()
+    structures = L.f64(structures)
+    if structures.ndim != 3 or structures.shape[2] != 3:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, f"structures must be (N, A, 3), got {structures.shape}")
+    atoms = np.asarray(atoms)
+    N, A = structures.shape[:2]
+    if atoms.shape[0] != A:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "len(atoms) != number of atoms")
+    if max_dev is None:
+        max_dev = 2 * max_rmsd
+    if N == 0:
+        return structures, np.ones(0, dtype=bool)
+    torsions = [] if torsions is None else list(torsions)
+    T = len(torsions)
+    quads = L.i64(np.array([t[:4] for t in torsions], dtype=np.int64).reshape(T, 4))
+    if rotation_masks is None:
+        if T and graph is None:
+            raise L.FirecodeHipInputError(L.FC_E_INVALID, "rotation_masks or graph is required with torsions")
+        rotation_masks = [rotation_mask(graph, t[:4], A) for t in torsions]
+    masks = L.u8(np.asarray(rotation_masks, dtype=bool).reshape(T, A))
+    sets = [N_FOLD_ANGLES[int(t[4])] for t in torsions]
+    max_angles = max([len(a) for a in sets] + [1])
+    angles = np.zeros((T, max_angles))
+    n_angles = np.zeros(T, dtype=np.int32)
+    for k, a in enumerate(sets):
+        angles[k, : len(a)] = a
+        n_angles[k] = len(a)
+    heavy = L.u8(atoms != "H")
+    order, en_sorted = _sorted_by_energy(structures, energies)
+    X = structures if order is None else np.ascontiguousarray(structures[order])
+    mask_sorted = np.zeros(N, dtype=np.uint8)
+    W = (N + 63) // 64
+    bits = np.zeros((N, W), dtype=np.uint64) if return_bits else None
+    import ctypes as C
+
+    L.call("fc_prune_rmsd_rot_corr", L.pf(X), N, A, L.pb(heavy), L.pi(quads), T, L.pb(masks), L.pf(angles),
+           n_angles.ctypes.data_as(C.POINTER(C.c_int32)), max_angles, float(max_rmsd), float(max_dev),
+           None if en_sorted is None else L.pf(L.f64(en_sorted)), float(max_dE), int(min_per_group),
+           L.pb(mask_sorted), None if bits is None else L.pw(bits))
+    mask = _unsort(mask_sorted.astype(bool), order)
+    for fn in (logfunction, debugfunction):
+        if fn is not None:
+            fn(f"DEBUG: prune_by_rmsd_rot_corr [gfx950] - {T} symmetric torsions, keeping {int(mask.sum())}/{N} "
+               f"in {perf_counter() - t0:.3f} s")
+    if return_bits:
+        return structures[mask], mask, bits
+    return structures[mask], mask
+
+
 def prune_by_moment_of_inertia(structures, atoms, max_deviation=0.01, energies=None, max_dE=0.0,
                                debugfunction=None, min_per_group=20):
     """MOI pruning: similar when all three principal moments differ by less

@@ -151,6 +151,22 @@ int fc_prune_export_pairs_dev(fc_ensemble *ens, uint64_t *dev_out, int64_t cap);
 int fc_prune_from_gathered_dev(fc_ensemble *ens, const uint64_t *dev_gathered, int64_t world,
                                int64_t cap, int64_t min_per_group, uint8_t *mask_out, int64_t *stats);
 
+/* ---- a7: prune_by_rmsd_rot_corr(structures, atoms, graph, max_rmsd=, energies=, max_dE=) --
+ * prism_pruner.pruner (NOT in the reference tree); call sites firecode/ensemble.py:253-260,
+ * embedder.py:1489-1496, operators.py:626-632.  PARITY UNPINNED: restated after the predecessor's
+ * published routine (see the kernel's header).  The caller does the graph perception and passes
+ * the locally symmetric torsions (T,4), the rotation mask of each (T,A: atoms that move with i4,
+ * firecode/torsion_module.py:354-382), and per torsion its n-fold trial angles in degrees
+ * (angles (T,max_angles), n_angles (T); 0 first, as Torsion.get_angles gives them).
+ * Structures are centred on their plain mean; similarity = rmsd_and_max over heavy_mask atoms
+ * after the torsional correction; then the same k-ladder as fc_prune_rmsd.  coords in processing
+ * order (energy-sorted by the caller when energies are given).  bits_out: optional (N, W). */
+int fc_prune_rmsd_rot_corr(const double *coords, int64_t N, int64_t A, const uint8_t *heavy_mask,
+                           const int64_t *torsions, int64_t T, const uint8_t *rotation_masks,
+                           const double *angles, const int32_t *n_angles, int64_t max_angles,
+                           double max_rmsd, double max_dev, const double *energies, double max_dE,
+                           int64_t min_per_group, uint8_t *mask_out, uint64_t *bits_out);
+
 /* ---- a9: align_by_moi(atoms, structures) -- firecode/hypermolecule_class.py:45-86.
  * Every structure centred on its plain mean; M = get_alignment_matrix(diag(I_ref), diag(I_n))
  * applied as (M @ X.T).T; structure 0 is copied unrotated.  masses (A,), out (N, A, 3). */

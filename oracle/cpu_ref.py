@@ -34,7 +34,12 @@ Parity status ("Oracle"):
   by property tests, not golden vectors: ``get_alignment_matrix``,
   ``rmsd_and_max``, ``prune_by_rmsd``, ``prune_by_moment_of_inertia``,
   ``get_inertia_moments``, ``align_structures``, ``rotate_dihedral``,
-  ``dihedral``, ``rot_mat_from_pointer``.
+  ``dihedral``, ``rot_mat_from_pointer``, ``align_by_moi`` (in-tree body over
+  the two third-party calls), ``random_csearch`` (in-tree loop over
+  ``rotate_dihedral``), and -- with the least evidence of all, no in-tree twin,
+  restated after the predecessor project's published routine --
+  ``rot_corr_rmsd_and_max`` / ``prune_by_rmsd_rot_corr``.
+  The trimolecular cyclical embed is restated in ``oracle/cyclical_ref.py``.
 """
 
 from __future__ import annotations
@@ -280,6 +285,60 @@ def prune_by_rmsd(structures, atoms, max_rmsd=0.25, max_dev=None, energies=None,
         r, m = rmsd_and_max(X[a], X[b])
         return r < max_rmsd and m < max_dev
 
+    mask = greedy_prune(len(X), similar, energies=energies, max_dE=max_dE)
+    return structures[mask], mask
+
+
+def rot_corr_rmsd_and_max(ref, coord, heavy, torsions, rotation_masks, angle_sets):
+    """Rotationally corrected ``rmsd_and_max`` between two centred structures -- the
+    similarity of ``prune_by_rmsd_rot_corr`` (prism_pruner.pruner; call sites
+    ensemble.py:253-260, embedder.py:1489-1496).  PARITY UNPINNED: the package is not in
+    the tree and the tree holds no twin; restated after the predecessor's published
+    routine (TSCoDe ``rotationally_corrected_rmsd_and_max``): for each locally symmetric
+    torsion in order, every angle of its n-fold set is tried by rotating ONLY atom i4 about
+    the i2-i3 bond and scoring the Kabsch RMSD of the four torsion atoms; the first angle
+    with the smallest score (strict ``<``) is applied to the whole rotating side; the
+    heavy-atom ``rmsd_and_max`` of the corrected structure is returned."""
+    ref = np.asarray(ref, dtype=np.float64)
+    coord = np.array(coord, dtype=np.float64)
+    for torsion, mask, angles in zip(torsions, rotation_masks, angle_sets):
+        torsion = [int(t) for t in torsion]
+        only_i4 = np.zeros(len(coord), dtype=bool)
+        only_i4[torsion[3]] = True
+        best_rmsd, best_angle = 1e10, 0
+        for angle in angles:
+            trial = rotate_dihedral(coord, torsion, angle, only_i4)
+            local, _ = rmsd_and_max(ref[torsion], trial[torsion])
+            if local < best_rmsd:
+                best_rmsd, best_angle = local, angle
+        if best_angle != 0:
+            coord = rotate_dihedral(coord, torsion, best_angle, np.asarray(mask, dtype=bool))
+    return rmsd_and_max(ref[heavy], coord[heavy])
+
+
+def prune_by_rmsd_rot_corr(structures, atoms, torsions, rotation_masks, angle_sets, max_rmsd=0.25, max_dev=None,
+                           energies=None, max_dE=0.0, return_matrix=False):
+    """``prune_by_rmsd_rot_corr`` with the graph perception done by the caller (PARITY
+    UNPINNED, see ``rot_corr_rmsd_and_max``): structures centred on their plain mean, the
+    corrected heavy-atom RMSD / max deviation as similarity, the k-ladder of the other
+    pruners.  Returns (structures[mask], mask)."""
+    structures = np.asarray(structures, dtype=np.float64)
+    if max_dev is None:
+        max_dev = 2 * max_rmsd
+    hv = heavy_mask(atoms)
+    X = structures - structures.mean(axis=1, keepdims=True)
+
+    def similar(a, b):
+        r, m = rot_corr_rmsd_and_max(X[a], X[b], hv, torsions, rotation_masks, angle_sets)
+        return r < max_rmsd and m < max_dev
+
+    if return_matrix:
+        n = len(X)
+        S = np.zeros((n, n), dtype=bool)
+        for a in range(n):
+            for b in range(a + 1, n):
+                S[a, b] = similar(a, b)
+        return S
     mask = greedy_prune(len(X), similar, energies=energies, max_dE=max_dE)
     return structures[mask], mask
 

@@ -138,6 +138,14 @@ G["tc_out"] = np.array([ft.torsion_comp_check(c, tuple(t), m.copy(), thresh=1.5)
 G["tc_out_mc2"] = np.array([ft.torsion_comp_check(c, tuple(t), m.copy(), thresh=1.5, max_clashes=2)
                             for c, t, m in zip(tc_in, tc_tors, tc_mask)])
 
+# ---- _get_rotation_mask (torsion_module.py:354-382) --------------------------
+rm_edges = [(0, 1), (1, 2), (2, 3), (3, 4), (3, 5), (3, 6), (0, 7), (0, 8), (4, 9), (5, 10), (6, 11), (8, 12), (12, 13)]
+rm_graph = nx.Graph(rm_edges)
+rm_tors = np.array([(1, 2, 3, 4), (2, 1, 0, 7), (0, 1, 2, 3), (3, 2, 1, 0), (1, 0, 8, 12), (7, 0, 8, 12)], dtype=np.int64)
+G["rotmask_edges"] = np.array(rm_edges, dtype=np.int64)
+G["rotmask_torsions"] = rm_tors
+G["rotmask_out"] = np.array([ft._get_rotation_mask(rm_graph, tuple(int(x) for x in t)) for t in rm_tors])
+
 # ---- tfd_similarity + prune_conformers_tfd loop (torsion_module.py:957-1067) -
 tf_a = rng.uniform(-180, 180, size=(40, 6))
 tf_b = tf_a + rng.normal(scale=2.0, size=tf_a.shape)

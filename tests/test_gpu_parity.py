@@ -696,6 +696,86 @@ def test_trimolecular_cyclical_embed_vs_oracle(fc, seed, thresh, pairing):
         assert det["passed"].sum() > det["accepted"].sum()
 
 
+def _tbu_ensemble(seed=0, n_backbone=4, jitter=0.01):
+    """A chain C0-C1-C2-C3 whose C3 carries three methyls (a 3-fold locally symmetric rotor)
+    and C0 carries two equivalent carbons (a 2-fold one); conformers = backbone dihedral in
+    `n_backbone` values x rotor turned by 0/120/240 (+ a few degrees) x flipper by 0/180"""
+    import networkx as nx
+
+    rng = np.random.default_rng(seed)
+    s, c = np.sin(np.radians(70.5)), np.cos(np.radians(70.5))
+    heavy = [[-3.7, 1.4, 0.3], [-2.2, 1.3, 0.0], [-1.5, 0.0, 0.0], [0.0, 0.0, 0.0]]
+    heavy += [[1.5 * c, 1.5 * s * np.cos(p), 1.5 * s * np.sin(p)] for p in np.radians([10.0, 130.0, 250.0])]
+    d = np.array(heavy[0]) - np.array(heavy[1])
+    d /= np.linalg.norm(d)
+    perp = np.cross(d, [0.0, 0.0, 1.0])
+    perp /= np.linalg.norm(perp)
+    heavy += [list(np.array(heavy[0]) + 1.4 * (0.5 * d + 0.87 * perp)), list(np.array(heavy[0]) + 1.4 * (0.5 * d - 0.87 * perp))]
+    # one hydrogen per methyl, on the C3->methyl line: the rotor stays 3-fold symmetric with its hydrogens
+    hyd = [list(np.array(heavy[k]) * (1.0 + 1.09 / 1.5)) for k in (4, 5, 6)]
+    base = np.array(heavy + hyd)
+    atoms = np.array(["C"] * 9 + ["H"] * 3)
+    edges = [(0, 1), (1, 2), (2, 3), (3, 4), (3, 5), (3, 6), (0, 7), (0, 8), (4, 9), (5, 10), (6, 11)]
+    graph = nx.Graph(edges)
+    torsions = [(1, 2, 3, 4, 3), (2, 1, 0, 7, 2)]
+    masks = np.array([fc_rotation_mask(graph, t[:4], len(atoms)) for t in torsions])
+    backbone = (0, 1, 2, 3)
+    bb_mask = fc_rotation_mask(graph, backbone, len(atoms))
+    out = []
+    for b in range(n_backbone):
+        x0 = o.rotate_dihedral(base, backbone, 50.0 * b, bb_mask)
+        for turn in (0.0, 120.0, 240.0):
+            for flip in (0.0, 180.0):
+                x = o.rotate_dihedral(x0, torsions[0][:4], turn + rng.uniform(-2, 2), masks[0])
+                x = o.rotate_dihedral(x, torsions[1][:4], flip + rng.uniform(-2, 2), masks[1])
+                x = x + rng.normal(scale=jitter, size=x.shape)
+                out.append(x @ syn.random_rotation(rng).T + rng.normal(scale=3.0, size=3))
+    order = rng.permutation(len(out))
+    return np.array(out)[order], atoms, graph, torsions, masks
+
+
+def fc_rotation_mask(graph, torsion, n):
+    from firecode_amd.pruner import rotation_mask
+
+    return rotation_mask(graph, torsion, n)
+
+
+def test_prune_by_rmsd_rot_corr_vs_oracle(fc):
+    """a7 (PARITY UNPINNED restatement): similarity bits, mask, energy window; and the point of
+    the function -- rotamers of locally symmetric groups collapse, which plain RMSD keeps apart"""
+    X, atoms, graph, torsions, masks = _tbu_ensemble(seed=3)
+    angle_sets = [(0, 120, 240), (0, 180)]
+    quads = [t[:4] for t in torsions]
+    S0 = o.prune_by_rmsd_rot_corr(X, atoms, quads, masks, angle_sets, max_rmsd=0.25, return_matrix=True)
+    _, ref_mask = o.prune_by_rmsd_rot_corr(X, atoms, quads, masks, angle_sets, max_rmsd=0.25)
+    kept, mask, bits = fc.pruner.prune_by_rmsd_rot_corr(X, atoms, graph, max_rmsd=0.25, torsions=torsions,
+                                                        return_bits=True)
+    from firecode_amd._lib import unpack_bits
+
+    assert np.array_equal(unpack_bits(bits, len(X)), S0)
+    assert np.array_equal(mask, ref_mask) and np.array_equal(kept, X[mask])
+    assert mask.sum() == 4  # one per backbone dihedral
+    _, plain = fc.pruner.prune_by_rmsd(X, atoms, max_rmsd=0.25)
+    assert plain.sum() > mask.sum()
+    # masks given explicitly == derived from the graph; no torsions == plain prune of centred structures
+    _, mask2 = fc.pruner.prune_by_rmsd_rot_corr(X, atoms, None, max_rmsd=0.25, torsions=torsions, rotation_masks=masks)
+    assert np.array_equal(mask2, mask)
+    _, mask3 = fc.pruner.prune_by_rmsd_rot_corr(X, atoms, graph, max_rmsd=0.25)
+    _, ref3 = o.prune_by_rmsd_rot_corr(X, atoms, [], [], [], max_rmsd=0.25)
+    assert np.array_equal(mask3, ref3)
+    # energy window, processing order by energy
+    en = np.random.default_rng(4).uniform(0, 3, size=len(X))
+    _, ref_e = o.prune_by_rmsd_rot_corr(X, atoms, quads, masks, angle_sets, max_rmsd=0.25, energies=en, max_dE=1.0)
+    _, mask_e = fc.pruner.prune_by_rmsd_rot_corr(X, atoms, graph, max_rmsd=0.25, torsions=torsions, energies=en,
+                                                 max_dE=1.0)
+    assert np.array_equal(mask_e, ref_e) and mask_e.sum() >= mask.sum()
+    # the driver (ensemble.py:185-276) with the third stage switched on
+    lines = []
+    ens = fc.ensemble.Ensemble(atoms=atoms, coords=X.copy(), basename="rotor", logfunction=lines.append)
+    ens.similarity_pruning(moi=False, rmsd=True, rmsd_rot_corr=True, symmetric_torsions=torsions, graph=graph)
+    assert len(ens.coords) == 4 and any("symmetry-corrected RMSD" in ln for ln in lines)
+
+
 # ---------------------------------------------------------------- screen-kernel variants / odd shapes
 @pytest.mark.parametrize("n,a", [(2, 1), (3, 2), (70, 3), (130, 5), (200, 80), (150, 104), (140, 110), (90, 130)])
 def test_prune_odd_shapes_and_all_screen_variants(fc, n, a):

@@ -56,3 +56,15 @@ def test_triangle_helpers_against_the_restatement():
     piv = [cy.Pivot(np.zeros(3), np.ones(3), a, b) for a, b in ((2, 7), (13, 19), (25, 31))]
     for v in range(8):
         assert hh.cyclical_reactive_indices_tri([(2, 7), (13, 19), (25, 31)], v) == cy.get_cyclical_reactive_indices(piv, v)
+
+
+def test_rotation_mask_golden(golden):
+    """pruner.rotation_mask against the reference's own _get_rotation_mask output"""
+    import networkx as nx
+
+    from firecode_amd.pruner import rotation_mask
+
+    graph = nx.Graph([tuple(int(x) for x in e) for e in golden["rotmask_edges"]])
+    out = np.array([rotation_mask(graph, t, graph.number_of_nodes()) for t in golden["rotmask_torsions"]])
+    assert np.array_equal(out, golden["rotmask_out"])
+    assert graph.number_of_edges() == len(golden["rotmask_edges"])  # the graph is restored
