@@ -12,6 +12,7 @@
 // conformers a wavefront treats as "rows" are 64 contiguous bytes that the
 // scalar unit fetches with s_load (wave-uniform address).
 #include "fc_common.h"
+#include <vector>
 #include "fc_kabsch_math.h"
 
 #include <algorithm>
@@ -296,12 +297,43 @@ __device__ __forceinline__ void push_pairs(uint64_t m, bool may, unsigned i, uns
                                            uint64_t *__restrict__ pairq, unsigned long long Q,
                                            unsigned long long *__restrict__ counters, int lane) {
   if (m == 0) return;  // wave-uniform
+#ifdef FC_ABLATE_PUSH  // timing experiment only: results are wrong
+  return;
+#endif
   unsigned long long base = 0;
   if (lane == 0) base = atomicAdd(&counters[6], (unsigned long long)__popcll(m));
   base = __shfl(base, 0);
   if (may) {
     const unsigned long long slot = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
     if (slot < Q) pairq[slot] = ((uint64_t)i << 32) | (uint64_t)j;
+  }
+}
+
+// Candidate staging of the MFMA screen: a workgroup collects its candidate pairs and
+// non-empty words in LDS and publishes them with ONE global atomic each when it is
+// done, instead of one contended atomic-with-return per non-empty ballot (measured:
+// 4 % of the kernel at 10^4 conformers, 17 % at 5*10^3).  A ballot that does not fit
+// goes straight to the global queue; the slots it reserved stay at the "empty" marker.
+constexpr int kStagePairs = 48;  // uint64 entries per workgroup
+constexpr int kStageWords = 24;  // uint32 entries per workgroup
+constexpr size_t kStageBytes = kStagePairs * 8 + kStageWords * 4 + 8;
+
+__device__ __forceinline__ void stage_pairs(uint64_t m, bool may, unsigned i, unsigned j,
+                                            uint64_t *__restrict__ sq, unsigned *__restrict__ scnt,
+                                            uint64_t *__restrict__ pairq, unsigned long long Q,
+                                            unsigned long long *__restrict__ counters, int lane) {
+  if (m == 0) return;  // wave-uniform
+#ifdef FC_ABLATE_PUSH
+  return;
+#endif
+  const unsigned n = (unsigned)__popcll(m);
+  unsigned base = 0;
+  if (lane == 0) base = atomicAdd(scnt, n);
+  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+  if (base + n <= (unsigned)kStagePairs) {
+    if (may) sq[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = ((uint64_t)i << 32) | (uint64_t)j;
+  } else {
+    push_pairs(m, may, i, j, pairq, Q, counters, lane);
   }
 }
 
@@ -441,36 +473,58 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
                       int64_t Npad, int A, double A_thr2, int IB, int64_t rank, int64_t world,
                       uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
                       unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
-                      unsigned long long Q, int compact, double *__restrict__ rmsd_out = nullptr) {
+                      unsigned long long Q, int compact, unsigned long long n_items,
+                      double *__restrict__ rmsd_out = nullptr) {
   extern __shared__ double lds[];
   constexpr int TC = 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int KS = (A + 3) >> 2;
+  double *__restrict__ ldsG = lds + KS * 12 * TC;  // [TC column sums | IB row sums]
+  uint64_t *__restrict__ stageQ = reinterpret_cast<uint64_t *>(ldsG + TC + IB);
+  uint32_t *__restrict__ stageW = reinterpret_cast<uint32_t *>(stageQ + kStagePairs);
+  unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWords);  // [pairs, words]
+#ifdef FC_TIMELINE  // tuning build: per-item start / fill-done / end timestamps (100 MHz)
+  unsigned long long *tl = reinterpret_cast<unsigned long long *>(rmsd_out);
+#endif
+  // One (row block, column tile) item per workgroup.  A persistent variant (grid = what the
+  // chip holds, items drawn from a device counter) was built and measured with
+  // tools/timeline_probe.py: it removes the ~6 us dispatch gap between two 74 us workgroups
+  // on a slot, but the 512 workgroups then run in lock-step -- all column tiles are fetched
+  // in the same 12 us bursts (3.3 TB/s) instead of spread out -- and the loop-carried state
+  // costs registers: 1.03 ms against 0.96 ms.  Not kept.
+  const unsigned long long b = blockIdx.x;
+  if (b >= n_items) return;
+#ifdef FC_TIMELINE
+  if (!VALUES && tl && tid == 0) {
+    tl[(size_t)b * 4] = wall_clock64();
+    tl[(size_t)b * 4 + 3] = b;
+  }
+#endif
   int64_t jt, lb;
   if (compact) {
-    // 1-D grid over the blocks that touch the upper triangle only (world == 1):
+    // items enumerate the blocks that touch the upper triangle only (world == 1):
     // row block lb owns NT - r*lb column tiles (r = IB/64), so the blocks before
     // it number C(lb) = lb*NT - r*lb*(lb-1)/2; invert with one sqrt and fix up.
-    const int64_t NT = Npad >> 6, r = IB >> 6, b = blockIdx.x;
+    const int64_t NT = Npad >> 6, r = IB >> 6;
     const double t = (double)(2 * NT + r);
     int64_t l = (int64_t)((t - sqrt(t * t - 8.0 * (double)r * (double)b)) / (2.0 * (double)r));
     if (l < 0) l = 0;
-    while (l > 0 && l * NT - r * l * (l - 1) / 2 > b) --l;
-    while ((l + 1) * NT - r * (l + 1) * l / 2 <= b) ++l;
+    while (l > 0 && l * NT - r * l * (l - 1) / 2 > (int64_t)b) --l;
+    while ((l + 1) * NT - r * (l + 1) * l / 2 <= (int64_t)b) ++l;
     lb = l;
-    jt = r * l + (b - (l * NT - r * l * (l - 1) / 2));
+    jt = r * l + ((int64_t)b - (l * NT - r * l * (l - 1) / 2));
   } else {
-    jt = blockIdx.x;
-    lb = blockIdx.y;
+    const int64_t NT = Npad >> 6;
+    jt = (int64_t)(b % (unsigned long long)NT);
+    lb = (int64_t)(b / (unsigned long long)NT);
   }
   const int64_t j0 = jt * TC;
   const int64_t i0 = global_block(lb, rank, world) * IB;
-  if (i0 >= N) return;
-  if (j0 + TC - 1 <= i0) return;
+  if (i0 >= N) return;               // block-uniform
+  if (j0 + TC - 1 <= i0) return;     // nothing above the diagonal in this item
 
-  double *__restrict__ ldsG = lds + KS * 12 * TC;  // [TC column sums | IB row sums]
   {  // stage the column tile: 16-byte loads, UNR of them in flight per lane
     typedef double d2_t __attribute__((ext_vector_type(2)));
     const int total2 = KS * 4 * 3 * (TC / 2);  // pairs of adjacent columns
@@ -505,7 +559,13 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
       const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
       ldsG[idx] = g < Npad ? G[g] : 0.0;
     }
+    if (tid < kStagePairs) stageQ[tid] = ~0ull;
+    if (tid < kStageWords) stageW[tid] = ~0u;
+    if (tid < 2) stageN[tid] = 0u;
     __syncthreads();
+#ifdef FC_TIMELINE
+    if (!VALUES && tl && tid == 0) tl[(size_t)b * 4 + 1] = wall_clock64();
+#endif
   }
   const int kq = lane >> 4, l15 = lane & 15;
   const int boff = (kq >> 1) * (2 * TC) + (kq & 1) * 16 + l15;
@@ -648,13 +708,13 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
             const bool in = (j > i) && (j < n32) && (i < n32);
             if (in) rmsd_out[(int64_t)i * N + j] = sqrt(fmax(msdA, 0.0) / (double)A);
             const bool redo = in && (msdA < A_thr2);
-            push_pairs(__ballot(redo), redo, (unsigned)i, (unsigned)j, pairq, Q, counters, lane);
+            stage_pairs(__ballot(redo), redo, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
             continue;
           }
           bool may = kabsch_may_be_below(B9, Gp + Gq, A_thr2);
           may = may && (j > i) && (j < n32) && (i < n32);
           const uint64_t m = __ballot(may);
-          push_pairs(m, may, (unsigned)i, (unsigned)j, pairq, Q, counters, lane);
+          stage_pairs(m, may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
           if (lane < 4) {
             const unsigned piece = (unsigned)((m >> (16 * lane)) & 0xffffull);
             if (ib32 + lane + 4 * r < n32) {
@@ -668,14 +728,62 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
         }
       }
     }
-    if (!VALUES && lane < 4) {  // queue the non-empty words of this row tile for the exact refine
+    if (!VALUES) {  // queue the non-empty words of this row tile for the exact refine
       const unsigned nz[4] = {nz0, nz1, nz2, nz3};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (nz[r]) {
-          const unsigned long long slot = atomicAdd(&counters[4], 1ull);
-          cand[slot] = (uint32_t)((lrow0 + lane + 4 * r) * W + jt);
+#ifdef FC_ABLATE_PUSH
+        continue;
+#endif
+        const bool has = lane < 4 && nz[r] != 0;
+        const uint64_t mw = __ballot(has);
+        if (mw == 0) continue;  // wave-uniform
+        const unsigned n = (unsigned)__popcll(mw);
+        const uint32_t word = (uint32_t)((lrow0 + lane + 4 * r) * W + jt);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(stageN + 1, n);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        const unsigned rank_in = (unsigned)__popcll(mw & ((1ull << lane) - 1ull));
+        if (base + n <= (unsigned)kStageWords) {
+          if (has) stageW[base + rank_in] = word;
+        } else {  // no room: straight to the global queue
+          unsigned long long gbase = 0;
+          if (lane == 0) gbase = atomicAdd(&counters[4], (unsigned long long)n);
+          gbase = __shfl(gbase, 0);
+          if (has) cand[gbase + rank_in] = word;
         }
+      }
+    }
+  }
+  // publish what the workgroup staged: one global atomic per queue
+  __syncthreads();
+#ifdef FC_TIMELINE
+  if (!VALUES && tl && tid == 0) tl[(size_t)b * 4 + 2] = wall_clock64();
+#endif
+  if (wv == 0) {
+    {
+      const uint64_t e = lane < kStagePairs ? stageQ[lane] : ~0ull;
+      const bool valid = e != ~0ull;
+      const uint64_t mv = __ballot(valid);
+      if (mv != 0) {
+        unsigned long long gbase = 0;
+        if (lane == 0) gbase = atomicAdd(&counters[6], (unsigned long long)__popcll(mv));
+        gbase = __shfl(gbase, 0);
+        if (valid) {
+          const unsigned long long slot = gbase + (unsigned long long)__popcll(mv & ((1ull << lane) - 1ull));
+          if (slot < Q) pairq[slot] = e;
+        }
+      }
+    }
+    if (!VALUES) {
+      const uint32_t wq = lane < kStageWords ? stageW[lane] : ~0u;
+      const bool valid = wq != ~0u;
+      const uint64_t mv = __ballot(valid);
+      if (mv != 0) {
+        unsigned long long gbase = 0;
+        if (lane == 0) gbase = atomicAdd(&counters[4], (unsigned long long)__popcll(mv));
+        gbase = __shfl(gbase, 0);
+        if (valid) cand[gbase + (unsigned long long)__popcll(mv & ((1ull << lane) - 1ull))] = wq;
       }
     }
   }
@@ -894,7 +1002,7 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev) {
   const int64_t NT = e->Npad >> 6;
   const int64_t rb = 128;
   const int64_t n_lblocks = ceil_div(e->N, rb);
-  const size_t lds_m = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)rb) * sizeof(double);
+  const size_t lds_m = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)rb) * sizeof(double) + kStageBytes;
   if (lds_m > kLdsLimit || NT == 0)
     return set_error(FC_E_LIMIT, "A=%lld atoms exceed the LDS column tile of the value kernel", (long long)e->A);
   const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32);
@@ -907,18 +1015,26 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev) {
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
     if (err != hipSuccess) return set_error(FC_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
   }
-  const dim3 grid((unsigned)NT, (unsigned)n_lblocks);
   const double A_small = (double)e->A * small_rmsd * small_rmsd;
+  // one workgroup per upper-triangle item (see launch_simbits_screen)
+  const int64_t r = rb / 64;
+  int64_t nvalid = 0;
+  for (int64_t l = 0; l < n_lblocks; ++l) nvalid += std::max<int64_t>(NT - r * l, 0);
+  const int compact = (nvalid > 0 && NT - r * (n_lblocks - 1) > 0) ? 1 : 0;
+  const unsigned long long n_items =
+      compact ? (unsigned long long)nvalid : (unsigned long long)NT * (unsigned long long)n_lblocks;
+  if (n_items >= (1ull << 31)) return set_error(FC_E_LIMIT, "too many value-kernel items for one launch");
+  const dim3 grid((unsigned)n_items);
   if (two_blocks)
     hipLaunchKernelGGL((k_simbits_screen_mfma<4, true>), grid, dim3(256), lds_m, ctx().stream,
                        e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,
                        (int64_t)0, (int64_t)1, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),
-                       (unsigned long long)e->pairq_cap, 0, rmsd_dev);
+                       (unsigned long long)e->pairq_cap, compact, n_items, rmsd_dev);
   else
     hipLaunchKernelGGL((k_simbits_screen_mfma<8, true>), grid, dim3(512), lds_m, ctx().stream,
                        e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,
                        (int64_t)0, (int64_t)1, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),
-                       (unsigned long long)e->pairq_cap, 0, rmsd_dev);
+                       (unsigned long long)e->pairq_cap, compact, n_items, rmsd_dev);
   FC_TRY(check_launch("k_simbits_screen_mfma<values>"));
   hipLaunchKernelGGL(k_rmsd_fix_small, dim3((unsigned)(ctx().n_cu * 4)), dim3(256), 0, ctx().stream,
                      e->Xa.as<double>(), (int)e->A, e->N, e->pairq.as<uint64_t>(), cnt,
@@ -977,7 +1093,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   const bool want_valu = cfg && std::strncmp(cfg, "valu", 4) == 0;
   const bool alt = cfg && std::strcmp(cfg, "valu4x8") == 0;
   {
-    const size_t lds_m = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)e->row_block) * sizeof(double);
+    const size_t lds_m = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)e->row_block) * sizeof(double) + kStageBytes;
     const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32);
     const bool two_blocks_fit = 2 * lds_m <= kLdsLimit;
     if (!want_valu && fits32 && lds_m <= kLdsLimit && e->row_block % (two_blocks_fit ? 64 : 128) == 0) {
@@ -997,30 +1113,56 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         fprintf(stderr, "[fc] screen_mfma<%d>: LDS %zu B, occupancy API says %d blocks/CU\n",
                 two_blocks ? 4 : 8, lds_m, nb);
       }
+      // one workgroup per item; world == 1: only the items that touch the upper triangle
       int compact = 0;
-      dim3 mgrid = grid;
+      unsigned long long n_items = (unsigned long long)NT * (unsigned long long)n_lblocks;
       if (e->world == 1 && e->row_block % 64 == 0) {
         const int64_t r = e->row_block / 64;
         int64_t nvalid = 0;
         for (int64_t l = 0; l < n_lblocks; ++l) nvalid += std::max<int64_t>(NT - r * l, 0);
-        if (nvalid > 0 && nvalid < (1ll << 31) && NT - r * (n_lblocks - 1) > 0) {
+        if (nvalid > 0 && NT - r * (n_lblocks - 1) > 0) {
           compact = 1;
-          mgrid = dim3((unsigned)nvalid);
+          n_items = (unsigned long long)nvalid;
         }
       }
+      if (n_items >= (1ull << 31)) return set_error(FC_E_LIMIT, "too many screen items for one launch");
+      const dim3 mgrid((unsigned)n_items);
+      double *dbg = nullptr;
+#ifdef FC_TIMELINE
+      static DevBuf tlbuf;
+      const bool timeline = two_blocks && getenv("FC_TIMELINE_OUT") != nullptr;
+      if (timeline) {
+        FC_TRY(tlbuf.reserve(n_items * 4 * sizeof(unsigned long long)));
+        FC_HIP_TRY(hipMemsetAsync(tlbuf.p, 0, n_items * 4 * sizeof(unsigned long long), ctx().stream));
+        dbg = tlbuf.as<double>();
+      }
+#endif
       if (two_blocks)
         hipLaunchKernelGGL(k_simbits_screen_mfma<4>, mgrid, dim3(256), lds_m, ctx().stream,
                            e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
                            (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                            e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
-                           (unsigned long long)e->pairq_cap, compact);
+                           (unsigned long long)e->pairq_cap, compact, n_items, dbg);
       else
         hipLaunchKernelGGL(k_simbits_screen_mfma<8>, mgrid, dim3(512), lds_m, ctx().stream,
                            e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
                            (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                            e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
-                           (unsigned long long)e->pairq_cap, compact);
-      return check_launch("k_simbits_screen_mfma");
+                           (unsigned long long)e->pairq_cap, compact, n_items, dbg);
+      FC_TRY(check_launch("k_simbits_screen_mfma"));
+#ifdef FC_TIMELINE
+      if (timeline) {
+        std::vector<unsigned long long> h(n_items * 4);
+        FC_HIP_TRY(hipMemcpyAsync(h.data(), tlbuf.p, n_items * 4 * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, ctx().stream));
+        FC_HIP_TRY(hipStreamSynchronize(ctx().stream));
+        if (FILE *f = fopen(getenv("FC_TIMELINE_OUT"), "wb")) {
+          fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+          fclose(f);
+        }
+      }
+#endif
+      return FC_OK;
     }
   }
 #define FC_LAUNCH_SCREEN(LDSFLAG, TI_, NW_, SMEM)                                                   \
