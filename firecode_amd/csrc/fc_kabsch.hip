@@ -525,33 +525,21 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
   if (i0 >= N) return;               // block-uniform
   if (j0 + TC - 1 <= i0) return;     // nothing above the diagonal in this item
 
-  {  // stage the column tile: 16-byte loads, UNR of them in flight per lane
-    typedef double d2_t __attribute__((ext_vector_type(2)));
-    const int total2 = KS * 4 * 3 * (TC / 2);  // pairs of adjacent columns
-    constexpr int UNR = 5;
-    for (int base = tid; base < total2; base += NW * 64 * UNR) {
-      d2_t v[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int idx = base + u * NW * 64;
-        const int col = (idx & (TC / 2 - 1)) * 2;
-        const int ac = idx >> 5;  // a*3 + c   (TC/2 = 32 pairs per row)
-        v[u] = (idx < total2)
-                   ? *reinterpret_cast<const d2_t *>(Xs + (int64_t)ac * Npad + j0 + col)
-                   : d2_t{0.0, 0.0};
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int idx = base + u * NW * 64;
-        if (idx < total2) {
-          const int col = (idx & (TC / 2 - 1)) * 2;
-          const int ac = idx >> 5;
-          const int a = ac / 3, c = ac - a * 3;
-          const int sgrp = a >> 2, k = a & 3;
-          *reinterpret_cast<d2_t *>(lds + (sgrp * 3 + c) * (4 * TC) + (k >> 1) * (2 * TC) +
-                                    (col >> 4) * 32 + (k & 1) * 16 + (col & 15)) = v[u];
-        }
-      }
+  {  // stage the column tile by LDS-DMA (global_load_lds_dwordx4): no VGPR staging, every
+    // piece of a wave in flight at once.  The hardware writes lane l's 16 bytes at
+    // (wave-uniform base) + 16 l, so each instruction fills one 1-KiB run of the swizzled
+    // image -- run q = (sgrp*3 + c)*2 + (k>>1) holds [cs][k&1][16 columns] -- and the swizzle
+    // is applied to the per-lane SOURCE address.  (Register staging took 4 dependent L2 round
+    // trips, 9.7 us of a 74 us workgroup: tools/timeline_probe.py.)
+    const int n_runs = KS * 6;
+    const int cs_l = lane >> 4, k1_l = (lane >> 3) & 1, c15_l = (lane & 7) * 2;
+    for (int q = wv; q < n_runs; q += NW) {
+      const int sc = q >> 1, kh = q & 1;  // sc = sgrp*3 + c
+      const int sg = sc / 3, c = sc - sg * 3;
+      const int a = sg * 4 + kh * 2 + k1_l;
+      const double *src = Xs + (int64_t)(a * 3 + c) * Npad + j0 + cs_l * 16 + c15_l;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(lds + q * 128), 16, 0, 0);
     }
     // sums of squares of the tile's columns and of the block's rows: the epilogue reads them
     // from LDS (lgkmcnt) so that it never waits on vmcnt behind the row-operand prefetch
