@@ -192,3 +192,75 @@ def prune_by_rmsd_sharded(ens, max_rmsd, max_dev=None, rank=0, world=1, allgathe
         return mask, stats
     mask = run_ladder(ens.N, ens.prune_level, allgather_fn, min_per_group=min_per_group, trace=trace)
     return mask, stats
+
+
+# ---------------------------------------------------------------------------------------
+# The embarrassingly parallel rows: clash / embed / torsion scan.
+# A contiguous slice of the outermost index per rank, the compute call unchanged, then ONE
+# all-gather of the bit-packed pass mask -- no other collective.
+# ---------------------------------------------------------------------------------------
+def shard_bounds(n, rank, world):
+    """Contiguous, balanced slice [lo, hi) of range(n) for ``rank`` (the first n % world
+    ranks get one more)."""
+    base, extra = divmod(int(n), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_mask_slices(local_mask, n_total, rank, world, allgather_fn):
+    """All-gather of per-rank boolean slices (leading axis sharded by ``shard_bounds``):
+    bits are packed 8 per byte, padded to the longest slice, exchanged with ONE collective
+    and reassembled in rank order.  Returns the full (n_total, ...) boolean array."""
+    local_mask = np.ascontiguousarray(local_mask, dtype=bool)
+    inner = local_mask.shape[1:]
+    per_row = int(np.prod(inner)) if inner else 1
+    longest = shard_bounds(n_total, 0, world)[1] * per_row  # rank 0 holds the longest slice
+    packed = np.zeros((longest + 7) // 8, dtype=np.uint8)
+    mine = np.packbits(local_mask.reshape(-1))
+    packed[: mine.shape[0]] = mine
+    rows = np.asarray(allgather_fn(packed)).reshape(world, -1)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        nbits = (hi - lo) * per_row
+        parts.append(np.unpackbits(rows[r])[:nbits].astype(bool).reshape((hi - lo,) + inner))
+    return np.concatenate(parts, axis=0)
+
+
+def torsion_scan_sharded(base, torsions, masks, angles, rank=0, world=1, allgather_fn=None, thresh=1.5,
+                         scan_fn=None):
+    """Angle-sets sharded over the ranks (clustered_csearch's inner loops,
+    torsion_module.py:812-856).  Every rank scans its slice on its GPU and keeps those
+    conformers; the (S,) "at least one bond rotated" flags are all-gathered.
+    Returns (local_coords (s_local, A, 3), local_rotated, (lo, hi), keep_all (S,) bool)."""
+    if scan_fn is None:
+        from firecode_amd.torsion_module import torsion_scan as scan_fn
+    if allgather_fn is None:
+        allgather_fn = lambda m: m[None]  # noqa: E731
+    angles = np.asarray(angles)
+    lo, hi = shard_bounds(len(angles), rank, world)
+    out, rot = scan_fn(base, torsions, masks, angles[lo:hi], thresh=thresh)
+    keep_all = gather_mask_slices(np.asarray(rot) != 0, len(angles), rank, world, allgather_fn)
+    return out, rot, (lo, hi), keep_all
+
+
+def embed_grid_clash_sharded(m1, reactive1, pivots1, m2, reactive2, pivots2, angles1, angles2=None, rank=0,
+                             world=1, allgather_fn=None, thresh=1.5, max_clashes=0, grid_fn=None):
+    """The bimolecular pose grid (embeds.py:597-722) sharded over the conformers of the SECOND
+    molecule -- the slowest index of the reference's loop, so every rank owns a contiguous
+    block of the flattened pose order.  One all-gather of the packed pass mask.
+    Returns pass (n2, n1, 2, na2, na1) bool, identical on every rank."""
+    if grid_fn is None:
+        from firecode_amd.embeds import embed_grid_clash as grid_fn
+    if allgather_fn is None:
+        allgather_fn = lambda m: m[None]  # noqa: E731
+    m2 = np.asarray(m2)
+    lo, hi = shard_bounds(len(m2), rank, world)
+    if hi > lo:
+        local = grid_fn(m1, reactive1, pivots1, m2[lo:hi], reactive2, np.asarray(pivots2)[lo:hi], angles1, angles2,
+                        thresh=thresh, max_clashes=max_clashes)[0]
+    else:
+        a1 = np.asarray(angles1).reshape(-1)
+        a2 = a1 if angles2 is None else np.asarray(angles2).reshape(-1)
+        local = np.zeros((0, len(np.asarray(m1)), 2, len(a2), len(a1)), dtype=bool)
+    return gather_mask_slices(local, len(m2), rank, world, allgather_fn)

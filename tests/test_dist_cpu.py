@@ -163,3 +163,101 @@ def test_run_ladder_world1_equals_oracle():
     shard = OracleShard(S, 0, 1, 64)
     mask = fdist.run_ladder(500, shard.prune_level, lambda m: m[None])
     assert np.array_equal(mask, o.greedy_prune_from_matrix(S))
+
+
+# ---- the embarrassingly parallel rows: torsion scan and pose grid ---------
+def _chain(n_atoms, n_tors, seed):
+    rng = np.random.default_rng(seed)
+    base = np.cumsum(rng.normal(scale=0.9, size=(n_atoms, 3)) + [1.3, 0, 0], axis=0)
+    step = (n_atoms - 4) // n_tors
+    tors = np.array([[1 + k * step, 2 + k * step, 3 + k * step, 4 + k * step] for k in range(n_tors)])
+    masks = np.zeros((n_tors, n_atoms), dtype=bool)
+    for k, t in enumerate(tors):
+        masks[k, t[3]:] = True
+    return base, tors, masks
+
+
+def _oracle_grid(m1, reactive1, pivots1, m2, reactive2, pivots2, angles1, angles2=None, thresh=1.5, max_clashes=0):
+    """oracle-backed stand-in for embeds.embed_grid_clash (same index order [c2, c1, o, a2, a1])"""
+    a1 = np.asarray(angles1, float).reshape(-1)
+    a2 = a1 if angles2 is None else np.asarray(angles2, float).reshape(-1)
+    out = np.zeros((len(m2), len(m1), 2, len(a2), len(a1)), dtype=bool)
+    for c2 in range(len(m2)):
+        for c1 in range(len(m1)):
+            for orient in (0, 1):
+                for i2, ang2 in enumerate(a2):
+                    for i1, ang1 in enumerate(a1):
+                        R1, t1, R2, t2 = o.bimol_pose_transforms(m1[c1], m2[c2], reactive1, reactive2, pivots1[c1],
+                                                                 pivots2[c2], (ang1, ang2), orient)
+                        pose = o.get_embed([m1[c1], m2[c2]], [R1, R2], [t1, t2])
+                        out[c2, c1, orient, i2, i1] = o.compenetration_check(
+                            pose, ids=[m1.shape[1], m2.shape[1]], thresh=thresh, max_clashes=max_clashes)
+    return out, 0.0
+
+
+def _grid_case(seed):
+    rng = np.random.default_rng(seed)
+    m1 = rng.normal(scale=1.6, size=(3, 7, 3))
+    m2 = rng.normal(scale=1.6, size=(5, 6, 3))
+    r1, r2 = np.array([0, 3]), np.array([1, 4])
+    p1 = np.stack([m1[:, 0] + 0.9, m1[:, 3] - 0.8], axis=1)
+    p2 = np.stack([m2[:, 1] + 0.7, m2[:, 4] - 1.0], axis=1)
+    return m1, r1, p1, m2, r2, p2, np.array([-45.0, 0.0, 45.0])
+
+
+def _worker_parallel_rows(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ag = fdist.torch_allgather()
+    base, tors, masks = _chain(16, 3, seed=9)
+    angles = o.cartesian_product((0, 120, 240), (0, 180), (0, 120, 240))
+    out, rot, (lo, hi), keep = fdist.torsion_scan_sharded(base, tors, masks, angles, rank=rank, world=world,
+                                                          allgather_fn=ag, scan_fn=o.torsion_scan)
+    np.savez(os.path.join(out_dir, f"scan_{rank}.npz"), out=out, rot=rot, lo=lo, hi=hi, keep=keep)
+    m1, r1, p1, m2, r2, p2, ang = _grid_case(4)
+    ok = fdist.embed_grid_clash_sharded(m1, r1, p1, m2, r2, p2, ang, rank=rank, world=world, allgather_fn=ag,
+                                        thresh=1.4, grid_fn=_oracle_grid)
+    np.save(os.path.join(out_dir, f"grid_{rank}.npy"), ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_scan_and_pose_grid(tmp_path, world):
+    mp.spawn(_worker_parallel_rows, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    base, tors, masks = _chain(16, 3, seed=9)
+    angles = o.cartesian_product((0, 120, 240), (0, 180), (0, 120, 240))
+    ref_out, ref_rot = o.torsion_scan(base, tors, masks, angles)
+    covered = []
+    for r in range(world):
+        d = np.load(tmp_path / f"scan_{r}.npz")
+        lo, hi = int(d["lo"]), int(d["hi"])
+        covered.extend(range(lo, hi))
+        assert np.array_equal(d["out"], ref_out[lo:hi]) and np.array_equal(d["rot"], ref_rot[lo:hi])
+        assert np.array_equal(d["keep"], ref_rot != 0)
+    assert covered == list(range(len(angles)))
+    m1, r1, p1, m2, r2, p2, ang = _grid_case(4)
+    ref_ok, _ = _oracle_grid(m1, r1, p1, m2, r2, p2, ang, thresh=1.4)
+    assert 0 < ref_ok.sum() < ref_ok.size
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"grid_{r}.npy"), ref_ok)
+
+
+def test_shard_bounds_and_mask_gather():
+    for n in (0, 1, 7, 64, 1000):
+        for world in (1, 2, 3, 8):
+            b = [fdist.shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+    rng = np.random.default_rng(0)
+    full = rng.random((11, 3, 5)) < 0.4
+    world = 4
+    sent = []
+    for r in range(world):
+        lo, hi = fdist.shard_bounds(11, r, world)
+        fdist.gather_mask_slices(full[lo:hi], 11, r, world, lambda p: sent.append(p) or np.zeros((world, p.shape[0]), np.uint8))
+    rows = np.stack(sent)
+    for r in range(world):
+        lo, hi = fdist.shard_bounds(11, r, world)
+        assert np.array_equal(fdist.gather_mask_slices(full[lo:hi], 11, r, world, lambda p: rows), full)

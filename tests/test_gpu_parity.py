@@ -776,6 +776,40 @@ def test_prune_by_rmsd_rot_corr_vs_oracle(fc):
     assert len(ens.coords) == 4 and any("symmetry-corrected RMSD" in ln for ln in lines)
 
 
+def test_sharded_scan_and_pose_grid_logical_ranks(fc):
+    """SURVEY 8e item 3 with the real kernels: 3 logical ranks on one GPU, the all-gather
+    emulated by stacking the ranks' packed masks"""
+    from firecode_amd import dist as fdist
+
+    base, tors, masks = _chain_case(24, 3, seed=51)
+    angles = o.cartesian_product((0, 120, 240), (0, 60, 120, 180, 240, 300), (0, 180))
+    full_out, full_rot = fc.torsion_module.torsion_scan(base, tors, masks, angles)
+    rng = np.random.default_rng(52)
+    m1 = rng.normal(scale=1.8, size=(4, 9, 3))
+    m2 = rng.normal(scale=1.8, size=(7, 8, 3))
+    r1, r2 = np.array([0, 4]), np.array([2, 5])
+    p1 = np.stack([m1[:, 0] + 0.9, m1[:, 4] - 0.8], axis=1)
+    p2 = np.stack([m2[:, 2] + 0.7, m2[:, 5] - 1.0], axis=1)
+    ang = fc.host_helpers.systematic_angles(5, 45)
+    full_ok, _ = fc.embeds.embed_grid_clash(m1, r1, p1, m2, r2, p2, ang, thresh=1.3)
+    world = 3
+    sent_scan, sent_grid = [], []
+    for r in range(world):  # first pass: what every rank would send
+        fdist.torsion_scan_sharded(base, tors, masks, angles, rank=r, world=world,
+                                   allgather_fn=lambda p: sent_scan.append(p) or np.zeros((world, len(p)), np.uint8))
+        fdist.embed_grid_clash_sharded(m1, r1, p1, m2, r2, p2, ang, rank=r, world=world, thresh=1.3,
+                                       allgather_fn=lambda p: sent_grid.append(p) or np.zeros((world, len(p)), np.uint8))
+    for r in range(world):  # second pass: with the gathered messages
+        out, rot, (lo, hi), keep = fdist.torsion_scan_sharded(base, tors, masks, angles, rank=r, world=world,
+                                                              allgather_fn=lambda p: np.stack(sent_scan))
+        assert np.array_equal(rot, full_rot[lo:hi]) and np.array_equal(out, full_out[lo:hi])
+        assert np.array_equal(keep, full_rot != 0)
+        ok = fdist.embed_grid_clash_sharded(m1, r1, p1, m2, r2, p2, ang, rank=r, world=world, thresh=1.3,
+                                            allgather_fn=lambda p: np.stack(sent_grid))
+        assert np.array_equal(ok, full_ok)
+    assert 0 < full_ok.sum() < full_ok.size
+
+
 # ---------------------------------------------------------------- screen-kernel variants / odd shapes
 @pytest.mark.parametrize("n,a", [(2, 1), (3, 2), (70, 3), (130, 5), (200, 80), (150, 104), (140, 110), (90, 130)])
 def test_prune_odd_shapes_and_all_screen_variants(fc, n, a):
