@@ -16,6 +16,7 @@
 // rebuild in slot order) and the xxHash-style tuple hash (tupleobject.c).
 // tests/test_pyset_emulation.py checks both against the running interpreter.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <thread>
@@ -305,14 +306,19 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
   unsigned hw = std::thread::hardware_concurrency();
   if (hw == 0) hw = 1;
   if (hw > 16) hw = 16;
+  if (const char *v = getenv("FC_TFD_THREADS")) {  // test knob
+    const long t = std::strtol(v, nullptr, 10);
+    if (t >= 1 && t <= 64) hw = (unsigned)t;
+  }
   for (double kd : kl) {
     const int64_t k = (int64_t)kd;
     int64_t num_active = 0;
     for (int64_t i = 0; i < N; ++i) num_active += mask_out[i];
     if (!(k == 1 || 5 * k < num_active)) continue;
     const int64_t d = N / k;
-    // fine levels: many independent chunks -> host threads; coarse levels: one thread
-    const int64_t nthreads = (k >= 64 && N >= 100000) ? (int64_t)hw : 1;
+    // chunks are independent: host threads over them at every level (one thread per chunk at the
+    // coarse end of the ladder; the single chunk of k = 1 stays serial)
+    const int64_t nthreads = (N >= 100000) ? std::min<int64_t>((int64_t)hw, k) : 1;
     if (nthreads == 1) {
       level_chunks(fm, N, k, d, num_active, 0, k, mask_out);
     } else {

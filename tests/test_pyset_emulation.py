@@ -124,3 +124,31 @@ def _oracle_ladder_from_fm(fm):
                     for i in set(group) - {group[0]}:
                         final_mask[i + d * step] = 0
     return final_mask
+
+
+def test_threaded_ladder_equals_serial(monkeypatch):
+    """above 10^5 structures every ladder level runs its chunks on host threads: same mask as
+    one thread (chunks own disjoint row ranges), on a first-match array with long runs,
+    hubs and isolated structures"""
+    rng = np.random.default_rng(11)
+    n = 150_000
+    fm = np.full(n, -1, dtype=np.int64)
+    idx = np.arange(n)
+    step = rng.integers(1, 40, size=n)
+    has = rng.random(n) < 0.8
+    tgt = idx + step
+    ok = has & (tgt < n)
+    fm[ok] = tgt[ok]
+    hub = rng.integers(0, n, size=50)  # many structures whose first match is the same later one
+    for h in hub:
+        lo = max(0, h - 200)
+        sel = np.arange(lo, h)[rng.random(h - lo) < 0.5]
+        fm[sel] = h
+    masks = []
+    for threads in ("1", "7"):
+        monkeypatch.setenv("FC_TFD_THREADS", threads)
+        mask = np.zeros(n, dtype=np.uint8)
+        L.call("fc_tfd_ladder_from_first_match", L.pi(fm), n, L.pb(mask))
+        masks.append(mask)
+    assert np.array_equal(masks[0], masks[1])
+    assert 0 < masks[0].sum() < n
