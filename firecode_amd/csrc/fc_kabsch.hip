@@ -314,6 +314,12 @@ __device__ __forceinline__ void push_pairs(uint64_t m, bool may, unsigned i, uns
 // done, instead of one contended atomic-with-return per non-empty ballot (measured:
 // 4 % of the kernel at 10^4 conformers, 17 % at 5*10^3).  A ballot that does not fit
 // goes straight to the global queue; the slots it reserved stay at the "empty" marker.
+#ifndef FC_REFINE_ROUNDS
+#define FC_REFINE_ROUNDS 4  // measured: 8 -> 66 us, 4 -> 53 us, 2 -> 59 us, 1 (all redundant) -> 82 us
+#endif
+#ifndef FC_REFINE_UNROLL
+#define FC_REFINE_UNROLL 1
+#endif
 constexpr int kStagePairs = 48;  // uint64 entries per workgroup
 constexpr int kStageWords = 24;  // uint32 entries per workgroup
 constexpr size_t kStageBytes = kStagePairs * 8 + kStageWords * 4 + 8;
@@ -797,31 +803,87 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const unsigned long long n_pairs = counters[6];
   if (n_pairs <= Q) {
-    // pair mode: the queue is complete -> eight lanes per candidate pair (8 pairs
-    // per wavefront); a pair that is not similar has its screen bit cleared
+    // pair mode: the queue is complete.  A wavefront takes 64 candidate pairs.  The two atom
+    // passes (covariance, rotated difference) run with EIGHT lanes per pair, 8 pairs per
+    // round, 8 rounds -- coalesced 192-byte pieces of Xa -- while the 4x4 eigen-solve between
+    // them, 85 % of the arithmetic, runs ONCE with one lane per pair instead of redundantly
+    // in the 8 lanes of a group (that redundancy made the kernel VALU bound: 84 us for 3*10^4
+    // pairs).  Pair (round r, group s) is owned by lane 8 r + s; sums travel by shuffles.
     const int sub = lane & 7, slot = lane >> 3;
-    for (int64_t base = wave0 * 8; base < (int64_t)n_pairs; base += nwaves * 8) {
-      const int64_t p = base + slot;
-      const bool on = p < (int64_t)n_pairs;
+    constexpr int kRounds = FC_REFINE_ROUNDS;  // pairs per wavefront = 8 * kRounds
+    for (int64_t base = wave0 * (8 * kRounds); base < (int64_t)n_pairs; base += nwaves * (8 * kRounds)) {
+      const int64_t p_own = base + lane;
+      const bool on = lane < 8 * kRounds && p_own < (int64_t)n_pairs;
+      const uint64_t e = on ? pairq[p_own] : 0ull;
+      double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll FC_REFINE_UNROLL
+      for (int round = 0; round < kRounds; ++round) {
+        const uint64_t eg = __shfl(e, round * 8 + slot);  // the pair of this 8-lane group
+        const bool og = base + round * 8 + slot < (int64_t)n_pairs;
+        double Bg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (og) {
+          const double *__restrict__ pp = Xa + (int64_t)(eg >> 32) * (int64_t)A * 3;
+          const double *__restrict__ qq = Xa + (int64_t)(eg & 0xffffffffull) * (int64_t)A * 3;
+          for (int a = sub; a < A; a += 8) {
+            const double px = pp[a * 3], py = pp[a * 3 + 1], pz = pp[a * 3 + 2];
+            const double qx = qq[a * 3], qy = qq[a * 3 + 1], qz = qq[a * 3 + 2];
+            Bg[0] = fma(px, qx, Bg[0]); Bg[1] = fma(px, qy, Bg[1]); Bg[2] = fma(px, qz, Bg[2]);
+            Bg[3] = fma(py, qx, Bg[3]); Bg[4] = fma(py, qy, Bg[4]); Bg[5] = fma(py, qz, Bg[5]);
+            Bg[6] = fma(pz, qx, Bg[6]); Bg[7] = fma(pz, qy, Bg[7]); Bg[8] = fma(pz, qz, Bg[8]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const double tot = group8_sum(Bg[k]);
+          const double mine = __shfl(tot, sub * 8);  // group `sub` holds the pair lane 8*round+sub owns
+          if (slot == round) B[k] = mine;
+        }
+      }
+      double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      if (on) (void)kabsch_rotation(B, R);
+      double ssq_own = 0.0, mx_own = 0.0;
+#pragma unroll FC_REFINE_UNROLL
+      for (int round = 0; round < kRounds; ++round) {
+        const uint64_t eg = __shfl(e, round * 8 + slot);
+        const bool og = base + round * 8 + slot < (int64_t)n_pairs;
+        double Rg[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rg[k] = __shfl(R[k], round * 8 + slot);
+        double ssq = 0.0, mx = 0.0;
+        if (og) {
+          const double *__restrict__ pp = Xa + (int64_t)(eg >> 32) * (int64_t)A * 3;
+          const double *__restrict__ qq = Xa + (int64_t)(eg & 0xffffffffull) * (int64_t)A * 3;
+          for (int a = sub; a < A; a += 8) {
+            const double px = pp[a * 3], py = pp[a * 3 + 1], pz = pp[a * 3 + 2];
+            const double qx = qq[a * 3], qy = qq[a * 3 + 1], qz = qq[a * 3 + 2];
+            const double dx = px - (Rg[0] * qx + Rg[1] * qy + Rg[2] * qz);
+            const double dy = py - (Rg[3] * qx + Rg[4] * qy + Rg[5] * qz);
+            const double dz = pz - (Rg[6] * qx + Rg[7] * qy + Rg[8] * qz);
+            const double sq = dx * dx + dy * dy + dz * dz;
+            ssq += sq;
+            mx = fmax(mx, sq);
+          }
+        }
+        const double ts = __shfl(group8_sum(ssq), sub * 8), tm = __shfl(group8_max(mx), sub * 8);
+        if (slot == round) {
+          ssq_own = ts;
+          mx_own = tm;
+        }
+      }
       bool sim = false, grey = false;
-      uint64_t e = 0;
-      if (on) {  // uniform inside each 8-lane group
-        e = pairq[p];
+      if (on) {
         const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
-        double r, m;
-        pair_exact_group8(Xa, A, i, j, sub, r, m);
+        const double r = sqrt(ssq_own / (double)A), m = sqrt(mx_own);
         sim = (r < max_rmsd) && (m < max_dev);
         grey = (fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9);
         if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
-        if (!sim && sub == 0) {
+        if (!sim) {
           const int64_t lrow = ((i / IB) / world) * IB + (i % IB);
           atomicAnd(reinterpret_cast<unsigned long long *>(&bits[lrow * W + (j >> 6)]),
                     ~(1ull << (j & 63)));
         }
       }
-      // one representative lane per pair in the ballots
-      const bool rep = on && sub == 0;
-      const uint64_t mo = __ballot(rep), ms = __ballot(rep && sim), mg = __ballot(rep && grey);
+      const uint64_t mo = __ballot(on), ms = __ballot(on && sim), mg = __ballot(on && grey);
       unsigned long long sbase = 0;
       if (lane == 0) {
         atomicAdd(&counters[1], (unsigned long long)__popcll(mo));
@@ -831,7 +893,7 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
       // list of exactly-similar pairs (same capacity as the candidate queue):
       // what the one-launch ladder and the multi-GPU exchange consume
       sbase = __shfl(sbase, 0);
-      if (rep && sim) simq[sbase + (unsigned long long)__popcll(ms & ((1ull << lane) - 1ull))] = e;
+      if (on && sim) simq[sbase + (unsigned long long)__popcll(ms & ((1ull << lane) - 1ull))] = e;
     }
     return;
   }
