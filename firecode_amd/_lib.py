@@ -71,6 +71,7 @@ _SIGNATURES = {
     "fc_prune_export_pairs_dev": [_ens, C.c_void_p, _i64],
     "fc_prune_from_gathered_dev": [_ens, C.c_void_p, _i64, _i64, _i64, _p_u8, _p_i64],
     "fc_stream_set": [C.c_void_p],
+    "fc_memory_trim": [],
     "fc_inertia_moments": [_p_f64, _i64, _i64, _p_f64, _p_f64],
     "fc_prune_rmsd_rot_corr": [_p_f64, _i64, _i64, _p_u8, _p_i64, _i64, _p_u8, _p_f64, C.POINTER(C.c_int32), _i64,
                                _f64, _f64, _p_f64, _f64, _i64, _p_u8, _p_u64],
@@ -221,6 +222,11 @@ def stream_set(hip_stream):
     """Enqueue on the caller's HIP stream (integer handle, e.g. ``torch.cuda.Stream().cuda_stream``);
     None / 0 switches back to the library's own stream."""
     call("fc_stream_set", C.c_void_p(int(hip_stream) if hip_stream else None))
+
+
+def memory_trim():
+    """Return the device blocks kept by the library's caching pool to the HIP runtime."""
+    call("fc_memory_trim")
 
 
 def device_count():

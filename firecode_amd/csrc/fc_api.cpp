@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <memory>
 
+#include <map>
+#include <mutex>
 #include "fc_common.h"
 
 namespace fc {
@@ -105,10 +107,93 @@ Context &ctx() {
   return c;
 }
 
+// ---- caching pool behind DevBuf (fc_common.h) ---------------------------------------------
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::multimap<size_t, void *> free_blocks;  // capacity -> block
+  size_t cached = 0;
+  size_t limit = (size_t)2048 << 20;
+  bool limit_read = false;
+};
+Pool &pool() {
+  static Pool *p = new Pool;  // never destroyed: DevBufs with static storage may outlive it otherwise
+  return *p;
+}
+size_t size_class(size_t n) {
+  if (n <= 256) return 256;
+  if (n <= ((size_t)1 << 20)) {
+    size_t c = 256;
+    while (c < n) c <<= 1;
+    return c;
+  }
+  const size_t step = (size_t)2 << 20;
+  return (n + step - 1) / step * step;
+}
+}  // namespace
+
+void *pool_take(size_t n, size_t *capacity) {
+  Pool &P = pool();
+  const size_t want = size_class(n);
+  {
+    std::lock_guard<std::mutex> lock(P.mu);
+    if (!P.limit_read) {
+      if (const char *v = getenv("FC_POOL_MB")) P.limit = (size_t)std::strtoull(v, nullptr, 10) << 20;
+      P.limit_read = true;
+    }
+    auto it = P.free_blocks.lower_bound(want);
+    if (it != P.free_blocks.end() && it->first <= 2 * want) {  // never hand a huge block to a small request
+      void *p = it->second;
+      *capacity = it->first;
+      P.cached -= it->first;
+      P.free_blocks.erase(it);
+      return p;
+    }
+  }
+  void *p = nullptr;
+  if (hipMalloc(&p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    pool_trim();  // give the cached blocks back and try once more
+    if (hipMalloc(&p, want) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+  }
+  *capacity = want;
+  return p;
+}
+
+void pool_give(void *p, size_t capacity) {
+  if (!p) return;
+  Pool &P = pool();
+  {
+    std::lock_guard<std::mutex> lock(P.mu);
+    if (ctx().ready && P.cached + capacity <= P.limit) {
+      P.free_blocks.emplace(capacity, p);
+      P.cached += capacity;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
+void pool_trim() {
+  Pool &P = pool();
+  std::multimap<size_t, void *> blocks;
+  {
+    std::lock_guard<std::mutex> lock(P.mu);
+    blocks.swap(P.free_blocks);
+    P.cached = 0;
+  }
+  for (auto &b : blocks) (void)hipFree(b.second);
+}
+
 static int do_init(int device) {
   Context &c = ctx();
   if (c.ready && c.device == device) return FC_OK;
   if (c.ready) {
+    (void)hipStreamSynchronize(c.stream);
+    pool_trim();  // cached blocks belong to the device being left
     (void)hipStreamDestroy(c.own_stream);
     c.ready = false;
   }
@@ -366,6 +451,7 @@ int fc_shutdown(void) {
   Context &c = ctx();
   if (c.ready) {
     (void)hipStreamSynchronize(c.stream);
+    pool_trim();
     (void)hipEventDestroy(c.ev0);
     (void)hipEventDestroy(c.ev1);
     (void)hipEventDestroy(c.ev2);
@@ -381,6 +467,12 @@ int fc_shutdown(void) {
 }
 
 const char *fc_last_error(void) { return last_error().c_str(); }
+
+int fc_memory_trim(void) {
+  if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+  pool_trim();
+  return FC_OK;
+}
 
 int fc_stream_set(void *hip_stream) {
   FC_TRY(ensure_init());

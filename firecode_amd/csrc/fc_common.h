@@ -58,7 +58,17 @@ int pinned_reserve(size_t bytes);  // grows ctx().pinned
 Context &ctx();
 int ensure_init();  // lazy init on device 0 (or the one given to fc_init)
 
-// ---- RAII device buffer -------------------------------------------------------
+// ---- device memory: grow-only RAII buffers over a small caching pool ------------------
+// hipMalloc / hipFree cost ~0.1-0.3 ms each and hipFree synchronises the device; a drop-in
+// call (host arrays in, mask out) makes 5-15 temporaries.  Released blocks are therefore
+// kept (size classes: powers of two up to 1 MiB, multiples of 2 MiB above) and handed out
+// again.  Reuse is safe because everything of this library is enqueued on ONE stream
+// (fc_stream_set drains the old one): the next user of a block is ordered behind the last.
+// FC_POOL_MB caps what is kept (default 2048, 0 = no caching); fc_memory_trim() empties it.
+void *pool_take(size_t n, size_t *capacity);  // nullptr when the device is out of memory
+void pool_give(void *p, size_t capacity);
+void pool_trim();
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -67,7 +77,7 @@ struct DevBuf {
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) pool_give(p, bytes);
     p = nullptr;
     bytes = 0;
   }
@@ -76,12 +86,10 @@ struct DevBuf {
     if (n <= bytes && p) return FC_OK;
     release();
     if (n == 0) n = 8;
-    hipError_t e = hipMalloc(&p, n);
-    if (e != hipSuccess) {
-      p = nullptr;
-      return set_error(FC_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
-    }
-    bytes = n;
+    size_t cap = 0;
+    p = pool_take(n, &cap);
+    if (!p) return set_error(FC_E_NOMEM, "device allocation of %zu bytes failed", n);
+    bytes = cap;
     return FC_OK;
   }
   template <class T>

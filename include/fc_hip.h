@@ -48,6 +48,10 @@ const char *fc_last_error(void);
  * stream; NULL switches back.  The previous stream is drained first.  The legacy null
  * stream cannot be named this way (NULL means "own stream"). */
 int fc_stream_set(void *hip_stream);
+/* Device temporaries of the entry points come from a caching pool (released blocks are kept
+ * and reused; FC_POOL_MB caps what is kept, default 2048, 0 disables).  fc_memory_trim returns
+ * the kept blocks to the HIP runtime; fc_shutdown does the same. */
+int fc_memory_trim(void);
 /* name, CU count and bytes of HBM of the active device (diagnostics) */
 int fc_device_info(char *name, int64_t name_len, int64_t *n_cu, int64_t *hbm_bytes);
 

@@ -157,7 +157,31 @@ def tri():
                       "accepted": int(len(poses)), "seconds": dt, "poses_per_s": n_poses / dt}))
 
 
+def small():
+    """latency of one-structure calls through the drop-in names (what FIRECODE's Python loops issue)"""
+    rng = np.random.default_rng(3)
+    c = rng.normal(scale=2.0, size=(36, 3))
+    p, q = rng.normal(size=(30, 3)), rng.normal(size=(30, 3))
+    X = rng.normal(scale=2.0, size=(200, 30, 3))
+    atoms = np.array(["C"] * 30)
+
+    def lat(fn, n=200):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    print(json.dumps({
+        "workload": "per-call latency (us), host arrays in -> result out, pool FC_POOL_MB=%s" % os.environ.get("FC_POOL_MB", "default"),
+        "compenetration_check_36_atoms": lat(lambda: fc.utils.compenetration_check(c, ids=[20, 16], thresh=1.5)),
+        "rmsd_and_max_30_atoms": lat(lambda: fc.rmsd.rmsd_and_max(p, q)),
+        "count_clashes_36_atoms": lat(lambda: fc.algebra.count_clashes(c)),
+        "prune_by_rmsd_200x30": lat(lambda: fc.pruner.prune_by_rmsd(X, atoms, 0.5), n=50),
+    }))
+
+
 if __name__ == "__main__":
     fc.init(0)
     for w in sys.argv[1:] or ["embed", "csearch", "prune80"]:
-        {"embed": embed, "csearch": csearch, "prune80": prune80, "pcie": pcie, "values": values, "tri": tri}[w]()
+        {"embed": embed, "csearch": csearch, "prune80": prune80, "pcie": pcie, "values": values, "tri": tri, "small": small}[w]()
