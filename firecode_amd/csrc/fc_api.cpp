@@ -336,7 +336,7 @@ static int simbits_local(fc_ensemble *e, double max_rmsd, double max_dev, const 
     en_dev = e->energies.as<double>();
   }
   if (zero_counters)
-    FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, 8 * sizeof(uint64_t), ctx().stream));
+    FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, 16 * sizeof(uint64_t), ctx().stream));
   // HIP events bracket the screen kernel (the dominant one) on the library's stream
   FC_HIP_TRY(hipEventRecord(ctx().ev2, ctx().stream));
   FC_TRY(launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin));
@@ -368,10 +368,10 @@ static const unsigned long long kPairLadderCap = 1ull << 20;
 static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_per_group,
                          uint8_t *mask_out, int64_t *levels, int64_t *survivors,
                          unsigned long long *counters_out = nullptr, const uint64_t *pairs_dev = nullptr,
-                         bool pairs_are_final = false) {
+                         bool pairs_are_final = false, bool counters_zeroed = false) {
   const int64_t N = e->N, W = e->W;
   const int n_ladder = (int)(sizeof(kLadder) / sizeof(kLadder[0]));
-  FC_TRY(e->ladder.reserve((size_t)(n_ladder + 1) * W * sizeof(uint64_t)));
+  FC_TRY(e->ladder.reserve(((size_t)(n_ladder + 1) * W + 16) * sizeof(uint64_t)));
   FC_TRY(pinned_reserve((size_t)(W + 16) * sizeof(uint64_t)));
   uint64_t *mb = e->ladder.as<uint64_t>();
   auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
@@ -381,7 +381,7 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
     if (k == 1 || min_per_group * k < N) ks.push_back(k);
   const int n_lv = (int)ks.size();
   // counters[8] = levels run, counters[9] = "k_ladder_pairs produced the mask"
-  FC_HIP_TRY(hipMemsetAsync(cnt + 8, 0, 2 * sizeof(uint64_t), ctx().stream));
+  if (!counters_zeroed) FC_HIP_TRY(hipMemsetAsync(cnt + 8, 0, 2 * sizeof(uint64_t), ctx().stream));
   uint64_t *words = static_cast<uint64_t *>(ctx().pinned);
   uint64_t *cnt_host = words + W;
   bool have_mask = false;
@@ -400,8 +400,8 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
                                pairs_are_final ? nullptr : cnt + 6,
                                (unsigned long long)e->pairq_cap, kPairLadderCap, N, W, min_per_group,
                                e->ladder_k.as<int64_t>(), n_lv, mb + (size_t)n_lv * W, cnt));
-    FC_TRY(d2h(words, mb + (size_t)n_lv * W, (size_t)W * sizeof(uint64_t)));
-    FC_TRY(d2h(cnt_host, cnt, 16 * sizeof(uint64_t)));
+    // mask words and the 16 counters behind them (written by the kernel): one copy
+    FC_TRY(d2h(words, mb + (size_t)n_lv * W, (size_t)(W + 16) * sizeof(uint64_t)));
     FC_TRY(sync());
     have_mask = cnt_host[9] != 0;
   }
@@ -687,7 +687,7 @@ int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const doubl
   unsigned long long cnt[8];
   int64_t levels = 0, survivors = 0;
   FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), min_per_group, mask_out, &levels, &survivors, cnt,
-                       ens->simq.as<uint64_t>()));
+                       ens->simq.as<uint64_t>(), false, true));
   if (stats) {
     stats[0] = ens->N * (ens->N - 1) / 2;
     stats[1] = (int64_t)cnt[1];
@@ -1562,14 +1562,14 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
   int64_t levels = 0, survivors = 0;
   unsigned long long cnt[8] = {0};
   for (int64_t r = 0; r < reps; ++r) {
-    FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 8 * sizeof(uint64_t), c.stream));
+    FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 16 * sizeof(uint64_t), c.stream));
     FC_HIP_TRY(hipEventRecord(c.ev0, c.stream));
     FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
     FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
     FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
     ens->bits_valid = true;
-    FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, r + 1 == reps ? mask_out : nullptr, &levels,
-                         &survivors, cnt, ens->simq.as<uint64_t>()));
+    FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, mask_out, &levels, &survivors, cnt,
+                         ens->simq.as<uint64_t>(), false, true));
     FC_HIP_TRY(hipEventRecord(c.ev2, c.stream));
     FC_HIP_TRY(hipEventSynchronize(c.ev2));
     float a = 0.f, b = 0.f;

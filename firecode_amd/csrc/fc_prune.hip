@@ -198,6 +198,7 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ 
   const unsigned long long P = *n_pairs_ptr;
   if ((n_cand_ptr != nullptr && *n_cand_ptr > cand_cap) || P > cap) {
     if (tid == 0) counters[9] = 0;
+    if (tid < 16) mask_out[W + tid] = tid == 9 ? 0ull : counters[tid];
     return;
   }
   unsigned long long *cur = lm, *nxt = lm + W;
@@ -254,6 +255,9 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ 
     counters[8] = (unsigned long long)levels;
     counters[9] = 1;
   }
+  // the 16 counters ride behind the mask words so that the host needs ONE copy
+  if (tid < 16)
+    mask_out[W + tid] = tid == 8 ? (unsigned long long)levels : tid == 9 ? 1ull : counters[tid];
 }
 
 // ---------------------------------------------------------------------------
