@@ -62,7 +62,7 @@ int launch_embed_poses_clash(const double *, int64_t, const double *, int64_t, c
                              double *);
 int launch_torsion_scan(const double *, int64_t, const int64_t *, int64_t, const uint8_t *,
                         const int16_t *, const int16_t *, const int32_t *, const int32_t *,
-                        const int64_t *, int64_t, double, int64_t, double *, int64_t *);
+                        const int64_t *, int64_t, double, int64_t, double *, int64_t *, const int64_t *, int64_t, double *);
 int launch_torsion_fingerprint(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
 int launch_tfd_first_match(const double *, int64_t, int64_t, int64_t, double, int64_t *);
 int tfd_ladder_from_first_match(const int64_t *, int64_t, uint8_t *);
@@ -1398,14 +1398,18 @@ int fc_string_embed(const double *m1, int64_t n1, int64_t A1, const double *cent
 }
 
 // ---- a17-a20 -----------------------------------------------------------------------
-int fc_torsion_scan(const double *base, int64_t A, const int64_t *torsions, int64_t T,
-                    const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
-                    int64_t backoff_deg, double *coords_out, int64_t *rotated_bonds_out) {
-  FC_REQUIRE(A >= 2 && T >= 1 && S >= 0, "bad shape");
+static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsions, int64_t T,
+                             const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
+                             int64_t backoff_deg, const int64_t *quads, int64_t Q, double *coords_out,
+                             int64_t *rotated_bonds_out, double *tf_out) {
+  FC_REQUIRE(A >= 2 && T >= 1 && S >= 0 && Q >= 0, "bad shape");
   FC_REQUIRE(backoff_deg != 0, "backoff_deg must be non-zero");
   if (S == 0) return FC_OK;
-  FC_REQUIRE(base && torsions && rotmasks && angles && coords_out && rotated_bonds_out,
-             "NULL pointer argument");
+  FC_REQUIRE(base && torsions && rotmasks && angles && rotated_bonds_out, "NULL pointer argument");
+  FC_REQUIRE(coords_out || tf_out, "nothing to compute: coords_out and tf_out are both NULL");
+  FC_REQUIRE(tf_out == nullptr || (quads != nullptr && Q >= 1), "fingerprints need quadruplets");
+  if (tf_out)
+    for (int64_t k = 0; k < Q * 4; ++k) FC_REQUIRE(quads[k] >= 0 && quads[k] < A, "quadruplet index out of range");
   if (4 * A * 24 > 160 * 1024 || A > 32767)
     return set_error(FC_E_LIMIT, "A=%lld too large for the LDS slice", (long long)A);
   // moving / rest index lists per torsion (torsion_module.py:907-915)
@@ -1421,7 +1425,7 @@ int fc_torsion_scan(const double *base, int64_t A, const int64_t *torsions, int6
     }
   }
   FC_TRY(ensure_init());
-  DevBuf db, dt, dmk, dmv, drs, dnm, dnr, da, dout, drot;
+  DevBuf db, dt, dmk, dmv, drs, dnm, dnr, da, dout, drot, dq, dtf;
   FC_TRY(upload(db, base, (size_t)A * 3));
   FC_TRY(upload(dt, torsions, (size_t)T * 4));
   FC_TRY(upload(dmk, rotmasks, (size_t)T * A));
@@ -1430,15 +1434,38 @@ int fc_torsion_scan(const double *base, int64_t A, const int64_t *torsions, int6
   FC_TRY(upload(dnm, nmv.data(), nmv.size()));
   FC_TRY(upload(dnr, nrs.data(), nrs.size()));
   FC_TRY(upload(da, angles, (size_t)S * T));
-  FC_TRY(dout.reserve((size_t)S * A * 3 * sizeof(double)));
+  if (coords_out) FC_TRY(dout.reserve((size_t)S * A * 3 * sizeof(double)));
   FC_TRY(drot.reserve((size_t)S * sizeof(int64_t)));
+  if (tf_out) {
+    FC_TRY(upload(dq, quads, (size_t)Q * 4));
+    FC_TRY(dtf.reserve((size_t)S * Q * sizeof(double)));
+  }
   FC_TRY(launch_torsion_scan(db.as<double>(), A, dt.as<int64_t>(), T, dmk.as<uint8_t>(),
                              dmv.as<int16_t>(), drs.as<int16_t>(), dnm.as<int32_t>(),
                              dnr.as<int32_t>(), da.as<int64_t>(), S, thresh, backoff_deg,
-                             dout.as<double>(), drot.as<int64_t>()));
-  FC_TRY(d2h(coords_out, dout.p, (size_t)S * A * 3 * sizeof(double)));
+                             coords_out ? dout.as<double>() : nullptr, drot.as<int64_t>(),
+                             tf_out ? dq.as<int64_t>() : nullptr, Q, tf_out ? dtf.as<double>() : nullptr));
+  if (coords_out) FC_TRY(d2h(coords_out, dout.p, (size_t)S * A * 3 * sizeof(double)));
+  if (tf_out) FC_TRY(d2h(tf_out, dtf.p, (size_t)S * Q * sizeof(double)));
   FC_TRY(d2h(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t)));
   return sync();
+}
+
+int fc_torsion_scan(const double *base, int64_t A, const int64_t *torsions, int64_t T,
+                    const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
+                    int64_t backoff_deg, double *coords_out, int64_t *rotated_bonds_out) {
+  FC_REQUIRE(S == 0 || coords_out != nullptr, "NULL pointer argument");
+  return torsion_scan_impl(base, A, torsions, T, rotmasks, angles, S, thresh, backoff_deg, nullptr, 0, coords_out,
+                           rotated_bonds_out, nullptr);
+}
+
+int fc_torsion_scan_fingerprints(const double *base, int64_t A, const int64_t *torsions, int64_t T,
+                                 const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
+                                 int64_t backoff_deg, const int64_t *quads, int64_t Q, double *tf_out,
+                                 int64_t *rotated_bonds_out, double *coords_out) {
+  FC_REQUIRE(S == 0 || tf_out != nullptr, "NULL pointer argument");
+  return torsion_scan_impl(base, A, torsions, T, rotmasks, angles, S, thresh, backoff_deg, quads, Q, coords_out,
+                           rotated_bonds_out, tf_out);
 }
 
 int fc_torsion_fingerprint(const double *coords, int64_t N, int64_t A, const int64_t *quads,

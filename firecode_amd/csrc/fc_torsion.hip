@@ -78,12 +78,31 @@ __device__ __forceinline__ bool comp_check(const double *x, const int16_t *mv, i
 }
 
 
+// dihedral (prism_pruner.algebra.dihedral, "praxeolitic" form) per lane
+__device__ __forceinline__ double dihedral_deg(const double *p0, const double *p1, const double *p2,
+                                               const double *p3) {
+  const double b0x = -1.0 * (p1[0] - p0[0]), b0y = -1.0 * (p1[1] - p0[1]), b0z = -1.0 * (p1[2] - p0[2]);
+  double b1x = p2[0] - p1[0], b1y = p2[1] - p1[1], b1z = p2[2] - p1[2];
+  const double b2x = p3[0] - p2[0], b2y = p3[1] - p2[1], b2z = p3[2] - p2[2];
+  const double n1 = sqrt((b1x * b1x + b1y * b1y) + b1z * b1z);
+  b1x /= n1; b1y /= n1; b1z /= n1;
+  const double d0 = (b0x * b1x + b0y * b1y) + b0z * b1z;
+  const double d2 = (b2x * b1x + b2y * b1y) + b2z * b1z;
+  const double vx = b0x - d0 * b1x, vy = b0y - d0 * b1y, vz = b0z - d0 * b1z;
+  const double wx = b2x - d2 * b1x, wy = b2y - d2 * b1y, wz = b2z - d2 * b1z;
+  const double xx = (vx * wx + vy * wy) + vz * wz;
+  const double cx = b1y * vz - b1z * vy, cy = b1z * vx - b1x * vz, cz = b1x * vy - b1y * vx;
+  const double yy = (cx * wx + cy * wy) + cz * wz;
+  return atan2(yy, xx) * (180.0 / 3.141592653589793);
+}
+
 __global__ void __launch_bounds__(256)
 k_torsion_scan(const double *__restrict__ base, int A, const int64_t *__restrict__ torsions, int T,
                const uint8_t *__restrict__ rotmasks, const int16_t *__restrict__ mv_idx,
                const int16_t *__restrict__ rs_idx, const int32_t *__restrict__ n_mv,
                const int32_t *__restrict__ n_rs, const int64_t *__restrict__ angles, int64_t S,
-               double thr2, int backoff, double *__restrict__ out, int64_t *__restrict__ rotated) {
+               double thr2, int backoff, double *__restrict__ out, int64_t *__restrict__ rotated,
+               const int64_t *__restrict__ quads, int Q, double *__restrict__ tf) {
   extern __shared__ double s[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -118,8 +137,16 @@ k_torsion_scan(const double *__restrict__ base, int A, const int64_t *__restrict
         ++rot;
       }
     }
-    double *o = out + sidx * (int64_t)A * 3;
-    for (int k = lane; k < A * 3; k += 64) o[k] = x[k];
+    if (out != nullptr) {
+      double *o = out + sidx * (int64_t)A * 3;
+      for (int k = lane; k < A * 3; k += 64) o[k] = x[k];
+    }
+    // torsion fingerprint of the conformer while it is still in LDS (get_torsion_fingerprint,
+    // torsion_module.py:1070-1077): the same doubles a separate pass over `out` would read
+    if (tf != nullptr)
+      for (int q = lane; q < Q; q += 64)
+        tf[sidx * (int64_t)Q + q] = dihedral_deg(x + quads[q * 4] * 3, x + quads[q * 4 + 1] * 3,
+                                                 x + quads[q * 4 + 2] * 3, x + quads[q * 4 + 3] * 3);
     if (lane == 0) rotated[sidx] = rot;
     __builtin_amdgcn_wave_barrier();
   }
@@ -257,24 +284,6 @@ k_rotcorr_simbits(const double *__restrict__ X, int64_t N, int A, const uint8_t 
   if (lane == 0 && rmsd < max_rmsd && maxdev < max_dev) atomicOr(&bits[i * W + (j >> 6)], 1ull << (j & 63));
 }
 
-// dihedral (prism_pruner.algebra.dihedral, "praxeolitic" form) per lane
-__device__ __forceinline__ double dihedral_deg(const double *p0, const double *p1, const double *p2,
-                                               const double *p3) {
-  const double b0x = -1.0 * (p1[0] - p0[0]), b0y = -1.0 * (p1[1] - p0[1]), b0z = -1.0 * (p1[2] - p0[2]);
-  double b1x = p2[0] - p1[0], b1y = p2[1] - p1[1], b1z = p2[2] - p1[2];
-  const double b2x = p3[0] - p2[0], b2y = p3[1] - p2[1], b2z = p3[2] - p2[2];
-  const double n1 = sqrt((b1x * b1x + b1y * b1y) + b1z * b1z);
-  b1x /= n1; b1y /= n1; b1z /= n1;
-  const double d0 = (b0x * b1x + b0y * b1y) + b0z * b1z;
-  const double d2 = (b2x * b1x + b2y * b1y) + b2z * b1z;
-  const double vx = b0x - d0 * b1x, vy = b0y - d0 * b1y, vz = b0z - d0 * b1z;
-  const double wx = b2x - d2 * b1x, wy = b2y - d2 * b1y, wz = b2z - d2 * b1z;
-  const double xx = (vx * wx + vy * wy) + vz * wz;
-  const double cx = b1y * vz - b1z * vy, cy = b1z * vx - b1x * vz, cz = b1x * vy - b1y * vx;
-  const double yy = (cx * wx + cy * wy) + cz * wz;
-  return atan2(yy, xx) * (180.0 / 3.141592653589793);
-}
-
 __global__ void __launch_bounds__(256)
 k_torsion_fingerprint(const double *__restrict__ coords, int64_t N, int64_t A,
                       const int64_t *__restrict__ quads, int Q, double *__restrict__ tf) {
@@ -292,7 +301,7 @@ int launch_torsion_scan(const double *base_dev, int64_t A, const int64_t *torsio
                         const uint8_t *rotmasks_dev, const int16_t *mv_dev, const int16_t *rs_dev,
                         const int32_t *nmv_dev, const int32_t *nrs_dev, const int64_t *angles_dev,
                         int64_t S, double thresh, int64_t backoff, double *out_dev,
-                        int64_t *rot_dev) {
+                        int64_t *rot_dev, const int64_t *quads_dev, int64_t Q, double *tf_dev) {
   if (S == 0) return FC_OK;
   const double thr2 = sq_threshold_lt(thresh);
   int64_t blocks = ceil_div(S, 4);
@@ -301,7 +310,7 @@ int launch_torsion_scan(const double *base_dev, int64_t A, const int64_t *torsio
   hipLaunchKernelGGL(k_torsion_scan, dim3((unsigned)blocks), dim3(256),
                      (size_t)4 * A * 3 * sizeof(double), ctx().stream, base_dev, (int)A,
                      torsions_dev, (int)T, rotmasks_dev, mv_dev, rs_dev, nmv_dev, nrs_dev,
-                     angles_dev, S, thr2, (int)backoff, out_dev, rot_dev);
+                     angles_dev, S, thr2, (int)backoff, out_dev, rot_dev, quads_dev, (int)Q, tf_dev);
   return check_launch("k_torsion_scan");
 }
 

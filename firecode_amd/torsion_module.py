@@ -24,6 +24,26 @@ def torsion_scan(base, torsions, masks, angles, thresh=1.5, backoff=5):
     return out, rot
 
 
+def torsion_scan_fingerprints(base, torsions, masks, angles, quadruplets, thresh=1.5, backoff=5, want_coords=False):
+    """``torsion_scan`` plus the torsion fingerprint (degrees, (S, Q)) of every generated
+    conformer, taken inside the kernel; the (S, A, 3) conformers themselves are only
+    returned on request.  Returns (tf, rotated_bonds[, coords])."""
+    base = L.f64(base)
+    tors = L.i64(torsions).reshape(-1, 4)
+    msk = L.u8(np.asarray(masks, dtype=bool)).reshape(tors.shape[0], -1)
+    ang = L.i64(angles).reshape(-1, tors.shape[0])
+    quads = L.i64(quadruplets).reshape(-1, 4)
+    A, T, S, Q = base.shape[0], tors.shape[0], ang.shape[0], quads.shape[0]
+    if base.ndim != 2 or base.shape[1] != 3 or msk.shape[1] != A or Q == 0:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "base (A, 3), masks (T, A) and at least one quadruplet expected")
+    tf = np.empty((S, Q))
+    rot = np.zeros(S, dtype=np.int64)
+    out = np.empty((S, A, 3)) if want_coords else None
+    L.call("fc_torsion_scan_fingerprints", L.pf(base), A, L.pi(tors), T, L.pb(msk), L.pi(ang), S, float(thresh),
+           int(backoff), L.pi(quads), Q, L.pf(tf), L.pi(rot), None if out is None else L.pf(out))
+    return (tf, rot, out) if want_coords else (tf, rot)
+
+
 def torsion_comp_check(coords, torsion, mask, thresh=1.5, max_clashes=0):
     """firecode/torsion_module.py:894-918: rest-vs-moving clash count <= max_clashes."""
     X = L.f64(coords)
@@ -119,14 +139,23 @@ def clustered_csearch(coords, torsions, rotation_masks, n_out=100, thresh=1.5, s
     quads = np.array([t[:4] for t in torsions], dtype=np.int64)
     angles = cartesian_product(*[n_fold_angles[int(t[4])] for t in torsions])
     base = L.f64(coords)
-    out, rot = torsion_scan(base, quads, rotation_masks, angles, thresh=thresh)
-    new_structures = np.concatenate([base[None], out[rot != 0]])
+    # Fingerprint every scanned conformer inside the scan kernel, TFD-prune on the (S, Q)
+    # fingerprints, then generate coordinates only for the survivors -- the scan of 1.7 M
+    # angle-sets would otherwise move 2 GB of conformers to the host to keep a few thousand.
+    tf, rot = torsion_scan_fingerprints(base, quads, rotation_masks, angles, quads, thresh=thresh)
+    kept = np.flatnonzero(rot != 0)
+    tf_all = np.concatenate([get_torsion_fingerprint(base, quads)[None], tf[kept]])
+    n_new = len(tf_all)  # the starting structure first, as the reference lists it (:858-861)
     if logfunction is not None:
         logfunction(f"> Group 1/1 - {len(torsions)} bonds, {[int(t[4]) for t in torsions]} n-folds, "
                     f"1 starting point = {len(angles)} conformers")
-    pruned, _ = prune_conformers_tfd(new_structures, quads)
+    mask = prune_tfd_from_tf_mat(tf_all, 10)
+    survivors = np.flatnonzero(mask[1:])
+    pruned = torsion_scan(base, quads, rotation_masks, angles[kept[survivors]], thresh=thresh)[0]
+    if mask[0]:
+        pruned = np.concatenate([base[None], pruned])
     output = list(pruned)
-    if len(new_structures) > n_out:
+    if n_new > n_out:
         output = most_diverse_conformers(n_out, output, seed=seed)
     return np.array(output)
 

@@ -308,6 +308,14 @@ int fc_string_embed(const double *m1, int64_t n1, int64_t A1, const double *cent
 int fc_torsion_scan(const double *base, int64_t A, const int64_t *torsions, int64_t T,
                     const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
                     int64_t backoff_deg, double *coords_out, int64_t *rotated_bonds_out);
+/* The same scan with the torsion fingerprint of every generated conformer taken while it is
+ * still in LDS (get_torsion_fingerprint, torsion_module.py:1070-1077): tf_out (S, Q) degrees for
+ * quads (Q,4).  coords_out may be NULL -- for 1.7 M angle-sets the conformers are 2 GB of which
+ * prune_conformers_tfd keeps a few thousand: fingerprint all, prune, re-scan only the survivors. */
+int fc_torsion_scan_fingerprints(const double *base, int64_t A, const int64_t *torsions, int64_t T,
+                                 const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
+                                 int64_t backoff_deg, const int64_t *quads, int64_t Q, double *tf_out,
+                                 int64_t *rotated_bonds_out, double *coords_out);
 
 /* ---- a20: torsion fingerprints and TFD similarity bits --
  * firecode/torsion_module.py:1046-1076.

@@ -338,6 +338,20 @@ def test_align_by_moi_vs_oracle(fc):
     assert np.abs(out[0] - (X[0] - X[0].mean(axis=0))).max() < 1e-12
 
 
+def test_scan_with_fingerprints_equals_two_passes(fc):
+    """fc_torsion_scan_fingerprints: fingerprints taken inside the scan kernel == fingerprints of
+    the conformers the plain scan returns (and == the oracle's), with and without coordinates"""
+    base, tors, masks = _chain_case(30, 4, seed=36)
+    quads = np.array([[0, 3, 9, 20], [5, 6, 7, 8], [29, 2, 14, 1]] + [list(t) for t in tors])
+    angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 4)[::7]
+    out, rot = fc.torsion_module.torsion_scan(base, tors, masks, angles)
+    tf, rot2 = fc.torsion_module.torsion_scan_fingerprints(base, tors, masks, angles, quads)
+    tf3, rot3, out3 = fc.torsion_module.torsion_scan_fingerprints(base, tors, masks, angles, quads, want_coords=True)
+    assert np.array_equal(rot, rot2) and np.array_equal(rot, rot3) and np.array_equal(out, out3)
+    assert np.array_equal(tf, fc.torsion_module.get_tf_mat(out, quads)) and np.array_equal(tf, tf3)
+    assert np.abs(tf - o.get_tf_mat(o.torsion_scan(base, tors, masks, angles)[0], quads)).max() < 1e-9
+
+
 def test_rotate_dihedral_and_comp_check(fc, golden):
     base, tors, masks = _chain_case(20, 2, seed=32)
     new = fc.utils.rotate_dihedral(base, tors[0], 120, mask=masks[0])
