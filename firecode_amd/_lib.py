@@ -137,7 +137,10 @@ def _share_torch_hip_runtime():
     path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
     if not os.path.exists(path):
         return None
-    C.CDLL(path, mode=C.RTLD_GLOBAL)
+    try:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:  # an unusable torch install must not take the library down with it
+        return None
     return path
 
 

@@ -15,7 +15,9 @@
 // LINEAR_PROBES = 9, PERTURB_SHIFT = 5, growth used*4 / used*2 above 50 000,
 // rebuild in slot order) and the xxHash-style tuple hash (tupleobject.c).
 // tests/test_pyset_emulation.py checks both against the running interpreter.
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -310,8 +312,10 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
     const long t = std::strtol(v, nullptr, 10);
     if (t >= 1 && t <= 64) hw = (unsigned)t;
   }
+  const bool debug = getenv("FC_DEBUG") != nullptr;
   for (double kd : kl) {
     const int64_t k = (int64_t)kd;
+    const auto t_level = std::chrono::steady_clock::now();
     int64_t num_active = 0;
     for (int64_t i = 0; i < N; ++i) num_active += mask_out[i];
     if (!(k == 1 || 5 * k < num_active)) continue;
@@ -331,6 +335,10 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
       }
       for (auto &th : pool) th.join();
     }
+    if (debug)
+      fprintf(stderr, "[fc] tfd ladder k=%lld: %lld active in, %lld threads, %.1f ms\n", (long long)k,
+              (long long)num_active, (long long)nthreads,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_level).count());
   }
   return FC_OK;
 }
