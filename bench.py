@@ -28,7 +28,7 @@ N_CONF, N_ATOMS, MAX_RMSD = 10000, 50, 0.5
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(coords, budget_s=20.0):
+def cpu_baseline(coords, budget_s=float(os.environ.get("FC_BENCH_CPU_SECONDS", "20"))):
     """Oracle ('port' of the reference's per-pair NumPy path) on a bounded
     sample: all pairs of the first n0 conformers, one core."""
     from oracle import cpu_ref as o
