@@ -263,3 +263,81 @@ def cyclical_embed_trimolecular(mols, systematic_angles, pairings_table=None, in
         return poses, constrained, {"jobs": jobs, "directions": dirs_out, "passed": passed.astype(bool),
                                     "accepted": accepted.astype(bool), "run": np.array(run).astype(bool)}
     return poses, constrained
+
+
+def cyclical_embed_bimolecular(mols, systematic_angles, pairings_table=None, internal_constraints=(),
+                               clash_thresh=1.5, max_clashes=0, rmsd_thr=1.0, max_norm_delta=10.0):
+    """``_fast_bimol_rigid_cyclical_embed`` (firecode/embeds.py:588-750) for two molecules
+    given like in ``cyclical_embed_trimolecular`` (any number of pivots per conformer).
+
+    Every (conformer, pivot) of a molecule becomes one entry of its table, the whole pose grid
+    -- clash test and the in-group ``rmsd_similarity`` filter -- is ONE library call
+    (``fc_embed_grid_dedupe``); the host then walks the reference's loop order (conformer pairs,
+    pivot pairs, orientation), drops what the reference skips (pivot norms more than
+    ``max_norm_delta`` apart, :624-626; orientations that do not realise the requested
+    pairings, :640-643) and builds the accepted poses.  ``systematic_angles`` must be the
+    embedder's grid (embedder.py:1090-1098).  Returns (poses, constrained_indices (P, 2, 2))."""
+    from firecode_amd import host_helpers as hh
+
+    if len(mols) != 2:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "two molecules expected")
+    coords, reactive, pivots, _ = zip(*[_tri_mol(m) for m in mols])
+    ang = L.f64(systematic_angles).reshape(-1, 2)
+    ua = [np.unique(ang[:, i]) for i in range(2)]
+    grid = np.stack([np.tile(ua[0], len(ua[1])), np.repeat(ua[1], len(ua[0]))], axis=1)
+    if grid.shape != ang.shape or not np.array_equal(grid, ang):
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "systematic_angles is not the cartesian_product grid of the embedder")
+    # tables of (conformer, pivot) entries
+    vconf, vpiv, vidx = [], [], []
+    for m in range(2):
+        conf_of, piv_of, index = [], [], []
+        for c in range(len(coords[m])):
+            row = []
+            for p, pv in enumerate(pivots[m][c]):
+                row.append(len(conf_of))
+                conf_of.append(c)
+                piv_of.append(pv)
+            index.append(row)
+        vconf.append(np.array(conf_of, dtype=np.int64))
+        vpiv.append(piv_of)
+        vidx.append(index)
+    A = [c.shape[1] for c in coords]
+    if min(len(v) for v in vconf) == 0:
+        return np.empty((0, sum(A), 3)), np.empty((0, 2, 2), dtype=np.int64)
+    vcoords = [np.ascontiguousarray(coords[m][vconf[m]]) for m in range(2)]
+    vpv = [np.array([[np.asarray(p[0], float), np.asarray(p[1], float)] for p in vpiv[m]]) for m in range(2)]
+    norms = [np.linalg.norm(vpv[m][:, 0] - vpv[m][:, 1], axis=1) for m in range(2)]
+    acc, _ = embed_grid_poses(vcoords[0], reactive[0], vpv[0], vcoords[1], reactive[1], vpv[1], ua[0], ua[1],
+                              thresh=clash_thresh, max_clashes=max_clashes, rmsd_thr=rmsd_thr)
+    wanted = [tuple(p) for p in pairings_table.values()] if pairings_table else []
+    internal = [tuple(c) for c in np.asarray(internal_constraints).tolist()] if len(internal_constraints) else []
+    sel_vb, sel_va, sel_o, sel_a2, sel_a1, cons = [], [], [], [], [], []
+    n0, n1 = len(coords[0]), len(coords[1])
+    for c1 in range(n1):          # cartesian_product: the second molecule's index is the slowest
+        for c0 in range(n0):
+            for p1 in range(len(vidx[1][c1])):
+                for p0 in range(len(vidx[0][c0])):
+                    va, vb = vidx[0][c0][p0], vidx[1][c1][p1]
+                    if abs(norms[0][va] - norms[1][vb]) > max_norm_delta:
+                        continue
+                    cum = [(int(vpiv[0][va][2]), int(vpiv[0][va][3])), (int(vpiv[1][vb][2]), int(vpiv[1][vb][3]))]
+                    for orient in (0, 1):
+                        ids = hh.cyclical_reactive_indices(cum[0], cum[1], orient)
+                        if wanted and not all((p in ids) or (p in internal) for p in wanted):
+                            continue
+                        a2i, a1i = np.nonzero(acc[vb, va, orient])
+                        sel_vb.extend([vb] * len(a1i))
+                        sel_va.extend([va] * len(a1i))
+                        sel_o.extend([orient] * len(a1i))
+                        sel_a2.extend(a2i.tolist())
+                        sel_a1.extend(a1i.tolist())
+                        cons.extend([ids] * len(a1i))
+    if not sel_va:
+        return np.empty((0, sum(A), 3)), np.empty((0, 2, 2), dtype=np.int64)
+    R0, t0 = embed_mol_transforms(vcoords[0], reactive[0], vpv[0], 0, ua[0])
+    R1, t1 = embed_mol_transforms(vcoords[1], reactive[1], vpv[1], 1, ua[1])
+    va, vb, oo = np.array(sel_va), np.array(sel_vb), np.array(sel_o)
+    a1i, a2i = np.array(sel_a1), np.array(sel_a2)
+    part0 = rototranslate(vcoords[0][va], R0[va, oo, a1i], t0[va, oo, a1i])
+    part1 = rototranslate(vcoords[1][vb], R1[vb, oo, a2i], t1[vb, oo, a2i])
+    return np.concatenate([part0, part1], axis=1), np.array(cons, dtype=np.int64).reshape(-1, 2, 2)

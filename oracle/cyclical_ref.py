@@ -1,4 +1,5 @@
-"""CPU restatement of the TRIMOLECULAR cyclical embed -- TEST INFRASTRUCTURE ONLY.
+"""CPU restatement of the cyclical embed drivers (trimolecular ``cyclical_embed`` and the
+bimolecular ``_fast_bimol_rigid_cyclical_embed``, embeds.py:588-750) -- TEST INFRASTRUCTURE ONLY.
 
 Only ``tests/`` may import this module (same rule as ``oracle/cpu_ref.py``); the
 product path is the HIP library and never routes through here.
@@ -269,3 +270,75 @@ def cyclical_embed_trimolecular(objects, systematic_angles, pairings_table=None,
                                       np.array(directions), np.array(passed), np.array(accepted)))
     n_atoms = sum(ids_atoms)
     return (np.array(poses) if poses else np.empty((0, n_atoms, 3))), np.array(constrained_indices, dtype=np.int64).reshape(-1, 3, 2)
+
+
+def get_cyclical_reactive_indices_bimol(pivots, n):
+    """embeds.py:753-773, bimolecular branch (couples are NOT sorted here)."""
+    cumulative_pivots_ids = [[p.start_cumnum, p.end_cumnum] for p in pivots]
+    swaps = [(0, 0), (0, 1)]
+    oriented = [list(reversed(ids)) if swaps[n][i] else ids for i, ids in enumerate(cumulative_pivots_ids)]
+    return [(oriented[0][0], oriented[1][0]), (oriented[0][1], oriented[1][1])]
+
+
+def cyclical_embed_bimolecular(objects, systematic_angles, pairings_table=None, internal_constraints=(),
+                               clash_thresh=1.5, max_norm_delta=10.0, trace=None):
+    """``_fast_bimol_rigid_cyclical_embed`` (embeds.py:588-750), literal, with plain data
+    for the Embedder.  Returns (poses, constrained_indices (P, 2, 2))."""
+    ids_atoms = [m.coords.shape[1] for m in objects]
+    conf_number = [len(mol.coords) for mol in objects]
+    conf_indices = o.cartesian_product(*[np.array(range(i)) for i in conf_number])
+    poses, constrained_indices = [], []
+    for conf_ids in conf_indices:
+        pivots_indices = o.cartesian_product(
+            *[range(len(mol.pivots[conf_ids[i]])) for i, mol in enumerate(objects)]
+        )
+        for pi in pivots_indices:
+            pivots = [objects[m].pivots[conf_ids[m]][pi[m]] for m, _ in enumerate(objects)]
+            norms = np.linalg.norm(np.array([p.pivot for p in pivots]), axis=1)
+            if abs(norms[0] - norms[1]) > max_norm_delta:
+                continue
+            polygon_vectors = o.polygonize(norms)
+            directions = np.array([[0, 1, 0], [0, -1, 0]])
+            for v, vecs in enumerate(polygon_vectors):
+                ids = get_cyclical_reactive_indices_bimol(pivots, v)
+                if not pairings_table or all(
+                    (pair in ids) or (pair in list(internal_constraints)) for pair in pairings_table.values()
+                ):
+                    angular_poses = []
+                    n_acc = 0
+                    for angles in systematic_angles:
+                        for i, vec_pair in enumerate(vecs):
+                            start, end = vec_pair
+                            angle = angles[i]
+                            reactive_coords = objects[i].coords[conf_ids[i]][objects[i].reactive_indices]
+                            atomic_pivot_mean = np.mean(reactive_coords, axis=0)
+                            mol_direction = pivots[i].meanpoint - atomic_pivot_mean
+                            if np.all(mol_direction == 0.0):
+                                mol_direction = pivots[i].meanpoint
+                            alignment_rotation = o.align_vec_pair(
+                                np.array([end - start, directions[i]]),
+                                np.array([pivots[i].pivot, mol_direction]),
+                            )
+                            if len(reactive_coords) == 2:
+                                axis_of_step_rotation = alignment_rotation @ (reactive_coords[0] - reactive_coords[1])
+                            else:
+                                axis_of_step_rotation = alignment_rotation @ pivots[i].pivot
+                            step_rotation = o.rot_mat_from_pointer(axis_of_step_rotation, angle)
+                            center_of_rotation = alignment_rotation @ atomic_pivot_mean
+                            objects[i].rotation = step_rotation @ alignment_rotation
+                            pos = np.mean(vec_pair, axis=0) - alignment_rotation @ pivots[i].meanpoint
+                            objects[i].position = center_of_rotation - step_rotation @ center_of_rotation + pos
+                        embedded_structure = o.get_embed(
+                            [m.coords[c] for m, c in zip(objects, conf_ids)],
+                            [m.rotation for m in objects], [m.position for m in objects])
+                        if o.compenetration_check(embedded_structure, ids=ids_atoms, thresh=clash_thresh):
+                            if not o.rmsd_similarity(embedded_structure, np.array(angular_poses), rmsd_thr=1):
+                                poses.append(embedded_structure)
+                                angular_poses.append(embedded_structure)
+                                constrained_indices.append(ids)
+                                n_acc += 1
+                    if trace is not None:
+                        trace.append((tuple(int(c) for c in conf_ids), tuple(int(p) for p in pi), v, n_acc))
+    n_atoms = sum(ids_atoms)
+    return ((np.array(poses) if poses else np.empty((0, n_atoms, 3))),
+            np.array(constrained_indices, dtype=np.int64).reshape(-1, 2, 2))

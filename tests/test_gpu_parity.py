@@ -883,6 +883,35 @@ def test_embed_grid_dedupe_vs_oracle(fc, seed, nr1, nr2, scale):
         assert ok.sum() < ok.size  # some poses clash
 
 
+@pytest.mark.parametrize("seed,thresh,delta,pairing", [(21, 1.2, 10.0, False), (22, 1.0, 0.35, False), (23, 1.1, 10.0, True)])
+def test_bimolecular_cyclical_embed_driver_vs_oracle(fc, seed, thresh, delta, pairing):
+    """_fast_bimol_rigid_cyclical_embed (embeds.py:588-750) end to end: several pivots per
+    conformer, the pivot-norm skip, the pairings filter, poses and constrained indices in order"""
+    from oracle import cyclical_ref as cy
+
+    mols = syn.synthetic_trimolecular(n_conf=(2, 3, 1), n_atoms=(9, 11, 8), seed=seed, pivots_per_conf=(2, 2, 1))[:2]
+    angles = o.cartesian_product(range(6), range(6)) * 2 * 45 / 5 - 45
+    table = None
+    if pairing:
+        cum = [list(m["reactive_cumnums"].values()) for m in mols]
+        table = {"a": (cum[0][0], cum[1][1])}  # realised by orientation 1 only
+    trace = []
+    ref_poses, ref_ci = cy.cyclical_embed_bimolecular(_tri_objects(mols), angles, pairings_table=table,
+                                                      clash_thresh=thresh, max_norm_delta=delta, trace=trace)
+    poses, ci = fc.embeds.cyclical_embed_bimolecular(mols, angles, pairings_table=table, clash_thresh=thresh,
+                                                     max_norm_delta=delta)
+    assert poses.shape == ref_poses.shape and len(poses) > 0
+    assert np.abs(poses - ref_poses).max() < 1e-9
+    assert np.array_equal(ci, ref_ci)
+    n_jobs_all = 2 * 3 * 2 * 2
+    if delta < 1.0:
+        assert 0 < len({(t[0], t[1]) for t in trace}) < n_jobs_all  # some pivot pairs were skipped
+    if pairing:
+        assert {t[2] for t in trace} == {1}
+    with pytest.raises(fc.FirecodeHipInputError):
+        fc.embeds.cyclical_embed_bimolecular(mols, angles[::-1], clash_thresh=thresh)
+
+
 # ---------------------------------------------------------------- a14: string embed
 @pytest.mark.parametrize("seed,thresh", [(75, 1.2), (76, 2.2)])
 def test_string_embed_vs_oracle(fc, seed, thresh):
