@@ -67,9 +67,11 @@ def energy_pruning(energies, kcal_thresh=10.0, logfunction=None):
 
 
 def similarity_refining(structures, atoms, rmsd_thr=0.5, quadruplets=None, tfd=False, moi=True, rmsd=True,
-                        max_structures=None, logfunction=None, debugfunction=None):
-    """embedder.py:1410-1514: [TFD] -> MOI -> RMSD (no energies are passed at
-    these call sites).  ``max_structures``: the reference skips MOI/RMSD above
+                        max_structures=None, logfunction=None, debugfunction=None, rmsd_rot_corr=False,
+                        symmetric_torsions=None, graph=None, rotation_masks=None):
+    """embedder.py:1410-1514: [TFD] -> MOI -> RMSD -> [symmetry-corrected RMSD, at most 1000
+    structures and only with locally symmetric torsions, :1480-1505] (no energies are passed
+    at these call sites).  ``max_structures``: the reference skips MOI/RMSD above
     1e5 structures (embedder.py:1446,1467); the GPU path has no such cap unless
     one is given.  Returns the cumulative mask over the input structures."""
     structures = np.asarray(structures, dtype=np.float64)
@@ -96,6 +98,15 @@ def similarity_refining(structures, atoms, rmsd_thr=0.5, quadruplets=None, tfd=F
             _log(logfunction, f"Skipped {label} pruning (>{max_structures} structures)")
             continue
         stage(fn, label, *args, debugfunction=debugfunction)
+    if rmsd_rot_corr and symmetric_torsions:
+        if len(alive) <= 1e3:
+            from firecode_amd.pruner import prune_by_rmsd_rot_corr
+
+            stage(lambda X: prune_by_rmsd_rot_corr(X, atoms, graph, max_rmsd=rmsd_thr, torsions=symmetric_torsions,
+                                                   rotation_masks=rotation_masks, debugfunction=debugfunction),
+                  "symmetry-corrected RMSD")
+        else:
+            _log(logfunction, "Skipped rotationally-corrected RMSD pruning (>1k structures)")
     mask = np.zeros(len(structures), dtype=bool)
     mask[alive] = True
     if mask.all():

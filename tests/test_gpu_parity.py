@@ -788,6 +788,9 @@ def test_prune_by_rmsd_rot_corr_vs_oracle(fc):
     ens = fc.ensemble.Ensemble(atoms=atoms, coords=X.copy(), basename="rotor", logfunction=lines.append)
     ens.similarity_pruning(moi=False, rmsd=True, rmsd_rot_corr=True, symmetric_torsions=torsions, graph=graph)
     assert len(ens.coords) == 4 and any("symmetry-corrected RMSD" in ln for ln in lines)
+    m = fc.refining.similarity_refining(X, atoms, rmsd_thr=0.25, moi=False, rmsd_rot_corr=True,
+                                        symmetric_torsions=torsions, graph=graph)
+    assert m.sum() == 4
 
 
 def test_sharded_scan_and_pose_grid_logical_ranks(fc):
