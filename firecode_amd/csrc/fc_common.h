@@ -146,6 +146,8 @@ struct fc_ensemble {
   int64_t pairq_cap = 0;
   fc::DevBuf simq;             // pairq_cap x uint64: exactly-similar pairs found by the refine
   fc::DevBuf bits_full;        // N x W uint64: whole bit matrix rebuilt from gathered pairs
+  fc::DevBuf item_table;       // screen items (lb << 32 | jt) that touch the upper triangle
+  int64_t item_key[4] = {-1, -1, -1, -1}, item_total = 0;
   fc::DevBuf gathered;         // world x cap uint64: all ranks' similar pairs, compacted (device exchange)
   fc::DevBuf energies;         // N doubles (optional)
   fc::DevBuf maskA, maskB;     // N bytes each

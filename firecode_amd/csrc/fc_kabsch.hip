@@ -479,7 +479,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
                       int64_t Npad, int A, double A_thr2, int IB, int64_t rank, int64_t world,
                       uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
                       unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
-                      unsigned long long Q, int compact, unsigned long long n_items,
+                      unsigned long long Q, const uint64_t *__restrict__ item_table, unsigned long long n_items,
                       double *__restrict__ rmsd_out = nullptr) {
   extern __shared__ double lds[];
   constexpr int TC = 64;
@@ -508,19 +508,13 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
     tl[(size_t)b * 4 + 3] = b;
   }
 #endif
+  // (row block, column tile) of this workgroup: from the host-built list of the items that
+  // touch the upper triangle (lb << 32 | jt), or the plain 2-D enumeration when there is none
   int64_t jt, lb;
-  if (compact) {
-    // items enumerate the blocks that touch the upper triangle only (world == 1):
-    // row block lb owns NT - r*lb column tiles (r = IB/64), so the blocks before
-    // it number C(lb) = lb*NT - r*lb*(lb-1)/2; invert with one sqrt and fix up.
-    const int64_t NT = Npad >> 6, r = IB >> 6;
-    const double t = (double)(2 * NT + r);
-    int64_t l = (int64_t)((t - sqrt(t * t - 8.0 * (double)r * (double)b)) / (2.0 * (double)r));
-    if (l < 0) l = 0;
-    while (l > 0 && l * NT - r * l * (l - 1) / 2 > (int64_t)b) --l;
-    while ((l + 1) * NT - r * (l + 1) * l / 2 <= (int64_t)b) ++l;
-    lb = l;
-    jt = r * l + ((int64_t)b - (l * NT - r * l * (l - 1) / 2));
+  if (item_table != nullptr) {
+    const uint64_t it = item_table[b];
+    lb = (int64_t)(it >> 32);
+    jt = (int64_t)(it & 0xffffffffull);
   } else {
     const int64_t NT = Npad >> 6;
     jt = (int64_t)(b % (unsigned long long)NT);
@@ -1047,6 +1041,31 @@ k_scatter_pairs(const uint64_t *__restrict__ pairs, int64_t n_pairs, int64_t N, 
   atomicOr(reinterpret_cast<unsigned long long *>(&bits[i * W + (j >> 6)]), 1ull << (j & 63));
 }
 
+// Items of the MFMA screen = (local row block, column tile) pairs that touch the upper
+// triangle, in dispatch order (row blocks ascending, tiles left to right); built on the host
+// and kept on the device until N or the sharding changes.  Without it (row blocks that are not
+// a multiple of 64) the kernel enumerates all NT x n_lblocks pairs and skips the empty ones.
+static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks) {
+  if (e->item_key[0] == e->N && e->item_key[1] == e->rank && e->item_key[2] == e->world &&
+      e->item_key[3] == e->row_block)
+    return FC_OK;
+  e->item_total = 0;
+  e->item_key[0] = e->N; e->item_key[1] = e->rank; e->item_key[2] = e->world; e->item_key[3] = e->row_block;
+  if (e->row_block % 64 != 0) return FC_OK;
+  const int64_t r = e->row_block / 64;
+  std::vector<uint64_t> items;
+  for (int64_t l = 0; l < n_lblocks; ++l) {
+    const int64_t first = r * global_block(l, e->rank, e->world);
+    for (int64_t jt = first; jt < NT; ++jt) items.push_back(((uint64_t)l << 32) | (uint64_t)jt);
+  }
+  if (items.empty() || items.size() >= (1ull << 31)) return FC_OK;
+  FC_TRY(e->item_table.reserve(items.size() * sizeof(uint64_t)));
+  FC_TRY(h2d(e->item_table.p, items.data(), items.size() * sizeof(uint64_t)));
+  FC_TRY(sync());  // `items` is a local
+  e->item_total = (int64_t)items.size();
+  return FC_OK;
+}
+
 // all-pairs RMSD values on the matrix pipe (world == 1 layout); rmsd_dev: (N, N), pre-zeroed
 int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev) {
   const int64_t NT = e->Npad >> 6;
@@ -1066,25 +1085,32 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev) {
     if (err != hipSuccess) return set_error(FC_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
   }
   const double A_small = (double)e->A * small_rmsd * small_rmsd;
-  // one workgroup per upper-triangle item (see launch_simbits_screen)
-  const int64_t r = rb / 64;
-  int64_t nvalid = 0;
-  for (int64_t l = 0; l < n_lblocks; ++l) nvalid += std::max<int64_t>(NT - r * l, 0);
-  const int compact = (nvalid > 0 && NT - r * (n_lblocks - 1) > 0) ? 1 : 0;
+  // one workgroup per upper-triangle item (see launch_simbits_screen); the value kernel uses
+  // the world == 1 layout with its own row block, so it keeps its own table
+  static thread_local fc_ensemble *tbl_owner = nullptr;
+  (void)tbl_owner;
+  const int64_t saved_rank = e->rank, saved_world = e->world, saved_rb = e->row_block;
+  e->rank = 0; e->world = 1; e->row_block = rb;
+  const int rc_tbl = screen_item_table(e, NT, n_lblocks);
+  e->rank = saved_rank; e->world = saved_world; e->row_block = saved_rb;
+  e->item_key[3] = -1;  // the table was built for rb, not for the ensemble's own sharding
+  if (rc_tbl != FC_OK) return rc_tbl;
+  const int compact = e->item_total > 0 ? 1 : 0;
   const unsigned long long n_items =
-      compact ? (unsigned long long)nvalid : (unsigned long long)NT * (unsigned long long)n_lblocks;
+      compact ? (unsigned long long)e->item_total : (unsigned long long)NT * (unsigned long long)n_lblocks;
+  const uint64_t *item_table_dev = compact ? e->item_table.as<uint64_t>() : nullptr;
   if (n_items >= (1ull << 31)) return set_error(FC_E_LIMIT, "too many value-kernel items for one launch");
   const dim3 grid((unsigned)n_items);
   if (two_blocks)
     hipLaunchKernelGGL((k_simbits_screen_mfma<4, true>), grid, dim3(256), lds_m, ctx().stream,
                        e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,
                        (int64_t)0, (int64_t)1, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),
-                       (unsigned long long)e->pairq_cap, compact, n_items, rmsd_dev);
+                       (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev);
   else
     hipLaunchKernelGGL((k_simbits_screen_mfma<8, true>), grid, dim3(512), lds_m, ctx().stream,
                        e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,
                        (int64_t)0, (int64_t)1, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),
-                       (unsigned long long)e->pairq_cap, compact, n_items, rmsd_dev);
+                       (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev);
   FC_TRY(check_launch("k_simbits_screen_mfma<values>"));
   hipLaunchKernelGGL(k_rmsd_fix_small, dim3((unsigned)(ctx().n_cu * 4)), dim3(256), 0, ctx().stream,
                      e->Xa.as<double>(), (int)e->A, e->N, e->pairq.as<uint64_t>(), cnt,
@@ -1164,16 +1190,12 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
                 two_blocks ? 4 : 8, lds_m, nb);
       }
       // one workgroup per item; world == 1: only the items that touch the upper triangle
-      int compact = 0;
       unsigned long long n_items = (unsigned long long)NT * (unsigned long long)n_lblocks;
-      if (e->world == 1 && e->row_block % 64 == 0) {
-        const int64_t r = e->row_block / 64;
-        int64_t nvalid = 0;
-        for (int64_t l = 0; l < n_lblocks; ++l) nvalid += std::max<int64_t>(NT - r * l, 0);
-        if (nvalid > 0 && NT - r * (n_lblocks - 1) > 0) {
-          compact = 1;
-          n_items = (unsigned long long)nvalid;
-        }
+      const uint64_t *item_table_dev = nullptr;
+      FC_TRY(screen_item_table(e, NT, n_lblocks));
+      if (e->item_total > 0) {
+        n_items = (unsigned long long)e->item_total;
+        item_table_dev = e->item_table.as<uint64_t>();
       }
       if (n_items >= (1ull << 31)) return set_error(FC_E_LIMIT, "too many screen items for one launch");
       const dim3 mgrid((unsigned)n_items);
@@ -1192,13 +1214,13 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
                            e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
                            (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                            e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
-                           (unsigned long long)e->pairq_cap, compact, n_items, dbg);
+                           (unsigned long long)e->pairq_cap, item_table_dev, n_items, dbg);
       else
         hipLaunchKernelGGL(k_simbits_screen_mfma<8>, mgrid, dim3(512), lds_m, ctx().stream,
                            e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
                            (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                            e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
-                           (unsigned long long)e->pairq_cap, compact, n_items, dbg);
+                           (unsigned long long)e->pairq_cap, item_table_dev, n_items, dbg);
       FC_TRY(check_launch("k_simbits_screen_mfma"));
 #ifdef FC_TIMELINE
       if (timeline) {
