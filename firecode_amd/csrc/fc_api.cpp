@@ -26,7 +26,7 @@ int launch_level(const uint64_t *, int64_t, const uint64_t *, const uint8_t *, u
                  int64_t, int64_t, int64_t, int64_t, int64_t);
 int launch_copy_bytes(const uint8_t *, uint8_t *, int64_t);
 int launch_mask_init(uint64_t *, int64_t, int64_t, int64_t);
-int launch_ladder_pairs(const uint64_t *, uint32_t *, const unsigned long long *, const unsigned long long *,
+int launch_ladder_pairs(const uint64_t *, uint64_t *, const unsigned long long *, const unsigned long long *,
                         unsigned long long, unsigned long long, int64_t, int64_t, int64_t, const int64_t *,
                         int, uint64_t *, unsigned long long *);
 int launch_scatter_pairs(const uint64_t *, int64_t, int64_t, int64_t, uint64_t *);
@@ -188,6 +188,8 @@ void pool_trim() {
   for (auto &b : blocks) (void)hipFree(b.second);
 }
 
+static const size_t kCounters = 64;  // uint64 words of fc_ensemble::counters
+
 static int do_init(int device) {
   Context &c = ctx();
   if (c.ready && c.device == device) return FC_OK;
@@ -274,7 +276,7 @@ static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const 
   FC_TRY(e->Xs.reserve((size_t)((e->A + 3) / 4 * 4) * 3 * e->Npad * sizeof(double)));
   FC_TRY(e->G.reserve((size_t)e->Npad * sizeof(double)));
   FC_TRY(e->Xa.reserve((size_t)std::max<int64_t>(N, 1) * e->A * 3 * sizeof(double)));
-  FC_TRY(e->counters.reserve(16 * sizeof(uint64_t)));
+  FC_TRY(e->counters.reserve(kCounters * sizeof(uint64_t)));
   DevBuf raw, dsel;
   FC_TRY(upload(raw, coords, (size_t)N * A_all * 3));
   FC_TRY(upload(dsel, sel.data(), sel.size()));
@@ -336,7 +338,7 @@ static int simbits_local(fc_ensemble *e, double max_rmsd, double max_dev, const 
     en_dev = e->energies.as<double>();
   }
   if (zero_counters)
-    FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, 16 * sizeof(uint64_t), ctx().stream));
+    FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, kCounters * sizeof(uint64_t), ctx().stream));
   // HIP events bracket the screen kernel (the dominant one) on the library's stream
   FC_HIP_TRY(hipEventRecord(ctx().ev2, ctx().stream));
   FC_TRY(launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin));
@@ -381,7 +383,8 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
     if (k == 1 || min_per_group * k < N) ks.push_back(k);
   const int n_lv = (int)ks.size();
   // counters[8] = levels run, counters[9] = "k_ladder_pairs produced the mask"
-  if (!counters_zeroed) FC_HIP_TRY(hipMemsetAsync(cnt + 8, 0, 2 * sizeof(uint64_t), ctx().stream));
+  // [8], [9]: ladder flags; [10], [11]: spare; [16 ..): bucket fill levels of the pair ladder
+  if (!counters_zeroed) FC_HIP_TRY(hipMemsetAsync(cnt + 8, 0, (kCounters - 8) * sizeof(uint64_t), ctx().stream));
   uint64_t *words = static_cast<uint64_t *>(ctx().pinned);
   uint64_t *cnt_host = words + W;
   bool have_mask = false;
@@ -395,8 +398,8 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
       e->ladder_k_n = n_lv;
       e->ladder_k_mpg = min_per_group;
     }
-    FC_TRY(e->levelmask.reserve((size_t)kPairLadderCap * sizeof(uint32_t)));
-    FC_TRY(launch_ladder_pairs(pairs_dev, e->levelmask.as<uint32_t>(), cnt + 2,
+    FC_TRY(e->levelmask.reserve((size_t)kPairLadderCap * (size_t)n_lv * sizeof(uint64_t)));  // level buckets
+    FC_TRY(launch_ladder_pairs(pairs_dev, e->levelmask.as<uint64_t>(), cnt + 2,
                                pairs_are_final ? nullptr : cnt + 6,
                                (unsigned long long)e->pairq_cap, kPairLadderCap, N, W, min_per_group,
                                e->ladder_k.as<int64_t>(), n_lv, mb + (size_t)n_lv * W, cnt));
@@ -713,7 +716,7 @@ int fc_greedy_prune_from_bits(const uint64_t *bits, int64_t N, int64_t min_per_g
   FC_TRY(e.maskA.reserve((size_t)e.Npad));
   FC_TRY(e.maskB.reserve((size_t)e.Npad));
   FC_TRY(e.mbits.reserve((size_t)e.W * sizeof(uint64_t)));
-  FC_TRY(e.counters.reserve(16 * sizeof(uint64_t)));
+  FC_TRY(e.counters.reserve(kCounters * sizeof(uint64_t)));
   // rows padded to a multiple of the row block so k_level's local row == global row
   const int64_t rows = ceil_div(N, e.row_block) * e.row_block;
   FC_TRY(e.bits.reserve((size_t)rows * e.W * sizeof(uint64_t)));
@@ -793,7 +796,7 @@ int fc_prune_from_pairs(fc_ensemble *ens, const uint64_t *pairs, int64_t n_pairs
   FC_TRY(ensure_init());
   const int64_t N = ens->N, W = ens->W;
   if (N == 0) return FC_OK;
-  FC_TRY(ens->counters.reserve(16 * sizeof(uint64_t)));
+  FC_TRY(ens->counters.reserve(kCounters * sizeof(uint64_t)));
   auto *cnt = reinterpret_cast<unsigned long long *>(ens->counters.p);
   DevBuf dp;
   FC_TRY(upload(dp, pairs, (size_t)n_pairs));
@@ -843,7 +846,7 @@ int fc_prune_from_gathered_dev(fc_ensemble *ens, const uint64_t *dev_gathered, i
   if ((uint64_t)world * (uint64_t)cap > kPairLadderCap || (size_t)2 * W * sizeof(uint64_t) > 60 * 1024)
     return set_error(FC_E_LIMIT, "exchange too large for the one-launch ladder (world*cap = %lld, N = %lld)",
                      (long long)(world * cap), (long long)N);
-  FC_TRY(ens->counters.reserve(16 * sizeof(uint64_t)));
+  FC_TRY(ens->counters.reserve(kCounters * sizeof(uint64_t)));
   FC_TRY(ens->gathered.reserve((size_t)std::max<int64_t>(world * cap, 1) * sizeof(uint64_t)));
   auto *cnt = reinterpret_cast<unsigned long long *>(ens->counters.p);
   unsigned long long local[8];
@@ -903,7 +906,7 @@ int fc_prune_moi(const double *coords, int64_t N, int64_t A, const double *masse
   FC_TRY(e.maskA.reserve((size_t)e.Npad));
   FC_TRY(e.maskB.reserve((size_t)e.Npad));
   FC_TRY(e.mbits.reserve((size_t)e.W * sizeof(uint64_t)));
-  FC_TRY(e.counters.reserve(16 * sizeof(uint64_t)));
+  FC_TRY(e.counters.reserve(kCounters * sizeof(uint64_t)));
   const int64_t rows = ceil_div(N, e.row_block) * e.row_block;
   FC_TRY(e.bits.reserve((size_t)rows * e.W * sizeof(uint64_t)));
   DevBuf dc, dm, dmom;
@@ -951,7 +954,7 @@ int fc_prune_rmsd_rot_corr(const double *coords, int64_t N, int64_t A, const uin
   FC_TRY(e.maskA.reserve((size_t)e.Npad));
   FC_TRY(e.maskB.reserve((size_t)e.Npad));
   FC_TRY(e.mbits.reserve((size_t)e.W * sizeof(uint64_t)));
-  FC_TRY(e.counters.reserve(16 * sizeof(uint64_t)));
+  FC_TRY(e.counters.reserve(kCounters * sizeof(uint64_t)));
   const int64_t rows = ceil_div(N, e.row_block) * e.row_block;
   const size_t bits_bytes = (size_t)rows * e.W * sizeof(uint64_t);
   FC_TRY(e.bits.reserve(bits_bytes));
@@ -1589,7 +1592,7 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
   int64_t levels = 0, survivors = 0;
   unsigned long long cnt[8] = {0};
   for (int64_t r = 0; r < reps; ++r) {
-    FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 16 * sizeof(uint64_t), c.stream));
+    FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, kCounters * sizeof(uint64_t), c.stream));
     FC_HIP_TRY(hipEventRecord(c.ev0, c.stream));
     FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
     FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));

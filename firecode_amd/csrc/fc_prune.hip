@@ -141,34 +141,55 @@ k_level_fused(const uint64_t *__restrict__ bits, int64_t W, const uint64_t *__re
   }
 }
 
-// per similar pair: bit l set when i and j share a chunk at ladder value ladder[l]
-// (the only levels at which the pair can act).  Massively parallel, so the
-// 2 x n_ladder integer divisions per pair cost nothing; the one-workgroup ladder
-// kernel below then touches a pair only at the levels where it matters.
+// Per ladder level, the similar pairs that can act at it: i and j share a chunk at ladder value
+// ladder[l].  k_pair_buckets (grid wide: the 2 x n_ladder integer divisions per pair cost
+// nothing there) copies every pair into the bucket of each such level -- wave-aggregated
+// appends, one atomic per wavefront and level -- so that the one-workgroup ladder kernel
+// below touches, at a level, only the pairs that matter at it: about 2 P visits in total
+// instead of n_ladder x P.  The last level (k = 1: one chunk, every pair) needs no bucket.
+// level_cnt = counters + 16; buckets: n_ladder regions of `cap` pairs.
 __global__ void __launch_bounds__(256)
-k_pair_levelmask(const uint64_t *__restrict__ pairs, const unsigned long long *__restrict__ n_pairs_ptr,
-                 unsigned long long cap, int64_t N, const int64_t *__restrict__ ladder, int n_ladder,
-                 uint32_t *__restrict__ levelmask) {
+k_pair_buckets(const uint64_t *__restrict__ pairs, const unsigned long long *__restrict__ n_pairs_ptr,
+               unsigned long long cap, int64_t N, const int64_t *__restrict__ ladder, int n_ladder,
+               uint64_t *__restrict__ buckets, unsigned long long *__restrict__ level_cnt) {
   const unsigned long long P = *n_pairs_ptr;
   if (P > cap) return;
   const uint32_t n32 = (uint32_t)N;
-  for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < P;
-       p += (unsigned long long)gridDim.x * blockDim.x) {
-    const uint64_t e = pairs[p];
+  const int lane = threadIdx.x & 63;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < P;
+       base += stride) {  // wave-uniform trip count: the ballots below see whole wavefronts
+    const unsigned long long p = base + lane;
+    const uint64_t e = p < P ? pairs[p] : ~0ull;
     const uint32_t i = (uint32_t)(e >> 32), j = (uint32_t)(e & 0xffffffffull);
-    uint32_t m = 0;
-    if (j > i && j < n32) {
-      for (int l = 0; l < n_ladder; ++l) {
-        const uint32_t k = (uint32_t)ladder[l];
-        const uint32_t chunk = n32 / k;
-        if (chunk == 0) continue;  // k > N: the level can never run
+    const bool valid = j > i && j < n32;  // padding / malformed entries never act
+    uint32_t mine = 0;                    // bit l: this lane's pair acts at level l
+    unsigned long long my_cnt = 0;        // lane l: how many pairs of the wavefront act at level l
+    for (int l = 0; l < n_ladder; ++l) {
+      const uint32_t k = (uint32_t)ladder[l];
+      if (k == 1u) continue;  // served from the list itself
+      const uint32_t chunk = n32 / k;
+      bool same = false;
+      if (valid && chunk != 0) {  // chunk == 0: k > N, the level can never run
         uint32_t ci = i / chunk, cj = j / chunk;
         if (ci > k - 1) ci = k - 1;
         if (cj > k - 1) cj = k - 1;
-        if (ci == cj) m |= 1u << l;
+        same = ci == cj;
       }
+      if (same) mine |= 1u << l;
+      const unsigned long long c = (unsigned long long)__popcll(__ballot(same));
+      if (lane == l) my_cnt = c;
     }
-    levelmask[p] = m;
+    // ONE atomic instruction reserves the wavefront's slots in every bucket: lane l asks for level l
+    unsigned long long my_at = 0;
+    if (my_cnt) my_at = atomicAdd(&level_cnt[lane], my_cnt);
+    for (int l = 0; l < n_ladder; ++l) {
+      const bool same = (mine >> l) & 1u;
+      const uint64_t m = __ballot(same);
+      if (m == 0) continue;  // wave-uniform
+      const unsigned long long at = __shfl(my_at, l);
+      if (same) buckets[(unsigned long long)l * cap + at + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = e;
+    }
   }
 }
 
@@ -176,9 +197,9 @@ k_pair_levelmask(const uint64_t *__restrict__ pairs, const unsigned long long *_
 // k_ladder_pairs: the WHOLE k-ladder in one launch when similarity is sparse.
 // With the exactly-similar pairs as a list (i < j), a level is
 //     for every pair: in[i] && in[j] && chunk_k(i) == chunk_k(j)  ->  out[i] = 0
-// so one 1024-thread workgroup keeps the mask words in LDS, walks the pair list
-// once per level and separates levels with __syncthreads(): no grid barrier, no
-// host round trip, ~1 us per level.  `n_pairs_ptr`/`n_cand_ptr` are device
+// so one 1024-thread workgroup keeps the mask words in LDS, walks the level's bucket
+// (k_pair_buckets; the list itself at k = 1) and separates levels with __syncthreads(): no
+// grid barrier, no host round trip.  `n_pairs_ptr`/`n_cand_ptr` are device
 // counters (the refine kernel's outputs); the kernel does nothing -- and leaves
 // counters[9] = 0 -- when the list is incomplete (candidate queue overflow) or
 // longer than `cap`, in which case the bit-matrix levels launched behind it do
@@ -186,7 +207,7 @@ k_pair_levelmask(const uint64_t *__restrict__ pairs, const unsigned long long *_
 // otherwise it sets counters[9] = 1.  counters[8] = levels that ran.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ levelmask,
+k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint64_t *__restrict__ buckets,
                const unsigned long long *__restrict__ n_pairs_ptr,
                const unsigned long long *__restrict__ n_cand_ptr, unsigned long long cand_cap,
                unsigned long long cap, int64_t N, int64_t W, int64_t min_per_group,
@@ -194,6 +215,7 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ 
                unsigned long long *__restrict__ counters) {
   extern __shared__ unsigned long long lm[];  // cur[W] | nxt[W]
   __shared__ int s_count;
+  __shared__ unsigned long long s_level_cnt[32];
   const int tid = threadIdx.x;
   const unsigned long long P = *n_pairs_ptr;
   if ((n_cand_ptr != nullptr && *n_cand_ptr > cand_cap) || P > cap) {
@@ -201,11 +223,13 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ 
     if (tid < 16) mask_out[W + tid] = tid == 9 ? 0ull : counters[tid];
     return;
   }
+  if (tid < 32) s_level_cnt[tid] = tid < n_ladder ? counters[16 + tid] : 0ull;  // one round trip, not one per level
   unsigned long long *cur = lm, *nxt = lm + W;
   for (int64_t w = tid; w < W; w += 1024) {
     const int64_t lo = w * 64;
     cur[w] = (lo + 64 <= N) ? ~0ull : ((lo < N) ? ((1ull << (N - lo)) - 1ull) : 0ull);
   }
+  const uint32_t n32 = (uint32_t)N;
   __syncthreads();
   int levels = 0;
   for (int l = 0; l < n_ladder; ++l) {
@@ -223,23 +247,23 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ 
     ++levels;
     for (int64_t w = tid; w < W; w += 1024) nxt[w] = cur[w];
     __syncthreads();
-    // eight independent (mask, pair) loads in flight per lane: a single workgroup
-    // cannot hide one L2 round trip per pair behind other waves
+    // the pairs of this level: its bucket, or the whole list at k = 1.  Eight independent
+    // loads in flight per lane: a single workgroup cannot hide one L2 round trip per pair
+    // behind other waves
+    const uint64_t *__restrict__ src = (k == 1) ? pairs : buckets + (unsigned long long)l * cap;
+    const unsigned long long n_src = (k == 1) ? P : s_level_cnt[l];
     constexpr int U = 8;
-    for (unsigned long long p0 = tid; p0 < P; p0 += 1024ull * U) {
-      uint32_t lmv[U];
+    for (unsigned long long p0 = tid; p0 < n_src; p0 += 1024ull * U) {
       uint64_t ev[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const unsigned long long p = p0 + 1024ull * u;
-        const bool ok = p < P;
-        lmv[u] = ok ? levelmask[p] : 0u;
-        ev[u] = ok ? pairs[p] : 0ull;
+        ev[u] = p < n_src ? src[p] : ~0ull;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if ((lmv[u] >> l) & 1u) {  // the pair shares a chunk at this level (never set for padding)
-          const uint32_t i = (uint32_t)(ev[u] >> 32), j = (uint32_t)(ev[u] & 0xffffffffull);
+        const uint32_t i = (uint32_t)(ev[u] >> 32), j = (uint32_t)(ev[u] & 0xffffffffull);
+        if (j > i && j < n32) {  // not padding
           if (((cur[i >> 6] >> (i & 63)) & 1ull) && ((cur[j >> 6] >> (j & 63)) & 1ull))
             atomicAnd(&nxt[i >> 6], ~(1ull << (i & 63)));
         }
@@ -659,16 +683,17 @@ int launch_level_fused(const uint64_t *bits_dev, int64_t W, const uint64_t *mb_i
   return check_launch("k_level_fused");
 }
 
-int launch_ladder_pairs(const uint64_t *pairs_dev, uint32_t *levelmask_dev,
+int launch_ladder_pairs(const uint64_t *pairs_dev, uint64_t *buckets_dev,
                         const unsigned long long *n_pairs_dev, const unsigned long long *n_cand_dev,
                         unsigned long long cand_cap, unsigned long long cap, int64_t N, int64_t W,
                         int64_t min_per_group, const int64_t *ladder_dev, int n_ladder,
                         uint64_t *mask_out_dev, unsigned long long *counters_dev) {
-  hipLaunchKernelGGL(k_pair_levelmask, dim3((unsigned)(ctx().n_cu * 2)), dim3(256), 0, ctx().stream,
-                     pairs_dev, n_pairs_dev, cap, N, ladder_dev, n_ladder, levelmask_dev);
-  FC_TRY(check_launch("k_pair_levelmask"));
+  // counters_dev[16 .. 16 + n_ladder) = bucket fill levels (zero on entry: the caller's reset)
+  hipLaunchKernelGGL(k_pair_buckets, dim3((unsigned)(ctx().n_cu * 2)), dim3(256), 0, ctx().stream,
+                     pairs_dev, n_pairs_dev, cap, N, ladder_dev, n_ladder, buckets_dev, counters_dev + 16);
+  FC_TRY(check_launch("k_pair_buckets"));
   const size_t lds = (size_t)2 * W * sizeof(uint64_t);
-  hipLaunchKernelGGL(k_ladder_pairs, dim3(1), dim3(1024), lds, ctx().stream, pairs_dev, levelmask_dev,
+  hipLaunchKernelGGL(k_ladder_pairs, dim3(1), dim3(1024), lds, ctx().stream, pairs_dev, buckets_dev,
                      n_pairs_dev, n_cand_dev, cand_cap, cap, N, W, min_per_group, ladder_dev, n_ladder,
                      mask_out_dev, counters_dev);
   return check_launch("k_ladder_pairs");
