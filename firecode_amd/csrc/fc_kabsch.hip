@@ -810,11 +810,13 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
       const bool on = lane < 8 * kRounds && p_own < (int64_t)n_pairs;
       const uint64_t e = on ? pairq[p_own] : 0ull;
       double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      double Gs = 0.0;  // sum of squares of both structures: start value of the eigenvalue iteration
 #pragma unroll FC_REFINE_UNROLL
       for (int round = 0; round < kRounds; ++round) {
         const uint64_t eg = __shfl(e, round * 8 + slot);  // the pair of this 8-lane group
         const bool og = base + round * 8 + slot < (int64_t)n_pairs;
         double Bg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double gg = 0.0;
         if (og) {
           const double *__restrict__ pp = Xa + (int64_t)(eg >> 32) * (int64_t)A * 3;
           const double *__restrict__ qq = Xa + (int64_t)(eg & 0xffffffffull) * (int64_t)A * 3;
@@ -824,6 +826,7 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
             Bg[0] = fma(px, qx, Bg[0]); Bg[1] = fma(px, qy, Bg[1]); Bg[2] = fma(px, qz, Bg[2]);
             Bg[3] = fma(py, qx, Bg[3]); Bg[4] = fma(py, qy, Bg[4]); Bg[5] = fma(py, qz, Bg[5]);
             Bg[6] = fma(pz, qx, Bg[6]); Bg[7] = fma(pz, qy, Bg[7]); Bg[8] = fma(pz, qz, Bg[8]);
+            gg += (px * px + py * py + pz * pz) + (qx * qx + qy * qy + qz * qz);
           }
         }
 #pragma unroll
@@ -832,9 +835,14 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
           const double mine = __shfl(tot, sub * 8);  // group `sub` holds the pair lane 8*round+sub owns
           if (slot == round) B[k] = mine;
         }
+        const double gmine = __shfl(group8_sum(gg), sub * 8);
+        if (slot == round) Gs = gmine;
       }
+      // rotation: Newton eigenvalue + adjugate eigenvector where the eigenvalue is clearly simple
+      // (every candidate of a sane ensemble), the Jacobi sweeps otherwise -- same R to ~1e-14
       double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-      if (on) (void)kabsch_rotation(B, R);
+      const bool fast = on && kabsch_rotation_qcp(B, Gs, R);
+      if (on && !fast) (void)kabsch_rotation(B, R);
       double ssq_own = 0.0, mx_own = 0.0;
 #pragma unroll FC_REFINE_UNROLL
       for (int round = 0; round < kRounds; ++round) {

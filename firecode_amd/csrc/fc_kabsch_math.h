@@ -211,4 +211,63 @@ __host__ __device__ __forceinline__ double kabsch_lambda_max(const double (&B)[9
   return x;
 }
 
+// Optimal rotation without the Jacobi sweeps, for pairs whose largest quaternion eigenvalue
+// is well separated (candidate pairs of the refine: nearly superposable structures): the
+// eigenvalue by Newton on the characteristic polynomial (above), its eigenvector as the
+// column of adj(K - lambda I) with the largest diagonal cofactor (for a simple eigenvalue
+// adj = c q q^T).  Returns false -- and the caller falls back to kabsch_rotation -- when the
+// eigenvalue is not clearly simple or the eigenvector leaves a residual above 1e-12 of the
+// matrix scale; ~300 flops against ~7 000 for the sweeps.
+__host__ __device__ __forceinline__ bool kabsch_rotation_qcp(const double (&B)[9], double GpGq,
+                                                             double (&R)[9]) {
+  const double lam = kabsch_lambda_max(B, GpGq);
+  const double Sxx = B[0], Sxy = B[3], Sxz = B[6];
+  const double Syx = B[1], Syy = B[4], Syz = B[7];
+  const double Szx = B[2], Szy = B[5], Szz = B[8];
+  // M = K - lambda I (symmetric), same K as kabsch_rotation
+  const double m00 = (Sxx + Syy + Szz) - lam, m01 = Syz - Szy, m02 = Szx - Sxz, m03 = Sxy - Syx;
+  const double m11 = (Sxx - Syy - Szz) - lam, m12 = Sxy + Syx, m13 = Szx + Sxz;
+  const double m22 = (-Sxx + Syy - Szz) - lam, m23 = Syz + Szy;
+  const double m33 = (-Sxx - Syy + Szz) - lam;
+  // adjugate of the symmetric M: A_ij = (-1)^(i+j) det(M without row i and column j)
+  const double m[4][4] = {{m00, m01, m02, m03}, {m01, m11, m12, m13}, {m02, m12, m22, m23}, {m03, m13, m23, m33}};
+  auto cof = [&](int i, int j) {
+    const int r0 = i == 0 ? 1 : 0, r1 = i <= 1 ? 2 : 1, r2 = i <= 2 ? 3 : 2;
+    const int c0 = j == 0 ? 1 : 0, c1 = j <= 1 ? 2 : 1, c2 = j <= 2 ? 3 : 2;
+    const double d = m[r0][c0] * (m[r1][c1] * m[r2][c2] - m[r1][c2] * m[r2][c1]) -
+                     m[r0][c1] * (m[r1][c0] * m[r2][c2] - m[r1][c2] * m[r2][c0]) +
+                     m[r0][c2] * (m[r1][c0] * m[r2][c1] - m[r1][c1] * m[r2][c0]);
+    return ((i + j) & 1) ? -d : d;
+  };
+  const double a00 = cof(0, 0), a01 = cof(0, 1), a02 = cof(0, 2), a03 = cof(0, 3);
+  const double a11 = cof(1, 1), a12 = cof(1, 2), a13 = cof(1, 3);
+  const double a22 = cof(2, 2), a23 = cof(2, 3), a33 = cof(3, 3);
+  // column with the largest diagonal entry
+  double q0 = a00, q1 = a01, q2 = a02, q3 = a03, best = fabs(a00);
+  if (fabs(a11) > best) { best = fabs(a11); q0 = a01; q1 = a11; q2 = a12; q3 = a13; }
+  if (fabs(a22) > best) { best = fabs(a22); q0 = a02; q1 = a12; q2 = a22; q3 = a23; }
+  if (fabs(a33) > best) { best = fabs(a33); q0 = a03; q1 = a13; q2 = a23; q3 = a33; }
+  const double scale = fabs(lam) + fabs(Sxx) + fabs(Syy) + fabs(Szz) + fabs(m01) + fabs(m02) + fabs(m03) +
+                       fabs(m12) + fabs(m13) + fabs(m23);
+  const double n2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+  if (!(best > 2e-3 * scale * scale * scale) || !(n2 > 0.0)) return false;  // eigenvalue not clearly simple
+  const double nrm = 1.0 / sqrt(n2);
+  q0 *= nrm; q1 *= nrm; q2 *= nrm; q3 *= nrm;
+  const double e0 = m00 * q0 + m01 * q1 + m02 * q2 + m03 * q3;
+  const double e1 = m01 * q0 + m11 * q1 + m12 * q2 + m13 * q3;
+  const double e2 = m02 * q0 + m12 * q1 + m22 * q2 + m23 * q3;
+  const double e3 = m03 * q0 + m13 * q1 + m23 * q2 + m33 * q3;
+  if (!(fmax(fmax(fabs(e0), fabs(e1)), fmax(fabs(e2), fabs(e3))) <= 1e-12 * scale)) return false;
+  R[0] = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3;
+  R[1] = 2.0 * (q1 * q2 - q0 * q3);
+  R[2] = 2.0 * (q1 * q3 + q0 * q2);
+  R[3] = 2.0 * (q1 * q2 + q0 * q3);
+  R[4] = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3;
+  R[5] = 2.0 * (q2 * q3 - q0 * q1);
+  R[6] = 2.0 * (q1 * q3 - q0 * q2);
+  R[7] = 2.0 * (q2 * q3 + q0 * q1);
+  R[8] = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
+  return true;
+}
+
 }  // namespace fc
