@@ -370,11 +370,14 @@ static const unsigned long long kPairLadderCap = 1ull << 20;
 static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_per_group,
                          uint8_t *mask_out, int64_t *levels, int64_t *survivors,
                          unsigned long long *counters_out = nullptr, const uint64_t *pairs_dev = nullptr,
-                         bool pairs_are_final = false, bool counters_zeroed = false) {
+                         bool pairs_are_final = false, bool counters_zeroed = false, int64_t defer_slot = -1) {
+  // defer_slot >= 0: enqueue the pair ladder and the copy of its result into slot `defer_slot` of
+  // the pinned staging area and return WITHOUT waiting (the caller synchronises once for many
+  // prunes and reads the slots with ladder_collect; pinned memory for all slots is the caller's)
   const int64_t N = e->N, W = e->W;
   const int n_ladder = (int)(sizeof(kLadder) / sizeof(kLadder[0]));
   FC_TRY(e->ladder.reserve(((size_t)(n_ladder + 1) * W + 16) * sizeof(uint64_t)));
-  FC_TRY(pinned_reserve((size_t)(W + 16) * sizeof(uint64_t)));
+  if (defer_slot < 0) FC_TRY(pinned_reserve((size_t)(W + 16) * sizeof(uint64_t)));
   uint64_t *mb = e->ladder.as<uint64_t>();
   auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
   // ladder values that can ever run (n_active <= N) -- decided here, the rest on the device
@@ -385,7 +388,7 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
   // counters[8] = levels run, counters[9] = "k_ladder_pairs produced the mask"
   // [8], [9]: ladder flags; [10], [11]: spare; [16 ..): bucket fill levels of the pair ladder
   if (!counters_zeroed) FC_HIP_TRY(hipMemsetAsync(cnt + 8, 0, (kCounters - 8) * sizeof(uint64_t), ctx().stream));
-  uint64_t *words = static_cast<uint64_t *>(ctx().pinned);
+  uint64_t *words = static_cast<uint64_t *>(ctx().pinned) + (defer_slot > 0 ? (size_t)defer_slot * (size_t)(W + 16) : 0);
   uint64_t *cnt_host = words + W;
   bool have_mask = false;
   const bool lds_ok = (size_t)2 * W * sizeof(uint64_t) <= 60 * 1024;
@@ -405,9 +408,11 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
                                e->ladder_k.as<int64_t>(), n_lv, mb + (size_t)n_lv * W, cnt));
     // mask words and the 16 counters behind them (written by the kernel): one copy
     FC_TRY(d2h(words, mb + (size_t)n_lv * W, (size_t)(W + 16) * sizeof(uint64_t)));
+    if (defer_slot >= 0) return FC_OK;
     FC_TRY(sync());
     have_mask = cnt_host[9] != 0;
   }
+  if (defer_slot >= 0) return set_error(FC_E_INVALID, "deferred ladder needs the pair list");
   if (!have_mask) {
     // dense similarity / no pair list: one fused launch per level over the bit matrix
     if (bits_dev == nullptr) return set_error(FC_E_LIMIT, "pair list too long for the one-launch ladder and no bit matrix given");
@@ -431,6 +436,25 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
   if (counters_out)
     for (int k = 0; k < 8; ++k) counters_out[k] = cnt_host[k];
   return FC_OK;
+}
+
+// result of a deferred pair ladder (after the caller's synchronisation); false: the kernel
+// declined (queue overflow / list too long) and the prune has to be redone synchronously
+static bool ladder_collect(const fc_ensemble *e, int64_t slot, uint8_t *mask_out, int64_t *levels,
+                           int64_t *survivors, unsigned long long *counters_out) {
+  const int64_t N = e->N, W = e->W;
+  const uint64_t *words = static_cast<const uint64_t *>(ctx().pinned) + (size_t)slot * (size_t)(W + 16);
+  const uint64_t *cnt_host = words + W;
+  if (cnt_host[9] == 0) return false;
+  int64_t alive = 0;
+  for (int64_t w = 0; w < W; ++w) alive += __builtin_popcountll(words[w]);
+  if (mask_out)
+    for (int64_t i = 0; i < N; ++i) mask_out[i] = (uint8_t)((words[(size_t)(i >> 6)] >> (i & 63)) & 1ull);
+  if (levels) *levels = (int64_t)cnt_host[8];
+  if (survivors) *survivors = alive;
+  if (counters_out)
+    for (int k = 0; k < 8; ++k) counters_out[k] = cnt_host[k];
+  return true;
 }
 
 }  // namespace fc
@@ -1584,32 +1608,57 @@ int fc_xyz_read(const char *path, int64_t N, int64_t A, char *atoms_out, double 
 int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
                         double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
                         int64_t *stats) {
-  FC_REQUIRE(ens && reps >= 1, "bad arguments");
+  FC_REQUIRE(ens && reps >= 1 && reps <= 4096, "bad arguments");
   FC_TRY(ensure_init());
   FC_TRY(ensemble_shard(ens, 0, 1, default_row_block()));
   Context &c = ctx();
-  double t_kernel = 0.0, t_step = 0.0;
+  // The `reps` prunes are enqueued back to back -- counters reset, screen, refine, level buckets,
+  // ladder, copy of the survivor words + counters into the prune's own pinned slot -- and the
+  // host waits ONCE.  Every prune runs in full and delivers its mask to host memory; only the
+  // idle gap of a host round trip between two prunes (~45 us of sync wake-up and launch
+  // latency on an idle GPU) is gone, as for any caller that has more than one ensemble queued.
+  static std::vector<hipEvent_t> ev;  // 2 per prune: around the screen kernel
+  while ((int64_t)ev.size() < 2 * reps + 2) {
+    hipEvent_t e = nullptr;
+    FC_HIP_TRY(hipEventCreate(&e));
+    ev.push_back(e);
+  }
+  const int64_t W = ens->W;
+  FC_TRY(pinned_reserve((size_t)reps * (size_t)(W + 16) * sizeof(uint64_t)));
   int64_t levels = 0, survivors = 0;
   unsigned long long cnt[8] = {0};
+  FC_HIP_TRY(hipEventRecord(ev[2 * reps], c.stream));
   for (int64_t r = 0; r < reps; ++r) {
     FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, kCounters * sizeof(uint64_t), c.stream));
-    FC_HIP_TRY(hipEventRecord(c.ev0, c.stream));
+    FC_HIP_TRY(hipEventRecord(ev[2 * r], c.stream));
     FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
-    FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
+    FC_HIP_TRY(hipEventRecord(ev[2 * r + 1], c.stream));
     FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
     ens->bits_valid = true;
+    FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, nullptr, nullptr, nullptr, nullptr,
+                         ens->simq.as<uint64_t>(), false, true, r));
+  }
+  FC_HIP_TRY(hipEventRecord(ev[2 * reps + 1], c.stream));
+  FC_HIP_TRY(hipEventSynchronize(ev[2 * reps + 1]));
+  double t_kernel = 0.0;
+  float total = 0.f;
+  FC_HIP_TRY(hipEventElapsedTime(&total, ev[2 * reps], ev[2 * reps + 1]));
+  bool redo = false;
+  for (int64_t r = 0; r < reps; ++r) {
+    float a = 0.f;
+    FC_HIP_TRY(hipEventElapsedTime(&a, ev[2 * r], ev[2 * r + 1]));
+    t_kernel += a;
+    if (!ladder_collect(ens, r, mask_out, &levels, &survivors, cnt)) redo = true;
+  }
+  if (redo) {  // dense similarity: the pair ladder declined; one synchronous prune through the bit matrix
+    FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, kCounters * sizeof(uint64_t), c.stream));
+    FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
+    FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
     FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, mask_out, &levels, &survivors, cnt,
                          ens->simq.as<uint64_t>(), false, true));
-    FC_HIP_TRY(hipEventRecord(c.ev2, c.stream));
-    FC_HIP_TRY(hipEventSynchronize(c.ev2));
-    float a = 0.f, b = 0.f;
-    FC_HIP_TRY(hipEventElapsedTime(&a, c.ev0, c.ev1));
-    FC_HIP_TRY(hipEventElapsedTime(&b, c.ev0, c.ev2));
-    t_kernel += a;
-    t_step += b;
   }
   if (ms_simbits_kernel) *ms_simbits_kernel = t_kernel / (double)reps;
-  if (ms_step) *ms_step = t_step / (double)reps;
+  if (ms_step) *ms_step = (double)total / (double)reps;
   if (stats) {
     stats[0] = ens->N * (ens->N - 1) / 2;
     stats[1] = (int64_t)cnt[1];
