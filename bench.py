@@ -148,10 +148,18 @@ def main():
         barrier()
         t0 = time.perf_counter()
         tk_ns, owned = 0, 0
-        for _ in range(args.steps):
-            mask, stats = step()
-            tk_ns += int(stats[4])
-            owned = int(stats[0])
+        if backend == "gloo":
+            for _ in range(args.steps):
+                mask, stats = step()
+                tk_ns += int(stats[4])
+                owned = int(stats[0])
+        else:
+            # the K steps are stream-ordered: every step's screen, refine, export, all-gather and
+            # ladder are enqueued behind the previous step's, the host waits once for all K
+            for mask, stats in fdist.prune_steps_sharded_device(ens, args.steps, MAX_RMSD, rank=rank, world=world,
+                                                                device=torch.device("cuda", local_rank)):
+                tk_ns += int(stats[4])
+                owned = int(stats[0])
         barrier()
         elapsed = time.perf_counter() - t0
         import torch
@@ -188,7 +196,7 @@ def main():
                        "sharding": f"row blocks of 128 dealt in snake order over {world} rank(s); one all-gather "
                                    "of similar-pair lists, ladder replayed on every rank",
                        "host_sync": ("once for the K steps (stream-ordered steps, one pinned result slot each)"
-                                     if not sharded else "once per step"),
+                                     if (not sharded or backend != "gloo") else "once per step"),
                        "exchange": ("none (single GPU, resident step)" if not sharded else
                                     "host lists through gloo" if backend == "gloo" else
                                     "device-resident: export kernel -> RCCL all_gather_into_tensor -> ladder, "

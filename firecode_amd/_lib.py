@@ -70,6 +70,8 @@ _SIGNATURES = {
     "fc_prune_rmsd_begin_async": [_ens, _f64, _f64, _i64, _i64, _i64],
     "fc_prune_export_pairs_dev": [_ens, C.c_void_p, _i64],
     "fc_prune_from_gathered_dev": [_ens, C.c_void_p, _i64, _i64, _i64, _p_u8, _p_i64],
+    "fc_prune_from_gathered_dev_enqueue": [_ens, C.c_void_p, _i64, _i64, _i64, _i64, _i64],
+    "fc_prune_collect": [_ens, _i64, _i64, _p_u8, _p_i64],
     "fc_stream_set": [C.c_void_p],
     "fc_memory_trim": [],
     "fc_inertia_moments": [_p_f64, _i64, _i64, _p_f64, _p_f64],
@@ -366,6 +368,16 @@ class DeviceEnsemble:
         stats = np.zeros(6, dtype=np.int64)
         call("fc_prune_from_gathered_dev", self.handle, C.c_void_p(int(dev_ptr)), int(world), int(cap),
              int(min_per_group), pb(mask), pi(stats))
+        return mask.astype(bool), stats
+
+    def prune_from_gathered_enqueue(self, dev_ptr, world, cap, slot, n_slots, min_per_group=20):
+        call("fc_prune_from_gathered_dev_enqueue", self.handle, C.c_void_p(int(dev_ptr)), int(world), int(cap),
+             int(min_per_group), int(slot), int(n_slots))
+
+    def prune_collect(self, slot, n_slots):
+        mask = np.zeros(self.N, dtype=np.uint8)
+        stats = np.zeros(6, dtype=np.int64)
+        call("fc_prune_collect", self.handle, int(slot), int(n_slots), pb(mask), pi(stats))
         return mask.astype(bool), stats
 
     def bench_prune(self, max_rmsd, max_dev, reps=1, want_mask=True):

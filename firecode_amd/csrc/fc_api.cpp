@@ -899,6 +899,64 @@ int fc_prune_from_gathered_dev(fc_ensemble *ens, const uint64_t *dev_gathered, i
   return FC_OK;
 }
 
+// The same, stream-ordered: enqueue prune number `slot` of `n_slots` and return without waiting;
+// fc_prune_collect waits for the stream and reads that prune's result.  Lets a caller keep the
+// GPU busy across prunes (the next screen starts while the host is still in Python).
+int fc_prune_from_gathered_dev_enqueue(fc_ensemble *ens, const uint64_t *dev_gathered, int64_t world,
+                                       int64_t cap, int64_t min_per_group, int64_t slot, int64_t n_slots) {
+  FC_REQUIRE(ens && dev_gathered, "NULL pointer argument");
+  FC_REQUIRE(world >= 1 && world <= 64 && cap >= 0 && min_per_group >= 1, "bad arguments");
+  FC_REQUIRE(n_slots >= 1 && n_slots <= 4096 && slot >= 0 && slot < n_slots, "bad slot %lld of %lld", (long long)slot,
+             (long long)n_slots);
+  FC_TRY(ensure_init());
+  const int64_t N = ens->N, W = ens->W;
+  FC_REQUIRE(N > 0, "empty ensemble");
+  if ((uint64_t)world * (uint64_t)cap > kPairLadderCap || (size_t)2 * W * sizeof(uint64_t) > 60 * 1024)
+    return set_error(FC_E_LIMIT, "exchange too large for the one-launch ladder (world*cap = %lld, N = %lld)",
+                     (long long)(world * cap), (long long)N);
+  FC_TRY(ens->counters.reserve(kCounters * sizeof(uint64_t)));
+  FC_TRY(ens->gathered.reserve((size_t)std::max<int64_t>(world * cap, 1) * sizeof(uint64_t)));
+  auto *cnt = reinterpret_cast<unsigned long long *>(ens->counters.p);
+  // pinned layout: n_slots x (W + 16) ladder results, then n_slots x 8 local counters; sized by
+  // the first prune of a batch (growing it later would move results that are still in flight)
+  const size_t need = ((size_t)n_slots * (size_t)(W + 16) + (size_t)n_slots * 8) * sizeof(uint64_t);
+  if (slot == 0) FC_TRY(pinned_reserve(need));
+  FC_REQUIRE(ctx().pinned_bytes >= need, "slot 0 of this batch has not been enqueued");
+  unsigned long long *local_host =
+      static_cast<unsigned long long *>(ctx().pinned) + (size_t)n_slots * (size_t)(W + 16) + (size_t)slot * 8;
+  FC_TRY(d2h(local_host, cnt, 8 * sizeof(uint64_t)));
+  FC_TRY(launch_compact_gathered(dev_gathered, (int)world, cap, ens->gathered.as<uint64_t>(), cnt));
+  return ladder_single(ens, nullptr, min_per_group, nullptr, nullptr, nullptr, nullptr,
+                       ens->gathered.as<uint64_t>(), true, false, slot);
+}
+
+int fc_prune_collect(fc_ensemble *ens, int64_t slot, int64_t n_slots, uint8_t *mask_out, int64_t *stats) {
+  FC_REQUIRE(ens && mask_out, "NULL pointer argument");
+  FC_REQUIRE(n_slots >= 1 && slot >= 0 && slot < n_slots, "bad slot");
+  FC_TRY(ensure_init());
+  FC_TRY(sync());
+  const int64_t N = ens->N, W = ens->W;
+  int64_t survivors = 0;
+  if (!ladder_collect(ens, slot, mask_out, nullptr, &survivors, nullptr))
+    return set_error(FC_E_LIMIT, "prune %lld: a rank's pair list was missing or too long for the device ladder",
+                     (long long)slot);
+  if (stats) {
+    const unsigned long long *local =
+        static_cast<const unsigned long long *>(ctx().pinned) + (size_t)n_slots * (size_t)(W + 16) + (size_t)slot * 8;
+    stats[0] = 0;
+    const int64_t nb = ceil_div(N, ens->row_block);
+    for (int64_t lb = 0, b; (b = global_block(lb, ens->rank, ens->world)) < nb; ++lb)
+      for (int64_t i = b * ens->row_block; i < std::min(N, (b + 1) * ens->row_block); ++i)
+        stats[0] += N - 1 - i;
+    stats[1] = (int64_t)local[1];
+    stats[2] = (int64_t)local[2];
+    stats[3] = (int64_t)local[3];
+    stats[4] = last_screen_ns();  // the most recent screen kernel of this rank
+    stats[5] = survivors;
+  }
+  return FC_OK;
+}
+
 // ---- a6 ------------------------------------------------------------------------
 int fc_inertia_moments(const double *coords, int64_t N, int64_t A, const double *masses,
                        double *moments_out) {

@@ -157,6 +157,64 @@ def prune_by_rmsd_sharded_device(ens, max_rmsd, max_dev=None, rank=0, world=1, g
                                  row_block=row_block, min_per_group=min_per_group)
 
 
+def prune_steps_sharded_device(ens, steps, max_rmsd, max_dev=None, rank=0, world=1, group=None, device=None,
+                               row_block=128, min_per_group=20, gather_fn=None):
+    """``steps`` sharded prunes of the same resident ensemble, STREAM-ORDERED: screen + refine,
+    export, the RCCL all-gather and the ladder of every prune are enqueued one after the other on
+    one HIP stream and the host waits once at the end (``fc_prune_collect``), so the GPU goes
+    from the ladder of prune k straight into the screen of prune k + 1 while the host is still
+    issuing calls.  The single send / receive buffer pair is safe: RCCL orders its stream
+    against the compute stream in both directions.  Returns a list of (mask, stats); a prune
+    whose device ladder declined is redone through the host exchange on every rank alike."""
+    import torch
+    import torch.distributed as tdist
+
+    from firecode_amd import _lib
+
+    if max_dev is None:
+        max_dev = 2 * max_rmsd
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    stream = _streams.get(device)
+    if stream is None:
+        stream = _streams[device] = torch.cuda.Stream(device=device)
+    cap = exchange_cap(ens.N, world)
+    results = []
+    with torch.cuda.stream(stream):
+        _lib.stream_set(stream.cuda_stream)
+        try:
+            key = (device, world, cap)
+            if key not in _buffers:
+                _buffers.clear()
+                _buffers[key] = (torch.empty(cap + 1, dtype=torch.int64, device=device),
+                                 torch.empty(world * (cap + 1), dtype=torch.int64, device=device))
+            send, recv = _buffers[key]
+            for k in range(steps):
+                ens.prune_begin_async(max_rmsd, max_dev, rank, world, row_block=row_block)
+                ens.export_pairs_dev(send.data_ptr(), cap)
+                if gather_fn is not None:
+                    gather_fn(send, recv)
+                elif world == 1 and group is None and not tdist.is_initialized():
+                    recv.copy_(send)
+                else:
+                    tdist.all_gather_into_tensor(recv, send, group=group)
+                ens.prune_from_gathered_enqueue(recv.data_ptr(), world, cap, k, steps, min_per_group=min_per_group)
+            for k in range(steps):
+                try:
+                    results.append(ens.prune_collect(k, steps))
+                except _lib.FirecodeHipInputError as e:
+                    if e.code != _lib.FC_E_LIMIT:
+                        raise
+                    results.append(None)
+        finally:
+            _lib.stream_set(None)
+    if any(r is None for r in results):
+        allgather = torch_allgather(group=group, device=device) if (world > 1 or tdist.is_initialized()) else None
+        results = [r if r is not None else
+                   prune_by_rmsd_sharded(ens, max_rmsd, max_dev, rank=rank, world=world, allgather_fn=allgather,
+                                         row_block=row_block, min_per_group=min_per_group) for r in results]
+    return results
+
+
 def prune_by_rmsd_sharded(ens, max_rmsd, max_dev=None, rank=0, world=1, allgather_fn=None,
                           row_block=128, min_per_group=20, trace=None, mode="auto"):
     """``ens``: a ``DeviceEnsemble`` holding the whole ensemble on this rank's

@@ -154,6 +154,14 @@ int fc_prune_rmsd_begin_async(fc_ensemble *ens, double max_rmsd, double max_dev,
 int fc_prune_export_pairs_dev(fc_ensemble *ens, uint64_t *dev_out, int64_t cap);
 int fc_prune_from_gathered_dev(fc_ensemble *ens, const uint64_t *dev_gathered, int64_t world,
                                int64_t cap, int64_t min_per_group, uint8_t *mask_out, int64_t *stats);
+/* Stream-ordered form for a batch of n_slots prunes: ..._enqueue(slot) returns without waiting
+ * (begin_async, export, all-gather and this call of prune k+1 may be issued while prune k still
+ * runs); fc_prune_collect(slot) waits for the stream and delivers that prune's mask and stats
+ * (FC_E_LIMIT: its ladder declined -- redo that prune through fc_prune_from_gathered_dev or the
+ * host exchange).  Slot 0 must be enqueued first: it sizes the pinned result area of the batch. */
+int fc_prune_from_gathered_dev_enqueue(fc_ensemble *ens, const uint64_t *dev_gathered, int64_t world,
+                                       int64_t cap, int64_t min_per_group, int64_t slot, int64_t n_slots);
+int fc_prune_collect(fc_ensemble *ens, int64_t slot, int64_t n_slots, uint8_t *mask_out, int64_t *stats);
 
 /* ---- a7: prune_by_rmsd_rot_corr(structures, atoms, graph, max_rmsd=, energies=, max_dE=) --
  * prism_pruner.pruner (NOT in the reference tree); call sites firecode/ensemble.py:253-260,

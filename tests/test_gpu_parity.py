@@ -639,6 +639,25 @@ def test_device_resident_exchange_driver_and_fallback(fc, monkeypatch):
         assert np.array_equal(mask, ref)
 
 
+def test_stream_ordered_sharded_steps(fc, monkeypatch):
+    """prune_steps_sharded_device: several prunes enqueued back to back, one host wait; every
+    prune delivers the right mask; a declined device ladder is redone through the host path"""
+    from firecode_amd import dist as fdist
+
+    X, atoms, asg = syn.synthetic_ensemble(900, 22, seed=197)
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        res = fdist.prune_steps_sharded_device(ens, 5, 0.5)
+        assert len(res) == 5
+        for mask, stats in res:
+            assert np.array_equal(mask, ref) and stats[2] == np.triu(S0, 1).sum() and stats[5] == ref.sum()
+    monkeypatch.setattr(fdist, "exchange_cap", lambda n, world: 16)  # messages longer than the capacity
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        for mask, stats in fdist.prune_steps_sharded_device(ens, 3, 0.5):
+            assert np.array_equal(mask, ref)
+
+
 def test_device_resident_exchange_over_rccl_single_rank(fc):
     """the real collective (torch.distributed nccl = RCCL) on a 1-rank group: stream ordering
     between the library's kernels and RCCL's stream, no host synchronisation in between"""
@@ -657,6 +676,8 @@ def test_device_resident_exchange_over_rccl_single_rank(fc):
         with fc.DeviceEnsemble(X, center=True) as ens:
             for _ in range(3):
                 mask, stats = fdist.prune_by_rmsd_sharded_device(ens, 0.5, rank=0, world=1)
+                assert np.array_equal(mask, ref)
+            for mask, stats in fdist.prune_steps_sharded_device(ens, 4, 0.5, rank=0, world=1):
                 assert np.array_equal(mask, ref)
     finally:
         tdist.destroy_process_group()
