@@ -510,11 +510,16 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 #endif
   // (row block, column tile) of this workgroup: from the host-built list of the items that
   // touch the upper triangle (lb << 32 | jt), or the plain 2-D enumeration when there is none
+  // bit 31 / bit 63 of an entry: the item covers only the first / second half of the row
+  // block's 16-row tiles (the last items of a launch are halves, which shortens the tail)
   int64_t jt, lb;
+  int it_first = 0, it_last = IB >> 4;
   if (item_table != nullptr) {
     const uint64_t it = item_table[b];
-    lb = (int64_t)(it >> 32);
-    jt = (int64_t)(it & 0xffffffffull);
+    lb = (int64_t)((it >> 32) & 0x7fffffffull);
+    jt = (int64_t)(it & 0x7fffffffull);
+    if (it & (1ull << 31)) it_last = IB >> 5;
+    if (it & (1ull << 63)) it_first = IB >> 5;
   } else {
     const int64_t NT = Npad >> 6;
     jt = (int64_t)(b % (unsigned long long)NT);
@@ -577,7 +582,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
     for (int c = 0; c < 3; ++c) a[c] = xs_s[vo[c]];
   };
 
-  for (int it = wv; it * 16 < IB; it += NW) {
+  for (int it = it_first + wv; it < it_last; it += NW) {
     const int64_t ib = i0 + (int64_t)it * 16;
     if (ib >= N) break;
     if (j0 + TC - 1 <= ib) break;
@@ -663,7 +668,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 #undef FC_KSTEP
       {  // request the next unit's first three k-steps now; they land during the epilogue
         const int nit = half == 0 ? it : it + NW;
-        const bool more = half == 0 || ((nit * 16 < IB) && (i0 + (int64_t)nit * 16 < N) &&
+        const bool more = half == 0 || ((nit < it_last) && (i0 + (int64_t)nit * 16 < N) &&
                                         !(j0 + TC - 1 <= i0 + (int64_t)nit * 16));
         if (more) {
           unsigned vn[3];
@@ -1065,6 +1070,22 @@ static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks) {
   for (int64_t l = 0; l < n_lblocks; ++l) {
     const int64_t first = r * global_block(l, e->rank, e->world);
     for (int64_t jt = first; jt < NT; ++jt) items.push_back(((uint64_t)l << 32) | (uint64_t)jt);
+  }
+  // the last items of the launch as two half-row-block items each: workgroups finish within
+  // half an item of each other instead of a whole one (FC_SCREEN_TAIL_SLOTS items, default
+  // one round of resident workgroups; needs 8 row tiles per block and 4-wave workgroups)
+  {
+    int64_t tail = 2 * (int64_t)ctx().n_cu;
+    if (const char *v = getenv("FC_SCREEN_TAIL_SLOTS")) tail = std::strtoll(v, nullptr, 10);
+    if (e->row_block == 128 && tail > 0 && (int64_t)items.size() > 4 * tail && e->A <= 52) {
+      std::vector<uint64_t> halves;
+      for (int64_t k = (int64_t)items.size() - tail; k < (int64_t)items.size(); ++k) {
+        halves.push_back(items[(size_t)k] | (1ull << 31));
+        halves.push_back(items[(size_t)k] | (1ull << 63));
+      }
+      items.resize(items.size() - (size_t)tail);
+      items.insert(items.end(), halves.begin(), halves.end());
+    }
   }
   if (items.empty() || items.size() >= (1ull << 31)) return FC_OK;
   FC_TRY(e->item_table.reserve(items.size() * sizeof(uint64_t)));
