@@ -205,6 +205,30 @@ G["ens_text"] = np.array(text)
 G["ens_back_coords"] = back.coords
 G["ens_back_atoms"] = back.atoms
 
+# ---- the reference's own test fixtures through its own reader (ensemble.py:58-98) -----------
+# data files of firecode/tests: text in, (atoms, coords) out; plus the in-tree clash functions
+# on these real molecules
+_fx = {"anti_to_gauche": "multithread_refine/anti_to_gauche.xyz", "catalyst": "operator_firecode_search/catalyst.xyz",
+       "salt": "operator_crest_search/salt.xyz", "butane": "operator_rdkit_search/butane.xyz",
+       "propane_ts": "propane_ts.xyz", "c2h4_hyper": "embed_cyclical/C2H4_hypermolecule.xyz"}
+_tests_dir = os.path.join(os.path.dirname(fens.__file__), "tests")
+saved_pt = fens.pt
+fens.pt = types.SimpleNamespace(number=lambda s: 0)
+try:
+    for name, rel in _fx.items():
+        path = os.path.join(_tests_dir, rel)
+        e = fens.Ensemble.from_xyz(path)
+        G[f"fx_{name}_text"] = np.array(open(path).read())
+        G[f"fx_{name}_atoms"] = np.array(e.atoms)
+        G[f"fx_{name}_coords"] = np.array(e.coords)
+        G[f"fx_{name}_clashes"] = np.array([fa.count_clashes(c) for c in e.coords], dtype=np.int64)
+        A_ = e.coords.shape[1]
+        G[f"fx_{name}_frag"] = np.array([[fu.compenetration_check(c, ids=[A_ // 2, A_ - A_ // 2], thresh=1.6, max_clashes=mc)
+                                          for mc in (0, 1, 2, 4, 8)] for c in e.coords])
+finally:
+    fens.pt = saved_pt
+G["fx_names"] = np.array(list(_fx))
+
 en = np.sort(rng.uniform(0, 30, size=50))
 en[0] = 0.0
 ens2 = fens.Ensemble(atoms=ens_atoms, coords=rng.normal(size=(50, 7, 3)), energies=en.copy(), logfunction=None)

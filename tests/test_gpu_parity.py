@@ -352,6 +352,18 @@ def test_scan_with_fingerprints_equals_two_passes(fc):
     assert np.abs(tf - o.get_tf_mat(o.torsion_scan(base, tors, masks, angles)[0], quads)).max() < 1e-9
 
 
+def test_clash_functions_on_the_reference_fixture_molecules(fc, golden):
+    """count_clashes / fragment compenetration_check on the molecules of the reference's own test
+    files, against the reference's own outputs"""
+    for name in golden["fx_names"]:
+        coords = golden[f"fx_{name}_coords"]
+        A = coords.shape[1]
+        assert np.array_equal(fc.algebra.count_clashes_batch(coords), golden[f"fx_{name}_clashes"])
+        for k, mc in enumerate((0, 1, 2, 4, 8)):
+            out = fc.utils.compenetration_check_batch(coords, ids=[A // 2, A - A // 2], thresh=1.6, max_clashes=mc)
+            assert np.array_equal(out, golden[f"fx_{name}_frag"][:, k])
+
+
 def test_rotate_dihedral_and_comp_check(fc, golden):
     base, tors, masks = _chain_case(20, 2, seed=32)
     new = fc.utils.rotate_dihedral(base, tors[0], 120, mask=masks[0])

@@ -89,3 +89,18 @@ def test_xyz_format(golden):
     atoms, coords = o.ensemble_from_xyz_text(text)
     assert np.array_equal(coords, golden["ens_back_coords"])
     assert np.array_equal(atoms, golden["ens_back_atoms"])
+
+
+def test_reference_fixture_files(golden, tmp_path):
+    """the reference's own test data files (firecode/tests/**.xyz): its reader's output and its
+    in-tree clash functions on those molecules"""
+    for name in golden["fx_names"]:
+        text = str(golden[f"fx_{name}_text"])
+        atoms, coords = o.ensemble_from_xyz_text(text)
+        assert np.array_equal(np.asarray(atoms), golden[f"fx_{name}_atoms"])
+        assert np.array_equal(coords, golden[f"fx_{name}_coords"])
+        A = coords.shape[1]
+        assert np.array_equal([o.count_clashes(c) for c in coords], golden[f"fx_{name}_clashes"])
+        frag = [[o.compenetration_check(c, ids=[A // 2, A - A // 2], thresh=1.6, max_clashes=mc) for mc in (0, 1, 2, 4, 8)]
+                for c in coords]
+        assert np.array_equal(frag, golden[f"fx_{name}_frag"])

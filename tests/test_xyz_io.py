@@ -97,3 +97,18 @@ def test_ensemble_roundtrip_and_energies(tmp_path):
     p.write_text("\n".join(f"2\nE = -{n}.250 Eh\nH 0 0 0\nH 0 0 {n}" for n in range(1, 4)))
     e = fe.Ensemble.from_xyz(p, read_energies=True)
     assert e.energies.tolist() == [-1.25, -2.25, -3.25] and e.coords.shape == (3, 2, 3)
+
+
+def test_reads_the_reference_fixture_files_like_the_reference(golden, tmp_path):
+    """the library's reader on the reference's own test data files (firecode/tests/**.xyz) against
+    what the reference's Ensemble.from_xyz made of them; and its writer round-trips them"""
+    for name in golden["fx_names"]:
+        path = tmp_path / f"{name}.xyz"
+        path.write_text(str(golden[f"fx_{name}_text"]))
+        atoms, coords = L.xyz_read(str(path))
+        assert list(atoms) == list(golden[f"fx_{name}_atoms"])
+        assert np.array_equal(coords, golden[f"fx_{name}_coords"])
+        out = tmp_path / f"{name}_out.xyz"
+        L.xyz_write(str(out), atoms, coords, label=name, mode=0)
+        atoms2, coords2 = L.xyz_read(str(out))
+        assert list(atoms2) == list(atoms) and np.abs(coords2 - coords).max() < 1e-8
