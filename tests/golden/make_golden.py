@@ -128,6 +128,19 @@ for R, t, ids in zip(ge_R, ge_t, ge_ids):
 G["ge_c1"], G["ge_c2"], G["ge_R"], G["ge_t"], G["ge_ids"] = m1.coords, m2.coords, ge_R, ge_t, ge_ids
 G["ge_out"] = np.array(ge_out)
 
+# ---- _get_cyclical_reactive_indices (embeds.py:753-784), both branches ------------------------
+def _piv(a, b):
+    return types.SimpleNamespace(start_atom=types.SimpleNamespace(cumnum=a), end_atom=types.SimpleNamespace(cumnum=b))
+
+
+cri_cum2 = np.array([[3, 9], [20, 25]])
+cri_cum3 = np.array([[2, 7], [13, 19], [31, 25]])
+emb2 = types.SimpleNamespace(objects=[None, None])
+emb3 = types.SimpleNamespace(objects=[None, None, None])
+G["cri_cum2"], G["cri_cum3"] = cri_cum2, cri_cum3
+G["cri_out2"] = np.array([fe._get_cyclical_reactive_indices(emb2, [_piv(*c) for c in cri_cum2.tolist()], n) for n in range(2)])
+G["cri_out3"] = np.array([fe._get_cyclical_reactive_indices(emb3, [_piv(*c) for c in cri_cum3.tolist()], n) for n in range(8)])
+
 # ---- torsion_comp_check (torsion_module.py:894-918) -------------------------
 tc_in = rng.normal(scale=1.8, size=(50, 40, 3))
 tc_mask = rng.random(size=(50, 40)) < 0.4

@@ -68,3 +68,18 @@ def test_rotation_mask_golden(golden):
     out = np.array([rotation_mask(graph, t, graph.number_of_nodes()) for t in golden["rotmask_torsions"]])
     assert np.array_equal(out, golden["rotmask_out"])
     assert graph.number_of_edges() == len(golden["rotmask_edges"])  # the graph is restored
+
+
+def test_cyclical_reactive_indices_golden(golden):
+    """host helpers (and the oracle's copies) against the reference's _get_cyclical_reactive_indices"""
+    from oracle import cyclical_ref as cy
+
+    c2, c3 = golden["cri_cum2"].tolist(), golden["cri_cum3"].tolist()
+    for n in range(2):
+        assert np.array_equal(hh.cyclical_reactive_indices(c2[0], c2[1], n), golden["cri_out2"][n])
+        piv = [cy.Pivot(np.zeros(3), np.ones(3), a, b) for a, b in c2]
+        assert np.array_equal(cy.get_cyclical_reactive_indices_bimol(piv, n), golden["cri_out2"][n])
+    for n in range(8):
+        assert np.array_equal(hh.cyclical_reactive_indices_tri([tuple(c) for c in c3], n), golden["cri_out3"][n])
+        piv = [cy.Pivot(np.zeros(3), np.ones(3), a, b) for a, b in c3]
+        assert np.array_equal(cy.get_cyclical_reactive_indices(piv, n), golden["cri_out3"][n])
