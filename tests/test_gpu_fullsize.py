@@ -113,3 +113,39 @@ def test_cfg3_full_scan_samples_and_tfd(fc):
         d = np.abs(d - (d > 180) * 360).sum(axis=1)
         d[i] = 1e9
         assert d.min() < 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_multi_gpu_sizes_with_logical_ranks(fc, world):
+    """the exact problem of `bench.py --gpus N` (10^4 sqrt(N) conformers, exchange capacity, item
+    tables, half-item tail) with the N ranks played one after the other on ONE GPU: every
+    rank's message fits, the replayed ladder gives the single-GPU mask, one survivor per cluster"""
+    import torch
+
+    from firecode_amd import _lib
+    from firecode_amd import dist as fdist
+
+    n = int(round(10000 * np.sqrt(world)))
+    X, atoms, asg = syn.synthetic_ensemble(n, 50, seed=2)
+    cap = fdist.exchange_cap(n, world)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        ref, stats0 = ens.prune(0.5, 1.0)
+        with torch.cuda.stream(stream):
+            _lib.stream_set(stream.cuda_stream)
+            try:
+                recv = torch.zeros(world * (cap + 1), dtype=torch.int64, device=dev)
+                for r in range(world):
+                    ens.prune_begin_async(0.5, 1.0, r, world, row_block=128)
+                    ens.export_pairs_dev(recv.data_ptr() + 8 * r * (cap + 1), cap)
+                ens.prune_from_gathered_enqueue(recv.data_ptr(), world, cap, 0, 1)
+                mask, stats = ens.prune_collect(0, 1)
+                counts = recv.cpu().numpy().view(np.uint64).reshape(world, cap + 1)[:, 0]
+            finally:
+                _lib.stream_set(None)
+    assert np.array_equal(mask, ref)
+    assert mask.sum() == len(np.unique(asg))
+    assert int(counts.sum()) == stats0[2] and int(counts.max()) <= cap
+    assert counts.max() - counts.min() < 0.1 * counts.mean()  # the snake deal balances the pairs too
