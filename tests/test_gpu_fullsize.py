@@ -149,3 +149,40 @@ def test_bench_multi_gpu_sizes_with_logical_ranks(fc, world):
     assert mask.sum() == len(np.unique(asg))
     assert int(counts.sum()) == stats0[2] and int(counts.max()) <= cap
     assert counts.max() - counts.min() < 0.1 * counts.mean()  # the snake deal balances the pairs too
+
+
+def test_cfg4_full_size_eight_logical_ranks(fc):
+    """BASELINE configs[3] whole: 100 000 conformers x 80 atoms, the 8 ranks of the sharded prune
+    played on one GPU (row blocks in snake order, one message per rank, replayed ladder):
+    one survivor per cluster, messages within capacity and balanced"""
+    import torch
+
+    from firecode_amd import _lib
+    from firecode_amd import dist as fdist
+
+    n, world = 100_000, 8
+    X, atoms, asg = syn.synthetic_ensemble(n, 80, seed=6)
+    n_clusters = len(np.unique(asg))
+    cap = fdist.exchange_cap(n, world)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        del X
+        with torch.cuda.stream(stream):
+            _lib.stream_set(stream.cuda_stream)
+            try:
+                recv = torch.zeros(world * (cap + 1), dtype=torch.int64, device=dev)
+                for r in range(world):
+                    ens.prune_begin_async(0.5, 1.0, r, world, row_block=128)
+                    ens.export_pairs_dev(recv.data_ptr() + 8 * r * (cap + 1), cap)
+                ens.prune_from_gathered_enqueue(recv.data_ptr(), world, cap, 0, 1)
+                mask, stats = ens.prune_collect(0, 1)
+                counts = recv.cpu().numpy().view(np.uint64).reshape(world, cap + 1)[:, 0].astype(np.int64)
+            finally:
+                _lib.stream_set(None)
+    assert mask.sum() == n_clusters
+    first = np.zeros(n_clusters, dtype=np.int64)  # the greedy ladder keeps the LAST member of a cluster (i removed when a later j matches)
+    np.maximum.at(first, asg, np.arange(n))
+    assert np.array_equal(np.flatnonzero(mask), np.sort(first))
+    assert counts.max() <= cap and counts.max() - counts.min() < 0.1 * counts.mean()
+    assert int(counts.sum()) == int(sum(c * (c - 1) // 2 for c in np.bincount(asg)))
