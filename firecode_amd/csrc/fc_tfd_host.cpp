@@ -30,12 +30,15 @@ namespace fc {
 
 // ---- CPython set emulation ---------------------------------------------------
 struct PySetEmu {
+  // 16-byte entries (an empty slot has key == kEmpty; keys are non-negative), a spare table that
+  // keeps its pages across growths, and prefetches of the home slot: the emulation of a set of
+  // ~10^6 tuples is bound by DRAM latency (tables of 2^22 slots), not by arithmetic
+  static constexpr int64_t kEmpty = -1;
   struct Entry {
-    int64_t key = 0;   // caller-defined id (int value, or index of a pair)
+    int64_t key = kEmpty;  // caller-defined id (int value, or index of a pair)
     int64_t hash = 0;
-    bool used = false;
   };
-  std::vector<Entry> table;
+  std::vector<Entry> table, spare;
   size_t mask = 7, fill = 0, used_n = 0;
   PySetEmu() : table(8) {}
   void reset() {  // back to an empty 8-slot set; keeps the allocation
@@ -43,21 +46,22 @@ struct PySetEmu {
     mask = 7;
     fill = used_n = 0;
   }
+  void prefetch(int64_t hash) const { __builtin_prefetch(&table[(size_t)hash & mask], 1, 0); }
 
   static void insert_clean(std::vector<Entry> &t, size_t mask, int64_t key, int64_t hash) {
     size_t perturb = (size_t)hash;
     size_t i = (size_t)hash & mask;
     while (true) {
       size_t e = i;
-      if (!t[e].used) {
-        t[e] = {key, hash, true};
+      if (t[e].key == kEmpty) {
+        t[e] = {key, hash};
         return;
       }
       if (i + 9 <= mask) {
         for (int j = 0; j < 9; ++j) {
           ++e;
-          if (!t[e].used) {
-            t[e] = {key, hash, true};
+          if (t[e].key == kEmpty) {
+            t[e] = {key, hash};
             return;
           }
         }
@@ -70,11 +74,15 @@ struct PySetEmu {
   void resize(size_t minused) {
     size_t newsize = 8;
     while (newsize <= minused) newsize <<= 1;
-    std::vector<Entry> nt(newsize);
+    spare.assign(newsize, Entry{});
     const size_t newmask = newsize - 1;
-    for (size_t s = 0; s <= mask; ++s)
-      if (table[s].used) insert_clean(nt, newmask, table[s].key, table[s].hash);
-    table.swap(nt);
+    constexpr size_t kAhead = 16;  // slots of the old table looked at in advance
+    for (size_t s = 0; s <= mask; ++s) {
+      if (s + kAhead <= mask && table[s + kAhead].key != kEmpty)
+        __builtin_prefetch(&spare[(size_t)table[s + kAhead].hash & newmask], 1, 0);
+      if (table[s].key != kEmpty) insert_clean(spare, newmask, table[s].key, table[s].hash);
+    }
+    table.swap(spare);
     mask = newmask;
     fill = used_n;
   }
@@ -88,8 +96,8 @@ struct PySetEmu {
       size_t e = i;
       int probes = (i + 9 <= mask) ? 9 : 0;
       do {
-        if (!table[e].used) {
-          table[e] = {key, hash, true};
+        if (table[e].key == kEmpty) {
+          table[e] = {key, hash};
           ++fill;
           ++used_n;
           if (fill * 5 >= mask * 3) resize(used_n > 50000 ? used_n * 2 : used_n * 4);
@@ -111,7 +119,7 @@ struct PySetEmu {
       size_t e = i;
       int probes = (i + 9 <= mask) ? 9 : 0;
       do {
-        if (!table[e].used) return false;
+        if (table[e].key == kEmpty) return false;
         if (table[e].hash == hash && eq(table[e].key, key)) return true;
         ++e;
       } while (probes--);
@@ -123,7 +131,7 @@ struct PySetEmu {
   template <class F>
   void for_each(F f) const {  // iteration order of `for x in the_set`
     for (size_t s = 0; s <= mask; ++s)
-      if (table[s].used) f(table[s].key);
+      if (table[s].key != kEmpty) f(table[s].key);
   }
 };
 
@@ -166,7 +174,7 @@ void pyset_order_pairs(const int64_t *pairs, int64_t n, std::vector<int64_t> &ou
 // Scratch that survives across the ~10^5 chunks of a fine ladder level.
 struct ChunkScratch {
   PySetEmu edge_set, comp, view;
-  std::vector<int64_t> order, nodes, members, level, next, adj_head, adj_next, adj_to, adj_tail;
+  std::vector<int64_t> order, nodes, members, level, next, adj_head, adj_next, adj_to, adj_tail, hashes;
   std::vector<int64_t> pos_of;     // relative index -> position in `nodes` (valid when stamp matches)
   std::vector<int64_t> stamp;
   std::vector<char> seen;
@@ -176,6 +184,9 @@ struct ChunkScratch {
 // edges[k] = (i_rel, j_rel) in the order the reference adds them to `matches`.
 static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, ChunkScratch &w,
                           std::vector<int64_t> &rejects) {
+  const bool dbg = chunk_len > 200000 && getenv("FC_DEBUG");
+  auto T0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) { if (dbg) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[fc]   chunk %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
   rejects.clear();
   const int64_t m = (int64_t)edges.size() / 2;
   if (m == 0) return;
@@ -186,44 +197,63 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
     auto eq = [&](int64_t x, int64_t y) {
       return pairs[x * 2] == pairs[y * 2] && pairs[x * 2 + 1] == pairs[y * 2 + 1];
     };
-    for (int64_t k = 0; k < m; ++k) w.edge_set.add(k, py_tuple2_hash(pairs[k * 2], pairs[k * 2 + 1]), eq);
+    constexpr int64_t kAhead = 12;
+    w.hashes.resize((size_t)m);
+    for (int64_t k = 0; k < m; ++k) w.hashes[(size_t)k] = py_tuple2_hash(pairs[k * 2], pairs[k * 2 + 1]);
+    for (int64_t k = 0; k < m; ++k) {
+      if (k + kAhead < m) w.edge_set.prefetch(w.hashes[(size_t)(k + kAhead)]);
+      w.edge_set.add(k, w.hashes[(size_t)k], eq);
+    }
     w.order.clear();
     w.edge_set.for_each([&](int64_t key) { w.order.push_back(key); });
   }
+  lap("edge set");
   if ((int64_t)w.pos_of.size() < chunk_len) {
     w.pos_of.resize((size_t)chunk_len);
     w.stamp.resize((size_t)chunk_len, -1);
   }
   const int64_t gen = ++w.generation;
   w.nodes.clear();
-  w.adj_head.clear();  // per node: first adjacency record (-1 = none); records form insertion-ordered lists
-  w.adj_tail.clear();
-  w.adj_next.clear();
-  w.adj_to.clear();
   auto node_of = [&](int64_t v) {
     if (w.stamp[(size_t)v] == gen) return w.pos_of[(size_t)v];
     const int64_t p = (int64_t)w.nodes.size();
     w.stamp[(size_t)v] = gen;
     w.pos_of[(size_t)v] = p;
     w.nodes.push_back(v);
-    w.adj_head.push_back(-1);
-    w.adj_tail.push_back(-1);
     return p;
   };
-  auto link = [&](int64_t from, int64_t to) {  // matches are unique pairs: no duplicate neighbours
-    const int64_t rec = (int64_t)w.adj_to.size();
-    w.adj_to.push_back(to);
-    w.adj_next.push_back(-1);
-    if (w.adj_head[(size_t)from] < 0) w.adj_head[(size_t)from] = rec;
-    else w.adj_next[(size_t)w.adj_tail[(size_t)from]] = rec;
-    w.adj_tail[(size_t)from] = rec;
-  };
-  for (int64_t e : w.order) {
-    const int64_t pu = node_of(edges[e * 2]);
-    const int64_t pv = node_of(edges[e * 2 + 1]);
-    link(pu, pv);
-    link(pv, pu);
+  // edges arrive in hash order, i.e. at random: two-stage prefetch (the edge, then its endpoints'
+  // stamp / position slots) hides most of the DRAM latency of a 10^6-node chunk
+  const int64_t n_ord = (int64_t)w.order.size();
+  w.adj_to.resize((size_t)n_ord * 2);  // (pu, pv) per edge, in the order Graph() sees them
+  for (int64_t q = 0; q < n_ord; ++q) {
+    if (q + 16 < n_ord) __builtin_prefetch(&edges[(size_t)w.order[(size_t)(q + 16)] * 2], 0, 0);
+    if (q + 8 < n_ord) {
+      const int64_t e8 = w.order[(size_t)(q + 8)];
+      const int64_t u8 = edges[(size_t)e8 * 2], v8 = edges[(size_t)e8 * 2 + 1];
+      __builtin_prefetch(&w.stamp[(size_t)u8], 1, 0);
+      __builtin_prefetch(&w.pos_of[(size_t)u8], 1, 0);
+      __builtin_prefetch(&w.stamp[(size_t)v8], 1, 0);
+      __builtin_prefetch(&w.pos_of[(size_t)v8], 1, 0);
+    }
+    const int64_t e = w.order[(size_t)q];
+    w.adj_to[(size_t)q * 2] = node_of(edges[e * 2]);
+    w.adj_to[(size_t)q * 2 + 1] = node_of(edges[e * 2 + 1]);
   }
+  // neighbour lists in insertion order (what networkx's adjacency dicts iterate), as CSR:
+  // matches are unique pairs, so there are no duplicate neighbours
+  const int64_t n_nodes_csr = (int64_t)w.nodes.size();
+  w.adj_head.assign((size_t)n_nodes_csr + 1, 0);  // start offsets
+  for (int64_t q = 0; q < 2 * n_ord; ++q) ++w.adj_head[(size_t)w.adj_to[(size_t)q] + 1];
+  for (int64_t v = 0; v < n_nodes_csr; ++v) w.adj_head[(size_t)v + 1] += w.adj_head[(size_t)v];
+  w.adj_tail.assign(w.adj_head.begin(), w.adj_head.end() - 1);  // fill cursors
+  w.adj_next.resize((size_t)n_ord * 2);                          // neighbour array
+  for (int64_t q = 0; q < n_ord; ++q) {
+    const int64_t pu = w.adj_to[(size_t)q * 2], pv = w.adj_to[(size_t)q * 2 + 1];
+    w.adj_next[(size_t)w.adj_tail[(size_t)pu]++] = pv;
+    w.adj_next[(size_t)w.adj_tail[(size_t)pv]++] = pu;
+  }
+  lap("adjacency");
   const int64_t n_nodes = (int64_t)w.nodes.size();
   w.seen.assign((size_t)n_nodes, 0);
   int64_t n_seen = 0;
@@ -241,8 +271,8 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
     while (!w.level.empty() && !full) {
       w.next.clear();
       for (int64_t v : w.level) {
-        for (int64_t rec = w.adj_head[(size_t)v]; rec >= 0; rec = w.adj_next[(size_t)rec]) {
-          const int64_t x = w.adj_to[(size_t)rec];
+        for (int64_t rec = w.adj_head[(size_t)v]; rec < w.adj_head[(size_t)v + 1]; ++rec) {
+          const int64_t x = w.adj_next[(size_t)rec];
           if (!w.seen[(size_t)x]) {
             w.seen[(size_t)x] = 1;
             w.comp.add(w.nodes[(size_t)x], w.nodes[(size_t)x], int_eq);
@@ -273,6 +303,7 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
     for (int64_t p : w.members)
       if (w.nodes[(size_t)p] != first) rejects.push_back(w.nodes[(size_t)p]);
   }
+  lap("components");
 }
 
 // chunks [step_begin, step_end) of one ladder level; chunks are independent
