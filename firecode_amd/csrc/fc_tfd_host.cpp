@@ -270,11 +270,21 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
     bool full = (int64_t)w.members.size() == limit;
     while (!w.level.empty() && !full) {
       w.next.clear();
-      for (int64_t v : w.level) {
+      const size_t n_level = w.level.size();
+      for (size_t li = 0; li < n_level; ++li) {
+        const int64_t v = w.level[li];
+        if (li + 3 < n_level) {  // neighbours of a node three places ahead: their flags and ids
+          const int64_t v3 = w.level[li + 3];
+          for (int64_t rec = w.adj_head[(size_t)v3]; rec < w.adj_head[(size_t)v3 + 1]; ++rec) {
+            __builtin_prefetch(&w.seen[(size_t)w.adj_next[(size_t)rec]], 1, 0);
+            __builtin_prefetch(&w.nodes[(size_t)w.adj_next[(size_t)rec]], 0, 0);
+          }
+        }
         for (int64_t rec = w.adj_head[(size_t)v]; rec < w.adj_head[(size_t)v + 1]; ++rec) {
           const int64_t x = w.adj_next[(size_t)rec];
           if (!w.seen[(size_t)x]) {
             w.seen[(size_t)x] = 1;
+            __builtin_prefetch(&w.adj_head[(size_t)x], 0, 0);  // read when x is expanded, one level on
             w.comp.add(w.nodes[(size_t)x], w.nodes[(size_t)x], int_eq);
             w.members.push_back(x);
             w.next.push_back(x);
