@@ -542,32 +542,45 @@ k_tfd_first_match(const double *__restrict__ tfT, int64_t N, int64_t Npad, int Q
   if (tid < 64) best[tid] = (i0 + tid < N) ? (long long)N : -2;  // N = none yet, -2 = no such row
   if (tid == 0) n_open = (int)((N - i0 < 64) ? (N - i0) : 64);
   __syncthreads();
-  for (int64_t jb = i0 + 1; jb < N; jb += 256) {
-    const int64_t j = jb + tid;
-    if (j < N) {
-      double cj[QT > 0 ? QT : 1];
-      if (QT > 0) {
+  // Rows retire at very different distances (in a systematic scan the first match of a
+  // conformer can be 10^5 columns away), so the window loop works on the COMPACTED list of
+  // rows that are still open and widens the window as that list shrinks: a workgroup left
+  // with one open row covers 4096 columns per pair of barriers instead of 256.
+  __shared__ int open_rows[64];
+  int64_t jb = i0 + 1;
+  while (jb < N) {
+    if (tid < 64) {  // wave 0: compact the open rows (ballot order = row order)
+      const bool is_open = best[tid] == (long long)N;
+      const uint64_t m = __ballot(is_open);
+      if (is_open) open_rows[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+      if (tid == 0) n_open = __popcll(m);
+    }
+    __syncthreads();
+    const int R = n_open;
+    if (R == 0) break;
+    const int cpt = R >= 32 ? 1 : R >= 16 ? 2 : R >= 8 ? 4 : R >= 4 ? 8 : 16;  // columns per thread
+    for (int c = 0; c < cpt; ++c) {
+      const int64_t j = jb + (int64_t)c * 256 + tid;
+      if (j < N) {
+        double cj[QT > 0 ? QT : 1];
+        if (QT > 0) {
 #pragma unroll
-        for (int q = 0; q < QT; ++q) cj[q] = tfT[(int64_t)q * Npad + j];
-      }
-      for (int r = 0; r < 64; ++r) {
-        const int64_t i = i0 + r;
-        // rows are retired in increasing-column windows: a hit in an earlier
-        // window is final, a hit in this window is resolved with atomicMin
-        if (i >= N || j <= i || best[r] < jb) continue;
-        const double sum = (QT > 0) ? tfd_sum(rows + r * Q, 1, cj, 1, QT)
-                                    : tfd_sum(rows + r * Q, 1, tfT + j, Npad, Q);
-        if (sum < thresh) atomicMin(&best[r], (long long)j);
+          for (int q = 0; q < QT; ++q) cj[q] = tfT[(int64_t)q * Npad + j];
+        }
+        for (int k = 0; k < R; ++k) {
+          const int r = open_rows[k];
+          const int64_t i = i0 + r;
+          // a hit in an earlier window is final (the row is no longer in the list); hits inside
+          // this window are resolved with atomicMin
+          if (j <= i) continue;
+          const double sum = (QT > 0) ? tfd_sum(rows + r * Q, 1, cj, 1, QT)
+                                      : tfd_sum(rows + r * Q, 1, tfT + j, Npad, Q);
+          if (sum < thresh) atomicMin(&best[r], (long long)j);
+        }
       }
     }
+    jb += (int64_t)cpt * 256;
     __syncthreads();
-    if (tid == 0) {
-      int open = 0;
-      for (int r = 0; r < 64; ++r) open += (best[r] == (long long)N) ? 1 : 0;
-      n_open = open;
-    }
-    __syncthreads();
-    if (n_open == 0) break;
   }
   if (tid < 64 && i0 + tid < N) first_match[i0 + tid] = (best[tid] >= (long long)N) ? -1 : best[tid];
 }
