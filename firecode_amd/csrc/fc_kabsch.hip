@@ -317,6 +317,9 @@ __device__ __forceinline__ void push_pairs(uint64_t m, bool may, unsigned i, uns
 #ifndef FC_REFINE_ROUNDS
 #define FC_REFINE_ROUNDS 4  // measured: 8 -> 66 us, 4 -> 53 us, 2 -> 59 us, 1 (all redundant) -> 82 us
 #endif
+#ifndef FC_V2_ALIGN
+#define FC_V2_ALIGN 1
+#endif
 #ifndef FC_REFINE_UNROLL
 #define FC_REFINE_UNROLL 1
 #endif
@@ -783,6 +786,285 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// k_screen_rowsweep -- the same screen, other schedule.  MEASURED SLOWER, kept as evidence
+// (FC_SCREEN_V2=1): 1.05 ms with the phase barriers, 1.00 ms without them (-DFC_V2_ALIGN=0), against
+// 0.96 ms for the kernel above at 10^4 conformers (3.80 / 3.64 / 3.43 ms at 2*10^4).
+//
+// What the one-item-per-workgroup kernel above loses is known: the
+// polynomial epilogue of one wavefront is ADDED to the MFMA stream of the other wavefront of
+// its SIMD and issues at half rate while it runs alone; a freed slot waits ~6 us for its
+// next workgroup; the column tile is fetched in front of every item.  Here a workgroup is
+// 8 wavefronts (2 per SIMD, one workgroup per CU) that stays resident and sweeps a contiguous
+// run of items:
+//   * the next item's column tile arrives by LDS-DMA in the OTHER half of LDS while this one
+//     is computed (two 78 KB buffers);
+//   * barriers keep the wavefronts in phase -- K loop, epilogue, K loop, epilogue -- so the
+//     two wavefronts of a SIMD do their fp64 VALU work together, at full issue rate, and
+//     their MFMA work together;
+//   * no dispatch between items, equal item counts per workgroup (tail <= one item).
+// Wavefront w owns the 16-row tile w of the 128-row block.  A <= 52 atoms, row blocks of 128.
+// Why it loses: two fp64-VALU wavefronts on a SIMD only reach 1.4x the rate of one
+// (tools/ubench_f64: 52 vs 38 TFLOP/s), so aligned epilogues gain little, while waves in phase
+// stall together on the first operand loads of every K loop and wait for the slowest of eight
+// at every barrier; without the phase barriers the per-item barrier and the spills (124 B)
+// still cost more than the dispatch gap and the tile fill they remove.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 1)
+k_screen_rowsweep(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N, int64_t Npad,
+                  int A, double A_thr2, int64_t rank, int64_t world, uint64_t *__restrict__ bits, int64_t W,
+                  uint32_t *__restrict__ cand, unsigned long long *__restrict__ counters,
+                  uint64_t *__restrict__ pairq, unsigned long long Q, const uint64_t *__restrict__ item_table,
+                  unsigned long long n_items) {
+  extern __shared__ double lds[];
+  constexpr int TC = 64, IB = 128, NW = 8;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KS = (A + 3) >> 2;
+  const int tile_doubles = KS * 12 * TC;
+  double *__restrict__ ldsGc = lds + 2 * tile_doubles;  // [2][TC] column sums of squares
+  double *__restrict__ ldsGr = ldsGc + 2 * TC;          // [IB] row sums of squares
+  uint64_t *__restrict__ stageQ = reinterpret_cast<uint64_t *>(ldsGr + IB);
+  uint32_t *__restrict__ stageW = reinterpret_cast<uint32_t *>(stageQ + kStagePairs);
+  unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWords);
+  const unsigned long long t_begin = n_items * blockIdx.x / gridDim.x;
+  const unsigned long long t_end = n_items * (blockIdx.x + 1ull) / gridDim.x;
+  if (t_begin >= t_end) return;
+  const int kq = lane >> 4, l15 = lane & 15;
+  const int boff = (kq >> 1) * (2 * TC) + (kq & 1) * 16 + l15;
+  const int cs_l = lane >> 4, k1_l = (lane >> 3) & 1, c15_l = (lane & 7) * 2;
+  uint16_t *bits16 = reinterpret_cast<uint16_t *>(bits);
+  const int n32 = (int)N;
+
+  auto dma_tile = [&](int64_t jt_, int which) {  // column tile jt_ -> buffer `which` (see the kernel above)
+    double *dst = lds + which * tile_doubles;
+    const int n_runs = KS * 6;
+    for (int q = wv; q < n_runs; q += NW) {
+      const int sc = q >> 1, kh = q & 1;
+      const int sg = sc / 3, c = sc - sg * 3;
+      const int a = sg * 4 + kh * 2 + k1_l;
+      const double *src = Xs + (int64_t)(a * 3 + c) * Npad + jt_ * TC + cs_l * 16 + c15_l;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(dst + q * 128), 16, 0, 0);
+    }
+    if (tid < TC) {
+      const int64_t g = jt_ * TC + tid;
+      ldsGc[which * TC + tid] = g < Npad ? G[g] : 0.0;
+    }
+  };
+  auto flush_stage = [&]() {  // wavefront 0: publish and reset the staged candidates
+    {
+      const uint64_t e = lane < kStagePairs ? stageQ[lane] : ~0ull;
+      const bool valid = e != ~0ull;
+      const uint64_t mv = __ballot(valid);
+      if (mv != 0) {
+        unsigned long long gbase = 0;
+        if (lane == 0) gbase = atomicAdd(&counters[6], (unsigned long long)__popcll(mv));
+        gbase = __shfl(gbase, 0);
+        if (valid) {
+          const unsigned long long slot = gbase + (unsigned long long)__popcll(mv & ((1ull << lane) - 1ull));
+          if (slot < Q) pairq[slot] = e;
+        }
+      }
+      if (lane < kStagePairs) stageQ[lane] = ~0ull;
+    }
+    {
+      const uint32_t wq = lane < kStageWords ? stageW[lane] : ~0u;
+      const bool valid = wq != ~0u;
+      const uint64_t mv = __ballot(valid);
+      if (mv != 0) {
+        unsigned long long gbase = 0;
+        if (lane == 0) gbase = atomicAdd(&counters[4], (unsigned long long)__popcll(mv));
+        gbase = __shfl(gbase, 0);
+        if (valid) cand[gbase + (unsigned long long)__popcll(mv & ((1ull << lane) - 1ull))] = wq;
+      }
+      if (lane < kStageWords) stageW[lane] = ~0u;
+    }
+    if (lane < 2) stageN[lane] = 0u;
+  };
+
+  if (tid < kStagePairs) stageQ[tid] = ~0ull;
+  if (tid < kStageWords) stageW[tid] = ~0u;
+  if (tid < 2) stageN[tid] = 0u;
+  {
+    const uint64_t it0 = item_table[t_begin];
+    dma_tile((int64_t)(it0 & 0x7fffffffull), 0);
+  }
+  int64_t cur_lb = -1;
+  double a0[3], a1[3], a2[3];
+  unsigned voff[3] = {0, 0, 0};
+  bool pre_ok = false;  // a0..a2 hold the first three k-steps of this wavefront's rows
+
+  for (unsigned long long t = t_begin; t < t_end; ++t) {
+    const uint64_t item = item_table[t];
+    const int64_t lb = (int64_t)((item >> 32) & 0x7fffffffull);
+    const int64_t jt = (int64_t)(item & 0x7fffffffull);
+    const int p = (int)((t - t_begin) & 1ull);
+    const int64_t j0 = jt * TC;
+    const int64_t i0 = global_block(lb, rank, world) * IB;
+    const int64_t ib = i0 + (int64_t)wv * 16;
+    const int64_t lrow0 = lb * IB + (int64_t)wv * 16;
+    const double *__restrict__ cur = lds + p * tile_doubles;
+    __syncthreads();  // (A) this item's tile has landed; everybody is done with the other buffer
+    if (t + 1 < t_end) dma_tile((int64_t)(item_table[t + 1] & 0x7fffffffull), p ^ 1);
+    if (wv == 0 && t != t_begin) flush_stage();
+    if (lb != cur_lb) {
+      if (tid < IB) {
+        const int64_t g = i0 + tid;
+        ldsGr[tid] = g < Npad ? G[g] : 0.0;  // read after barrier (B)
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) voff[c] = (unsigned)((int64_t)(kq * 3 + c) * Npad + ib + l15);
+      cur_lb = lb;
+      pre_ok = false;
+#if !FC_V2_ALIGN
+      __syncthreads();  // block-uniform branch: the row sums are read in the first epilogue
+#endif
+    }
+    const bool row_on = ib < N && !(j0 + TC - 1 <= ib);
+    unsigned nz0 = 0, nz1 = 0, nz2 = 0, nz3 = 0;
+
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      const int cs0 = half * 2;
+      const bool below = j0 + (cs0 + 2) * 16 - 1 <= ib;  // both sub-tiles at or below the diagonal
+      const bool active = row_on && !below;
+      d4_t acc[2][9];
+      if (active) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int e = 0; e < 9; ++e) acc[tt][e] = d4_t{0.0, 0.0, 0.0, 0.0};
+        const double *__restrict__ lb0 = cur + cs0 * 32 + boff;
+        double b0[2][3], b1[2][3];
+        auto fetch_a = [&](double (&a)[3], int sx) {
+          const int sl = sx < KS ? sx : KS - 1;
+          const double *__restrict__ xs_s = Xs + (int64_t)sl * 12 * Npad;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a[c] = xs_s[voff[c]];
+        };
+        auto fetch_b = [&](double (&b)[2][3], int sx) {
+          const int sl = sx < KS ? sx : KS - 1;
+          const double *__restrict__ lb_s = lb0 + sl * (12 * TC);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) b[tt][c] = lb_s[c * (4 * TC) + tt * 32];
+        };
+        auto mma = [&](const double (&a)[3], const double (&b)[2][3]) {
+#pragma unroll
+          for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y)
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt)
+                acc[tt][x * 3 + y] =
+                    __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[tt][y], acc[tt][x * 3 + y], 0, 0, 0);
+        };
+        if (!pre_ok) {
+          fetch_a(a0, 0);
+          fetch_a(a1, 1);
+          fetch_a(a2, 2);
+        }
+        fetch_b(b0, 0);
+        fetch_b(b1, 1);
+#define FC_KSTEP2(AX, BX, U)          \
+  if (sgrp + (U) < KS) {              \
+    mma(AX, BX);                      \
+    fetch_a(AX, sgrp + (U) + 3);      \
+    fetch_b(BX, sgrp + (U) + 2);      \
+  }
+        for (int sgrp = 0; sgrp < KS; sgrp += 6) {
+          FC_KSTEP2(a0, b0, 0)
+          FC_KSTEP2(a1, b1, 1)
+          FC_KSTEP2(a2, b0, 2)
+          FC_KSTEP2(a0, b1, 3)
+          FC_KSTEP2(a1, b0, 4)
+          FC_KSTEP2(a2, b1, 5)
+        }
+#undef FC_KSTEP2
+        // the same rows serve the next unit (second half, or the next item of this row block)
+        fetch_a(a0, 0);
+        fetch_a(a1, 1);
+        fetch_a(a2, 2);
+        pre_ok = true;
+      }
+#if FC_V2_ALIGN
+      __syncthreads();  // (B)/(D): both wavefronts of a SIMD leave their K loops together
+#endif
+      if (active) {
+        const int ib32 = (int)ib;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int cs = cs0 + tt;
+          const int j = (int)j0 + cs * 16 + l15;
+          const double Gq = ldsGc[p * TC + cs * 16 + l15];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = ib32 + kq + 4 * r;
+            const double Gp = ldsGr[wv * 16 + kq + 4 * r];
+            double B9[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) B9[e] = acc[tt][e][r];
+            bool may = kabsch_may_be_below(B9, Gp + Gq, A_thr2);
+            may = may && (j > i) && (j < n32) && (i < n32);
+            const uint64_t m = __ballot(may);
+            stage_pairs(m, may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+            if (lane < 4) {
+              const unsigned piece = (unsigned)((m >> (16 * lane)) & 0xffffull);
+              if (ib32 + lane + 4 * r < n32) {
+                bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs] = (uint16_t)piece;
+                if (r == 0) nz0 |= piece;
+                if (r == 1) nz1 |= piece;
+                if (r == 2) nz2 |= piece;
+                if (r == 3) nz3 |= piece;
+              }
+            }
+          }
+        }
+      } else if (row_on && below && lane < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = ib + lane + 4 * r;
+          if (row < N) {
+            bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs0] = 0;
+            bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs0 + 1] = 0;
+          }
+        }
+      }
+#if FC_V2_ALIGN
+      if (half == 0) __syncthreads();  // (C): ... and their epilogues together
+#endif
+    }
+    if (row_on) {  // queue the non-empty words of this row tile for the exact refine
+      const unsigned nz[4] = {nz0, nz1, nz2, nz3};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool has = lane < 4 && nz[r] != 0;
+        const uint64_t mw = __ballot(has);
+        if (mw == 0) continue;  // wave-uniform
+        const unsigned n = (unsigned)__popcll(mw);
+        const uint32_t word = (uint32_t)((lrow0 + lane + 4 * r) * W + jt);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(stageN + 1, n);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        const unsigned rank_in = (unsigned)__popcll(mw & ((1ull << lane) - 1ull));
+        if (base + n <= (unsigned)kStageWords) {
+          if (has) stageW[base + rank_in] = word;
+        } else {
+          unsigned long long gbase = 0;
+          if (lane == 0) gbase = atomicAdd(&counters[4], (unsigned long long)n);
+          gbase = __shfl(gbase, 0);
+          if (has) cand[gbase + rank_in] = word;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wv == 0) flush_stage();
+}
+
+// ---------------------------------------------------------------------------
 // k_simbits_refine: one wavefront per bit word; lane b re-evaluates pair
 // (row, jt*64+b) exactly if its screen bit is set and the word is rewritten
 // with the final decision  rmsd < max_rmsd && maxdev < max_dev
@@ -1058,12 +1340,13 @@ k_scatter_pairs(const uint64_t *__restrict__ pairs, int64_t n_pairs, int64_t N, 
 // triangle, in dispatch order (row blocks ascending, tiles left to right); built on the host
 // and kept on the device until N or the sharding changes.  Without it (row blocks that are not
 // a multiple of 64) the kernel enumerates all NT x n_lblocks pairs and skips the empty ones.
-static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks) {
+static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks, bool halves = true) {
+  const int64_t rb_key = e->row_block * 2 + (halves ? 1 : 0);
   if (e->item_key[0] == e->N && e->item_key[1] == e->rank && e->item_key[2] == e->world &&
-      e->item_key[3] == e->row_block)
+      e->item_key[3] == rb_key)
     return FC_OK;
   e->item_total = 0;
-  e->item_key[0] = e->N; e->item_key[1] = e->rank; e->item_key[2] = e->world; e->item_key[3] = e->row_block;
+  e->item_key[0] = e->N; e->item_key[1] = e->rank; e->item_key[2] = e->world; e->item_key[3] = rb_key;
   if (e->row_block % 64 != 0) return FC_OK;
   const int64_t r = e->row_block / 64;
   std::vector<uint64_t> items;
@@ -1077,7 +1360,7 @@ static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks) {
   {
     int64_t tail = 2 * (int64_t)ctx().n_cu;
     if (const char *v = getenv("FC_SCREEN_TAIL_SLOTS")) tail = std::strtoll(v, nullptr, 10);
-    if (e->row_block == 128 && tail > 0 && (int64_t)items.size() > 4 * tail && e->A <= 52) {
+    if (halves && e->row_block == 128 && tail > 0 && (int64_t)items.size() > 4 * tail && e->A <= 52) {
       std::vector<uint64_t> halves;
       for (int64_t k = (int64_t)items.size() - tail; k < (int64_t)items.size(); ++k) {
         halves.push_back(items[(size_t)k] | (1ull << 31));
@@ -1221,7 +1504,13 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
       // one workgroup per item; world == 1: only the items that touch the upper triangle
       unsigned long long n_items = (unsigned long long)NT * (unsigned long long)n_lblocks;
       const uint64_t *item_table_dev = nullptr;
-      FC_TRY(screen_item_table(e, NT, n_lblocks));
+      static int use_v2 = -1;
+      if (use_v2 < 0) {
+        const char *v = getenv("FC_SCREEN_V2");
+        use_v2 = (v && v[0] == '1') ? 1 : 0;
+      }
+      const bool want_v2 = use_v2 && two_blocks && e->row_block == 128;
+      FC_TRY(screen_item_table(e, NT, n_lblocks, /*halves=*/!want_v2));
       if (e->item_total > 0) {
         n_items = (unsigned long long)e->item_total;
         item_table_dev = e->item_table.as<uint64_t>();
@@ -1238,6 +1527,23 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         dbg = tlbuf.as<double>();
       }
 #endif
+      if (want_v2 && e->item_total > 0 && dbg == nullptr) {
+        // row-sweep schedule: plain item list (no half items), one resident workgroup per CU
+        const size_t tile = (size_t)((e->A + 3) / 4) * 4 * 3 * 64 * sizeof(double);
+        const size_t lds2 = 2 * tile + (size_t)(2 * 64 + 128) * sizeof(double) + kStageBytes;
+        if (lds2 <= kLdsLimit) {
+          FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen_rowsweep),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+          const unsigned wgs = (unsigned)std::min<unsigned long long>((unsigned long long)ctx().n_cu,
+                                                                      (unsigned long long)e->item_total);
+          hipLaunchKernelGGL(k_screen_rowsweep, dim3(wgs), dim3(512), lds2, ctx().stream, e->Xs.as<double>(),
+                             e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2, e->rank, e->world,
+                             e->bits.as<uint64_t>(), e->W, e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
+                             (unsigned long long)e->pairq_cap, e->item_table.as<uint64_t>(),
+                             (unsigned long long)e->item_total);
+          return check_launch("k_screen_rowsweep");
+        }
+      }
       if (two_blocks)
         hipLaunchKernelGGL(k_simbits_screen_mfma<4>, mgrid, dim3(256), lds_m, ctx().stream,
                            e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
