@@ -165,8 +165,8 @@ def main():
             # the K steps are stream-ordered: every step's screen, refine, export, all-gather and
             # ladder are enqueued behind the previous step's, the host waits once for all K
             done = 0
-            while done < args.steps:  # batches of at most 1024 stream-ordered steps
-                n = min(1024, args.steps - done)
+            while done < args.steps:  # batches of at most 64 stream-ordered steps (64 collectives in flight)
+                n = min(64, args.steps - done)
                 for mask, stats in fdist.prune_steps_sharded_device(ens, n, MAX_RMSD, rank=rank, world=world,
                                                                     device=torch.device("cuda", local_rank)):
                     tk_ns += int(stats[4])
