@@ -50,6 +50,61 @@ def cpu_baseline(coords, budget_s=float(os.environ.get("FC_BENCH_CPU_SECONDS", "
                       f"{len(os.sched_getaffinity(0))} host cores visible (3x3 LAPACK calls do not thread)"}
 
 
+def cpu_baseline_other_configs(budget_s=8.0):
+    """Oracle rates for the secondary configurations of BASELINE.json on bounded samples
+    ("CPU baseline beside it"): cfg3 angle-sets/s, cfg5 poses/s.  CPU only."""
+    from firecode_amd import synthetic as syn
+    from oracle import cpu_ref as o
+
+    out = {}
+    rng = np.random.default_rng(3)
+    A, T = 50, 8
+    base = syn.synthetic_skeleton(A, rng)
+    centres = np.linspace(3, A - 6, T).astype(int)
+    torsions = np.array([(c - 1, c, c + 1, c + 2) for c in centres])
+    masks = np.zeros((T, A), dtype=bool)
+    for t, c in enumerate(centres):
+        masks[t, c + 2:] = True
+    angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * T)
+    pick = np.random.default_rng(0).choice(len(angles), size=4000, replace=False)
+    t0, done = time.perf_counter(), 0
+    for k in range(0, len(pick), 20):
+        o.torsion_scan(base, torsions, masks, angles[pick[k: k + 20]])
+        done += 20
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    out["cfg3_torsion_scan"] = {"value": done / dt, "unit": "angle-sets/s", "cores": 1, "kind": "port",
+                                "sample": f"{done} random angle-sets of the 1 679 616, oracle torsion_scan, {dt:.1f} s"}
+    rng = np.random.default_rng(5)
+    m1 = rng.normal(scale=2.5, size=(4, 40, 3))
+    m2 = rng.normal(scale=2.5, size=(4, 40, 3))
+    r1, r2 = np.array([0, 7]), np.array([3, 11])
+    p1 = np.stack([m1[:, 0] + 0.9, m1[:, 7] - 0.8], axis=1)
+    p2 = np.stack([m2[:, 3] + 0.7, m2[:, 11] - 1.0], axis=1)
+    ang = np.arange(16) * 2 * 45 / 15 - 45
+    t0, done = time.perf_counter(), 0
+    for c1 in range(4):
+        for c2 in range(4):
+            for orient in (0, 1):
+                for a1 in ang:
+                    for a2 in ang[::4]:
+                        R1, t1, R2, t2 = o.bimol_pose_transforms(m1[c1], m2[c2], r1, r2, p1[c1], p2[c2], (a1, a2), orient)
+                        pose = o.get_embed([m1[c1], m2[c2]], [R1, R2], [t1, t2])
+                        o.compenetration_check(pose, ids=[40, 40], thresh=1.5)
+                        done += 1
+                if time.perf_counter() - t0 > budget_s:
+                    break
+            if time.perf_counter() - t0 > budget_s:
+                break
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    out["cfg5_pose_clash"] = {"value": done / dt, "unit": "poses/s", "cores": 1, "kind": "port",
+                              "sample": f"{done} poses (40+40 atoms): oracle transforms + get_embed + compenetration_check, {dt:.1f} s"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,7 +113,13 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-configs", action="store_true",
+                    help="only time the CPU oracle on samples of BASELINE configs 3 and 5 (no GPU needed) and exit")
     args = ap.parse_args()
+    if args.cpu_baseline_configs:
+        print(json.dumps({"cpu_baseline_other_configs": cpu_baseline_other_configs(),
+                          "host_cores_visible": len(os.sched_getaffinity(0))}))
+        return
 
     # dmabuf IPC for RCCL; must be in the environment before the HSA runtime starts
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
