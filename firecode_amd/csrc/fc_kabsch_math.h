@@ -150,7 +150,7 @@ __host__ __device__ __forceinline__ bool kabsch_may_be_below(const double (&B)[9
 #pragma clang fp contract(fast)
   const double s = 0.5 * GpGq;
   const double L = s - 0.5 * A_thr2;
-  if (!(A_thr2 < 0.5 * s)) return true;  // tiny structure w.r.t. threshold
+  const bool tiny = !(A_thr2 < 0.5 * s);  // tiny structure w.r.t. threshold: cannot be screened
   const double Sxx = B[0], Sxy = B[1], Sxz = B[2];
   const double Syx = B[3], Syy = B[4], Syz = B[5];
   const double Szx = B[6], Szy = B[7], Szz = B[8];
@@ -160,22 +160,23 @@ __host__ __device__ __forceinline__ bool kabsch_may_be_below(const double (&B)[9
   //   P''/4 = 2 L^2 + u,   P'/4 = u L - 2 det B,   P = u^2 - 4 (|cof B|_F^2 + 2 L det B)
   // (C2 = -2 n2, C1 = -8 det B, C0 = n2^2 - 4 |cof B|_F^2: with s_i the singular values of B
   // the eigenvalues of K are (+-s1 +- s2 +- s3) with an even number of minus signs, s3 signed
-  // by det B, whose product is (s1^2+s2^2+s3^2)^2 - 4 (s1^2 s2^2 + s2^2 s3^2 + s3^2 s1^2))
+  // by det B, whose product is (s1^2+s2^2+s3^2)^2 - 4 (s1^2 s2^2 + s2^2 s3^2 + s3^2 s1^2)).
+  // Evaluated without branches: nearly every lane needs all three values anyway, and the
+  // early exits cost the wavefront an exec-mask dance per condition.
   const double L2 = L * L;
   const double u = L2 - n2;
-  if (2.0 * L2 + u < 0.0) return true;
   const double c00 = Syy * Szz - Syz * Szy, c01 = Syz * Szx - Syx * Szz, c02 = Syx * Szy - Syy * Szx;
   const double c10 = Sxz * Szy - Sxy * Szz, c11 = Sxx * Szz - Sxz * Szx, c12 = Sxy * Szx - Sxx * Szy;
   const double c20 = Sxy * Syz - Sxz * Syy, c21 = Sxz * Syx - Sxx * Syz, c22 = Sxx * Syy - Sxy * Syx;
   const double detB = Sxx * c00 + Sxy * c01 + Sxz * c02;
-  if (u * L - 2.0 * detB < 0.0) return true;
   const double e2 = c00 * c00 + c01 * c01 + c02 * c02 + c10 * c10 + c11 * c11 + c12 * c12 +
                     c20 * c20 + c21 * c21 + c22 * c22;
+  const double P2 = 2.0 * L2 + u;
+  const double P1 = u * L - 2.0 * detB;
   const double P0 = u * u - 4.0 * (e2 + 2.0 * L * detB);
   const double eps = 1e-12 * (s * s) * (s * s);
-  return !(P0 > eps);
+  return tiny | (P2 < 0.0) | (P1 < 0.0) | !(P0 > eps);
 }
-
 
 
 // Largest eigenvalue of the quaternion matrix by Newton's iteration on its
