@@ -207,9 +207,10 @@ def main():
         values_ms = min(ens.rmsd_values(want_matrix=False)[1] for _ in range(3))
         # ... and BASELINE's second metric as SURVEY 8d words it: one full prune through the drop-in
         # function, host arrays in -> mask out, H2D / D2H included
-        fc.pruner.prune_by_rmsd(coords[:2000], atoms, MAX_RMSD)
         host_in_out_s = []
-        for _ in range(5):
+        if not args.no_cpu_baseline:  # (skipped with the other side measurements in profile runs)
+            fc.pruner.prune_by_rmsd(coords[:2000], atoms, MAX_RMSD)
+        for _ in range(0 if args.no_cpu_baseline else 5):
             t1 = time.perf_counter()
             fc.pruner.prune_by_rmsd(coords, atoms, MAX_RMSD)
             host_in_out_s.append(time.perf_counter() - t1)
@@ -285,7 +286,7 @@ def main():
                                     "one stream, one host sync")},
             "pruned_ensembles_per_s": args.steps / elapsed,
             "rmsd_values_per_s": (pairs_total / (values_ms * 1e-3)) if not sharded else None,
-            "pruned_ensembles_per_s_host_in_mask_out": (1.0 / min(host_in_out_s)) if not sharded else None,
+            "pruned_ensembles_per_s_host_in_mask_out": (1.0 / min(host_in_out_s)) if (not sharded and host_in_out_s) else None,
             "survivors": survivors,
             "survivors_expected": expected,
             "mask_ok": survivors == expected,
