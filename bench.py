@@ -280,6 +280,10 @@ def main():
                                    "of similar-pair lists, ladder replayed on every rank",
                        "host_sync": ("once for the K steps (stream-ordered steps, one pinned result slot each)"
                                      if (not sharded or backend != "gloo") else "once per step"),
+                       "step_overlap": ("screens in order on one stream; refine + ladder + result copy of step r run "
+                                        "beside the screen of step r+1 (two workspaces over the same resident "
+                                        "coordinates; FC_BENCH_LANES=1 turns it off)"
+                                        if (not sharded and os.environ.get("FC_BENCH_LANES") != "1") else "none"),
                        "exchange": ("none (single GPU, resident step)" if not sharded else
                                     "host lists through gloo" if backend == "gloo" else
                                     "device-resident: export kernel -> RCCL all_gather_into_tensor -> ladder, "

@@ -1675,36 +1675,104 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
   // host waits ONCE.  Every prune runs in full and delivers its mask to host memory; only the
   // idle gap of a host round trip between two prunes (~45 us of sync wake-up and launch
   // latency on an idle GPU) is gone, as for any caller that has more than one ensemble queued.
-  static std::vector<hipEvent_t> ev;  // 2 per prune: around the screen kernel
-  while ((int64_t)ev.size() < 2 * reps + 2) {
+  static std::vector<hipEvent_t> ev;  // 3 per prune: around the screen kernel, counters reset
+  while ((int64_t)ev.size() < 3 * reps + 4) {
     hipEvent_t e = nullptr;
     FC_HIP_TRY(hipEventCreate(&e));
     ev.push_back(e);
   }
+  hipEvent_t const ev_begin = ev[3 * reps], ev_end = ev[3 * reps + 1];
   const int64_t W = ens->W;
   FC_TRY(pinned_reserve((size_t)reps * (size_t)(W + 16) * sizeof(uint64_t)));
   int64_t levels = 0, survivors = 0;
   unsigned long long cnt[8] = {0};
-  FC_HIP_TRY(hipEventRecord(ev[2 * reps], c.stream));
-  for (int64_t r = 0; r < reps; ++r) {
-    FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, kCounters * sizeof(uint64_t), c.stream));
-    FC_HIP_TRY(hipEventRecord(ev[2 * r], c.stream));
-    FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
-    FC_HIP_TRY(hipEventRecord(ev[2 * r + 1], c.stream));
-    FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
-    ens->bits_valid = true;
-    FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, nullptr, nullptr, nullptr, nullptr,
-                         ens->simq.as<uint64_t>(), false, true, r));
+  // Two lanes (FC_BENCH_LANES=1: one).  Odd prunes use a second workspace (bit rows, queues,
+  // counters, ladder words) over the same resident coordinates.  All screens go, in order, to
+  // one high-priority stream, so they never share the chip with each other and their event
+  // durations stay those of a kernel running alone; the ~80 us of refine, level buckets, ladder
+  // and result copy of prune r go to lane r&1's low-priority stream and run beside the screen
+  // of prune r+1 (mostly in its tail, where compute units stand idle).  Prune r+2 reuses lane
+  // r&1's workspace and is ordered behind prune r on that lane's stream.
+  static const bool two_lanes = [] {
+    const char *v = getenv("FC_BENCH_LANES");
+    return !(v && atoi(v) == 1);
+  }();
+  static hipStream_t s_screen = nullptr, s_lane[2] = {nullptr, nullptr};
+  hipStream_t const home = c.stream;
+  struct Restore {
+    Context &c;
+    hipStream_t s;
+    ~Restore() { c.stream = s; }
+  } restore{c, home};
+  const bool lanes = two_lanes && reps > 1;
+  fc_ensemble *lane[2] = {ens, ens};
+  if (lanes) {
+    if (!s_screen) {
+      int least = 0, greatest = 0;
+      FC_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      FC_HIP_TRY(hipStreamCreateWithPriority(&s_screen, hipStreamNonBlocking, greatest));
+      FC_HIP_TRY(hipStreamCreateWithPriority(&s_lane[0], hipStreamNonBlocking, least));
+      FC_HIP_TRY(hipStreamCreateWithPriority(&s_lane[1], hipStreamNonBlocking, least));
+    }
+    if (!ens->twin) {
+      std::unique_ptr<fc_ensemble> t(new (std::nothrow) fc_ensemble);
+      if (!t) return set_error(FC_E_NOMEM, "host allocation failed");
+      t->N = ens->N, t->A = ens->A, t->Npad = ens->Npad, t->W = ens->W;
+      t->Xs.alias(ens->Xs), t->Xa.alias(ens->Xa), t->G.alias(ens->G);
+      FC_TRY(t->counters.reserve(kCounters * sizeof(uint64_t)));
+      FC_TRY(ensemble_shard(t.get(), 0, 1, default_row_block()));
+      // one whole prune per workspace on the home stream: every grow-only buffer reaches its
+      // size here, so no block changes hands while several streams are in flight
+      for (fc_ensemble *e : {ens, t.get()}) {
+        FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, kCounters * sizeof(uint64_t), c.stream));
+        FC_TRY(launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin));
+        FC_TRY(launch_simbits_refine(e, max_rmsd, max_dev, nullptr, 0.0));
+        e->bits_valid = true;
+        FC_TRY(ladder_single(e, e->bits.as<uint64_t>(), 20, nullptr, nullptr, nullptr, nullptr,
+                             e->simq.as<uint64_t>(), false, true, 0));
+      }
+      FC_TRY(sync());
+      ens->twin = t.release();
+    }
+    lane[1] = ens->twin;
   }
-  FC_HIP_TRY(hipEventRecord(ev[2 * reps + 1], c.stream));
-  FC_HIP_TRY(hipEventSynchronize(ev[2 * reps + 1]));
+  FC_HIP_TRY(hipEventRecord(ev_begin, home));
+  if (lanes)
+    for (hipStream_t s : {s_screen, s_lane[0], s_lane[1]}) FC_HIP_TRY(hipStreamWaitEvent(s, ev_begin, 0));
+  for (int64_t r = 0; r < reps; ++r) {
+    fc_ensemble *e = lane[r & 1];
+    hipStream_t const tail = lanes ? s_lane[r & 1] : home, scr = lanes ? s_screen : home;
+    FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, kCounters * sizeof(uint64_t), tail));
+    if (lanes) {
+      FC_HIP_TRY(hipEventRecord(ev[3 * r + 2], tail));
+      FC_HIP_TRY(hipStreamWaitEvent(scr, ev[3 * r + 2], 0));
+    }
+    c.stream = scr;
+    FC_HIP_TRY(hipEventRecord(ev[3 * r], scr));
+    FC_TRY(launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin));
+    FC_HIP_TRY(hipEventRecord(ev[3 * r + 1], scr));
+    if (lanes) FC_HIP_TRY(hipStreamWaitEvent(tail, ev[3 * r + 1], 0));
+    c.stream = tail;
+    FC_TRY(launch_simbits_refine(e, max_rmsd, max_dev, nullptr, 0.0));
+    e->bits_valid = true;
+    FC_TRY(ladder_single(e, e->bits.as<uint64_t>(), 20, nullptr, nullptr, nullptr, nullptr,
+                         e->simq.as<uint64_t>(), false, true, r));
+  }
+  c.stream = home;
+  if (lanes)  // the home stream ends behind the last prune of either lane
+    for (int l = 0; l < 2; ++l) {
+      FC_HIP_TRY(hipEventRecord(ev[3 * reps + 2 + l], s_lane[l]));
+      FC_HIP_TRY(hipStreamWaitEvent(home, ev[3 * reps + 2 + l], 0));
+    }
+  FC_HIP_TRY(hipEventRecord(ev_end, home));
+  FC_HIP_TRY(hipEventSynchronize(ev_end));
   double t_kernel = 0.0;
   float total = 0.f;
-  FC_HIP_TRY(hipEventElapsedTime(&total, ev[2 * reps], ev[2 * reps + 1]));
+  FC_HIP_TRY(hipEventElapsedTime(&total, ev_begin, ev_end));
   bool redo = false;
   for (int64_t r = 0; r < reps; ++r) {
     float a = 0.f;
-    FC_HIP_TRY(hipEventElapsedTime(&a, ev[2 * r], ev[2 * r + 1]));
+    FC_HIP_TRY(hipEventElapsedTime(&a, ev[3 * r], ev[3 * r + 1]));
     t_kernel += a;
     if (!ladder_collect(ens, r, mask_out, &levels, &survivors, cnt)) redo = true;
   }

@@ -72,14 +72,23 @@ void pool_trim();
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
+  bool owned = true;  // false: a view of another DevBuf's block (see alias())
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) pool_give(p, bytes);
+    if (p && owned) pool_give(p, bytes);
     p = nullptr;
     bytes = 0;
+    owned = true;
+  }
+  // read-only view of `o`; the caller keeps `o` alive for as long as the view is used
+  void alias(const DevBuf &o) {
+    release();
+    p = o.p;
+    bytes = o.bytes;
+    owned = false;
   }
   // grow-only allocation; contents are NOT preserved
   int reserve(size_t n) {
@@ -162,4 +171,11 @@ struct fc_ensemble {
   int64_t rank = 0, world = 1, row_block = 64;
   int64_t rows_local = 0;
   bool bits_valid = false;
+  // second prune workspace over the same coordinates (Xs/Xa/G are views): lets the refine and
+  // ladder of one prune run beside the screen of the next one (fc_bench_prune_rmsd)
+  fc_ensemble *twin = nullptr;
+  fc_ensemble() = default;
+  fc_ensemble(const fc_ensemble &) = delete;
+  fc_ensemble &operator=(const fc_ensemble &) = delete;
+  ~fc_ensemble() { delete twin; }
 };
