@@ -112,6 +112,7 @@ _SIGNATURES = {
     "fc_xyz_scan": [C.c_char_p, _p_i64, _p_i64],
     "fc_xyz_read": [C.c_char_p, _i64, _i64, C.c_char_p, _p_f64],
     "fc_bench_prune_rmsd": [_ens, _f64, _f64, _i64, _p_f64, _p_f64, _p_u8, _p_i64],
+    "fc_prune_rmsd_many": [C.POINTER(_ens), _i64, _f64, _f64, _i64, C.POINTER(_p_u8), _p_i64],
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("fc_last_error",)
@@ -387,6 +388,18 @@ class DeviceEnsemble:
         call("fc_bench_prune_rmsd", self.handle, float(max_rmsd), float(max_dev), int(reps),
              C.byref(t_k), C.byref(t_s), pb(mask), pi(stats))
         return t_k.value, t_s.value, (None if mask is None else mask.astype(bool)), stats
+
+
+def prune_many(ensembles, max_rmsd, max_dev, min_per_group=20):
+    """fc_prune_rmsd_many over DeviceEnsemble objects: list of bool masks, survivor counts."""
+    n = len(ensembles)
+    handles = (_ens * max(n, 1))(*[e.handle for e in ensembles])
+    masks = [np.zeros(max(int(e.N), 1), dtype=np.uint8) for e in ensembles]
+    ptrs = (_p_u8 * max(n, 1))(*[m.ctypes.data_as(_p_u8) for m in masks])
+    survivors = np.zeros(max(n, 1), dtype=np.int64)
+    call("fc_prune_rmsd_many", handles, n, float(max_rmsd), float(max_dev), int(min_per_group), ptrs,
+         survivors.ctypes.data_as(_p_i64))
+    return [m[: int(e.N)].astype(bool) for m, e in zip(masks, ensembles)], survivors[:n]
 
 
 def unpack_bits(bits, n):

@@ -370,10 +370,12 @@ static const unsigned long long kPairLadderCap = 1ull << 20;
 static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_per_group,
                          uint8_t *mask_out, int64_t *levels, int64_t *survivors,
                          unsigned long long *counters_out = nullptr, const uint64_t *pairs_dev = nullptr,
-                         bool pairs_are_final = false, bool counters_zeroed = false, int64_t defer_slot = -1) {
+                         bool pairs_are_final = false, bool counters_zeroed = false, int64_t defer_slot = -1,
+                         int64_t slot_stride = 0) {
   // defer_slot >= 0: enqueue the pair ladder and the copy of its result into slot `defer_slot` of
   // the pinned staging area and return WITHOUT waiting (the caller synchronises once for many
-  // prunes and reads the slots with ladder_collect; pinned memory for all slots is the caller's)
+  // prunes and reads the slots with ladder_collect; pinned memory for all slots is the caller's;
+  // slot_stride: words per slot when the prunes differ in size, default W + 16)
   const int64_t N = e->N, W = e->W;
   const int n_ladder = (int)(sizeof(kLadder) / sizeof(kLadder[0]));
   FC_TRY(e->ladder.reserve(((size_t)(n_ladder + 1) * W + 16) * sizeof(uint64_t)));
@@ -388,7 +390,7 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
   // counters[8] = levels run, counters[9] = "k_ladder_pairs produced the mask"
   // [8], [9]: ladder flags; [10], [11]: spare; [16 ..): bucket fill levels of the pair ladder
   if (!counters_zeroed) FC_HIP_TRY(hipMemsetAsync(cnt + 8, 0, (kCounters - 8) * sizeof(uint64_t), ctx().stream));
-  uint64_t *words = static_cast<uint64_t *>(ctx().pinned) + (defer_slot > 0 ? (size_t)defer_slot * (size_t)(W + 16) : 0);
+  uint64_t *words = static_cast<uint64_t *>(ctx().pinned) + (defer_slot > 0 ? (size_t)defer_slot * (size_t)(slot_stride > 0 ? slot_stride : W + 16) : 0);
   uint64_t *cnt_host = words + W;
   bool have_mask = false;
   const bool lds_ok = (size_t)2 * W * sizeof(uint64_t) <= 60 * 1024;
@@ -401,10 +403,13 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
       e->ladder_k_n = n_lv;
       e->ladder_k_mpg = min_per_group;
     }
-    FC_TRY(e->levelmask.reserve((size_t)kPairLadderCap * (size_t)n_lv * sizeof(uint64_t)));  // level buckets
+    // level buckets: one per level, each as long as the longest list the ladder accepts
+    const unsigned long long ladder_cap =
+        std::min<unsigned long long>(kPairLadderCap, std::max<unsigned long long>(1024, (unsigned long long)N * (N - 1) / 2));
+    FC_TRY(e->levelmask.reserve((size_t)ladder_cap * (size_t)n_lv * sizeof(uint64_t)));
     FC_TRY(launch_ladder_pairs(pairs_dev, e->levelmask.as<uint64_t>(), cnt + 2,
                                pairs_are_final ? nullptr : cnt + 6,
-                               (unsigned long long)e->pairq_cap, kPairLadderCap, N, W, min_per_group,
+                               (unsigned long long)e->pairq_cap, ladder_cap, N, W, min_per_group,
                                e->ladder_k.as<int64_t>(), n_lv, mb + (size_t)n_lv * W, cnt));
     // mask words and the 16 counters behind them (written by the kernel): one copy
     FC_TRY(d2h(words, mb + (size_t)n_lv * W, (size_t)(W + 16) * sizeof(uint64_t)));
@@ -441,9 +446,10 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
 // result of a deferred pair ladder (after the caller's synchronisation); false: the kernel
 // declined (queue overflow / list too long) and the prune has to be redone synchronously
 static bool ladder_collect(const fc_ensemble *e, int64_t slot, uint8_t *mask_out, int64_t *levels,
-                           int64_t *survivors, unsigned long long *counters_out) {
+                           int64_t *survivors, unsigned long long *counters_out, int64_t slot_stride = 0) {
   const int64_t N = e->N, W = e->W;
-  const uint64_t *words = static_cast<const uint64_t *>(ctx().pinned) + (size_t)slot * (size_t)(W + 16);
+  const uint64_t *words = static_cast<const uint64_t *>(ctx().pinned) +
+                          (size_t)slot * (size_t)(slot_stride > 0 ? slot_stride : W + 16);
   const uint64_t *cnt_host = words + W;
   if (cnt_host[9] == 0) return false;
   int64_t alive = 0;
@@ -1662,41 +1668,31 @@ int fc_xyz_read(const char *path, int64_t N, int64_t A, char *atoms_out, double 
   return xyz_read(path, &N, &A, atoms_out, coords_out);
 }
 
-// ---- bench hook ----------------------------------------------------------------------
-int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
-                        double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
-                        int64_t *stats) {
-  FC_REQUIRE(ens && reps >= 1 && reps <= 4096, "bad arguments");
-  FC_TRY(ensure_init());
-  FC_TRY(ensemble_shard(ens, 0, 1, default_row_block()));
+// ---- many prunes in flight -----------------------------------------------------------
+// Enqueues the prunes work[0..n) -- counters reset, screen, refine, level buckets, ladder, copy
+// of the survivor words + counters into pinned slot r -- and waits ONCE.  Every prune runs in
+// full and delivers its mask words to host memory; what goes away is the host round trip
+// between two prunes (~45 us of sync wake-up and launch latency on an idle GPU).
+//
+// overlap: all screens go, in order, to one stream, so two screens never share the chip and
+// their event durations stay those of a kernel that has the matrix pipes to itself; the ~80 us
+// of refine, level buckets, ladder and result copy of prune r go to stream r&1 of two others
+// and run beside the screen of prune r+1.  A workspace may therefore appear again only an even
+// number of places later (same lane: ordered on that lane's stream); fc_prune_rmsd_many passes
+// distinct ensembles, the bench hook alternates an ensemble and its twin.
+// The caller reads the slots with ladder_collect(work[r], r, ..., stride).
+static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, double max_dev,
+                          int64_t min_per_group, bool overlap, int64_t stride, double *screen_ms_sum,
+                          double *total_ms) {
   Context &c = ctx();
-  // The `reps` prunes are enqueued back to back -- counters reset, screen, refine, level buckets,
-  // ladder, copy of the survivor words + counters into the prune's own pinned slot -- and the
-  // host waits ONCE.  Every prune runs in full and delivers its mask to host memory; only the
-  // idle gap of a host round trip between two prunes (~45 us of sync wake-up and launch
-  // latency on an idle GPU) is gone, as for any caller that has more than one ensemble queued.
   static std::vector<hipEvent_t> ev;  // 3 per prune: around the screen kernel, counters reset
-  while ((int64_t)ev.size() < 3 * reps + 4) {
+  while ((int64_t)ev.size() < 3 * n + 4) {
     hipEvent_t e = nullptr;
     FC_HIP_TRY(hipEventCreate(&e));
     ev.push_back(e);
   }
-  hipEvent_t const ev_begin = ev[3 * reps], ev_end = ev[3 * reps + 1];
-  const int64_t W = ens->W;
-  FC_TRY(pinned_reserve((size_t)reps * (size_t)(W + 16) * sizeof(uint64_t)));
-  int64_t levels = 0, survivors = 0;
-  unsigned long long cnt[8] = {0};
-  // Two lanes (FC_BENCH_LANES=1: one).  Odd prunes use a second workspace (bit rows, queues,
-  // counters, ladder words) over the same resident coordinates.  All screens go, in order, to
-  // one high-priority stream, so they never share the chip with each other and their event
-  // durations stay those of a kernel running alone; the ~80 us of refine, level buckets, ladder
-  // and result copy of prune r go to lane r&1's low-priority stream and run beside the screen
-  // of prune r+1 (mostly in its tail, where compute units stand idle).  Prune r+2 reuses lane
-  // r&1's workspace and is ordered behind prune r on that lane's stream.
-  static const bool two_lanes = [] {
-    const char *v = getenv("FC_BENCH_LANES");
-    return !(v && atoi(v) == 1);
-  }();
+  hipEvent_t const ev_begin = ev[3 * n], ev_end = ev[3 * n + 1];
+  FC_TRY(pinned_reserve((size_t)n * (size_t)stride * sizeof(uint64_t)));
   static hipStream_t s_screen = nullptr, s_lane[2] = {nullptr, nullptr};
   hipStream_t const home = c.stream;
   struct Restore {
@@ -1704,44 +1700,22 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
     hipStream_t s;
     ~Restore() { c.stream = s; }
   } restore{c, home};
-  const bool lanes = two_lanes && reps > 1;
-  fc_ensemble *lane[2] = {ens, ens};
-  if (lanes) {
-    if (!s_screen) {
-      int least = 0, greatest = 0;
-      FC_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      FC_HIP_TRY(hipStreamCreateWithPriority(&s_screen, hipStreamNonBlocking, greatest));
-      FC_HIP_TRY(hipStreamCreateWithPriority(&s_lane[0], hipStreamNonBlocking, least));
-      FC_HIP_TRY(hipStreamCreateWithPriority(&s_lane[1], hipStreamNonBlocking, least));
-    }
-    if (!ens->twin) {
-      std::unique_ptr<fc_ensemble> t(new (std::nothrow) fc_ensemble);
-      if (!t) return set_error(FC_E_NOMEM, "host allocation failed");
-      t->N = ens->N, t->A = ens->A, t->Npad = ens->Npad, t->W = ens->W;
-      t->Xs.alias(ens->Xs), t->Xa.alias(ens->Xa), t->G.alias(ens->G);
-      FC_TRY(t->counters.reserve(kCounters * sizeof(uint64_t)));
-      FC_TRY(ensemble_shard(t.get(), 0, 1, default_row_block()));
-      // one whole prune per workspace on the home stream: every grow-only buffer reaches its
-      // size here, so no block changes hands while several streams are in flight
-      for (fc_ensemble *e : {ens, t.get()}) {
-        FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, kCounters * sizeof(uint64_t), c.stream));
-        FC_TRY(launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin));
-        FC_TRY(launch_simbits_refine(e, max_rmsd, max_dev, nullptr, 0.0));
-        e->bits_valid = true;
-        FC_TRY(ladder_single(e, e->bits.as<uint64_t>(), 20, nullptr, nullptr, nullptr, nullptr,
-                             e->simq.as<uint64_t>(), false, true, 0));
-      }
-      FC_TRY(sync());
-      ens->twin = t.release();
-    }
-    lane[1] = ens->twin;
+  const bool lanes = overlap && n > 1;
+  if (lanes && !s_screen) {
+    FC_HIP_TRY(hipStreamCreateWithFlags(&s_screen, hipStreamNonBlocking));
+    FC_HIP_TRY(hipStreamCreateWithFlags(&s_lane[0], hipStreamNonBlocking));
+    FC_HIP_TRY(hipStreamCreateWithFlags(&s_lane[1], hipStreamNonBlocking));
   }
+  // everything enqueued here is ordered behind what the home stream already holds (also what
+  // makes pool blocks released by earlier calls safe to reuse on the other streams)
   FC_HIP_TRY(hipEventRecord(ev_begin, home));
   if (lanes)
     for (hipStream_t s : {s_screen, s_lane[0], s_lane[1]}) FC_HIP_TRY(hipStreamWaitEvent(s, ev_begin, 0));
-  for (int64_t r = 0; r < reps; ++r) {
-    fc_ensemble *e = lane[r & 1];
+  for (int64_t r = 0; r < n; ++r) {
+    fc_ensemble *e = work[r];
     hipStream_t const tail = lanes ? s_lane[r & 1] : home, scr = lanes ? s_screen : home;
+    c.stream = tail;
+    FC_TRY(ensemble_shard(e, 0, 1, default_row_block()));
     FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, kCounters * sizeof(uint64_t), tail));
     if (lanes) {
       FC_HIP_TRY(hipEventRecord(ev[3 * r + 2], tail));
@@ -1755,27 +1729,123 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
     c.stream = tail;
     FC_TRY(launch_simbits_refine(e, max_rmsd, max_dev, nullptr, 0.0));
     e->bits_valid = true;
-    FC_TRY(ladder_single(e, e->bits.as<uint64_t>(), 20, nullptr, nullptr, nullptr, nullptr,
-                         e->simq.as<uint64_t>(), false, true, r));
+    FC_TRY(ladder_single(e, e->bits.as<uint64_t>(), min_per_group, nullptr, nullptr, nullptr, nullptr,
+                         e->simq.as<uint64_t>(), false, true, r, stride));
   }
   c.stream = home;
   if (lanes)  // the home stream ends behind the last prune of either lane
     for (int l = 0; l < 2; ++l) {
-      FC_HIP_TRY(hipEventRecord(ev[3 * reps + 2 + l], s_lane[l]));
-      FC_HIP_TRY(hipStreamWaitEvent(home, ev[3 * reps + 2 + l], 0));
+      FC_HIP_TRY(hipEventRecord(ev[3 * n + 2 + l], s_lane[l]));
+      FC_HIP_TRY(hipStreamWaitEvent(home, ev[3 * n + 2 + l], 0));
     }
   FC_HIP_TRY(hipEventRecord(ev_end, home));
   FC_HIP_TRY(hipEventSynchronize(ev_end));
-  double t_kernel = 0.0;
-  float total = 0.f;
-  FC_HIP_TRY(hipEventElapsedTime(&total, ev_begin, ev_end));
-  bool redo = false;
-  for (int64_t r = 0; r < reps; ++r) {
-    float a = 0.f;
-    FC_HIP_TRY(hipEventElapsedTime(&a, ev[3 * r], ev[3 * r + 1]));
-    t_kernel += a;
-    if (!ladder_collect(ens, r, mask_out, &levels, &survivors, cnt)) redo = true;
+  if (total_ms) {
+    float t = 0.f;
+    FC_HIP_TRY(hipEventElapsedTime(&t, ev_begin, ev_end));
+    *total_ms = t;
   }
+  if (screen_ms_sum) {
+    *screen_ms_sum = 0.0;
+    for (int64_t r = 0; r < n; ++r) {
+      float a = 0.f;
+      FC_HIP_TRY(hipEventElapsedTime(&a, ev[3 * r], ev[3 * r + 1]));
+      *screen_ms_sum += a;
+    }
+  }
+  return FC_OK;
+}
+
+int fc_prune_rmsd_many(fc_ensemble *const *ens, int64_t n, double max_rmsd, double max_dev,
+                       int64_t min_per_group, uint8_t *const *mask_out, int64_t *survivors_out) {
+  FC_REQUIRE(n >= 0 && n <= 4096, "n=%lld outside 0..4096", (long long)n);
+  if (n == 0) return FC_OK;
+  FC_REQUIRE(ens && mask_out, "NULL pointer argument");
+  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
+  FC_REQUIRE(min_per_group >= 1, "min_per_group must be >= 1");
+  FC_TRY(ensure_init());
+  std::vector<fc_ensemble *> sorted(ens, ens + n);
+  std::sort(sorted.begin(), sorted.end());
+  for (int64_t r = 0; r < n; ++r) {
+    FC_REQUIRE(sorted[r] != nullptr, "NULL ensemble in the list");
+    FC_REQUIRE(r == 0 || sorted[r] != sorted[r - 1], "the same ensemble appears twice in the list");
+    FC_REQUIRE(mask_out[r] != nullptr || ens[r]->N == 0, "mask_out[%lld] is NULL", (long long)r);
+  }
+  // in flight together: ensembles the one-launch ladder can take; the rest one by one behind them
+  std::vector<fc_ensemble *> work;
+  std::vector<int64_t> where;
+  int64_t stride = 0;
+  for (int64_t r = 0; r < n; ++r)
+    if (ens[r]->N >= 2 && (size_t)2 * ens[r]->W * sizeof(uint64_t) <= 60 * 1024) {
+      work.push_back(ens[r]);
+      where.push_back(r);
+      stride = std::max(stride, ens[r]->W + 16);
+    }
+  static const bool overlap = [] {
+    const char *v = getenv("FC_PRUNE_LANES");
+    return !(v && atoi(v) == 1);
+  }();
+  std::vector<char> done((size_t)n, 0);
+  if (!work.empty()) {
+    FC_TRY(prune_pipeline(work.data(), (int64_t)work.size(), max_rmsd, max_dev, min_per_group, overlap,
+                          stride, nullptr, nullptr));
+    for (size_t q = 0; q < work.size(); ++q) {
+      int64_t levels = 0, alive = 0;
+      const int64_t r = where[q];
+      if (ladder_collect(work[q], (int64_t)q, mask_out[r], &levels, &alive, nullptr, stride)) {
+        done[(size_t)r] = 1;
+        if (survivors_out) survivors_out[r] = alive;
+      }
+    }
+  }
+  for (int64_t r = 0; r < n; ++r) {
+    if (done[(size_t)r]) continue;
+    int64_t st[6] = {0};
+    if (ens[r]->N > 0) FC_TRY(fc_prune_rmsd(ens[r], max_rmsd, max_dev, nullptr, 0.0, min_per_group, mask_out[r], st));
+    if (survivors_out) survivors_out[r] = st[5];
+  }
+  return FC_OK;
+}
+
+// ---- bench hook ----------------------------------------------------------------------
+int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
+                        double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
+                        int64_t *stats) {
+  FC_REQUIRE(ens && reps >= 1 && reps <= 4096, "bad arguments");
+  FC_TRY(ensure_init());
+  FC_TRY(ensemble_shard(ens, 0, 1, default_row_block()));
+  // `reps` prunes of the same resident ensemble through prune_pipeline.  FC_BENCH_LANES=1:
+  // strictly one after another; default: odd prunes use a second workspace (bit rows, queues,
+  // counters, ladder words) over the same coordinates, so that the small kernels of one prune
+  // can run beside the screen of the next.
+  static const bool two_lanes = [] {
+    const char *v = getenv("FC_BENCH_LANES");
+    return !(v && atoi(v) == 1);
+  }();
+  const bool lanes = two_lanes && reps > 1;
+  const int64_t stride = ens->W + 16;
+  if (lanes && !ens->twin) {
+    std::unique_ptr<fc_ensemble> t(new (std::nothrow) fc_ensemble);
+    if (!t) return set_error(FC_E_NOMEM, "host allocation failed");
+    t->N = ens->N, t->A = ens->A, t->Npad = ens->Npad, t->W = ens->W;
+    t->Xs.alias(ens->Xs), t->Xa.alias(ens->Xa), t->G.alias(ens->G);
+    FC_TRY(t->counters.reserve(kCounters * sizeof(uint64_t)));
+    // one whole prune per workspace on the home stream: every grow-only buffer reaches its
+    // size here, so no block changes hands while several streams are in flight
+    fc_ensemble *both[2] = {ens, t.get()};
+    FC_TRY(prune_pipeline(both, 2, max_rmsd, max_dev, 20, false, stride, nullptr, nullptr));
+    ens->twin = t.release();
+  }
+  std::vector<fc_ensemble *> work((size_t)reps);
+  for (int64_t r = 0; r < reps; ++r) work[(size_t)r] = (lanes && (r & 1)) ? ens->twin : ens;
+  double t_kernel = 0.0, total = 0.0;
+  FC_TRY(prune_pipeline(work.data(), reps, max_rmsd, max_dev, 20, lanes, stride, &t_kernel, &total));
+  int64_t levels = 0, survivors = 0;
+  unsigned long long cnt[8] = {0};
+  bool redo = false;
+  for (int64_t r = 0; r < reps; ++r)
+    if (!ladder_collect(ens, r, mask_out, &levels, &survivors, cnt, stride)) redo = true;
+  Context &c = ctx();
   if (redo) {  // dense similarity: the pair ladder declined; one synchronous prune through the bit matrix
     FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, kCounters * sizeof(uint64_t), c.stream));
     FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
@@ -1784,7 +1854,7 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
                          ens->simq.as<uint64_t>(), false, true));
   }
   if (ms_simbits_kernel) *ms_simbits_kernel = t_kernel / (double)reps;
-  if (ms_step) *ms_step = (double)total / (double)reps;
+  if (ms_step) *ms_step = total / (double)reps;
   if (stats) {
     stats[0] = ens->N * (ens->N - 1) / 2;
     stats[1] = (int64_t)cnt[1];

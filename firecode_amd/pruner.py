@@ -85,6 +85,42 @@ def rotation_mask(graph, torsion, n_atoms=None):
     return mask
 
 
+def prune_many_by_rmsd(ensembles, max_rmsd=0.25, max_dev=None, heavy_atoms_only=True, min_per_group=20):
+    """``prune_by_rmsd`` for a queue of ensembles: ``ensembles`` is a list of
+    ``(structures, atoms)``; returns a list of ``(structures[mask], mask)``, each identical to
+    what ``prune_by_rmsd(structures, atoms, max_rmsd, max_dev)`` returns.  All ensembles are made
+    resident, their prunes are enqueued together (``fc_prune_rmsd_many``) and the host waits once;
+    the reference prunes one ensemble per call (firecode/pruning.py:45-50)."""
+    if max_dev is None:
+        max_dev = 2 * max_rmsd
+    items, resident = [], []
+    try:
+        for structures, atoms in ensembles:
+            structures = L.f64(structures)
+            if structures.ndim != 3 or structures.shape[2] != 3:
+                raise L.FirecodeHipInputError(L.FC_E_INVALID, f"structures must be (N, A, 3), got {structures.shape}")
+            atoms = np.asarray(atoms)
+            if atoms.shape[0] != structures.shape[1]:
+                raise L.FirecodeHipInputError(L.FC_E_INVALID, "len(atoms) != number of atoms")
+            items.append(structures)
+            if structures.shape[0] == 0:
+                resident.append(None)
+                continue
+            heavy = (atoms != "H") if heavy_atoms_only else np.ones(len(atoms), dtype=bool)
+            resident.append(L.DeviceEnsemble(structures, atom_mask=heavy, center=True))
+        live = [e for e in resident if e is not None]
+        masks, _ = L.prune_many(live, max_rmsd, max_dev, min_per_group) if live else ([], None)
+    finally:
+        for e in resident:
+            if e is not None:
+                e.close()
+    out, it = [], iter(masks)
+    for structures, e in zip(items, resident):
+        mask = np.ones(0, dtype=bool) if e is None else next(it)
+        out.append((structures[mask], mask))
+    return out
+
+
 def prune_by_rmsd_rot_corr(structures, atoms, graph=None, max_rmsd=0.25, max_dev=None, energies=None, max_dE=0.0,
                            logfunction=None, debugfunction=None, torsions=None, rotation_masks=None,
                            min_per_group=20, return_bits=False):

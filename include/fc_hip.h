@@ -362,6 +362,19 @@ int fc_xyz_write(const char *path, const char *const *atoms, int64_t A, const do
 int fc_xyz_scan(const char *path, int64_t *N_out, int64_t *A_out);
 int fc_xyz_read(const char *path, int64_t N, int64_t A, char *atoms_out, double *coords_out);
 
+/* ---- many ensembles in flight -------------------------------------------
+ * fc_prune_rmsd_many: fc_prune_rmsd (no energy window) for `n` distinct resident ensembles,
+ * enqueued together and waited for once.  What a caller with a queue of ensembles gains:
+ * no host round trip between two prunes, and the small kernels of one prune (refine, level
+ * buckets, ladder, result copy) run beside the all-pairs screen of the next one on other
+ * streams (FC_PRUNE_LANES=1: strictly one after another).  Results are those of n calls of
+ * fc_prune_rmsd: the reference has no batched form, a maintainer's loop over
+ * prune_by_rmsd (firecode/ensemble.py:247-251, firecode/pruning.py:45-50) maps to one call.
+ * mask_out[r]: N_r bytes; survivors_out (may be NULL): n counts.
+ * FC_E_INVALID: NULL or repeated ensemble, n outside 0..4096, thresholds <= 0. */
+int fc_prune_rmsd_many(fc_ensemble *const *ens, int64_t n, double max_rmsd, double max_dev,
+                       int64_t min_per_group, uint8_t *const *mask_out, int64_t *survivors_out);
+
 /* ---- bench / profiling hooks (resident data, device-side timing) --------
  * Runs the all-pairs similarity stage + greedy replay `reps` times on the
  * resident ensemble and returns HIP-event times (ms, per rep) of the

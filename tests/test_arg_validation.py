@@ -101,3 +101,15 @@ def test_c_entry_points_reject_null_and_bad_sizes():
         L.call("fc_rototranslate", L.pf(out), 2, 5, None, None, L.pf(out))
     with pytest.raises(fc.FirecodeHipInputError):
         L.call("fc_prune_export_pairs_dev", None, None, 4)
+
+
+def test_prune_many_rejects_bad_lists():
+    one = (C.c_void_p * 1)(None)
+    masks = (C.POINTER(C.c_uint8) * 1)()
+    with pytest.raises(fc.FirecodeHipInputError):  # n out of range
+        L.call("fc_prune_rmsd_many", one, 5000, 0.5, 1.0, 20, masks, None)
+    with pytest.raises(fc.FirecodeHipInputError):  # NULL list
+        L.call("fc_prune_rmsd_many", None, 1, 0.5, 1.0, 20, masks, None)
+    with pytest.raises(fc.FirecodeHipInputError):  # threshold
+        L.call("fc_prune_rmsd_many", one, 1, 0.0, 1.0, 20, masks, None)
+    L.call("fc_prune_rmsd_many", None, 0, 0.5, 1.0, 20, None, None)  # empty queue: nothing to do

@@ -107,6 +107,45 @@ def test_prune_by_rmsd_mask_bit_exact(fc, n, a, seed):
     assert mask.sum() == len(np.unique(asg))
 
 
+def test_prune_many_equals_one_by_one_and_oracle(fc):
+    """a queue of ensembles of different sizes (one structure, empty, below and above one row
+    block, one where everything is similar) pruned in flight together: each mask is the mask
+    of its own prune_by_rmsd call and of the oracle"""
+    rng = np.random.default_rng(5)
+    queue = []
+    for n, a, seed in [(300, 20, 21), (1, 9, 22), (64, 12, 23), (700, 33, 24), (129, 50, 25), (257, 8, 26)]:
+        X, atoms, _ = syn.synthetic_ensemble(n, a, seed=seed)
+        queue.append((X, atoms))
+    queue.insert(2, (np.zeros((0, 7, 3)), np.array(["C"] * 7)))
+    same = np.repeat(rng.normal(size=(1, 15, 3)), 90, axis=0) + rng.normal(scale=1e-3, size=(90, 15, 3))
+    queue.append((same, np.array(["C"] * 15)))
+    many = fc.pruner.prune_many_by_rmsd(queue, 0.5)
+    assert len(many) == len(queue)
+    for (X, atoms), (pruned, mask) in zip(queue, many):
+        _, single = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+        assert np.array_equal(mask, single)
+        assert np.array_equal(pruned, X[mask])
+        if 1 < len(X) <= 300:
+            S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+            assert np.array_equal(mask, o.greedy_prune_from_matrix(S0))
+    assert many[-1][1].sum() == 1
+    # the same queue again: workspaces of the first call are gone, results are not
+    again = fc.pruner.prune_many_by_rmsd(queue[:3], 0.5)
+    for (_, m0), (_, m1) in zip(many[:3], again):
+        assert np.array_equal(m0, m1)
+
+
+def test_prune_many_rejects_a_repeated_ensemble(fc):
+    X, atoms, _ = syn.synthetic_ensemble(80, 10, seed=3)
+    from firecode_amd import _lib as L
+
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        with pytest.raises(fc.FirecodeHipInputError):
+            L.prune_many([ens, ens], 0.5, 1.0)
+        masks, alive = L.prune_many([ens], 0.5, 1.0)
+        assert alive[0] == masks[0].sum()
+
+
 def test_prune_by_rmsd_literal_oracle_small(fc):
     """against the literal (sequential, cached) restatement, not the matrix form"""
     X, atoms, _ = syn.synthetic_ensemble(150, 20, seed=12)

@@ -6,6 +6,7 @@ other named shapes and prints one JSON line per workload.
   python tools/bench_workloads.py embed      # cfg5: 500x500 conformer pairs x 512 rigid transforms
   python tools/bench_workloads.py csearch    # cfg3: 8 torsions x 6-fold = 1 679 616 angle-sets
   python tools/bench_workloads.py prune80    # cfg4 shape on ONE GPU at reduced N (A = 80)
+  python tools/bench_workloads.py queue      # many resident ensembles: one call each vs all in flight
 """
 
 import json
@@ -183,6 +184,33 @@ def small():
     }))
 
 
+def queue():
+    """a queue of resident ensembles pruned one call each vs. all in flight (fc_prune_rmsd_many)"""
+    from firecode_amd import _lib as L
+
+    out = {"workload": "queue of resident ensembles, prune at 0.5 A: one fc_prune_rmsd per ensemble vs fc_prune_rmsd_many"}
+    for label, count, n, a in [("64x(1000x30)", 64, 1000, 30), ("32x(3000x40)", 32, 3000, 40), ("16x(10000x50)", 16, 10000, 50)]:
+        ens = []
+        for q in range(count):
+            X, _, _ = syn.synthetic_ensemble(n, a, seed=100 + q)
+            ens.append(fc.DeviceEnsemble(X, center=True))
+        ref = [e.prune(0.5, 1.0)[0] for e in ens]  # also warms every workspace
+        best = {"loop": 1e9, "many": 1e9}
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for e in ens:
+                e.prune(0.5, 1.0)
+            best["loop"] = min(best["loop"], time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            masks, _ = L.prune_many(ens, 0.5, 1.0)
+            best["many"] = min(best["many"], time.perf_counter() - t0)
+        assert all(np.array_equal(m, r) for m, r in zip(masks, ref))
+        out[label] = {"loop_ms_per_ensemble": best["loop"] / count * 1e3, "many_ms_per_ensemble": best["many"] / count * 1e3}
+        for e in ens:
+            e.close()
+    print(json.dumps(out))
+
+
 def cfg4():
     """BASELINE configs[3] whole (100 000 x 80): each of the 8 ranks of the sharded prune run on ONE GPU"""
     X, atoms, asg = syn.synthetic_ensemble(100_000, 80, seed=6)
@@ -205,4 +233,4 @@ def cfg4():
 if __name__ == "__main__":
     fc.init(0)
     for w in sys.argv[1:] or ["embed", "csearch", "prune80"]:
-        {"embed": embed, "csearch": csearch, "prune80": prune80, "pcie": pcie, "values": values, "tri": tri, "small": small, "cfg4": cfg4}[w]()
+        {"embed": embed, "csearch": csearch, "prune80": prune80, "pcie": pcie, "values": values, "tri": tri, "small": small, "cfg4": cfg4, "queue": queue}[w]()
