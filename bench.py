@@ -283,11 +283,16 @@ def main():
                        "step_overlap": ("screens in order on one stream; refine + ladder + result copy of step r run "
                                         "beside the screen of step r+1 (two workspaces over the same resident "
                                         "coordinates; FC_BENCH_LANES=1 turns it off)"
-                                        if (not sharded and os.environ.get("FC_BENCH_LANES") != "1") else "none"),
+                                        if (not sharded and os.environ.get("FC_BENCH_LANES") != "1") else
+                                        "screens in order on one stream; refine + export + all-gather + ladder of step r "
+                                        "run beside the screen of step r+1 (ensemble and twin workspace, two message "
+                                        "buffers; FC_SHARD_LANES=1 turns it off)"
+                                        if (sharded and backend != "gloo" and os.environ.get("FC_SHARD_LANES") != "1")
+                                        else "none"),
                        "exchange": ("none (single GPU, resident step)" if not sharded else
                                     "host lists through gloo" if backend == "gloo" else
                                     "device-resident: export kernel -> RCCL all_gather_into_tensor -> ladder, "
-                                    "one stream, one host sync")},
+                                    "no host sync inside a batch of 64 steps")},
             "pruned_ensembles_per_s": args.steps / elapsed,
             "rmsd_values_per_s": (pairs_total / (values_ms * 1e-3)) if not sharded else None,
             "pruned_ensembles_per_s_host_in_mask_out": (1.0 / min(host_in_out_s)) if (not sharded and host_in_out_s) else None,

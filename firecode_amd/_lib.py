@@ -112,6 +112,9 @@ _SIGNATURES = {
     "fc_xyz_scan": [C.c_char_p, _p_i64, _p_i64],
     "fc_xyz_read": [C.c_char_p, _i64, _i64, C.c_char_p, _p_f64],
     "fc_bench_prune_rmsd": [_ens, _f64, _f64, _i64, _p_f64, _p_f64, _p_u8, _p_i64],
+    "fc_stream_use": [C.c_void_p],
+    "fc_ensemble_twin": [_ens, C.POINTER(_ens)],
+    "fc_prune_rmsd_begin_split_async": [_ens, _f64, _f64, _i64, _i64, _i64, C.c_void_p],
     "fc_prune_rmsd_many": [C.POINTER(_ens), _i64, _f64, _f64, _i64, C.POINTER(_p_u8), _p_i64],
 }
 
@@ -230,6 +233,11 @@ def stream_set(hip_stream):
     """Enqueue on the caller's HIP stream (integer handle, e.g. ``torch.cuda.Stream().cuda_stream``);
     None / 0 switches back to the library's own stream."""
     call("fc_stream_set", C.c_void_p(int(hip_stream) if hip_stream else None))
+
+
+def stream_use(hip_stream):
+    """``stream_set`` without draining the previous stream (the caller orders streams with events)."""
+    call("fc_stream_use", C.c_void_p(int(hip_stream) if hip_stream else None))
 
 
 def memory_trim():
@@ -361,6 +369,19 @@ class DeviceEnsemble:
         call("fc_prune_rmsd_begin_async", self.handle, float(max_rmsd), float(max_dev), int(rank), int(world),
              int(row_block))
 
+    def prune_begin_split_async(self, max_rmsd, max_dev, rank, world, screen_stream, row_block=128):
+        call("fc_prune_rmsd_begin_split_async", self.handle, float(max_rmsd), float(max_dev), int(rank),
+             int(world), int(row_block), C.c_void_p(int(screen_stream)))
+
+    def twin(self):
+        """Second prune workspace over the same resident coordinates (owned by this ensemble)."""
+        t = getattr(self, "_twin", None)
+        if t is None:
+            h = _ens()
+            call("fc_ensemble_twin", self.handle, C.byref(h))
+            t = self._twin = _EnsembleView(self, h)
+        return t
+
     def export_pairs_dev(self, dev_ptr, cap):
         call("fc_prune_export_pairs_dev", self.handle, C.c_void_p(int(dev_ptr)), int(cap))
 
@@ -388,6 +409,26 @@ class DeviceEnsemble:
         call("fc_bench_prune_rmsd", self.handle, float(max_rmsd), float(max_dev), int(reps),
              C.byref(t_k), C.byref(t_s), pb(mask), pi(stats))
         return t_k.value, t_s.value, (None if mask is None else mask.astype(bool)), stats
+
+
+class _EnsembleView(DeviceEnsemble):
+    """A handle owned by another ensemble (its twin workspace): never destroyed from here."""
+
+    def __init__(self, parent, handle):
+        self._parent = parent
+        self._view_h = handle
+        self.N, self.A_all, self.W = parent.N, parent.A_all, parent.W
+
+    @property
+    def handle(self):
+        self._parent.handle  # raises when the owner is gone
+        return self._view_h
+
+    def close(self):
+        pass
+
+    def twin(self):
+        return self._parent
 
 
 def prune_many(ensembles, max_rmsd, max_dev, min_per_group=20):

@@ -463,6 +463,20 @@ static bool ladder_collect(const fc_ensemble *e, int64_t slot, uint8_t *mask_out
   return true;
 }
 
+// second prune workspace over the coordinates of `ens` (created once, destroyed with it)
+static int ensemble_twin(fc_ensemble *ens, fc_ensemble **out) {
+  if (!ens->twin) {
+    std::unique_ptr<fc_ensemble> t(new (std::nothrow) fc_ensemble);
+    if (!t) return set_error(FC_E_NOMEM, "host allocation failed");
+    t->N = ens->N, t->A = ens->A, t->Npad = ens->Npad, t->W = ens->W;
+    t->Xs.alias(ens->Xs), t->Xa.alias(ens->Xa), t->G.alias(ens->G);
+    FC_TRY(t->counters.reserve(kCounters * sizeof(uint64_t)));
+    ens->twin = t.release();
+  }
+  *out = ens->twin;
+  return FC_OK;
+}
+
 }  // namespace fc
 
 using namespace fc;
@@ -511,6 +525,13 @@ int fc_stream_set(void *hip_stream) {
   FC_TRY(ensure_init());
   Context &c = ctx();
   FC_HIP_TRY(hipStreamSynchronize(c.stream));  // nothing of ours may still be queued on the old one
+  c.stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c.own_stream;
+  return FC_OK;
+}
+
+int fc_stream_use(void *hip_stream) {
+  FC_TRY(ensure_init());
+  Context &c = ctx();
   c.stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c.own_stream;
   return FC_OK;
 }
@@ -854,6 +875,45 @@ int fc_prune_rmsd_begin_async(fc_ensemble *ens, double max_rmsd, double max_dev,
   FC_TRY(ensemble_shard(ens, rank, world, row_block));
   if (ens->N == 0) return FC_OK;
   return simbits_local(ens, max_rmsd, max_dev, nullptr, 0.0, true);
+}
+
+int fc_ensemble_twin(fc_ensemble *ens, fc_ensemble **twin_out) {
+  FC_REQUIRE(ens && twin_out, "NULL pointer argument");
+  FC_TRY(ensure_init());
+  return ensemble_twin(ens, twin_out);
+}
+
+int fc_prune_rmsd_begin_split_async(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t rank,
+                                    int64_t world, int64_t row_block, void *screen_stream) {
+  FC_REQUIRE(ens != nullptr, "ens is NULL");
+  FC_REQUIRE(screen_stream != nullptr, "screen_stream is NULL");
+  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
+  FC_TRY(ensure_init());
+  FC_TRY(ensemble_shard(ens, rank, world, row_block));
+  if (ens->N == 0) return FC_OK;
+  Context &c = ctx();
+  static hipEvent_t ev_reset = nullptr;
+  if (!ev_reset) FC_HIP_TRY(hipEventCreateWithFlags(&ev_reset, hipEventDisableTiming));
+  hipStream_t const tail = c.stream, scr = static_cast<hipStream_t>(screen_stream);
+  struct Restore {
+    Context &c;
+    hipStream_t s;
+    ~Restore() { c.stream = s; }
+  } restore{c, tail};
+  // counters reset on the caller's stream (behind the last user of this workspace), the screen
+  // on `screen_stream` (behind the previous screen), the refine back on the caller's stream
+  FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, kCounters * sizeof(uint64_t), tail));
+  FC_HIP_TRY(hipEventRecord(ev_reset, tail));
+  FC_HIP_TRY(hipStreamWaitEvent(scr, ev_reset, 0));
+  c.stream = scr;
+  FC_HIP_TRY(hipEventRecord(c.ev2, scr));
+  FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
+  FC_HIP_TRY(hipEventRecord(c.ev3, scr));
+  FC_HIP_TRY(hipStreamWaitEvent(tail, c.ev3, 0));
+  c.stream = tail;
+  FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
+  ens->bits_valid = true;
+  return FC_OK;
 }
 
 int fc_prune_export_pairs_dev(fc_ensemble *ens, uint64_t *dev_out, int64_t cap) {
@@ -1825,16 +1885,11 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
   const bool lanes = two_lanes && reps > 1;
   const int64_t stride = ens->W + 16;
   if (lanes && !ens->twin) {
-    std::unique_ptr<fc_ensemble> t(new (std::nothrow) fc_ensemble);
-    if (!t) return set_error(FC_E_NOMEM, "host allocation failed");
-    t->N = ens->N, t->A = ens->A, t->Npad = ens->Npad, t->W = ens->W;
-    t->Xs.alias(ens->Xs), t->Xa.alias(ens->Xa), t->G.alias(ens->G);
-    FC_TRY(t->counters.reserve(kCounters * sizeof(uint64_t)));
     // one whole prune per workspace on the home stream: every grow-only buffer reaches its
     // size here, so no block changes hands while several streams are in flight
-    fc_ensemble *both[2] = {ens, t.get()};
+    fc_ensemble *both[2] = {ens, nullptr};
+    FC_TRY(ensemble_twin(ens, &both[1]));
     FC_TRY(prune_pipeline(both, 2, max_rmsd, max_dev, 20, false, stride, nullptr, nullptr));
-    ens->twin = t.release();
   }
   std::vector<fc_ensemble *> work((size_t)reps);
   for (int64_t r = 0; r < reps; ++r) work[(size_t)r] = (lanes && (r & 1)) ? ens->twin : ens;

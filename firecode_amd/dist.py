@@ -13,6 +13,8 @@ gathered masks is the owner's value.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 LADDER = (500000, 200000, 100000, 50000, 20000, 10000, 5000, 2000, 1000, 500,
@@ -102,6 +104,8 @@ def exchange_cap(n, world):
 
 _streams = {}
 _buffers = {}
+_lane_streams = {}  # device -> [home, second lane, screens]
+_lane_buffers = {}  # (device, world, cap) -> [(send, recv)] x 2
 
 
 def prune_by_rmsd_sharded_device(ens, max_rmsd, max_dev=None, rank=0, world=1, group=None, device=None,
@@ -158,14 +162,20 @@ def prune_by_rmsd_sharded_device(ens, max_rmsd, max_dev=None, rank=0, world=1, g
 
 
 def prune_steps_sharded_device(ens, steps, max_rmsd, max_dev=None, rank=0, world=1, group=None, device=None,
-                               row_block=128, min_per_group=20, gather_fn=None):
+                               row_block=128, min_per_group=20, gather_fn=None, overlap=None):
     """``steps`` sharded prunes of the same resident ensemble, STREAM-ORDERED: screen + refine,
-    export, the RCCL all-gather and the ladder of every prune are enqueued one after the other on
-    one HIP stream and the host waits once at the end (``fc_prune_collect``), so the GPU goes
-    from the ladder of prune k straight into the screen of prune k + 1 while the host is still
-    issuing calls.  The single send / receive buffer pair is safe: RCCL orders its stream
-    against the compute stream in both directions.  Returns a list of (mask, stats); a prune
-    whose device ladder declined is redone through the host exchange on every rank alike."""
+    export, the RCCL all-gather and the ladder of every prune are enqueued without a host wait in
+    between and the host waits once at the end (``fc_prune_collect``).
+
+    ``overlap`` (default: on for more than one step, ``FC_SHARD_LANES=1`` turns it off): all
+    screens go, in order, to one stream; counters reset, refine, export, all-gather and ladder of
+    prune k go to stream k&1 of two others and work on workspace k&1 (the ensemble and its twin,
+    each with its own send / receive buffers), so they run beside the screen of prune k + 1.
+    Prune k + 2 is ordered behind prune k on the same stream.  torch issues every collective on
+    the process group's own stream in call order, so the all-gathers of the two lanes stay
+    serialised and in the same order on every rank.  Without overlap everything is enqueued on
+    one stream.  Returns a list of (mask, stats); a prune whose device ladder declined is redone
+    through the host exchange on every rank alike."""
     import torch
     import torch.distributed as tdist
 
@@ -173,40 +183,65 @@ def prune_steps_sharded_device(ens, steps, max_rmsd, max_dev=None, rank=0, world
 
     if max_dev is None:
         max_dev = 2 * max_rmsd
+    if overlap is None:
+        overlap = os.environ.get("FC_SHARD_LANES") != "1"
+    overlap = bool(overlap) and steps > 1
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    stream = _streams.get(device)
-    if stream is None:
-        stream = _streams[device] = torch.cuda.Stream(device=device)
+    pool = _lane_streams.get(device)
+    if pool is None:
+        pool = _lane_streams[device] = [torch.cuda.Stream(device=device) for _ in range(3)]
+    home, lane_b, screen = pool
+    lanes = [home, lane_b] if overlap else [home, home]
+    work = [ens, ens.twin()] if overlap else [ens, ens]
     cap = exchange_cap(ens.N, world)
+    key = (device, world, cap)
+    if key not in _lane_buffers:
+        _lane_buffers.clear()
+        _lane_buffers[key] = [(torch.empty(cap + 1, dtype=torch.int64, device=device),
+                          torch.empty(world * (cap + 1), dtype=torch.int64, device=device)) for _ in range(2)]
     results = []
-    with torch.cuda.stream(stream):
-        _lib.stream_set(stream.cuda_stream)
-        try:
-            key = (device, world, cap)
-            if key not in _buffers:
-                _buffers.clear()
-                _buffers[key] = (torch.empty(cap + 1, dtype=torch.int64, device=device),
-                                 torch.empty(world * (cap + 1), dtype=torch.int64, device=device))
-            send, recv = _buffers[key]
-            for k in range(steps):
-                ens.prune_begin_async(max_rmsd, max_dev, rank, world, row_block=row_block)
-                ens.export_pairs_dev(send.data_ptr(), cap)
-                if gather_fn is not None:
-                    gather_fn(send, recv)
-                elif world == 1 and group is None and not tdist.is_initialized():
-                    recv.copy_(send)
+
+    def gather(send, recv):
+        if gather_fn is not None:
+            gather_fn(send, recv)
+        elif world == 1 and group is None and not tdist.is_initialized():
+            recv.copy_(send)
+        else:
+            tdist.all_gather_into_tensor(recv, send, group=group)
+
+    caller = torch.cuda.current_stream(device)
+    home.wait_stream(caller)
+    _lib.stream_set(home.cuda_stream)
+    try:
+        if overlap:  # both other streams start behind what the home stream holds
+            lane_b.wait_stream(home)
+            screen.wait_stream(home)
+        for k in range(steps):
+            e, lane = work[k & 1], lanes[k & 1]
+            send, recv = _lane_buffers[key][k & 1]
+            with torch.cuda.stream(lane):
+                _lib.stream_use(lane.cuda_stream)
+                if overlap:
+                    e.prune_begin_split_async(max_rmsd, max_dev, rank, world, screen.cuda_stream, row_block=row_block)
                 else:
-                    tdist.all_gather_into_tensor(recv, send, group=group)
-                ens.prune_from_gathered_enqueue(recv.data_ptr(), world, cap, k, steps, min_per_group=min_per_group)
-            for k in range(steps):
-                try:
-                    results.append(ens.prune_collect(k, steps))
-                except _lib.FirecodeHipInputError as e:
-                    if e.code != _lib.FC_E_LIMIT:
-                        raise
-                    results.append(None)
-        finally:
-            _lib.stream_set(None)
+                    e.prune_begin_async(max_rmsd, max_dev, rank, world, row_block=row_block)
+                e.export_pairs_dev(send.data_ptr(), cap)
+                gather(send, recv)
+                e.prune_from_gathered_enqueue(recv.data_ptr(), world, cap, k, steps, min_per_group=min_per_group)
+        _lib.stream_use(home.cuda_stream)
+        if overlap:
+            home.wait_stream(lane_b)
+            home.wait_stream(screen)
+        for k in range(steps):
+            try:
+                results.append(work[k & 1].prune_collect(k, steps))  # the first one waits for the home stream
+            except _lib.FirecodeHipInputError as e:
+                if e.code != _lib.FC_E_LIMIT:
+                    raise
+                results.append(None)
+    finally:
+        _lib.stream_use(home.cuda_stream)
+        _lib.stream_set(None)
     if any(r is None for r in results):
         allgather = torch_allgather(group=group, device=device) if (world > 1 or tdist.is_initialized()) else None
         results = [r if r is not None else

@@ -48,6 +48,9 @@ const char *fc_last_error(void);
  * stream; NULL switches back.  The previous stream is drained first.  The legacy null
  * stream cannot be named this way (NULL means "own stream"). */
 int fc_stream_set(void *hip_stream);
+/* The same switch WITHOUT draining the previous stream: for a caller that orders its streams
+ * with events itself (the overlapped multi-GPU steps of firecode_amd/dist.py). */
+int fc_stream_use(void *hip_stream);
 /* Device temporaries of the entry points come from a caching pool (released blocks are kept
  * and reused; FC_POOL_MB caps what is kept, default 2048, 0 disables).  fc_memory_trim returns
  * the kept blocks to the HIP runtime; fc_shutdown does the same. */
@@ -162,6 +165,18 @@ int fc_prune_from_gathered_dev(fc_ensemble *ens, const uint64_t *dev_gathered, i
 int fc_prune_from_gathered_dev_enqueue(fc_ensemble *ens, const uint64_t *dev_gathered, int64_t world,
                                        int64_t cap, int64_t min_per_group, int64_t slot, int64_t n_slots);
 int fc_prune_collect(fc_ensemble *ens, int64_t slot, int64_t n_slots, uint8_t *mask_out, int64_t *stats);
+/* Overlap of consecutive sharded prunes of ONE resident ensemble:
+ *   fc_ensemble_twin                  a second prune workspace (bit rows, queues, counters, ladder
+ *                                     words) over the same coordinates; owned by `ens`, destroyed
+ *                                     with it; takes every prune call an ensemble takes;
+ *   fc_prune_rmsd_begin_split_async   begin_async with the screen on `screen_stream` (all screens of a
+ *                                     batch go there, in order) and counters reset + refine on the
+ *                                     current stream (fc_stream_use), tied together with events.
+ * Prune k on workspace k&1 and stream k&1 of two: export, all-gather and ladder of prune k run
+ * beside the screen of prune k+1. */
+int fc_ensemble_twin(fc_ensemble *ens, fc_ensemble **twin_out);
+int fc_prune_rmsd_begin_split_async(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t rank,
+                                    int64_t world, int64_t row_block, void *screen_stream);
 
 /* ---- a7: prune_by_rmsd_rot_corr(structures, atoms, graph, max_rmsd=, energies=, max_dE=) --
  * prism_pruner.pruner (NOT in the reference tree); call sites firecode/ensemble.py:253-260,

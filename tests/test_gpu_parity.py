@@ -709,6 +709,42 @@ def test_stream_ordered_sharded_steps(fc, monkeypatch):
             assert np.array_equal(mask, ref)
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_sharded_steps_two_logical_ranks_with_and_without_overlap(fc, overlap):
+    """rank 0 of a 2-rank prune on one GPU: rank 1's message is computed beforehand and the
+    collective is replaced by a copy of both messages; consecutive steps on one stream, or
+    overlapped (ensemble + twin workspace, screens on a stream of their own) -- same masks"""
+    import torch
+
+    from firecode_amd import _lib
+    from firecode_amd import dist as fdist
+
+    X, atoms, asg = syn.synthetic_ensemble(1100, 18, seed=199)
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    world, cap = 2, fdist.exchange_cap(len(X), 2)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        other = torch.empty(cap + 1, dtype=torch.int64, device="cuda:0")
+        ens.prune_begin_async(0.5, 1.0, 1, world)
+        ens.export_pairs_dev(other.data_ptr(), cap)
+        _lib.call("fc_memory_trim")  # also a host wait for the library's stream
+        calls = []
+
+        def gather(send, recv):
+            calls.append(send.data_ptr())
+            recv.view(world, cap + 1)[0].copy_(send)
+            recv.view(world, cap + 1)[1].copy_(other)
+
+        res = fdist.prune_steps_sharded_device(ens, 6, 0.5, rank=0, world=world, gather_fn=gather, overlap=overlap)
+        assert len(res) == 6 and len(calls) == 6
+        own = int(np.triu(S0, 1)[fdist.owner_of_rows(len(X), world, 128) == 0].sum())
+        for mask, stats in res:
+            assert np.array_equal(mask, ref) and stats[2] == own and stats[5] == ref.sum()
+        # the plain one-shot call still works on the same ensemble afterwards
+        mask, _ = ens.prune(0.5, 1.0)
+        assert np.array_equal(mask, ref)
+
+
 def test_device_resident_exchange_over_rccl_single_rank(fc):
     """the real collective (torch.distributed nccl = RCCL) on a 1-rank group: stream ordering
     between the library's kernels and RCCL's stream, no host synchronisation in between"""
