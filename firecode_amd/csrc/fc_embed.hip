@@ -171,7 +171,7 @@ k_embed_pretransform(const double *__restrict__ coords, int64_t n, int64_t A, in
 //   p = ((c2*n1 + c1)*2 + o) * (na1*na2) + (a2*na1 + a1)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_embed_grid_clash(const double *__restrict__ X1, int64_t n1, int A1, int64_t na1,
+k_embed_grid_clash_f64(const double *__restrict__ X1, int64_t n1, int A1, int64_t na1,
                    const double *__restrict__ X2s, int64_t n2, int A2, int64_t na2, int64_t S2,
                    double thr2, int max_clashes, int strips, uint8_t *__restrict__ pass,
                    int32_t *__restrict__ counts) {
@@ -201,6 +201,135 @@ k_embed_grid_clash(const double *__restrict__ X1, int64_t n1, int A1, int64_t na
       }
       // whole wave past the limit: nothing left to learn
       if (__all(cnt > max_clashes || !on)) break;
+    }
+    if (on) {
+      const int64_t c2 = s2 / na2, a2 = s2 % na2;
+      const int64_t p = ((c2 * n1 + c1) * 2 + o) * (na1 * na2) + (a2 * na1 + a1);
+      pass[p] = (cnt <= max_clashes) ? 1 : 0;
+      if (counts) counts[p] = cnt;
+    }
+  }
+}
+
+// The fp64 arithmetic of the reference decides only the pairs an fp32 pass cannot: per
+// (molecule-2 atom, molecule-1 structure) the minimum squared distance is taken in packed fp32
+// (two molecule-1 atoms per instruction, 3.5 instructions per pair instead of 10 fp64 ones) and
+// compared with thr2 pushed up by a bound on the fp32 error,
+//   e1 = (2 M + thr) 2^-24   (M = largest |coordinate| of both tables: conversion + difference),
+//   |d2_fp32 - d2| < 2 sqrt(3) e1 thr + 3 e1^2 + 4 2^-24 d2     for d < thr,
+// taken 2x wide below.  A minimum at or above that bound proves "no clash with this atom" for
+// the exact arithmetic too; anything below is recounted exactly as before (same operations, same
+// order), so pass flags and counts are bit-identical to the all-fp64 kernel kept beside it
+// (FC_GRID_F64=1; tests compare both with the oracle).  NaN / inf coordinates: an fp32 minimum
+// ignores NaN like the exact `<` does; an infinite M makes every atom take the exact path.
+typedef float fc_f2 __attribute__((ext_vector_type(2)));
+
+__global__ void k_max_abs(const double *__restrict__ x, int64_t n, unsigned long long *__restrict__ out) {
+  double m = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = fabs(x[i]);
+    if (v > m) m = v;  // false for NaN
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(m, off);
+    if (o > m) m = o;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
+#ifndef FC_GRID_NB
+#define FC_GRID_NB 8
+#endif
+__global__ void __launch_bounds__(256)
+k_embed_grid_clash(const double *__restrict__ X1, int64_t n1, int A1, int64_t na1,
+                   const double *__restrict__ X2s, int64_t n2, int A2, int64_t na2, int64_t S2,
+                   double thr2, int max_clashes, int strips, const unsigned long long *__restrict__ maxabs,
+                   uint8_t *__restrict__ pass, int32_t *__restrict__ counts) {
+  constexpr int NB = FC_GRID_NB;  // molecule-2 atoms per trip through molecule 1
+  extern __shared__ double s[];  // A1 x 3 doubles, then three arrays of P1 float pairs (x, y, z)
+  const int tid = threadIdx.x;
+  const int P1 = (A1 + 1) / 2;
+  fc_f2 *SX = reinterpret_cast<fc_f2 *>(s + A1 * 3), *SY = SX + P1, *SZ = SY + P1;
+  const int64_t g1 = blockIdx.x;  // (c1, o, a1)
+  const int64_t a1 = g1 % na1;
+  const int o = (int)((g1 / na1) % 2);
+  const int64_t c1 = g1 / (2 * na1);
+  for (int k = tid; k < A1 * 3; k += 256) s[k] = X1[g1 * (int64_t)A1 * 3 + k];
+  for (int k = tid; k < P1 * 2; k += 256) {  // an odd last pair is filled with a far-away atom
+    const bool real = k < A1;
+    const double *src = X1 + g1 * (int64_t)A1 * 3 + (int64_t)k * 3;
+    reinterpret_cast<float *>(SX)[k] = real ? (float)src[0] : 3.0e18f;
+    reinterpret_cast<float *>(SY)[k] = real ? (float)src[1] : 3.0e18f;
+    reinterpret_cast<float *>(SZ)[k] = real ? (float)src[2] : 3.0e18f;
+  }
+  __syncthreads();
+  float t_hi;
+  {
+    const double M = __longlong_as_double((long long)maxabs[0]);
+    const double thr = sqrt(thr2) * (1.0 + 0x1p-40);
+    const double e1 = (2.0 * M + thr) * 0x1p-24;
+    const double T = (thr2 + 8.0 * e1 * thr + 8.0 * e1 * e1) * (1.0 + 0x1p-20);
+    t_hi = (float)T;
+    if (!(T < 3.0e38)) t_hi = INFINITY;  // overflow or NaN: everything takes the exact path
+    else if ((double)t_hi <= T) t_hi = nextafterf(t_hi, INFINITY);  // strictly above T
+  }
+  const int64_t n_s2 = n2 * na2;
+  const double *__restrict__ base2 = X2s + (int64_t)o * A2 * 3 * S2;
+  for (int64_t s2 = (int64_t)blockIdx.y * 256 + tid; s2 < S2; s2 += (int64_t)strips * 256) {
+    const bool on = s2 < n_s2;
+    int cnt = 0;
+    int resume = on ? 0 : A2;  // first molecule-2 atom this lane has not dealt with
+    // Scan passes.  In a pass a lane runs the fp32 test over its remaining atoms until one
+    // cannot be ruled out (`pending`), then waits; when no lane scans any more, every waiting
+    // lane recounts its atom exactly -- ONE divergent recount per pass and wave instead of one
+    // per suspicious atom.  With max_clashes = 0 a second pass happens only when a recount finds
+    // no clash after all (a distance within ~1e-6 of the threshold).
+    for (;;) {
+      int pending = -1;
+      int first = resume;
+      for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
+      if (first >= A2) break;  // every lane is done (wave-uniform)
+      for (int b0 = first & ~(NB - 1); b0 < A2; b0 += NB) {
+        const bool scanning = pending < 0 && resume < A2;
+        if (__all(!scanning)) break;
+        float bx[NB], by[NB], bz[NB], m[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const int b = min(b0 + q, A2 - 1);
+          bx[q] = (float)base2[(int64_t)(b * 3 + 0) * S2 + s2];
+          by[q] = (float)base2[(int64_t)(b * 3 + 1) * S2 + s2];
+          bz[q] = (float)base2[(int64_t)(b * 3 + 2) * S2 + s2];
+          m[q] = INFINITY;
+        }
+        for (int ap = 0; ap < P1; ++ap) {
+          const fc_f2 X = SX[ap], Y = SY[ap], Z = SZ[ap];
+#pragma unroll
+          for (int q = 0; q < NB; ++q) {
+            const fc_f2 dx = fc_f2{bx[q], bx[q]} - X, dy = fc_f2{by[q], by[q]} - Y, dz = fc_f2{bz[q], bz[q]} - Z;
+            fc_f2 d = dx * dx;
+            d = __builtin_elementwise_fma(dy, dy, d);
+            d = __builtin_elementwise_fma(dz, dz, d);
+            m[q] = fminf(fminf(m[q], d.x), d.y);
+          }
+        }
+        if (scanning) {
+#pragma unroll
+          for (int q = NB - 1; q >= 0; --q)  // the FIRST suspicious atom at or behind `resume` wins
+            if (b0 + q < A2 && b0 + q >= resume && m[q] < t_hi) pending = b0 + q;
+          if (pending < 0) resume = max(resume, min(b0 + NB, A2));
+        }
+      }
+      if (pending >= 0) {  // exact recount of that atom: the reference's arithmetic and order
+        const double ex = base2[(int64_t)(pending * 3 + 0) * S2 + s2];
+        const double ey = base2[(int64_t)(pending * 3 + 1) * S2 + s2];
+        const double ez = base2[(int64_t)(pending * 3 + 2) * S2 + s2];
+        for (int a = 0; a < A1; ++a) {
+          const double dx = ex - s[a * 3], dy = ey - s[a * 3 + 1], dz = ez - s[a * 3 + 2];
+          const double d2 = ((dx * dx) + dy * dy) + dz * dz;
+          cnt += (d2 < thr2) ? 1 : 0;
+        }
+        resume = (cnt > max_clashes) ? A2 : pending + 1;  // past the limit: nothing left to learn
+      }
     }
     if (on) {
       const int64_t c2 = s2 / na2, a2 = s2 % na2;
@@ -485,8 +614,8 @@ int launch_embed_pretransform(const double *coords_dev, int64_t n, int64_t A, in
 
 int launch_embed_grid_clash(const double *X1_dev, int64_t n1, int64_t A1, int64_t na1,
                             const double *X2s_dev, int64_t n2, int64_t A2, int64_t na2, int64_t S2,
-                            double thresh, int64_t max_clashes, uint8_t *pass_dev,
-                            int32_t *counts_dev) {
+                            double thresh, int64_t max_clashes, unsigned long long *scratch_dev,
+                            uint8_t *pass_dev, int32_t *counts_dev) {
   const int64_t g1 = n1 * 2 * na1;
   if (g1 == 0 || n2 * na2 == 0) return FC_OK;
   const double thr2 = sq_threshold_lt(thresh);
@@ -494,9 +623,25 @@ int launch_embed_grid_clash(const double *X1_dev, int64_t n1, int64_t A1, int64_
   // enough workgroups to fill the chip, few enough that the LDS stage is amortised
   const int64_t want = ceil_div((int64_t)ctx().n_cu * 16, g1);
   if (strips > want) strips = std::max<int64_t>(want, 1);
-  hipLaunchKernelGGL(k_embed_grid_clash, dim3((unsigned)g1, (unsigned)strips), dim3(256),
-                     (size_t)A1 * 3 * sizeof(double), ctx().stream, X1_dev, n1, (int)A1, na1, X2s_dev,
-                     n2, (int)A2, na2, S2, thr2, (int)max_clashes, (int)strips, pass_dev, counts_dev);
+  const char *f64_env = getenv("FC_GRID_F64");  // read per call: the tests switch it
+  if (f64_env && atoi(f64_env) == 1) {
+    hipLaunchKernelGGL(k_embed_grid_clash_f64, dim3((unsigned)g1, (unsigned)strips), dim3(256),
+                       (size_t)A1 * 3 * sizeof(double), ctx().stream, X1_dev, n1, (int)A1, na1, X2s_dev,
+                       n2, (int)A2, na2, S2, thr2, (int)max_clashes, (int)strips, pass_dev, counts_dev);
+    return check_launch("k_embed_grid_clash_f64");
+  }
+  // largest |coordinate| of both tables (X2s: the padding is zero) for the fp32 error bound
+  FC_HIP_TRY(hipMemsetAsync(scratch_dev, 0, sizeof(unsigned long long), ctx().stream));
+  const int64_t len1 = g1 * A1 * 3, len2 = 2 * A2 * 3 * S2;
+  hipLaunchKernelGGL(k_max_abs, dim3((unsigned)std::min<int64_t>(ceil_div(len1, 256), 1024)), dim3(256), 0,
+                     ctx().stream, X1_dev, len1, scratch_dev);
+  hipLaunchKernelGGL(k_max_abs, dim3((unsigned)std::min<int64_t>(ceil_div(len2, 256), 1024)), dim3(256), 0,
+                     ctx().stream, X2s_dev, len2, scratch_dev);
+  FC_TRY(check_launch("k_max_abs"));
+  const size_t lds = (size_t)A1 * 3 * sizeof(double) + (size_t)3 * ((A1 + 1) / 2) * sizeof(fc_f2);
+  hipLaunchKernelGGL(k_embed_grid_clash, dim3((unsigned)g1, (unsigned)strips), dim3(256), lds, ctx().stream,
+                     X1_dev, n1, (int)A1, na1, X2s_dev, n2, (int)A2, na2, S2, thr2, (int)max_clashes,
+                     (int)strips, scratch_dev, pass_dev, counts_dev);
   return check_launch("k_embed_grid_clash");
 }
 

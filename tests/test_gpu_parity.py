@@ -554,6 +554,46 @@ def test_embed_grid_vs_oracle(fc, seed, nr1, nr2):
     assert np.array_equal(np.minimum(counts, 1), np.minimum(ref_cnt, 1))  # counts saturate past max_clashes
 
 
+@pytest.mark.parametrize("a1,a2,seed", [(13, 11, 71), (24, 17, 72), (9, 40, 73)])
+def test_embed_grid_fp32_screen_equals_all_fp64_kernel(fc, monkeypatch, a1, a2, seed):
+    """the pose-grid clash kernel rules pairs out in packed fp32 and recounts the rest exactly;
+    pass flags AND counts must equal the all-fp64 kernel (FC_GRID_F64=1) bit for bit: odd atom
+    counts (padding atom, partial atom groups), thresholds that sit exactly ON an interatomic
+    distance of a pose (the fp32 screen cannot decide, the exact recount says "no clash" and the
+    lane has to resume), tiny and huge thresholds, several max_clashes"""
+    rng = np.random.default_rng(seed)
+    m1, r1, pv1, m2, r2, pv2 = _embed_case(seed, nr1=2, nr2=1)
+    m1, m2 = m1[:, :a1].copy(), np.concatenate([m2] * 2, axis=1)[:, :a2].copy()
+    m2[:, m2.shape[1] // 2:] += rng.normal(scale=0.7, size=m2[:, m2.shape[1] // 2:].shape)
+    r1, r2 = np.array([0, 1]), np.array([2])
+    angles = np.array([-45.0, 0.0, 30.0])
+
+    def both(thresh, mc):
+        monkeypatch.setenv("FC_GRID_F64", "0")
+        ok, cnt, _ = fc.embeds.embed_grid_clash(m1, r1, pv1, m2, r2, pv2, angles, thresh=thresh, max_clashes=mc,
+                                                return_counts=True)
+        monkeypatch.setenv("FC_GRID_F64", "1")
+        ok64, cnt64, _ = fc.embeds.embed_grid_clash(m1, r1, pv1, m2, r2, pv2, angles, thresh=thresh, max_clashes=mc,
+                                                    return_counts=True)
+        assert np.array_equal(ok, ok64) and np.array_equal(cnt, cnt64)
+        return ok, cnt
+
+    # distances of one real pose: thresholds exactly on them
+    R1, t1 = fc.embeds.embed_mol_transforms(m1, r1, pv1, 0, angles)
+    R2, t2 = fc.embeds.embed_mol_transforms(m2, r2, pv2, 1, angles)
+    pose = o.get_embed([m1[0], m2[0]], [R1[0, 0, 1], R2[0, 0, 2]], [t1[0, 0, 1], t2[0, 0, 2]])
+    from scipy.spatial.distance import cdist
+
+    d = np.sort(cdist(pose[a1:], pose[:a1]).reshape(-1))
+    seen = []
+    for thresh in [1.5, 1e-3, 0.4, 40.0, float(d[0]), float(d[3]), float(np.nextafter(d[3], 9.0)), float(d[len(d) // 2])]:
+        for mc in (0, 1, 2):
+            ok, _ = both(thresh, mc)
+            seen.append(ok.mean())
+    assert min(seen) == 0.0 and max(seen) == 1.0 and len(set(seen)) > 4  # all regimes were visited
+    monkeypatch.delenv("FC_GRID_F64")
+
+
 # ---------------------------------------------------------------- graph clash, fitness, drivers
 def test_compenetration_graph_mode_golden(fc, golden):
     edges = golden["cp_graph_edges"]
