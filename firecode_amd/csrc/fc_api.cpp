@@ -75,7 +75,7 @@ int launch_embed_mol_transforms(const double *, int64_t, int64_t, const int64_t 
 int launch_embed_pretransform(const double *, int64_t, int64_t, int64_t, const double *,
                               const double *, int, int64_t, double *);
 int launch_embed_grid_clash(const double *, int64_t, int64_t, int64_t, const double *, int64_t, int64_t,
-                            int64_t, int64_t, double, int64_t, unsigned long long *, uint8_t *, int32_t *);
+                            int64_t, int64_t, double, int64_t, void *, size_t, uint8_t *, int32_t *);
 int launch_string_transforms(const double *, const double *, int64_t, int64_t, const double *, const double *,
                              int64_t, int64_t, const double *, int64_t, double *, double *, int64_t *, int64_t *);
 int launch_pose_fingerprints(const double *, int64_t, const double *, int64_t, const int64_t *, const int64_t *,
@@ -1332,13 +1332,12 @@ static int embed_grid(const double *m1, int64_t n1, int64_t A1, const int64_t *r
   FC_TRY(check_embed_mol(m1, n1, A1, reactive1, nr1, ps1, pe1, angles1, na1));
   FC_TRY(check_embed_mol(m2, n2, A2, reactive2, nr2, ps2, pe2, angles2, na2));
   FC_REQUIRE(pass_out != nullptr && max_clashes >= 0, "bad arguments");
-  if (A1 * 36 + 64 > 64 * 1024) return set_error(FC_E_LIMIT, "A1=%lld too large for the LDS stage", (long long)A1);
+  if (A1 * 40 + 64 > 64 * 1024) return set_error(FC_E_LIMIT, "A1=%lld too large for the LDS stage", (long long)A1);
   FC_TRY(ensure_init());
   Context &c = ctx();
   const int64_t P = n1 * n2 * 2 * na1 * na2;
   const int64_t S2 = ceil_div(n2 * na2, 64) * 64;
   DevBuf d1, d2, r1, r2, s1, e1, s2, e2, a1, a2, R1, t1, R2, t2, X1, X2s, dpass, dcnt, dmax;
-  FC_TRY(dmax.reserve(sizeof(unsigned long long)));
   FC_TRY(upload(d1, m1, (size_t)n1 * A1 * 3));
   FC_TRY(upload(d2, m2, (size_t)n2 * A2 * 3));
   FC_TRY(upload(r1, reactive1, (size_t)nr1));
@@ -1356,6 +1355,7 @@ static int embed_grid(const double *m1, int64_t n1, int64_t A1, const int64_t *r
   FC_TRY(t2.reserve(G2 * 3 * sizeof(double)));
   FC_TRY(X1.reserve(G1 * A1 * 3 * sizeof(double)));
   FC_TRY(X2s.reserve((size_t)2 * A2 * 3 * S2 * sizeof(double)));
+  FC_TRY(dmax.reserve(256 + (size_t)2 * A2 * 3 * S2 * sizeof(float)));  // scratch of the clash kernel
   FC_TRY(dpass.reserve((size_t)P));
   if (counts_out) FC_TRY(dcnt.reserve((size_t)P * sizeof(int32_t)));
   FC_HIP_TRY(hipMemsetAsync(X2s.p, 0, (size_t)2 * A2 * 3 * S2 * sizeof(double), c.stream));
@@ -1369,7 +1369,7 @@ static int embed_grid(const double *m1, int64_t n1, int64_t A1, const int64_t *r
                                    X2s.as<double>()));
   FC_HIP_TRY(hipEventRecord(c.ev0, c.stream));
   FC_TRY(launch_embed_grid_clash(X1.as<double>(), n1, A1, na1, X2s.as<double>(), n2, A2, na2, S2, thresh,
-                                 max_clashes, dmax.as<unsigned long long>(), dpass.as<uint8_t>(),
+                                 max_clashes, dmax.p, dmax.bytes, dpass.as<uint8_t>(),
                                  counts_out ? dcnt.as<int32_t>() : nullptr));
   FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
   DevBuf X2a, dacc;

@@ -211,18 +211,27 @@ k_embed_grid_clash_f64(const double *__restrict__ X1, int64_t n1, int A1, int64_
   }
 }
 
-// The fp64 arithmetic of the reference decides only the pairs an fp32 pass cannot: per
-// (molecule-2 atom, molecule-1 structure) the minimum squared distance is taken in packed fp32
-// (two molecule-1 atoms per instruction, 3.5 instructions per pair instead of 10 fp64 ones) and
-// compared with thr2 pushed up by a bound on the fp32 error,
-//   e1 = (2 M + thr) 2^-24   (M = largest |coordinate| of both tables: conversion + difference),
-//   |d2_fp32 - d2| < 2 sqrt(3) e1 thr + 3 e1^2 + 4 2^-24 d2     for d < thr,
-// taken 2x wide below.  A minimum at or above that bound proves "no clash with this atom" for
-// the exact arithmetic too; anything below is recounted exactly as before (same operations, same
-// order), so pass flags and counts are bit-identical to the all-fp64 kernel kept beside it
-// (FC_GRID_F64=1; tests compare both with the oracle).  NaN / inf coordinates: an fp32 minimum
-// ignores NaN like the exact `<` does; an infinite M makes every atom take the exact path.
+// The fp64 arithmetic of the reference decides only the pairs an fp32 pass cannot.  Per
+// (molecule-2 atom b, molecule-1 structure) the fp32 pass takes the minimum over atoms a of
+//   v = |a^|^2 - 2 b^.a^        (a^, b^: coordinates rounded to fp32; = |b^ - a^|^2 - |b^|^2)
+// as three fused multiply-adds per pair (two pairs per packed instruction) and compares it with
+// tb = T - |b^|^2, where T is thr2 pushed up by a bound on everything fp32 did, for d < thr:
+//   conversion:  | |b^-a^|^2 - d^2 | <= 2 thr sqrt(3) 2 e0 + 12 e0^2,   e0 = M 2^-24
+//   evaluation:  |v_fp32 - v|        <= 30 M^2 2^-24   (|a^|^2 rounded once, three fma's on
+//                                       partial sums below 9 M^2)
+// (M = largest |coordinate| of both tables), taken 2x wide.  v >= tb proves "atom b clashes
+// with nothing" for the exact arithmetic too; any other atom is recounted exactly as before
+// (same operations, same order), so pass flags and counts are bit-identical to the all-fp64
+// kernel kept beside it (FC_GRID_F64=1; the tests compare the two and the oracle).  The band
+// grows with M^2: for coordinates beyond a few hundred Angstrom most atoms take the exact path
+// (slow, still exact).  NaN / inf coordinates: an fp32 minimum ignores NaN like the exact `<`
+// does; |coordinates| of 1e15 and more (also +-inf) send every atom down the exact path.
 typedef float fc_f2 __attribute__((ext_vector_type(2)));
+
+__global__ void k_to_f32(const double *__restrict__ x, int64_t n, float *__restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (float)x[i];
+}
 
 __global__ void k_max_abs(const double *__restrict__ x, int64_t n, unsigned long long *__restrict__ out) {
   double m = 0.0;
@@ -244,37 +253,43 @@ __global__ void __launch_bounds__(256)
 k_embed_grid_clash(const double *__restrict__ X1, int64_t n1, int A1, int64_t na1,
                    const double *__restrict__ X2s, int64_t n2, int A2, int64_t na2, int64_t S2,
                    double thr2, int max_clashes, int strips, const unsigned long long *__restrict__ maxabs,
-                   uint8_t *__restrict__ pass, int32_t *__restrict__ counts) {
+                   const float *__restrict__ X2f, uint8_t *__restrict__ pass, int32_t *__restrict__ counts) {
   constexpr int NB = FC_GRID_NB;  // molecule-2 atoms per trip through molecule 1
-  extern __shared__ double s[];  // A1 x 3 doubles, then three arrays of P1 float pairs (x, y, z)
+  extern __shared__ double s[];  // A1 x 3 doubles, then four arrays of P1 float pairs (-2x, -2y, -2z, |a|^2)
   const int tid = threadIdx.x;
   const int P1 = (A1 + 1) / 2;
-  fc_f2 *SX = reinterpret_cast<fc_f2 *>(s + A1 * 3), *SY = SX + P1, *SZ = SY + P1;
+  fc_f2 *SX = reinterpret_cast<fc_f2 *>(s + A1 * 3), *SY = SX + P1, *SZ = SY + P1, *SN = SZ + P1;
   const int64_t g1 = blockIdx.x;  // (c1, o, a1)
   const int64_t a1 = g1 % na1;
   const int o = (int)((g1 / na1) % 2);
   const int64_t c1 = g1 / (2 * na1);
   for (int k = tid; k < A1 * 3; k += 256) s[k] = X1[g1 * (int64_t)A1 * 3 + k];
-  for (int k = tid; k < P1 * 2; k += 256) {  // an odd last pair is filled with a far-away atom
+  for (int k = tid; k < P1 * 2; k += 256) {  // -2 a^ and |a^|^2; an odd last pair gets an atom at "infinity"
     const bool real = k < A1;
     const double *src = X1 + g1 * (int64_t)A1 * 3 + (int64_t)k * 3;
-    reinterpret_cast<float *>(SX)[k] = real ? (float)src[0] : 3.0e18f;
-    reinterpret_cast<float *>(SY)[k] = real ? (float)src[1] : 3.0e18f;
-    reinterpret_cast<float *>(SZ)[k] = real ? (float)src[2] : 3.0e18f;
+    const float x = real ? (float)src[0] : 0.f, y = real ? (float)src[1] : 0.f, z = real ? (float)src[2] : 0.f;
+    reinterpret_cast<float *>(SX)[k] = -2.f * x;
+    reinterpret_cast<float *>(SY)[k] = -2.f * y;
+    reinterpret_cast<float *>(SZ)[k] = -2.f * z;
+    // products of floats are exact in double; the sum is rounded to fp32 once (up to 2 ulp(double))
+    reinterpret_cast<float *>(SN)[k] = real ? (float)(((double)x * x + (double)y * y) + (double)z * z) : 3.0e37f;
   }
   __syncthreads();
-  float t_hi;
+  float Tf;  // the threshold of the fp32 pass before |b^|^2 is taken off
   {
     const double M = __longlong_as_double((long long)maxabs[0]);
     const double thr = sqrt(thr2) * (1.0 + 0x1p-40);
-    const double e1 = (2.0 * M + thr) * 0x1p-24;
-    const double T = (thr2 + 8.0 * e1 * thr + 8.0 * e1 * e1) * (1.0 + 0x1p-20);
-    t_hi = (float)T;
-    if (!(T < 3.0e38)) t_hi = INFINITY;  // overflow or NaN: everything takes the exact path
-    else if ((double)t_hi <= T) t_hi = nextafterf(t_hi, INFINITY);  // strictly above T
+    const double e0 = M * 0x1p-24;
+    // conversion + evaluation of v (header) + |b^|^2 in fp32 (three roundings on sums <= 3 M^2)
+    // + the subtraction Tf - |b^|^2 (one rounding, covered by the relative factor), all 2x wide
+    double T = thr2 + 2.0 * ((2.0 * thr * 3.47 * e0 + 12.0 * e0 * e0) + (30.0 + 16.0) * M * M * 0x1p-24);
+    T *= 1.0 + 0x1p-20;
+    Tf = nextafterf((float)T, INFINITY);
+    if (!(M < 1.0e15)) Tf = INFINITY;  // fp32 products could overflow (or M is NaN): everything takes the exact path
   }
   const int64_t n_s2 = n2 * na2;
   const double *__restrict__ base2 = X2s + (int64_t)o * A2 * 3 * S2;
+  const float *__restrict__ base2f = X2f + (int64_t)o * A2 * 3 * S2;
   for (int64_t s2 = (int64_t)blockIdx.y * 256 + tid; s2 < S2; s2 += (int64_t)strips * 256) {
     const bool on = s2 < n_s2;
     int cnt = 0;
@@ -292,30 +307,32 @@ k_embed_grid_clash(const double *__restrict__ X1, int64_t n1, int A1, int64_t na
       for (int b0 = first & ~(NB - 1); b0 < A2; b0 += NB) {
         const bool scanning = pending < 0 && resume < A2;
         if (__all(!scanning)) break;
-        float bx[NB], by[NB], bz[NB], m[NB];
+        fc_f2 bx[NB], by[NB], bz[NB];
+        float m[NB], tb[NB];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
           const int b = min(b0 + q, A2 - 1);
-          bx[q] = (float)base2[(int64_t)(b * 3 + 0) * S2 + s2];
-          by[q] = (float)base2[(int64_t)(b * 3 + 1) * S2 + s2];
-          bz[q] = (float)base2[(int64_t)(b * 3 + 2) * S2 + s2];
-          m[q] = INFINITY;
+          const float x = base2f[(int64_t)(b * 3 + 0) * S2 + s2];
+          const float y = base2f[(int64_t)(b * 3 + 1) * S2 + s2];
+          const float z = base2f[(int64_t)(b * 3 + 2) * S2 + s2];
+          bx[q] = fc_f2{x, x}, by[q] = fc_f2{y, y}, bz[q] = fc_f2{z, z};
+          tb[q] = Tf - fmaf(x, x, fmaf(y, y, z * z));  // +inf when Tf is: the atom is recounted
+          m[q] = 3.0e38f;                              // finite, so that `m >= +inf` is false
         }
         for (int ap = 0; ap < P1; ++ap) {
-          const fc_f2 X = SX[ap], Y = SY[ap], Z = SZ[ap];
+          const fc_f2 X = SX[ap], Y = SY[ap], Z = SZ[ap], Nn = SN[ap];
 #pragma unroll
           for (int q = 0; q < NB; ++q) {
-            const fc_f2 dx = fc_f2{bx[q], bx[q]} - X, dy = fc_f2{by[q], by[q]} - Y, dz = fc_f2{bz[q], bz[q]} - Z;
-            fc_f2 d = dx * dx;
-            d = __builtin_elementwise_fma(dy, dy, d);
-            d = __builtin_elementwise_fma(dz, dz, d);
-            m[q] = fminf(fminf(m[q], d.x), d.y);
+            fc_f2 v = __builtin_elementwise_fma(bz[q], Z, Nn);
+            v = __builtin_elementwise_fma(by[q], Y, v);
+            v = __builtin_elementwise_fma(bx[q], X, v);
+            m[q] = fminf(fminf(m[q], v.x), v.y);
           }
         }
         if (scanning) {
 #pragma unroll
           for (int q = NB - 1; q >= 0; --q)  // the FIRST suspicious atom at or behind `resume` wins
-            if (b0 + q < A2 && b0 + q >= resume && m[q] < t_hi) pending = b0 + q;
+            if (b0 + q < A2 && b0 + q >= resume && !(m[q] >= tb[q])) pending = b0 + q;
           if (pending < 0) resume = max(resume, min(b0 + NB, A2));
         }
       }
@@ -614,7 +631,7 @@ int launch_embed_pretransform(const double *coords_dev, int64_t n, int64_t A, in
 
 int launch_embed_grid_clash(const double *X1_dev, int64_t n1, int64_t A1, int64_t na1,
                             const double *X2s_dev, int64_t n2, int64_t A2, int64_t na2, int64_t S2,
-                            double thresh, int64_t max_clashes, unsigned long long *scratch_dev,
+                            double thresh, int64_t max_clashes, void *scratch, size_t scratch_bytes,
                             uint8_t *pass_dev, int32_t *counts_dev) {
   const int64_t g1 = n1 * 2 * na1;
   if (g1 == 0 || n2 * na2 == 0) return FC_OK;
@@ -630,18 +647,22 @@ int launch_embed_grid_clash(const double *X1_dev, int64_t n1, int64_t A1, int64_
                        n2, (int)A2, na2, S2, thr2, (int)max_clashes, (int)strips, pass_dev, counts_dev);
     return check_launch("k_embed_grid_clash_f64");
   }
-  // largest |coordinate| of both tables (X2s: the padding is zero) for the fp32 error bound
-  FC_HIP_TRY(hipMemsetAsync(scratch_dev, 0, sizeof(unsigned long long), ctx().stream));
+  // scratch: [largest |coordinate| of both tables | fp32 copy of the molecule-2 table]
   const int64_t len1 = g1 * A1 * 3, len2 = 2 * A2 * 3 * S2;
+  if (scratch_bytes < 256 + (size_t)len2 * sizeof(float)) return set_error(FC_E_INVALID, "pose grid scratch too small");
+  auto *scratch_dev = static_cast<unsigned long long *>(scratch);
+  float *X2f_dev = reinterpret_cast<float *>(static_cast<char *>(scratch) + 256);
+  FC_HIP_TRY(hipMemsetAsync(scratch_dev, 0, sizeof(unsigned long long), ctx().stream));
+  hipLaunchKernelGGL(k_to_f32, dim3((unsigned)ceil_div(len2, 256)), dim3(256), 0, ctx().stream, X2s_dev, len2, X2f_dev);
   hipLaunchKernelGGL(k_max_abs, dim3((unsigned)std::min<int64_t>(ceil_div(len1, 256), 1024)), dim3(256), 0,
                      ctx().stream, X1_dev, len1, scratch_dev);
   hipLaunchKernelGGL(k_max_abs, dim3((unsigned)std::min<int64_t>(ceil_div(len2, 256), 1024)), dim3(256), 0,
                      ctx().stream, X2s_dev, len2, scratch_dev);
   FC_TRY(check_launch("k_max_abs"));
-  const size_t lds = (size_t)A1 * 3 * sizeof(double) + (size_t)3 * ((A1 + 1) / 2) * sizeof(fc_f2);
+  const size_t lds = (size_t)A1 * 3 * sizeof(double) + (size_t)4 * ((A1 + 1) / 2) * sizeof(fc_f2);
   hipLaunchKernelGGL(k_embed_grid_clash, dim3((unsigned)g1, (unsigned)strips), dim3(256), lds, ctx().stream,
                      X1_dev, n1, (int)A1, na1, X2s_dev, n2, (int)A2, na2, S2, thr2, (int)max_clashes,
-                     (int)strips, scratch_dev, pass_dev, counts_dev);
+                     (int)strips, scratch_dev, X2f_dev, pass_dev, counts_dev);
   return check_launch("k_embed_grid_clash");
 }
 
