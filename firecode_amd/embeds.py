@@ -43,8 +43,8 @@ def embed_poses_clash(m1, m2, c1, c2, R1, t1, R2, t2, thresh=1.5, max_clashes=0,
            L.pi(c1), L.pi(c2), L.pf(R1), L.pf(t1), L.pf(R2), L.pf(t2), P, float(thresh), int(max_clashes),
            L.pi(counts), L.pb(ok), L.pf(poses))
     if return_poses:
-        return ok.astype(bool), counts, poses
-    return ok.astype(bool), counts
+        return ok.view(np.bool_), counts, poses
+    return ok.view(np.bool_), counts
 
 
 def _mol_args(coords, reactive, pivots):
@@ -91,8 +91,8 @@ def embed_grid_clash(m1, reactive1, pivots1, m2, reactive2, pivots2, angles1, an
            L.pf(a1), a1.shape[0], L.pf(a2), a2.shape[0], float(thresh), int(max_clashes), L.pb(ok),
            None if counts is None else counts.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms))
     if return_counts:
-        return ok.astype(bool), counts, ms.value
-    return ok.astype(bool), ms.value
+        return ok.view(np.bool_), counts, ms.value
+    return ok.view(np.bool_), ms.value
 
 
 def embed_grid_poses(m1, reactive1, pivots1, m2, reactive2, pivots2, angles1, angles2=None,
@@ -113,7 +113,7 @@ def embed_grid_poses(m1, reactive1, pivots1, m2, reactive2, pivots2, angles1, an
            L.pf(X2), X2.shape[0], X2.shape[1], L.pi(r2), r2.shape[0], L.pf(ps2), L.pf(pe2),
            L.pf(a1), a1.shape[0], L.pf(a2), a2.shape[0], float(thresh), int(max_clashes), float(rmsd_thr),
            L.pb(ok), L.pb(acc))
-    return acc.astype(bool), ok.astype(bool)
+    return acc.view(np.bool_), ok.view(np.bool_)
 
 
 def string_embed(m1, centers1, orbvecs1, m2, centers2, orbvecs2, angles, quadruplets,
@@ -139,12 +139,12 @@ def string_embed(m1, centers1, orbvecs1, m2, centers2, orbvecs2, angles, quadrup
     L.call("fc_string_embed", L.pf(X1), n1, X1.shape[1], L.pf(c1), L.pf(v1), K1, L.pf(X2), n2, X2.shape[1],
            L.pf(c2), L.pf(v2), K2, L.pf(ang), nA, L.pi(quads), quads.shape[0], float(thresh), int(max_clashes),
            float(tfd_thresh), L.pb(ok), L.pb(acc), L.pf(R2), L.pf(t2))
-    acc = acc.astype(bool)
+    acc = acc.view(np.bool_)
     sel = np.flatnonzero(acc)
     ci = sel // (K1 * K2 * nA)
     moved = rototranslate(X2[ci // n1], R2[sel], t2[sel]) if len(sel) else np.zeros((0, X2.shape[1], 3))
     poses = np.concatenate([X1[ci % n1], moved], axis=1)
-    return poses, acc, ok.astype(bool)
+    return poses, acc, ok.view(np.bool_)
 
 
 def _tri_mol(m):
