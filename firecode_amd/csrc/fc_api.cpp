@@ -470,6 +470,7 @@ static int ensemble_twin(fc_ensemble *ens, fc_ensemble **out) {
     if (!t) return set_error(FC_E_NOMEM, "host allocation failed");
     t->N = ens->N, t->A = ens->A, t->Npad = ens->Npad, t->W = ens->W;
     t->Xs.alias(ens->Xs), t->Xa.alias(ens->Xa), t->G.alias(ens->G);
+    if (ens->xsf_valid) t->Xsf.alias(ens->Xsf), t->xsf_valid = true;
     FC_TRY(t->counters.reserve(kCounters * sizeof(uint64_t)));
     ens->twin = t.release();
   }

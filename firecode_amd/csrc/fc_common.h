@@ -148,6 +148,8 @@ struct fc_ensemble {
   fc::DevBuf Xs;               // [(a*3+c)*Npad + n] doubles, zero padded
   fc::DevBuf Xa;               // [n][a][c] doubles: same (centred, selected) atoms, conformer-major
   fc::DevBuf G;                // [Npad] sum of squares per conformer
+  fc::DevBuf Xsf;              // fp32 copy of Xs for the single-precision screen (made on first use)
+  bool xsf_valid = false;
   // prune workspace (allocated on first use, kept for later calls)
   fc::DevBuf bits;             // rows_local * W uint64
   fc::DevBuf cand;             // rows_local * W uint32: queue of words to refine

@@ -786,6 +786,279 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// k_simbits_screen_mfma_f32 -- the same screen with the covariance on the fp32 matrix pipe
+// (v_mfma_f32_16x16x4_f32: twice the rate of the f64 instruction, half the LDS and L2 bytes)
+// and the polynomial in fp32 against proven bounds (kabsch_may_be_below_f32).  The screen only
+// has to be CONSERVATIVE -- every pair it lets through is decided by the exact fp64 refine --
+// so single precision costs candidates, never results: a pair is dropped only when P, P', P''
+// clear a bound on the fp32 error; pairs within ~0.03 A^2 of the threshold become candidates.
+// Same tiling, item table, staging queues and outputs as the f64 kernel above.  Differences:
+//   * operands come from Xsf, an fp32 copy of Xs (same layout);
+//   * one LDS-DMA instruction fills a whole [(s*3+c)] run of 256 floats: lane l carries 4
+//     consecutive columns of (k>>1 = l>>5, cs = (l>>3)&3, k&1 = (l>>2)&1);
+//   * D layout of the f32 instruction: lane (kq, l15), register r holds row 4*kq + r
+//     (the f64 one: row kq + 4*r).
+// ---------------------------------------------------------------------------
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2)
+k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restrict__ G, int64_t N,
+                          int64_t Npad, int A, double A_thr2, KabschF32Bounds bd, int IB, int64_t rank,
+                          int64_t world, uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
+                          unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
+                          unsigned long long Q, const uint64_t *__restrict__ item_table,
+                          unsigned long long n_items) {
+  extern __shared__ double lds_raw[];
+  float *__restrict__ lds = reinterpret_cast<float *>(lds_raw);
+  constexpr int TC = 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KS = (A + 3) >> 2;
+  double *__restrict__ ldsG = reinterpret_cast<double *>(lds + KS * 12 * TC);  // [TC column sums | IB row sums]
+  uint64_t *__restrict__ stageQ = reinterpret_cast<uint64_t *>(ldsG + TC + IB);
+  uint32_t *__restrict__ stageW = reinterpret_cast<uint32_t *>(stageQ + kStagePairs);
+  unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWords);  // [pairs, words]
+  const unsigned long long b = blockIdx.x;
+  if (b >= n_items) return;
+  int64_t jt, lb;
+  int it_first = 0, it_last = IB >> 4;
+  if (item_table != nullptr) {
+    const uint64_t it = item_table[b];
+    lb = (int64_t)((it >> 32) & 0x7fffffffull);
+    jt = (int64_t)(it & 0x7fffffffull);
+    if (it & (1ull << 31)) it_last = IB >> 5;
+    if (it & (1ull << 63)) it_first = IB >> 5;
+  } else {
+    const int64_t NT = Npad >> 6;
+    jt = (int64_t)(b % (unsigned long long)NT);
+    lb = (int64_t)(b / (unsigned long long)NT);
+  }
+  const int64_t j0 = jt * TC;
+  const int64_t i0 = global_block(lb, rank, world) * IB;
+  if (i0 >= N) return;               // block-uniform
+  if (j0 + TC - 1 <= i0) return;     // nothing above the diagonal in this item
+
+  {  // column tile by LDS-DMA: one 1-KiB instruction per (s, c) run
+    const int n_runs = KS * 3;
+    const int kh_l = lane >> 5, cs_l = (lane >> 3) & 3, k1_l = (lane >> 2) & 1, c4_l = (lane & 3) * 4;
+    for (int q = wv; q < n_runs; q += NW) {
+      const int sg = q / 3, c = q - sg * 3;
+      const int a = sg * 4 + kh_l * 2 + k1_l;
+      const float *src = Xsf + (int64_t)(a * 3 + c) * Npad + j0 + cs_l * 16 + c4_l;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(lds + q * 256), 16, 0, 0);
+    }
+    for (int idx = tid; idx < TC + IB; idx += NW * 64) {
+      const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
+      ldsG[idx] = g < Npad ? G[g] : 0.0;
+    }
+    if (tid < kStagePairs) stageQ[tid] = ~0ull;
+    if (tid < kStageWords) stageW[tid] = ~0u;
+    if (tid < 2) stageN[tid] = 0u;
+    __syncthreads();
+  }
+  const int kq = lane >> 4, l15 = lane & 15;
+  const int boff = (kq >> 1) * (2 * TC) + (kq & 1) * 16 + l15;
+  uint16_t *bits16 = reinterpret_cast<uint16_t *>(bits);
+
+  float a0[3], a1[3], a2[3];
+  int pre_it = -1;
+  auto row_offsets = [&](int it_, unsigned (&vo)[3]) {
+    const int64_t ib_ = i0 + (int64_t)it_ * 16;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vo[c] = (unsigned)((int64_t)(kq * 3 + c) * Npad + ib_ + l15);
+  };
+  auto fetch_a_at = [&](float (&a)[3], const unsigned (&vo)[3], int sx) {
+    const int sl = sx < KS ? sx : KS - 1;  // fewer than 3 k-steps: harmless re-read
+    const float *__restrict__ xs_s = Xsf + (int64_t)sl * 12 * Npad;  // wave-uniform base
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[c] = xs_s[vo[c]];
+  };
+
+  for (int it = it_first + wv; it < it_last; it += NW) {
+    const int64_t ib = i0 + (int64_t)it * 16;
+    if (ib >= N) break;
+    if (j0 + TC - 1 <= ib) break;
+    const int64_t lrow0 = lb * IB + (int64_t)it * 16;
+    unsigned nz0 = 0, nz1 = 0, nz2 = 0, nz3 = 0;
+    unsigned voff[3];
+    row_offsets(it, voff);
+
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      const int cs0 = half * 2;
+      if (j0 + (cs0 + 2) * 16 - 1 <= ib) {  // both sub-tiles at or below the diagonal
+        if (lane < 4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t row = ib + lane + 4 * r;
+            if (row < N) {
+              bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs0] = 0;
+              bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs0 + 1] = 0;
+            }
+          }
+        }
+        continue;
+      }
+      f4_t acc[2][9];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc[t][e] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+      const float *__restrict__ lb0 = lds + cs0 * 32 + boff;
+      float b0[2][3], b1[2][3];
+      const int KSe = KS;
+      auto fetch_a = [&](float (&a)[3], int sx) { fetch_a_at(a, voff, sx); };
+      auto fetch_b = [&](float (&b)[2][3], int sx) {
+        const int sl = sx < KS ? sx : KS - 1;
+        const float *__restrict__ lb_s = lb0 + sl * (12 * TC);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) b[t][c] = lb_s[c * (4 * TC) + t * 32];
+      };
+      auto mma = [&](const float (&a)[3], const float (&b)[2][3]) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+          for (int y = 0; y < 3; ++y)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              acc[t][x * 3 + y] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[t][y], acc[t][x * 3 + y], 0, 0, 0);
+      };
+      if (pre_it != it) {  // first unit of the wave, or the prediction below missed
+        fetch_a_at(a0, voff, 0);
+        fetch_a_at(a1, voff, 1);
+        fetch_a_at(a2, voff, 2);
+      }
+      fetch_b(b0, 0);
+      fetch_b(b1, 1);
+#define FC_KSTEP(AX, BX, U)             \
+  if (sgrp + (U) < KSe) {               \
+    mma(AX, BX);                        \
+    fetch_a(AX, sgrp + (U) + 3);        \
+    fetch_b(BX, sgrp + (U) + 2);        \
+  }
+      for (int sgrp = 0; sgrp < KSe; sgrp += 6) {
+        FC_KSTEP(a0, b0, 0)
+        FC_KSTEP(a1, b1, 1)
+        FC_KSTEP(a2, b0, 2)
+        FC_KSTEP(a0, b1, 3)
+        FC_KSTEP(a1, b0, 4)
+        FC_KSTEP(a2, b1, 5)
+      }
+#undef FC_KSTEP
+      {  // request the next unit's first three k-steps now; they land during the epilogue
+        const int nit = half == 0 ? it : it + NW;
+        const bool more = half == 0 || ((nit < it_last) && (i0 + (int64_t)nit * 16 < N) &&
+                                        !(j0 + TC - 1 <= i0 + (int64_t)nit * 16));
+        if (more) {
+          unsigned vn[3];
+          row_offsets(nit, vn);
+          fetch_a_at(a0, vn, 0);
+          fetch_a_at(a1, vn, 1);
+          fetch_a_at(a2, vn, 2);
+          pre_it = nit;
+        } else {
+          pre_it = -1;
+        }
+      }
+      // epilogue: lane owns pairs (ib + 4 kq + r, j0 + cs*16 + l15), r = 0..3
+      const int n32 = (int)N, ib32 = (int)ib;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int cs = cs0 + t;
+        const int j = (int)j0 + cs * 16 + l15;
+        const double Gq = ldsG[cs * 16 + l15];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ib32 + 4 * kq + r;
+          const double Gp = ldsG[TC + it * 16 + 4 * kq + r];
+          float B9[9];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
+          bool may = kabsch_may_be_below_f32(B9, Gp + Gq, A_thr2, bd);
+          may = may && (j > i) && (j < n32) && (i < n32);
+          const uint64_t m = __ballot(may);
+          stage_pairs(m, may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+          if (lane < 4) {  // lane stands for kq: 16-bit piece of row 4*lane + r
+            const unsigned piece = (unsigned)((m >> (16 * lane)) & 0xffffull);
+            if (ib32 + 4 * lane + r < n32) {
+              bits16[((lrow0 + 4 * lane + r) * W + jt) * 4 + cs] = (uint16_t)piece;
+              if (r == 0) nz0 |= piece;
+              if (r == 1) nz1 |= piece;
+              if (r == 2) nz2 |= piece;
+              if (r == 3) nz3 |= piece;
+            }
+          }
+        }
+      }
+    }
+    {  // queue the non-empty words of this row tile for the exact refine
+      const unsigned nz[4] = {nz0, nz1, nz2, nz3};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool has = lane < 4 && nz[r] != 0;
+        const uint64_t mw = __ballot(has);
+        if (mw == 0) continue;  // wave-uniform
+        const unsigned n = (unsigned)__popcll(mw);
+        const uint32_t word = (uint32_t)((lrow0 + 4 * lane + r) * W + jt);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(stageN + 1, n);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        const unsigned rank_in = (unsigned)__popcll(mw & ((1ull << lane) - 1ull));
+        if (base + n <= (unsigned)kStageWords) {
+          if (has) stageW[base + rank_in] = word;
+        } else {  // no room: straight to the global queue
+          unsigned long long gbase = 0;
+          if (lane == 0) gbase = atomicAdd(&counters[4], (unsigned long long)n);
+          gbase = __shfl(gbase, 0);
+          if (has) cand[gbase + rank_in] = word;
+        }
+      }
+    }
+  }
+  // publish what the workgroup staged: one global atomic per queue
+  __syncthreads();
+  if (wv == 0) {
+    {
+      const uint64_t e = lane < kStagePairs ? stageQ[lane] : ~0ull;
+      const bool valid = e != ~0ull;
+      const uint64_t mv = __ballot(valid);
+      if (mv != 0) {
+        unsigned long long gbase = 0;
+        if (lane == 0) gbase = atomicAdd(&counters[6], (unsigned long long)__popcll(mv));
+        gbase = __shfl(gbase, 0);
+        if (valid) {
+          const unsigned long long slot = gbase + (unsigned long long)__popcll(mv & ((1ull << lane) - 1ull));
+          if (slot < Q) pairq[slot] = e;
+        }
+      }
+    }
+    {
+      const uint32_t wq = lane < kStageWords ? stageW[lane] : ~0u;
+      const bool valid = wq != ~0u;
+      const uint64_t mv = __ballot(valid);
+      if (mv != 0) {
+        unsigned long long gbase = 0;
+        if (lane == 0) gbase = atomicAdd(&counters[4], (unsigned long long)__popcll(mv));
+        gbase = __shfl(gbase, 0);
+        if (valid) cand[gbase + (unsigned long long)__popcll(mv & ((1ull << lane) - 1ull))] = wq;
+      }
+    }
+  }
+}
+
+__global__ void k_f64_to_f32(const double *__restrict__ x, int64_t n, float *__restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (float)x[i];
+}
+
+// ---------------------------------------------------------------------------
 // k_screen_rowsweep -- the same screen, other schedule.  MEASURED SLOWER, kept as evidence
 // (FC_SCREEN_V2=1): 1.05 ms with the phase barriers, 1.00 ms without them (-DFC_V2_ALIGN=0), against
 // 0.96 ms for the kernel above at 10^4 conformers (3.80 / 3.64 / 3.43 ms at 2*10^4).
@@ -1447,6 +1720,7 @@ int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_
   hipLaunchKernelGGL(k_prep, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, coords_dev, N,
                      A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
                      e->Xa.as<double>());
+  e->xsf_valid = false;
   return check_launch("k_prep");
 }
 
@@ -1543,6 +1817,32 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
                              (unsigned long long)e->item_total);
           return check_launch("k_screen_rowsweep");
         }
+      }
+      // Default: the single-precision screen (fp32 MFMA + bounded fp32 polynomial; candidates are
+      // decided by the exact fp64 refine either way).  FC_SCREEN_F32=0, a timeline build's probe,
+      // or so many atoms that the proven bounds stop being small select the fp64 screen below.
+      const char *f32_env = getenv("FC_SCREEN_F32");
+      const int64_t A4 = (e->A + 3) / 4 * 4;
+      const KabschF32Bounds bd = kabsch_f32_bounds(A4);
+      if (!(f32_env && f32_env[0] == '0') && dbg == nullptr && bd.p0 < 2.0e-3f && e->row_block % 64 == 0) {
+        const size_t lds_f = (size_t)A4 * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(double) + kStageBytes;
+        if (!e->xsf_valid) {
+          const int64_t n = A4 * 3 * e->Npad;
+          FC_TRY(e->Xsf.reserve((size_t)n * sizeof(float)));
+          hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream,
+                             e->Xs.as<double>(), n, e->Xsf.as<float>());
+          FC_TRY(check_launch("k_f64_to_f32"));
+          e->xsf_valid = true;
+        }
+        if (lds_f > 64 * 1024)
+          FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_simbits_screen_mfma_f32<4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+        hipLaunchKernelGGL(k_simbits_screen_mfma_f32<4>, mgrid, dim3(256), lds_f, ctx().stream,
+                           e->Xsf.as<float>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2, bd,
+                           (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
+                           e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
+                           (unsigned long long)e->pairq_cap, item_table_dev, n_items);
+        return check_launch("k_simbits_screen_mfma_f32");
       }
       if (two_blocks)
         hipLaunchKernelGGL(k_simbits_screen_mfma<4>, mgrid, dim3(256), lds_m, ctx().stream,
