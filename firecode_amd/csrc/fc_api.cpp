@@ -188,7 +188,6 @@ void pool_trim() {
   for (auto &b : blocks) (void)hipFree(b.second);
 }
 
-static const size_t kCounters = 64;  // uint64 words of fc_ensemble::counters
 
 static int do_init(int device) {
   Context &c = ctx();
@@ -471,6 +470,7 @@ static int ensemble_twin(fc_ensemble *ens, fc_ensemble **out) {
     t->N = ens->N, t->A = ens->A, t->Npad = ens->Npad, t->W = ens->W;
     t->Xs.alias(ens->Xs), t->Xa.alias(ens->Xa), t->G.alias(ens->G);
     if (ens->xsf_valid) t->Xsf.alias(ens->Xsf), t->xsf_valid = true;
+    t->g_max = ens->g_max;
     FC_TRY(t->counters.reserve(kCounters * sizeof(uint64_t)));
     ens->twin = t.release();
   }

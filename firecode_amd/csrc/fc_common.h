@@ -127,6 +127,10 @@ inline int check_launch(const char *what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// uint64 words of fc_ensemble::counters: [0..10] queue lengths and flags, [16..) bucket fill
+// levels of the pair ladder, [63] scratch of the screen launcher
+constexpr size_t kCounters = 64;
+
 // Row blocks of the bit matrix are dealt to ranks in snake order (0..W-1,
 // W-1..0, 0..W-1, ...): the work of a row block falls linearly with its index,
 // so pairs of consecutive cycles carry equal work on every rank.
@@ -150,6 +154,7 @@ struct fc_ensemble {
   fc::DevBuf G;                // [Npad] sum of squares per conformer
   fc::DevBuf Xsf;              // fp32 copy of Xs for the single-precision screen (made on first use)
   bool xsf_valid = false;
+  double g_max = -1.0;         // largest G (host copy, found on first use): sizes the fp32 screen's band
   // prune workspace (allocated on first use, kept for later calls)
   fc::DevBuf bits;             // rows_local * W uint64
   fc::DevBuf cand;             // rows_local * W uint32: queue of words to refine

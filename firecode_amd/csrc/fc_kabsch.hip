@@ -1053,6 +1053,20 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
   }
 }
 
+// largest element of a non-negative array (bit patterns of non-negative doubles order like integers)
+__global__ void k_max_nonneg(const double *__restrict__ x, int64_t n, unsigned long long *__restrict__ out) {
+  double m = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = x[i];
+    if (v > m) m = v;  // false for NaN
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(m, off);
+    if (o > m) m = o;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
 __global__ void k_f64_to_f32(const double *__restrict__ x, int64_t n, float *__restrict__ y) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = (float)x[i];
@@ -1721,6 +1735,7 @@ int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_
                      A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
                      e->Xa.as<double>());
   e->xsf_valid = false;
+  e->g_max = -1.0;
   return check_launch("k_prep");
 }
 
@@ -1824,7 +1839,29 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
       const char *f32_env = getenv("FC_SCREEN_F32");
       const int64_t A4 = (e->A + 3) / 4 * 4;
       const KabschF32Bounds bd = kabsch_f32_bounds(A4);
-      if (!(f32_env && f32_env[0] == '0') && dbg == nullptr && bd.p0 < 2.0e-3f && e->row_block % 64 == 0) {
+      bool use_f32 = !(f32_env && f32_env[0] == '0') && dbg == nullptr && bd.p0 < 2.0e-3f && e->row_block % 64 == 0;
+      if (use_f32 && !(f32_env && f32_env[0] == '2')) {  // FC_SCREEN_F32=2: no matter how wide the band
+        // Band of mean square deviations above the threshold that the bounded fp32 test cannot
+        // rule out: the factor (L - lambda_max)/s = A (msd - thr2) / (2 s) of P has to clear
+        // p0 / (product of the other three factors, ~0.4 and more for real structures).  Large
+        // structures with a tight threshold make it wide -- many candidates for the exact
+        // refine -- so the fp64 screen takes those (a matter of speed only, not of results).
+        if (e->g_max < 0.0) {
+          auto *cnt_max = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
+          FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
+          hipLaunchKernelGGL(k_max_nonneg, dim3((unsigned)std::min<int64_t>(ceil_div(e->Npad, 256), 256)), dim3(256), 0,
+                             ctx().stream, e->G.as<double>(), e->Npad, cnt_max);
+          FC_TRY(check_launch("k_max_nonneg"));
+          unsigned long long bits_max = 0;
+          FC_TRY(d2h(&bits_max, cnt_max, sizeof bits_max));
+          FC_TRY(sync());
+          FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
+          std::memcpy(&e->g_max, &bits_max, sizeof(double));
+        }
+        const double band = (double)bd.p0 * 2.7 * e->g_max / (double)e->A;
+        use_f32 = band <= 0.5 * thr2_margin;
+      }
+      if (use_f32) {
         const size_t lds_f = (size_t)A4 * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(double) + kStageBytes;
         if (!e->xsf_valid) {
           const int64_t n = A4 * 3 * e->Npad;

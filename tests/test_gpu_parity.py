@@ -166,6 +166,62 @@ def test_simbits_match_oracle_matrix(fc):
     assert grey == 0
 
 
+@pytest.mark.parametrize("n,a,seed,thr", [(500, 50, 31, 0.5), (400, 13, 32, 0.35), (300, 90, 33, 0.25), (257, 30, 34, 1.2)])
+def test_fp32_screen_and_fp64_screen_give_the_same_similarity_bits(fc, monkeypatch, n, a, seed, thr):
+    """the single-precision screen (fp32 MFMA + bounded polynomial) may only ADD candidates for
+    the exact refine: similarity bits, grey count and the pruned mask are those of the fp64 screen
+    and of the oracle matrix.  Thresholds are also put exactly on, one ulp below and one ulp above
+    the RMSD of real pairs (the band the fp32 test cannot decide), with the band check switched
+    off (FC_SCREEN_F32=2) so that the fp32 kernel runs whatever the geometry"""
+    from firecode_amd._lib import unpack_bits
+
+    X, atoms, _ = syn.synthetic_ensemble(n, a, seed=seed)
+    S0, R0, D0 = o.rmsd_similarity_matrix(X, atoms, thr)
+    near = np.sort(R0[np.triu_indices(n, 1)])
+    k = int(np.searchsorted(near, thr))
+    picks = [thr] + [float(v) for v in near[max(k - 2, 0): k + 2]]
+    picks += [float(np.nextafter(picks[1], 0.0)), float(np.nextafter(picks[1], 9.0))]
+    for t in picks:
+        ref = np.triu((R0 < t) & (D0 < 2 * t), 1)
+        got = {}
+        for mode in ("0", "2"):
+            monkeypatch.setenv("FC_SCREEN_F32", mode)
+            with fc.DeviceEnsemble(X, center=True) as ens:
+                bits, grey = ens.simbits(t, 2 * t)
+                mask, stats = ens.prune(t, 2 * t)
+            got[mode] = (unpack_bits(bits, n), grey, mask, int(stats[2]))
+        assert np.array_equal(got["0"][0], got["2"][0]) and got["0"][1] == got["2"][1]
+        assert np.array_equal(got["0"][2], got["2"][2]) and got["0"][3] == got["2"][3]
+        if t == thr:  # off-threshold by construction: the oracle's own arithmetic agrees as well
+            assert np.abs(near - thr).min() > 1e-7
+            assert np.array_equal(got["2"][0], ref)
+            assert np.array_equal(got["2"][2], o.greedy_prune_from_matrix(ref | ref.T))
+    monkeypatch.delenv("FC_SCREEN_F32")
+
+
+def test_fp32_screen_far_from_the_origin(fc, monkeypatch):
+    """uncentred structures 40 A from the origin (G large against A * thr^2): the fp32 test can
+    rule out next to nothing, every pair becomes a candidate, the result must not change; by
+    default the launcher sees the wide band and takes the fp64 screen"""
+    rng = np.random.default_rng(41)
+    bases = rng.normal(scale=2.5, size=(40, 1, 20, 3))  # 40 shapes x 8 noisy copies, no rotation between copies
+    X = (bases + rng.normal(scale=0.05, size=(40, 8, 20, 3))).reshape(320, 20, 3) + np.array([40.0, -25.0, 10.0])
+    from firecode_amd._lib import unpack_bits
+
+    out = {}
+    for mode in ("0", "2", None):
+        if mode is None:
+            monkeypatch.delenv("FC_SCREEN_F32")
+        else:
+            monkeypatch.setenv("FC_SCREEN_F32", mode)
+        with fc.DeviceEnsemble(X, center=False) as ens:
+            bits, grey = ens.simbits(0.5, 1.0)
+            out[mode] = (unpack_bits(bits, len(X)), grey)
+    assert np.array_equal(out["0"][0], out["2"][0]) and np.array_equal(out["0"][0], out[None][0])
+    assert out["0"][1] == out["2"][1] == out[None][1]
+    assert out["0"][0].any()
+
+
 def test_refine_word_queue_fallback(fc, monkeypatch):
     """pair queue too small -> the refine kernel must fall back to the word
     queue (sparse words: wave per pair; dense words: lane per pair)"""

@@ -5,7 +5,16 @@
 // Build: hipcc -O3 --offload-arch=gfx950 tools/ubench_coexec.hip -o tools/ubench_coexec
 #include <hip/hip_runtime.h>
 #include <cstdio>
+// -DFC_UB_F32: the MFMA stream is v_mfma_f32_16x16x4_f32 instead (binary tools/ubench_coexec_f32)
+#ifdef FC_UB_F32
+typedef float double4_t __attribute__((ext_vector_type(4)));
+#define FC_UB_MFMA __builtin_amdgcn_mfma_f32_16x16x4f32
+typedef float ub_t;
+#else
 typedef double double4_t __attribute__((ext_vector_type(4)));
+#define FC_UB_MFMA __builtin_amdgcn_mfma_f64_16x16x4f64
+typedef double ub_t;
+#endif
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 template <int MODE>
@@ -13,14 +22,14 @@ __global__ void __launch_bounds__(512) k_mix(double *out, int iters, int compani
   const int wv = threadIdx.x >> 6;
   if (wv < 4) {  // waves 0-3: one per SIMD; waves 4-7 are their companions on the same SIMDs
     double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0;
-    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-6;
+    ub_t a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-6;
     for (int i = 0; i < iters; ++i) {
-      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
-      c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
-      c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
-      c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
-      c5 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c5, 0, 0, 0);
+      c0 = FC_UB_MFMA(a, b, c0, 0, 0, 0);
+      c1 = FC_UB_MFMA(a, b, c1, 0, 0, 0);
+      c2 = FC_UB_MFMA(a, b, c2, 0, 0, 0);
+      c3 = FC_UB_MFMA(a, b, c3, 0, 0, 0);
+      c4 = FC_UB_MFMA(a, b, c4, 0, 0, 0);
+      c5 = FC_UB_MFMA(a, b, c5, 0, 0, 0);
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + c4[0] + c5[1];
   } else {
