@@ -132,6 +132,7 @@ def main():
         args.gpus = world
 
     import firecode_amd as fc
+    from firecode_amd import _lib
     from firecode_amd import dist as fdist
     from firecode_amd import synthetic as syn
 
@@ -304,29 +305,35 @@ def main():
             # dominant kernel: k_simbits_screen, HIP events on the library's stream
             owned_pairs = pairs_total if not sharded else owned_pairs_rank0  # pairs of the timed launch
             achieved = owned_pairs * bytes_per_alignment / (t_kernel_ms * 1e-3) / 1e9
-            # fabric-side bytes per launch of the same kernel on the same workload, from the
-            # committed PMC passes (rocprofv3 cannot run inside this process)
+            # The bound that binds: the screen kernel runs its contraction on the matrix pipe
+            # (DESIGN.md section 5).  achieved = executed MFMA flops per launch (9 covariance
+            # entries x K = atoms padded to 4, per pair) / HIP-event kernel time.  Default screen:
+            # fp32 MFMA + fp32 polynomial against proven bounds, every pair it lets through is
+            # decided by the exact fp64 refine (peak 157.3 TFLOP/s dense fp32, f32-input MFMA);
+            # FC_SCREEN_F32=0: the fp64 screen (peak 78.6 TFLOP/s dense fp64).
+            kind = _lib.screen_last_kind()
+            f32 = kind == 32
+            peak = 157.3 if f32 else 78.6
+            kname = "k_simbits_screen_mfma_f32" if f32 else "k_simbits_screen_mfma"
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_screen_f32.json" if f32 else "r01_pmc_screen_final.json")
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_screen_final.json")
             if world == 1 and n_conf == N_CONF and os.path.exists(pmc):
                 traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-                traffic_src = "profiles/r01_pmc_screen_final.json"
-            # The bound that binds: the screen kernel runs its contraction on the fp64 matrix
-            # pipe.  achieved = executed MFMA flops per launch
-            # (9 covariance entries x K = atoms padded to 4, per pair) / HIP-event kernel time;
-            # peak = 78.6 TFLOP/s dense fp64 (tools/ubench_f64.hip measures 77.7).
+                traffic_src = os.path.relpath(pmc, ROOT)
             a4 = (N_ATOMS + 3) // 4 * 4
             flops_per_alignment = 2 * 9 * a4
             tflops = owned_pairs * flops_per_alignment / (t_kernel_ms * 1e-3) / 1e12
             out["roofline"] = {
-                "bound": "mfma", "kernel": "k_simbits_screen_mfma", "achieved": tflops, "peak": 78.6,
-                "unit": "TFLOP/s", "frac": tflops / 78.6, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel_ms": t_kernel_ms, "flops_per_alignment": flops_per_alignment, "dtype": "f64",
+                "bound": "mfma", "kernel": kname, "achieved": tflops, "peak": peak,
+                "unit": "TFLOP/s", "frac": tflops / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel_ms": t_kernel_ms, "flops_per_alignment": flops_per_alignment,
+                "dtype": "f32" if f32 else "f64",
             }
+            out["dtype"] = "f32 screen + f64 exact refine" if f32 else "f64"
             # the north star's view: algorithmic bytes (two conformers in, rmsd + maxdev out)
             # against the 8 TB/s HBM roof; > 1 because a staged tile serves 64-256 partners
             out["roofline_hbm"] = {
-                "bound": "hbm", "kernel": "k_simbits_screen_mfma", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_alignment": bytes_per_alignment,
                 "compulsory_bytes": n_conf * N_ATOMS * 24 + n_conf * ((n_conf + 63) // 64) * 8,

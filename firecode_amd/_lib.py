@@ -115,6 +115,7 @@ _SIGNATURES = {
     "fc_stream_use": [C.c_void_p],
     "fc_ensemble_twin": [_ens, C.POINTER(_ens)],
     "fc_prune_rmsd_begin_split_async": [_ens, _f64, _f64, _i64, _i64, _i64, C.c_void_p],
+    "fc_screen_last_kind": [],
     "fc_prune_rmsd_many": [C.POINTER(_ens), _i64, _f64, _f64, _i64, C.POINTER(_p_u8), _p_i64],
 }
 
@@ -238,6 +239,11 @@ def stream_set(hip_stream):
 def stream_use(hip_stream):
     """``stream_set`` without draining the previous stream (the caller orders streams with events)."""
     call("fc_stream_use", C.c_void_p(int(hip_stream) if hip_stream else None))
+
+
+def screen_last_kind():
+    """32 / 64 / 1: arithmetic of the all-pairs screen the last prune launched (fc_screen_last_kind)."""
+    return int(load().fc_screen_last_kind())
 
 
 def memory_trim():

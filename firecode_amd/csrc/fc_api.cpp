@@ -74,6 +74,7 @@ int launch_embed_mol_transforms(const double *, int64_t, int64_t, const int64_t 
                                 const double *, int, const double *, int64_t, double *, double *);
 int launch_embed_pretransform(const double *, int64_t, int64_t, int64_t, const double *,
                               const double *, int, int64_t, double *);
+int last_screen_kind();
 int launch_embed_grid_clash(const double *, int64_t, int64_t, int64_t, const double *, int64_t, int64_t,
                             int64_t, int64_t, double, int64_t, void *, size_t, uint8_t *, int32_t *);
 int launch_string_transforms(const double *, const double *, int64_t, int64_t, const double *, const double *,
@@ -1871,6 +1872,8 @@ int fc_prune_rmsd_many(fc_ensemble *const *ens, int64_t n, double max_rmsd, doub
 }
 
 // ---- bench hook ----------------------------------------------------------------------
+int fc_screen_last_kind(void) { return last_screen_kind(); }
+
 int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
                         double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
                         int64_t *stats) {

@@ -801,8 +801,11 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 // ---------------------------------------------------------------------------
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
+#ifndef FC_F32_WGS
+#define FC_F32_WGS 2
+#endif
 template <int NW>
-__global__ void __launch_bounds__(NW * 64, 2)
+__global__ void __launch_bounds__(NW * 64, FC_F32_WGS)
 k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restrict__ G, int64_t N,
                           int64_t Npad, int A, double A_thr2, KabschF32Bounds bd, int IB, int64_t rank,
                           int64_t world, uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
@@ -816,7 +819,8 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int KS = (A + 3) >> 2;
-  double *__restrict__ ldsG = reinterpret_cast<double *>(lds + KS * 12 * TC);  // [TC column sums | IB row sums]
+  const float half_A_thr2 = (float)(0.5 * A_thr2);
+  float *__restrict__ ldsG = lds + KS * 12 * TC;  // G/2 as fp32: [TC columns | IB rows]
   uint64_t *__restrict__ stageQ = reinterpret_cast<uint64_t *>(ldsG + TC + IB);
   uint32_t *__restrict__ stageW = reinterpret_cast<uint32_t *>(stageQ + kStagePairs);
   unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWords);  // [pairs, words]
@@ -852,7 +856,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
     }
     for (int idx = tid; idx < TC + IB; idx += NW * 64) {
       const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
-      ldsG[idx] = g < Npad ? G[g] : 0.0;
+      ldsG[idx] = g < Npad ? (float)(0.5 * G[g]) : 0.f;
     }
     if (tid < kStagePairs) stageQ[tid] = ~0ull;
     if (tid < kStageWords) stageW[tid] = ~0u;
@@ -973,15 +977,15 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
       for (int t = 0; t < 2; ++t) {
         const int cs = cs0 + t;
         const int j = (int)j0 + cs * 16 + l15;
-        const double Gq = ldsG[cs * 16 + l15];
+        const float Gq = ldsG[cs * 16 + l15];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = ib32 + 4 * kq + r;
-          const double Gp = ldsG[TC + it * 16 + 4 * kq + r];
+          const float Gp = ldsG[TC + it * 16 + 4 * kq + r];
           float B9[9];
 #pragma unroll
           for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
-          bool may = kabsch_may_be_below_f32(B9, Gp + Gq, A_thr2, bd);
+          bool may = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd);
           may = may && (j > i) && (j < n32) && (i < n32);
           const uint64_t m = __ballot(may);
           stage_pairs(m, may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
@@ -1757,6 +1761,10 @@ int launch_matrix_exact(const fc_ensemble *e, double *rmsd_dev, double *maxdev_d
 }
 
 
+// which screen the last launch_simbits_screen used: 32 (fp32 MFMA), 64 (fp64 MFMA), 1 (VALU), 0 (none yet)
+static int g_last_screen = 0;
+int last_screen_kind() { return g_last_screen; }
+
 int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   const int64_t NT = e->Npad >> 6;
   const int64_t n_gblocks = ceil_div(e->N, e->row_block);
@@ -1862,7 +1870,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         use_f32 = band <= 0.5 * thr2_margin;
       }
       if (use_f32) {
-        const size_t lds_f = (size_t)A4 * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(double) + kStageBytes;
+        const size_t lds_f = (size_t)A4 * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytes;
         if (!e->xsf_valid) {
           const int64_t n = A4 * 3 * e->Npad;
           FC_TRY(e->Xsf.reserve((size_t)n * sizeof(float)));
@@ -1879,6 +1887,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
                            (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                            e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
                            (unsigned long long)e->pairq_cap, item_table_dev, n_items);
+        g_last_screen = 32;
         return check_launch("k_simbits_screen_mfma_f32");
       }
       if (two_blocks)
@@ -1893,6 +1902,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
                            (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                            e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
                            (unsigned long long)e->pairq_cap, item_table_dev, n_items, dbg);
+      g_last_screen = 64;
       FC_TRY(check_launch("k_simbits_screen_mfma"));
 #ifdef FC_TIMELINE
       if (timeline) {
@@ -1932,6 +1942,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
     else FC_LAUNCH_SCREEN(false, 8, 4, 0);
   }
 #undef FC_LAUNCH_SCREEN
+  g_last_screen = 1;
   return check_launch("k_simbits_screen");
 }
 

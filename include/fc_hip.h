@@ -394,6 +394,11 @@ int fc_prune_rmsd_many(fc_ensemble *const *ens, int64_t n, double max_rmsd, doub
  * Runs the all-pairs similarity stage + greedy replay `reps` times on the
  * resident ensemble and returns HIP-event times (ms, per rep) of the
  * dominant kernel and of the whole step measured on the library's stream. */
+/* Arithmetic of the all-pairs screen the last prune launched: 32 = fp32 matrix pipe + bounded fp32
+ * polynomial (default where its undecidable band is narrow), 64 = fp64 matrix pipe (FC_SCREEN_F32=0,
+ * large structures with tight thresholds), 1 = VALU kernel, 0 = none yet.  Results do not depend on
+ * it: every pair a screen lets through is decided by the exact fp64 refine. */
+int fc_screen_last_kind(void);
 int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
                         double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
                         int64_t *stats);
