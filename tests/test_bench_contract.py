@@ -32,7 +32,10 @@ def test_bench_prints_one_contract_line(sharded):
         assert k in d, k
     assert d["metric"] == "conformer-pair RMSD alignments/s" and d["unit"] == "alignments/s"
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    # the arithmetic of the dominant kernel decides the label; the decisions themselves are fp64 either way
+    assert (d["dtype"], d["roofline"]["dtype"], d["roofline"]["peak"]) in (
+        ("f32 screen + f64 exact refine", "f32", 157.3), ("f64", "f64", 78.6))
     assert "workload" in d["config"] and d["mask_ok"] is True
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
