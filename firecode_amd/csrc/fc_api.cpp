@@ -341,8 +341,10 @@ static int simbits_local(fc_ensemble *e, double max_rmsd, double max_dev, const 
     FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, kCounters * sizeof(uint64_t), ctx().stream));
   // HIP events bracket the screen kernel (the dominant one) on the library's stream
   FC_HIP_TRY(hipEventRecord(ctx().ev2, ctx().stream));
-  FC_TRY(launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin));
-  FC_HIP_TRY(hipEventRecord(ctx().ev3, ctx().stream));
+  ctx().mark_after_screen = ctx().ev3;  // recorded by the launcher right behind the screen kernel
+  const int rc_screen = launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin);
+  ctx().mark_after_screen = nullptr;
+  FC_TRY(rc_screen);
   FC_TRY(launch_simbits_refine(e, max_rmsd, max_dev, en_dev, max_dE));
   e->bits_valid = true;
   return FC_OK;
@@ -894,8 +896,9 @@ int fc_prune_rmsd_begin_split_async(fc_ensemble *ens, double max_rmsd, double ma
   FC_TRY(ensemble_shard(ens, rank, world, row_block));
   if (ens->N == 0) return FC_OK;
   Context &c = ctx();
-  static hipEvent_t ev_reset = nullptr;
+  static hipEvent_t ev_reset = nullptr, ev_screened = nullptr;
   if (!ev_reset) FC_HIP_TRY(hipEventCreateWithFlags(&ev_reset, hipEventDisableTiming));
+  if (!ev_screened) FC_HIP_TRY(hipEventCreateWithFlags(&ev_screened, hipEventDisableTiming));
   hipStream_t const tail = c.stream, scr = static_cast<hipStream_t>(screen_stream);
   struct Restore {
     Context &c;
@@ -909,9 +912,12 @@ int fc_prune_rmsd_begin_split_async(fc_ensemble *ens, double max_rmsd, double ma
   FC_HIP_TRY(hipStreamWaitEvent(scr, ev_reset, 0));
   c.stream = scr;
   FC_HIP_TRY(hipEventRecord(c.ev2, scr));
-  FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
-  FC_HIP_TRY(hipEventRecord(c.ev3, scr));
-  FC_HIP_TRY(hipStreamWaitEvent(tail, c.ev3, 0));
+  c.mark_after_screen = c.ev3;
+  const int rc_screen = launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin);
+  c.mark_after_screen = nullptr;
+  FC_TRY(rc_screen);
+  FC_HIP_TRY(hipEventRecord(ev_screened, scr));  // behind the verdict and the gated fp64 screen, too
+  FC_HIP_TRY(hipStreamWaitEvent(tail, ev_screened, 0));
   c.stream = tail;
   FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
   ens->bits_valid = true;
@@ -1749,13 +1755,13 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
                           int64_t min_per_group, bool overlap, int64_t stride, double *screen_ms_sum,
                           double *total_ms) {
   Context &c = ctx();
-  static std::vector<hipEvent_t> ev;  // 3 per prune: around the screen kernel, counters reset
-  while ((int64_t)ev.size() < 3 * n + 4) {
+  static std::vector<hipEvent_t> ev;  // 4 per prune: around the screen kernel, counters reset, screen phase done
+  while ((int64_t)ev.size() < 4 * n + 4) {
     hipEvent_t e = nullptr;
     FC_HIP_TRY(hipEventCreate(&e));
     ev.push_back(e);
   }
-  hipEvent_t const ev_begin = ev[3 * n], ev_end = ev[3 * n + 1];
+  hipEvent_t const ev_begin = ev[4 * n], ev_end = ev[4 * n + 1];
   FC_TRY(pinned_reserve((size_t)n * (size_t)stride * sizeof(uint64_t)));
   static hipStream_t s_screen = nullptr, s_lane[2] = {nullptr, nullptr};
   hipStream_t const home = c.stream;
@@ -1782,14 +1788,19 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
     FC_TRY(ensemble_shard(e, 0, 1, default_row_block()));
     FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, kCounters * sizeof(uint64_t), tail));
     if (lanes) {
-      FC_HIP_TRY(hipEventRecord(ev[3 * r + 2], tail));
-      FC_HIP_TRY(hipStreamWaitEvent(scr, ev[3 * r + 2], 0));
+      FC_HIP_TRY(hipEventRecord(ev[4 * r + 2], tail));
+      FC_HIP_TRY(hipStreamWaitEvent(scr, ev[4 * r + 2], 0));
     }
     c.stream = scr;
-    FC_HIP_TRY(hipEventRecord(ev[3 * r], scr));
-    FC_TRY(launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin));
-    FC_HIP_TRY(hipEventRecord(ev[3 * r + 1], scr));
-    if (lanes) FC_HIP_TRY(hipStreamWaitEvent(tail, ev[3 * r + 1], 0));
+    FC_HIP_TRY(hipEventRecord(ev[4 * r], scr));
+    c.mark_after_screen = ev[4 * r + 1];  // the launcher records it right behind the screen kernel
+    const int rc_screen = launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin);
+    c.mark_after_screen = nullptr;
+    FC_TRY(rc_screen);
+    if (lanes) {  // the rest of the prune waits for the whole screen phase (verdict, gated fp64 screen)
+      FC_HIP_TRY(hipEventRecord(ev[4 * r + 3], scr));
+      FC_HIP_TRY(hipStreamWaitEvent(tail, ev[4 * r + 3], 0));
+    }
     c.stream = tail;
     FC_TRY(launch_simbits_refine(e, max_rmsd, max_dev, nullptr, 0.0));
     e->bits_valid = true;
@@ -1799,8 +1810,8 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
   c.stream = home;
   if (lanes)  // the home stream ends behind the last prune of either lane
     for (int l = 0; l < 2; ++l) {
-      FC_HIP_TRY(hipEventRecord(ev[3 * n + 2 + l], s_lane[l]));
-      FC_HIP_TRY(hipStreamWaitEvent(home, ev[3 * n + 2 + l], 0));
+      FC_HIP_TRY(hipEventRecord(ev[4 * n + 2 + l], s_lane[l]));
+      FC_HIP_TRY(hipStreamWaitEvent(home, ev[4 * n + 2 + l], 0));
     }
   FC_HIP_TRY(hipEventRecord(ev_end, home));
   FC_HIP_TRY(hipEventSynchronize(ev_end));
@@ -1813,7 +1824,7 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
     *screen_ms_sum = 0.0;
     for (int64_t r = 0; r < n; ++r) {
       float a = 0.f;
-      FC_HIP_TRY(hipEventElapsedTime(&a, ev[3 * r], ev[3 * r + 1]));
+      FC_HIP_TRY(hipEventElapsedTime(&a, ev[4 * r], ev[4 * r + 1]));
       *screen_ms_sum += a;
     }
   }

@@ -47,6 +47,9 @@ struct Context {
   hipStream_t stream = nullptr;      // the stream every launch and copy goes to
   hipStream_t own_stream = nullptr;  // the library's own; `stream` differs after fc_stream_set
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  // when set, launch_simbits_screen records it right behind its main kernel (the fp32 screen is
+  // followed by a verdict kernel and a gated fp64 screen that a timing of the kernel must not include)
+  hipEvent_t mark_after_screen = nullptr;
   int n_cu = 0;
   size_t hbm = 0;
   char name[128] = {0};
@@ -128,7 +131,8 @@ inline int check_launch(const char *what) {
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // uint64 words of fc_ensemble::counters: [0..10] queue lengths and flags, [16..) bucket fill
-// levels of the pair ladder, [63] scratch of the screen launcher
+// levels of the pair ladder, [11] "the fp64 screen has to run again" (k_screen_verdict),
+// [63] scratch of the screen launcher
 constexpr size_t kCounters = 64;
 
 // Row blocks of the bit matrix are dealt to ranks in snake order (0..W-1,

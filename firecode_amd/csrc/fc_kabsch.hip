@@ -483,7 +483,9 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
                       uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
                       unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
                       unsigned long long Q, const uint64_t *__restrict__ item_table, unsigned long long n_items,
-                      double *__restrict__ rmsd_out = nullptr) {
+                      double *__restrict__ rmsd_out = nullptr, const unsigned long long *__restrict__ gate = nullptr) {
+  // behind a speculative fp32 screen: run only when k_screen_verdict asked for it
+  if (gate != nullptr && *gate == 0ull) return;
   extern __shared__ double lds[];
   constexpr int TC = 64;
   const int tid = threadIdx.x;
@@ -1053,6 +1055,51 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
         if (valid) cand[gbase + (unsigned long long)__popcll(mv & ((1ull << lane) - 1ull))] = wq;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_screen_verdict -- was the single-precision screen worth it?  Its undecidable band turns
+// dissimilar pairs into candidates for the exact refine (~2.7 ns each); a second, fp64 screen
+// costs what ~0.64 % of the owned pairs cost there.  One workgroup: when the fp32 screen queued
+// more than `max_false` candidates, 256 of them (spread over the queue) are put through the fp64
+// polynomial on their exact covariance; if the candidates that fail it, scaled to the whole
+// queue, exceed `max_false`, counters[11] := 1 and the queues are reset -- the gated fp64 screen
+// behind this kernel then redoes the launch.  Otherwise counters[11] := 0 and the fp64 screen's
+// workgroups return at once.  Results do not depend on the verdict (both screens only ever add
+// candidates); time is bounded by fp32 screen + fp64 screen whatever the data look like.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_screen_verdict(const double *__restrict__ Xa, const double *__restrict__ G, int A, double A_thr2,
+                 const uint64_t *__restrict__ pairq, unsigned long long Q, unsigned long long max_false,
+                 unsigned long long *__restrict__ counters) {
+  const unsigned long long n = counters[6];
+  if (n <= max_false) {  // block-uniform
+    if (threadIdx.x == 0) counters[11] = 0ull;
+    return;
+  }
+  const unsigned long long avail = n < Q ? n : Q;
+  const unsigned long long sampled = avail < 256ull ? avail : 256ull;
+  int pass = 0;
+  if (threadIdx.x < sampled) {
+    const uint64_t pr = pairq[(unsigned long long)threadIdx.x * avail / sampled];
+    const int64_t i = (int64_t)(pr >> 32), j = (int64_t)(pr & 0xffffffffull);
+    const double *__restrict__ p = Xa + i * (int64_t)A * 3, *__restrict__ q = Xa + j * (int64_t)A * 3;
+    double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < A; ++a) {
+#pragma unroll
+      for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) B[x * 3 + y] = fma(p[a * 3 + x], q[a * 3 + y], B[x * 3 + y]);
+    }
+    pass = kabsch_may_be_below(B, G[i] + G[j], A_thr2) ? 1 : 0;
+  }
+  const int passed = __syncthreads_count(pass);
+  if (threadIdx.x == 0) {
+    const double est_false = (double)n * (1.0 - (double)passed / (double)sampled);
+    const bool redo = est_false > (double)max_false;
+    counters[11] = redo ? 1ull : 0ull;
+    if (redo) counters[4] = 0ull, counters[6] = 0ull;
   }
 }
 
@@ -1765,10 +1812,19 @@ static int g_last_screen = 0;
 int last_screen_kind() { return g_last_screen; }
 
 int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
+  // Context::mark_after_screen: recorded once, right behind the main screen kernel of this launch
+  bool marked = false;
+  auto mark_main = [&]() {
+    if (!marked && ctx().mark_after_screen) (void)hipEventRecord(ctx().mark_after_screen, ctx().stream);
+    marked = true;
+  };
   const int64_t NT = e->Npad >> 6;
   const int64_t n_gblocks = ceil_div(e->N, e->row_block);
   const int64_t n_lblocks = local_block_count(n_gblocks, e->rank, e->world);
-  if (n_lblocks <= 0 || NT == 0) return FC_OK;
+  if (n_lblocks <= 0 || NT == 0) {
+    mark_main();
+    return FC_OK;
+  }
   const double A_thr2 = (double)e->A * thr2_margin;
   const size_t lds = (size_t)e->A * 3 * 64 * sizeof(double);
   dim3 grid((unsigned)NT, (unsigned)n_lblocks);
@@ -1814,6 +1870,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
       if (n_items >= (1ull << 31)) return set_error(FC_E_LIMIT, "too many screen items for one launch");
       const dim3 mgrid((unsigned)n_items);
       double *dbg = nullptr;
+      const unsigned long long *gate = nullptr;  // set behind a speculative fp32 screen
 #ifdef FC_TIMELINE
       static DevBuf tlbuf;
       const bool timeline = two_blocks && getenv("FC_TIMELINE_OUT") != nullptr;
@@ -1837,6 +1894,8 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
                              e->bits.as<uint64_t>(), e->W, e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
                              (unsigned long long)e->pairq_cap, e->item_table.as<uint64_t>(),
                              (unsigned long long)e->item_total);
+          g_last_screen = 64;
+          mark_main();
           return check_launch("k_screen_rowsweep");
         }
       }
@@ -1847,12 +1906,14 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
       const int64_t A4 = (e->A + 3) / 4 * 4;
       const KabschF32Bounds bd = kabsch_f32_bounds(A4);
       bool use_f32 = !(f32_env && f32_env[0] == '0') && dbg == nullptr && bd.p0 < 2.0e-3f && e->row_block % 64 == 0;
-      if (use_f32 && !(f32_env && f32_env[0] == '2')) {  // FC_SCREEN_F32=2: no matter how wide the band
+      bool speculative = f32_env && f32_env[0] == '3';  // FC_SCREEN_F32=3: always with the verdict
+      if (use_f32 && !(f32_env && (f32_env[0] == '2' || f32_env[0] == '3'))) {  // FC_SCREEN_F32=2 / 3: no matter how wide the band
         // Band of mean square deviations above the threshold that the bounded fp32 test cannot
         // rule out: the factor (L - lambda_max)/s = A (msd - thr2) / (2 s) of P has to clear
-        // p0 / (product of the other three factors, ~0.4 and more for real structures).  Large
-        // structures with a tight threshold make it wide -- many candidates for the exact
-        // refine -- so the fp64 screen takes those (a matter of speed only, not of results).
+        // p0 / (product of the other three factors: 8 (f2+f3)(f1+f3)(f1+f2) for singular values
+        // f_i s of B, 1.3 for a chain, 2.4 for a ball; 1 assumed).  Large structures with a
+        // tight threshold make it wide -- many candidates for the exact refine -- so the fp64
+        // screen takes those at once; in between, k_screen_verdict decides on the device.
         if (e->g_max < 0.0) {
           auto *cnt_max = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
           FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
@@ -1865,8 +1926,9 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
           FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
           std::memcpy(&e->g_max, &bits_max, sizeof(double));
         }
-        const double band = (double)bd.p0 * 2.7 * e->g_max / (double)e->A;
+        const double band = (double)bd.p0 * 2.0 * e->g_max / (double)e->A;
         use_f32 = band <= 0.5 * thr2_margin;
+        speculative = band > 0.1 * thr2_margin;  // narrow band: not worth the verdict's ~10 us
       }
       if (use_f32) {
         const size_t lds_f = (size_t)A4 * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytes;
@@ -1886,23 +1948,35 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
                            (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                            e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
                            (unsigned long long)e->pairq_cap, item_table_dev, n_items);
+        FC_TRY(check_launch("k_simbits_screen_mfma_f32"));
+        mark_main();
         g_last_screen = 32;
-        return check_launch("k_simbits_screen_mfma_f32");
+        if (!speculative) return FC_OK;
+        // speculative: the verdict kernel decides on the device whether the fp64 screen below
+        // has to redo the launch (k_screen_verdict); its workgroups return at once otherwise
+        const double owned_pairs = 0.5 * (double)e->N * (double)e->N / (double)e->world;
+        const auto max_false = (unsigned long long)std::max(1024.0, 0.0064 * owned_pairs);
+        hipLaunchKernelGGL(k_screen_verdict, dim3(1), dim3(256), 0, ctx().stream, e->Xa.as<double>(),
+                           e->G.as<double>(), (int)e->A, A_thr2, e->pairq.as<uint64_t>(),
+                           (unsigned long long)e->pairq_cap, max_false, cnt);
+        FC_TRY(check_launch("k_screen_verdict"));
+        gate = cnt + 11;
       }
       if (two_blocks)
         hipLaunchKernelGGL(k_simbits_screen_mfma<4>, mgrid, dim3(256), lds_m, ctx().stream,
                            e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
                            (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                            e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
-                           (unsigned long long)e->pairq_cap, item_table_dev, n_items, dbg);
+                           (unsigned long long)e->pairq_cap, item_table_dev, n_items, dbg, gate);
       else
         hipLaunchKernelGGL(k_simbits_screen_mfma<8>, mgrid, dim3(512), lds_m, ctx().stream,
                            e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2,
                            (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                            e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
-                           (unsigned long long)e->pairq_cap, item_table_dev, n_items, dbg);
-      g_last_screen = 64;
+                           (unsigned long long)e->pairq_cap, item_table_dev, n_items, dbg, gate);
+      if (gate == nullptr) g_last_screen = 64;
       FC_TRY(check_launch("k_simbits_screen_mfma"));
+      mark_main();
 #ifdef FC_TIMELINE
       if (timeline) {
         std::vector<unsigned long long> h(n_items * 4);
@@ -1942,6 +2016,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   }
 #undef FC_LAUNCH_SCREEN
   g_last_screen = 1;
+  mark_main();
   return check_launch("k_simbits_screen");
 }
 

@@ -184,14 +184,15 @@ def test_fp32_screen_and_fp64_screen_give_the_same_similarity_bits(fc, monkeypat
     for t in picks:
         ref = np.triu((R0 < t) & (D0 < 2 * t), 1)
         got = {}
-        for mode in ("0", "2"):
+        for mode in ("0", "2", "3"):
             monkeypatch.setenv("FC_SCREEN_F32", mode)
             with fc.DeviceEnsemble(X, center=True) as ens:
                 bits, grey = ens.simbits(t, 2 * t)
                 mask, stats = ens.prune(t, 2 * t)
             got[mode] = (unpack_bits(bits, n), grey, mask, int(stats[2]))
-        assert np.array_equal(got["0"][0], got["2"][0]) and got["0"][1] == got["2"][1]
-        assert np.array_equal(got["0"][2], got["2"][2]) and got["0"][3] == got["2"][3]
+        for mode in ("2", "3"):
+            assert np.array_equal(got["0"][0], got[mode][0]) and got["0"][1] == got[mode][1]
+            assert np.array_equal(got["0"][2], got[mode][2]) and got["0"][3] == got[mode][3]
         if t == thr:  # off-threshold by construction: the oracle's own arithmetic agrees as well
             assert np.abs(near - thr).min() > 1e-7
             assert np.array_equal(got["2"][0], ref)
@@ -209,7 +210,7 @@ def test_fp32_screen_far_from_the_origin(fc, monkeypatch):
     from firecode_amd._lib import unpack_bits
 
     out = {}
-    for mode in ("0", "2", None):
+    for mode in ("0", "2", "3", None):  # fp64, fp32, fp32 + verdict (-> fp64 redo on the device), the launcher's own choice
         if mode is None:
             monkeypatch.delenv("FC_SCREEN_F32")
         else:
@@ -218,7 +219,8 @@ def test_fp32_screen_far_from_the_origin(fc, monkeypatch):
             bits, grey = ens.simbits(0.5, 1.0)
             out[mode] = (unpack_bits(bits, len(X)), grey)
     assert np.array_equal(out["0"][0], out["2"][0]) and np.array_equal(out["0"][0], out[None][0])
-    assert out["0"][1] == out["2"][1] == out[None][1]
+    assert np.array_equal(out["0"][0], out["3"][0])
+    assert out["0"][1] == out["2"][1] == out["3"][1] == out[None][1]
     assert out["0"][0].any()
 
 
