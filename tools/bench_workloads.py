@@ -101,7 +101,8 @@ def prune80():
         "workload": f"cfg4 shape on one GPU: {n} conformers x {A} atoms all-pairs RMSD prune",
         "pairs": pairs, "kernel_ms": tk, "step_ms": ts, "alignments_per_s": pairs / (ts * 1e-3),
         "survivors": int(mask.sum()), "expected": int(len(np.unique(asg))),
-        "roofline_fp64_frac": pairs * 2 * 9 * 80 / (tk * 1e-3) / 78.6e12,
+        "screen": "fp32 MFMA" if fc._lib.screen_last_kind() == 32 else "fp64 MFMA",
+        "roofline_mfma_frac": pairs * 2 * 9 * 80 / (tk * 1e-3) / (157.3e12 if fc._lib.screen_last_kind() == 32 else 78.6e12),
     }))
 
 
