@@ -1,0 +1,109 @@
+"""Numerical check of the bounds behind the single-precision screen (csrc/fc_kabsch_math.h,
+kabsch_f32_bounds / kabsch_may_be_below_f32): the kernel drops a pair only when the fp32 values
+of P, P', P'' clear a bound on their own error.  Here the same arithmetic is replayed in NumPy
+float32 -- inputs rounded to fp32, covariance accumulated atom by atom in fp32, the polynomial
+in fp32 in the kernel's order -- and compared with float64 on the exact inputs.  No GPU needed:
+this pins the CONSTANTS of the analysis (an error of a factor of a few would show here), the
+GPU tests pin the kernel's results."""
+
+import numpy as np
+import pytest
+
+U = 2.0 ** -24
+
+
+def bounds(a4):  # kabsch_f32_bounds without its factor 2
+    db = (a4 + 4.0) * U + U
+    return 45.0 * db + 172.0 * U, 9.5 * db + 46.0 * U, 6.0 * db + 52.0 * U
+
+
+def poly(B, s, L, dt):
+    """P0, P1/4-like and P2/4-like values of kabsch_may_be_below(_f32) in units of s (dtype dt)."""
+    r = (dt(1.0) / s.astype(dt)).astype(dt)
+    b = (B.astype(dt) * r[:, None, None]).astype(dt)
+    lq = (L.astype(dt) * r).astype(dt)
+    n2 = (b * b).sum(axis=(1, 2), dtype=dt)
+    L2 = lq * lq
+    uu = L2 - n2
+    c = np.empty_like(b)
+    for i in range(3):
+        for j in range(3):
+            i1, i2, j1, j2 = (i + 1) % 3, (i + 2) % 3, (j + 1) % 3, (j + 2) % 3
+            c[:, i, j] = b[:, i1, j1] * b[:, i2, j2] - b[:, i1, j2] * b[:, i2, j1]
+    det = (b[:, 0, :] * c[:, 0, :]).sum(axis=1, dtype=dt)
+    e2 = (c * c).sum(axis=(1, 2), dtype=dt)
+    P2 = dt(2.0) * L2 + uu
+    P1 = uu * lq - dt(2.0) * det
+    P0 = uu * uu - dt(4.0) * (e2 + dt(2.0) * lq * det)
+    return P0, P1, P2
+
+
+@pytest.mark.parametrize("A,offset,thr", [(13, 0.0, 0.5), (50, 0.0, 0.5), (50, 0.0, 0.25), (88, 0.0, 0.7), (50, 6.0, 0.5)])
+def test_fp32_polynomial_stays_inside_the_proven_bounds(A, offset, thr):
+    rng = np.random.default_rng(A)
+    P = 4000
+    base = rng.normal(scale=2.5, size=(P, A, 3))
+    # pairs at every distance: copies with noise from 1e-3 to 2 A, half of them rotated
+    noise = rng.normal(size=(P, A, 3)) * np.geomspace(1e-3, 2.0, P)[:, None, None]
+    x = base - base.mean(axis=1, keepdims=True) + offset
+    y = base + noise
+    q = rng.normal(size=(P, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    a, b, c, d = q.T
+    R = np.stack([np.stack([a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)], -1),
+                  np.stack([2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b)], -1),
+                  np.stack([2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d], -1)], 1)
+    y[::2] = np.einsum("pij,paj->pai", R[::2], y[::2])
+    y = y - y.mean(axis=1, keepdims=True) + offset
+    # exact side
+    B64 = np.einsum("pax,pay->pxy", x, y)
+    G = (x * x).sum(axis=(1, 2)) + (y * y).sum(axis=(1, 2))
+    s = 0.5 * G
+    L = s - 0.5 * A * thr * thr
+    keep = (A * thr * thr) < 0.5 * s  # the kernel's "tiny" pairs are never screened
+    assert keep.mean() > 0.9
+    ref = poly(B64, s, L, np.float64)
+    # fp32 side: inputs rounded, sequential accumulation, products rounded before they are added
+    xf, yf = x.astype(np.float32), y.astype(np.float32)
+    B32 = np.zeros((P, 3, 3), dtype=np.float32)
+    for k in range(A):
+        B32 += xf[:, k, :, None] * yf[:, k, None, :]
+    s32 = ((0.5 * (x * x).sum(axis=(1, 2))).astype(np.float32).astype(np.float64)
+           + (0.5 * (y * y).sum(axis=(1, 2))).astype(np.float32).astype(np.float64))
+    got = poly(B32, s32, (s32 - 0.5 * A * thr * thr), np.float32)
+    a4 = (A + 3) // 4 * 4
+    for name, g, r, bd in zip(("P0", "P1", "P2"), got, ref, bounds(a4)):
+        err = np.abs(g.astype(np.float64) - r)[keep]
+        assert err.max() <= bd, (name, err.max(), bd)
+        # and the analysis is not absurdly loose either: within 4 orders of magnitude of what happens
+        assert err.max() > bd * 1e-4, (name, err.max(), bd)
+
+
+def test_decisions_are_conservative():
+    """a pair whose exact msd is below the threshold is never dropped by the bounded fp32 test"""
+    rng = np.random.default_rng(3)
+    A, P, thr = 40, 20000, 0.5
+    base = rng.normal(scale=2.0, size=(P, A, 3))
+    x = base - base.mean(axis=1, keepdims=True)
+    scale = np.concatenate([np.full(P // 2, 1.0), np.geomspace(0.2, 3.0, P - P // 2)])
+    y = base + rng.normal(size=(P, A, 3)) * (thr / np.sqrt(3.0)) * scale[:, None, None]
+    y = y - y.mean(axis=1, keepdims=True)
+    B64 = np.einsum("pax,pay->pxy", x, y)
+    G = (x * x).sum(axis=(1, 2)) + (y * y).sum(axis=(1, 2))
+    sv = np.linalg.svd(B64, compute_uv=False)
+    sv[:, 2] *= np.sign(np.linalg.det(B64))
+    msd = (G - 2.0 * sv.sum(axis=1)) / A
+    xf, yf = x.astype(np.float32), y.astype(np.float32)
+    B32 = np.zeros((P, 3, 3), dtype=np.float32)
+    for k in range(A):
+        B32 += xf[:, k, :, None] * yf[:, k, None, :]
+    s = 0.5 * G
+    P0, P1, P2 = poly(B32, s, s - 0.5 * A * thr * thr, np.float32)
+    b0, b1, b2 = (2.0 * v for v in bounds(40))
+    dropped = (P2 > b2) & (P1 > b1) & (P0 > b0)
+    similar = msd < thr * thr
+    assert similar.sum() > 1000 and (~similar).sum() > 1000
+    assert not (dropped & similar).any()
+    # the band: dissimilar pairs the fp32 test keeps are all close to the threshold
+    kept_far = (~dropped) & (msd > thr * thr + 0.05)
+    assert not kept_far.any()
