@@ -327,6 +327,10 @@ def main():
                 "bound": "mfma", "kernel": kname, "achieved": tflops, "peak": peak,
                 "unit": "TFLOP/s", "frac": tflops / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms": t_kernel_ms, "flops_per_alignment": flops_per_alignment,
+                "kernel_ms_source": ("HIP events on the kernel's stream around every %sth launch of the timed region "
+                                     "(an event pair costs the stream ~14 us; FC_BENCH_EVENT_STRIDE=1 times all)"
+                                     % os.environ.get("FC_BENCH_EVENT_STRIDE", "8")) if not sharded else
+                                    "HIP events around rank 0's launches",
                 "dtype": "f32" if f32 else "f64",
             }
             out["dtype"] = "f32 screen + f64 exact refine" if f32 else "f64"

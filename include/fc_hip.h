@@ -393,7 +393,8 @@ int fc_prune_rmsd_many(fc_ensemble *const *ens, int64_t n, double max_rmsd, doub
 /* ---- bench / profiling hooks (resident data, device-side timing) --------
  * Runs the all-pairs similarity stage + greedy replay `reps` times on the
  * resident ensemble and returns HIP-event times (ms, per rep) of the
- * dominant kernel and of the whole step measured on the library's stream. */
+ * dominant kernel and of the whole step measured on the library's stream.  The kernel time is
+ * the mean over every 8th prune (FC_BENCH_EVENT_STRIDE): the event pair costs the stream ~14 us. */
 /* Arithmetic of the all-pairs screen the last prune launched: 32 = fp32 matrix pipe + bounded fp32
  * polynomial (default where its undecidable band is narrow), 64 = fp64 matrix pipe (FC_SCREEN_F32=0,
  * large structures with tight thresholds), 1 = VALU kernel, 0 = none yet.  Results do not depend on
