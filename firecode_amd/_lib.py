@@ -114,7 +114,7 @@ _SIGNATURES = {
     "fc_bench_prune_rmsd": [_ens, _f64, _f64, _i64, _p_f64, _p_f64, _p_u8, _p_i64],
     "fc_stream_use": [C.c_void_p],
     "fc_ensemble_twin": [_ens, C.POINTER(_ens)],
-    "fc_prune_rmsd_begin_split_async": [_ens, _f64, _f64, _i64, _i64, _i64, C.c_void_p],
+    "fc_prune_rmsd_begin_split_async": [_ens, _f64, _f64, _i64, _i64, _i64, C.c_void_p, C.c_int],
     "fc_screen_last_kind": [],
     "fc_prune_rmsd_many": [C.POINTER(_ens), _i64, _f64, _f64, _i64, C.POINTER(_p_u8), _p_i64],
 }
@@ -375,9 +375,9 @@ class DeviceEnsemble:
         call("fc_prune_rmsd_begin_async", self.handle, float(max_rmsd), float(max_dev), int(rank), int(world),
              int(row_block))
 
-    def prune_begin_split_async(self, max_rmsd, max_dev, rank, world, screen_stream, row_block=128):
+    def prune_begin_split_async(self, max_rmsd, max_dev, rank, world, screen_stream, row_block=128, timed=True):
         call("fc_prune_rmsd_begin_split_async", self.handle, float(max_rmsd), float(max_dev), int(rank),
-             int(world), int(row_block), C.c_void_p(int(screen_stream)))
+             int(world), int(row_block), C.c_void_p(int(screen_stream)), int(bool(timed)))
 
     def twin(self):
         """Second prune workspace over the same resident coordinates (owned by this ensemble)."""

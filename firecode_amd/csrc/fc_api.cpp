@@ -888,7 +888,7 @@ int fc_ensemble_twin(fc_ensemble *ens, fc_ensemble **twin_out) {
 }
 
 int fc_prune_rmsd_begin_split_async(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t rank,
-                                    int64_t world, int64_t row_block, void *screen_stream) {
+                                    int64_t world, int64_t row_block, void *screen_stream, int timed) {
   FC_REQUIRE(ens != nullptr, "ens is NULL");
   FC_REQUIRE(screen_stream != nullptr, "screen_stream is NULL");
   FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
@@ -911,8 +911,8 @@ int fc_prune_rmsd_begin_split_async(fc_ensemble *ens, double max_rmsd, double ma
   FC_HIP_TRY(hipEventRecord(ev_reset, tail));
   FC_HIP_TRY(hipStreamWaitEvent(scr, ev_reset, 0));
   c.stream = scr;
-  FC_HIP_TRY(hipEventRecord(c.ev2, scr));
-  c.mark_after_screen = c.ev3;
+  if (timed) FC_HIP_TRY(hipEventRecord(c.ev2, scr));  // the pair costs the stream ~14 us: not every step needs it
+  c.mark_after_screen = timed ? c.ev3 : nullptr;
   const int rc_screen = launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin);
   c.mark_after_screen = nullptr;
   FC_TRY(rc_screen);

@@ -222,7 +222,8 @@ def prune_steps_sharded_device(ens, steps, max_rmsd, max_dev=None, rank=0, world
             with torch.cuda.stream(lane):
                 _lib.stream_use(lane.cuda_stream)
                 if overlap:
-                    e.prune_begin_split_async(max_rmsd, max_dev, rank, world, screen.cuda_stream, row_block=row_block)
+                    e.prune_begin_split_async(max_rmsd, max_dev, rank, world, screen.cuda_stream, row_block=row_block,
+                                              timed=(k % 8 == 0 or k == steps - 1))  # stats[4]: the last timed screen
                 else:
                     e.prune_begin_async(max_rmsd, max_dev, rank, world, row_block=row_block)
                 e.export_pairs_dev(send.data_ptr(), cap)

@@ -171,12 +171,14 @@ int fc_prune_collect(fc_ensemble *ens, int64_t slot, int64_t n_slots, uint8_t *m
  *                                     with it; takes every prune call an ensemble takes;
  *   fc_prune_rmsd_begin_split_async   begin_async with the screen on `screen_stream` (all screens of a
  *                                     batch go there, in order) and counters reset + refine on the
- *                                     current stream (fc_stream_use), tied together with events.
+ *                                     current stream (fc_stream_use), tied together with events;
+ *                                     timed != 0: HIP events around the screen kernel (what stats[4]
+ *                                     of fc_prune_collect reports; ~14 us of stream time).
  * Prune k on workspace k&1 and stream k&1 of two: export, all-gather and ladder of prune k run
  * beside the screen of prune k+1. */
 int fc_ensemble_twin(fc_ensemble *ens, fc_ensemble **twin_out);
 int fc_prune_rmsd_begin_split_async(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t rank,
-                                    int64_t world, int64_t row_block, void *screen_stream);
+                                    int64_t world, int64_t row_block, void *screen_stream, int timed);
 
 /* ---- a7: prune_by_rmsd_rot_corr(structures, atoms, graph, max_rmsd=, energies=, max_dE=) --
  * prism_pruner.pruner (NOT in the reference tree); call sites firecode/ensemble.py:253-260,
