@@ -889,7 +889,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
     if (ib >= N) break;
     if (j0 + TC - 1 <= ib) break;
     const int64_t lrow0 = lb * IB + (int64_t)it * 16;
-    unsigned nz0 = 0, nz1 = 0, nz2 = 0, nz3 = 0;
+    unsigned nz = 0;  // lanes 0..15: OR of the 16-bit pieces written for row ib + lane
     unsigned voff[3];
     row_offsets(it, voff);
 
@@ -897,15 +897,9 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
     for (int half = 0; half < 2; ++half) {
       const int cs0 = half * 2;
       if (j0 + (cs0 + 2) * 16 - 1 <= ib) {  // both sub-tiles at or below the diagonal
-        if (lane < 4) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t row = ib + lane + 4 * r;
-            if (row < N) {
-              bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs0] = 0;
-              bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs0 + 1] = 0;
-            }
-          }
+        if (lane < 16 && ib + lane < N) {
+          bits16[((lrow0 + lane) * W + jt) * 4 + cs0] = 0;
+          bits16[((lrow0 + lane) * W + jt) * 4 + cs0 + 1] = 0;
         }
         continue;
       }
@@ -981,6 +975,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
         const int cs = cs0 + t;
         const int j = (int)j0 + cs * 16 + l15;
         const float Gq = ldsG[cs * 16 + l15];
+        uint64_t mr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = ib32 + 4 * kq + r;
@@ -990,30 +985,26 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
           for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
           bool may = kabsch_may_be_below_f32(B9, 2.0 * ((double)Gp + (double)Gq), A_thr2, bd);
           may = may && (j > i) && (j < n32) && (i < n32);
-          const uint64_t m = __ballot(may);
-          stage_pairs(m, may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
-          if (lane < 4) {  // lane stands for kq: 16-bit piece of row 4*lane + r
-            const unsigned piece = (unsigned)((m >> (16 * lane)) & 0xffffull);
-            if (ib32 + 4 * lane + r < n32) {
-              bits16[((lrow0 + 4 * lane + r) * W + jt) * 4 + cs] = (uint16_t)piece;
-              if (r == 0) nz0 |= piece;
-              if (r == 1) nz1 |= piece;
-              if (r == 2) nz2 |= piece;
-              if (r == 3) nz3 |= piece;
-            }
-          }
+          mr[r] = __ballot(may);
+          stage_pairs(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+        }
+        // bit (16 kq' + c) of mr[r] belongs to row 4 kq' + r: lane l < 16 writes the piece of
+        // row l = 4 (l >> 2) + (l & 3), one store per sub-tile instead of one per register
+        if (lane < 16 && ib32 + lane < n32) {
+          const int rr = lane & 3;
+          const uint64_t mine = rr == 0 ? mr[0] : rr == 1 ? mr[1] : rr == 2 ? mr[2] : mr[3];
+          const unsigned piece = (unsigned)((mine >> (16 * (lane >> 2))) & 0xffffull);
+          bits16[((lrow0 + lane) * W + jt) * 4 + cs] = (uint16_t)piece;
+          nz |= piece;
         }
       }
     }
     {  // queue the non-empty words of this row tile for the exact refine
-      const unsigned nz[4] = {nz0, nz1, nz2, nz3};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool has = lane < 4 && nz[r] != 0;
-        const uint64_t mw = __ballot(has);
-        if (mw == 0) continue;  // wave-uniform
+      const bool has = lane < 16 && nz != 0;
+      const uint64_t mw = __ballot(has);
+      if (mw != 0) {  // wave-uniform
         const unsigned n = (unsigned)__popcll(mw);
-        const uint32_t word = (uint32_t)((lrow0 + 4 * lane + r) * W + jt);
+        const uint32_t word = (uint32_t)((lrow0 + lane) * W + jt);
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(stageN + 1, n);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
