@@ -317,7 +317,6 @@ static int ensemble_shard(fc_ensemble *e, int64_t rank, int64_t world, int64_t r
   return FC_OK;
 }
 
-static const double kScreenMargin = 1e-6;  // A^2, added to max_rmsd^2 in the screen
 
 // rows of the bit matrix per workgroup (tuning knob FC_ROW_BLOCK, multiple of 128)
 static int64_t default_row_block() {

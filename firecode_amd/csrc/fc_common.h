@@ -130,6 +130,9 @@ inline int check_launch(const char *what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// A^2 added to max_rmsd^2 in the all-pairs screens (and in the refine's own early exit)
+constexpr double kScreenMargin = 1e-6;
+
 // uint64 words of fc_ensemble::counters: [0..10] queue lengths and flags, [16..) bucket fill
 // levels of the pair ladder, [11] "the fp64 screen has to run again" (k_screen_verdict),
 // [63] scratch of the screen launcher

@@ -1455,14 +1455,22 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
         const double gmine = __shfl(group8_sum(gg), sub * 8);
         if (slot == round) Gs = gmine;
       }
+      // The fp64 screen polynomial on this exact covariance first: the single-precision screen
+      // passes dissimilar pairs inside its band, and what the fp64 screen would have dropped
+      // needs neither a rotation nor a second pass over the atoms (same decision as with the
+      // fp64 screen; a wave without any other pair skips both).
+      const bool may = on && kabsch_may_be_below(B, Gs, (double)A * (max_rmsd * max_rmsd + kScreenMargin));
+      const bool any_may = __any(may);
       // rotation: Newton eigenvalue + adjugate eigenvector where the eigenvalue is clearly simple
       // (every candidate of a sane ensemble), the Jacobi sweeps otherwise -- same R to ~1e-14
       double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-      const bool fast = on && kabsch_rotation_qcp(B, Gs, R);
-      if (on && !fast) (void)kabsch_rotation(B, R);
+      if (any_may) {
+        const bool fast = may && kabsch_rotation_qcp(B, Gs, R);
+        if (may && !fast) (void)kabsch_rotation(B, R);
+      }
       double ssq_own = 0.0, mx_own = 0.0;
 #pragma unroll FC_REFINE_UNROLL
-      for (int round = 0; round < kRounds; ++round) {
+      for (int round = 0; any_may && round < kRounds; ++round) {
         const uint64_t eg = __shfl(e, round * 8 + slot);
         const bool og = base + round * 8 + slot < (int64_t)n_pairs;
         double Rg[9];
@@ -1493,8 +1501,8 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
       if (on) {
         const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
         const double r = sqrt(ssq_own / (double)A), m = sqrt(mx_own);
-        sim = (r < max_rmsd) && (m < max_dev);
-        grey = (fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9);
+        sim = may && (r < max_rmsd) && (m < max_dev);
+        grey = may && ((fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9));
         if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
         if (!sim) {
           const int64_t lrow = ((i / IB) / world) * IB + (i % IB);
