@@ -823,6 +823,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int KS = (A + 3) >> 2;
+  const float half_A_thr2 = (float)(0.5 * A_thr2);
   float *__restrict__ ldsG = lds + KS * 12 * TC;  // G/2 as fp32: [TC columns | IB rows]
   uint64_t *__restrict__ stageQ = reinterpret_cast<uint64_t *>(ldsG + TC + IB);
   uint32_t *__restrict__ stageW = reinterpret_cast<uint32_t *>(stageQ + kStagePairs);
@@ -983,7 +984,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
           float B9[9];
 #pragma unroll
           for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
-          bool may = kabsch_may_be_below_f32(B9, 2.0 * ((double)Gp + (double)Gq), A_thr2, bd);
+          bool may = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd);
           may = may && (j > i) && (j < n32) && (i < n32);
           mr[r] = __ballot(may);
           stage_pairs(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);

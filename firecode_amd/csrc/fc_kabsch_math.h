@@ -202,24 +202,22 @@ inline KabschF32Bounds kabsch_f32_bounds(int64_t A4) {
           (float)(2.0 * (6.0 * db + 52.0 * u))};
 }
 
-// B and L are first scaled by r ~ 1/s (any r works as long as both see the same one; s and L in
-// fp64 from the fp32 halves of G the kernel keeps).  A leaner all-fp32 form without the scaling
-// (P compared with p s^k: 14 instructions fewer, no fp64) measured 2 % SLOWER in the kernel, so
-// did computing all eight pairs of a unit before their queue / store work: not kept.
-__device__ __forceinline__ bool kabsch_may_be_below_f32(const float (&B)[9], double GpGq, double A_thr2,
+// Nothing is divided: with s = (Gp + Gq)/2 in fp32 (the kernel keeps G/2 as floats: one more u on
+// s, two more on L, inside the 2x) P'', P', P are compared with p2 s^2, p1 s^3, p0 s^4.  (A form
+// scaled by 1/s with s and L in fp64 costs 14 instructions more: 0.495 against 0.474 ms for the
+// kernel.  While the SLP vectoriser still packed this polynomial into v_pk_*_f32 the order was
+// the other way round.)
+__device__ __forceinline__ bool kabsch_may_be_below_f32(const float (&B)[9], float s, float half_A_thr2,
                                                         const KabschF32Bounds &bd) {
 #pragma clang fp contract(fast)
-  const double s = 0.5 * GpGq;
-  const double L = s - 0.5 * A_thr2;
-  const bool tiny = !(A_thr2 < 0.5 * s);  // tiny structure w.r.t. threshold: cannot be screened
-  const float r = __builtin_amdgcn_rcpf((float)s);
-  const float l = (float)L * r;
-  const float Sxx = B[0] * r, Sxy = B[1] * r, Sxz = B[2] * r;
-  const float Syx = B[3] * r, Syy = B[4] * r, Syz = B[5] * r;
-  const float Szx = B[6] * r, Szy = B[7] * r, Szz = B[8] * r;
+  const float L = s - half_A_thr2;
+  const bool tiny = !(4.0f * half_A_thr2 < s);  // tiny structure w.r.t. threshold: cannot be screened
+  const float Sxx = B[0], Sxy = B[1], Sxz = B[2];
+  const float Syx = B[3], Syy = B[4], Syz = B[5];
+  const float Szx = B[6], Szy = B[7], Szz = B[8];
   const float n2 = Sxx * Sxx + Sxy * Sxy + Sxz * Sxz + Syx * Syx + Syy * Syy + Syz * Syz +
                    Szx * Szx + Szy * Szy + Szz * Szz;
-  const float L2 = l * l;
+  const float L2 = L * L;
   const float uu = L2 - n2;
   const float c00 = Syy * Szz - Syz * Szy, c01 = Syz * Szx - Syx * Szz, c02 = Syx * Szy - Syy * Szx;
   const float c10 = Sxz * Szy - Sxy * Szz, c11 = Sxx * Szz - Sxz * Szx, c12 = Sxy * Szx - Sxx * Szy;
@@ -228,10 +226,12 @@ __device__ __forceinline__ bool kabsch_may_be_below_f32(const float (&B)[9], dou
   const float e2 = c00 * c00 + c01 * c01 + c02 * c02 + c10 * c10 + c11 * c11 + c12 * c12 +
                    c20 * c20 + c21 * c21 + c22 * c22;
   const float P2 = 2.0f * L2 + uu;
-  const float P1 = uu * l - 2.0f * detB;
-  const float P0 = uu * uu - 4.0f * (e2 + 2.0f * l * detB);
-  // NaN (inf or NaN coordinates) fails every `>`: the pair goes to the exact path
-  return tiny | !(P2 > bd.p2) | !(P1 > bd.p1) | !(P0 > bd.p0);
+  const float P1 = uu * L - 2.0f * detB;
+  const float P0 = uu * uu - 4.0f * (e2 + 2.0f * L * detB);
+  const float s2 = s * s;
+  // NaN and overflow (inf or NaN coordinates, s^4 beyond fp32) fail every `>`: the pair goes
+  // to the exact path; so does an underflow of s^4 to zero
+  return tiny | !(P2 > bd.p2 * s2) | !(P1 > bd.p1 * (s2 * s)) | !(P0 > bd.p0 * (s2 * s2));
 }
 
 // Largest eigenvalue of the quaternion matrix by Newton's iteration on its
