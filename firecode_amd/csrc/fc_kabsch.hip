@@ -327,6 +327,15 @@ constexpr int kStagePairs = 48;  // uint64 entries per workgroup
 constexpr int kStageWords = 24;  // uint32 entries per workgroup
 constexpr size_t kStageBytes = kStagePairs * 8 + kStageWords * 4 + 8;
 
+// the single-precision screen has LDS to spare (three workgroups of 42 KB per CU): its staging
+// area takes the candidates of an ensemble with ~4 % of similar pairs before it has to fall back
+// to one global atomic per ballot (measured on a 10^4 x 50 ensemble with a continuous RMSD
+// distribution, 1.7 % candidates: screen 4.3 ms with 48 slots)
+constexpr int kStagePairsF32 = 384;
+constexpr int kStageWordsF32 = 128;
+constexpr size_t kStageBytesF32 = kStagePairsF32 * 8 + kStageWordsF32 * 4 + 8;
+
+template <int CAP = kStagePairs>
 __device__ __forceinline__ void stage_pairs(uint64_t m, bool may, unsigned i, unsigned j,
                                             uint64_t *__restrict__ sq, unsigned *__restrict__ scnt,
                                             uint64_t *__restrict__ pairq, unsigned long long Q,
@@ -339,7 +348,7 @@ __device__ __forceinline__ void stage_pairs(uint64_t m, bool may, unsigned i, un
   unsigned base = 0;
   if (lane == 0) base = atomicAdd(scnt, n);
   base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-  if (base + n <= (unsigned)kStagePairs) {
+  if (base + n <= (unsigned)CAP) {
     if (may) sq[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = ((uint64_t)i << 32) | (uint64_t)j;
   } else {
     push_pairs(m, may, i, j, pairq, Q, counters, lane);
@@ -826,8 +835,8 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
   const float half_A_thr2 = (float)(0.5 * A_thr2);
   float *__restrict__ ldsG = lds + KS * 12 * TC;  // G/2 as fp32: [TC columns | IB rows]
   uint64_t *__restrict__ stageQ = reinterpret_cast<uint64_t *>(ldsG + TC + IB);
-  uint32_t *__restrict__ stageW = reinterpret_cast<uint32_t *>(stageQ + kStagePairs);
-  unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWords);  // [pairs, words]
+  uint32_t *__restrict__ stageW = reinterpret_cast<uint32_t *>(stageQ + kStagePairsF32);
+  unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWordsF32);  // [pairs, words]
   const unsigned long long b = blockIdx.x;
   if (b >= n_items) return;
   int64_t jt, lb;
@@ -862,8 +871,8 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
       const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
       ldsG[idx] = g < Npad ? (float)(0.5 * G[g]) : 0.f;
     }
-    if (tid < kStagePairs) stageQ[tid] = ~0ull;
-    if (tid < kStageWords) stageW[tid] = ~0u;
+    for (int idx = tid; idx < kStagePairsF32; idx += NW * 64) stageQ[idx] = ~0ull;
+    if (tid < kStageWordsF32) stageW[tid] = ~0u;
     if (tid < 2) stageN[tid] = 0u;
     __syncthreads();
   }
@@ -987,7 +996,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
           bool may = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd);
           may = may && (j > i) && (j < n32) && (i < n32);
           mr[r] = __ballot(may);
-          stage_pairs(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+          stage_pairs<kStagePairsF32>(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
         }
         // bit (16 kq' + c) of mr[r] belongs to row 4 kq' + r: lane l < 16 writes the piece of
         // row l = 4 (l >> 2) + (l & 3), one store per sub-tile instead of one per register
@@ -1010,7 +1019,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
         if (lane == 0) base = atomicAdd(stageN + 1, n);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
         const unsigned rank_in = (unsigned)__popcll(mw & ((1ull << lane) - 1ull));
-        if (base + n <= (unsigned)kStageWords) {
+        if (base + n <= (unsigned)kStageWordsF32) {
           if (has) stageW[base + rank_in] = word;
         } else {  // no room: straight to the global queue
           unsigned long long gbase = 0;
@@ -1024,8 +1033,9 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
   // publish what the workgroup staged: one global atomic per queue
   __syncthreads();
   if (wv == 0) {
-    {
-      const uint64_t e = lane < kStagePairs ? stageQ[lane] : ~0ull;
+    const int used_q = min((int)stageN[0], kStagePairsF32), used_w = min((int)stageN[1], kStageWordsF32);
+    for (int c0 = 0; c0 < used_q; c0 += 64) {
+      const uint64_t e = c0 + lane < kStagePairsF32 ? stageQ[c0 + lane] : ~0ull;
       const bool valid = e != ~0ull;
       const uint64_t mv = __ballot(valid);
       if (mv != 0) {
@@ -1038,8 +1048,8 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
         }
       }
     }
-    {
-      const uint32_t wq = lane < kStageWords ? stageW[lane] : ~0u;
+    for (int c0 = 0; c0 < used_w; c0 += 64) {
+      const uint32_t wq = c0 + lane < kStageWordsF32 ? stageW[c0 + lane] : ~0u;
       const bool valid = wq != ~0u;
       const uint64_t mv = __ballot(valid);
       if (mv != 0) {
@@ -1054,8 +1064,8 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
 
 // ---------------------------------------------------------------------------
 // k_screen_verdict -- was the single-precision screen worth it?  Its undecidable band turns
-// dissimilar pairs into candidates for the exact refine (~2.7 ns each); a second, fp64 screen
-// costs what ~0.64 % of the owned pairs cost there.  One workgroup: when the fp32 screen queued
+// dissimilar pairs into candidates (queue traffic in the screen, one atom pass in the refine); a
+// second, fp64 screen costs about what 0.64 % of the owned pairs cost as candidates.  One workgroup: when the fp32 screen queued
 // more than `max_false` candidates, 256 of them (spread over the queue) are put through the fp64
 // polynomial on their exact covariance; if the candidates that fail it, scaled to the whole
 // queue, exceed `max_false`, counters[11] := 1 and the queues are reset -- the gated fp64 screen
@@ -1933,7 +1943,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         speculative = band > 0.1 * thr2_margin;  // narrow band: not worth the verdict's ~10 us
       }
       if (use_f32) {
-        const size_t lds_f = (size_t)A4 * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytes;
+        const size_t lds_f = (size_t)A4 * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32;
         if (!e->xsf_valid) {
           const int64_t n = A4 * 3 * e->Npad;
           FC_TRY(e->Xsf.reserve((size_t)n * sizeof(float)));
