@@ -190,6 +190,8 @@ def main():
         # is the whole pass -- counters reset, screen, refine, level buckets, ladder, survivor words
         # + counters copied to the step's own pinned host slot -- and the host waits once for all K
         # (the barrier + synchronisation the contract asks for, not one per step)
+        # set-up outside the timed region, whatever W is: second workspace, streams, fp32 operand copy
+        ens.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=2, want_mask=False)
         if args.warmup:
             ens.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=min(args.warmup, 1024), want_mask=True)
         barrier()
@@ -225,6 +227,10 @@ def main():
                                                           device=torch.device("cuda", local_rank))
         for _ in range(args.warmup):
             step()
+        if backend != "gloo":  # set-up of the overlapped batch path outside the timed region, whatever W is:
+            # second workspace and its operand copy, lane streams, the two message buffer pairs
+            fdist.prune_steps_sharded_device(ens, 2, MAX_RMSD, rank=rank, world=world,
+                                             device=torch.device("cuda", local_rank))
         barrier()
         t0 = time.perf_counter()
         tk_ns, owned = 0, 0
