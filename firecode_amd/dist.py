@@ -189,7 +189,12 @@ def prune_steps_sharded_device(ens, steps, max_rmsd, max_dev=None, rank=0, world
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     pool = _lane_streams.get(device)
     if pool is None:
-        pool = _lane_streams[device] = [torch.cuda.Stream(device=device) for _ in range(3)]
+        # the screen fills every workgroup slot of the chip: the lanes' small kernels (and RCCL behind them)
+        # need the dispatcher's preference to run beside it, so the lanes get the highest stream priority
+        lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        pool = _lane_streams[device] = [torch.cuda.Stream(device=device, priority=hi),
+                                        torch.cuda.Stream(device=device, priority=hi),
+                                        torch.cuda.Stream(device=device, priority=lo)]
     home, lane_b, screen = pool
     lanes = [home, lane_b] if overlap else [home, home]
     work = [ens, ens.twin()] if overlap else [ens, ens]
