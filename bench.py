@@ -162,11 +162,14 @@ def main():
             allgather = fdist.torch_allgather()
         else:
             torch.cuda.set_device(local_rank)
+            # the screens fill every workgroup slot of the chip and run at the lowest stream priority;
+            # RCCL's own stream gets the highest, like the lanes that feed it (firecode_amd/dist.py)
+            pg_opts = tdist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
             if world == 1 and "RANK" not in os.environ:
                 tdist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29655", rank=0,
-                                         world_size=1, device_id=torch.device("cuda", local_rank))
+                                         world_size=1, device_id=torch.device("cuda", local_rank), pg_options=pg_opts)
             else:
-                tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), pg_options=pg_opts)
             allgather = fdist.torch_allgather(device=torch.device("cuda", local_rank))
 
     n_conf = int(round(N_CONF * np.sqrt(world)))
