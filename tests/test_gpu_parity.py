@@ -218,10 +218,19 @@ def test_fp32_screen_far_from_the_origin(fc, monkeypatch):
         with fc.DeviceEnsemble(X, center=False) as ens:
             bits, grey = ens.simbits(0.5, 1.0)
             out[mode] = (unpack_bits(bits, len(X)), grey)
+        from firecode_amd import _lib
+
+        # which screen was launched (first): forced by the knob, fp64 by the launcher's own band estimate here
+        assert _lib.screen_last_kind() == {"0": 64, "2": 32, "3": 32, None: 64}[mode]
     assert np.array_equal(out["0"][0], out["2"][0]) and np.array_equal(out["0"][0], out[None][0])
     assert np.array_equal(out["0"][0], out["3"][0])
     assert out["0"][1] == out["2"][1] == out["3"][1] == out[None][1]
     assert out["0"][0].any()
+    # a compact, centred ensemble of the bench's kind: the launcher takes the single-precision screen
+    Xc, _, _ = syn.synthetic_ensemble(300, 50, seed=5)
+    with fc.DeviceEnsemble(Xc, center=True) as ens:
+        ens.simbits(0.5, 1.0)
+    assert _lib.screen_last_kind() == 32
 
 
 def test_refine_word_queue_fallback(fc, monkeypatch):
