@@ -80,6 +80,67 @@ k_prep(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_
   G[n] = g;
 }
 
+// k_prep_tile: the same preparation for 64 conformers per workgroup through LDS -- the input
+// block of 64 conformers (64 x A_all x 3 doubles, contiguous) is read with coalesced loads and
+// every output is written coalesced too: Xs across the 64 conformers of a column, Xa as the
+// contiguous image of the tile.  (k_prep reads with a 1200-byte stride between lanes and keeps
+// 40 CUs busy at 10^4 conformers: 75 us against ~15 us.)  Same arithmetic, same order.
+__global__ void __launch_bounds__(256)
+k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_t *__restrict__ sel,
+            int64_t A, int center, int64_t Npad, double *__restrict__ Xs, double *__restrict__ G,
+            double *__restrict__ Xa) {
+  extern __shared__ double tile[];  // [64][A_all*3 + 1] (the +1 spreads the conformers over the banks)
+  __shared__ double cen[64][3];
+  const int tid = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.x * 64;
+  const int64_t row = A_all * 3, ld = row + 1;
+  const int64_t n_here = (N - n0 < 64) ? (N - n0 > 0 ? N - n0 : 0) : 64;
+  const double *src = coords + n0 * row;
+  for (int64_t k = tid; k < n_here * row; k += 256) tile[(k / row) * ld + (k % row)] = src[k];
+  __syncthreads();
+  if (tid < 64) {
+    double cx = 0.0, cy = 0.0, cz = 0.0, g = 0.0;
+    if (tid < n_here) {
+      const double *t = tile + (int64_t)tid * ld;
+      if (center) {
+        // same order as numpy's mean(axis=0): running sum over atoms, then / A
+        for (int64_t a = 0; a < A; ++a) {
+          const double *r = t + (int64_t)sel[a] * 3;
+          cx += r[0];
+          cy += r[1];
+          cz += r[2];
+        }
+        cx /= (double)A;
+        cy /= (double)A;
+        cz /= (double)A;
+      }
+      for (int64_t a = 0; a < A; ++a) {
+        const double *r = t + (int64_t)sel[a] * 3;
+        const double x = r[0] - cx, y = r[1] - cy, z = r[2] - cz;
+        g += x * x + y * y + z * z;
+      }
+    }
+    cen[tid][0] = cx, cen[tid][1] = cy, cen[tid][2] = cz;
+    if (n0 + tid < Npad) G[n0 + tid] = g;
+  }
+  __syncthreads();
+  // Xs: element (a, c) of 64 consecutive conformers is one coalesced 512-byte store; rows A..A4-1 are zero
+  const int64_t A4 = (A + 3) & ~(int64_t)3;
+  for (int64_t k = tid; k < A4 * 3 * 64; k += 256) {
+    const int64_t ac = k >> 6, l = k & 63;
+    const int64_t a = ac / 3, c = ac - a * 3;
+    double v = 0.0;
+    if (a < A && l < n_here) v = tile[l * ld + (int64_t)sel[a] * 3 + c] - cen[l][c];
+    if (n0 + l < Npad) Xs[ac * Npad + n0 + l] = v;
+  }
+  // Xa: [n][a][c], contiguous for the tile
+  for (int64_t k = tid; k < n_here * A * 3; k += 256) {
+    const int64_t l = k / (A * 3), rest = k - l * (A * 3);
+    const int64_t a = rest / 3, c = rest - a * 3;
+    Xa[(n0 + l) * A * 3 + rest] = tile[l * ld + (int64_t)sel[a] * 3 + c] - cen[l][c];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Exact pair evaluation on the SoA layout: covariance, optimal rotation,
 // explicit rotated difference -> (rmsd, maxdev).  One lane per pair.
@@ -1792,10 +1853,20 @@ int launch_scatter_pairs(const uint64_t *pairs_dev, int64_t n_pairs, int64_t N, 
 // ---------------------------------------------------------------------------
 int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_t *sel_dev,
                 int64_t A, int center, fc_ensemble *e) {
-  const int64_t blocks = ceil_div(e->Npad, 256);
-  hipLaunchKernelGGL(k_prep, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, coords_dev, N,
-                     A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
-                     e->Xa.as<double>());
+  const size_t lds_tile = (size_t)64 * (size_t)(A_all * 3 + 1) * sizeof(double);
+  if (lds_tile + 2048 <= kLdsLimit && !getenv("FC_PREP_LANES")) {  // FC_PREP_LANES=1: the one-lane-per-conformer kernel
+    if (lds_tile > 64 * 1024)
+      FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_tile),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
+    hipLaunchKernelGGL(k_prep_tile, dim3((unsigned)(e->Npad / 64)), dim3(256), lds_tile, ctx().stream, coords_dev,
+                       N, A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
+                       e->Xa.as<double>());
+  } else {
+    const int64_t blocks = ceil_div(e->Npad, 256);
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, coords_dev, N,
+                       A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
+                       e->Xa.as<double>());
+  }
   e->xsf_valid = false;
   e->g_max = -1.0;
   return check_launch("k_prep");
