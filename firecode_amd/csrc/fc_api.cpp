@@ -281,7 +281,13 @@ static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const 
   FC_TRY(upload(raw, coords, (size_t)N * A_all * 3));
   FC_TRY(upload(dsel, sel.data(), sel.size()));
   FC_TRY(launch_prep(raw.as<double>(), N, A_all, dsel.as<int32_t>(), e->A, center, e));
+  // the largest G (left by the prep kernel in the last counter word) comes back behind the same wait
+  unsigned long long gmax_bits = 0;
+  auto *gmax_dev = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
+  FC_TRY(d2h(&gmax_bits, gmax_dev, sizeof gmax_bits));
   FC_TRY(sync());
+  std::memcpy(&e->g_max, &gmax_bits, sizeof(double));
+  FC_HIP_TRY(hipMemsetAsync(gmax_dev, 0, sizeof(unsigned long long), ctx().stream));
   return FC_OK;
 }
 

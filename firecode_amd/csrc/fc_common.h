@@ -171,6 +171,7 @@ struct fc_ensemble {
   fc::DevBuf bits_full;        // N x W uint64: whole bit matrix rebuilt from gathered pairs
   fc::DevBuf item_table;       // screen items (lb << 32 | jt) that touch the upper triangle
   int64_t item_key[4] = {-1, -1, -1, -1}, item_total = 0;
+  std::vector<uint64_t> item_host;  // source of the (asynchronous) upload: lives as long as the ensemble
   fc::DevBuf gathered;         // world x cap uint64: all ranks' similar pairs, compacted (device exchange)
   fc::DevBuf energies;         // N doubles (optional)
   fc::DevBuf maskA, maskB;     // N bytes each

@@ -32,7 +32,7 @@ static constexpr size_t kLdsLimit = 160 * 1024;
 __global__ void __launch_bounds__(256)
 k_prep(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_t *__restrict__ sel,
        int64_t A, int center, int64_t Npad, double *__restrict__ Xs, double *__restrict__ G,
-       double *__restrict__ Xa) {
+       double *__restrict__ Xa, unsigned long long *__restrict__ gmax_bits) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= Npad) return;
   // atom rows A .. A4-1 (A4 = A rounded up to 4) are zero: the MFMA K loop
@@ -78,6 +78,8 @@ k_prep(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_
     g += x * x + y * y + z * z;
   }
   G[n] = g;
+  // largest G (sizes the single-precision screen's band): non-negative doubles order like their bits
+  if (g == g) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(g));
 }
 
 // k_prep_tile: the same preparation for 64 conformers per workgroup through LDS -- the input
@@ -88,7 +90,7 @@ k_prep(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_
 __global__ void __launch_bounds__(256)
 k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_t *__restrict__ sel,
             int64_t A, int center, int64_t Npad, double *__restrict__ Xs, double *__restrict__ G,
-            double *__restrict__ Xa) {
+            double *__restrict__ Xa, unsigned long long *__restrict__ gmax_bits) {
   extern __shared__ double tile[];  // [64][A_all*3 + 1] (the +1 spreads the conformers over the banks)
   __shared__ double cen[64][3];
   const int tid = threadIdx.x;
@@ -122,6 +124,13 @@ k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const i
     }
     cen[tid][0] = cx, cen[tid][1] = cy, cen[tid][2] = cz;
     if (n0 + tid < Npad) G[n0 + tid] = g;
+    // largest G (sizes the single-precision screen's band): one atomic per workgroup
+    double gm = (g == g) ? g : 0.0;
+    for (int off = 32; off > 0; off >>= 1) {
+      const double o = __shfl_xor(gm, off);
+      if (o > gm) gm = o;
+    }
+    if (tid == 0) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(gm));
   }
   __syncthreads();
   // Xs: element (a, c) of 64 consecutive conformers is one coalesced 512-byte store; rows A..A4-1 are zero
@@ -1782,9 +1791,9 @@ static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks, bool
   }
   if (items.empty() || items.size() >= (1ull << 31)) return FC_OK;
   FC_TRY(e->item_table.reserve(items.size() * sizeof(uint64_t)));
-  FC_TRY(h2d(e->item_table.p, items.data(), items.size() * sizeof(uint64_t)));
-  FC_TRY(sync());  // `items` is a local
-  e->item_total = (int64_t)items.size();
+  e->item_host.swap(items);  // the copy is asynchronous: its source stays with the ensemble (no host wait here)
+  FC_TRY(h2d(e->item_table.p, e->item_host.data(), e->item_host.size() * sizeof(uint64_t)));
+  e->item_total = (int64_t)e->item_host.size();
   return FC_OK;
 }
 
@@ -1853,6 +1862,9 @@ int launch_scatter_pairs(const uint64_t *pairs_dev, int64_t n_pairs, int64_t N, 
 // ---------------------------------------------------------------------------
 int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_t *sel_dev,
                 int64_t A, int center, fc_ensemble *e) {
+  // the largest G lands in the last counter word (zeroed here); ensemble_build reads it behind its own wait
+  auto *gmax_bits = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
+  FC_HIP_TRY(hipMemsetAsync(gmax_bits, 0, sizeof(unsigned long long), ctx().stream));
   const size_t lds_tile = (size_t)64 * (size_t)(A_all * 3 + 1) * sizeof(double);
   if (lds_tile + 2048 <= kLdsLimit && !getenv("FC_PREP_LANES")) {  // FC_PREP_LANES=1: the one-lane-per-conformer kernel
     if (lds_tile > 64 * 1024)
@@ -1860,12 +1872,12 @@ int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
     hipLaunchKernelGGL(k_prep_tile, dim3((unsigned)(e->Npad / 64)), dim3(256), lds_tile, ctx().stream, coords_dev,
                        N, A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
-                       e->Xa.as<double>());
+                       e->Xa.as<double>(), gmax_bits);
   } else {
     const int64_t blocks = ceil_div(e->Npad, 256);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, coords_dev, N,
                        A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
-                       e->Xa.as<double>());
+                       e->Xa.as<double>(), gmax_bits);
   }
   e->xsf_valid = false;
   e->g_max = -1.0;
