@@ -671,7 +671,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
     if (ib >= N) break;
     if (j0 + TC - 1 <= ib) break;
     const int64_t lrow0 = lb * IB + (int64_t)it * 16;
-    unsigned nz0 = 0, nz1 = 0, nz2 = 0, nz3 = 0;
+    unsigned nz = 0;  // lanes 0..15: OR of the 16-bit pieces written for row ib + lane
     // per-lane element offsets of the lane's row operand inside one k-step
     // (fits 32 bits: checked by the launcher)
     unsigned voff[3];
@@ -681,15 +681,9 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
     for (int half = 0; half < 2; ++half) {
       const int cs0 = half * 2;
       if (j0 + (cs0 + 2) * 16 - 1 <= ib) {  // both sub-tiles at or below the diagonal
-        if (!VALUES && lane < 4) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t row = ib + lane + 4 * r;
-            if (row < N) {
-              bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs0] = 0;
-              bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs0 + 1] = 0;
-            }
-          }
+        if (!VALUES && lane < 16 && ib + lane < N) {
+          bits16[((lrow0 + lane) * W + jt) * 4 + cs0] = 0;
+          bits16[((lrow0 + lane) * W + jt) * 4 + cs0 + 1] = 0;
         }
         continue;
       }
@@ -772,6 +766,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
         const int cs = cs0 + t;
         const int j = (int)j0 + cs * 16 + l15;
         const double Gq = ldsG[cs * 16 + l15];
+        uint64_t mr[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = ib32 + kq + 4 * r;
@@ -790,33 +785,27 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
           }
           bool may = kabsch_may_be_below(B9, Gp + Gq, A_thr2);
           may = may && (j > i) && (j < n32) && (i < n32);
-          const uint64_t m = __ballot(may);
-          stage_pairs(m, may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
-          if (lane < 4) {
-            const unsigned piece = (unsigned)((m >> (16 * lane)) & 0xffffull);
-            if (ib32 + lane + 4 * r < n32) {
-              bits16[((lrow0 + lane + 4 * r) * W + jt) * 4 + cs] = (uint16_t)piece;
-              if (r == 0) nz0 |= piece;
-              if (r == 1) nz1 |= piece;
-              if (r == 2) nz2 |= piece;
-              if (r == 3) nz3 |= piece;
-            }
-          }
+          mr[r] = __ballot(may);
+          stage_pairs(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+        }
+        // bit (16 kq' + c) of mr[r] belongs to row kq' + 4 r: lane l < 16 writes the piece of
+        // row l = (l & 3) + 4 (l >> 2), one store per sub-tile instead of one per register
+        if (!VALUES && lane < 16 && ib32 + lane < n32) {
+          const int rr = lane >> 2;
+          const uint64_t mine = rr == 0 ? mr[0] : rr == 1 ? mr[1] : rr == 2 ? mr[2] : mr[3];
+          const unsigned piece = (unsigned)((mine >> (16 * (lane & 3))) & 0xffffull);
+          bits16[((lrow0 + lane) * W + jt) * 4 + cs] = (uint16_t)piece;
+          nz |= piece;
         }
       }
     }
     if (!VALUES) {  // queue the non-empty words of this row tile for the exact refine
-      const unsigned nz[4] = {nz0, nz1, nz2, nz3};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#ifdef FC_ABLATE_PUSH
-        continue;
-#endif
-        const bool has = lane < 4 && nz[r] != 0;
-        const uint64_t mw = __ballot(has);
-        if (mw == 0) continue;  // wave-uniform
+#ifndef FC_ABLATE_PUSH
+      const bool has = lane < 16 && nz != 0;
+      const uint64_t mw = __ballot(has);
+      if (mw != 0) {  // wave-uniform
         const unsigned n = (unsigned)__popcll(mw);
-        const uint32_t word = (uint32_t)((lrow0 + lane + 4 * r) * W + jt);
+        const uint32_t word = (uint32_t)((lrow0 + lane) * W + jt);
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(stageN + 1, n);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
@@ -830,6 +819,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
           if (has) cand[gbase + rank_in] = word;
         }
       }
+#endif
     }
   }
   // publish what the workgroup staged: one global atomic per queue
