@@ -1125,7 +1125,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
 // ---------------------------------------------------------------------------
 // k_screen_verdict -- was the single-precision screen worth it?  Its undecidable band turns
 // dissimilar pairs into candidates (queue traffic in the screen, one atom pass in the refine); a
-// second, fp64 screen costs about what 0.64 % of the owned pairs cost as candidates.  One workgroup: when the fp32 screen queued
+// second, fp64 screen costs about what 1.5 % of the owned pairs cost as candidates (50 atoms).  One workgroup: when the fp32 screen queued
 // more than `max_false` candidates, 256 of them (spread over the queue) are put through the fp64
 // polynomial on their exact covariance; if the candidates that fail it, scaled to the whole
 // queue, exceed `max_false`, counters[11] := 1 and the queues are reset -- the gated fp64 screen
@@ -2012,7 +2012,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
           std::memcpy(&e->g_max, &bits_max, sizeof(double));
         }
         const double band = (double)bd.p0 * 2.0 * e->g_max / (double)e->A;
-        use_f32 = band <= 0.5 * thr2_margin;
+        use_f32 = band <= 1.0 * thr2_margin;  // beyond: the fp64 screen at once
         speculative = band > 0.1 * thr2_margin;  // narrow band: not worth the verdict's ~10 us
       }
       if (use_f32) {
@@ -2040,7 +2040,9 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         // speculative: the verdict kernel decides on the device whether the fp64 screen below
         // has to redo the launch (k_screen_verdict); its workgroups return at once otherwise
         const double owned_pairs = 0.5 * (double)e->N * (double)e->N / (double)e->world;
-        const auto max_false = (unsigned long long)std::max(1024.0, 0.0064 * owned_pairs);
+        // a false candidate costs ~1 ns (staging, one atom pass of the refine: tools/broad_probe.py), a second
+        // screen in fp64 ~0.017 ns per owned pair at 52 padded atoms and in proportion to them beyond
+        const auto max_false = (unsigned long long)std::max(1024.0, 0.015 * ((double)A4 / 52.0) * owned_pairs);
         hipLaunchKernelGGL(k_screen_verdict, dim3(1), dim3(256), 0, ctx().stream, e->Xa.as<double>(),
                            e->G.as<double>(), (int)e->A, A_thr2, e->pairq.as<uint64_t>(),
                            (unsigned long long)e->pairq_cap, max_false, cnt);
