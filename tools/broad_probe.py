@@ -10,18 +10,19 @@ from firecode_amd import synthetic as syn
 
 fc.init(0)
 rng = np.random.default_rng(11)
-N, A, M = 10000, 50, 6
+N, A, M = int(os.environ.get("BROAD_N", 10000)), int(os.environ.get("BROAD_A", 50)), 6
+THR = float(os.environ.get("BROAD_THR", 0.5))  # the amplitudes scale with it: same distribution of rmsd / THR
 base, _, _ = syn.synthetic_ensemble(1, A, seed=2)
 modes = np.linalg.qr(rng.normal(size=(A * 3, M)))[0].T.reshape(M, A, 3)  # orthonormal displacement fields
-amp = rng.normal(scale=0.35 * np.sqrt(A), size=(N, M))
+amp = rng.normal(scale=0.35 * np.sqrt(A) * (THR / 0.5), size=(N, M))
 X = base[0][None] + np.einsum("nm,mac->nac", amp, modes)
-out = {"workload": "10000 x 50, continuous RMSD distribution (6 collective modes), prune at 0.5 A"}
+out = {"workload": "%d x %d, continuous RMSD distribution (6 collective modes), prune at %g A" % (N, A, THR)}
 with fc.DeviceEnsemble(X, center=True) as ens:
     for _ in range(2):
-        mask, st = ens.prune(0.5, 1.0)
+        mask, st = ens.prune(THR, 2 * THR)
     t0 = time.perf_counter()
     for _ in range(5):
-        mask, st = ens.prune(0.5, 1.0)
+        mask, st = ens.prune(THR, 2 * THR)
     out.update({"ms_per_prune": (time.perf_counter() - t0) / 5 * 1e3, "pairs": int(st[0]), "refined": int(st[1]),
                 "similar": int(st[2]), "survivors": int(mask.sum()), "screen_launched_first": fc._lib.screen_last_kind(),
                 "FC_SCREEN_F32": os.environ.get("FC_SCREEN_F32")})
