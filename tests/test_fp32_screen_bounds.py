@@ -107,3 +107,44 @@ def test_decisions_are_conservative():
     # the band: dissimilar pairs the fp32 test keeps are all close to the threshold
     kept_far = (~dropped) & (msd > thr * thr + 0.05)
     assert not kept_far.any()
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-3, 300.0])
+def test_unscaled_form_of_the_kernel(scale):
+    """the kernel compares P'', P', P with p2 s^2, p1 s^3, p0 s^4 instead of scaling B and L by 1/s:
+    the same decisions as the scaled form for structures measured in Angstrom, in nm-like and in
+    pm-like units (fp32 range: s^4 up to ~1e38)"""
+    rng = np.random.default_rng(9)
+    A, P, thr = 50, 6000, 0.5 * scale
+    base = rng.normal(scale=2.5 * scale, size=(P, A, 3))
+    x = base - base.mean(axis=1, keepdims=True)
+    y = base + rng.normal(size=(P, A, 3)) * (np.geomspace(0.02, 2.0, P) * scale)[:, None, None]
+    y = y - y.mean(axis=1, keepdims=True)
+    xf, yf = x.astype(np.float32), y.astype(np.float32)
+    B = np.zeros((P, 3, 3), dtype=np.float32)
+    for k in range(A):
+        B += xf[:, k, :, None] * yf[:, k, None, :]
+    f = np.float32
+    s = ((0.5 * (x * x).sum(axis=(1, 2))).astype(f) + (0.5 * (y * y).sum(axis=(1, 2))).astype(f)).astype(f)
+    L = (s - f(0.5 * A * thr * thr)).astype(f)
+    n2 = (B * B).sum(axis=(1, 2), dtype=f)
+    uu = L * L - n2
+    c = np.empty_like(B)
+    for i in range(3):
+        for j in range(3):
+            i1, i2, j1, j2 = (i + 1) % 3, (i + 2) % 3, (j + 1) % 3, (j + 2) % 3
+            c[:, i, j] = B[:, i1, j1] * B[:, i2, j2] - B[:, i1, j2] * B[:, i2, j1]
+    det = (B[:, 0, :] * c[:, 0, :]).sum(axis=1, dtype=f)
+    e2 = (c * c).sum(axis=(1, 2), dtype=f)
+    P2, P1, P0 = f(2) * L * L + uu, uu * L - f(2) * det, uu * uu - f(4) * (e2 + f(2) * L * det)
+    b0, b1, b2 = (f(2.0 * v) for v in bounds(52))
+    s2 = s * s
+    dropped = (P2 > b2 * s2) & (P1 > b1 * s2 * s) & (P0 > b0 * s2 * s2)
+    assert np.isfinite(P0).all() and np.isfinite(s2 * s2).all()
+    sv = np.linalg.svd(np.einsum("pax,pay->pxy", x, y), compute_uv=False)
+    sv[:, 2] *= np.sign(np.linalg.det(np.einsum("pax,pay->pxy", x, y)))
+    msd = ((x * x).sum(axis=(1, 2)) + (y * y).sum(axis=(1, 2)) - 2.0 * sv.sum(axis=1)) / A
+    similar = msd < thr * thr
+    assert similar.sum() > 300 and dropped.sum() > 300
+    assert not (dropped & similar).any()
+    assert not ((~dropped) & (msd > 1.2 * thr * thr)).any()  # the band stays narrow in every unit system
