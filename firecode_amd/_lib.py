@@ -59,6 +59,8 @@ _SIGNATURES = {
     "fc_ensemble_rmsd_pairs": [_ens, _p_i64, _p_i64, _i64, _p_f64, _p_f64],
     "fc_ensemble_rmsd_matrix": [_ens, _p_f64, _p_f64],
     "fc_ensemble_rmsd_values": [_ens, _p_f64, _p_f64],
+    "fc_ensemble_rmsd_and_max_all": [_ens, _p_f64, _p_f64, _p_f64],
+    "fc_screen_select": [C.c_int],
     "fc_alignment_matrices": [_p_f64, _p_f64, _i64, _i64, _p_f64],
     "fc_rmsd_simbits": [_ens, _f64, _f64, _p_f64, _f64, _i64, _i64, _p_u64, _p_i64],
     "fc_prune_rmsd": [_ens, _f64, _f64, _p_f64, _f64, _i64, _p_u8, _p_i64],
@@ -116,47 +118,91 @@ _SIGNATURES = {
     "fc_ensemble_twin": [_ens, C.POINTER(_ens)],
     "fc_prune_rmsd_begin_split_async": [_ens, _f64, _f64, _i64, _i64, _i64, C.c_void_p, C.c_int],
     "fc_screen_last_kind": [],
+    "fc_comm_unique_id": [_p_u8],
+    "fc_comm_init": [_i64, _i64, _p_u8],
+    "fc_comm_destroy": [],
+    "fc_comm_info": [_p_i64, _p_i64],
+    "fc_allgather_mask": [_p_u8, _i64, _p_u8],
+    "fc_allgather_u8_dev": [C.c_void_p, C.c_void_p, _i64],
+    "fc_comm_barrier": [],
+    "fc_debug_comm_loopback": [_i64, _i64],
+    "fc_prune_rmsd_sharded": [_ens, _f64, _f64, _i64, _i64, _p_u8, _p_i64],
+    "fc_bench_prune_rmsd_sharded": [_ens, _f64, _f64, _i64, C.c_int, _p_f64, _p_f64, _p_u8, _p_i64],
     "fc_prune_rmsd_many": [C.POINTER(_ens), _i64, _f64, _f64, _i64, C.POINTER(_p_u8), _p_i64],
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("fc_last_error",)
 
 
+def _hip_runtime_mode():
+    """Which HIP runtime libfc_hip.so binds to.  Default ``system``: the ROCm install the library was
+    built against -- the product does not depend on PyTorch being installed.  ``FC_HIP_RUNTIME=torch``
+    (explicit opt-in, for callers that hand the library torch streams / tensors: the legacy
+    torch.distributed exchange in ``firecode_amd.dist``) maps the ``libamdhip64.so`` bundled with
+    PyTorch's ROCm wheel first, so that both sides share ONE runtime and one device context; two HIP
+    runtimes in one process cannot both own the GPU.  Importing torch BEFORE this module has the same
+    effect (its copy is then already mapped under the same soname) and is reported as ``torch``."""
+    want = os.environ.get("FC_HIP_RUNTIME", "system")
+    if want not in ("system", "torch", "auto"):
+        raise FirecodeHipInputError(FC_E_INVALID, f"FC_HIP_RUNTIME={want!r}: expected 'system' or 'torch'")
+    return "system" if want == "auto" else want
+
+
+def _mapped_hip_runtimes():
+    """paths of every libamdhip64 already mapped into this process"""
+    try:
+        with open("/proc/self/maps") as fh:
+            return sorted({ln.split()[-1] for ln in fh if "libamdhip64" in ln})
+    except OSError:
+        return []
+
+
+HIP_RUNTIME = None  # "system" | "torch": set by load()
+
+
 def _share_torch_hip_runtime():
-    """PyTorch's ROCm wheels carry their own libamdhip64.so / libhsa-runtime64.so, and two HIP
-    runtimes in one process cannot both own the GPU: whichever initialises second reports
-    "no HIP GPUs".  libfc_hip.so asks for ``libamdhip64.so.7`` by soname, so when torch's copy
-    (same soname) is mapped first both sides share ONE runtime, one device context and
-    compatible streams -- which the RCCL exchange in ``firecode_amd.dist`` needs.  torch
-    itself is not imported here.  ``FC_HIP_RUNTIME=system`` keeps the ROCm install's runtime
-    (torch.cuda is then unusable in this process)."""
+    """FC_HIP_RUNTIME=torch: map torch's bundled HIP runtime ahead of libfc_hip.so (see
+    ``_hip_runtime_mode``).  Refuses when another libamdhip64 is already mapped (a second copy
+    would leave one side without a device) or when the bundled file does not carry the soname
+    libfc_hip.so asks for."""
     import importlib.util
     import sys
 
-    if os.environ.get("FC_HIP_RUNTIME", "auto") == "system" or "torch" in sys.modules:
-        return None
+    mapped = _mapped_hip_runtimes()
+    if "torch" in sys.modules:
+        return mapped[0] if mapped else None  # torch's copy is in: libfc_hip.so binds to it by soname
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
     if spec is None or not spec.origin:
-        return None
+        raise FirecodeHipDeviceError(FC_E_NODEVICE, "FC_HIP_RUNTIME=torch but PyTorch is not installed")
     path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if mapped and os.path.realpath(mapped[0]) != os.path.realpath(path):
+        raise FirecodeHipDeviceError(
+            FC_E_NODEVICE, f"FC_HIP_RUNTIME=torch but {mapped[0]} is already mapped: a second HIP runtime "
+            "in this process would see no GPU")
     if not os.path.exists(path):
-        return None
-    try:
-        C.CDLL(path, mode=C.RTLD_GLOBAL)
-    except OSError:  # an unusable torch install must not take the library down with it
-        return None
+        raise FirecodeHipDeviceError(FC_E_NODEVICE, f"FC_HIP_RUNTIME=torch but {path} does not exist")
+    with open(path, "rb") as fh:  # the soname libfc_hip.so was linked against must be the one it carries
+        if b"libamdhip64.so.7" not in fh.read():
+            raise FirecodeHipDeviceError(
+                FC_E_NODEVICE, f"{path} does not carry the soname libamdhip64.so.7 that libfc_hip.so binds to")
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
     return path
 
 
 def load():
     """dlopen the library (no device is touched) and set the prototypes."""
-    global _lib
+    global _lib, HIP_RUNTIME
     if _lib is not None:
         return _lib
-    _share_torch_hip_runtime()
+    import sys
+
+    mode = _hip_runtime_mode()
+    if mode == "torch":
+        _share_torch_hip_runtime()
+    HIP_RUNTIME = "torch" if (mode == "torch" or "torch" in sys.modules) else "system"
     if not os.path.exists(LIB_PATH):
         raise FirecodeHipDeviceError(
             FC_E_NODEVICE,
@@ -246,6 +292,48 @@ def screen_last_kind():
     return int(load().fc_screen_last_kind())
 
 
+def screen_select(kind=0):
+    """0 = automatic, 32 = single-precision screen, 64 = fp64 screen for the prunes that follow."""
+    call("fc_screen_select", int(kind))
+
+
+# ---- the exchange (RCCL behind the C ABI; firecode_amd/dist.py holds the bootstrap) ------------
+def comm_unique_id():
+    buf = np.zeros(128, dtype=np.uint8)
+    call("fc_comm_unique_id", pb(buf))
+    return buf.tobytes()
+
+
+def comm_init(rank, world, unique_id):
+    buf = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+    if buf.shape[0] != 128:
+        raise FirecodeHipInputError(FC_E_INVALID, "the RCCL unique id has 128 bytes")
+    call("fc_comm_init", int(rank), int(world), pb(buf))
+
+
+def comm_destroy():
+    call("fc_comm_destroy")
+
+
+def comm_info():
+    r, w = C.c_int64(0), C.c_int64(1)
+    call("fc_comm_info", C.byref(r), C.byref(w))
+    return r.value, w.value
+
+
+def comm_barrier():
+    call("fc_comm_barrier")
+
+
+def allgather_mask(mask_u8):
+    """(n,) uint8 on every rank -> (world, n) uint8 (fc_allgather_mask; a group of one without comm_init)."""
+    m = u8(mask_u8).reshape(-1)
+    _, world = comm_info()
+    out = np.zeros((world, m.shape[0]), dtype=np.uint8)
+    call("fc_allgather_mask", pb(m), int(m.shape[0]), pb(out))
+    return out
+
+
 def memory_trim():
     """Return the device blocks kept by the library's caching pool to the HIP runtime."""
     call("fc_memory_trim")
@@ -320,6 +408,14 @@ class DeviceEnsemble:
         ms = C.c_double(0)
         call("fc_ensemble_rmsd_values", self.handle, pf(r), C.byref(ms))
         return r, ms.value
+
+    def rmsd_and_max_all(self, want_matrices=True):
+        """Complete alignment of all pairs: ((rmsd, maxdev) matrices or (None, None), kernel ms)."""
+        r = np.zeros((self.N, self.N)) if want_matrices else None
+        m = np.zeros((self.N, self.N)) if want_matrices else None
+        ms = C.c_double(0)
+        call("fc_ensemble_rmsd_and_max_all", self.handle, pf(r), pf(m), C.byref(ms))
+        return r, m, ms.value
 
     def simbits(self, max_rmsd, max_dev, energies=None, max_dE=0.0, row_begin=0, row_end=None):
         row_end = self.N if row_end is None else int(row_end)
@@ -407,6 +503,24 @@ class DeviceEnsemble:
         stats = np.zeros(6, dtype=np.int64)
         call("fc_prune_collect", self.handle, int(slot), int(n_slots), pb(mask), pi(stats))
         return mask.astype(bool), stats
+
+    def prune_sharded(self, max_rmsd, max_dev, min_per_group=20, row_block=0):
+        """fc_prune_rmsd_sharded: this rank's part of the prune over the communicator of
+        ``firecode_amd.dist.comm_init`` (a group of one without it) -> (mask, stats)."""
+        mask = np.zeros(self.N, dtype=np.uint8)
+        stats = np.zeros(6, dtype=np.int64)
+        call("fc_prune_rmsd_sharded", self.handle, float(max_rmsd), float(max_dev), int(min_per_group),
+             int(row_block), pb(mask), pi(stats))
+        return mask.astype(bool), stats
+
+    def bench_prune_sharded(self, max_rmsd, max_dev, reps=1, overlap=True):
+        """``reps`` stream-ordered sharded prunes -> (screen kernel ms, step ms, mask, stats)."""
+        mask = np.zeros(self.N, dtype=np.uint8)
+        stats = np.zeros(6, dtype=np.int64)
+        t_k, t_s = C.c_double(0), C.c_double(0)
+        call("fc_bench_prune_rmsd_sharded", self.handle, float(max_rmsd), float(max_dev), int(reps),
+             int(bool(overlap)), C.byref(t_k), C.byref(t_s), pb(mask), pi(stats))
+        return t_k.value, t_s.value, mask.astype(bool), stats
 
     def bench_prune(self, max_rmsd, max_dev, reps=1, want_mask=True):
         mask = np.zeros(self.N, dtype=np.uint8) if want_mask else None

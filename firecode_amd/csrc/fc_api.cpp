@@ -16,7 +16,8 @@ int launch_prep(const double *, int64_t, int64_t, const int32_t *, int64_t, int,
 int launch_pairs_exact(const fc_ensemble *, const int64_t *, const int64_t *, int64_t, double *,
                        double *, double *);
 int launch_matrix_exact(const fc_ensemble *, double *, double *);
-int launch_rmsd_values(fc_ensemble *, double, double *);
+int launch_rmsd_values(fc_ensemble *, double, double *, double *);
+void screen_select(int);
 int launch_simbits_screen(fc_ensemble *, double);
 int launch_simbits_refine(fc_ensemble *, double, double, const double *, double);
 int launch_align_to_first(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
@@ -75,6 +76,11 @@ int launch_embed_mol_transforms(const double *, int64_t, int64_t, const int64_t 
 int launch_embed_pretransform(const double *, int64_t, int64_t, int64_t, const double *,
                               const double *, int, int64_t, double *);
 int last_screen_kind();
+void comm_teardown();  // fc_comm.cpp
+int comm_rank();
+int comm_world();
+bool comm_ready();
+int comm_allgather_dev(const void *, void *, size_t, int);
 int launch_embed_grid_clash(const double *, int64_t, int64_t, int64_t, const double *, int64_t, int64_t,
                             int64_t, int64_t, double, int64_t, void *, size_t, uint8_t *, int32_t *);
 int launch_string_transforms(const double *, const double *, int64_t, int64_t, const double *, const double *,
@@ -106,6 +112,11 @@ int set_error(int code, const char *fmt, ...) {
 Context &ctx() {
   static Context c;
   return c;
+}
+
+std::recursive_mutex &api_mutex() {
+  static std::recursive_mutex *m = new std::recursive_mutex;  // never destroyed (see pool())
+  return *m;
 }
 
 // ---- caching pool behind DevBuf (fc_common.h) ---------------------------------------------
@@ -190,15 +201,38 @@ void pool_trim() {
 }
 
 
+// everything the context owns on its device: streams, events, pinned staging, cached blocks
+static void context_teardown() {
+  Context &c = ctx();
+  if (!c.ready) return;
+  (void)hipStreamSynchronize(c.stream);
+  for (hipStream_t s : {c.s_screen, c.s_lane[0], c.s_lane[1], c.s_comm})
+    if (s) {
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamDestroy(s);
+    }
+  c.s_screen = c.s_lane[0] = c.s_lane[1] = c.s_comm = nullptr;
+  for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
+  c.ev_pool.clear();
+  for (hipEvent_t *e : {&c.ev0, &c.ev1, &c.ev2, &c.ev3, &c.ev_reset, &c.ev_screened, &c.ev_comm[0], &c.ev_comm[1]})
+    if (*e) {
+      (void)hipEventDestroy(*e);
+      *e = nullptr;
+    }
+  pool_trim();  // cached blocks belong to the device being left
+  (void)hipStreamDestroy(c.own_stream);
+  c.stream = c.own_stream = nullptr;
+  if (c.pinned) (void)hipHostFree(c.pinned);
+  c.pinned = nullptr;
+  c.pinned_bytes = 0;
+  c.mark_after_screen = nullptr;
+  c.ready = false;
+}
+
 static int do_init(int device) {
   Context &c = ctx();
   if (c.ready && c.device == device) return FC_OK;
-  if (c.ready) {
-    (void)hipStreamSynchronize(c.stream);
-    pool_trim();  // cached blocks belong to the device being left
-    (void)hipStreamDestroy(c.own_stream);
-    c.ready = false;
-  }
+  context_teardown();  // a device switch: nothing of the old context survives (ensembles are refused by epoch)
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
@@ -224,7 +258,29 @@ static int do_init(int device) {
   c.n_cu = prop.multiProcessorCount;
   c.hbm = prop.totalGlobalMem;
   std::snprintf(c.name, sizeof c.name, "%s (%s)", prop.name, prop.gcnArchName);
+  ++c.epoch;
   c.ready = true;
+  return FC_OK;
+}
+
+int side_streams() {
+  Context &c = ctx();
+  if (c.s_screen) return FC_OK;
+  // The screen fills every workgroup slot of the chip (three per CU): the small kernels of the
+  // previous prune (and the collective behind them) get compute units only if the dispatcher
+  // prefers them, so their streams have the highest priority and the screens' the lowest.
+  // (Without: a refine launched beside a screen took 450 us instead of 45 and the prune after
+  // next waited for it.)
+  int least = 0, greatest = 0;
+  FC_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  FC_HIP_TRY(hipStreamCreateWithPriority(&c.s_screen, hipStreamNonBlocking, least));
+  FC_HIP_TRY(hipStreamCreateWithPriority(&c.s_lane[0], hipStreamNonBlocking, greatest));
+  FC_HIP_TRY(hipStreamCreateWithPriority(&c.s_lane[1], hipStreamNonBlocking, greatest));
+  FC_HIP_TRY(hipStreamCreateWithPriority(&c.s_comm, hipStreamNonBlocking, greatest));
+  FC_HIP_TRY(hipEventCreateWithFlags(&c.ev_reset, hipEventDisableTiming));
+  FC_HIP_TRY(hipEventCreateWithFlags(&c.ev_screened, hipEventDisableTiming));
+  FC_HIP_TRY(hipEventCreateWithFlags(&c.ev_comm[0], hipEventDisableTiming));
+  FC_HIP_TRY(hipEventCreateWithFlags(&c.ev_comm[1], hipEventDisableTiming));
   return FC_OK;
 }
 
@@ -293,6 +349,8 @@ static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const 
 
 // (re)shape the bit-matrix workspace for a given sharding
 static int ensemble_shard(fc_ensemble *e, int64_t rank, int64_t world, int64_t row_block) {
+  FC_REQUIRE(e->epoch == 0 || e->epoch == ctx().epoch,
+             "this ensemble was created before fc_shutdown / a device switch: create it again");
   FC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world %lld/%lld", (long long)rank,
              (long long)world);
   FC_REQUIRE(row_block >= 32 && row_block % 32 == 0 && row_block <= 4096,
@@ -475,6 +533,7 @@ static int ensemble_twin(fc_ensemble *ens, fc_ensemble **out) {
   if (!ens->twin) {
     std::unique_ptr<fc_ensemble> t(new (std::nothrow) fc_ensemble);
     if (!t) return set_error(FC_E_NOMEM, "host allocation failed");
+    t->epoch = ens->epoch;
     t->N = ens->N, t->A = ens->A, t->Npad = ens->Npad, t->W = ens->W;
     t->Xs.alias(ens->Xs), t->Xa.alias(ens->Xa), t->G.alias(ens->G);
     if (ens->xsf_valid) t->Xsf.alias(ens->Xsf), t->xsf_valid = true;
@@ -501,36 +560,29 @@ int fc_device_count(void) {
   return n;
 }
 
-int fc_init(int device) { return do_init(device); }
+int fc_init(int device) {
+  FC_API_LOCK;
+  return do_init(device);
+}
 
 int fc_shutdown(void) {
-  Context &c = ctx();
-  if (c.ready) {
-    (void)hipStreamSynchronize(c.stream);
-    pool_trim();
-    (void)hipEventDestroy(c.ev0);
-    (void)hipEventDestroy(c.ev1);
-    (void)hipEventDestroy(c.ev2);
-    (void)hipEventDestroy(c.ev3);
-    (void)hipStreamDestroy(c.own_stream);
-    c.stream = c.own_stream = nullptr;
-    if (c.pinned) (void)hipHostFree(c.pinned);
-    c.pinned = nullptr;
-    c.pinned_bytes = 0;
-    c.ready = false;
-  }
+  FC_API_LOCK;
+  comm_teardown();
+  context_teardown();
   return FC_OK;
 }
 
 const char *fc_last_error(void) { return last_error().c_str(); }
 
 int fc_memory_trim(void) {
+  FC_API_LOCK;
   if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
   pool_trim();
   return FC_OK;
 }
 
 int fc_stream_set(void *hip_stream) {
+  FC_API_LOCK;
   FC_TRY(ensure_init());
   Context &c = ctx();
   FC_HIP_TRY(hipStreamSynchronize(c.stream));  // nothing of ours may still be queued on the old one
@@ -539,6 +591,7 @@ int fc_stream_set(void *hip_stream) {
 }
 
 int fc_stream_use(void *hip_stream) {
+  FC_API_LOCK;
   FC_TRY(ensure_init());
   Context &c = ctx();
   c.stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c.own_stream;
@@ -546,6 +599,7 @@ int fc_stream_use(void *hip_stream) {
 }
 
 int fc_device_info(char *name, int64_t name_len, int64_t *n_cu, int64_t *hbm_bytes) {
+  FC_API_LOCK;
   FC_TRY(ensure_init());
   if (name && name_len > 0) std::snprintf(name, (size_t)name_len, "%s", ctx().name);
   if (n_cu) *n_cu = ctx().n_cu;
@@ -556,6 +610,7 @@ int fc_device_info(char *name, int64_t name_len, int64_t *n_cu, int64_t *hbm_byt
 // ---- ensemble ------------------------------------------------------------------
 int fc_ensemble_create(const double *coords, int64_t N, int64_t A, const uint8_t *atom_mask,
                        int center, fc_ensemble **out) {
+  FC_API_LOCK;
   FC_REQUIRE(out != nullptr, "out is NULL");
   *out = nullptr;
   FC_REQUIRE(coords != nullptr || N == 0, "coords is NULL");
@@ -564,17 +619,20 @@ int fc_ensemble_create(const double *coords, int64_t N, int64_t A, const uint8_t
   FC_TRY(ensure_init());
   std::unique_ptr<fc_ensemble> e(new (std::nothrow) fc_ensemble);
   if (!e) return set_error(FC_E_NOMEM, "host allocation failed");
+  e->epoch = ctx().epoch;
   FC_TRY(ensemble_build(coords, N, A, atom_mask, center, e.get()));
   *out = e.release();
   return FC_OK;
 }
 
 int fc_ensemble_destroy(fc_ensemble *ens) {
+  FC_API_LOCK;
   delete ens;
   return FC_OK;
 }
 
 int fc_ensemble_shape(const fc_ensemble *ens, int64_t *N, int64_t *A_selected) {
+  FC_API_LOCK;
   FC_REQUIRE(ens != nullptr, "ens is NULL");
   if (N) *N = ens->N;
   if (A_selected) *A_selected = ens->A;
@@ -584,7 +642,9 @@ int fc_ensemble_shape(const fc_ensemble *ens, int64_t *N, int64_t *A_selected) {
 // ---- a4 ------------------------------------------------------------------------
 int fc_ensemble_rmsd_pairs(fc_ensemble *ens, const int64_t *pair_i, const int64_t *pair_j,
                            int64_t P, double *rmsd_out, double *maxdev_out) {
+  FC_API_LOCK;
   FC_REQUIRE(ens != nullptr, "ens is NULL");
+  FC_REQUIRE(ens->epoch == ctx().epoch, "this ensemble was created before fc_shutdown / a device switch: create it again");
   FC_REQUIRE(P >= 0, "P < 0");
   if (P == 0) return FC_OK;
   FC_REQUIRE(pair_i && pair_j && rmsd_out && maxdev_out, "NULL pointer argument");
@@ -608,6 +668,7 @@ int fc_ensemble_rmsd_pairs(fc_ensemble *ens, const int64_t *pair_i, const int64_
 int fc_kabsch_rmsd_pairs(const double *coords, int64_t N, int64_t A, const uint8_t *atom_mask,
                          const int64_t *pair_i, const int64_t *pair_j, int64_t P, int center,
                          double *rmsd_out, double *maxdev_out) {
+  FC_API_LOCK;
   fc_ensemble *e = nullptr;
   FC_TRY(fc_ensemble_create(coords, N, A, atom_mask, center, &e));
   const int rc = fc_ensemble_rmsd_pairs(e, pair_i, pair_j, P, rmsd_out, maxdev_out);
@@ -615,30 +676,70 @@ int fc_kabsch_rmsd_pairs(const double *coords, int64_t N, int64_t A, const uint8
   return rc;
 }
 
-int fc_ensemble_rmsd_matrix(fc_ensemble *ens, double *rmsd_out, double *maxdev_out) {
-  FC_REQUIRE(ens && rmsd_out && maxdev_out, "NULL pointer argument");
+// all pairs, both outputs: covariance tiles on the fp64 matrix pipe, rotation + explicit rotated
+// difference in the epilogue (k_simbits_screen_mfma<.., 2>); structures beyond the LDS column tile
+// (A > 104) take the one-wave-per-row kernel.  Outputs may both be NULL (timing only).
+static int rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_out, double *ms_kernel) {
   FC_TRY(ensure_init());
   const int64_t N = ens->N;
   if (N == 0) return FC_OK;
+  Context &c = ctx();
   DevBuf dr, dm;
   const size_t bytes = (size_t)N * N * sizeof(double);
   FC_TRY(dr.reserve(bytes));
   FC_TRY(dm.reserve(bytes));
-  FC_HIP_TRY(hipMemsetAsync(dr.p, 0, bytes, ctx().stream));
-  FC_HIP_TRY(hipMemsetAsync(dm.p, 0, bytes, ctx().stream));
-  FC_TRY(launch_matrix_exact(ens, dr.as<double>(), dm.as<double>()));
-  FC_TRY(d2h(rmsd_out, dr.p, bytes));
-  FC_TRY(d2h(maxdev_out, dm.p, bytes));
+  FC_HIP_TRY(hipMemsetAsync(dr.p, 0, bytes, c.stream));
+  FC_HIP_TRY(hipMemsetAsync(dm.p, 0, bytes, c.stream));
+  const size_t lds_m = ((size_t)((ens->A + 3) / 4) * 4 * 3 * 64 + 64 + 128) * sizeof(double) + 1024;
+  const bool tiled = lds_m <= (size_t)160 * 1024 &&
+                     (uint64_t)((ens->A + 3) / 4 * 4) * 3 * (uint64_t)ens->Npad < (1ull << 32);
+  unsigned long long cnt[16] = {0};
+  if (tiled) {
+    FC_TRY(ensemble_shard(ens, 0, 1, 256));  // sizes the pair queue of the fix-up
+    FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 16 * sizeof(uint64_t), c.stream));
+  }
+  FC_HIP_TRY(hipEventRecord(c.ev0, c.stream));
+  if (tiled) FC_TRY(launch_rmsd_values(ens, 0.0, dr.as<double>(), dm.as<double>()));
+  else FC_TRY(launch_matrix_exact(ens, dr.as<double>(), dm.as<double>()));
+  FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
+  if (tiled) FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
+  if (rmsd_out) FC_TRY(d2h(rmsd_out, dr.p, bytes));
+  if (maxdev_out) FC_TRY(d2h(maxdev_out, dm.p, bytes));
   FC_TRY(sync());
-  for (int64_t i = 0; i < N; ++i)
+  if (ms_kernel) {
+    float ms = 0.f;
+    FC_HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    *ms_kernel = ms;
+  }
+  if (tiled && cnt[6] > (unsigned long long)ens->pairq_cap) {
+    // more degenerate pairs than the fix-up queue holds: the plain kernel redoes the matrix
+    FC_TRY(launch_matrix_exact(ens, dr.as<double>(), dm.as<double>()));
+    if (rmsd_out) FC_TRY(d2h(rmsd_out, dr.p, bytes));
+    if (maxdev_out) FC_TRY(d2h(maxdev_out, dm.p, bytes));
+    FC_TRY(sync());
+  }
+  for (int64_t i = 0; i < N && (rmsd_out || maxdev_out); ++i)
     for (int64_t j = i + 1; j < N; ++j) {
-      rmsd_out[j * N + i] = rmsd_out[i * N + j];
-      maxdev_out[j * N + i] = maxdev_out[i * N + j];
+      if (rmsd_out) rmsd_out[j * N + i] = rmsd_out[i * N + j];
+      if (maxdev_out) maxdev_out[j * N + i] = maxdev_out[i * N + j];
     }
   return FC_OK;
 }
 
+int fc_ensemble_rmsd_matrix(fc_ensemble *ens, double *rmsd_out, double *maxdev_out) {
+  FC_API_LOCK;
+  FC_REQUIRE(ens && rmsd_out && maxdev_out, "NULL pointer argument");
+  return rmsd_and_max_all(ens, rmsd_out, maxdev_out, nullptr);
+}
+
+int fc_ensemble_rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_out, double *ms_kernel) {
+  FC_API_LOCK;
+  FC_REQUIRE(ens != nullptr, "ens is NULL");
+  return rmsd_and_max_all(ens, rmsd_out, maxdev_out, ms_kernel);
+}
+
 int fc_ensemble_rmsd_values(fc_ensemble *ens, double *rmsd_out, double *ms_kernel) {
+  FC_API_LOCK;
   FC_REQUIRE(ens != nullptr, "ens is NULL");
   FC_TRY(ensure_init());
   const int64_t N = ens->N;
@@ -651,7 +752,7 @@ int fc_ensemble_rmsd_values(fc_ensemble *ens, double *rmsd_out, double *ms_kerne
   FC_HIP_TRY(hipMemsetAsync(dr.p, 0, bytes, c.stream));
   FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 16 * sizeof(uint64_t), c.stream));
   FC_HIP_TRY(hipEventRecord(c.ev0, c.stream));
-  FC_TRY(launch_rmsd_values(ens, 0.02, dr.as<double>()));
+  FC_TRY(launch_rmsd_values(ens, 0.02, dr.as<double>(), nullptr));
   FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
   unsigned long long cnt[16];
   FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
@@ -673,6 +774,7 @@ int fc_ensemble_rmsd_values(fc_ensemble *ens, double *rmsd_out, double *ms_kerne
 
 int fc_alignment_matrices(const double *p, const double *q, int64_t n_pairs, int64_t A,
                           double *M_out) {
+  FC_API_LOCK;
   FC_REQUIRE(n_pairs >= 0 && A >= 1, "bad shape");
   if (n_pairs == 0) return FC_OK;
   FC_REQUIRE(p && q && M_out, "NULL pointer argument");
@@ -688,6 +790,7 @@ int fc_alignment_matrices(const double *p, const double *q, int64_t n_pairs, int
 
 // ---- a9: align_by_moi (firecode/hypermolecule_class.py:45-86) ------------------------------
 int fc_align_by_moi(const double *coords, int64_t N, int64_t A, const double *masses, double *out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
   if (N == 0) return FC_OK;
   FC_REQUIRE(coords && masses && out, "NULL pointer argument");
@@ -717,6 +820,7 @@ int fc_align_by_moi(const double *coords, int64_t N, int64_t A, const double *ma
 int fc_rmsd_simbits(fc_ensemble *ens, double max_rmsd, double max_dev, const double *energies,
                     double max_dE, int64_t row_begin, int64_t row_end, uint64_t *bits_out,
                     int64_t *n_grey) {
+  FC_API_LOCK;
   FC_REQUIRE(ens && bits_out, "NULL pointer argument");
   FC_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= ens->N, "bad row range");
   FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
@@ -740,6 +844,7 @@ int fc_rmsd_simbits(fc_ensemble *ens, double max_rmsd, double max_dev, const dou
 
 int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const double *energies,
                   double max_dE, int64_t min_per_group, uint8_t *mask_out, int64_t *stats) {
+  FC_API_LOCK;
   FC_REQUIRE(ens && mask_out, "NULL pointer argument");
   FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
   FC_REQUIRE(min_per_group >= 1, "min_per_group must be >= 1");
@@ -764,6 +869,7 @@ int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const doubl
 
 int fc_greedy_prune_from_bits(const uint64_t *bits, int64_t N, int64_t min_per_group,
                               uint8_t *mask_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && min_per_group >= 1, "bad arguments");
   if (N == 0) return FC_OK;
   FC_REQUIRE(bits && mask_out, "NULL pointer argument");
@@ -787,6 +893,7 @@ int fc_greedy_prune_from_bits(const uint64_t *bits, int64_t N, int64_t min_per_g
 int fc_prune_rmsd_begin(fc_ensemble *ens, double max_rmsd, double max_dev, const double *energies,
                         double max_dE, int64_t rank, int64_t world, int64_t row_block,
                         int64_t *stats) {
+  FC_API_LOCK;
   FC_REQUIRE(ens != nullptr, "ens is NULL");
   FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
   FC_TRY(ensure_init());
@@ -812,6 +919,7 @@ int fc_prune_rmsd_begin(fc_ensemble *ens, double max_rmsd, double max_dev, const
 }
 
 int fc_prune_level(fc_ensemble *ens, int64_t k, const uint8_t *mask_in, uint8_t *mask_out) {
+  FC_API_LOCK;
   FC_REQUIRE(ens && mask_in && mask_out, "NULL pointer argument");
   FC_REQUIRE(ens->bits_valid, "fc_prune_rmsd_begin has not been called on this ensemble");
   FC_REQUIRE(k >= 1, "k must be >= 1");
@@ -831,6 +939,7 @@ int fc_prune_level(fc_ensemble *ens, int64_t k, const uint8_t *mask_in, uint8_t 
 }
 
 int fc_prune_similar_pairs(fc_ensemble *ens, uint64_t *pairs_out, int64_t capacity, int64_t *n_out) {
+  FC_API_LOCK;
   FC_REQUIRE(ens && n_out, "NULL pointer argument");
   FC_REQUIRE(ens->bits_valid, "fc_prune_rmsd_begin has not been called on this ensemble");
   FC_TRY(ensure_init());
@@ -851,6 +960,7 @@ int fc_prune_similar_pairs(fc_ensemble *ens, uint64_t *pairs_out, int64_t capaci
 
 int fc_prune_from_pairs(fc_ensemble *ens, const uint64_t *pairs, int64_t n_pairs,
                         int64_t min_per_group, uint8_t *mask_out) {
+  FC_API_LOCK;
   FC_REQUIRE(ens && mask_out && (pairs || n_pairs == 0), "NULL pointer argument");
   FC_REQUIRE(n_pairs >= 0 && min_per_group >= 1, "bad arguments");
   FC_TRY(ensure_init());
@@ -878,6 +988,7 @@ int fc_prune_from_pairs(fc_ensemble *ens, const uint64_t *pairs, int64_t n_pairs
 // ---- device-resident exchange (no host round trip between screen and mask) --------------
 int fc_prune_rmsd_begin_async(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t rank,
                               int64_t world, int64_t row_block) {
+  FC_API_LOCK;
   FC_REQUIRE(ens != nullptr, "ens is NULL");
   FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
   FC_TRY(ensure_init());
@@ -887,49 +998,57 @@ int fc_prune_rmsd_begin_async(fc_ensemble *ens, double max_rmsd, double max_dev,
 }
 
 int fc_ensemble_twin(fc_ensemble *ens, fc_ensemble **twin_out) {
+  FC_API_LOCK;
   FC_REQUIRE(ens && twin_out, "NULL pointer argument");
   FC_TRY(ensure_init());
   return ensemble_twin(ens, twin_out);
 }
 
-int fc_prune_rmsd_begin_split_async(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t rank,
-                                    int64_t world, int64_t row_block, void *screen_stream, int timed) {
-  FC_REQUIRE(ens != nullptr, "ens is NULL");
-  FC_REQUIRE(screen_stream != nullptr, "screen_stream is NULL");
-  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
-  FC_TRY(ensure_init());
+// counters reset on the current stream (behind the last user of this workspace), the screen on
+// `scr` (behind the previous screen), the refine back on the current stream; ev_a / ev_b (may be
+// null): timing events recorded right around the main screen kernel
+static int begin_split(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t rank, int64_t world,
+                       int64_t row_block, hipStream_t scr, hipEvent_t ev_a, hipEvent_t ev_b) {
   FC_TRY(ensemble_shard(ens, rank, world, row_block));
   if (ens->N == 0) return FC_OK;
   Context &c = ctx();
-  static hipEvent_t ev_reset = nullptr, ev_screened = nullptr;
-  if (!ev_reset) FC_HIP_TRY(hipEventCreateWithFlags(&ev_reset, hipEventDisableTiming));
-  if (!ev_screened) FC_HIP_TRY(hipEventCreateWithFlags(&ev_screened, hipEventDisableTiming));
-  hipStream_t const tail = c.stream, scr = static_cast<hipStream_t>(screen_stream);
+  FC_TRY(side_streams());
+  hipStream_t const tail = c.stream;
   struct Restore {
     Context &c;
     hipStream_t s;
     ~Restore() { c.stream = s; }
   } restore{c, tail};
-  // counters reset on the caller's stream (behind the last user of this workspace), the screen
-  // on `screen_stream` (behind the previous screen), the refine back on the caller's stream
   FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, kCounters * sizeof(uint64_t), tail));
-  FC_HIP_TRY(hipEventRecord(ev_reset, tail));
-  FC_HIP_TRY(hipStreamWaitEvent(scr, ev_reset, 0));
+  FC_HIP_TRY(hipEventRecord(c.ev_reset, tail));
+  FC_HIP_TRY(hipStreamWaitEvent(scr, c.ev_reset, 0));
   c.stream = scr;
-  if (timed) FC_HIP_TRY(hipEventRecord(c.ev2, scr));  // the pair costs the stream ~14 us: not every step needs it
-  c.mark_after_screen = timed ? c.ev3 : nullptr;
+  if (ev_a) FC_HIP_TRY(hipEventRecord(ev_a, scr));  // the pair costs the stream ~14 us: not every step needs it
+  c.mark_after_screen = ev_a ? ev_b : nullptr;
   const int rc_screen = launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin);
   c.mark_after_screen = nullptr;
   FC_TRY(rc_screen);
-  FC_HIP_TRY(hipEventRecord(ev_screened, scr));  // behind the verdict and the gated fp64 screen, too
-  FC_HIP_TRY(hipStreamWaitEvent(tail, ev_screened, 0));
+  FC_HIP_TRY(hipEventRecord(c.ev_screened, scr));  // behind the verdict and the gated fp64 screen, too
+  FC_HIP_TRY(hipStreamWaitEvent(tail, c.ev_screened, 0));
   c.stream = tail;
   FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
   ens->bits_valid = true;
   return FC_OK;
 }
 
+int fc_prune_rmsd_begin_split_async(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t rank,
+                                    int64_t world, int64_t row_block, void *screen_stream, int timed) {
+  FC_API_LOCK;
+  FC_REQUIRE(ens != nullptr, "ens is NULL");
+  FC_REQUIRE(screen_stream != nullptr, "screen_stream is NULL");
+  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
+  FC_TRY(ensure_init());
+  return begin_split(ens, max_rmsd, max_dev, rank, world, row_block, static_cast<hipStream_t>(screen_stream),
+                     timed ? ctx().ev2 : nullptr, timed ? ctx().ev3 : nullptr);
+}
+
 int fc_prune_export_pairs_dev(fc_ensemble *ens, uint64_t *dev_out, int64_t cap) {
+  FC_API_LOCK;
   FC_REQUIRE(ens && dev_out, "NULL pointer argument");
   FC_REQUIRE(cap >= 0, "cap must be >= 0");
   FC_REQUIRE(ens->bits_valid, "fc_prune_rmsd_begin has not been called on this ensemble");
@@ -941,6 +1060,7 @@ int fc_prune_export_pairs_dev(fc_ensemble *ens, uint64_t *dev_out, int64_t cap) 
 
 int fc_prune_from_gathered_dev(fc_ensemble *ens, const uint64_t *dev_gathered, int64_t world, int64_t cap,
                                int64_t min_per_group, uint8_t *mask_out, int64_t *stats) {
+  FC_API_LOCK;
   FC_REQUIRE(ens && dev_gathered && mask_out, "NULL pointer argument");
   FC_REQUIRE(world >= 1 && world <= 64 && cap >= 0 && min_per_group >= 1, "bad arguments");
   FC_TRY(ensure_init());
@@ -983,6 +1103,7 @@ int fc_prune_from_gathered_dev(fc_ensemble *ens, const uint64_t *dev_gathered, i
 // GPU busy across prunes (the next screen starts while the host is still in Python).
 int fc_prune_from_gathered_dev_enqueue(fc_ensemble *ens, const uint64_t *dev_gathered, int64_t world,
                                        int64_t cap, int64_t min_per_group, int64_t slot, int64_t n_slots) {
+  FC_API_LOCK;
   FC_REQUIRE(ens && dev_gathered, "NULL pointer argument");
   FC_REQUIRE(world >= 1 && world <= 64 && cap >= 0 && min_per_group >= 1, "bad arguments");
   FC_REQUIRE(n_slots >= 1 && n_slots <= 4096 && slot >= 0 && slot < n_slots, "bad slot %lld of %lld", (long long)slot,
@@ -1010,6 +1131,7 @@ int fc_prune_from_gathered_dev_enqueue(fc_ensemble *ens, const uint64_t *dev_gat
 }
 
 int fc_prune_collect(fc_ensemble *ens, int64_t slot, int64_t n_slots, uint8_t *mask_out, int64_t *stats) {
+  FC_API_LOCK;
   FC_REQUIRE(ens && mask_out, "NULL pointer argument");
   FC_REQUIRE(n_slots >= 1 && slot >= 0 && slot < n_slots, "bad slot");
   FC_TRY(ensure_init());
@@ -1039,6 +1161,7 @@ int fc_prune_collect(fc_ensemble *ens, int64_t slot, int64_t n_slots, uint8_t *m
 // ---- a6 ------------------------------------------------------------------------
 int fc_inertia_moments(const double *coords, int64_t N, int64_t A, const double *masses,
                        double *moments_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
   if (N == 0) return FC_OK;
   FC_REQUIRE(coords && masses && moments_out, "NULL pointer argument");
@@ -1055,6 +1178,7 @@ int fc_inertia_moments(const double *coords, int64_t N, int64_t A, const double 
 int fc_prune_moi(const double *coords, int64_t N, int64_t A, const double *masses,
                  double max_deviation, const double *energies, double max_dE,
                  int64_t min_per_group, uint8_t *mask_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && A >= 1 && min_per_group >= 1, "bad arguments");
   if (N == 0) return FC_OK;
   FC_REQUIRE(coords && masses && mask_out, "NULL pointer argument");
@@ -1091,6 +1215,7 @@ int fc_prune_rmsd_rot_corr(const double *coords, int64_t N, int64_t A, const uin
                            const double *angles, const int32_t *n_angles, int64_t max_angles,
                            double max_rmsd, double max_dev, const double *energies, double max_dE,
                            int64_t min_per_group, uint8_t *mask_out, uint64_t *bits_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && A >= 1 && T >= 0 && min_per_group >= 1, "bad arguments");
   if (N == 0) return FC_OK;
   FC_REQUIRE(coords && heavy_mask && mask_out, "NULL pointer argument");
@@ -1146,6 +1271,7 @@ int fc_prune_rmsd_rot_corr(const double *coords, int64_t N, int64_t A, const uin
 // ---- a8 / a13 --------------------------------------------------------------------
 int fc_align_to_first(const double *coords, int64_t N, int64_t A, const int64_t *idx,
                       int64_t n_idx, double *out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
   if (N == 0) return FC_OK;
   FC_REQUIRE(coords && out, "NULL pointer argument");
@@ -1167,6 +1293,7 @@ int fc_align_to_first(const double *coords, int64_t N, int64_t A, const int64_t 
 
 int fc_rototranslate(const double *coords, int64_t n, int64_t A, const double *R, const double *t,
                      double *out) {
+  FC_API_LOCK;
   FC_REQUIRE(n >= 0 && A >= 1, "bad shape");
   if (n == 0) return FC_OK;
   FC_REQUIRE(coords && R && t && out, "NULL pointer argument");
@@ -1187,6 +1314,7 @@ static const int64_t kMaxLdsAtoms = 160 * 1024 / 24;  // one structure per wavef
 
 int fc_clash_self(const double *coords, int64_t N, int64_t A, double lo, double hi,
                   int64_t *counts_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
   if (N == 0) return FC_OK;
   FC_REQUIRE(coords && counts_out, "NULL pointer argument");
@@ -1203,6 +1331,7 @@ int fc_clash_self(const double *coords, int64_t N, int64_t A, double lo, double 
 int fc_clash_fragments(const double *coords, int64_t N, int64_t A, const int64_t *ids,
                        int64_t n_ids, double thresh, int64_t max_clashes, int64_t *counts_out,
                        uint8_t *pass_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
   FC_REQUIRE(ids != nullptr && (n_ids == 2 || n_ids == 3), "ids must hold 2 or 3 fragment lengths");
   int64_t tot = 0;
@@ -1229,6 +1358,7 @@ int fc_clash_fragments(const double *coords, int64_t N, int64_t A, const int64_t
 
 int fc_clash_graph(const double *coords, int64_t N, int64_t A, const uint8_t *adj, double thresh,
                    int64_t *counts_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && A >= 1, "bad shape");
   if (N == 0) return FC_OK;
   FC_REQUIRE(coords && adj && counts_out, "NULL pointer argument");
@@ -1247,6 +1377,7 @@ int fc_clash_graph(const double *coords, int64_t N, int64_t A, const uint8_t *ad
 int fc_fitness_check(const double *coords, int64_t N, int64_t A, const int64_t *pairs,
                      const double *targets, int64_t C, double threshold, double *error_out,
                      uint8_t *pass_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && A >= 1 && C >= 0, "bad shape");
   if (N == 0) return FC_OK;
   FC_REQUIRE(coords && pass_out && (C == 0 || (pairs && targets)), "NULL pointer argument");
@@ -1271,6 +1402,7 @@ int fc_embed_poses_clash(const double *m1, int64_t n1, int64_t A1, const double 
                          const double *t1, const double *R2, const double *t2, int64_t P,
                          double thresh, int64_t max_clashes, int64_t *counts_out,
                          uint8_t *pass_out, double *poses_out) {
+  FC_API_LOCK;
   FC_REQUIRE(n1 >= 1 && n2 >= 1 && A1 >= 1 && A2 >= 1 && P >= 0, "bad shape");
   if (P == 0) return FC_OK;
   FC_REQUIRE(m1 && m2 && c1 && c2 && R1 && t1 && R2 && t2, "NULL pointer argument");
@@ -1315,6 +1447,7 @@ int fc_embed_mol_transforms(const double *coords, int64_t n, int64_t A, const in
                             int64_t nr, const double *pivot_start, const double *pivot_end,
                             int64_t mol, const double *angles, int64_t na, double *R_out,
                             double *t_out) {
+  FC_API_LOCK;
   FC_TRY(check_embed_mol(coords, n, A, reactive, nr, pivot_start, pivot_end, angles, na));
   FC_REQUIRE((mol == 0 || mol == 1) && R_out && t_out, "bad arguments");
   FC_TRY(ensure_init());
@@ -1414,6 +1547,7 @@ int fc_embed_grid_clash(const double *m1, int64_t n1, int64_t A1, const int64_t 
                         const double *ps2, const double *pe2, const double *angles1, int64_t na1,
                         const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
                         uint8_t *pass_out, int32_t *counts_out, double *ms_kernel) {
+  FC_API_LOCK;
   return embed_grid(m1, n1, A1, reactive1, nr1, ps1, pe1, m2, n2, A2, reactive2, nr2, ps2, pe2, angles1,
                     na1, angles2, na2, thresh, max_clashes, pass_out, counts_out, ms_kernel, 0.0, nullptr);
 }
@@ -1424,6 +1558,7 @@ int fc_embed_grid_dedupe(const double *m1, int64_t n1, int64_t A1, const int64_t
                          const double *ps2, const double *pe2, const double *angles1, int64_t na1,
                          const double *angles2, int64_t na2, double thresh, int64_t max_clashes,
                          double rmsd_thr, uint8_t *pass_out, uint8_t *accept_out) {
+  FC_API_LOCK;
   FC_REQUIRE(accept_out != nullptr, "accept_out is NULL");
   return embed_grid(m1, n1, A1, reactive1, nr1, ps1, pe1, m2, n2, A2, reactive2, nr2, ps2, pe2, angles1,
                     na1, angles2, na2, thresh, max_clashes, pass_out, nullptr, nullptr, rmsd_thr, accept_out);
@@ -1437,6 +1572,7 @@ int fc_embed_trimolecular(const double *const coords[3], const int64_t n_conf[3]
                           const double *norms, const double *ua, int64_t U, const int32_t *aidx, int64_t S,
                           double thresh, int64_t max_clashes, double rmsd_thr, double *dirs_out,
                           double *Rt_out, uint8_t *pass_out, uint8_t *accept_out) {
+  FC_API_LOCK;
   FC_REQUIRE(coords && n_conf && n_atoms && reactive && n_reactive, "NULL pointer argument");
   FC_REQUIRE(J >= 0 && U >= 1 && S >= 1, "bad shape");
   if (J == 0) return FC_OK;
@@ -1513,6 +1649,7 @@ int fc_string_embed(const double *m1, int64_t n1, int64_t A1, const double *cent
                     const double *angles, int64_t nA, const int64_t *quads, int64_t Q,
                     double thresh, int64_t max_clashes, double tfd_thresh, uint8_t *pass_out,
                     uint8_t *accept_out, double *R2_out, double *t2_out) {
+  FC_API_LOCK;
   FC_REQUIRE(m1 && m2 && centers1 && orbvecs1 && centers2 && orbvecs2 && angles && pass_out && accept_out,
              "NULL pointer argument");
   FC_REQUIRE(n1 >= 1 && n2 >= 1 && A1 >= 1 && A2 >= 1 && K1 >= 1 && K2 >= 1 && nA >= 1 && Q >= 0, "bad shape");
@@ -1620,6 +1757,7 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
 int fc_torsion_scan(const double *base, int64_t A, const int64_t *torsions, int64_t T,
                     const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
                     int64_t backoff_deg, double *coords_out, int64_t *rotated_bonds_out) {
+  FC_API_LOCK;
   FC_REQUIRE(S == 0 || coords_out != nullptr, "NULL pointer argument");
   return torsion_scan_impl(base, A, torsions, T, rotmasks, angles, S, thresh, backoff_deg, nullptr, 0, coords_out,
                            rotated_bonds_out, nullptr);
@@ -1629,6 +1767,7 @@ int fc_torsion_scan_fingerprints(const double *base, int64_t A, const int64_t *t
                                  const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
                                  int64_t backoff_deg, const int64_t *quads, int64_t Q, double *tf_out,
                                  int64_t *rotated_bonds_out, double *coords_out) {
+  FC_API_LOCK;
   FC_REQUIRE(S == 0 || tf_out != nullptr, "NULL pointer argument");
   return torsion_scan_impl(base, A, torsions, T, rotmasks, angles, S, thresh, backoff_deg, quads, Q, coords_out,
                            rotated_bonds_out, tf_out);
@@ -1636,6 +1775,7 @@ int fc_torsion_scan_fingerprints(const double *base, int64_t A, const int64_t *t
 
 int fc_torsion_fingerprint(const double *coords, int64_t N, int64_t A, const int64_t *quads,
                            int64_t Q, double *tf_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && A >= 1 && Q >= 0, "bad shape");
   if (N == 0 || Q == 0) return FC_OK;
   FC_REQUIRE(coords && quads && tf_out, "NULL pointer argument");
@@ -1652,6 +1792,7 @@ int fc_torsion_fingerprint(const double *coords, int64_t N, int64_t A, const int
 
 int fc_tfd_simbits(const double *tf, int64_t N, int64_t Q, double thresh, int64_t row_begin,
                    int64_t row_end, uint64_t *bits_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && Q >= 0, "bad shape");
   FC_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= N, "bad row range");
   if (row_end == row_begin) return FC_OK;
@@ -1669,6 +1810,7 @@ int fc_tfd_simbits(const double *tf, int64_t N, int64_t Q, double thresh, int64_
 }
 
 int fc_tfd_first_match(const double *tf, int64_t N, int64_t Q, double thresh, int64_t *first_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && Q >= 0, "bad shape");
   if (N == 0) return FC_OK;
   FC_REQUIRE(first_out && (tf || Q == 0), "NULL pointer argument");
@@ -1688,6 +1830,7 @@ int fc_tfd_first_match(const double *tf, int64_t N, int64_t Q, double thresh, in
 }
 
 int fc_tfd_ladder_from_first_match(const int64_t *first_match, int64_t N, uint8_t *mask_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0, "bad shape");
   if (N == 0) return FC_OK;
   FC_REQUIRE(first_match && mask_out, "NULL pointer argument");
@@ -1697,6 +1840,7 @@ int fc_tfd_ladder_from_first_match(const int64_t *first_match, int64_t N, uint8_
 }
 
 int fc_tfd_prune(const double *tf, int64_t N, int64_t Q, double thresh, uint8_t *mask_out) {
+  FC_API_LOCK;
   FC_REQUIRE(N >= 0 && Q >= 0, "bad shape");
   if (N == 0) return FC_OK;
   FC_REQUIRE(mask_out != nullptr, "NULL pointer argument");
@@ -1706,6 +1850,7 @@ int fc_tfd_prune(const double *tf, int64_t N, int64_t Q, double thresh, uint8_t 
 }
 
 int fc_debug_pyset_order_ints(const int64_t *keys, int64_t n, int64_t *order_out, int64_t *n_out) {
+  FC_API_LOCK;
   FC_REQUIRE(n >= 0 && (keys || n == 0) && order_out && n_out, "bad arguments");
   for (int64_t k = 0; k < n; ++k) FC_REQUIRE(keys[k] >= 0, "keys must be non-negative");
   std::vector<int64_t> o;
@@ -1716,6 +1861,7 @@ int fc_debug_pyset_order_ints(const int64_t *keys, int64_t n, int64_t *order_out
 }
 
 int fc_debug_pyset_order_pairs(const int64_t *pairs, int64_t n, int64_t *order_out, int64_t *n_out) {
+  FC_API_LOCK;
   FC_REQUIRE(n >= 0 && (pairs || n == 0) && order_out && n_out, "bad arguments");
   std::vector<int64_t> o;
   pyset_order_pairs(pairs, n, o);
@@ -1726,6 +1872,7 @@ int fc_debug_pyset_order_pairs(const int64_t *pairs, int64_t n, int64_t *order_o
 
 int fc_xyz_write(const char *path, const char *const *atoms, int64_t A, const double *coords,
                  int64_t N, const char *label, int mode) {
+  FC_API_LOCK;
   FC_REQUIRE(path && atoms && label && (coords || N == 0), "NULL pointer argument");
   FC_REQUIRE(A >= 1 && N >= 0 && (mode == 0 || mode == 1), "bad arguments");
   for (int64_t a = 0; a < A; ++a) FC_REQUIRE(atoms[a] != nullptr, "atoms[%lld] is NULL", (long long)a);
@@ -1733,11 +1880,13 @@ int fc_xyz_write(const char *path, const char *const *atoms, int64_t A, const do
 }
 
 int fc_xyz_scan(const char *path, int64_t *N_out, int64_t *A_out) {
+  FC_API_LOCK;
   FC_REQUIRE(path && N_out && A_out, "NULL pointer argument");
   return xyz_read(path, N_out, A_out, nullptr, nullptr);
 }
 
 int fc_xyz_read(const char *path, int64_t N, int64_t A, char *atoms_out, double *coords_out) {
+  FC_API_LOCK;
   FC_REQUIRE(path && atoms_out && coords_out, "NULL pointer argument");
   FC_REQUIRE(N >= 0 && A >= 0, "bad shape");
   return xyz_read(path, &N, &A, atoms_out, coords_out);
@@ -1760,7 +1909,7 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
                           int64_t min_per_group, bool overlap, int64_t stride, double *screen_ms_sum,
                           double *total_ms) {
   Context &c = ctx();
-  static std::vector<hipEvent_t> ev;  // 4 per prune: around the screen kernel, counters reset, screen phase done
+  std::vector<hipEvent_t> &ev = c.ev_pool;  // 4 per prune: around the screen kernel, counters reset, screen phase done
   while ((int64_t)ev.size() < 4 * n + 4) {
     hipEvent_t e = nullptr;
     FC_HIP_TRY(hipEventCreate(&e));
@@ -1768,7 +1917,6 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
   }
   hipEvent_t const ev_begin = ev[4 * n], ev_end = ev[4 * n + 1];
   FC_TRY(pinned_reserve((size_t)n * (size_t)stride * sizeof(uint64_t)));
-  static hipStream_t s_screen = nullptr, s_lane[2] = {nullptr, nullptr};
   static const int64_t stride_ev = [] {
     const char *v = getenv("FC_BENCH_EVENT_STRIDE");
     const long k = v ? std::strtol(v, nullptr, 10) : 8;
@@ -1781,17 +1929,8 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
     ~Restore() { c.stream = s; }
   } restore{c, home};
   const bool lanes = overlap && n > 1;
-  if (lanes && !s_screen) {
-    // The screen fills every workgroup slot of the chip (three per CU): the small kernels of the
-    // previous prune get compute units only if the dispatcher prefers them, so their streams have
-    // the highest priority and the screens' the lowest.  (Without: a refine launched beside a
-    // screen took 450 us instead of 45 and the prune after next waited for it.)
-    int least = 0, greatest = 0;
-    FC_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    FC_HIP_TRY(hipStreamCreateWithPriority(&s_screen, hipStreamNonBlocking, least));
-    FC_HIP_TRY(hipStreamCreateWithPriority(&s_lane[0], hipStreamNonBlocking, greatest));
-    FC_HIP_TRY(hipStreamCreateWithPriority(&s_lane[1], hipStreamNonBlocking, greatest));
-  }
+  if (lanes) FC_TRY(side_streams());
+  hipStream_t const s_screen = c.s_screen, s_lane[2] = {c.s_lane[0], c.s_lane[1]};
   // everything enqueued here is ordered behind what the home stream already holds (also what
   // makes pool blocks released by earlier calls safe to reuse on the other streams)
   FC_HIP_TRY(hipEventRecord(ev_begin, home));
@@ -1855,6 +1994,7 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
 
 int fc_prune_rmsd_many(fc_ensemble *const *ens, int64_t n, double max_rmsd, double max_dev,
                        int64_t min_per_group, uint8_t *const *mask_out, int64_t *survivors_out) {
+  FC_API_LOCK;
   FC_REQUIRE(n >= 0 && n <= 4096, "n=%lld outside 0..4096", (long long)n);
   if (n == 0) return FC_OK;
   FC_REQUIRE(ens && mask_out, "NULL pointer argument");
@@ -1904,12 +2044,217 @@ int fc_prune_rmsd_many(fc_ensemble *const *ens, int64_t n, double max_rmsd, doub
   return FC_OK;
 }
 
+}  // extern "C"
+
+// ---- sharded prune over the ranks of the communicator (fc_comm.cpp), no host round trips -------
+// Prune k works on workspace k&1 (the ensemble and its twin) and on lane k&1: counters reset,
+// refine, export of the rank's similar-pair list, the all-gather (RCCL, on its own stream between
+// two events) and the ladder replay; all screens go, in order, to the screen stream.  So the ~0.13 ms
+// behind a screen run beside the next screen.  overlap = false: everything on the current stream.
+static int sharded_pipeline(fc_ensemble *ens, int64_t steps, double max_rmsd, double max_dev,
+                            int64_t min_per_group, int64_t row_block, bool overlap, double *screen_ms_mean,
+                            double *total_ms) {
+  Context &c = ctx();
+  const int64_t rank = comm_rank(), world = comm_world();
+  const int64_t cap = 1024 + 4 * ens->N / world;  // pairs a rank can send in the fixed-size message
+  FC_TRY(side_streams());
+  overlap = overlap && steps > 1;
+  fc_ensemble *work[2] = {ens, ens};
+  if (overlap) FC_TRY(ensemble_twin(ens, &work[1]));
+  for (fc_ensemble *w : work) {  // every grow-only buffer reaches its size before the streams fork
+    FC_TRY(ensemble_shard(w, rank, world, row_block));
+    FC_TRY(w->msg_send.reserve((size_t)(cap + 1) * sizeof(uint64_t)));
+    const size_t recv_bytes = (size_t)world * (size_t)(cap + 1) * sizeof(uint64_t);
+    if (w->msg_recv.bytes < recv_bytes || !w->msg_recv.p) {  // a new block starts as "every rank sent an empty list"
+      FC_TRY(w->msg_recv.reserve(recv_bytes));
+      FC_HIP_TRY(hipMemsetAsync(w->msg_recv.p, 0, w->msg_recv.bytes, c.stream));
+    }
+    FC_TRY(w->gathered.reserve((size_t)std::max<int64_t>(world * cap, 1) * sizeof(uint64_t)));
+  }
+  std::vector<hipEvent_t> &ev = c.ev_pool;
+  while ((int64_t)ev.size() < 2 * steps + 4) {
+    hipEvent_t e = nullptr;
+    FC_HIP_TRY(hipEventCreate(&e));
+    ev.push_back(e);
+  }
+  static const int64_t stride_ev = [] {
+    const char *v = getenv("FC_BENCH_EVENT_STRIDE");
+    const long k = v ? std::strtol(v, nullptr, 10) : 8;
+    return (int64_t)(k >= 1 && k <= 4096 ? k : 8);
+  }();
+  hipEvent_t const ev_begin = ev[2 * steps], ev_end = ev[2 * steps + 1];
+  hipStream_t const home = c.stream;
+  struct Restore {
+    Context &c;
+    hipStream_t s;
+    ~Restore() { c.stream = s; }
+  } restore{c, home};
+  FC_HIP_TRY(hipEventRecord(ev_begin, home));
+  for (hipStream_t s : {c.s_screen, c.s_lane[0], c.s_lane[1], c.s_comm}) FC_HIP_TRY(hipStreamWaitEvent(s, ev_begin, 0));
+  for (int64_t k = 0; k < steps; ++k) {
+    fc_ensemble *e = work[k & 1];
+    c.stream = overlap ? c.s_lane[k & 1] : home;
+    const bool timed = k % stride_ev == 0;
+    FC_TRY(begin_split(e, max_rmsd, max_dev, rank, world, row_block, overlap ? c.s_screen : c.stream,
+                       timed ? ev[2 * k] : nullptr, timed ? ev[2 * k + 1] : nullptr));
+    FC_TRY(fc_prune_export_pairs_dev(e, e->msg_send.as<uint64_t>(), cap));
+    FC_TRY(comm_allgather_dev(e->msg_send.p, e->msg_recv.p, (size_t)(cap + 1) * sizeof(uint64_t), (int)(k & 1)));
+    FC_TRY(fc_prune_from_gathered_dev_enqueue(e, e->msg_recv.as<uint64_t>(), world, cap, min_per_group, k, steps));
+  }
+  c.stream = home;
+  if (overlap)
+    for (hipStream_t s : {c.s_lane[0], c.s_lane[1], c.s_screen}) {
+      FC_HIP_TRY(hipEventRecord(ev[2 * steps + 2], s));
+      FC_HIP_TRY(hipStreamWaitEvent(home, ev[2 * steps + 2], 0));
+    }
+  FC_HIP_TRY(hipEventRecord(ev_end, home));
+  FC_HIP_TRY(hipEventSynchronize(ev_end));
+  if (total_ms) {
+    float t = 0.f;
+    FC_HIP_TRY(hipEventElapsedTime(&t, ev_begin, ev_end));
+    *total_ms = t;
+  }
+  if (screen_ms_mean) {
+    double sum = 0.0;
+    int64_t n_timed = 0;
+    for (int64_t k = 0; k < steps; k += stride_ev) {
+      float a = 0.f;
+      FC_HIP_TRY(hipEventElapsedTime(&a, ev[2 * k], ev[2 * k + 1]));
+      sum += a;
+      ++n_timed;
+    }
+    *screen_ms_mean = sum / (double)std::max<int64_t>(n_timed, 1);
+  }
+  return FC_OK;
+}
+
+static int64_t owned_pairs(const fc_ensemble *ens) {
+  int64_t n = 0;
+  const int64_t nb = ceil_div(ens->N, ens->row_block);
+  for (int64_t lb = 0, b; (b = global_block(lb, ens->rank, ens->world)) < nb; ++lb)
+    for (int64_t i = b * ens->row_block; i < std::min(ens->N, (b + 1) * ens->row_block); ++i) n += ens->N - 1 - i;
+  return n;
+}
+
+// dense similarity (a rank's candidate queue overflowed or its list did not fit the message): one
+// all-gather of the (N,) mask per ladder level; every rank takes this path together because every
+// rank saw the same gathered headers
+static int sharded_levels_fallback(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t min_per_group,
+                                   int64_t row_block, uint8_t *mask_out, int64_t *stats) {
+  const int64_t rank = comm_rank(), world = comm_world(), N = ens->N;
+  int64_t st[6] = {0};
+  FC_TRY(fc_prune_rmsd_begin(ens, max_rmsd, max_dev, nullptr, 0.0, rank, world, row_block, st));
+  std::vector<uint8_t> mask((size_t)N, 1), mine((size_t)N), all((size_t)N * (size_t)world);
+  for (int64_t k : kLadder) {
+    int64_t alive = 0;
+    for (uint8_t m : mask) alive += m;
+    if (!(k == 1 || min_per_group * k < alive)) continue;
+    FC_TRY(fc_prune_level(ens, k, mask.data(), mine.data()));
+    FC_TRY(fc_allgather_mask(mine.data(), N, all.data()));
+    for (int64_t i = 0; i < N; ++i) {
+      uint8_t m = 1;
+      for (int64_t r = 0; r < world; ++r) m = std::min(m, all[(size_t)r * N + i]);
+      mask[(size_t)i] = m;
+    }
+  }
+  int64_t alive = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    mask_out[i] = mask[(size_t)i];
+    alive += mask[(size_t)i];
+  }
+  if (stats) {
+    for (int k = 0; k < 5; ++k) stats[k] = st[k];
+    stats[5] = alive;
+  }
+  return FC_OK;
+}
+
+static int sharded_collect(fc_ensemble *ens, int64_t steps, bool overlap, uint8_t *mask_out, int64_t *stats,
+                           bool *all_ok) {
+  const int64_t W = ens->W;
+  *all_ok = true;
+  int64_t survivors = 0;
+  for (int64_t k = 0; k < steps; ++k)
+    if (!ladder_collect(ens, k, k == steps - 1 ? mask_out : nullptr, nullptr, &survivors, nullptr)) *all_ok = false;
+  if (*all_ok && stats) {
+    const unsigned long long *local = static_cast<const unsigned long long *>(ctx().pinned) +
+                                      (size_t)steps * (size_t)(W + 16) + (size_t)(steps - 1) * 8;
+    stats[0] = owned_pairs(ens);
+    stats[1] = (int64_t)local[1];
+    stats[2] = (int64_t)local[2];
+    stats[3] = (int64_t)local[3];
+    stats[4] = 0;
+    stats[5] = survivors;
+  }
+  (void)overlap;
+  return FC_OK;
+}
+
+extern "C" {
+
+int fc_prune_rmsd_sharded(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t min_per_group,
+                          int64_t row_block, uint8_t *mask_out, int64_t *stats) {
+  FC_API_LOCK;
+  FC_REQUIRE(ens && mask_out, "NULL pointer argument");
+  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0 && min_per_group >= 1, "bad arguments");
+  FC_TRY(ensure_init());
+  if (ens->N == 0) return FC_OK;
+  if (row_block <= 0) row_block = default_row_block();
+  bool ok = false;
+  const int64_t world = comm_world();
+  const int64_t cap = 1024 + 4 * ens->N / world;
+  const bool device_path = (uint64_t)world * (uint64_t)cap <= kPairLadderCap && (size_t)2 * ens->W * sizeof(uint64_t) <= 60 * 1024;
+  if (device_path) {
+    double ms = 0.0;
+    FC_TRY(sharded_pipeline(ens, 1, max_rmsd, max_dev, min_per_group, row_block, false, &ms, nullptr));
+    FC_TRY(sharded_collect(ens, 1, false, mask_out, stats, &ok));
+    if (ok && stats) stats[4] = (int64_t)(ms * 1e6);
+  }
+  if (!ok) FC_TRY(sharded_levels_fallback(ens, max_rmsd, max_dev, min_per_group, row_block, mask_out, stats));
+  return FC_OK;
+}
+
+int fc_bench_prune_rmsd_sharded(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps, int overlap,
+                                double *ms_screen_kernel, double *ms_step, uint8_t *mask_out, int64_t *stats) {
+  FC_API_LOCK;
+  FC_REQUIRE(ens && reps >= 1 && reps <= 1024, "bad arguments");
+  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
+  FC_TRY(ensure_init());
+  FC_REQUIRE(ens->N > 0, "empty ensemble");
+  const int64_t row_block = default_row_block();
+  double ms = 0.0, total = 0.0;
+  FC_TRY(sharded_pipeline(ens, reps, max_rmsd, max_dev, 20, row_block, overlap != 0, &ms, &total));
+  bool ok = false;
+  std::vector<uint8_t> scratch;
+  if (!mask_out) {
+    scratch.resize((size_t)ens->N);
+    mask_out = scratch.data();
+  }
+  FC_TRY(sharded_collect(ens, reps, overlap != 0, mask_out, stats, &ok));
+  if (!ok) FC_TRY(sharded_levels_fallback(ens, max_rmsd, max_dev, 20, row_block, mask_out, stats));
+  if (ms_screen_kernel) *ms_screen_kernel = ms;
+  if (ms_step) *ms_step = total / (double)reps;
+  return FC_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
 // ---- bench hook ----------------------------------------------------------------------
 int fc_screen_last_kind(void) { return last_screen_kind(); }
+
+int fc_screen_select(int kind) {
+  FC_API_LOCK;
+  FC_REQUIRE(kind == 0 || kind == 32 || kind == 64, "kind must be 0 (automatic), 32 or 64");
+  screen_select(kind);
+  return FC_OK;
+}
 
 int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
                         double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
                         int64_t *stats) {
+  FC_API_LOCK;
   FC_REQUIRE(ens && reps >= 1 && reps <= 4096, "bad arguments");
   FC_TRY(ensure_init());
   FC_TRY(ensemble_shard(ens, 0, 1, default_row_block()));

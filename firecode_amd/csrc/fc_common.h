@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -56,7 +57,21 @@ struct Context {
   // pinned host staging for small device->host results (truly asynchronous copies)
   void *pinned = nullptr;
   size_t pinned_bytes = 0;
+  // side streams and events of the pipelined prunes (prune_pipeline, the sharded steps): created on
+  // first use by side_streams(), destroyed by fc_shutdown and when fc_init moves to another device
+  hipStream_t s_screen = nullptr, s_lane[2] = {nullptr, nullptr}, s_comm = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  hipEvent_t ev_reset = nullptr, ev_screened = nullptr, ev_comm[2] = {nullptr, nullptr};
+  // incremented by every (re)initialisation: an fc_ensemble remembers the epoch it was built in and
+  // is refused afterwards (its buffers and workspaces belong to the context that is gone)
+  uint64_t epoch = 0;
 };
+// Threading contract (include/fc_hip.h): every extern "C" entry point that touches the context holds
+// this lock for its whole duration -- two host threads may call the library, their calls run one
+// after the other.  Recursive: entry points are also used as building blocks of others.
+std::recursive_mutex &api_mutex();
+#define FC_API_LOCK std::lock_guard<std::recursive_mutex> fc_api_lock_guard(::fc::api_mutex())
+int side_streams();  // creates Context::s_screen / s_lane / s_comm and the ordering events once
 int pinned_reserve(size_t bytes);  // grows ctx().pinned
 Context &ctx();
 int ensure_init();  // lazy init on device 0 (or the one given to fc_init)
@@ -65,8 +80,10 @@ int ensure_init();  // lazy init on device 0 (or the one given to fc_init)
 // hipMalloc / hipFree cost ~0.1-0.3 ms each and hipFree synchronises the device; a drop-in
 // call (host arrays in, mask out) makes 5-15 temporaries.  Released blocks are therefore
 // kept (size classes: powers of two up to 1 MiB, multiples of 2 MiB above) and handed out
-// again.  Reuse is safe because everything of this library is enqueued on ONE stream
-// (fc_stream_set drains the old one): the next user of a block is ordered behind the last.
+// again.  Reuse is safe because a block's next user is ordered behind its last one: entry points
+// enqueue on ONE stream (fc_stream_set drains the old one), and every multi-stream region
+// (prune_pipeline, the sharded steps) starts behind an event recorded on that stream, ends with a
+// wait on all its side streams, and sizes its grow-only buffers before it forks.
 // FC_POOL_MB caps what is kept (default 2048, 0 = no caching); fc_memory_trim() empties it.
 void *pool_take(size_t n, size_t *capacity);  // nullptr when the device is out of memory
 void pool_give(void *p, size_t capacity);
@@ -75,13 +92,17 @@ void pool_trim();
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
+  uint64_t epoch = 0;  // context epoch the block was taken in: blocks of a context that is gone are freed, not pooled
   bool owned = true;  // false: a view of another DevBuf's block (see alias())
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p && owned) pool_give(p, bytes);
+    if (p && owned) {
+      if (ctx().ready && epoch == ctx().epoch) pool_give(p, bytes);
+      else (void)hipFree(p);
+    }
     p = nullptr;
     bytes = 0;
     owned = true;
@@ -91,6 +112,7 @@ struct DevBuf {
     release();
     p = o.p;
     bytes = o.bytes;
+    epoch = o.epoch;
     owned = false;
   }
   // grow-only allocation; contents are NOT preserved
@@ -102,6 +124,7 @@ struct DevBuf {
     p = pool_take(n, &cap);
     if (!p) return set_error(FC_E_NOMEM, "device allocation of %zu bytes failed", n);
     bytes = cap;
+    epoch = ctx().epoch;
     return FC_OK;
   }
   template <class T>
@@ -154,6 +177,7 @@ inline int64_t local_block_count(int64_t n_gblocks, int64_t rank, int64_t world)
 
 // ---- resident ensemble -----------------------------------------------------------
 struct fc_ensemble {
+  uint64_t epoch = 0;          // fc::Context::epoch at creation
   int64_t N = 0, A = 0;        // conformers, selected atoms
   int64_t Npad = 0, W = 0;     // N rounded up to 64; words per bit row
   fc::DevBuf Xs;               // [(a*3+c)*Npad + n] doubles, zero padded
@@ -173,6 +197,7 @@ struct fc_ensemble {
   int64_t item_key[4] = {-1, -1, -1, -1}, item_total = 0;
   std::vector<uint64_t> item_host;  // source of the (asynchronous) upload: lives as long as the ensemble
   fc::DevBuf gathered;         // world x cap uint64: all ranks' similar pairs, compacted (device exchange)
+  fc::DevBuf msg_send, msg_recv;  // this workspace's message of the all-gather: cap + 1 / world x (cap + 1) uint64
   fc::DevBuf energies;         // N doubles (optional)
   fc::DevBuf maskA, maskB;     // N bytes each
   fc::DevBuf mbits;            // W uint64 active-flag words

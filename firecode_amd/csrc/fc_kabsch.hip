@@ -555,14 +555,16 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // eigenvalue (Newton) and stores rmsd(i, j) into a dense (N, N) matrix instead of
 // screening; pairs with rmsd below `A_thr2` (reused as the small-rmsd^2 * A limit)
 // are queued for the exact explicit-difference evaluation.
-template <int NW, bool VALUES = false>
+template <int NW, int MODE = 0>
 __global__ void __launch_bounds__(NW * 64, 2)
 k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N,
                       int64_t Npad, int A, double A_thr2, int IB, int64_t rank, int64_t world,
                       uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
                       unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
                       unsigned long long Q, const uint64_t *__restrict__ item_table, unsigned long long n_items,
-                      double *__restrict__ rmsd_out = nullptr, const unsigned long long *__restrict__ gate = nullptr) {
+                      double *__restrict__ rmsd_out = nullptr, const unsigned long long *__restrict__ gate = nullptr,
+                      double *__restrict__ maxdev_out = nullptr) {
+  constexpr bool VALUES = MODE != 0;  // 1: rmsd values (Newton), 2: (rmsd, maxdev) by explicit difference
   // behind a speculative fp32 screen: run only when k_screen_verdict asked for it
   if (gate != nullptr && *gate == 0ull) return;
   extern __shared__ double lds[];
@@ -767,6 +769,61 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
         const int j = (int)j0 + cs * 16 + l15;
         const double Gq = ldsG[cs * 16 + l15];
         uint64_t mr[4] = {0, 0, 0, 0};
+        if (MODE == 2) {
+          // complete alignment (a4: rmsd_and_max): rotation of each of the lane's four pairs from its
+          // covariance (Newton eigenvalue + adjugate column), then ONE pass over the atoms for the
+          // four of them -- the column conformer from the LDS tile (shared by the four pairs), the
+          // four row conformers from L1/L2 (16 lanes read the same address) -- accumulating the
+          // explicit rotated difference, which is what the reference computes.  Pairs whose largest
+          // eigenvalue is not clearly simple are queued for k_pairs_fix (Jacobi sweeps).
+          // (two rows at a time: four rotations next to the 72 accumulator registers of the other
+          // sub-tile spill)
+          const double *__restrict__ qcol = lds + cs * 32 + l15;
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            double R2[2][9];
+            bool ok2[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int r = 2 * rr + u;
+              const double Gp = ldsG[TC + it * 16 + kq + 4 * r];
+              double B9[9];
+#pragma unroll
+              for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
+              ok2[u] = kabsch_rotation_qcp(B9, Gp + Gq, R2[u]);
+            }
+            double ssq[2] = {0.0, 0.0}, mx[2] = {0.0, 0.0};
+            const double *__restrict__ prow = Xs + ib + kq + 8 * rr;
+            for (int a = 0; a < A; ++a) {
+              const int sg = a >> 2, k = a & 3;
+              const double *__restrict__ ql = qcol + sg * (12 * TC) + (k >> 1) * (2 * TC) + (k & 1) * 16;
+              const double qx = ql[0], qy = ql[4 * TC], qz = ql[8 * TC];
+              const double *__restrict__ pa = prow + (int64_t)(a * 3) * Npad;
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const double px = pa[4 * u], py = pa[Npad + 4 * u], pz = pa[2 * Npad + 4 * u];
+                const double dx = px - (R2[u][0] * qx + R2[u][1] * qy + R2[u][2] * qz);
+                const double dy = py - (R2[u][3] * qx + R2[u][4] * qy + R2[u][5] * qz);
+                const double dz = pz - (R2[u][6] * qx + R2[u][7] * qy + R2[u][8] * qz);
+                const double s2 = dx * dx + dy * dy + dz * dz;
+                ssq[u] += s2;
+                mx[u] = fmax(mx[u], s2);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int i = ib32 + kq + 4 * (2 * rr + u);
+              const bool in = (j > i) && (j < n32) && (i < n32);
+              if (in) {
+                rmsd_out[(int64_t)i * N + j] = sqrt(ssq[u] / (double)A);
+                maxdev_out[(int64_t)i * N + j] = sqrt(mx[u]);
+              }
+              const bool redo = in && !ok2[u];
+              stage_pairs(__ballot(redo), redo, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+            }
+          }
+          continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = ib32 + kq + 4 * r;
@@ -1714,7 +1771,7 @@ k_alignment_matrices(const double *__restrict__ p, const double *__restrict__ q,
 __global__ void __launch_bounds__(256)
 k_rmsd_fix_small(const double *__restrict__ Xa, int A, int64_t N, const uint64_t *__restrict__ pairq,
                  const unsigned long long *__restrict__ counters, unsigned long long Q,
-                 double *__restrict__ rmsd_out) {
+                 double *__restrict__ rmsd_out, double *__restrict__ maxdev_out) {
   const int lane = threadIdx.x & 63, sub = lane & 7, slot = lane >> 3;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -1727,7 +1784,10 @@ k_rmsd_fix_small(const double *__restrict__ Xa, int A, int64_t N, const uint64_t
       const int64_t i = (int64_t)(e >> 32), j = (int64_t)(e & 0xffffffffull);
       double r, m;
       pair_exact_group8(Xa, A, i, j, sub, r, m);
-      if (sub == 0) rmsd_out[i * N + j] = r;
+      if (sub == 0) {
+        rmsd_out[i * N + j] = r;
+        if (maxdev_out) maxdev_out[i * N + j] = m;
+      }
     }
   }
 }
@@ -1787,8 +1847,10 @@ static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks, bool
   return FC_OK;
 }
 
-// all-pairs RMSD values on the matrix pipe (world == 1 layout); rmsd_dev: (N, N), pre-zeroed
-int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev) {
+// all-pairs RMSD values on the matrix pipe (world == 1 layout); rmsd_dev: (N, N), pre-zeroed.
+// maxdev_dev != nullptr: the complete alignment of every pair -- (rmsd, maxdev) from the explicit
+// rotated difference (MODE 2 of the kernel); pairs it could not rotate are redone by the fix-up.
+int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, double *maxdev_dev) {
   const int64_t NT = e->Npad >> 6;
   const int64_t rb = 128;
   const int64_t n_lblocks = ceil_div(e->N, rb);
@@ -1799,8 +1861,11 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev) {
   if (!fits32) return set_error(FC_E_LIMIT, "ensemble too large for 32-bit operand offsets");
   auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
   const bool two_blocks = 2 * lds_m <= kLdsLimit;
-  const void *fn = two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4, true>)
-                              : reinterpret_cast<const void *>(k_simbits_screen_mfma<8, true>);
+  const bool complete = maxdev_dev != nullptr;
+  const void *fn = complete ? (two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4, 2>)
+                                          : reinterpret_cast<const void *>(k_simbits_screen_mfma<8, 2>))
+                            : (two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4, 1>)
+                                          : reinterpret_cast<const void *>(k_simbits_screen_mfma<8, 1>));
   if (lds_m > 64 * 1024) {
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
     if (err != hipSuccess) return set_error(FC_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
@@ -1808,8 +1873,6 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev) {
   const double A_small = (double)e->A * small_rmsd * small_rmsd;
   // one workgroup per upper-triangle item (see launch_simbits_screen); the value kernel uses
   // the world == 1 layout with its own row block, so it keeps its own table
-  static thread_local fc_ensemble *tbl_owner = nullptr;
-  (void)tbl_owner;
   const int64_t saved_rank = e->rank, saved_world = e->world, saved_rb = e->row_block;
   e->rank = 0; e->world = 1; e->row_block = rb;
   const int rc_tbl = screen_item_table(e, NT, n_lblocks);
@@ -1822,20 +1885,23 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev) {
   const uint64_t *item_table_dev = compact ? e->item_table.as<uint64_t>() : nullptr;
   if (n_items >= (1ull << 31)) return set_error(FC_E_LIMIT, "too many value-kernel items for one launch");
   const dim3 grid((unsigned)n_items);
-  if (two_blocks)
-    hipLaunchKernelGGL((k_simbits_screen_mfma<4, true>), grid, dim3(256), lds_m, ctx().stream,
-                       e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,
-                       (int64_t)0, (int64_t)1, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),
-                       (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev);
-  else
-    hipLaunchKernelGGL((k_simbits_screen_mfma<8, true>), grid, dim3(512), lds_m, ctx().stream,
-                       e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,
-                       (int64_t)0, (int64_t)1, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),
-                       (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev);
+#define FC_LAUNCH_VALUES(NW_, MODE_)                                                                      \
+  hipLaunchKernelGGL((k_simbits_screen_mfma<NW_, MODE_>), grid, dim3(NW_ * 64), lds_m, ctx().stream,      \
+                     e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,   \
+                     (int64_t)0, (int64_t)1, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),        \
+                     (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev, nullptr, maxdev_dev)
+  if (complete) {
+    if (two_blocks) FC_LAUNCH_VALUES(4, 2);
+    else FC_LAUNCH_VALUES(8, 2);
+  } else {
+    if (two_blocks) FC_LAUNCH_VALUES(4, 1);
+    else FC_LAUNCH_VALUES(8, 1);
+  }
+#undef FC_LAUNCH_VALUES
   FC_TRY(check_launch("k_simbits_screen_mfma<values>"));
   hipLaunchKernelGGL(k_rmsd_fix_small, dim3((unsigned)(ctx().n_cu * 4)), dim3(256), 0, ctx().stream,
                      e->Xa.as<double>(), (int)e->A, e->N, e->pairq.as<uint64_t>(), cnt,
-                     (unsigned long long)e->pairq_cap, rmsd_dev);
+                     (unsigned long long)e->pairq_cap, rmsd_dev, maxdev_dev);
   return check_launch("k_rmsd_fix_small");
 }
 
@@ -1895,6 +1961,9 @@ int launch_matrix_exact(const fc_ensemble *e, double *rmsd_dev, double *maxdev_d
 // which screen the last launch_simbits_screen used: 32 (fp32 MFMA), 64 (fp64 MFMA), 1 (VALU), 0 (none yet)
 static int g_last_screen = 0;
 int last_screen_kind() { return g_last_screen; }
+// fc_screen_select: 0 = automatic (FC_SCREEN_F32 / band estimate), 32 / 64 = that screen whatever the band
+static int g_screen_forced = 0;
+void screen_select(int kind) { g_screen_forced = kind; }
 
 int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   // Context::mark_after_screen: recorded once, right behind the main screen kernel of this launch
@@ -1987,7 +2056,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
       // Default: the single-precision screen (fp32 MFMA + bounded fp32 polynomial; candidates are
       // decided by the exact fp64 refine either way).  FC_SCREEN_F32=0, a timeline build's probe,
       // or so many atoms that the proven bounds stop being small select the fp64 screen below.
-      const char *f32_env = getenv("FC_SCREEN_F32");
+      const char *f32_env = g_screen_forced == 64 ? "0" : g_screen_forced == 32 ? "2" : getenv("FC_SCREEN_F32");
       const int64_t A4 = (e->A + 3) / 4 * 4;
       const KabschF32Bounds bd = kabsch_f32_bounds(A4);
       bool use_f32 = !(f32_env && f32_env[0] == '0') && dbg == nullptr && bd.p0 < 2.0e-3f && e->row_block % 64 == 0;

@@ -3,12 +3,20 @@
 Every rank holds the whole (small) ensemble in its own HBM and owns the row
 blocks of the similarity bit matrix dealt in snake order (``owner_of_rows``:
 balances the triangular work).  The similarity stage needs no
-communication.  The greedy k-ladder needs the *global* survivor mask of the
-previous level, so after every level the ranks exchange their rows' new flags
-with ONE all-gather of (N,) uint8 (RCCL on GPUs -- ``backend="nccl"`` of
-torch.distributed -- gloo in the CPU tests) and combine them: a flag can only
-go 1 -> 0 and only its owner changes it, so the element-wise minimum over the
-gathered masks is the owner's value.
+communication.  Then ONE all-gather exchanges the ranks' exactly-similar pair
+lists and every rank replays the whole k-ladder (identical mask everywhere);
+with dense similarity the ranks exchange the (N,) mask once per ladder level
+instead: a flag can only go 1 -> 0 and only its owner changes it, so the
+element-wise minimum over the gathered masks is the owner's value.
+
+The exchange is RCCL behind the C ABI (``fc_comm_init``, ``fc_prune_rmsd_sharded``,
+``fc_allgather_mask``: csrc/fc_comm.cpp) -- no PyTorch: ``comm_init_from_env``
+bootstraps the communicator for one process per GPU started by any launcher that
+sets RANK / WORLD_SIZE / LOCAL_RANK (``python -m torch.distributed.run`` does; the
+ranks themselves never import torch).  The ``allgather_fn`` / ``gather_fn`` hooks of
+the functions below let the CPU tests drive the same host logic over gloo, and
+``prune_by_rmsd_sharded_device`` / ``prune_steps_sharded_device`` remain for callers
+that already live on torch streams (needs ``FC_HIP_RUNTIME=torch``).
 """
 
 from __future__ import annotations
@@ -19,6 +27,88 @@ import numpy as np
 
 LADDER = (500000, 200000, 100000, 50000, 20000, 10000, 5000, 2000, 1000, 500,
           200, 100, 50, 20, 10, 5, 2, 1)
+
+
+# ---------------------------------------------------------------------------------------
+# RCCL without PyTorch: bootstrap of the communicator and the calls over it
+# ---------------------------------------------------------------------------------------
+def _id_file():
+    """Where rank 0 leaves the 128-byte RCCL unique id for the other ranks of this launch:
+    FC_COMM_ID_FILE, or a name made of the rendezvous port and the launcher's pid (the ranks of one
+    launch share their parent process, so the name is new for every launch)."""
+    explicit = os.environ.get("FC_COMM_ID_FILE")
+    if explicit:
+        return explicit
+    import tempfile
+
+    tag = "_".join([os.environ.get("MASTER_ADDR", "local").replace("/", "_"), os.environ.get("MASTER_PORT", "0"),
+                    os.environ.get("TORCHELASTIC_RUN_ID", "none").replace("/", "_"), str(os.getppid())])
+    return os.path.join(tempfile.gettempdir(), f"fc_comm_{tag}.id")
+
+
+def comm_init_from_env(timeout_s=180.0):
+    """Create the RCCL communicator of this launch from RANK / WORLD_SIZE / LOCAL_RANK and return
+    (rank, world, local_rank).  Call it BEFORE any other GPU use in the process; it selects
+    device LOCAL_RANK (``fc_init``).  Rank 0 makes the unique id (``fc_comm_unique_id``) and
+    publishes it atomically in ``_id_file()``; the others wait for that file.  A single rank needs
+    no file.  FC_COMM_ID (256 hex digits) replaces the file for launchers that can pass it."""
+    import time
+
+    from firecode_amd import _lib
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the host driver supports nothing else
+    _lib.init(local_rank)
+    hex_id = os.environ.get("FC_COMM_ID")
+    if hex_id:
+        uid = bytes.fromhex(hex_id)
+    elif world == 1:
+        uid = _lib.comm_unique_id()
+    elif rank == 0:
+        uid = _lib.comm_unique_id()
+        path = _id_file()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as fh:
+            fh.write(uid)
+        os.replace(tmp, path)
+    else:
+        path, t0 = _id_file(), time.monotonic()
+        while True:
+            try:
+                with open(path, "rb") as fh:
+                    uid = fh.read()
+                if len(uid) == 128:
+                    break
+            except OSError:
+                pass
+            if time.monotonic() - t0 > timeout_s:
+                raise TimeoutError(f"rank {rank}: no RCCL unique id in {path} after {timeout_s:.0f} s")
+            time.sleep(0.02)
+    _lib.comm_init(rank, world, uid)  # collective: returns once every rank has joined
+    if world > 1 and rank == 0 and not hex_id:
+        try:
+            os.remove(_id_file())
+        except OSError:
+            pass
+    return rank, world, local_rank
+
+
+def rccl_allgather():
+    """``allgather_fn`` for the host-level functions of this module over the C-ABI communicator:
+    (n,) uint8 on every rank -> (world, n) uint8 (``fc_allgather_mask``)."""
+    from firecode_amd import _lib
+
+    return _lib.allgather_mask
+
+
+def prune_by_rmsd_sharded_rccl(ens, max_rmsd, max_dev=None, min_per_group=20, row_block=0):
+    """The sharded prune entirely behind the C ABI (``fc_prune_rmsd_sharded``): the ranks of
+    ``comm_init_from_env`` call it with the same resident ensemble -> (mask, stats), identical
+    mask on every rank.  A group of one without a communicator."""
+    if max_dev is None:
+        max_dev = 2 * max_rmsd
+    return ens.prune_sharded(max_rmsd, max_dev, min_per_group=min_per_group, row_block=row_block)
 
 
 def owner_of_rows(n, world, row_block):

@@ -58,6 +58,19 @@ def synthetic_ensemble(n_conf, n_atoms, seed, cluster_size=5, sigma_cluster=0.6,
     return np.ascontiguousarray(coords), np.array(["C"] * n_atoms), assign
 
 
+def continuous_ensemble(n_conf, n_atoms, seed=11, n_modes=6, thr=0.5):
+    """An ensemble WITHOUT cluster structure: one skeleton displaced along ``n_modes`` random
+    orthonormal collective modes with Gaussian amplitudes.  Pair RMSDs spread continuously from 0
+    to ~5 x ``thr``, ~1.5 % of the pairs fall below ``thr`` and the density is smooth across the
+    threshold -- the case the clustered bench ensemble does not exercise (its pairs sit at 0.07 A
+    or 1.5 A).  Returns coords (N, A, 3)."""
+    rng = np.random.default_rng(seed)
+    base, _, _ = synthetic_ensemble(1, n_atoms, seed=2)
+    modes = np.linalg.qr(rng.normal(size=(n_atoms * 3, n_modes)))[0].T.reshape(n_modes, n_atoms, 3)
+    amp = rng.normal(scale=0.35 * np.sqrt(n_atoms) * (thr / 0.5), size=(n_conf, n_modes))
+    return np.ascontiguousarray(base[0][None] + np.einsum("nm,mac->nac", amp, modes))
+
+
 def synthetic_trimolecular(n_conf=(2, 2, 2), n_atoms=(9, 11, 8), seed=0, pivots_per_conf=(1, 2, 1), sep=(3, 4, 3)):
     """Three small molecules for the trimolecular cyclical embed: per molecule ``coords``
     (n, A, 3) (conformers = jittered copies of a random skeleton), two reactive atoms

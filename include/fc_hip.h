@@ -18,6 +18,12 @@
  *     the output buffers.
  *   - the HIP context is created lazily, per process, on the first call
  *     (the reference may call from spawn()ed pool workers, embedder.py:116).
+ *   - threads: the library keeps ONE context (device, streams, staging buffers) per
+ *     process.  Entry points may be called from several host threads; each holds the
+ *     library's lock for its whole duration, so calls run one after the other (the
+ *     reference's hot path is single-threaded per process).  fc_last_error() is per thread.
+ *     fc_shutdown / fc_init(other device) end the context: ensembles created before are
+ *     refused afterwards (FC_E_INVALID) and may only be destroyed.
  *   - there is NO CPU fallback: without a usable gfx950 device every compute
  *     entry point returns FC_E_NODEVICE.
  */
@@ -83,6 +89,14 @@ int fc_ensemble_rmsd_pairs(fc_ensemble *ens, const int64_t *pair_i, const int64_
                            int64_t P, double *rmsd_out, double *maxdev_out);
 /* all pairs: rmsd_out / maxdev_out are (N, N) row-major, symmetric, 0 diagonal */
 int fc_ensemble_rmsd_matrix(fc_ensemble *ens, double *rmsd_out, double *maxdev_out);
+/* The complete alignment of ALL pairs, timed on the device: rmsd_and_max's two outputs (RMSD and
+ * max per-atom deviation, both from the explicit rotated difference) for every i < j --
+ * covariance tiles on the fp64 matrix pipe, rotation (Newton eigenvalue + adjugate column;
+ * Jacobi sweeps where the eigenvalue is not clearly simple) and one atom pass in the epilogue.
+ * rmsd_out / maxdev_out (N, N) symmetric with 0 diagonal, either may be NULL (timing only);
+ * ms_kernel (may be NULL) = HIP-event time of the kernels.  fc_ensemble_rmsd_matrix is this
+ * call with both outputs required. */
+int fc_ensemble_rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_out, double *ms_kernel);
 /* all-pairs RMSD VALUES on the fp64 matrix pipe: covariance by MFMA, largest
  * quaternion eigenvalue by Newton (QCP), rmsd = sqrt((Gp+Gq-2*lambda)/A); pairs
  * below 0.02 A are re-evaluated with the explicit rotated difference.  No max
@@ -179,6 +193,41 @@ int fc_prune_collect(fc_ensemble *ens, int64_t slot, int64_t n_slots, uint8_t *m
 int fc_ensemble_twin(fc_ensemble *ens, fc_ensemble **twin_out);
 int fc_prune_rmsd_begin_split_async(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t rank,
                                     int64_t world, int64_t row_block, void *screen_stream, int timed);
+
+/* ---- the exchange of the sharded path: RCCL over xGMI behind the C ABI (no PyTorch) ---------
+ * "ensembles shard by conformer across the GPUs of one node with a single RCCL
+ * all-gather to reassemble the surviving-conformer mask".  One process per GPU, started by any
+ * launcher; librccl.so is bound at run time (dlopen) by the first of these calls, so single-GPU
+ * users never load it.  Rank 0 calls fc_comm_unique_id and passes the 128 bytes to the other
+ * ranks out of band (firecode_amd/dist.py: a file next to MASTER_PORT, or FC_COMM_ID);
+ * every rank then calls fc_comm_init (collective; after fc_init(device of this rank)).
+ * Without a communicator the calls below behave as a group of one rank.
+ *   fc_allgather_mask     host buffers, blocking: mask_global = world x n_local bytes, rank-major
+ *                         (the per-level mask exchange and the pass masks of the pose grid / scan);
+ *   fc_allgather_u8_dev   device buffers, enqueued behind the library's current stream;
+ *   fc_comm_barrier       all ranks have arrived (a 1-byte all-gather + wait). */
+#define FC_COMM_ID_BYTES 128
+int fc_comm_unique_id(uint8_t *id_out);
+int fc_comm_init(int64_t rank, int64_t world, const uint8_t *id);
+int fc_comm_destroy(void);
+int fc_comm_info(int64_t *rank, int64_t *world);
+int fc_allgather_mask(const uint8_t *mask_local, int64_t n_local, uint8_t *mask_global);
+int fc_allgather_u8_dev(const uint8_t *send_dev, uint8_t *recv_dev, int64_t bytes_per_rank);
+int fc_comm_barrier(void);
+/* test hook: act as `rank` of `world` without a communicator -- the all-gather writes only this
+ * rank's slot and leaves the others as earlier calls left them, so the logical ranks of one GPU can
+ * be run one after the other (tests/test_gpu_parity.py); world = 0 switches it off */
+int fc_debug_comm_loopback(int64_t rank, int64_t world);
+/* prune_by_rmsd over the ranks of the communicator: every rank holds the whole ensemble and
+ * calls this with the same arguments; rows of the similarity matrix are dealt in snake order
+ * (row_block rows at a time, <= 0: default), each rank screens + refines its own, ONE all-gather of
+ * the ranks' exactly-similar pair lists (cap = 1024 + 4N/world pairs each), the whole k-ladder
+ * replayed on every rank: identical mask_out (N bytes) everywhere.  Dense similarity (a list that
+ * does not fit): one fc_allgather_mask per ladder level instead, decided alike on every rank.
+ * stats (6, may be NULL): [0] pairs owned, [1] refined, [2] similar (this rank), [3] grey,
+ * [4] screen kernel ns, [5] survivors. */
+int fc_prune_rmsd_sharded(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t min_per_group,
+                          int64_t row_block, uint8_t *mask_out, int64_t *stats);
 
 /* ---- a7: prune_by_rmsd_rot_corr(structures, atoms, graph, max_rmsd=, energies=, max_dE=) --
  * prism_pruner.pruner (NOT in the reference tree); call sites firecode/ensemble.py:253-260,
@@ -402,9 +451,18 @@ int fc_prune_rmsd_many(fc_ensemble *const *ens, int64_t n, double max_rmsd, doub
  * large structures with tight thresholds), 1 = VALU kernel, 0 = none yet.  Results do not depend on
  * it: every pair a screen lets through is decided by the exact fp64 refine. */
 int fc_screen_last_kind(void);
+/* Choice of the all-pairs screen for the prunes that follow: 0 = automatic (default), 32 = the
+ * single-precision screen whatever its band, 64 = the fp64 screen (the reference's arithmetic in
+ * every kernel of the step).  Process-wide; results never depend on it. */
+int fc_screen_select(int kind);
 int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
                         double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
                         int64_t *stats);
+/* the same for fc_prune_rmsd_sharded: `reps` sharded prunes enqueued back to back, one host wait;
+ * overlap != 0: prune k on workspace / lane k&1, its refine + export + all-gather + ladder beside
+ * the screen of prune k+1 */
+int fc_bench_prune_rmsd_sharded(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps, int overlap,
+                                double *ms_screen_kernel, double *ms_step, uint8_t *mask_out, int64_t *stats);
 
 #ifdef __cplusplus
 }

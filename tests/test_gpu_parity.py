@@ -738,143 +738,71 @@ def test_sharded_pairs_exchange_on_one_gpu(fc, world):
         ens.close()
 
 
-@pytest.mark.parametrize("world", [1, 3])
-def test_device_resident_exchange_logical_ranks(fc, world):
-    """fc_prune_export_pairs_dev / fc_prune_from_gathered_dev: the messages of `world`
-    logical ranks are written by kernels into one torch buffer (standing in for the
-    all-gather's output), the ladder is replayed from it -- all on a torch stream"""
-    import torch
-
+def test_sharded_prune_behind_the_c_abi_single_rank(fc, monkeypatch):
+    """fc_prune_rmsd_sharded / fc_bench_prune_rmsd_sharded with the real RCCL communicator of one
+    rank (fc_comm_init through firecode_amd.dist.comm_init_from_env -- no torch): stream ordering
+    between the library's kernels and RCCL's stream, no host wait in between; then the dense
+    fallback (4-entry candidate queue -> one fc_allgather_mask per ladder level)"""
     from firecode_amd import _lib
-    from firecode_amd import dist as fdist
-
-    X, atoms, asg = syn.synthetic_ensemble(1100, 24, seed=180 + world)
-    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
-    ref = o.greedy_prune_from_matrix(S0)
-    cap = fdist.exchange_cap(len(X), world)
-    dev = torch.device("cuda", 0)
-    stream = torch.cuda.Stream(device=dev)
-    with fc.DeviceEnsemble(X, center=True) as ens, torch.cuda.stream(stream):
-        _lib.stream_set(stream.cuda_stream)
-        try:
-            recv = torch.zeros(world * (cap + 1), dtype=torch.int64, device=dev)
-            for r in range(world):
-                ens.prune_begin_async(0.5, 1.0, r, world, row_block=128)
-                ens.export_pairs_dev(recv.data_ptr() + 8 * r * (cap + 1), cap)
-            mask, stats = ens.prune_from_gathered_dev(recv.data_ptr(), world, cap)
-            host = recv.cpu().numpy().view(np.uint64).reshape(world, cap + 1)
-        finally:
-            _lib.stream_set(None)
-    assert np.array_equal(mask, ref)
-    assert int(host[:, 0].sum()) == int(np.triu(S0, 1).sum())
-    for r in range(world):  # message layout: count, pairs, padding
-        c = int(host[r, 0])
-        assert (host[r, 1 + c:] == fdist.PAD).all() and (host[r, 1: 1 + c] != fdist.PAD).all()
-    assert stats[5] == ref.sum() and stats[4] > 0
-
-
-def test_device_resident_exchange_driver_and_fallback(fc, monkeypatch):
-    """prune_by_rmsd_sharded_device on one rank (copy instead of the collective); then with a
-    4-entry candidate queue: the message header says "no list", the device ladder declines
-    (FC_E_LIMIT) and the driver repeats the exchange on the host path -- same mask"""
-    from firecode_amd import dist as fdist
-
-    X, atoms, asg = syn.synthetic_ensemble(700, 20, seed=191)
-    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
-    ref = o.greedy_prune_from_matrix(S0)
-    with fc.DeviceEnsemble(X, center=True) as ens:
-        mask, stats = fdist.prune_by_rmsd_sharded_device(ens, 0.5)
-        assert np.array_equal(mask, ref) and stats[2] == np.triu(S0, 1).sum()
-    monkeypatch.setenv("FC_PAIRQ_CAP", "4")
-    with fc.DeviceEnsemble(X, center=True) as ens:
-        mask, stats = fdist.prune_by_rmsd_sharded_device(ens, 0.5)
-        assert np.array_equal(mask, ref)
-    # a message longer than the fixed capacity takes the same way out
-    monkeypatch.delenv("FC_PAIRQ_CAP")
-    monkeypatch.setattr(fdist, "exchange_cap", lambda n, world: 16)
-    with fc.DeviceEnsemble(X, center=True) as ens:
-        mask, stats = fdist.prune_by_rmsd_sharded_device(ens, 0.5)
-        assert np.array_equal(mask, ref)
-
-
-def test_stream_ordered_sharded_steps(fc, monkeypatch):
-    """prune_steps_sharded_device: several prunes enqueued back to back, one host wait; every
-    prune delivers the right mask; a declined device ladder is redone through the host path"""
-    from firecode_amd import dist as fdist
-
-    X, atoms, asg = syn.synthetic_ensemble(900, 22, seed=197)
-    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
-    ref = o.greedy_prune_from_matrix(S0)
-    with fc.DeviceEnsemble(X, center=True) as ens:
-        res = fdist.prune_steps_sharded_device(ens, 5, 0.5)
-        assert len(res) == 5
-        for mask, stats in res:
-            assert np.array_equal(mask, ref) and stats[2] == np.triu(S0, 1).sum() and stats[5] == ref.sum()
-    monkeypatch.setattr(fdist, "exchange_cap", lambda n, world: 16)  # messages longer than the capacity
-    with fc.DeviceEnsemble(X, center=True) as ens:
-        for mask, stats in fdist.prune_steps_sharded_device(ens, 3, 0.5):
-            assert np.array_equal(mask, ref)
-
-
-@pytest.mark.parametrize("overlap", [False, True])
-def test_sharded_steps_two_logical_ranks_with_and_without_overlap(fc, overlap):
-    """rank 0 of a 2-rank prune on one GPU: rank 1's message is computed beforehand and the
-    collective is replaced by a copy of both messages; consecutive steps on one stream, or
-    overlapped (ensemble + twin workspace, screens on a stream of their own) -- same masks"""
-    import torch
-
-    from firecode_amd import _lib
-    from firecode_amd import dist as fdist
-
-    X, atoms, asg = syn.synthetic_ensemble(1100, 18, seed=199)
-    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
-    ref = o.greedy_prune_from_matrix(S0)
-    world, cap = 2, fdist.exchange_cap(len(X), 2)
-    with fc.DeviceEnsemble(X, center=True) as ens:
-        other = torch.empty(cap + 1, dtype=torch.int64, device="cuda:0")
-        ens.prune_begin_async(0.5, 1.0, 1, world)
-        ens.export_pairs_dev(other.data_ptr(), cap)
-        _lib.call("fc_memory_trim")  # also a host wait for the library's stream
-        calls = []
-
-        def gather(send, recv):
-            calls.append(send.data_ptr())
-            recv.view(world, cap + 1)[0].copy_(send)
-            recv.view(world, cap + 1)[1].copy_(other)
-
-        res = fdist.prune_steps_sharded_device(ens, 6, 0.5, rank=0, world=world, gather_fn=gather, overlap=overlap)
-        assert len(res) == 6 and len(calls) == 6
-        own = int(np.triu(S0, 1)[fdist.owner_of_rows(len(X), world, 128) == 0].sum())
-        for mask, stats in res:
-            assert np.array_equal(mask, ref) and stats[2] == own and stats[5] == ref.sum()
-        # the plain one-shot call still works on the same ensemble afterwards
-        mask, _ = ens.prune(0.5, 1.0)
-        assert np.array_equal(mask, ref)
-
-
-def test_device_resident_exchange_over_rccl_single_rank(fc):
-    """the real collective (torch.distributed nccl = RCCL) on a 1-rank group: stream ordering
-    between the library's kernels and RCCL's stream, no host synchronisation in between"""
-    import torch
-    import torch.distributed as tdist
-
     from firecode_amd import dist as fdist
 
     X, atoms, asg = syn.synthetic_ensemble(1500, 30, seed=195)
     S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
     ref = o.greedy_prune_from_matrix(S0)
-    torch.cuda.set_device(0)
-    tdist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1,
-                             device_id=torch.device("cuda", 0))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FC_COMM_ID"):
+        monkeypatch.delenv(k, raising=False)
+    assert fdist.comm_init_from_env() == (0, 1, 0)
     try:
+        assert _lib.comm_info() == (0, 1)
+        assert np.array_equal(_lib.allgather_mask(np.arange(7, dtype=np.uint8)), np.arange(7, dtype=np.uint8)[None])
+        _lib.comm_barrier()
         with fc.DeviceEnsemble(X, center=True) as ens:
             for _ in range(3):
-                mask, stats = fdist.prune_by_rmsd_sharded_device(ens, 0.5, rank=0, world=1)
-                assert np.array_equal(mask, ref)
-            for mask, stats in fdist.prune_steps_sharded_device(ens, 4, 0.5, rank=0, world=1):
-                assert np.array_equal(mask, ref)
+                mask, stats = fdist.prune_by_rmsd_sharded_rccl(ens, 0.5)
+                assert np.array_equal(mask, ref) and stats[2] == np.triu(S0, 1).sum() and stats[5] == ref.sum()
+                assert stats[0] == len(X) * (len(X) - 1) // 2 and stats[4] > 0
+            for overlap in (False, True):
+                tk, ts, mask, stats = ens.bench_prune_sharded(0.5, 1.0, reps=5, overlap=overlap)
+                assert np.array_equal(mask, ref) and stats[5] == ref.sum() and tk > 0 and ts > 0
+            mask, _ = ens.prune(0.5, 1.0)  # the plain call still works on the same ensemble afterwards
+            assert np.array_equal(mask, ref)
+        monkeypatch.setenv("FC_PAIRQ_CAP", "4")
+        with fc.DeviceEnsemble(X, center=True) as ens:
+            mask, stats = ens.prune_sharded(0.5, 1.0)
+            assert np.array_equal(mask, ref) and stats[5] == ref.sum()
     finally:
-        tdist.destroy_process_group()
+        _lib.comm_destroy()
+    assert _lib.comm_info() == (0, 1)
+
+
+@pytest.mark.parametrize("world,overlap", [(2, False), (2, True), (3, True)])
+def test_sharded_prune_c_path_logical_ranks(fc, world, overlap):
+    """The C pipeline with more than one rank, on one GPU: fc_debug_comm_loopback(rank, world) makes
+    the library act as `rank` of `world` with the all-gather writing only its own slot of the
+    workspace's receive buffer -- the ranks run one after the other on the same ensemble, the last
+    one sees every message.  Same mask as the oracle, owned pairs add up."""
+    from firecode_amd import _lib
+    from firecode_amd import dist as fdist
+
+    X, atoms, asg = syn.synthetic_ensemble(1100, 18, seed=199 + world)
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    owner = fdist.owner_of_rows(len(X), world, 128)
+    owned_total = 0
+    try:
+        with fc.DeviceEnsemble(X, center=True) as ens:
+            for r in list(range(1, world)) + [0]:
+                _lib.call("fc_debug_comm_loopback", r, world)
+                if overlap:
+                    _, _, mask, stats = ens.bench_prune_sharded(0.5, 1.0, reps=4, overlap=True)
+                else:
+                    mask, stats = ens.prune_sharded(0.5, 1.0)
+                assert stats[2] == int(np.triu(S0, 1)[owner == r].sum())
+                owned_total += int(stats[0])
+            assert np.array_equal(mask, ref) and stats[5] == ref.sum()
+            assert owned_total == len(X) * (len(X) - 1) // 2
+    finally:
+        _lib.call("fc_debug_comm_loopback", -1, 0)
 
 
 def _tri_objects(mols):
@@ -1195,3 +1123,69 @@ def test_rmsd_values_matrix(fc):
     iu, ju = np.triu_indices(150, 1)
     r0, _ = o.rmsd_and_max_batch(Y[iu], Y[ju], center=True)
     assert np.abs(R[iu, ju] - r0).max() < TOL
+
+
+def test_rmsd_and_max_all_pairs_tiled_kernel(fc):
+    """fc_ensemble_rmsd_and_max_all (covariance on the fp64 matrix pipe, rotation + explicit
+    difference in the epilogue) against the oracle, also where the rotation is not unique:
+    duplicated conformers, a planar and a collinear structure, mirror images"""
+    rng = np.random.default_rng(77)
+    X, atoms, _ = syn.synthetic_ensemble(157, 23, seed=41)
+    X[5] = X[4]                                   # identical pair: rmsd 0
+    X[9] = X[8] @ _rot(rng).T + 3.0               # same structure, moved
+    X[20, :, 2] = 0.0                             # planar
+    X[21] = np.outer(np.linspace(-8, 8, 23), [1.0, 0.5, -0.2])  # collinear
+    X[30] = X[31] * np.array([1.0, 1.0, -1.0])    # mirror image of its neighbour
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        R, D, ms = ens.rmsd_and_max_all()
+        R2, D2 = ens.rmsd_matrix()
+        assert ms > 0 and ens.rmsd_and_max_all(want_matrices=False)[0] is None
+    iu, ju = np.triu_indices(len(X), 1)
+    r0, d0 = o.rmsd_and_max_batch(X[iu], X[ju], center=True)
+    assert np.abs(R[iu, ju] - r0).max() < TOL and np.array_equal(R, R2) and np.array_equal(D, D2)
+    assert np.allclose(R, R.T) and np.all(np.diag(R) == 0) and np.allclose(D, D.T)
+    # the max deviation is only defined up to the choice among equally good rotations where the
+    # optimum is degenerate (collinear structure); everywhere else it matches
+    ok = (iu != 21) & (ju != 21)
+    assert np.abs(D[iu, ju] - d0)[ok].max() < 1e-8
+    assert R[4, 5] < 1e-12 and R[8, 9] < 1e-7
+
+
+def test_context_lifecycle_and_threads(fc):
+    """fc_shutdown / fc_init: streams, events and staging are rebuilt, ensembles of the old context
+    are refused (never used), pipelined prunes work again; two host threads may call the library
+    (their calls are serialised by its lock)"""
+    import threading
+
+    from firecode_amd import _lib
+
+    X, atoms, asg = syn.synthetic_ensemble(600, 20, seed=303)
+    S0, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    old = fc.DeviceEnsemble(X, center=True)
+    old.bench_prune(0.5, 1.0, reps=4)            # side streams and the event pool exist now
+    _lib.shutdown()
+    _lib.init(0)
+    with pytest.raises(_lib.FirecodeHipInputError):
+        old.prune(0.5, 1.0)
+    old.close()
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        _, _, mask, _ = ens.bench_prune(0.5, 1.0, reps=4)
+        assert np.array_equal(mask, ref)
+    results, errors = {}, []
+
+    def worker(k):
+        try:
+            with fc.DeviceEnsemble(X, center=True) as e:
+                for _ in range(5):
+                    m, _ = e.prune(0.5, 1.0)
+                    _, _, m2, _ = e.bench_prune(0.5, 1.0, reps=3)
+                    assert np.array_equal(m, ref) and np.array_equal(m2, ref)
+            results[k] = True
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors and len(results) == 3
