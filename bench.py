@@ -177,6 +177,11 @@ def timed_prunes(ens, steps, warmup, sharded, overlap=True):
         return ens.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=n, want_mask=True)
 
     run(2)  # set-up outside the timed region, whatever W is: second workspace, streams, operand copy
+    # ... and the chip at its steady clocks: a dozen 0.5 ms steps end before the device has ramped up
+    # (measured: 6 % longer steps at K = 20 than at K = 200); ~0.15 s of the same prunes, untimed
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < float(os.environ.get("FC_BENCH_SETTLE_S", "0.15")):
+        run(64 if not sharded else 8)
     done = 0
     while done < warmup:
         n = min(512, warmup - done)
@@ -322,6 +327,9 @@ def run_prune(args, workload, fc, _lib, fdist, syn, rank, world, sharded, barrie
                    "comm": "RCCL through libfc_hip.so's C ABI (fc_comm_init / ncclAllGather), no PyTorch in the ranks"
                            if sharded else "none",
                    "host_sync": "once per batch of <= 512 stream-ordered steps (one pinned result slot each)",
+                   "untimed_before_warmup": "set-up (second workspace, streams, fp32 operand copy) and "
+                                            + os.environ.get("FC_BENCH_SETTLE_S", "0.15") + " s of the same prunes so that the "
+                                            "W + K steps run at the device's steady clocks",
                    "step_overlap": "screens in order on one stream; refine" + (" + export + all-gather" if sharded else "")
                                    + " + ladder + result copy of step r run beside the screen of step r+1 "
                                      "(two workspaces over the same resident coordinates)"},

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfc_hip.so")
+LIB_PATH = os.environ.get("FC_LIB_PATH") or os.path.join(_HERE, "libfc_hip.so")  # FC_LIB_PATH: a tuning build
 
 FC_OK = 0
 FC_E_INVALID, FC_E_NODEVICE, FC_E_HIP, FC_E_NOMEM, FC_E_LIMIT = -1, -2, -3, -4, -5

@@ -394,7 +394,8 @@ static int64_t default_row_block() {
 
 // similarity bits of this rank's rows: screen + exact refine; counters[1..3]
 static int simbits_local(fc_ensemble *e, double max_rmsd, double max_dev, const double *energies,
-                         double max_dE, bool zero_counters) {
+                         double max_dE, bool zero_counters, bool lean = false) {
+  e->lean = lean;
   const double *en_dev = nullptr;
   if (energies != nullptr) {
     FC_TRY(upload(e->energies, energies, (size_t)e->N));
@@ -851,11 +852,19 @@ int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const doubl
   FC_TRY(ensure_init());
   if (ens->N == 0) return FC_OK;
   FC_TRY(ensemble_shard(ens, 0, 1, default_row_block()));
-  FC_TRY(simbits_local(ens, max_rmsd, max_dev, energies, max_dE, true));
+  // lean first: only the pair lists (no bit matrix); the pair ladder declines when the candidate
+  // queue overflowed or the list is too long for it -- then the same prune again with the bits
+  FC_TRY(simbits_local(ens, max_rmsd, max_dev, energies, max_dE, true, /*lean=*/true));
   unsigned long long cnt[8];
   int64_t levels = 0, survivors = 0;
-  FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), min_per_group, mask_out, &levels, &survivors, cnt,
-                       ens->simq.as<uint64_t>(), false, true));
+  int rc = ladder_single(ens, nullptr, min_per_group, mask_out, &levels, &survivors, cnt,
+                         ens->simq.as<uint64_t>(), false, true);
+  if (rc == FC_E_LIMIT) {
+    FC_TRY(simbits_local(ens, max_rmsd, max_dev, energies, max_dE, true, /*lean=*/false));
+    rc = ladder_single(ens, ens->bits.as<uint64_t>(), min_per_group, mask_out, &levels, &survivors, cnt,
+                       ens->simq.as<uint64_t>(), false, true);
+  }
+  FC_TRY(rc);
   if (stats) {
     stats[0] = ens->N * (ens->N - 1) / 2;
     stats[1] = (int64_t)cnt[1];
@@ -921,7 +930,7 @@ int fc_prune_rmsd_begin(fc_ensemble *ens, double max_rmsd, double max_dev, const
 int fc_prune_level(fc_ensemble *ens, int64_t k, const uint8_t *mask_in, uint8_t *mask_out) {
   FC_API_LOCK;
   FC_REQUIRE(ens && mask_in && mask_out, "NULL pointer argument");
-  FC_REQUIRE(ens->bits_valid, "fc_prune_rmsd_begin has not been called on this ensemble");
+  FC_REQUIRE(ens->bits_valid && !ens->lean, "fc_prune_rmsd_begin has not been called on this ensemble");
   FC_REQUIRE(k >= 1, "k must be >= 1");
   FC_TRY(ensure_init());
   const int64_t N = ens->N;
@@ -994,7 +1003,7 @@ int fc_prune_rmsd_begin_async(fc_ensemble *ens, double max_rmsd, double max_dev,
   FC_TRY(ensure_init());
   FC_TRY(ensemble_shard(ens, rank, world, row_block));
   if (ens->N == 0) return FC_OK;
-  return simbits_local(ens, max_rmsd, max_dev, nullptr, 0.0, true);
+  return simbits_local(ens, max_rmsd, max_dev, nullptr, 0.0, true, /*lean=*/true);  // consumer: the exported pair list
 }
 
 int fc_ensemble_twin(fc_ensemble *ens, fc_ensemble **twin_out) {
@@ -1022,6 +1031,7 @@ static int begin_split(fc_ensemble *ens, double max_rmsd, double max_dev, int64_
   FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, kCounters * sizeof(uint64_t), tail));
   FC_HIP_TRY(hipEventRecord(c.ev_reset, tail));
   FC_HIP_TRY(hipStreamWaitEvent(scr, c.ev_reset, 0));
+  ens->lean = true;  // consumer: the exported pair list
   c.stream = scr;
   if (ev_a) FC_HIP_TRY(hipEventRecord(ev_a, scr));  // the pair costs the stream ~14 us: not every step needs it
   c.mark_after_screen = ev_a ? ev_b : nullptr;
@@ -1949,6 +1959,7 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
     c.stream = scr;
     // timing events around the screen kernel of every `stride`-th prune only: the pair costs the
     // screen stream ~14 us (0.542 -> 0.528 ms per step when all 200 prunes carry it)
+    e->lean = true;  // consumer: the one-launch pair ladder (a prune it declines is redone by the caller)
     const bool timed = screen_ms_sum != nullptr && r % stride_ev == 0;
     if (timed) FC_HIP_TRY(hipEventRecord(ev[4 * r], scr));
     c.mark_after_screen = timed ? ev[4 * r + 1] : nullptr;  // the launcher records it right behind the screen kernel
@@ -1962,7 +1973,7 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
     c.stream = tail;
     FC_TRY(launch_simbits_refine(e, max_rmsd, max_dev, nullptr, 0.0));
     e->bits_valid = true;
-    FC_TRY(ladder_single(e, e->bits.as<uint64_t>(), min_per_group, nullptr, nullptr, nullptr, nullptr,
+    FC_TRY(ladder_single(e, nullptr, min_per_group, nullptr, nullptr, nullptr, nullptr,
                          e->simq.as<uint64_t>(), false, true, r, stride));
   }
   c.stream = home;
@@ -2286,6 +2297,7 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
     if (!ladder_collect(ens, r, mask_out, &levels, &survivors, cnt, stride)) redo = true;
   Context &c = ctx();
   if (redo) {  // dense similarity: the pair ladder declined; one synchronous prune through the bit matrix
+    ens->lean = false;
     FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, kCounters * sizeof(uint64_t), c.stream));
     FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
     FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));

@@ -211,6 +211,10 @@ struct fc_ensemble {
   int64_t rank = 0, world = 1, row_block = 64;
   int64_t rows_local = 0;
   bool bits_valid = false;
+  // lean prune: only the candidate / similar PAIR lists are produced (no bit matrix, no word queue);
+  // set by the entry points whose consumer is the pair ladder or the exchange, which repeat the prune
+  // with lean = false when the pair queue overflowed
+  bool lean = false;
   // second prune workspace over the same coordinates (Xs/Xa/G are views): lets the refine and
   // ladder of one prune run beside the screen of the next one (fc_bench_prune_rmsd)
   fc_ensemble *twin = nullptr;

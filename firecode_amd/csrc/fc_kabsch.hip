@@ -934,7 +934,11 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 #ifndef FC_F32_WGS
 #define FC_F32_WGS 3
 #endif
-template <int NW>
+// BITS = false ("lean"): the caller consumes only the candidate-pair queue (the one-launch pair
+// ladder, the multi-GPU exchange) -- the dense bit matrix, 12.6 MB of mostly zeros per launch at
+// 10^4 conformers, is neither written nor queued by words; when the pair queue overflows the host
+// repeats the prune with BITS = true.
+template <int NW, bool BITS = true>
 __global__ void __launch_bounds__(NW * 64, FC_F32_WGS)
 k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restrict__ G, int64_t N,
                           int64_t Npad, int A, double A_thr2, KabschF32Bounds bd, int IB, int64_t rank,
@@ -1024,7 +1028,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
     for (int half = 0; half < 2; ++half) {
       const int cs0 = half * 2;
       if (j0 + (cs0 + 2) * 16 - 1 <= ib) {  // both sub-tiles at or below the diagonal
-        if (lane < 16 && ib + lane < N) {
+        if (BITS && lane < 16 && ib + lane < N) {
           bits16[((lrow0 + lane) * W + jt) * 4 + cs0] = 0;
           bits16[((lrow0 + lane) * W + jt) * 4 + cs0 + 1] = 0;
         }
@@ -1071,7 +1075,11 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
     fetch_a(AX, sgrp + (U) + 3);        \
     fetch_b(BX, sgrp + (U) + 2);        \
   }
+#ifdef FC_F32_ABLATE_K  // timing experiment only (results are wrong): one k-step instead of all
+      for (int sgrp = 0; sgrp < 1; sgrp += 6) {
+#else
       for (int sgrp = 0; sgrp < KSe; sgrp += 6) {
+#endif
         FC_KSTEP(a0, b0, 0)
         FC_KSTEP(a1, b1, 1)
         FC_KSTEP(a2, b0, 2)
@@ -1110,14 +1118,18 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
           float B9[9];
 #pragma unroll
           for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
+#ifdef FC_F32_ABLATE_POLY  // timing experiment only (results are wrong): the K loop without the polynomial
+          bool may = (B9[0] + B9[4] + B9[8]) * B9[1] * B9[2] * B9[3] * B9[5] * B9[6] * B9[7] == 12345.678f;
+#else
           bool may = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd);
+#endif
           may = may && (j > i) && (j < n32) && (i < n32);
           mr[r] = __ballot(may);
           stage_pairs<kStagePairsF32>(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
         }
         // bit (16 kq' + c) of mr[r] belongs to row 4 kq' + r: lane l < 16 writes the piece of
         // row l = 4 (l >> 2) + (l & 3), one store per sub-tile instead of one per register
-        if (lane < 16 && ib32 + lane < n32) {
+        if (BITS && lane < 16 && ib32 + lane < n32) {
           const int rr = lane & 3;
           const uint64_t mine = rr == 0 ? mr[0] : rr == 1 ? mr[1] : rr == 2 ? mr[2] : mr[3];
           const unsigned piece = (unsigned)((mine >> (16 * (lane >> 2))) & 0xffffull);
@@ -1126,7 +1138,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
         }
       }
     }
-    {  // queue the non-empty words of this row tile for the exact refine
+    if (BITS) {  // queue the non-empty words of this row tile for the exact refine
       const bool has = lane < 16 && nz != 0;
       const uint64_t mw = __ballot(has);
       if (mw != 0) {  // wave-uniform
@@ -1632,7 +1644,7 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
         sim = may && (r < max_rmsd) && (m < max_dev);
         grey = may && ((fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9));
         if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
-        if (!sim) {
+        if (!sim && bits != nullptr) {
           const int64_t lrow = ((i / IB) / world) * IB + (i % IB);
           atomicAnd(reinterpret_cast<unsigned long long *>(&bits[lrow * W + (j >> 6)]),
                     ~(1ull << (j & 63)));
@@ -1652,6 +1664,7 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
     }
     return;
   }
+  if (bits == nullptr) return;  // lean screen: the host repeats this prune with the bit matrix
   const int64_t n_cand = (int64_t)counters[4];
   for (int64_t c = wave0; c < n_cand; c += nwaves) {
   const int64_t widx = cand[c];
@@ -2094,14 +2107,24 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
           FC_TRY(check_launch("k_f64_to_f32"));
           e->xsf_valid = true;
         }
-        if (lds_f > 64 * 1024)
-          FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_simbits_screen_mfma_f32<4>),
+        if (lds_f > 64 * 1024) {
+          FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_simbits_screen_mfma_f32<4, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-        hipLaunchKernelGGL(k_simbits_screen_mfma_f32<4>, mgrid, dim3(256), lds_f, ctx().stream,
-                           e->Xsf.as<float>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2, bd,
-                           (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
-                           e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
-                           (unsigned long long)e->pairq_cap, item_table_dev, n_items);
+          FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_simbits_screen_mfma_f32<4, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+        }
+        if (e->lean)
+          hipLaunchKernelGGL((k_simbits_screen_mfma_f32<4, false>), mgrid, dim3(256), lds_f, ctx().stream,
+                             e->Xsf.as<float>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2, bd,
+                             (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
+                             e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
+                             (unsigned long long)e->pairq_cap, item_table_dev, n_items);
+        else
+          hipLaunchKernelGGL((k_simbits_screen_mfma_f32<4, true>), mgrid, dim3(256), lds_f, ctx().stream,
+                             e->Xsf.as<float>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2, bd,
+                             (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
+                             e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
+                             (unsigned long long)e->pairq_cap, item_table_dev, n_items);
         FC_TRY(check_launch("k_simbits_screen_mfma_f32"));
         mark_main();
         g_last_screen = 32;
@@ -2185,7 +2208,7 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
                      ctx().stream, e->Xs.as<double>(), e->Xa.as<double>(), e->N, e->Npad, (int)e->A,
                      max_rmsd, max_dev, energies_dev, max_dE, (int)e->row_block, e->rank, e->world,
                      e->rows_local,
-                     e->bits.as<uint64_t>(), e->W, e->cand.as<uint32_t>(),
+                     e->lean ? nullptr : e->bits.as<uint64_t>(), e->W, e->cand.as<uint32_t>(),
                      reinterpret_cast<unsigned long long *>(e->counters.p), e->pairq.as<uint64_t>(),
                      (unsigned long long)e->pairq_cap, e->simq.as<uint64_t>());
   return check_launch("k_simbits_refine");
