@@ -109,9 +109,9 @@ class Ensemble:
         most 1000 structures, :246-270) the symmetry-corrected RMSD prune; masks propagated to
         ``energies``; same log lines.  ``max_rmsd`` is explicit here (the reference relies on
         prism_pruner's default).  The rot-corr stage needs the locally symmetric torsions
-        ``(i1, i2, i3, i4, n_fold)`` and ``graph`` (or ``rotation_masks``): the reference
-        perceives them inside prism_pruner from ``graphize(atoms, coords[0])``; that graph work
-        is the caller's here."""
+        ``(i1, i2, i3, i4, n_fold)``: like the reference (:250) the graph is built with
+        ``graphize(atoms, coords[0])`` when none is given, and ``prune_by_rmsd_rot_corr`` perceives the
+        torsions from it (``symmetric_torsions=`` / ``rotation_masks=`` override the perception)."""
         log = self.logfunction if verbose else None
         if log is not None:
             log("--> Similarity Processing")
@@ -139,6 +139,10 @@ class Ensemble:
                     from firecode_amd.pruner import prune_by_rmsd_rot_corr
 
                     n0, t0 = len(self.coords), perf_counter()
+                    if graph is None:
+                        from firecode_amd.torsion_perception import graphize
+
+                        graph = graphize(self.atoms, self.coords[0])  # firecode/ensemble.py:250
                     self.coords, mask = prune_by_rmsd_rot_corr(
                         self.coords, self.atoms, graph, max_rmsd=max_rmsd,
                         energies=self.energies if use_en else None, max_dE=max_dE, torsions=symmetric_torsions,

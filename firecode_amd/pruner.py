@@ -124,15 +124,19 @@ def prune_many_by_rmsd(ensembles, max_rmsd=0.25, max_dev=None, heavy_atoms_only=
 def prune_by_rmsd_rot_corr(structures, atoms, graph=None, max_rmsd=0.25, max_dev=None, energies=None, max_dE=0.0,
                            logfunction=None, debugfunction=None, torsions=None, rotation_masks=None,
                            min_per_group=20, return_bits=False):
-    """``prune_by_rmsd_rot_corr`` (prism_pruner.pruner; ensemble.py:253-260): RMSD pruning
-    that is invariant to rotations of locally symmetric groups (tBu, Ph, NMe2 ...).
+    """``prune_by_rmsd_rot_corr`` (prism_pruner.pruner; call sites firecode/ensemble.py:253-260,
+    embedder.py:1489-1496, operators.py:626-632): RMSD pruning that is invariant to rotations of
+    locally symmetric groups (tBu, Ph, NMe2 ...).
 
-    ``torsions``: the locally symmetric torsions as ``(i1, i2, i3, i4, n_fold)`` -- what the
-    reference's own perception (``_get_torsions(..., mode="symmetry")`` filtered to dummy
-    rotations) yields; perceiving them is graph work that stays with the caller.
+    Called as the reference calls it -- ``(structures, atoms, graph, max_rmsd=..., energies=...,
+    max_dE=..., logfunction=..., debugfunction=...)`` -- the locally symmetric torsions are
+    perceived from ``graph`` (``firecode_amd.torsion_perception.symmetric_torsions``: the in-tree
+    ``_get_torsions(..., keepdummy=True, mode="symmetry")`` filtered to dummy rotations).
+    ``torsions=`` may instead give them explicitly as ``(i1, i2, i3, i4, n_fold)`` (an empty list:
+    the molecule has none, plain heavy-atom RMSD prune); without both ``graph`` and ``torsions``
+    the call is refused -- it never runs as an uncorrected prune under this name.
     ``rotation_masks`` (T, A) may be given, or are derived from ``graph`` like
-    ``_get_rotation_mask`` does.  With no torsions this is a plain heavy-atom RMSD prune of
-    the mean-centred structures.  PARITY UNPINNED (third-party algorithm restated, see
+    ``_get_rotation_mask`` does.  PARITY UNPINNED (third-party algorithm restated, see
     include/fc_hip.h)."""
     from firecode_amd.torsion_module import N_FOLD_ANGLES
 
@@ -148,7 +152,15 @@ def prune_by_rmsd_rot_corr(structures, atoms, graph=None, max_rmsd=0.25, max_dev
         max_dev = 2 * max_rmsd
     if N == 0:
         return structures, np.ones(0, dtype=bool)
-    torsions = [] if torsions is None else list(torsions)
+    if torsions is None:
+        if graph is None:
+            raise L.FirecodeHipInputError(
+                L.FC_E_INVALID, "prune_by_rmsd_rot_corr needs the molecular graph (third positional argument, as "
+                "firecode/ensemble.py:253 passes it) or torsions=: without them no symmetry correction is possible")
+        from firecode_amd.torsion_perception import symmetric_torsions
+
+        torsions = symmetric_torsions(graph, structures[0], atoms)
+    torsions = list(torsions)
     T = len(torsions)
     quads = L.i64(np.array([t[:4] for t in torsions], dtype=np.int64).reshape(T, 4))
     if rotation_masks is None:

@@ -70,7 +70,7 @@ def similarity_refining(structures, atoms, rmsd_thr=0.5, quadruplets=None, tfd=F
                         max_structures=None, logfunction=None, debugfunction=None, rmsd_rot_corr=False,
                         symmetric_torsions=None, graph=None, rotation_masks=None):
     """embedder.py:1410-1514: [TFD] -> MOI -> RMSD -> [symmetry-corrected RMSD, at most 1000
-    structures and only with locally symmetric torsions, :1480-1505] (no energies are passed
+    structures and only with the molecular graph (``embed_graph``), :1480-1505] (no energies are passed
     at these call sites).  ``max_structures``: the reference skips MOI/RMSD above
     1e5 structures (embedder.py:1446,1467); the GPU path has no such cap unless
     one is given.  Returns the cumulative mask over the input structures."""
@@ -98,7 +98,9 @@ def similarity_refining(structures, atoms, rmsd_thr=0.5, quadruplets=None, tfd=F
             _log(logfunction, f"Skipped {label} pruning (>{max_structures} structures)")
             continue
         stage(fn, label, *args, debugfunction=debugfunction)
-    if rmsd_rot_corr and symmetric_torsions:
+    if rmsd_rot_corr and (symmetric_torsions is not None or graph is not None):
+        # embedder.py:1485-1496: runs whenever the embedder holds the graph; the torsions come from
+        # it unless the caller names them
         if len(alive) <= 1e3:
             from firecode_amd.pruner import prune_by_rmsd_rot_corr
 

@@ -874,6 +874,7 @@ def _tbu_ensemble(seed=0, n_backbone=4, jitter=0.01):
     atoms = np.array(["C"] * 9 + ["H"] * 3)
     edges = [(0, 1), (1, 2), (2, 3), (3, 4), (3, 5), (3, 6), (0, 7), (0, 8), (4, 9), (5, 10), (6, 11)]
     graph = nx.Graph(edges)
+    nx.set_node_attributes(graph, {i: str(a) for i, a in enumerate(atoms)}, "atoms")  # as graphize() leaves them
     torsions = [(1, 2, 3, 4, 3), (2, 1, 0, 7, 2)]
     masks = np.array([fc_rotation_mask(graph, t[:4], len(atoms)) for t in torsions])
     backbone = (0, 1, 2, 3)
@@ -917,9 +918,17 @@ def test_prune_by_rmsd_rot_corr_vs_oracle(fc):
     # masks given explicitly == derived from the graph; no torsions == plain prune of centred structures
     _, mask2 = fc.pruner.prune_by_rmsd_rot_corr(X, atoms, None, max_rmsd=0.25, torsions=torsions, rotation_masks=masks)
     assert np.array_equal(mask2, mask)
-    _, mask3 = fc.pruner.prune_by_rmsd_rot_corr(X, atoms, graph, max_rmsd=0.25)
+    _, mask3 = fc.pruner.prune_by_rmsd_rot_corr(X, atoms, None, max_rmsd=0.25, torsions=[])
     _, ref3 = o.prune_by_rmsd_rot_corr(X, atoms, [], [], [], max_rmsd=0.25)
     assert np.array_equal(mask3, ref3)
+    # THE REFERENCE'S CALL (firecode/ensemble.py:253-260): structures, atoms, graph, keywords -- the
+    # locally symmetric torsions are perceived from the graph, the rotamers collapse all the same
+    logged = []
+    kept4, mask4 = fc.pruner.prune_by_rmsd_rot_corr(X, atoms, graph, max_rmsd=0.25, energies=None, max_dE=1.0,
+                                                    logfunction=logged.append, debugfunction=logged.append)
+    assert np.array_equal(mask4, mask) and np.array_equal(kept4, X[mask]) and "2 symmetric torsions" in logged[0]
+    with pytest.raises(ValueError):  # never an uncorrected prune under this name
+        fc.pruner.prune_by_rmsd_rot_corr(X, atoms, max_rmsd=0.25)
     # energy window, processing order by energy
     en = np.random.default_rng(4).uniform(0, 3, size=len(X))
     _, ref_e = o.prune_by_rmsd_rot_corr(X, atoms, quads, masks, angle_sets, max_rmsd=0.25, energies=en, max_dE=1.0)
@@ -931,6 +940,9 @@ def test_prune_by_rmsd_rot_corr_vs_oracle(fc):
     ens = fc.ensemble.Ensemble(atoms=atoms, coords=X.copy(), basename="rotor", logfunction=lines.append)
     ens.similarity_pruning(moi=False, rmsd=True, rmsd_rot_corr=True, symmetric_torsions=torsions, graph=graph)
     assert len(ens.coords) == 4 and any("symmetry-corrected RMSD" in ln for ln in lines)
+    ens = fc.ensemble.Ensemble(atoms=atoms, coords=X.copy(), basename="rotor", logfunction=lines.append)
+    ens.similarity_pruning(moi=False, rmsd=True, rmsd_rot_corr=True, graph=graph)  # perception from the graph
+    assert len(ens.coords) == 4
     m = fc.refining.similarity_refining(X, atoms, rmsd_thr=0.25, moi=False, rmsd_rot_corr=True,
                                         symmetric_torsions=torsions, graph=graph)
     assert m.sum() == 4
