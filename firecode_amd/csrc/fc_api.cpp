@@ -76,6 +76,8 @@ int launch_embed_mol_transforms(const double *, int64_t, int64_t, const int64_t 
 int launch_embed_pretransform(const double *, int64_t, int64_t, int64_t, const double *,
                               const double *, int, int64_t, double *);
 int last_screen_kind();
+void prune_conventions_set(int);
+int prune_drop_later();
 void comm_teardown();  // fc_comm.cpp
 int comm_rank();
 int comm_world();
@@ -486,6 +488,9 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
   if (defer_slot >= 0) return set_error(FC_E_INVALID, "deferred ladder needs the pair list");
   if (!have_mask) {
     // dense similarity / no pair list: one fused launch per level over the bit matrix
+    if (prune_drop_later())
+      return set_error(FC_E_INVALID, "fc_prune_conventions(drop_later = 1) is implemented by the pair ladder only; "
+                       "this prune needs the bit-matrix levels (dense similarity or no pair list)");
     if (bits_dev == nullptr) return set_error(FC_E_LIMIT, "pair list too long for the one-launch ladder and no bit matrix given");
     FC_TRY(launch_mask_init(mb, N, W, (int64_t)(n_lv + 1) * W));
     int cur = 0;
@@ -2254,6 +2259,12 @@ extern "C" {
 
 // ---- bench hook ----------------------------------------------------------------------
 int fc_screen_last_kind(void) { return last_screen_kind(); }
+
+int fc_prune_conventions(int drop_later) {
+  FC_API_LOCK;
+  prune_conventions_set(drop_later);
+  return FC_OK;
+}
 
 int fc_screen_select(int kind) {
   FC_API_LOCK;

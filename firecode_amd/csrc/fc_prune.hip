@@ -212,7 +212,7 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint64_t *__restrict__ 
                const unsigned long long *__restrict__ n_cand_ptr, unsigned long long cand_cap,
                unsigned long long cap, int64_t N, int64_t W, int64_t min_per_group,
                const int64_t *__restrict__ ladder, int n_ladder, uint64_t *__restrict__ mask_out,
-               unsigned long long *__restrict__ counters) {
+               unsigned long long *__restrict__ counters, int drop_later) {
   extern __shared__ unsigned long long lm[];  // cur[W] | nxt[W]
   __shared__ int s_count;
   __shared__ unsigned long long s_level_cnt[32];
@@ -264,8 +264,10 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint64_t *__restrict__ 
       for (int u = 0; u < U; ++u) {
         const uint32_t i = (uint32_t)(ev[u] >> 32), j = (uint32_t)(ev[u] & 0xffffffffull);
         if (j > i && j < n32) {  // not padding
-          if (((cur[i >> 6] >> (i & 63)) & 1ull) && ((cur[j >> 6] >> (j & 63)) & 1ull))
-            atomicAnd(&nxt[i >> 6], ~(1ull << (i & 63)));
+          if (((cur[i >> 6] >> (i & 63)) & 1ull) && ((cur[j >> 6] >> (j & 63)) & 1ull)) {
+            const uint32_t kill = drop_later ? j : i;  // fc_prune_conventions: which member of a similar pair falls
+            atomicAnd(&nxt[kill >> 6], ~(1ull << (kill & 63)));
+          }
         }
       }
     }
@@ -696,6 +698,12 @@ int launch_level_fused(const uint64_t *bits_dev, int64_t W, const uint64_t *mb_i
   return check_launch("k_level_fused");
 }
 
+// fc_prune_conventions: "a structure is removed at the first LATER similar one" (0, default) or the
+// mirror rule (1); only the pair ladder implements the mirror rule
+static int g_drop_later = 0;
+void prune_conventions_set(int drop_later) { g_drop_later = drop_later ? 1 : 0; }
+int prune_drop_later() { return g_drop_later; }
+
 int launch_ladder_pairs(const uint64_t *pairs_dev, uint64_t *buckets_dev,
                         const unsigned long long *n_pairs_dev, const unsigned long long *n_cand_dev,
                         unsigned long long cand_cap, unsigned long long cap, int64_t N, int64_t W,
@@ -708,7 +716,7 @@ int launch_ladder_pairs(const uint64_t *pairs_dev, uint64_t *buckets_dev,
   const size_t lds = (size_t)2 * W * sizeof(uint64_t);
   hipLaunchKernelGGL(k_ladder_pairs, dim3(1), dim3(1024), lds, ctx().stream, pairs_dev, buckets_dev,
                      n_pairs_dev, n_cand_dev, cand_cap, cap, N, W, min_per_group, ladder_dev, n_ladder,
-                     mask_out_dev, counters_dev);
+                     mask_out_dev, counters_dev, g_drop_later);
   return check_launch("k_ladder_pairs");
 }
 

@@ -13,6 +13,36 @@ from firecode_amd import _lib as L
 from firecode_amd.pt import pt
 
 
+# The conventions of prism_pruner's pruners that the reference tree does not show (SURVEY.md
+# Appendix A: every call site treats the package as a black box), one named switch each, same names
+# and defaults as the CONVENTIONS table of the test oracle.  Once `tests/golden/make_golden_prism.py` has been run
+# where the package is installed (tests/test_prism_golden.py then says which values reproduce its masks)
+# a differing convention is a one-line change here:
+#   strict_lt        similar <=> rmsd < thr and maxdev < max_dev (True), or <= (False)
+#   maxdev_factor    max_dev = maxdev_factor * max_rmsd when not given (firecode/utils.py:501: 2)
+#   drop             "earlier": a structure is removed at the first later similar one; "later": mirror rule
+#   default_max_rmsd threshold of a call that passes none (firecode/ensemble.py:230-235)
+#   window_strict    pairs are comparable iff |dE| < max_dE (True) or <= (False)
+#   moi_tolerance    relative tolerance of prune_by_moment_of_inertia (CHANGELOG.md:256: 1 %)
+CONVENTIONS = {"strict_lt": True, "maxdev_factor": 2.0, "drop": "earlier", "default_max_rmsd": 0.25,
+               "window_strict": True, "moi_tolerance": 0.01}
+
+
+def _thresholds(max_rmsd, max_dev, max_dE):
+    """The conventions as the kernels see them: `<=` is `<` against the next double up."""
+    cv = CONVENTIONS
+    max_rmsd = cv["default_max_rmsd"] if max_rmsd is None else float(max_rmsd)
+    max_dev = cv["maxdev_factor"] * max_rmsd if max_dev is None else float(max_dev)
+    if cv["drop"] not in ("earlier", "later"):
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, f"CONVENTIONS['drop'] = {cv['drop']!r}")
+    L.call("fc_prune_conventions", int(cv["drop"] == "later"))
+    if not cv["strict_lt"]:
+        max_rmsd, max_dev = np.nextafter(max_rmsd, np.inf), np.nextafter(max_dev, np.inf)
+    if not cv["window_strict"]:
+        max_dE = np.nextafter(float(max_dE), np.inf)
+    return float(max_rmsd), float(max_dev), float(max_dE)
+
+
 def _sorted_by_energy(structures, energies):
     """The reference processes structures in ascending-energy order when
     energies are given; same ``np.argsort`` call."""
@@ -33,10 +63,11 @@ def _unsort(mask_sorted, order):
     return mask
 
 
-def prune_by_rmsd(structures, atoms, max_rmsd=0.25, max_dev=None, energies=None, max_dE=0.0,
+def prune_by_rmsd(structures, atoms, max_rmsd=None, max_dev=None, energies=None, max_dE=0.0,
                   debugfunction=None, heavy_atoms_only=True, min_per_group=20):
     """Heavy-atom Kabsch-RMSD pruning: a pair is similar when
-    ``rmsd < max_rmsd and maxdev < max_dev`` (default ``2*max_rmsd``)."""
+    ``rmsd < max_rmsd and maxdev < max_dev`` (default ``2*max_rmsd``; ``max_rmsd`` defaults to
+    ``CONVENTIONS["default_max_rmsd"]``, the case of firecode/ensemble.py:230 which passes none)."""
     t0 = perf_counter()
     structures = L.f64(structures)
     if structures.ndim != 3 or structures.shape[2] != 3:
@@ -44,8 +75,7 @@ def prune_by_rmsd(structures, atoms, max_rmsd=0.25, max_dev=None, energies=None,
     atoms = np.asarray(atoms)
     if atoms.shape[0] != structures.shape[1]:
         raise L.FirecodeHipInputError(L.FC_E_INVALID, "len(atoms) != number of atoms")
-    if max_dev is None:
-        max_dev = 2 * max_rmsd
+    max_rmsd, max_dev, max_dE = _thresholds(max_rmsd, max_dev, max_dE)
     N = structures.shape[0]
     if N == 0:
         return structures, np.ones(0, dtype=bool)
@@ -85,14 +115,14 @@ def rotation_mask(graph, torsion, n_atoms=None):
     return mask
 
 
-def prune_many_by_rmsd(ensembles, max_rmsd=0.25, max_dev=None, heavy_atoms_only=True, min_per_group=20):
+def prune_many_by_rmsd(ensembles, max_rmsd=None, max_dev=None, heavy_atoms_only=True, min_per_group=20):
     """``prune_by_rmsd`` for a queue of ensembles: ``ensembles`` is a list of
     ``(structures, atoms)``; returns a list of ``(structures[mask], mask)``, each identical to
     what ``prune_by_rmsd(structures, atoms, max_rmsd, max_dev)`` returns.  All ensembles are made
     resident, their prunes are enqueued together (``fc_prune_rmsd_many``) and the host waits once;
-    the reference prunes one ensemble per call (firecode/pruning.py:45-50)."""
-    if max_dev is None:
-        max_dev = 2 * max_rmsd
+    the reference prunes one ensemble per call (the loop a maintainer would write around
+    firecode/ensemble.py:230-235)."""
+    max_rmsd, max_dev, _ = _thresholds(max_rmsd, max_dev, 0.0)
     items, resident = [], []
     try:
         for structures, atoms in ensembles:
@@ -148,8 +178,7 @@ def prune_by_rmsd_rot_corr(structures, atoms, graph=None, max_rmsd=0.25, max_dev
     N, A = structures.shape[:2]
     if atoms.shape[0] != A:
         raise L.FirecodeHipInputError(L.FC_E_INVALID, "len(atoms) != number of atoms")
-    if max_dev is None:
-        max_dev = 2 * max_rmsd
+    max_rmsd, max_dev, max_dE = _thresholds(max_rmsd, max_dev, max_dE)
     if N == 0:
         return structures, np.ones(0, dtype=bool)
     if torsions is None:
@@ -197,7 +226,7 @@ def prune_by_rmsd_rot_corr(structures, atoms, graph=None, max_rmsd=0.25, max_dev
     return structures[mask], mask
 
 
-def prune_by_moment_of_inertia(structures, atoms, max_deviation=0.01, energies=None, max_dE=0.0,
+def prune_by_moment_of_inertia(structures, atoms, max_deviation=None, energies=None, max_dE=0.0,
                                debugfunction=None, min_per_group=20):
     """MOI pruning: similar when all three principal moments differ by less
     than ``max_deviation`` relative to the earlier structure of the pair."""
@@ -208,6 +237,8 @@ def prune_by_moment_of_inertia(structures, atoms, max_deviation=0.01, energies=N
     N, A = structures.shape[0], structures.shape[1]
     if N == 0:
         return structures, np.ones(0, dtype=bool)
+    if max_deviation is None:
+        max_deviation = CONVENTIONS["moi_tolerance"]
     masses = np.array([pt.mass(a) for a in atoms], dtype=np.float64)
     order, en_sorted = _sorted_by_energy(structures, energies)
     X = structures if order is None else np.ascontiguousarray(structures[order])

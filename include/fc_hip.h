@@ -129,6 +129,13 @@ int fc_rmsd_simbits(fc_ensemble *ens, double max_rmsd, double max_dev, const dou
                     int64_t *n_grey);
 int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const double *energies,
                   double max_dE, int64_t min_per_group, uint8_t *mask_out, int64_t *stats);
+/* One of the conventions of prism_pruner's pruner that the reference tree does not show (SURVEY.md
+ * Appendix A) as a switch: 0 (default) = inside a chunk a structure is removed at the first LATER
+ * similar one; 1 = the mirror rule (a structure falls to any earlier similar one of its chunk).
+ * The other conventions need no kernel support: "<" against "<=" is one ulp on the threshold
+ * (firecode_amd.pruner.CONVENTIONS).  Process-wide; 1 is served by the pair ladder only
+ * (FC_E_INVALID from a prune that needs the bit-matrix levels). */
+int fc_prune_conventions(int drop_later);
 /* greedy k-ladder replay over caller-supplied bits (N rows x ceil(N/64) words) */
 int fc_greedy_prune_from_bits(const uint64_t *bits, int64_t N, int64_t min_per_group,
                               uint8_t *mask_out);
@@ -435,7 +442,7 @@ int fc_xyz_read(const char *path, int64_t N, int64_t A, char *atoms_out, double 
  * buckets, ladder, result copy) run beside the all-pairs screen of the next one on other
  * streams (FC_PRUNE_LANES=1: strictly one after another).  Results are those of n calls of
  * fc_prune_rmsd: the reference has no batched form, a maintainer's loop over
- * prune_by_rmsd (firecode/ensemble.py:247-251, firecode/pruning.py:45-50) maps to one call.
+ * prune_by_rmsd (firecode/ensemble.py:230-235 in a loop over ensembles) maps to one call.
  * mask_out[r]: N_r bytes; survivors_out (may be NULL): n counts.
  * FC_E_INVALID: NULL or repeated ensemble, n outside 0..4096, thresholds <= 0. */
 int fc_prune_rmsd_many(fc_ensemble *const *ens, int64_t n, double max_rmsd, double max_dev,

@@ -177,7 +177,21 @@ def heavy_mask(atoms):
     return np.asarray(atoms) != "H"
 
 
-def greedy_prune(n, similar, energies=None, max_dE=0.0, min_per_group=20, trace=None):
+# The UNKNOWNs of SURVEY.md Appendix A, one named switch each (defaults = the choices this
+# restatement makes; `tests/golden/make_golden_prism.py` produces the vectors that settle them
+# wherever prism_pruner is installed, and `firecode_amd.pruner.CONVENTIONS` carries the same names):
+#   strict_lt       similar <=> rmsd <  thr (True)  or  rmsd <= thr (False); same for the max deviation
+#   maxdev_factor   max deviation threshold = maxdev_factor * max_rmsd when not given (utils.py:501: 2)
+#   drop            which member of a similar pair falls: "earlier" (a structure is removed at the first
+#                   later similar one) or "later" (a structure falls to any earlier similar one)
+#   default_max_rmsd  threshold of the call that passes none (firecode/ensemble.py:230)
+#   window_strict   energy window: a pair is comparable iff |dE| < max_dE (True) or <= (False)
+CONVENTIONS = {"strict_lt": True, "maxdev_factor": 2.0, "drop": "earlier", "default_max_rmsd": 0.25,
+               "window_strict": True}
+
+
+def greedy_prune(n, similar, energies=None, max_dE=0.0, min_per_group=20, trace=None, drop="earlier",
+                 window_strict=True):
     """Iterative subset pruning (CHANGELOG.md:120,188,198,206).
 
     For each ladder value k with ``k == 1 or min_per_group*k < n_active`` the
@@ -191,8 +205,12 @@ def greedy_prune(n, similar, energies=None, max_dE=0.0, min_per_group=20, trace=
     similar, and the mask is returned in the caller's order.
 
     ``similar(i, j)`` receives indices into the caller's (unsorted) arrays.
+    ``drop="later"``: the mirror rule -- inside a chunk a structure j active at the start of the
+    level is removed as soon as an active i < j with ``similar(i, j)`` is found.
     Returns the boolean survivor mask (n,).
     """
+    if drop not in ("earlier", "later"):
+        raise ValueError(drop)
     if energies is not None and len(energies) == n and n > 0:
         energies = np.asarray(energies, dtype=np.float64)
         order = np.argsort(energies)
@@ -213,13 +231,15 @@ def greedy_prune(n, similar, energies=None, max_dE=0.0, min_per_group=20, trace=
                     if not mask[i]:
                         out[i] = False
                         continue
-                    for j in range(i + 1, last):
+                    partners = range(i + 1, last) if drop == "earlier" else range(first, i)
+                    for j in partners:
                         if not mask[j]:
                             continue
-                        if (i, j) in cache:
+                        if (min(i, j), max(i, j)) in cache:
                             continue
-                        a, b = order[i], order[j]
-                        if energies is not None and abs(energies[a] - energies[b]) >= max_dE:
+                        a, b = order[min(i, j)], order[max(i, j)]
+                        dE = abs(energies[a] - energies[b]) if energies is not None else 0.0
+                        if energies is not None and (dE >= max_dE if window_strict else dE > max_dE):
                             sim = False
                         else:
                             sim = bool(similar(a, b))
@@ -227,7 +247,7 @@ def greedy_prune(n, similar, energies=None, max_dE=0.0, min_per_group=20, trace=
                         if sim:
                             out[i] = False
                             break
-                        cache.add((i, j))
+                        cache.add((min(i, j), max(i, j)))
             mask = out
             if trace is not None:
                 trace.append((k, int(np.count_nonzero(mask))))
@@ -236,7 +256,7 @@ def greedy_prune(n, similar, energies=None, max_dE=0.0, min_per_group=20, trace=
     return result
 
 
-def greedy_prune_from_matrix(S, energies=None, max_dE=0.0, min_per_group=20):
+def greedy_prune_from_matrix(S, energies=None, max_dE=0.0, min_per_group=20, drop="earlier", window_strict=True):
     """Same result as ``greedy_prune`` when every pair's similarity is known
     up front: S[a, b] (bool, indices in the caller's order, symmetric use of
     the (min,max) processing pair).  A level reduces to
@@ -248,7 +268,8 @@ def greedy_prune_from_matrix(S, energies=None, max_dE=0.0, min_per_group=20):
         order = np.argsort(energies)
         Ss = S[np.ix_(order, order)]
         e = energies[order]
-        Ss = Ss & (np.abs(e[:, None] - e[None, :]) < max_dE)
+        dE = np.abs(e[:, None] - e[None, :])
+        Ss = Ss & ((dE < max_dE) if window_strict else (dE <= max_dE))
     else:
         order = np.arange(n)
         Ss = S
@@ -260,32 +281,43 @@ def greedy_prune_from_matrix(S, energies=None, max_dE=0.0, min_per_group=20):
             for c in range(k):
                 first = c * chunk
                 last = n if c == k - 1 else chunk * (c + 1)
-                sub = np.triu(Ss[first:last, first:last], 1) & mask[first:last][None, :]
-                out[first:last] &= ~sub.any(axis=1)
+                if drop == "earlier":
+                    sub = np.triu(Ss[first:last, first:last], 1) & mask[first:last][None, :]
+                    out[first:last] &= ~sub.any(axis=1)
+                else:  # a structure falls to any EARLIER active similar one of its chunk
+                    sub = np.triu(Ss[first:last, first:last], 1) & mask[first:last][:, None]
+                    out[first:last] &= ~sub.any(axis=0)
             mask = out
     result = np.empty(n, dtype=bool)
     result[order] = mask
     return result
 
 
-def prune_by_rmsd(structures, atoms, max_rmsd=0.25, max_dev=None, energies=None, max_dE=0.0):
+def prune_by_rmsd(structures, atoms, max_rmsd=None, max_dev=None, energies=None, max_dE=0.0, strict_lt=None,
+                  maxdev_factor=None, drop=None, window_strict=None):
     """Heavy-atom Kabsch-RMSD pruning (call sites ensemble.py:230-235,
     embedder.py:1472-1474).  Similar <=> ``rmsd < max_rmsd and maxdev <
     max_dev`` with ``max_dev = 2*max_rmsd`` by default -- the rule of the
     in-tree sibling utils.py:501.  Structures are centred on their heavy-atom
-    centroid.  Returns (structures[mask], mask)."""
+    centroid.  The keyword switches default to ``CONVENTIONS``.  Returns (structures[mask], mask)."""
+    cv = CONVENTIONS
+    strict_lt = cv["strict_lt"] if strict_lt is None else strict_lt
+    maxdev_factor = cv["maxdev_factor"] if maxdev_factor is None else maxdev_factor
+    drop = cv["drop"] if drop is None else drop
+    window_strict = cv["window_strict"] if window_strict is None else window_strict
+    max_rmsd = cv["default_max_rmsd"] if max_rmsd is None else max_rmsd
     structures = np.asarray(structures, dtype=np.float64)
     if max_dev is None:
-        max_dev = 2 * max_rmsd
+        max_dev = maxdev_factor * max_rmsd
     hv = heavy_mask(atoms)
     X = structures[:, hv, :]
     X = X - X.mean(axis=1, keepdims=True)
 
     def similar(a, b):
         r, m = rmsd_and_max(X[a], X[b])
-        return r < max_rmsd and m < max_dev
+        return (r < max_rmsd and m < max_dev) if strict_lt else (r <= max_rmsd and m <= max_dev)
 
-    mask = greedy_prune(len(X), similar, energies=energies, max_dE=max_dE)
+    mask = greedy_prune(len(X), similar, energies=energies, max_dE=max_dE, drop=drop, window_strict=window_strict)
     return structures[mask], mask
 
 

@@ -1201,3 +1201,34 @@ def test_context_lifecycle_and_threads(fc):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errors and len(results) == 3
+
+
+def test_convention_switches_reach_the_kernels(fc):
+    """firecode_amd.pruner.CONVENTIONS: each switch against the oracle's same-named switch --
+    '<=' as '<' against the next double, the mirror drop rule in the pair ladder, the factor,
+    the window and the default threshold"""
+    from firecode_amd import pruner
+
+    X, atoms, _ = syn.synthetic_ensemble(400, 14, seed=21)
+    en = np.random.default_rng(5).uniform(0, 2, len(X))
+    Xz = X - X.mean(axis=1, keepdims=True)
+    r01 = o.rmsd_and_max(Xz[0], Xz[1])[0]
+    saved = dict(pruner.CONVENTIONS)
+    try:
+        for kw in (dict(drop="later"), dict(strict_lt=False), dict(maxdev_factor=1.0), dict(window_strict=False),
+                   dict(drop="later", strict_lt=False, maxdev_factor=3.0)):
+            pruner.CONVENTIONS.update(saved)
+            pruner.CONVENTIONS.update(kw)
+            okw = {k: v for k, v in kw.items()}
+            assert np.array_equal(pruner.prune_by_rmsd(X, atoms, 0.5)[1], o.prune_by_rmsd(X, atoms, 0.5, **okw)[1]), kw
+            assert np.array_equal(pruner.prune_by_rmsd(X, atoms, 0.5, energies=en, max_dE=1.0)[1],
+                                  o.prune_by_rmsd(X, atoms, 0.5, energies=en, max_dE=1.0, **okw)[1]), kw
+            assert np.array_equal(pruner.prune_by_rmsd(X[:2], atoms, r01, max_dev=10.0)[1],
+                                  o.prune_by_rmsd(X[:2], atoms, r01, max_dev=10.0, **okw)[1]), kw
+        pruner.CONVENTIONS.update(saved)
+        pruner.CONVENTIONS["default_max_rmsd"] = 0.4
+        assert np.array_equal(pruner.prune_by_rmsd(X, atoms)[1], o.prune_by_rmsd(X, atoms, 0.4)[1])
+    finally:
+        pruner.CONVENTIONS.clear()
+        pruner.CONVENTIONS.update(saved)
+        pruner._thresholds(0.5, None, 0.0)  # back to the default drop rule in the library

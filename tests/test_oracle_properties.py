@@ -160,3 +160,45 @@ def test_random_csearch_stop_rule_and_align_by_moi_identity():
     X = rng.normal(scale=2.0, size=(5, 12, 3)) + 3.0
     out = o.align_by_moi(rng.uniform(1, 16, size=12), X)
     assert np.abs(out - (X - X.mean(axis=1, keepdims=True))).max() < 1e-13
+
+
+def test_oracle_kabsch_against_an_independent_implementation():
+    """scipy.spatial.transform.Rotation.align_vectors solves the same problem (Wahba / Kabsch) with its
+    own SVD path: rssd = sqrt(sum |a - R b|^2), so rmsd = rssd / sqrt(A); the rotation maps b onto a like
+    get_alignment_matrix does (hypermolecule_class.py:77-84) -- two implementations, one answer"""
+    from scipy.spatial.transform import Rotation
+
+    for A in (4, 7, 23, 50):
+        for _ in range(10):
+            p = rng.normal(size=(A, 3))
+            q = p @ syn.random_rotation(rng) + 0.3 * rng.normal(size=(A, 3))
+            p, q = p - p.mean(axis=0), q - q.mean(axis=0)
+            rot, rssd = Rotation.align_vectors(p, q)
+            r, m = o.rmsd_and_max(p, q)
+            assert abs(r - rssd / np.sqrt(A)) < 1e-12
+            assert np.allclose(o.get_alignment_matrix(p, q), rot.as_matrix(), atol=1e-10)
+            assert abs(m - np.linalg.norm(p - q @ rot.as_matrix().T, axis=1).max()) < 1e-10
+
+
+def test_convention_switches_are_what_their_names_say():
+    X, atoms, _ = syn.synthetic_ensemble(60, 12, seed=8)
+    Xz = X - X.mean(axis=1, keepdims=True)
+    r01 = o.rmsd_and_max(Xz[0], Xz[1])[0]
+    twin = np.stack([X[0], X[0] + 1e-4])
+    # "<" vs "<=" exactly on a pair's rmsd
+    assert o.prune_by_rmsd(X[:2], atoms, r01, max_dev=10.0)[1].all()
+    assert not o.prune_by_rmsd(X[:2], atoms, r01, max_dev=10.0, strict_lt=False)[1].all()
+    # which member of a similar pair falls
+    assert o.prune_by_rmsd(twin, atoms, 0.5)[1].tolist() == [False, True]
+    assert o.prune_by_rmsd(twin, atoms, 0.5, drop="later")[1].tolist() == [True, False]
+    # the max-deviation factor: one atom 1.3 A off, rmsd = 1.3 / sqrt(12) = 0.375
+    spike = np.stack([X[0], X[0].copy()])
+    spike[1, 0, 2] += 1.3
+    assert o.prune_by_rmsd(spike, atoms, 0.7)[1].tolist() == [False, True]                      # 1.3 < 2 * 0.7
+    assert o.prune_by_rmsd(spike, atoms, 0.7, maxdev_factor=1.0)[1].all()                       # ~1.1 after the fit > 0.7
+    # the energy window
+    assert not o.prune_by_rmsd(twin, atoms, 0.5, energies=np.array([0.0, 0.5]), max_dE=1.0)[1].all()
+    assert o.prune_by_rmsd(twin, atoms, 0.5, energies=np.array([0.0, 1.0]), max_dE=1.0)[1].all()
+    assert not o.prune_by_rmsd(twin, atoms, 0.5, energies=np.array([0.0, 1.0]), max_dE=1.0, window_strict=False)[1].all()
+    # no threshold given: the default
+    assert np.array_equal(o.prune_by_rmsd(X, atoms)[1], o.prune_by_rmsd(X, atoms, o.CONVENTIONS["default_max_rmsd"])[1])
