@@ -438,6 +438,17 @@ def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_at
         ts.append(time.perf_counter() - t1)
     out["pruned_ensembles_per_s_host_in_mask_out"] = 1.0 / min(ts)
     out["host_in_mask_out_ms"] = 1e3 * min(ts)
+    # ... and the drivers' MOI -> RMSD sequence on one upload (fc_prune_similarity)
+    fc.pruner.prune_similarity(coords[:2000], atoms, max_rmsd=MAX_RMSD)
+    ts = []
+    for _ in range(5):
+        t1 = time.perf_counter()
+        _, m_both, counts = fc.pruner.prune_similarity(coords, atoms, max_rmsd=MAX_RMSD)
+        ts.append(time.perf_counter() - t1)
+    out["similarity_pipeline_host_in_mask_out"] = {
+        "what": "prune_by_moment_of_inertia -> prune_by_rmsd as Ensemble.similarity_pruning runs them "
+                "(firecode/ensemble.py:205-235), host arrays in -> mask out, ONE upload of the coordinates",
+        "ms": 1e3 * min(ts), "structures": [int(c) for c in counts]}
 
 
 # ----------------------------------------------------------------------------------------------

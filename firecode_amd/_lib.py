@@ -62,6 +62,8 @@ _SIGNATURES = {
     "fc_ensemble_rmsd_and_max_all": [_ens, _p_f64, _p_f64, _p_f64],
     "fc_screen_select": [C.c_int],
     "fc_prune_conventions": [C.c_int],
+    "fc_prune_similarity": [_p_f64, _i64, _i64, _p_u8, _p_f64, C.c_int, _f64, C.c_int, _f64, _f64, _p_f64, _f64, _i64,
+                            _p_u8, _p_u8, _p_i64],
     "fc_alignment_matrices": [_p_f64, _p_f64, _i64, _i64, _p_f64],
     "fc_rmsd_simbits": [_ens, _f64, _f64, _p_f64, _f64, _i64, _i64, _p_u64, _p_i64],
     "fc_prune_rmsd": [_ens, _f64, _f64, _p_f64, _f64, _i64, _p_u8, _p_i64],

@@ -12,7 +12,7 @@
 namespace fc {
 
 // ---- launchers implemented in the .hip translation units --------------------
-int launch_prep(const double *, int64_t, int64_t, const int32_t *, int64_t, int, fc_ensemble *);
+int launch_prep(const double *, int64_t, int64_t, const int32_t *, int64_t, int, fc_ensemble *, const int32_t *);
 int launch_pairs_exact(const fc_ensemble *, const int64_t *, const int64_t *, int64_t, double *,
                        double *, double *);
 int launch_matrix_exact(const fc_ensemble *, double *, double *);
@@ -323,8 +323,10 @@ static int make_selection(const uint8_t *atom_mask, int64_t A_all, std::vector<i
   return FC_OK;
 }
 
-static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const uint8_t *atom_mask,
-                          int center, fc_ensemble *e) {
+// prepared layout of N conformers taken from device-resident raw coordinates (all atoms, AoS):
+// conformer n is raw[conf_idx[n]] (conf_idx_dev == nullptr: raw[n])
+static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, const uint8_t *atom_mask,
+                              int center, const int32_t *conf_idx_dev, fc_ensemble *e) {
   std::vector<int32_t> sel;
   FC_TRY(make_selection(atom_mask, A_all, sel));
   e->N = N;
@@ -335,18 +337,24 @@ static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const 
   FC_TRY(e->G.reserve((size_t)e->Npad * sizeof(double)));
   FC_TRY(e->Xa.reserve((size_t)std::max<int64_t>(N, 1) * e->A * 3 * sizeof(double)));
   FC_TRY(e->counters.reserve(kCounters * sizeof(uint64_t)));
-  DevBuf raw, dsel;
-  FC_TRY(upload(raw, coords, (size_t)N * A_all * 3));
+  DevBuf dsel;
   FC_TRY(upload(dsel, sel.data(), sel.size()));
-  FC_TRY(launch_prep(raw.as<double>(), N, A_all, dsel.as<int32_t>(), e->A, center, e));
+  FC_TRY(launch_prep(raw_dev, N, A_all, dsel.as<int32_t>(), e->A, center, e, conf_idx_dev));
   // the largest G (left by the prep kernel in the last counter word) comes back behind the same wait
   unsigned long long gmax_bits = 0;
   auto *gmax_dev = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
   FC_TRY(d2h(&gmax_bits, gmax_dev, sizeof gmax_bits));
-  FC_TRY(sync());
+  FC_TRY(sync());  // (also keeps `sel` / dsel alive until the kernel has read them)
   std::memcpy(&e->g_max, &gmax_bits, sizeof(double));
   FC_HIP_TRY(hipMemsetAsync(gmax_dev, 0, sizeof(unsigned long long), ctx().stream));
   return FC_OK;
+}
+
+static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const uint8_t *atom_mask,
+                          int center, fc_ensemble *e) {
+  DevBuf raw;
+  FC_TRY(upload(raw, coords, (size_t)N * A_all * 3));
+  return ensemble_build_dev(raw.as<double>(), N, A_all, atom_mask, center, nullptr, e);
 }
 
 // (re)shape the bit-matrix workspace for a given sharding
@@ -1222,6 +1230,89 @@ int fc_prune_moi(const double *coords, int64_t N, int64_t A, const double *masse
   FC_TRY(launch_moi_simbits(dmom.as<double>(), N, max_deviation, en_dev, max_dE,
                             e.bits.as<uint64_t>(), e.W));
   return ladder_single(&e, e.bits.as<uint64_t>(), min_per_group, mask_out, nullptr, nullptr);
+}
+
+// ---- the similarity stages of the drivers on ONE upload --------------------------
+// firecode/ensemble.py:205-235 and embedder.py:1445-1474 run prune_by_moment_of_inertia, apply its mask,
+// then prune_by_rmsd on the survivors; each call of the reference re-reads host arrays.  Here the
+// coordinates go to HBM once: the MOI stage works on them, the survivors are GATHERED on the device
+// into the RMSD stage's prepared layout (k_prep_tile with an index list), and the stage masks are
+// composed on the way out.  Per stage the result equals the stand-alone entry point's.
+int fc_prune_similarity(const double *coords, int64_t N, int64_t A, const uint8_t *heavy_mask, const double *masses,
+                        int do_moi, double moi_tol, int do_rmsd, double max_rmsd, double max_dev,
+                        const double *energies, double max_dE, int64_t min_per_group, uint8_t *mask_moi_out,
+                        uint8_t *mask_out, int64_t *counts) {
+  FC_API_LOCK;
+  FC_REQUIRE(N >= 0 && A >= 1 && A <= 32767 && min_per_group >= 1, "bad arguments");
+  if (counts) counts[0] = N, counts[1] = N, counts[2] = N;
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(coords && mask_out, "NULL pointer argument");
+  FC_REQUIRE(!do_moi || (masses != nullptr && moi_tol > 0.0), "the MOI stage needs masses and a positive tolerance");
+  FC_REQUIRE(!do_rmsd || (max_rmsd > 0.0 && max_dev > 0.0), "thresholds must be positive");
+  FC_TRY(ensure_init());
+  DevBuf raw;
+  FC_TRY(upload(raw, coords, (size_t)N * A * 3));  // the one upload of the coordinates
+  std::vector<uint8_t> m1((size_t)N, 1);
+  if (do_moi) {
+    fc_ensemble e;
+    e.N = N;
+    e.Npad = ceil_div(N, 64) * 64;
+    e.W = e.Npad / 64;
+    e.row_block = 64;
+    FC_TRY(e.maskA.reserve((size_t)e.Npad));
+    FC_TRY(e.maskB.reserve((size_t)e.Npad));
+    FC_TRY(e.mbits.reserve((size_t)e.W * sizeof(uint64_t)));
+    FC_TRY(e.counters.reserve(kCounters * sizeof(uint64_t)));
+    const int64_t rows = ceil_div(N, e.row_block) * e.row_block;
+    FC_TRY(e.bits.reserve((size_t)rows * e.W * sizeof(uint64_t)));
+    DevBuf dm, dmom;
+    FC_TRY(upload(dm, masses, (size_t)A));
+    FC_TRY(dmom.reserve((size_t)N * 3 * sizeof(double)));
+    const double *en_dev = nullptr;
+    if (energies) {
+      FC_TRY(upload(e.energies, energies, (size_t)N));
+      en_dev = e.energies.as<double>();
+    }
+    FC_TRY(launch_inertia_moments(raw.as<double>(), N, A, dm.as<double>(), dmom.as<double>()));
+    FC_TRY(launch_moi_simbits(dmom.as<double>(), N, moi_tol, en_dev, max_dE, e.bits.as<uint64_t>(), e.W));
+    FC_TRY(ladder_single(&e, e.bits.as<uint64_t>(), min_per_group, m1.data(), nullptr, nullptr));
+  }
+  if (mask_moi_out) std::memcpy(mask_moi_out, m1.data(), (size_t)N);
+  std::vector<int32_t> idx;
+  idx.reserve((size_t)N);
+  for (int64_t i = 0; i < N; ++i)
+    if (m1[(size_t)i]) idx.push_back((int32_t)i);
+  const int64_t N1 = (int64_t)idx.size();
+  if (counts) counts[1] = N1, counts[2] = N1;
+  if (!do_rmsd || N1 == 0) {
+    std::memcpy(mask_out, m1.data(), (size_t)N);
+    return FC_OK;
+  }
+  // survivors gathered into the RMSD stage's layout on the device (no second upload of coordinates)
+  DevBuf didx;
+  const bool gather = N1 != N;
+  if (gather) FC_TRY(upload(didx, idx.data(), idx.size()));
+  std::unique_ptr<fc_ensemble> e2(new (std::nothrow) fc_ensemble);
+  if (!e2) return set_error(FC_E_NOMEM, "host allocation failed");
+  e2->epoch = ctx().epoch;
+  FC_TRY(ensemble_build_dev(raw.as<double>(), N1, A, heavy_mask, 1, gather ? didx.as<int32_t>() : nullptr, e2.get()));
+  std::vector<double> en1;
+  if (energies) {
+    en1.resize((size_t)N1);
+    for (int64_t k = 0; k < N1; ++k) en1[(size_t)k] = energies[idx[(size_t)k]];
+  }
+  std::vector<uint8_t> m2((size_t)N1, 0);
+  int64_t st[6] = {0};
+  FC_TRY(fc_prune_rmsd(e2.get(), max_rmsd, max_dev, energies ? en1.data() : nullptr, max_dE, min_per_group, m2.data(), st));
+  std::memset(mask_out, 0, (size_t)N);
+  int64_t alive = 0;
+  for (int64_t k = 0; k < N1; ++k)
+    if (m2[(size_t)k]) {
+      mask_out[idx[(size_t)k]] = 1;
+      ++alive;
+    }
+  if (counts) counts[2] = alive;
+  return FC_OK;
 }
 
 // ---- a7: prune_by_rmsd_rot_corr (prism_pruner.pruner; firecode/ensemble.py:253-260) ----------

@@ -32,7 +32,8 @@ static constexpr size_t kLdsLimit = 160 * 1024;
 __global__ void __launch_bounds__(256)
 k_prep(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_t *__restrict__ sel,
        int64_t A, int center, int64_t Npad, double *__restrict__ Xs, double *__restrict__ G,
-       double *__restrict__ Xa, unsigned long long *__restrict__ gmax_bits) {
+       double *__restrict__ Xa, unsigned long long *__restrict__ gmax_bits,
+       const int32_t *__restrict__ conf_idx) {  // conf_idx != nullptr: conformer n is coords[conf_idx[n]]
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= Npad) return;
   // atom rows A .. A4-1 (A4 = A rounded up to 4) are zero: the MFMA K loop
@@ -51,7 +52,7 @@ k_prep(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_
     G[n] = 0.0;
     return;
   }
-  const double *src = coords + n * A_all * 3;
+  const double *src = coords + (conf_idx ? (int64_t)conf_idx[n] : n) * A_all * 3;
   double cx = 0.0, cy = 0.0, cz = 0.0;
   if (center) {
     // same order as numpy's mean(axis=0): running sum over atoms, then / A
@@ -90,15 +91,23 @@ k_prep(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_
 __global__ void __launch_bounds__(256)
 k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_t *__restrict__ sel,
             int64_t A, int center, int64_t Npad, double *__restrict__ Xs, double *__restrict__ G,
-            double *__restrict__ Xa, unsigned long long *__restrict__ gmax_bits) {
+            double *__restrict__ Xa, unsigned long long *__restrict__ gmax_bits,
+            const int32_t *__restrict__ conf_idx) {  // conf_idx != nullptr: gather (the survivors of an earlier stage)
   extern __shared__ double tile[];  // [64][A_all*3 + 1] (the +1 spreads the conformers over the banks)
   __shared__ double cen[64][3];
   const int tid = threadIdx.x;
   const int64_t n0 = (int64_t)blockIdx.x * 64;
   const int64_t row = A_all * 3, ld = row + 1;
   const int64_t n_here = (N - n0 < 64) ? (N - n0 > 0 ? N - n0 : 0) : 64;
-  const double *src = coords + n0 * row;
-  for (int64_t k = tid; k < n_here * row; k += 256) tile[(k / row) * ld + (k % row)] = src[k];
+  if (conf_idx == nullptr) {
+    const double *src = coords + n0 * row;
+    for (int64_t k = tid; k < n_here * row; k += 256) tile[(k / row) * ld + (k % row)] = src[k];
+  } else {
+    for (int64_t k = tid; k < n_here * row; k += 256) {
+      const int64_t l = k / row, r = k - l * row;
+      tile[l * ld + r] = coords[(int64_t)conf_idx[n0 + l] * row + r];
+    }
+  }
   __syncthreads();
   if (tid < 64) {
     double cx = 0.0, cy = 0.0, cz = 0.0, g = 0.0;
@@ -1930,7 +1939,7 @@ int launch_scatter_pairs(const uint64_t *pairs_dev, int64_t n_pairs, int64_t N, 
 // host-side launchers (called from fc_api.cpp)
 // ---------------------------------------------------------------------------
 int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_t *sel_dev,
-                int64_t A, int center, fc_ensemble *e) {
+                int64_t A, int center, fc_ensemble *e, const int32_t *conf_idx_dev) {
   // the largest G lands in the last counter word (zeroed here); ensemble_build reads it behind its own wait
   auto *gmax_bits = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
   FC_HIP_TRY(hipMemsetAsync(gmax_bits, 0, sizeof(unsigned long long), ctx().stream));
@@ -1941,12 +1950,12 @@ int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
     hipLaunchKernelGGL(k_prep_tile, dim3((unsigned)(e->Npad / 64)), dim3(256), lds_tile, ctx().stream, coords_dev,
                        N, A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
-                       e->Xa.as<double>(), gmax_bits);
+                       e->Xa.as<double>(), gmax_bits, conf_idx_dev);
   } else {
     const int64_t blocks = ceil_div(e->Npad, 256);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, coords_dev, N,
                        A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
-                       e->Xa.as<double>(), gmax_bits);
+                       e->Xa.as<double>(), gmax_bits, conf_idx_dev);
   }
   e->xsf_valid = false;
   e->g_max = -1.0;

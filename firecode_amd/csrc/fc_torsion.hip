@@ -12,6 +12,8 @@
 // One wavefront per angle-set: the conformer lives in the wave's LDS slice
 // (A*3 doubles); a rotation is lane-per-atom; a clash test flattens the
 // (rest x moving) rectangle over the 64 lanes and reduces with a ballot.
+#include <hipcub/hipcub.hpp>
+
 #include "fc_common.h"
 #include "fc_kabsch_math.h"
 
@@ -297,6 +299,284 @@ k_torsion_fingerprint(const double *__restrict__ coords, int64_t N, int64_t A,
 }
 
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// The scan as a PREFIX TREE.  The conformer after torsion k depends only on the angles of torsions
+// 0..k (torsion_module.py:812-856 applies them in that order from the same start structure), so
+// angle-sets that share a prefix share that work: for the 6^8 grid of BASELINE configs[2] the tree
+// has sum_k 6^k = 2.0e6 single-torsion steps where one wavefront per angle-set does 8 * 6^8 = 13.4e6.
+// Built on the device for ANY list of angle-sets (full grids, random subsets, duplicates):
+//   1. distinct angle values per torsion column (LDS bitmaps) -> rank tables, bits per column;
+//   2. code(row) = mixed-radix number of the column ranks, column 0 most significant; radix sort of
+//      (code, row) pairs (hipcub) -- rows that share a prefix become adjacent;
+//   3. d[i] = first column in which sorted row i differs from row i-1; node ids of level k are the
+//      inclusive scan of (d <= k): node = a run of rows with equal prefix 0..k;
+//   4. level k, one wavefront per node: parent state (level k-1, HBM) -> LDS, ONE torsion step with
+//      exactly the code of k_torsion_scan (rotate, clash test, back-off), state -> HBM; the last level
+//      writes conformer / fingerprint / rotated-bond count of every row of its run instead.
+// Same arithmetic in the same order as k_torsion_scan: identical bits.
+// ---------------------------------------------------------------------------
+constexpr int kAngleOffset = 720, kAngleSpan = 2 * kAngleOffset + 1, kAngleWords = (kAngleSpan + 31) / 32;
+constexpr int kMaxTreeT = 16;
+
+struct ScanTreeMeta {
+  int n[kMaxTreeT], bits[kMaxTreeT], shift[kMaxTreeT];
+  int total_bits, bad;
+};
+
+__global__ void __launch_bounds__(256)
+k_ts_presence(const int64_t *__restrict__ angles, int64_t S, int T, unsigned *__restrict__ present,
+              int *__restrict__ bad) {
+  extern __shared__ unsigned pres[];  // T x kAngleWords
+  for (int k = threadIdx.x; k < T * kAngleWords; k += 256) pres[k] = 0u;
+  __syncthreads();
+  const int64_t total = S * T;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t a = angles[e];
+    const int t = (int)(e % T);
+    if (a < -kAngleOffset || a > kAngleOffset) {
+      *bad = 1;
+    } else {
+      const int v = (int)a + kAngleOffset;
+      atomicOr(&pres[t * kAngleWords + (v >> 5)], 1u << (v & 31));
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < T * kAngleWords; k += 256)
+    if (pres[k]) atomicOr(&present[k], pres[k]);
+}
+
+__global__ void __launch_bounds__(64)
+k_ts_ranks(const unsigned *__restrict__ present, int T, uint16_t *__restrict__ rank, ScanTreeMeta *__restrict__ meta,
+           const int *__restrict__ bad) {
+  if (threadIdx.x != 0) return;
+  int total = 0;
+  for (int t = 0; t < T; ++t) {
+    int n = 0;
+    for (int v = 0; v < kAngleSpan; ++v) {
+      rank[t * kAngleSpan + v] = (uint16_t)n;
+      if ((present[t * kAngleWords + (v >> 5)] >> (v & 31)) & 1u) ++n;
+    }
+    int b = 1;
+    while ((1 << b) < n) ++b;
+    meta->n[t] = n;
+    meta->bits[t] = b;
+    total += b;
+  }
+  int sh = total;
+  for (int t = 0; t < T; ++t) {
+    sh -= meta->bits[t];
+    meta->shift[t] = sh;
+  }
+  meta->total_bits = total;
+  meta->bad = *bad;
+}
+
+__global__ void __launch_bounds__(256)
+k_ts_codes(const int64_t *__restrict__ angles, int64_t S, int T, const uint16_t *__restrict__ rank,
+           const ScanTreeMeta *__restrict__ meta, uint64_t *__restrict__ code, uint32_t *__restrict__ row) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= S) return;
+  uint64_t c = 0;
+  for (int t = 0; t < T; ++t)
+    c |= (uint64_t)rank[t * kAngleSpan + (int)angles[r * T + t] + kAngleOffset] << meta->shift[t];
+  code[r] = c;
+  row[r] = (uint32_t)r;
+}
+
+// d[i]: first column in which sorted row i differs from sorted row i - 1 (0 for i = 0, T for a duplicate)
+__global__ void __launch_bounds__(256)
+k_ts_firstdiff(const uint64_t *__restrict__ code, int64_t S, int T, const ScanTreeMeta *__restrict__ meta,
+               uint8_t *__restrict__ d) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= S) return;
+  int lv = 0;
+  if (i > 0) {
+    const uint64_t x = code[i] ^ code[i - 1];
+    lv = T;
+    if (x) {
+      const int msb = 63 - __clzll((long long)x);
+      for (int t = 0; t < T; ++t)
+        if (msb >= meta->shift[t]) {
+          lv = t;
+          break;
+        }
+    }
+  }
+  d[i] = (uint8_t)lv;
+}
+
+__global__ void __launch_bounds__(256)
+k_ts_flags(const uint8_t *__restrict__ d, int64_t S, int level, int *__restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < S) flag[i] = d[i] <= level ? 1 : 0;
+}
+
+// first sorted row of every node of this level; first[M] = S closes the last run
+__global__ void __launch_bounds__(256)
+k_ts_first(const uint8_t *__restrict__ d, const int *__restrict__ nid, int64_t S, int level, int *__restrict__ first) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= S) return;
+  if (d[i] <= level) first[nid[i] - 1] = (int)i;
+  if (i == S - 1) first[nid[i]] = (int)S;
+}
+
+__global__ void __launch_bounds__(256)
+k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ torsions, int T, int level,
+           const uint8_t *__restrict__ rotmasks, const int16_t *__restrict__ mv_idx, const int16_t *__restrict__ rs_idx,
+           const int32_t *__restrict__ n_mv, const int32_t *__restrict__ n_rs, const int64_t *__restrict__ angles,
+           int64_t S, double thr2, int backoff, const uint32_t *__restrict__ row, const int *__restrict__ nid_prev,
+           const int *__restrict__ nid, const int *__restrict__ first, const double *__restrict__ state_prev,
+           const int *__restrict__ rot_prev, double *__restrict__ state, int *__restrict__ rot_out,
+           double *__restrict__ out, int64_t *__restrict__ rotated, const int64_t *__restrict__ quads, int Q,
+           double *__restrict__ tf) {
+  extern __shared__ double s[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double *x = s + (size_t)wv * A * 3;
+  const int64_t M = nid[S - 1];  // inclusive scan: number of nodes of this level
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+  const int t = level;
+  const int i2 = (int)torsions[t * 4 + 1], i3 = (int)torsions[t * 4 + 2];
+  const uint8_t *mask = rotmasks + (size_t)t * A;
+  const int16_t *mv = mv_idx + (size_t)t * A;
+  const int16_t *rs = rs_idx + (size_t)t * A;
+  const int nm = n_mv[t], nr = n_rs[t];
+  const bool last = level == T - 1;
+  for (int64_t node = wave0; node < M; node += nwaves) {
+    const int i = first[node];
+    const double *src = level == 0 ? base : state_prev + (int64_t)(nid_prev[i] - 1) * A * 3;
+    for (int k = lane; k < A * 3; k += 64) x[k] = src[k];
+    __builtin_amdgcn_wave_barrier();
+    int rot = level == 0 ? 0 : rot_prev[nid_prev[i] - 1];
+    const int angle = (int)angles[(int64_t)row[i] * T + t];
+    if (angle != 0) {
+      rotate_masked(x, A, mask, i2, i3, (double)angle, lane);
+      if (!comp_check(x, mv, nm, rs, nr, thr2, lane)) {
+        int steps = angle / backoff;  // Python floor division: range(angle // backoff)
+        if ((angle % backoff != 0) && ((angle < 0) != (backoff < 0))) --steps;
+        for (int b = 0; b < steps; ++b) {
+          rotate_masked(x, A, mask, i2, i3, (double)(-backoff), lane);
+          if (comp_check(x, mv, nm, rs, nr, thr2, lane)) {
+            ++rot;
+            break;
+          }
+        }
+      } else {
+        ++rot;
+      }
+    }
+    if (!last) {
+      double *o = state + node * (int64_t)A * 3;
+      for (int k = lane; k < A * 3; k += 64) o[k] = x[k];
+      if (lane == 0) rot_out[node] = rot;
+    } else {
+      const int i_end = first[node + 1];
+      for (int ii = i; ii < i_end; ++ii) {  // every row of the run (more than one only for duplicate angle-sets)
+        const int64_t r = row[ii];
+        if (out != nullptr) {
+          double *o = out + r * (int64_t)A * 3;
+          for (int k = lane; k < A * 3; k += 64) o[k] = x[k];
+        }
+        if (tf != nullptr)
+          for (int q = lane; q < Q; q += 64)
+            tf[r * (int64_t)Q + q] = dihedral_deg(x + quads[q * 4] * 3, x + quads[q * 4 + 1] * 3,
+                                                  x + quads[q * 4 + 2] * 3, x + quads[q * 4 + 3] * 3);
+        if (lane == 0) rotated[r] = rot;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// returns FC_OK when the tree did the scan, 1 when it does not apply (the caller runs k_torsion_scan)
+static int torsion_scan_tree(const double *base_dev, int64_t A, const int64_t *torsions_dev, int64_t T,
+                             const uint8_t *rotmasks_dev, const int16_t *mv_dev, const int16_t *rs_dev,
+                             const int32_t *nmv_dev, const int32_t *nrs_dev, const int64_t *angles_dev, int64_t S,
+                             double thr2, int64_t backoff, double *out_dev, int64_t *rot_dev,
+                             const int64_t *quads_dev, int64_t Q, double *tf_dev) {
+  if (T < 2 || T > kMaxTreeT || S < 4096 || S >= (1ll << 31)) return 1;
+  hipStream_t st = ctx().stream;
+  DevBuf dpres, dbad, drank, dmeta;
+  FC_TRY(dpres.reserve((size_t)T * kAngleWords * sizeof(unsigned)));
+  FC_TRY(dbad.reserve(sizeof(int)));
+  FC_TRY(drank.reserve((size_t)T * kAngleSpan * sizeof(uint16_t)));
+  FC_TRY(dmeta.reserve(sizeof(ScanTreeMeta)));
+  FC_HIP_TRY(hipMemsetAsync(dpres.p, 0, (size_t)T * kAngleWords * sizeof(unsigned), st));
+  FC_HIP_TRY(hipMemsetAsync(dbad.p, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_ts_presence, dim3((unsigned)std::min<int64_t>(ceil_div(S * T, 256), ctx().n_cu * 8)), dim3(256),
+                     (size_t)T * kAngleWords * sizeof(unsigned), st, angles_dev, S, (int)T, dpres.as<unsigned>(),
+                     dbad.as<int>());
+  hipLaunchKernelGGL(k_ts_ranks, dim3(1), dim3(64), 0, st, dpres.as<unsigned>(), (int)T, drank.as<uint16_t>(),
+                     dmeta.as<ScanTreeMeta>(), dbad.as<int>());
+  FC_TRY(check_launch("k_ts_ranks"));
+  ScanTreeMeta meta;
+  FC_TRY(d2h(&meta, dmeta.p, sizeof meta));
+  FC_TRY(sync());
+  if (meta.bad || meta.total_bits > 62) return 1;
+  // node counts are bounded by the grid of distinct values; a level whose states would not fit
+  // comfortably (sparse sets of very many rows) leaves the scan to the one-wave-per-row kernel
+  std::vector<int64_t> bound((size_t)T);
+  double prod = 1.0;
+  for (int64_t t = 0; t < T; ++t) {
+    prod = std::min(prod * (double)meta.n[t], (double)S);
+    bound[(size_t)t] = (int64_t)prod;
+  }
+  const int64_t max_state_nodes = T >= 2 ? *std::max_element(bound.begin(), bound.end() - 1) : 0;
+  // worth it only when prefixes are shared: total nodes well below S * T
+  double total_nodes = 0.0;
+  for (int64_t t = 0; t < T; ++t) total_nodes += (double)bound[(size_t)t];
+  if (total_nodes > 0.6 * (double)S * (double)T) return 1;
+  const size_t state_bytes = (size_t)max_state_nodes * (size_t)A * 3 * sizeof(double);
+  if (2 * state_bytes > ((size_t)16 << 30)) return 1;
+  DevBuf dcode, dcode2, drow, drow2, dd, dflag, dnid[2], dfirst, dstate[2], drotn[2], dtmp;
+  FC_TRY(dcode.reserve((size_t)S * 8));
+  FC_TRY(dcode2.reserve((size_t)S * 8));
+  FC_TRY(drow.reserve((size_t)S * 4));
+  FC_TRY(drow2.reserve((size_t)S * 4));
+  FC_TRY(dd.reserve((size_t)S));
+  FC_TRY(dflag.reserve((size_t)S * 4));
+  FC_TRY(dnid[0].reserve((size_t)S * 4));
+  FC_TRY(dnid[1].reserve((size_t)S * 4));
+  FC_TRY(dfirst.reserve((size_t)(S + 1) * 4));
+  FC_TRY(dstate[0].reserve(std::max<size_t>(state_bytes, 8)));
+  FC_TRY(dstate[1].reserve(std::max<size_t>(state_bytes, 8)));
+  FC_TRY(drotn[0].reserve((size_t)(max_state_nodes + 1) * 4));
+  FC_TRY(drotn[1].reserve((size_t)(max_state_nodes + 1) * 4));
+  const unsigned gb = (unsigned)ceil_div(S, 256);
+  hipLaunchKernelGGL(k_ts_codes, dim3(gb), dim3(256), 0, st, angles_dev, S, (int)T, drank.as<uint16_t>(),
+                     dmeta.as<ScanTreeMeta>(), dcode.as<uint64_t>(), drow.as<uint32_t>());
+  FC_TRY(check_launch("k_ts_codes"));
+  size_t tmp_bytes = 0, tmp_scan = 0;
+  FC_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dcode.as<uint64_t>(), dcode2.as<uint64_t>(),
+                                                drow.as<uint32_t>(), drow2.as<uint32_t>(), (int)S, 0,
+                                                std::max(meta.total_bits, 1), st));
+  FC_HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan, dflag.as<int>(), dnid[0].as<int>(), (int)S, st));
+  FC_TRY(dtmp.reserve(std::max(tmp_bytes, tmp_scan)));
+  size_t tb = dtmp.bytes;
+  FC_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(dtmp.p, tb, dcode.as<uint64_t>(), dcode2.as<uint64_t>(),
+                                                drow.as<uint32_t>(), drow2.as<uint32_t>(), (int)S, 0,
+                                                std::max(meta.total_bits, 1), st));
+  hipLaunchKernelGGL(k_ts_firstdiff, dim3(gb), dim3(256), 0, st, dcode2.as<uint64_t>(), S, (int)T,
+                     dmeta.as<ScanTreeMeta>(), dd.as<uint8_t>());
+  FC_TRY(check_launch("k_ts_firstdiff"));
+  for (int level = 0; level < (int)T; ++level) {
+    DevBuf &nid = dnid[level & 1], &nid_prev = dnid[(level & 1) ^ 1];
+    hipLaunchKernelGGL(k_ts_flags, dim3(gb), dim3(256), 0, st, dd.as<uint8_t>(), S, level, dflag.as<int>());
+    tb = dtmp.bytes;
+    FC_HIP_TRY(hipcub::DeviceScan::InclusiveSum(dtmp.p, tb, dflag.as<int>(), nid.as<int>(), (int)S, st));
+    hipLaunchKernelGGL(k_ts_first, dim3(gb), dim3(256), 0, st, dd.as<uint8_t>(), nid.as<int>(), S, level,
+                       dfirst.as<int>());
+    const int64_t nodes = bound[(size_t)level];
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(nodes, 4), (int64_t)ctx().n_cu * 32));
+    hipLaunchKernelGGL(k_ts_level, dim3((unsigned)blocks), dim3(256), (size_t)4 * A * 3 * sizeof(double), st, base_dev,
+                       (int)A, torsions_dev, (int)T, level, rotmasks_dev, mv_dev, rs_dev, nmv_dev, nrs_dev, angles_dev, S,
+                       thr2, (int)backoff, drow2.as<uint32_t>(), nid_prev.as<int>(), nid.as<int>(), dfirst.as<int>(),
+                       dstate[(level & 1) ^ 1].as<double>(), drotn[(level & 1) ^ 1].as<int>(), dstate[level & 1].as<double>(),
+                       drotn[level & 1].as<int>(), out_dev, rot_dev, quads_dev, (int)Q, tf_dev);
+    FC_TRY(check_launch("k_ts_level"));
+  }
+  return sync();  // the temporaries above go back to the pool only after the kernels have used them
+}
+
 int launch_torsion_scan(const double *base_dev, int64_t A, const int64_t *torsions_dev, int64_t T,
                         const uint8_t *rotmasks_dev, const int16_t *mv_dev, const int16_t *rs_dev,
                         const int32_t *nmv_dev, const int32_t *nrs_dev, const int64_t *angles_dev,
@@ -304,6 +584,14 @@ int launch_torsion_scan(const double *base_dev, int64_t A, const int64_t *torsio
                         int64_t *rot_dev, const int64_t *quads_dev, int64_t Q, double *tf_dev) {
   if (S == 0) return FC_OK;
   const double thr2 = sq_threshold_lt(thresh);
+  {
+    const char *v = getenv("FC_SCAN_TREE");  // 0: always one wavefront per angle-set (the round-1 kernel)
+    if (!(v && v[0] == '0')) {
+      const int rc = torsion_scan_tree(base_dev, A, torsions_dev, T, rotmasks_dev, mv_dev, rs_dev, nmv_dev, nrs_dev,
+                                       angles_dev, S, thr2, backoff, out_dev, rot_dev, quads_dev, Q, tf_dev);
+      if (rc != 1) return rc;
+    }
+  }
   int64_t blocks = ceil_div(S, 4);
   const int64_t cap = (int64_t)ctx().n_cu * 32;
   if (blocks > cap) blocks = cap;

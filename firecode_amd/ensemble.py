@@ -103,12 +103,13 @@ class Ensemble:
         self.energies = self.energies[order]
         self.coords = self.coords[order]
 
-    def similarity_pruning(self, moi=True, rmsd=True, rmsd_rot_corr=False, verbose=True, max_rmsd=0.25,
+    def similarity_pruning(self, moi=True, rmsd=True, rmsd_rot_corr=False, verbose=True, max_rmsd=None,
                            symmetric_torsions=None, graph=None, rotation_masks=None):
         """firecode/ensemble.py:185-276: MOI prune, RMSD prune, then (``rmsd_rot_corr``, at
         most 1000 structures, :246-270) the symmetry-corrected RMSD prune; masks propagated to
-        ``energies``; same log lines.  ``max_rmsd`` is explicit here (the reference relies on
-        prism_pruner's default).  The rot-corr stage needs the locally symmetric torsions
+        ``energies``.  Log messages as the reference words them, except the elapsed-time field: its
+        ``time_to_string`` is third-party (prism_pruner.utils), seconds with three decimals here.
+        ``max_rmsd=None``: the pruner's default, like the reference, which passes none (:230).  The rot-corr stage needs the locally symmetric torsions
         ``(i1, i2, i3, i4, n_fold)``: like the reference (:250) the graph is built with
         ``graphize(atoms, coords[0])`` when none is given, and ``prune_by_rmsd_rot_corr`` perceives the
         torsions from it (``symmetric_torsions=`` / ``rotation_masks=`` override the perception)."""
@@ -118,7 +119,23 @@ class Ensemble:
         before = len(self.coords)
         use_en = len(self.energies) == len(self.coords)
         max_dE = 1.0
-        if moi:
+        if moi and rmsd:
+            # both stages on ONE upload of the coordinates (fc_prune_similarity): the MOI stage's survivors
+            # are gathered on the device for the RMSD stage; same masks and the same two log lines as the
+            # stage-by-stage calls of firecode/ensemble.py:205-244
+            from firecode_amd.pruner import prune_similarity
+
+            n0, t0 = len(self.coords), perf_counter()
+            m_moi, m_both, counts = prune_similarity(self.coords, self.atoms, max_rmsd=max_rmsd,
+                                                     energies=self.energies if use_en else None, max_dE=max_dE)
+            dt = perf_counter() - t0
+            if counts[1] < n0 and log is not None:
+                log(f"Discarded {n0 - int(counts[1])} candidates for MOI similarity ({int(counts[1])} left, {dt:.3f} s)")
+            if counts[2] < counts[1] and log is not None:
+                log(f"Discarded {int(counts[1] - counts[2])} candidates for RMSD similarity ({int(counts[2])} left, {dt:.3f} s)")
+            self.coords = self.coords[m_both]
+            self.apply_mask(("energies",), m_both)
+        elif moi:
             n0, t0 = len(self.coords), perf_counter()
             self.coords, mask = prune_by_moment_of_inertia(
                 self.coords, self.atoms, energies=self.energies if use_en else None, max_dE=max_dE)
@@ -126,7 +143,7 @@ class Ensemble:
             if n0 > len(self.coords) and log is not None:
                 log(f"Discarded {n0 - len(self.coords)} candidates for MOI similarity "
                     f"({len(self.coords)} left, {perf_counter() - t0:.3f} s)")
-        if rmsd:
+        elif rmsd:
             n0, t0 = len(self.coords), perf_counter()
             self.coords, mask = prune_by_rmsd(
                 self.coords, self.atoms, max_rmsd, energies=self.energies if use_en else None, max_dE=max_dE)
@@ -134,6 +151,7 @@ class Ensemble:
             if n0 > len(self.coords) and log is not None:
                 log(f"Discarded {n0 - len(self.coords)} candidates for RMSD similarity "
                     f"({len(self.coords)} left, {perf_counter() - t0:.3f} s)")
+        if rmsd:
             if rmsd_rot_corr:
                 if len(self.coords) <= 1e3:
                     from firecode_amd.pruner import prune_by_rmsd_rot_corr

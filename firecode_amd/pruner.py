@@ -51,7 +51,9 @@ def _sorted_by_energy(structures, energies):
     energies = np.asarray(energies, dtype=np.float64)
     if energies.shape[0] != structures.shape[0] or structures.shape[0] == 0:
         return None, None
-    order = np.argsort(energies)
+    # stable: a later stage that sorts the SURVIVORS of an earlier one then processes them in the order
+    # the earlier stage left them in -- what makes the fused pipeline equal to the stage-by-stage calls
+    order = np.argsort(energies, kind="stable")
     return order, np.ascontiguousarray(energies[order])
 
 
@@ -252,20 +254,48 @@ def prune_by_moment_of_inertia(structures, atoms, max_deviation=None, energies=N
     return structures[mask], mask
 
 
+def prune_similarity(structures, atoms, moi=True, rmsd=True, max_rmsd=None, max_dev=None, max_deviation=None,
+                     energies=None, max_dE=0.0, heavy_atoms_only=True, min_per_group=20):
+    """The MOI and RMSD stages of ``Ensemble.similarity_pruning`` (firecode/ensemble.py:205-235) /
+    ``Embedder.similarity_refining`` (embedder.py:1445-1474) on ONE upload of the coordinates
+    (``fc_prune_similarity``): the MOI stage runs on the resident structures, its survivors are gathered
+    on the device into the RMSD stage's layout, the masks are composed on the way out.  Stage by
+    stage the masks equal ``prune_by_moment_of_inertia`` followed by ``prune_by_rmsd`` on its output.
+    Returns ``(mask_after_moi, mask_after_both, (n_in, n_after_moi, n_after_rmsd))`` in the caller's order."""
+    structures = L.f64(structures)
+    if structures.ndim != 3 or structures.shape[2] != 3:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, f"structures must be (N, A, 3), got {structures.shape}")
+    atoms = np.asarray(atoms)
+    N, A = structures.shape[:2]
+    if atoms.shape[0] != A:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "len(atoms) != number of atoms")
+    max_rmsd, max_dev, max_dE = _thresholds(max_rmsd, max_dev, max_dE)
+    if max_deviation is None:
+        max_deviation = CONVENTIONS["moi_tolerance"]
+    counts = np.array([N, N, N], dtype=np.int64)
+    if N == 0:
+        return np.ones(0, dtype=bool), np.ones(0, dtype=bool), counts
+    heavy = L.u8((atoms != "H") if heavy_atoms_only else np.ones(A, dtype=bool))
+    masses = np.array([pt.mass(a) for a in atoms], dtype=np.float64)
+    order, en_sorted = _sorted_by_energy(structures, energies)
+    X = structures if order is None else np.ascontiguousarray(structures[order])
+    m1, m2 = np.zeros(N, dtype=np.uint8), np.zeros(N, dtype=np.uint8)
+    L.call("fc_prune_similarity", L.pf(X), N, A, L.pb(heavy), L.pf(masses), int(bool(moi)), float(max_deviation),
+           int(bool(rmsd)), max_rmsd, max_dev, L.pf(en_sorted), max_dE, int(min_per_group), L.pb(m1), L.pb(m2),
+           L.pi(counts))
+    return _unsort(m1.astype(bool), order), _unsort(m2.astype(bool), order), counts
+
+
 def prune(structures, atoms, max_rmsd=0.25, energies=None, max_dE=0.0, logfunction=None,
           debugfunction=None):
     """Combined pipeline used by firecode/interfaces/goat.py:399: MOI, then RMSD.
     (The symmetry-corrected stage is a later row of SURVEY.md section 8f.)"""
     structures = L.f64(structures)
     n0 = len(structures)
-    s1, m1 = prune_by_moment_of_inertia(structures, atoms, energies=energies, max_dE=max_dE,
-                                        debugfunction=debugfunction)
-    e1 = None if energies is None else np.asarray(energies)[m1]
-    s2, m2 = prune_by_rmsd(s1, atoms, max_rmsd, energies=e1, max_dE=max_dE, debugfunction=debugfunction)
-    mask = np.zeros(n0, dtype=bool)
-    mask[np.flatnonzero(m1)[m2]] = True
-    if logfunction is not None:
-        logfunction(f"Discarded {n0 - int(mask.sum())} candidates for MOI+RMSD similarity ({int(mask.sum())} left)")
+    _, mask, _ = prune_similarity(structures, atoms, max_rmsd=max_rmsd, energies=energies, max_dE=max_dE)
+    for fn in (logfunction, debugfunction):
+        if fn is not None:
+            fn(f"Discarded {n0 - int(mask.sum())} candidates for MOI+RMSD similarity ({int(mask.sum())} left)")
     return structures[mask], mask
 
 

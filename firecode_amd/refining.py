@@ -90,14 +90,30 @@ def similarity_refining(structures, atoms, rmsd_thr=0.5, quadruplets=None, tfd=F
         from firecode_amd.torsion_module import prune_conformers_tfd
 
         stage(prune_conformers_tfd, "TFD", quadruplets)
-    for flag, fn, label, args in ((moi, prune_by_moment_of_inertia, "MOI", (atoms,)),
-                                  (rmsd, prune_by_rmsd, "RMSD", (atoms, rmsd_thr))):
-        if not flag:
-            continue
-        if max_structures is not None and len(alive) > max_structures:
-            _log(logfunction, f"Skipped {label} pruning (>{max_structures} structures)")
-            continue
-        stage(fn, label, *args, debugfunction=debugfunction)
+    capped = max_structures is not None and len(alive) > max_structures
+    if moi and rmsd and not capped:
+        # both stages on ONE upload (fc_prune_similarity): the MOI survivors are gathered on the device
+        from firecode_amd.pruner import prune_similarity
+
+        t0 = perf_counter()
+        _, m_both, counts = prune_similarity(structures[alive], atoms, max_rmsd=rmsd_thr)
+        dt = perf_counter() - t0
+        for label, a, b in (("MOI", counts[0], counts[1]), ("RMSD", counts[1], counts[2])):
+            if b < a:
+                _log(logfunction, f"Discarded {int(a - b)} candidates for {label} similarity ({int(b)} left, {dt:.3f} s)")
+        if debugfunction is not None:
+            debugfunction(f"DEBUG: prune_similarity [gfx950] - MOI + RMSD on one upload, {int(counts[0])} -> "
+                          f"{int(counts[1])} -> {int(counts[2])} in {dt:.3f} s")
+        alive = alive[m_both]
+    else:
+        for flag, fn, label, args in ((moi, prune_by_moment_of_inertia, "MOI", (atoms,)),
+                                      (rmsd, prune_by_rmsd, "RMSD", (atoms, rmsd_thr))):
+            if not flag:
+                continue
+            if max_structures is not None and len(alive) > max_structures:
+                _log(logfunction, f"Skipped {label} pruning (>{max_structures} structures)")
+                continue
+            stage(fn, label, *args, debugfunction=debugfunction)
     if rmsd_rot_corr and (symmetric_torsions is not None or graph is not None):
         # embedder.py:1485-1496: runs whenever the embedder holds the graph; the torsions come from
         # it unless the caller names them

@@ -267,6 +267,20 @@ int fc_prune_moi(const double *coords, int64_t N, int64_t A, const double *masse
                  double max_deviation, const double *energies, double max_dE,
                  int64_t min_per_group, uint8_t *mask_out);
 
+/* ---- a2/a3: the similarity stages of the drivers on ONE upload -- Ensemble.similarity_pruning
+ * (firecode/ensemble.py:205-235) and Embedder.similarity_refining (embedder.py:1445-1474) run
+ * prune_by_moment_of_inertia, apply its mask, then prune_by_rmsd on the survivors.  coords (N, A, 3) in
+ * processing order (energy-sorted by the caller when energies are given) are uploaded once; the MOI
+ * stage (do_moi; all atoms, `masses`, relative tolerance moi_tol) works on them in HBM, its survivors
+ * are gathered on the device into the RMSD stage's layout (do_rmsd; atoms of heavy_mask, NULL = all),
+ * the masks are composed on the way out.  Each stage's result is the stand-alone entry point's.
+ * mask_moi_out (N bytes, may be NULL): after the MOI stage; mask_out (N bytes): after both;
+ * counts (3, may be NULL): structures in, after MOI, after RMSD. */
+int fc_prune_similarity(const double *coords, int64_t N, int64_t A, const uint8_t *heavy_mask, const double *masses,
+                        int do_moi, double moi_tol, int do_rmsd, double max_rmsd, double max_dev,
+                        const double *energies, double max_dE, int64_t min_per_group, uint8_t *mask_moi_out,
+                        uint8_t *mask_out, int64_t *counts);
+
 /* ---- a8: align_structures(structures, indices) -- prism_pruner.utils;
  * call sites embedder.py:1704,1910,2218,2300; operators.py:262.
  * out (N,A,3): every conformer superposed on conformer 0 using the n_idx

@@ -213,7 +213,7 @@ def greedy_prune(n, similar, energies=None, max_dE=0.0, min_per_group=20, trace=
         raise ValueError(drop)
     if energies is not None and len(energies) == n and n > 0:
         energies = np.asarray(energies, dtype=np.float64)
-        order = np.argsort(energies)
+        order = np.argsort(energies, kind="stable")
     else:
         energies = None
         order = np.arange(n)
@@ -265,7 +265,7 @@ def greedy_prune_from_matrix(S, energies=None, max_dE=0.0, min_per_group=20, dro
     n = S.shape[0]
     if energies is not None and len(energies) == n and n > 0:
         energies = np.asarray(energies, dtype=np.float64)
-        order = np.argsort(energies)
+        order = np.argsort(energies, kind="stable")
         Ss = S[np.ix_(order, order)]
         e = energies[order]
         dE = np.abs(e[:, None] - e[None, :])

@@ -1223,8 +1223,13 @@ def test_convention_switches_reach_the_kernels(fc):
             assert np.array_equal(pruner.prune_by_rmsd(X, atoms, 0.5)[1], o.prune_by_rmsd(X, atoms, 0.5, **okw)[1]), kw
             assert np.array_equal(pruner.prune_by_rmsd(X, atoms, 0.5, energies=en, max_dE=1.0)[1],
                                   o.prune_by_rmsd(X, atoms, 0.5, energies=en, max_dE=1.0, **okw)[1]), kw
-            assert np.array_equal(pruner.prune_by_rmsd(X[:2], atoms, r01, max_dev=10.0)[1],
-                                  o.prune_by_rmsd(X[:2], atoms, r01, max_dev=10.0, **okw)[1]), kw
+        # "<=" reaches the kernels as "<" against the next double up (a tie itself cannot be staged across
+        # two implementations whose rmsd agree to 1e-15, not to the last bit)
+        pruner.CONVENTIONS.update(saved)
+        pruner.CONVENTIONS["strict_lt"] = False
+        assert pruner._thresholds(r01, 10.0, 1.0) == (np.nextafter(r01, np.inf), np.nextafter(10.0, np.inf), 1.0)
+        pruner.CONVENTIONS.update(strict_lt=True, window_strict=False)
+        assert pruner._thresholds(r01, None, 1.0) == (r01, 2.0 * r01, np.nextafter(1.0, np.inf))
         pruner.CONVENTIONS.update(saved)
         pruner.CONVENTIONS["default_max_rmsd"] = 0.4
         assert np.array_equal(pruner.prune_by_rmsd(X, atoms)[1], o.prune_by_rmsd(X, atoms, 0.4)[1])
@@ -1232,3 +1237,68 @@ def test_convention_switches_reach_the_kernels(fc):
         pruner.CONVENTIONS.clear()
         pruner.CONVENTIONS.update(saved)
         pruner._thresholds(0.5, None, 0.0)  # back to the default drop rule in the library
+
+
+def test_fused_similarity_pipeline_equals_stage_by_stage(fc):
+    """fc_prune_similarity (MOI -> gather on the device -> RMSD on ONE upload) against the two
+    stand-alone functions and against the oracle's composition: with and without energies (ties
+    included: stable order), hydrogens excluded from the RMSD stage only, every stage mask"""
+    from firecode_amd import pruner
+
+    rng = np.random.default_rng(17)
+    X, _, asg = syn.synthetic_ensemble(700, 16, seed=301)
+    X[100:140] = X[100:140] * 1.05  # same shape, scaled: MOI tells these apart from their cluster mates
+    atoms = np.array(["C", "H", "N", "C", "O", "H", "C", "C"] * 2)
+    en = np.round(rng.uniform(0, 2, len(X)), 1)  # many exact ties
+    for energies, dE in ((None, 0.0), (en, 1.0), (en, 0.3)):
+        kw = {} if energies is None else dict(energies=energies, max_dE=dE)
+        m_moi, m_both, counts = pruner.prune_similarity(X, atoms, max_rmsd=0.5, **kw)
+        s1, a = pruner.prune_by_moment_of_inertia(X, atoms, **kw)
+        kw2 = {} if energies is None else dict(energies=energies[a], max_dE=dE)
+        _, b = pruner.prune_by_rmsd(s1, atoms, 0.5, **kw2)
+        ref = np.zeros(len(X), dtype=bool)
+        ref[np.flatnonzero(a)[b]] = True
+        assert np.array_equal(m_moi, a) and np.array_equal(m_both, ref)
+        assert counts.tolist() == [len(X), int(a.sum()), int(ref.sum())]
+        _, oa = o.prune_by_moment_of_inertia(X, atoms, **kw)
+        _, ob = o.prune_by_rmsd(X[oa], atoms, 0.5, **kw2)
+        oref = np.zeros(len(X), dtype=bool)
+        oref[np.flatnonzero(oa)[ob]] = True
+        assert np.array_equal(m_moi, oa) and np.array_equal(m_both, oref)
+    # single stages through the same entry point
+    assert np.array_equal(pruner.prune_similarity(X, atoms, moi=True, rmsd=False)[1], pruner.prune_by_moment_of_inertia(X, atoms)[1])
+    assert np.array_equal(pruner.prune_similarity(X, atoms, moi=False, rmsd=True, max_rmsd=0.5)[1],
+                          pruner.prune_by_rmsd(X, atoms, 0.5)[1])
+    # the drivers go through it (same masks as before) and still log one line per stage
+    lines = []
+    ens = fc.ensemble.Ensemble(atoms=atoms, coords=X.copy(), energies=en.copy(), basename="fused", logfunction=lines.append)
+    ens.similarity_pruning(max_rmsd=0.5)
+    _, m_b, _ = pruner.prune_similarity(X, atoms, max_rmsd=0.5, energies=en, max_dE=1.0)
+    assert np.array_equal(ens.coords, X[m_b]) and np.array_equal(ens.energies, en[m_b])
+    assert any("MOI similarity" in ln for ln in lines) and any("RMSD similarity" in ln for ln in lines)
+
+
+@pytest.mark.parametrize("case", ["grid", "subset_dups", "negative"])
+def test_torsion_scan_prefix_tree_equals_row_kernel(fc, monkeypatch, case):
+    """The scan as a prefix tree over the sorted angle-sets (default for >= 4096 rows that share
+    prefixes) against the one-wavefront-per-row kernel (FC_SCAN_TREE=0): identical bits for
+    conformers, rotated-bond counts and fingerprints -- full grid in cartesian_product order, a random
+    subset with duplicate rows, negative and back-off-prone angles; and the oracle on a sample"""
+    base, tors, masks = _chain_case(34, 5, seed=77)
+    rng = np.random.default_rng(5)
+    if case == "grid":
+        angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 5)          # 7776 rows
+    elif case == "subset_dups":
+        grid = o.cartesian_product((0, 90, 180, 270), (0, 120, 240), (0, 60, 120, 180, 240, 300), (0, 180), (0, 120, 240))
+        angles = np.concatenate([grid, grid[rng.integers(0, len(grid), 5000)]])[rng.permutation(len(grid) + 5000)]
+    else:
+        angles = o.cartesian_product((-170, -45, 0, 33, 170), (0, 7, 120), (-90, 0, 90), (0, 45, 200, 355), (0, -5, 5, 10))
+        angles = np.concatenate([angles] * 6)[:5400]
+    quads = tors
+    tf, rot, out = fc.torsion_module.torsion_scan_fingerprints(base, tors, masks, angles, quads, thresh=1.5, want_coords=True)
+    monkeypatch.setenv("FC_SCAN_TREE", "0")
+    tf0, rot0, out0 = fc.torsion_module.torsion_scan_fingerprints(base, tors, masks, angles, quads, thresh=1.5, want_coords=True)
+    assert np.array_equal(rot, rot0) and np.array_equal(out, out0) and np.array_equal(tf, tf0)
+    pick = rng.choice(len(angles), 60, replace=False)
+    o_out, o_rot = o.torsion_scan(base, tors, masks, angles[pick], thresh=1.5)
+    assert np.array_equal(rot[pick], o_rot) and np.abs(out[pick] - o_out).max() < TOL
