@@ -148,16 +148,29 @@ def mask_checks(mask, assign):
             "survivors_are_last_cluster_members": bool(np.array_equal(np.flatnonzero(mask), np.sort(last)))}
 
 
-def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, world=1):
+def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, world=1, stats=None):
     """Dominant kernel of the prune = the all-pairs screen, on the matrix pipe.
-    achieved = executed MFMA flops per launch (9 covariance entries x K = atoms padded to 4, per
-    pair) / HIP-event kernel time."""
+    achieved = MFMA flops of the all-pairs covariance (9 entries x K = atoms padded to 4, per pair) /
+    HIP-event time of the screen kernels.  The lean fp32 screen runs in two stages (subset of the
+    atoms for every 16 x 32 unit, the remaining work only for the units the subset cannot rule out):
+    `achieved` keeps counting the full covariance per pair -- the work a one-stage screen does --
+    and `executed_frac` gives what was actually issued to the matrix pipe."""
     kind = _lib.screen_last_kind()
     f32 = kind == 32
     peak = PEAK_F32_MFMA if f32 else PEAK_F64_MFMA
     a4 = (n_atoms + 3) // 4 * 4
     flops = 2 * 9 * a4
     tflops = owned_pairs * flops / (kernel_ms * 1e-3) / 1e12
+    staged = None
+    if f32 and stats is not None and len(stats) > 7 and stats[6] > 0 and stats[7] == 0:
+        ks = a4 // 4
+        ks1 = (ks + 1) // 2
+        executed = owned_pairs * 2 * 9 * 4 * ks1 + int(stats[6]) * 512 * 2 * 9 * 4 * ks
+        staged = {"units_queued_for_the_full_test": int(stats[6]), "units_total_about": int(owned_pairs // 512),
+                  "executed_mfma_tflops": executed / (kernel_ms * 1e-3) / 1e12,
+                  "executed_frac": executed / (kernel_ms * 1e-3) / 1e12 / peak,
+                  "kernels": "k_simbits_screen_mfma_f32<4, false, true> (subset stage, sample + rest) + "
+                             "k_screen_density_verdict + k_screen_units_f32 (full test per queued unit)"}
     traffic, src = None, None
     pmc = os.path.join(ROOT, "profiles", "r02_pmc_screen_f32.json" if f32 else "r02_pmc_screen_f64.json")
     if traffic_file and world == 1 and os.path.exists(pmc):
@@ -165,7 +178,8 @@ def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, wo
         src = "from_file: " + os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes of an earlier run of this kernel, not of this run)"
     return {"bound": "mfma", "kernel": "k_simbits_screen_mfma_f32" if f32 else "k_simbits_screen_mfma",
             "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": traffic,
-            "traffic_source": src, "kernel_ms": kernel_ms, "flops_per_pair": flops, "dtype": "f32" if f32 else "f64"}
+            "traffic_source": src, "kernel_ms": kernel_ms, "flops_per_pair": flops, "dtype": "f32" if f32 else "f64",
+            "two_stage": staged}
 
 
 def timed_prunes(ens, steps, warmup, sharded, overlap=True):
@@ -336,7 +350,7 @@ def run_prune(args, workload, fc, _lib, fdist, syn, rank, world, sharded, barrie
         "pruned_ensembles_per_s": steps / elapsed,
     }
     out.update(mask_checks(mask, assign))
-    out["roofline"] = screen_roofline(_lib, t_kernel_ms, owned, n_atoms, world=world)
+    out["roofline"] = screen_roofline(_lib, t_kernel_ms, owned, n_atoms, world=world, stats=stats)
     out["roofline"]["kernel_ms_source"] = ("HIP events on the kernel's stream around every %sth launch of the timed region "
                                            "(an event pair costs the stream ~14 us; FC_BENCH_EVENT_STRIDE=1 times all)"
                                            % os.environ.get("FC_BENCH_EVENT_STRIDE", "8")) + ("" if world == 1 else "; rank 0's launches")

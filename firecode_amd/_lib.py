@@ -527,7 +527,7 @@ class DeviceEnsemble:
 
     def bench_prune(self, max_rmsd, max_dev, reps=1, want_mask=True):
         mask = np.zeros(self.N, dtype=np.uint8) if want_mask else None
-        stats = np.zeros(6, dtype=np.int64)
+        stats = np.zeros(8, dtype=np.int64)  # [6], [7]: the subset stage of the lean fp32 screen
         t_k, t_s = C.c_double(0), C.c_double(0)
         call("fc_bench_prune_rmsd", self.handle, float(max_rmsd), float(max_dev), int(reps),
              C.byref(t_k), C.byref(t_s), pb(mask), pi(stats))

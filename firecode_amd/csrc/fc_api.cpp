@@ -550,7 +550,7 @@ static int ensemble_twin(fc_ensemble *ens, fc_ensemble **out) {
     t->epoch = ens->epoch;
     t->N = ens->N, t->A = ens->A, t->Npad = ens->Npad, t->W = ens->W;
     t->Xs.alias(ens->Xs), t->Xa.alias(ens->Xa), t->G.alias(ens->G);
-    if (ens->xsf_valid) t->Xsf.alias(ens->Xsf), t->xsf_valid = true;
+    if (ens->xsf_valid) t->Xsf.alias(ens->Xsf), t->sub.alias(ens->sub), t->xsf_valid = true;
     t->g_max = ens->g_max;
     FC_TRY(t->counters.reserve(kCounters * sizeof(uint64_t)));
     ens->twin = t.release();
@@ -2406,6 +2406,11 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
     FC_TRY(ladder_single(ens, ens->bits.as<uint64_t>(), 20, mask_out, &levels, &survivors, cnt,
                          ens->simq.as<uint64_t>(), false, true));
   }
+  if (getenv("FC_DEBUG")) {
+    const uint64_t *cnt_host = static_cast<const uint64_t *>(c.pinned) + (size_t)(reps - 1) * (size_t)stride + ens->W;
+    fprintf(stderr, "[fc] bench prune: candidates %llu, similar %llu, screen units the subset stage queued: %llu\n",
+            (unsigned long long)cnt_host[1], (unsigned long long)cnt_host[2], (unsigned long long)cnt_host[13]);
+  }
   if (ms_simbits_kernel) *ms_simbits_kernel = t_kernel;  // mean over the timed prunes
   if (ms_step) *ms_step = total / (double)reps;
   if (stats) {
@@ -2415,6 +2420,11 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
     stats[3] = (int64_t)cnt[3];
     stats[4] = levels;
     stats[5] = survivors;
+    // the subset stage of the lean fp32 screen in the last prune: units it queued for the full test
+    // (0 with the single-stage kernels), and whether its sample found similarity dense
+    const uint64_t *cnt_last = static_cast<const uint64_t *>(c.pinned) + (size_t)(reps - 1) * (size_t)stride + ens->W;
+    stats[6] = redo ? 0 : (int64_t)cnt_last[13];
+    stats[7] = redo ? 0 : (int64_t)cnt_last[15];
   }
   return FC_OK;
 }

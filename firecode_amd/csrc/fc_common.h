@@ -158,6 +158,7 @@ constexpr double kScreenMargin = 1e-6;
 
 // uint64 words of fc_ensemble::counters: [0..10] queue lengths and flags, [16..) bucket fill
 // levels of the pair ladder, [11] "the fp64 screen has to run again" (k_screen_verdict),
+// [13] units queued by the subset stage of the lean fp32 screen, [15] its density verdict (1 = dense),
 // [63] scratch of the screen launcher
 constexpr size_t kCounters = 64;
 
@@ -184,6 +185,8 @@ struct fc_ensemble {
   fc::DevBuf Xa;               // [n][a][c] doubles: same (centred, selected) atoms, conformer-major
   fc::DevBuf G;                // [Npad] sum of squares per conformer
   fc::DevBuf Xsf;              // fp32 copy of Xs for the single-precision screen (made on first use)
+  fc::DevBuf sub;              // [Npad][8] floats: stage-1 subset statistics per conformer (made with Xsf)
+  fc::DevBuf unitq;            // queue of the 16 x 32 units the subset stage could not rule out
   bool xsf_valid = false;
   double g_max = -1.0;         // largest G (host copy, found on first use): sizes the fp32 screen's band
   // prune workspace (allocated on first use, kept for later calls)

@@ -11,6 +11,8 @@
 // coordinate with one coalesced 512-byte access, and the 8 consecutive
 // conformers a wavefront treats as "rows" are 64 contiguous bytes that the
 // scalar unit fetches with s_load (wave-uniform address).
+#include <type_traits>
+
 #include "fc_common.h"
 #include <vector>
 #include "fc_kabsch_math.h"
@@ -412,7 +414,7 @@ constexpr size_t kStageBytes = kStagePairs * 8 + kStageWords * 4 + 8;
 // distribution, 1.7 % candidates: screen 4.3 ms with 48 slots)
 constexpr int kStagePairsF32 = 384;
 constexpr int kStageWordsF32 = 128;
-constexpr size_t kStageBytesF32 = kStagePairsF32 * 8 + kStageWordsF32 * 4 + 8;
+constexpr size_t kStageBytesF32 = kStagePairsF32 * 8 + kStageWordsF32 * 4 + 16 + 32 * 4;  // + counters + unit list
 
 template <int CAP = kStagePairs>
 __device__ __forceinline__ void stage_pairs(uint64_t m, bool may, unsigned i, unsigned j,
@@ -947,14 +949,38 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 // ladder, the multi-GPU exchange) -- the dense bit matrix, 12.6 MB of mostly zeros per launch at
 // 10^4 conformers, is neither written nor queued by words; when the pair queue overflows the host
 // repeats the prune with BITS = true.
-template <int NW, bool BITS = true>
+//
+// The lean kernel also runs the K loop in TWO STAGES (`sub` != nullptr).  The superposition residual
+// of a SUBSET S of the atoms bounds the whole from below:
+//     A * msd(p, q) = min_R sum_all |p_a - R q_a|^2  >=  min_{R,t} sum_S |p_a - R q_a - t|^2
+//                   = G_S^c(p) + G_S^c(q) - 2 lambda_max(B_S^c)
+// (G_S^c, B_S^c: norms and covariance of the subset centred on ITS OWN centroid), so a pair whose
+// subset already fails  lambda_max(B_S^c) > L_S = (G_S^c(p) + G_S^c(q) - A thr2) / 2  is dissimilar
+// whatever the other atoms do.  S = the atoms of the even k-steps (interleaved groups of four, so
+// that the subset's centroid stays near the structure's): stage 1 accumulates those k-steps only,
+// subtracts the rank-one centring term  C_S(p) C_S(q)^T / A_S  (C_S = sum of the subset's
+// coordinates, kept per conformer with G_S^c and the uncentred G_S^u, which scales the error
+// bounds: the accumulators hold UNcentred sums), and puts the same bounded polynomial to it.  A
+// 16 x 32 unit none of whose 512 pairs may be similar ends there -- half the matrix work; otherwise
+// the odd k-steps are accumulated on top and the full test decides as before.  With ~0.04 % of
+// similar pairs (the bench) four units in five end after stage 1.
+// STAGED: the subset stage only (flagged units go to the unit queue); otherwise the full test only --
+// two kernels, so that neither carries the other's registers
+template <int NW, bool BITS = true, bool STAGED = false>
 __global__ void __launch_bounds__(NW * 64, FC_F32_WGS)
 k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restrict__ G, int64_t N,
                           int64_t Npad, int A, double A_thr2, KabschF32Bounds bd, int IB, int64_t rank,
                           int64_t world, uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
                           unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
                           unsigned long long Q, const uint64_t *__restrict__ item_table,
-                          unsigned long long n_items) {
+                          unsigned long long n_items, const float *__restrict__ sub, KabschF32Bounds bd1,
+                          float inv_AS, uint64_t *__restrict__ unitq, int part, int gate) {
+  // The subset stage is launched in two parts -- every 16th item first (part 1), the other items behind
+  // a verdict on that sample (part 2) -- so that an ensemble with dense similarity (most units flagged:
+  // the subset stage would be pure overhead) costs only the sample: gate 1 = run iff the verdict said
+  // "sparse" (counters[15] == 0), gate 2 = run iff it said "dense" (the single-stage launch over all
+  // items, sub == nullptr), gate 0 = always.
+  if ((gate == 1 && counters[15] != 0ull) || (gate == 2 && counters[15] == 0ull)) return;
   extern __shared__ double lds_raw[];
   float *__restrict__ lds = reinterpret_cast<float *>(lds_raw);
   constexpr int TC = 64;
@@ -962,12 +988,18 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int KS = (A + 3) >> 2;
+  constexpr bool two = STAGED;
+  static_assert(!(STAGED && BITS), "the subset stage belongs to the lean kernel");
   const float half_A_thr2 = (float)(0.5 * A_thr2);
   float *__restrict__ ldsG = lds + KS * 12 * TC;  // G/2 as fp32: [TC columns | IB rows]
-  uint64_t *__restrict__ stageQ = reinterpret_cast<uint64_t *>(ldsG + TC + IB);
+  float *__restrict__ ldsS = ldsG + TC + IB;      // two: per conformer C_S (3), G_S^c / 2, G_S^u / 2
+  // (every block above is an even number of floats: IB is a multiple of 32)
+  uint64_t *__restrict__ stageQ = reinterpret_cast<uint64_t *>(ldsS + (two ? (TC + IB) * 5 : 0));
   uint32_t *__restrict__ stageW = reinterpret_cast<uint32_t *>(stageQ + kStagePairsF32);
-  unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWordsF32);  // [pairs, words]
-  const unsigned long long b = blockIdx.x;
+  unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWordsF32);  // [pairs, words, listed units, next unit | unit list x 32]
+  // part 0: item = workgroup; part 1: every 16th item; part 2: the items part 1 left out
+  const unsigned long long bx = blockIdx.x;
+  const unsigned long long b = part == 0 ? bx : part == 1 ? bx * 16ull : bx + bx / 15ull + 1ull;
   if (b >= n_items) return;
   int64_t jt, lb;
   int it_first = 0, it_last = IB >> 4;
@@ -1001,38 +1033,182 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
       const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
       ldsG[idx] = g < Npad ? (float)(0.5 * G[g]) : 0.f;
     }
+    if (two)
+      for (int idx = tid; idx < (TC + IB) * 5; idx += NW * 64) {
+        const int c = idx / 5, f = idx - c * 5;
+        const int64_t g = c < TC ? j0 + c : i0 + (c - TC);
+        ldsS[idx] = g < Npad ? sub[g * 8 + f] : 0.f;
+      }
     for (int idx = tid; idx < kStagePairsF32; idx += NW * 64) stageQ[idx] = ~0ull;
     if (tid < kStageWordsF32) stageW[tid] = ~0u;
-    if (tid < 2) stageN[tid] = 0u;
+    if (tid < 4) stageN[tid] = 0u;
     __syncthreads();
   }
   const int kq = lane >> 4, l15 = lane & 15;
   const int boff = (kq >> 1) * (2 * TC) + (kq & 1) * 16 + l15;
   uint16_t *bits16 = reinterpret_cast<uint16_t *>(bits);
+  const int n32 = (int)N;
 
   float a0[3], a1[3], a2[3];
-  int pre_it = -1;
+  int pre_key = -1;  // (it << 1 | half) whose first three k-steps a0 / a1 / a2 hold
   auto row_offsets = [&](int it_, unsigned (&vo)[3]) {
     const int64_t ib_ = i0 + (int64_t)it_ * 16;
 #pragma unroll
     for (int c = 0; c < 3; ++c) vo[c] = (unsigned)((int64_t)(kq * 3 + c) * Npad + ib_ + l15);
   };
-  auto fetch_a_at = [&](float (&a)[3], const unsigned (&vo)[3], int sx) {
-    const int sl = sx < KS ? sx : KS - 1;  // fewer than 3 k-steps: harmless re-read
+  // k-step `sl` of the layout for the lane's row
+  auto fetch_a_phys = [&](float (&a)[3], const unsigned (&vo)[3], int sl) {
     const float *__restrict__ xs_s = Xsf + (int64_t)sl * 12 * Npad;  // wave-uniform base
 #pragma unroll
     for (int c = 0; c < 3; ++c) a[c] = xs_s[vo[c]];
   };
+  auto unit_exists = [&](int it_, int half_) {
+    const int64_t ib_ = i0 + (int64_t)it_ * 16;
+    return it_ < it_last && ib_ < N && !(j0 + TC - 1 <= ib_) && !(j0 + (half_ * 2 + 2) * 16 - 1 <= ib_);
+  };
 
+  // ---- one 16 x 32 unit.  STAGE1: the even k-steps and the subset verdict only (returns whether any of
+  // its 512 pairs may be similar); otherwise all k-steps, the full test, candidates staged / bits stored.
+  // next_key: the unit whose first operands are requested behind this one's last MFMA (-1: none).
+#define FC_KSTEP(AX, BX, U)                                   \
+  if (kk0 + (U) < ke) {                                       \
+    mma(AX, BX);                                              \
+    fetch_a_phys(AX, voff, kstep(kk0 + (U) + 3 < ke ? kk0 + (U) + 3 : ke - 1)); \
+    fetch_b(BX, kstep(kk0 + (U) + 2 < ke ? kk0 + (U) + 2 : ke - 1));            \
+  }
+  auto run_unit = [&](auto stage1_tag, int it, int half, int next_key, unsigned &nz) -> bool {
+    constexpr bool STAGE1 = decltype(stage1_tag)::value;
+    const int64_t ib = i0 + (int64_t)it * 16;
+    const int64_t lrow0 = lb * IB + (int64_t)it * 16;
+    const int cs0 = half * 2;
+    const int ke = STAGE1 ? (KS + 1) >> 1 : KS;
+    auto kstep = [&](int kk) { return STAGE1 ? 2 * kk : kk; };  // stage 1: the even k-steps of the layout
+    unsigned voff[3];
+    row_offsets(it, voff);
+    f4_t acc[2][9];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 9; ++e) acc[t][e] = f4_t{0.f, 0.f, 0.f, 0.f};
+    const float *__restrict__ lb0 = lds + cs0 * 32 + boff;
+    float b0[2][3], b1[2][3];
+    auto fetch_b = [&](float (&bb)[2][3], int sl) {
+      const float *__restrict__ lb_s = lb0 + sl * (12 * TC);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bb[t][c] = lb_s[c * (4 * TC) + t * 32];
+    };
+    auto mma = [&](const float (&a)[3], const float (&bb)[2][3]) {
+#pragma unroll
+      for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int y = 0; y < 3; ++y)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[t][x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], bb[t][y], acc[t][x * 3 + y], 0, 0, 0);
+    };
+    if (pre_key != ((it << 1) | half)) {  // first unit of the wave, or nobody predicted this one
+      fetch_a_phys(a0, voff, kstep(0));
+      fetch_a_phys(a1, voff, kstep(1 < ke ? 1 : ke - 1));
+      fetch_a_phys(a2, voff, kstep(2 < ke ? 2 : ke - 1));
+    }
+    fetch_b(b0, kstep(0));
+    fetch_b(b1, kstep(1 < ke ? 1 : ke - 1));
+#ifdef FC_F32_ABLATE_K  // timing experiment only (results are wrong): one round of k-steps instead of all
+    for (int kk0 = 0; kk0 < 1; kk0 += 6) {
+#else
+    for (int kk0 = 0; kk0 < ke; kk0 += 6) {
+#endif
+      FC_KSTEP(a0, b0, 0)
+      FC_KSTEP(a1, b1, 1)
+      FC_KSTEP(a2, b0, 2)
+      FC_KSTEP(a0, b1, 3)
+      FC_KSTEP(a1, b0, 4)
+      FC_KSTEP(a2, b1, 5)
+    }
+    // request the next unit's first three k-steps now; they land during the epilogue
+    if (next_key >= 0) {
+      unsigned vn[3];
+      row_offsets(next_key >> 1, vn);
+      fetch_a_phys(a0, vn, kstep(0));
+      fetch_a_phys(a1, vn, kstep(1 < ke ? 1 : ke - 1));
+      fetch_a_phys(a2, vn, kstep(2 < ke ? 2 : ke - 1));
+    }
+    pre_key = next_key;
+    const int ib32 = (int)ib;
+    if (STAGE1) {
+      // the subset's centred covariance = accumulated sums - C_S(p) C_S(q)^T / A_S
+      bool any1 = false;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int cs = cs0 + t;
+        const int j = (int)j0 + cs * 16 + l15;
+        const float *__restrict__ sq = ldsS + (cs * 16 + l15) * 5;
+        const float qx = sq[0], qy = sq[1], qz = sq[2], gqc = sq[3], gqu = sq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ib32 + 4 * kq + r;
+          const float *__restrict__ sp = ldsS + (TC + it * 16 + 4 * kq + r) * 5;
+          const float px = -inv_AS * sp[0], py = -inv_AS * sp[1], pz = -inv_AS * sp[2];
+          float B9[9];
+          B9[0] = fmaf(px, qx, acc[t][0][r]); B9[1] = fmaf(px, qy, acc[t][1][r]); B9[2] = fmaf(px, qz, acc[t][2][r]);
+          B9[3] = fmaf(py, qx, acc[t][3][r]); B9[4] = fmaf(py, qy, acc[t][4][r]); B9[5] = fmaf(py, qz, acc[t][5][r]);
+          B9[6] = fmaf(pz, qx, acc[t][6][r]); B9[7] = fmaf(pz, qy, acc[t][7][r]); B9[8] = fmaf(pz, qz, acc[t][8][r]);
+          bool may = kabsch_may_be_below_f32(B9, sp[3] + gqc, half_A_thr2, bd1, sp[4] + gqu);
+          may = may && (j > i) && (j < n32) && (i < n32);
+          any1 = any1 || may;
+        }
+      }
+      return __any(any1);
+    }
+    // full epilogue: lane owns pairs (ib + 4 kq + r, j0 + cs*16 + l15), r = 0..3
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int cs = cs0 + t;
+      const int j = (int)j0 + cs * 16 + l15;
+      const float Gq = ldsG[cs * 16 + l15];
+      uint64_t mr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ib32 + 4 * kq + r;
+        const float Gp = ldsG[TC + it * 16 + 4 * kq + r];
+        float B9[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
+#ifdef FC_F32_ABLATE_POLY  // timing experiment only (results are wrong): the K loop without the polynomial
+        bool may = (B9[0] + B9[4] + B9[8]) * B9[1] * B9[2] * B9[3] * B9[5] * B9[6] * B9[7] == 12345.678f;
+#else
+        bool may = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd, Gp + Gq);
+#endif
+        may = may && (j > i) && (j < n32) && (i < n32);
+        mr[r] = __ballot(may);
+        stage_pairs<kStagePairsF32>(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+      }
+      // bit (16 kq' + c) of mr[r] belongs to row 4 kq' + r: lane l < 16 writes the piece of
+      // row l = 4 (l >> 2) + (l & 3), one store per sub-tile instead of one per register
+      if (BITS && lane < 16 && ib32 + lane < n32) {
+        const int rr = lane & 3;
+        const uint64_t mine = rr == 0 ? mr[0] : rr == 1 ? mr[1] : rr == 2 ? mr[2] : mr[3];
+        const unsigned piece = (unsigned)((mine >> (16 * (lane >> 2))) & 0xffffull);
+        bits16[((lrow0 + lane) * W + jt) * 4 + cs] = (uint16_t)piece;
+        nz |= piece;
+      }
+    }
+    return true;
+  };
+#undef FC_KSTEP
+
+  // ---- the wave's units in order: row tiles it = it_first + wv, + NW, ...; two 32-column halves each.
+  // Lean with the subset stage: phase 1 runs stage 1 on all of them and lists the units that may
+  // hold a similar pair in LDS; phase 2 hands those to the waves of the workgroup as they become free.
+  unsigned *__restrict__ unit_list = stageN + 4;  // [32]
   for (int it = it_first + wv; it < it_last; it += NW) {
     const int64_t ib = i0 + (int64_t)it * 16;
     if (ib >= N) break;
     if (j0 + TC - 1 <= ib) break;
     const int64_t lrow0 = lb * IB + (int64_t)it * 16;
     unsigned nz = 0;  // lanes 0..15: OR of the 16-bit pieces written for row ib + lane
-    unsigned voff[3];
-    row_offsets(it, voff);
-
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       const int cs0 = half * 2;
@@ -1043,108 +1219,12 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
         }
         continue;
       }
-      f4_t acc[2][9];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 9; ++e) acc[t][e] = f4_t{0.f, 0.f, 0.f, 0.f};
-
-      const float *__restrict__ lb0 = lds + cs0 * 32 + boff;
-      float b0[2][3], b1[2][3];
-      const int KSe = KS;
-      auto fetch_a = [&](float (&a)[3], int sx) { fetch_a_at(a, voff, sx); };
-      auto fetch_b = [&](float (&b)[2][3], int sx) {
-        const int sl = sx < KS ? sx : KS - 1;
-        const float *__restrict__ lb_s = lb0 + sl * (12 * TC);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) b[t][c] = lb_s[c * (4 * TC) + t * 32];
-      };
-      auto mma = [&](const float (&a)[3], const float (&b)[2][3]) {
-#pragma unroll
-        for (int x = 0; x < 3; ++x)
-#pragma unroll
-          for (int y = 0; y < 3; ++y)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-              acc[t][x * 3 + y] =
-                  __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[t][y], acc[t][x * 3 + y], 0, 0, 0);
-      };
-      if (pre_it != it) {  // first unit of the wave, or the prediction below missed
-        fetch_a_at(a0, voff, 0);
-        fetch_a_at(a1, voff, 1);
-        fetch_a_at(a2, voff, 2);
-      }
-      fetch_b(b0, 0);
-      fetch_b(b1, 1);
-#define FC_KSTEP(AX, BX, U)             \
-  if (sgrp + (U) < KSe) {               \
-    mma(AX, BX);                        \
-    fetch_a(AX, sgrp + (U) + 3);        \
-    fetch_b(BX, sgrp + (U) + 2);        \
-  }
-#ifdef FC_F32_ABLATE_K  // timing experiment only (results are wrong): one k-step instead of all
-      for (int sgrp = 0; sgrp < 1; sgrp += 6) {
-#else
-      for (int sgrp = 0; sgrp < KSe; sgrp += 6) {
-#endif
-        FC_KSTEP(a0, b0, 0)
-        FC_KSTEP(a1, b1, 1)
-        FC_KSTEP(a2, b0, 2)
-        FC_KSTEP(a0, b1, 3)
-        FC_KSTEP(a1, b0, 4)
-        FC_KSTEP(a2, b1, 5)
-      }
-#undef FC_KSTEP
-      {  // request the next unit's first three k-steps now; they land during the epilogue
-        const int nit = half == 0 ? it : it + NW;
-        const bool more = half == 0 || ((nit < it_last) && (i0 + (int64_t)nit * 16 < N) &&
-                                        !(j0 + TC - 1 <= i0 + (int64_t)nit * 16));
-        if (more) {
-          unsigned vn[3];
-          row_offsets(nit, vn);
-          fetch_a_at(a0, vn, 0);
-          fetch_a_at(a1, vn, 1);
-          fetch_a_at(a2, vn, 2);
-          pre_it = nit;
-        } else {
-          pre_it = -1;
-        }
-      }
-      // epilogue: lane owns pairs (ib + 4 kq + r, j0 + cs*16 + l15), r = 0..3
-      const int n32 = (int)N, ib32 = (int)ib;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int cs = cs0 + t;
-        const int j = (int)j0 + cs * 16 + l15;
-        const float Gq = ldsG[cs * 16 + l15];
-        uint64_t mr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = ib32 + 4 * kq + r;
-          const float Gp = ldsG[TC + it * 16 + 4 * kq + r];
-          float B9[9];
-#pragma unroll
-          for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
-#ifdef FC_F32_ABLATE_POLY  // timing experiment only (results are wrong): the K loop without the polynomial
-          bool may = (B9[0] + B9[4] + B9[8]) * B9[1] * B9[2] * B9[3] * B9[5] * B9[6] * B9[7] == 12345.678f;
-#else
-          bool may = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd);
-#endif
-          may = may && (j > i) && (j < n32) && (i < n32);
-          mr[r] = __ballot(may);
-          stage_pairs<kStagePairsF32>(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
-        }
-        // bit (16 kq' + c) of mr[r] belongs to row 4 kq' + r: lane l < 16 writes the piece of
-        // row l = 4 (l >> 2) + (l & 3), one store per sub-tile instead of one per register
-        if (BITS && lane < 16 && ib32 + lane < n32) {
-          const int rr = lane & 3;
-          const uint64_t mine = rr == 0 ? mr[0] : rr == 1 ? mr[1] : rr == 2 ? mr[2] : mr[3];
-          const unsigned piece = (unsigned)((mine >> (16 * (lane >> 2))) & 0xffffull);
-          bits16[((lrow0 + lane) * W + jt) * 4 + cs] = (uint16_t)piece;
-          nz |= piece;
-        }
+      const int nk = half == 0 ? ((it << 1) | 1) : (unit_exists(it + NW, 0) ? ((it + NW) << 1) : (unit_exists(it + NW, 1) ? (((it + NW) << 1) | 1) : -1));
+      if constexpr (STAGED) {
+        const bool any = run_unit(std::true_type{}, it, half, nk, nz);
+        if (any && lane == 0) unit_list[atomicAdd(stageN + 2, 1u)] = (unsigned)((it << 1) | half);
+      } else {
+        (void)run_unit(std::false_type{}, it, half, nk, nz);
       }
     }
     if (BITS) {  // queue the non-empty words of this row tile for the exact refine
@@ -1171,6 +1251,18 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
   // publish what the workgroup staged: one global atomic per queue
   __syncthreads();
   if (wv == 0) {
+    if (two && stageN[2]) {
+      // the units that may hold a similar pair go to the global unit queue (k_screen_units_f32 puts
+      // them through the full test): (first row << 32) | first column, one reservation per workgroup
+      const unsigned n_list = stageN[2];
+      unsigned long long ubase = 0;
+      if (lane == 0) ubase = atomicAdd(&counters[13], (unsigned long long)n_list);
+      ubase = __shfl(ubase, 0);
+      if ((unsigned)lane < n_list) {
+        const unsigned key = unit_list[lane];
+        unitq[ubase + lane] = ((uint64_t)(i0 + (int64_t)(key >> 1) * 16) << 32) | (uint64_t)(j0 + (int64_t)(key & 1u) * 32);
+      }
+    }
     const int used_q = min((int)stageN[0], kStagePairsF32), used_w = min((int)stageN[1], kStageWordsF32);
     for (int c0 = 0; c0 < used_q; c0 += 64) {
       const uint64_t e = c0 + lane < kStagePairsF32 ? stageQ[c0 + lane] : ~0ull;
@@ -1198,6 +1290,158 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// k_screen_units_f32 -- the full test for the units the subset stage could not rule out (~one in five
+// on the bench ensemble): one wavefront per queued 16 x 32 unit, drawn from a device counter, both
+// operands streamed from L2 three k-steps ahead (no column tile in LDS: the units are scattered over
+// the whole matrix), all k-steps, the bounded polynomial, candidates appended to the pair queue.
+// Steps aside (counters[15]) when the sample of the subset stage found similarity dense: the
+// single-stage tiled kernel launched behind it then does the whole launch.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 3)
+k_screen_units_f32(const float *__restrict__ Xsf, const double *__restrict__ G, int64_t N, int64_t Npad, int A,
+                   double A_thr2, KabschF32Bounds bd, const uint64_t *__restrict__ unitq,
+                   unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq, unsigned long long Q) {
+  if (counters[15] != 0ull) return;  // dense similarity: the single-stage launch behind this one does everything
+  const unsigned long long n_units = counters[13];
+  // candidates are staged per workgroup and published with ONE global atomic at the end: nearly every
+  // queued unit holds a candidate, and one atomic-with-return per unit on the same word (~88 per
+  // microsecond chip-wide) would cost more than the arithmetic (measured: 0.23 ms for 2*10^4 units)
+  __shared__ uint64_t stageQ[kStagePairsF32];
+  __shared__ unsigned stageN[2];
+  for (int idx = threadIdx.x; idx < kStagePairsF32; idx += 256) stageQ[idx] = ~0ull;
+  if (threadIdx.x < 2) stageN[threadIdx.x] = 0u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int kq = lane >> 4, l15 = lane & 15;
+  const int KS = (A + 3) >> 2;
+  const float half_A_thr2 = (float)(0.5 * A_thr2);
+  const int n32 = (int)N;
+  // units dealt to the wavefronts round-robin: they cost the same, and one shared dequeue counter
+  // saturates at ~88 atomics per microsecond (measured here: 0.24 ms for 2*10^4 units)
+  const unsigned long long wave0 = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const unsigned long long n_waves = (unsigned long long)gridDim.x * 4;
+  for (unsigned long long u = wave0; u < n_units; u += n_waves) {
+    const uint64_t key = unitq[u];
+    const int64_t ib = (int64_t)(key >> 32), jc = (int64_t)(key & 0xffffffffull);
+    unsigned va[3], vb[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      va[c] = (unsigned)((int64_t)(kq * 3 + c) * Npad + ib + l15);
+      vb[0][c] = (unsigned)((int64_t)(kq * 3 + c) * Npad + jc + l15);
+      vb[1][c] = vb[0][c] + 16u;
+    }
+    f4_t acc[2][9];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 9; ++e) acc[t][e] = f4_t{0.f, 0.f, 0.f, 0.f};
+    float a0[3], a1[3], a2[3], b0[2][3], b1[2][3], b2[2][3];
+    auto fetch = [&](float (&a)[3], float (&bb)[2][3], int sx) {
+      const float *__restrict__ xs_s = Xsf + (int64_t)(sx < KS ? sx : KS - 1) * 12 * Npad;  // wave-uniform base
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        a[c] = xs_s[va[c]];
+        bb[0][c] = xs_s[vb[0][c]];
+        bb[1][c] = xs_s[vb[1][c]];
+      }
+    };
+    auto mma = [&](const float (&a)[3], const float (&bb)[2][3]) {
+#pragma unroll
+      for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int y = 0; y < 3; ++y)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[t][x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], bb[t][y], acc[t][x * 3 + y], 0, 0, 0);
+    };
+    // (scheduling barriers: the loads must be ISSUED in the order they are consumed -- vmcnt counts in issue
+    // order, and the scheduler had put the first k-step's loads last, i.e. a full drain in front of every MFMA group)
+    fetch(a0, b0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(a1, b1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(a2, b2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s0 = 0; s0 < KS; s0 += 3) {
+      if (s0 < KS) { mma(a0, b0); fetch(a0, b0, s0 + 3); }
+      if (s0 + 1 < KS) { mma(a1, b1); fetch(a1, b1, s0 + 4); }
+      if (s0 + 2 < KS) { mma(a2, b2); fetch(a2, b2, s0 + 5); }
+    }
+    const int ib32 = (int)ib;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = (int)jc + t * 16 + l15;
+      const float Gq = (float)(0.5 * G[j]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ib32 + 4 * kq + r;
+        const float Gp = (float)(0.5 * G[i]);
+        float B9[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
+        bool may = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd, Gp + Gq);
+        may = may && (j > i) && (j < n32) && (i < n32);
+        stage_pairs<kStagePairsF32>(__ballot(may), may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+      }
+    }
+  }
+  __syncthreads();
+  if ((threadIdx.x >> 6) == 0) {
+    const int used_q = min((int)stageN[0], kStagePairsF32);
+    for (int c0 = 0; c0 < used_q; c0 += 64) {
+      const uint64_t e = c0 + lane < kStagePairsF32 ? stageQ[c0 + lane] : ~0ull;
+      const bool valid = e != ~0ull;
+      const uint64_t mv = __ballot(valid);
+      if (mv != 0) {
+        unsigned long long gbase = 0;
+        if (lane == 0) gbase = atomicAdd(&counters[6], (unsigned long long)__popcll(mv));
+        gbase = __shfl(gbase, 0);
+        if (valid) {
+          const unsigned long long slot = gbase + (unsigned long long)__popcll(mv & ((1ull << lane) - 1ull));
+          if (slot < Q) pairq[slot] = e;
+        }
+      }
+    }
+  }
+}
+
+// verdict on the sample of the subset stage (every 16th item): more than max_sample_units of its units
+// flagged = dense similarity -> counters[15] = 1, the sample's queue is discarded
+__global__ void k_screen_density_verdict(unsigned long long *__restrict__ counters, unsigned long long max_sample_units) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const bool dense = counters[13] > max_sample_units;
+    counters[15] = dense ? 1ull : 0ull;
+    if (dense) counters[13] = 0ull;
+  }
+}
+
+// per-conformer statistics of the stage-1 atom subset (the atoms of the even k-steps of the prepared
+// layout): sub[n*8 + 0..2] = sum of the subset's coordinates, [3] = G_S^c / 2 (centred on the subset's
+// centroid), [4] = G_S^u / 2 (as stored); fp64 arithmetic, fp32 results
+__global__ void __launch_bounds__(256)
+k_subset_stats(const double *__restrict__ Xs, int64_t Npad, int A, float *__restrict__ sub) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= Npad) return;
+  double cx = 0.0, cy = 0.0, cz = 0.0, g = 0.0;
+  int cnt = 0;
+  for (int a = 0; a < A; ++a) {
+    if ((a >> 2) & 1) continue;
+    const double x = Xs[(int64_t)(a * 3) * Npad + n], y = Xs[(int64_t)(a * 3 + 1) * Npad + n],
+                 z = Xs[(int64_t)(a * 3 + 2) * Npad + n];
+    cx += x; cy += y; cz += z;
+    g += x * x + y * y + z * z;
+    ++cnt;
+  }
+  const double gc = g - (cx * cx + cy * cy + cz * cz) / (double)(cnt > 0 ? cnt : 1);
+  sub[n * 8 + 0] = (float)cx;
+  sub[n * 8 + 1] = (float)cy;
+  sub[n * 8 + 2] = (float)cz;
+  sub[n * 8 + 3] = (float)(0.5 * (gc > 0.0 ? gc : 0.0));
+  sub[n * 8 + 4] = (float)(0.5 * g);
+  sub[n * 8 + 5] = sub[n * 8 + 6] = sub[n * 8 + 7] = 0.f;
 }
 
 // ---------------------------------------------------------------------------
@@ -2107,13 +2351,29 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         speculative = band > 0.1 * thr2_margin;  // narrow band: not worth the verdict's ~10 us
       }
       if (use_f32) {
-        const size_t lds_f = (size_t)A4 * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32;
+        // Subset stage (lean prunes only).  Measured on one box, screen kernels alone on the chip:
+        // 10^4 x 50: 0.432 ms (subset stage 0.31 + per-unit kernel 0.10 + verdict and gated launches)
+        // against 0.462 ms single-stage; 3*10^4 x 80: 4.77 ms against 6.81 ms (two workgroups per CU there);
+        // continuous RMSD distribution (dense: the sample's verdict sends everything to the single-stage
+        // launch): 1.70 ms against 1.72 ms.  FC_SCREEN_STAGES=1: never; structures below four k-steps and
+        // row blocks above 256 rows (no room for their unit list in the staging area) take the single stage.
+        static const int stages_env = [] {
+          const char *v = getenv("FC_SCREEN_STAGES");
+          return v ? atoi(v) : 0;
+        }();
+        const bool two = e->lean && stages_env != 1 && A4 >= 16 && e->row_block <= 256;
+        const size_t lds_f = (size_t)A4 * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) * (two ? 6 : 1) +
+                             kStageBytesF32;
         if (!e->xsf_valid) {
           const int64_t n = A4 * 3 * e->Npad;
           FC_TRY(e->Xsf.reserve((size_t)n * sizeof(float)));
           hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream,
                              e->Xs.as<double>(), n, e->Xsf.as<float>());
           FC_TRY(check_launch("k_f64_to_f32"));
+          FC_TRY(e->sub.reserve((size_t)e->Npad * 8 * sizeof(float)));
+          hipLaunchKernelGGL(k_subset_stats, dim3((unsigned)ceil_div(e->Npad, 256)), dim3(256), 0, ctx().stream,
+                             e->Xs.as<double>(), e->Npad, (int)e->A, e->sub.as<float>());
+          FC_TRY(check_launch("k_subset_stats"));
           e->xsf_valid = true;
         }
         if (lds_f > 64 * 1024) {
@@ -2121,19 +2381,54 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
           FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_simbits_screen_mfma_f32<4, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+          FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_simbits_screen_mfma_f32<4, false, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
         }
-        if (e->lean)
+        // stage 1 accumulates the even k-steps: A4_S atoms (padding included), A_S real ones; its bounds
+        // carry 8 u more per entry for the rank-one centring term (two rounded factors, 1/A_S, the fma)
+        const int64_t KS_all = A4 / 4, KS1 = (KS_all + 1) / 2;
+        int64_t A_S = 0;
+        for (int64_t a = 0; a < e->A; ++a) A_S += ((a >> 2) & 1) ? 0 : 1;
+        const KabschF32Bounds bd1 = kabsch_f32_bounds(4 * KS1 + 8);
+        const float inv_AS = (float)(1.0 / (double)std::max<int64_t>(A_S, 1));
+        const float *sub_dev = two ? e->sub.as<float>() : nullptr;
+        if (two) {
+          // subset stage over all units -> queue of the units it could not rule out -> the full test for
+          // those, one wavefront per unit; when more than ~a third of the units are queued (dense
+          // similarity) the per-unit kernel steps aside and the single-stage tiled kernel redoes the launch
+          const unsigned long long units_per_item = (unsigned long long)(e->row_block / 16) * 2ull;
+          FC_TRY(e->unitq.reserve((size_t)(n_items * units_per_item) * sizeof(uint64_t)));
+          const unsigned long long n_sample = (n_items + 15ull) / 16ull, n_rest = n_items - n_sample;
+          // "dense": more than a third of the sampled units could not be ruled out by the subset stage
+          const unsigned long long max_sample_units = n_sample * units_per_item / 3ull;
+#define FC_LAUNCH_F32_LEAN(GRID, SUB, PART, GATE, STAGED_)                                                            \
+  hipLaunchKernelGGL((k_simbits_screen_mfma_f32<4, false, STAGED_>), dim3((unsigned)(GRID)), dim3(256), lds_f, ctx().stream, \
+                     e->Xsf.as<float>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2, bd, (int)e->row_block,  \
+                     e->rank, e->world, e->bits.as<uint64_t>(), e->W, e->cand.as<uint32_t>(), cnt,                    \
+                     e->pairq.as<uint64_t>(), (unsigned long long)e->pairq_cap, item_table_dev, n_items, SUB, bd1,    \
+                     inv_AS, e->unitq.as<uint64_t>(), PART, GATE)
+          FC_LAUNCH_F32_LEAN(n_sample, sub_dev, 1, 0, true);
+          hipLaunchKernelGGL(k_screen_density_verdict, dim3(1), dim3(64), 0, ctx().stream, cnt, max_sample_units);
+          if (n_rest > 0) FC_LAUNCH_F32_LEAN(n_rest, sub_dev, 2, 1, true);
+          FC_TRY(check_launch("k_simbits_screen_mfma_f32<subset stage>"));
+          hipLaunchKernelGGL(k_screen_units_f32, dim3((unsigned)(ctx().n_cu * 3)), dim3(256), 0, ctx().stream,
+                             e->Xsf.as<float>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2, bd,
+                             e->unitq.as<uint64_t>(), cnt, e->pairq.as<uint64_t>(), (unsigned long long)e->pairq_cap);
+          FC_TRY(check_launch("k_screen_units_f32"));
+          FC_LAUNCH_F32_LEAN(n_items, nullptr, 0, 2, false);
+#undef FC_LAUNCH_F32_LEAN
+        } else if (e->lean)
           hipLaunchKernelGGL((k_simbits_screen_mfma_f32<4, false>), mgrid, dim3(256), lds_f, ctx().stream,
                              e->Xsf.as<float>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2, bd,
                              (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                              e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
-                             (unsigned long long)e->pairq_cap, item_table_dev, n_items);
+                             (unsigned long long)e->pairq_cap, item_table_dev, n_items, nullptr, bd1, inv_AS, nullptr, 0, 0);
         else
           hipLaunchKernelGGL((k_simbits_screen_mfma_f32<4, true>), mgrid, dim3(256), lds_f, ctx().stream,
                              e->Xsf.as<float>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2, bd,
                              (int)e->row_block, e->rank, e->world, e->bits.as<uint64_t>(), e->W,
                              e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
-                             (unsigned long long)e->pairq_cap, item_table_dev, n_items);
+                             (unsigned long long)e->pairq_cap, item_table_dev, n_items, nullptr, bd1, inv_AS, nullptr, 0, 0);
         FC_TRY(check_launch("k_simbits_screen_mfma_f32"));
         mark_main();
         g_last_screen = 32;

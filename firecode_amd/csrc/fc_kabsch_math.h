@@ -207,8 +207,12 @@ inline KabschF32Bounds kabsch_f32_bounds(int64_t A4) {
 // scaled by 1/s with s and L in fp64 costs 14 instructions more: 0.495 against 0.474 ms for the
 // kernel.  While the SLP vectoriser still packed this polynomial into v_pk_*_f32 the order was
 // the other way round.)
+// s_bound: the scale the ERROR bounds refer to.  The full test passes s itself.  The subset stage of
+// the lean kernel passes the UNcentred half-norm sum of the subset, s_u >= s: its accumulators hold
+// uncentred sums (entry error eta * s_u) from which a rank-one centring term is subtracted, so in units
+// of s_u: |b|_F <= s / s_u <= 1, l <= 1 and every derivative bound above holds a fortiori.
 __device__ __forceinline__ bool kabsch_may_be_below_f32(const float (&B)[9], float s, float half_A_thr2,
-                                                        const KabschF32Bounds &bd) {
+                                                        const KabschF32Bounds &bd, float s_bound) {
 #pragma clang fp contract(fast)
   const float L = s - half_A_thr2;
   const bool tiny = !(4.0f * half_A_thr2 < s);  // tiny structure w.r.t. threshold: cannot be screened
@@ -228,7 +232,7 @@ __device__ __forceinline__ bool kabsch_may_be_below_f32(const float (&B)[9], flo
   const float P2 = 2.0f * L2 + uu;
   const float P1 = uu * L - 2.0f * detB;
   const float P0 = uu * uu - 4.0f * (e2 + 2.0f * L * detB);
-  const float s2 = s * s;
+  const float s2 = s_bound * s_bound;
   // NaN and overflow (inf or NaN coordinates, s^4 beyond fp32) fail every `>`: the pair goes
   // to the exact path; so does an underflow of s^4 to zero
   return tiny | !(P2 > bd.p2 * s2) | !(P1 > bd.p1 * (s2 * s)) | !(P0 > bd.p0 * (s2 * s2));

@@ -151,9 +151,13 @@ k_level_fused(const uint64_t *__restrict__ bits, int64_t W, const uint64_t *__re
 __global__ void __launch_bounds__(256)
 k_pair_buckets(const uint64_t *__restrict__ pairs, const unsigned long long *__restrict__ n_pairs_ptr,
                unsigned long long cap, int64_t N, const int64_t *__restrict__ ladder, int n_ladder,
-               uint64_t *__restrict__ buckets, unsigned long long *__restrict__ level_cnt) {
+               uint64_t *__restrict__ buckets, unsigned long long *__restrict__ level_cnt,
+               const unsigned long long *__restrict__ n_cand_ptr, unsigned long long cand_cap) {
   const unsigned long long P = *n_pairs_ptr;
   if (P > cap) return;
+  // candidate queue overflow: the refine took the word queue and wrote no pair list -- counters[2]
+  // then counts similar pairs the list (sized like the candidate queue) does not hold
+  if (n_cand_ptr != nullptr && *n_cand_ptr > cand_cap) return;
   const uint32_t n32 = (uint32_t)N;
   const int lane = threadIdx.x & 63;
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -711,7 +715,8 @@ int launch_ladder_pairs(const uint64_t *pairs_dev, uint64_t *buckets_dev,
                         uint64_t *mask_out_dev, unsigned long long *counters_dev) {
   // counters_dev[16 .. 16 + n_ladder) = bucket fill levels (zero on entry: the caller's reset)
   hipLaunchKernelGGL(k_pair_buckets, dim3((unsigned)(ctx().n_cu * 2)), dim3(256), 0, ctx().stream,
-                     pairs_dev, n_pairs_dev, cap, N, ladder_dev, n_ladder, buckets_dev, counters_dev + 16);
+                     pairs_dev, n_pairs_dev, cap, N, ladder_dev, n_ladder, buckets_dev, counters_dev + 16, n_cand_dev,
+                     cand_cap);
   FC_TRY(check_launch("k_pair_buckets"));
   const size_t lds = (size_t)2 * W * sizeof(uint64_t);
   hipLaunchKernelGGL(k_ladder_pairs, dim3(1), dim3(1024), lds, ctx().stream, pairs_dev, buckets_dev,

@@ -479,6 +479,9 @@ int fc_screen_select(int kind);
 int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
                         double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
                         int64_t *stats);
+/* (fc_bench_prune_rmsd writes EIGHT stats: [6] = 16 x 32-pair units the subset stage of the lean fp32
+ * screen queued for the full test in the last prune, [7] = 1 when its sample found similarity dense
+ * and the single-stage kernel did the launch) */
 /* the same for fc_prune_rmsd_sharded: `reps` sharded prunes enqueued back to back, one host wait;
  * overlap != 0: prune k on workspace / lane k&1, its refine + export + all-gather + ladder beside
  * the screen of prune k+1 */

@@ -7,9 +7,6 @@ import socket
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from firecode_amd import dist as fdist
 from firecode_amd import synthetic as syn
@@ -55,6 +52,12 @@ class OraclePairShard(OracleShard):
         return o.greedy_prune_from_matrix(S | S.T, min_per_group=min_per_group)
 
 
+def _spawn(fn, args, nprocs, join=True):
+    import torch.multiprocessing as mp
+
+    return mp.spawn(fn, args=args, nprocs=nprocs, join=join)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -66,6 +69,8 @@ def _free_port():
 def _worker(rank, world, port, n, a, seed, row_block, out_dir, pairs_mode=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist  # lazily: collecting this file must not map torch's HIP runtime into a GPU test session
+
     dist.init_process_group("gloo", rank=rank, world_size=world)
     X, atoms, _ = syn.synthetic_ensemble(n, a, seed=seed)
     S, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
@@ -83,7 +88,7 @@ def _worker(rank, world, port, n, a, seed, row_block, out_dir, pairs_mode=False)
 @pytest.mark.parametrize("world,n,row_block", [(2, 700, 64), (3, 450, 32), (2, 130, 256)])
 def test_sharded_ladder_matches_single(tmp_path, world, n, row_block):
     a, seed = 12, 40 + world
-    mp.spawn(_worker, args=(world, _free_port(), n, a, seed, row_block, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_worker, args=(world, _free_port(), n, a, seed, row_block, str(tmp_path)), nprocs=world, join=True)
     X, atoms, _ = syn.synthetic_ensemble(n, a, seed=seed)
     S, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
     ref = o.greedy_prune_from_matrix(S)
@@ -98,7 +103,7 @@ def test_sharded_ladder_matches_single(tmp_path, world, n, row_block):
 @pytest.mark.parametrize("world,n", [(2, 600), (3, 333)])
 def test_sharded_pairs_exchange_matches_single(tmp_path, world, n):
     a, seed, row_block = 10, 60 + world, 64
-    mp.spawn(_worker, args=(world, _free_port(), n, a, seed, row_block, str(tmp_path), True), nprocs=world, join=True)
+    _spawn(_worker, args=(world, _free_port(), n, a, seed, row_block, str(tmp_path), True), nprocs=world, join=True)
     X, atoms, _ = syn.synthetic_ensemble(n, a, seed=seed)
     S, _, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
     ref = o.greedy_prune_from_matrix(S)
@@ -208,6 +213,8 @@ def _grid_case(seed):
 def _worker_parallel_rows(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ag = fdist.torch_allgather()
     base, tors, masks = _chain(16, 3, seed=9)
@@ -225,7 +232,7 @@ def _worker_parallel_rows(rank, world, port, out_dir):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_scan_and_pose_grid(tmp_path, world):
-    mp.spawn(_worker_parallel_rows, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    _spawn(_worker_parallel_rows, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     base, tors, masks = _chain(16, 3, seed=9)
     angles = o.cartesian_product((0, 120, 240), (0, 180), (0, 120, 240))
     ref_out, ref_rot = o.torsion_scan(base, tors, masks, angles)

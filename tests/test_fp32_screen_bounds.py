@@ -148,3 +148,81 @@ def test_unscaled_form_of_the_kernel(scale):
     assert similar.sum() > 300 and dropped.sum() > 300
     assert not (dropped & similar).any()
     assert not ((~dropped) & (msd > 1.2 * thr * thr)).any()  # the band stays narrow in every unit system
+
+
+@pytest.mark.parametrize("A,shape,thr", [(50, "ball", 0.5), (50, "chain", 0.5), (80, "chain", 0.35), (23, "ball", 0.7)])
+def test_subset_stage_is_conservative_and_inside_its_bounds(A, shape, thr):
+    """The subset stage of the lean fp32 screen (k_simbits_screen_mfma_f32<.., STAGED>): atoms of the even
+    groups of four only, accumulators hold UNcentred sums, the rank-one centring term C_S(p) C_S(q)^T / A_S
+    is subtracted in fp32, the polynomial is compared with bounds scaled by the uncentred norms.  Replayed
+    in NumPy float32: (1) the fp32 values of P, P', P'' stay within the bounds the kernel uses (in units of
+    the uncentred scale), (2) a pair whose FULL msd is below the threshold is never dropped -- chain-like
+    structures included, where the subset's centroid sits far from the structure's."""
+    rng = np.random.default_rng(A + len(shape))
+    P = 6000
+    if shape == "ball":
+        base = rng.normal(scale=2.5, size=(P, A, 3))
+    else:  # a random walk: elongated, subset centroid well away from the full centroid
+        base = np.cumsum(rng.normal(scale=0.9, size=(P, A, 3)), axis=1)
+    x = base - base.mean(axis=1, keepdims=True)
+    y = base + rng.normal(size=(P, A, 3)) * np.concatenate([np.full(P // 2, thr / np.sqrt(3.0) * 0.9),
+                                                              np.geomspace(0.05, 3.0, P - P // 2)])[:, None, None]
+    y = y - y.mean(axis=1, keepdims=True)
+    sub = ((np.arange(A) >> 2) & 1) == 0
+    A_S, A4_S = int(sub.sum()), 4 * (((A + 3) // 4 + 1) // 2)
+    f = np.float32
+    # exact side: full msd, and the subset quantities the stage tests
+    B = np.einsum("pax,pay->pxy", x, y)
+    sv = np.linalg.svd(B, compute_uv=False)
+    sv[:, 2] *= np.sign(np.linalg.det(B))
+    msd_full = ((x * x).sum(axis=(1, 2)) + (y * y).sum(axis=(1, 2)) - 2.0 * sv.sum(axis=1)) / A
+    xs, ys = x[:, sub], y[:, sub]
+    Cx, Cy = xs.sum(axis=1), ys.sum(axis=1)
+    Bc = np.einsum("pax,pay->pxy", xs, ys) - Cx[:, :, None] * Cy[:, None, :] / A_S
+    Gc = ((xs * xs).sum(axis=(1, 2)) - (Cx * Cx).sum(axis=1) / A_S) + ((ys * ys).sum(axis=(1, 2)) - (Cy * Cy).sum(axis=1) / A_S)
+    Gu = (xs * xs).sum(axis=(1, 2)) + (ys * ys).sum(axis=(1, 2))
+    s_c, s_u = 0.5 * Gc, 0.5 * Gu
+    L = s_c - 0.5 * A * thr * thr
+    # the lower bound itself (exact arithmetic): the subset residual never exceeds the full one
+    svs = np.linalg.svd(Bc, compute_uv=False)
+    svs[:, 2] *= np.sign(np.linalg.det(Bc))
+    assert np.all(Gc - 2.0 * svs.sum(axis=1) <= A * msd_full * (1 + 1e-12) + 1e-9)
+    # fp32 side, as the kernel does it
+    xf, yf = xs.astype(f), ys.astype(f)
+    acc = np.zeros((P, 3, 3), dtype=f)
+    for k in range(A_S):
+        acc += xf[:, k, :, None] * yf[:, k, None, :]
+    inv = f(1.0 / A_S)
+    cp, cq = Cx.astype(f), Cy.astype(f)
+    B32 = (acc + (-(inv * cp))[:, :, None] * cq[:, None, :]).astype(f)
+    half = lambda v: (0.5 * v).astype(f)  # noqa: E731  G_S^c / 2 and G_S^u / 2 are stored per conformer
+    gxc = half((xs * xs).sum(axis=(1, 2)) - (Cx * Cx).sum(axis=1) / A_S)
+    gyc = half((ys * ys).sum(axis=(1, 2)) - (Cy * Cy).sum(axis=1) / A_S)
+    gxu, gyu = half((xs * xs).sum(axis=(1, 2))), half((ys * ys).sum(axis=(1, 2)))
+    s32, su32 = (gxc + gyc).astype(f), (gxu + gyu).astype(f)
+    L32 = (s32 - f(0.5 * A * thr * thr)).astype(f)
+    n2 = (B32 * B32).sum(axis=(1, 2), dtype=f)
+    uu = L32 * L32 - n2
+    c = np.empty_like(B32)
+    for i in range(3):
+        for j in range(3):
+            i1, i2, j1, j2 = (i + 1) % 3, (i + 2) % 3, (j + 1) % 3, (j + 2) % 3
+            c[:, i, j] = B32[:, i1, j1] * B32[:, i2, j2] - B32[:, i1, j2] * B32[:, i2, j1]
+    det = (B32[:, 0, :] * c[:, 0, :]).sum(axis=1, dtype=f)
+    e2 = (c * c).sum(axis=(1, 2), dtype=f)
+    P2, P1, P0 = f(2) * L32 * L32 + uu, uu * L32 - f(2) * det, uu * uu - f(4) * (e2 + f(2) * L32 * det)
+    b0, b1, b2 = (f(2.0 * v) for v in bounds(A4_S + 8))   # kabsch_f32_bounds(4 KS1 + 8), factor 2 as in the launcher
+    su2 = su32 * su32
+    tiny = ~(f(4.0) * f(0.5 * A * thr * thr) < s32)
+    dropped = ~tiny & (P2 > b2 * su2) & (P1 > b1 * su2 * su32) & (P0 > b0 * su2 * su2)
+    similar = msd_full < thr * thr
+    assert similar.sum() > 500 and dropped.sum() > 500
+    assert not (dropped & similar).any()                      # (2) conservative
+    # (1) errors against the exact subset polynomial, in units of the UNcentred scale
+    ref = poly(Bc, s_u, L, np.float64)
+    got = poly(B32, su32.astype(np.float64), L32.astype(np.float64), np.float64)  # same fp32 inputs, exact polynomial
+    P0u, P1u, P2u = (P0.astype(np.float64) / s_u**4, P1.astype(np.float64) / s_u**3, P2.astype(np.float64) / s_u**2)
+    for name, g, r, bd in zip(("P0", "P1", "P2"), (P0u, P1u, P2u), ref, bounds(A4_S + 8)):
+        err = np.abs(g - r)[~tiny]
+        assert err.max() <= bd, (name, err.max(), bd)
+    del got

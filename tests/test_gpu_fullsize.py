@@ -121,30 +121,25 @@ def test_bench_multi_gpu_sizes_with_logical_ranks(fc, world):
     """the exact problem of `bench.py --gpus N` (10^4 sqrt(N) conformers, exchange capacity, item
     tables, half-item tail) with the N ranks played one after the other on ONE GPU: every
     rank's message fits, the replayed ladder gives the single-GPU mask, one survivor per cluster"""
-    import torch
-
     from firecode_amd import _lib
     from firecode_amd import dist as fdist
 
     n = int(round(10000 * np.sqrt(world)))
     X, atoms, asg = syn.synthetic_ensemble(n, 50, seed=2)
     cap = fdist.exchange_cap(n, world)
-    dev = torch.device("cuda", 0)
-    stream = torch.cuda.Stream(device=dev)
-    with fc.DeviceEnsemble(X, center=True) as ens:
-        ref, stats0 = ens.prune(0.5, 1.0)
-        with torch.cuda.stream(stream):
-            _lib.stream_set(stream.cuda_stream)
-            try:
-                recv = torch.zeros(world * (cap + 1), dtype=torch.int64, device=dev)
-                for r in range(world):
-                    ens.prune_begin_async(0.5, 1.0, r, world, row_block=128)
-                    ens.export_pairs_dev(recv.data_ptr() + 8 * r * (cap + 1), cap)
-                ens.prune_from_gathered_enqueue(recv.data_ptr(), world, cap, 0, 1)
-                mask, stats = ens.prune_collect(0, 1)
-                counts = recv.cpu().numpy().view(np.uint64).reshape(world, cap + 1)[:, 0]
-            finally:
-                _lib.stream_set(None)
+    counts = []
+    try:
+        with fc.DeviceEnsemble(X, center=True) as ens:
+            ref, stats0 = ens.prune(0.5, 1.0)
+            # fc_debug_comm_loopback: the library acts as rank r of `world`; its all-gather fills only slot r of
+            # the receive buffer, so after the last rank the buffer holds every message (C path, no torch)
+            for r in list(range(1, world)) + [0]:
+                _lib.call("fc_debug_comm_loopback", r, world)
+                mask, stats = ens.prune_sharded(0.5, 1.0)
+                counts.append(int(stats[2]))
+    finally:
+        _lib.call("fc_debug_comm_loopback", -1, 0)
+    counts = np.array(counts)
     assert np.array_equal(mask, ref)
     assert mask.sum() == len(np.unique(asg))
     assert int(counts.sum()) == stats0[2] and int(counts.max()) <= cap
@@ -155,8 +150,6 @@ def test_cfg4_full_size_eight_logical_ranks(fc):
     """BASELINE configs[3] whole: 100 000 conformers x 80 atoms, the 8 ranks of the sharded prune
     played on one GPU (row blocks in snake order, one message per rank, replayed ladder):
     one survivor per cluster, messages within capacity and balanced"""
-    import torch
-
     from firecode_amd import _lib
     from firecode_amd import dist as fdist
 
@@ -164,22 +157,17 @@ def test_cfg4_full_size_eight_logical_ranks(fc):
     X, atoms, asg = syn.synthetic_ensemble(n, 80, seed=6)
     n_clusters = len(np.unique(asg))
     cap = fdist.exchange_cap(n, world)
-    dev = torch.device("cuda", 0)
-    stream = torch.cuda.Stream(device=dev)
-    with fc.DeviceEnsemble(X, center=True) as ens:
-        del X
-        with torch.cuda.stream(stream):
-            _lib.stream_set(stream.cuda_stream)
-            try:
-                recv = torch.zeros(world * (cap + 1), dtype=torch.int64, device=dev)
-                for r in range(world):
-                    ens.prune_begin_async(0.5, 1.0, r, world, row_block=128)
-                    ens.export_pairs_dev(recv.data_ptr() + 8 * r * (cap + 1), cap)
-                ens.prune_from_gathered_enqueue(recv.data_ptr(), world, cap, 0, 1)
-                mask, stats = ens.prune_collect(0, 1)
-                counts = recv.cpu().numpy().view(np.uint64).reshape(world, cap + 1)[:, 0].astype(np.int64)
-            finally:
-                _lib.stream_set(None)
+    counts = []
+    try:
+        with fc.DeviceEnsemble(X, center=True) as ens:
+            del X
+            for r in list(range(1, world)) + [0]:  # the ranks one after the other (fc_debug_comm_loopback), C path
+                _lib.call("fc_debug_comm_loopback", r, world)
+                mask, stats = ens.prune_sharded(0.5, 1.0)
+                counts.append(int(stats[2]))
+    finally:
+        _lib.call("fc_debug_comm_loopback", -1, 0)
+    counts = np.array(counts, dtype=np.int64)
     assert mask.sum() == n_clusters
     first = np.zeros(n_clusters, dtype=np.int64)  # the greedy ladder keeps the LAST member of a cluster (i removed when a later j matches)
     np.maximum.at(first, asg, np.arange(n))
