@@ -179,7 +179,10 @@ def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, wo
     return {"bound": "mfma", "kernel": "k_simbits_screen_mfma_f32" if f32 else "k_simbits_screen_mfma",
             "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": traffic,
             "traffic_source": src, "kernel_ms": kernel_ms, "flops_per_pair": flops, "dtype": "f32" if f32 else "f64",
-            "two_stage": staged}
+            "two_stage": staged,
+            "note": ("frac = algorithmic covariance flops (the full K loop per pair, what a one-stage screen executes) / time / peak; "
+                     "the two-stage screen issues only two_stage.executed_frac of the peak to the matrix pipe -- the rest of the "
+                     "gap to 1 is work it avoids, not pipe utilisation") if staged else None}
 
 
 def timed_prunes(ens, steps, warmup, sharded, overlap=True):

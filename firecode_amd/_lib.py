@@ -517,9 +517,9 @@ class DeviceEnsemble:
         return mask.astype(bool), stats
 
     def bench_prune_sharded(self, max_rmsd, max_dev, reps=1, overlap=True):
-        """``reps`` stream-ordered sharded prunes -> (screen kernel ms, step ms, mask, stats)."""
+        """``reps`` stream-ordered sharded prunes -> (screen kernel ms, step ms, mask, stats (8))."""
         mask = np.zeros(self.N, dtype=np.uint8)
-        stats = np.zeros(6, dtype=np.int64)
+        stats = np.zeros(8, dtype=np.int64)
         t_k, t_s = C.c_double(0), C.c_double(0)
         call("fc_bench_prune_rmsd_sharded", self.handle, float(max_rmsd), float(max_dev), int(reps),
              int(bool(overlap)), C.byref(t_k), C.byref(t_s), pb(mask), pi(stats))

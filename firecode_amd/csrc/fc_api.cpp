@@ -2277,7 +2277,7 @@ static int sharded_levels_fallback(fc_ensemble *ens, double max_rmsd, double max
 }
 
 static int sharded_collect(fc_ensemble *ens, int64_t steps, bool overlap, uint8_t *mask_out, int64_t *stats,
-                           bool *all_ok) {
+                           bool *all_ok, int64_t *units = nullptr) {
   const int64_t W = ens->W;
   *all_ok = true;
   int64_t survivors = 0;
@@ -2294,6 +2294,11 @@ static int sharded_collect(fc_ensemble *ens, int64_t steps, bool overlap, uint8_
     stats[5] = survivors;
   }
   (void)overlap;
+  if (*all_ok && units) {  // the subset stage of this rank's lean fp32 screen in the last prune (counters ride behind the mask words)
+    const uint64_t *cnt_last = static_cast<const uint64_t *>(ctx().pinned) + (size_t)(steps - 1) * (size_t)(W + 16) + W;
+    units[0] = (int64_t)cnt_last[13];
+    units[1] = (int64_t)cnt_last[15];
+  }
   return FC_OK;
 }
 
@@ -2337,7 +2342,8 @@ int fc_bench_prune_rmsd_sharded(fc_ensemble *ens, double max_rmsd, double max_de
     scratch.resize((size_t)ens->N);
     mask_out = scratch.data();
   }
-  FC_TRY(sharded_collect(ens, reps, overlap != 0, mask_out, stats, &ok));
+  if (stats) stats[6] = stats[7] = 0;  // EIGHT stats, as fc_bench_prune_rmsd
+  FC_TRY(sharded_collect(ens, reps, overlap != 0, mask_out, stats, &ok, stats ? stats + 6 : nullptr));
   if (!ok) FC_TRY(sharded_levels_fallback(ens, max_rmsd, max_dev, 20, row_block, mask_out, stats));
   if (ms_screen_kernel) *ms_screen_kernel = ms;
   if (ms_step) *ms_step = total / (double)reps;

@@ -117,12 +117,14 @@ def prune_conformers_tfd(structures, quadruplets, thresh=10, verbose=False):
 
 
 def most_diverse_conformers(n, structures, seed=None):
-    """firecode/torsion_module.py:574-586: a RANDOM subsample of n structures
-    (with replacement, sorted indices).  The reference draws from the global,
-    unseeded NumPy RNG; pass ``seed`` for a reproducible draw."""
+    """firecode/torsion_module.py:574-586: everything when there are at most n structures (:581-582),
+    else a RANDOM subsample of n (with replacement, sorted indices, :585-586).  The reference draws
+    from the global, unseeded NumPy RNG; pass ``seed`` for a reproducible draw."""
+    if len(structures) <= n:
+        return list(np.array(structures))
     rng = np.random if seed is None else np.random.RandomState(seed)
     indices = np.sort(rng.choice(len(structures), size=n))
-    return [structures[i] for i in indices]
+    return list(np.array(structures)[indices])
 
 
 def clustered_csearch(coords, torsions, rotation_masks, n_out=100, thresh=1.5, seed=None, logfunction=None):

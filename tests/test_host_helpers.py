@@ -83,3 +83,26 @@ def test_cyclical_reactive_indices_golden(golden):
         assert np.array_equal(hh.cyclical_reactive_indices_tri([tuple(c) for c in c3], n), golden["cri_out3"][n])
         piv = [cy.Pivot(np.zeros(3), np.ones(3), a, b) for a, b in c3]
         assert np.array_equal(cy.get_cyclical_reactive_indices(piv, n), golden["cri_out3"][n])
+
+
+def test_most_diverse_conformers_is_the_reference_draw():
+    """a22 (firecode/torsion_module.py:574-586): all structures when there are at most n; otherwise
+    np.sort(np.random.choice(N, size=n)) -- with replacement, so indices may repeat -- from the global
+    RNG (unseeded in the reference), or from RandomState(seed) when a seed is given"""
+    import numpy as np
+
+    from firecode_amd.torsion_module import most_diverse_conformers
+
+    S = np.arange(40 * 6 * 3, dtype=float).reshape(40, 6, 3)
+    out = most_diverse_conformers(50, S)
+    assert len(out) == 40 and all(np.array_equal(a, b) for a, b in zip(out, S))
+    assert len(most_diverse_conformers(40, list(S))) == 40
+    for seed in (0, 7, 123):
+        idx = np.sort(np.random.RandomState(seed).choice(40, size=12))
+        out = most_diverse_conformers(12, S, seed=seed)
+        assert len(out) == 12 and all(np.array_equal(a, S[i]) for a, i in zip(out, idx))
+    np.random.seed(99)  # the reference's own path: the global RNG
+    idx = np.sort(np.random.choice(40, size=5))
+    np.random.seed(99)
+    out = most_diverse_conformers(5, S)
+    assert all(np.array_equal(a, S[i]) for a, i in zip(out, idx))
