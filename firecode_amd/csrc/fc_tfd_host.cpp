@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -316,11 +317,11 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
   lap("components");
 }
 
-// chunks [step_begin, step_end) of one ladder level; chunks are independent
+// chunks [step_begin, step_end) of one ladder level; chunks are independent.  The rejects go to `out`
+// as absolute indices (the caller applies them when -- and if -- the level runs).
 static void level_chunks(const int64_t *fm, int64_t N, int64_t k, int64_t d, int64_t num_active,
-                         int64_t step_begin, int64_t step_end, uint8_t *mask_out) {
+                         int64_t step_begin, int64_t step_end, ChunkScratch &scratch, std::vector<int64_t> &out) {
   std::vector<int64_t> edges, rejects;
-  ChunkScratch scratch;
   for (int64_t step = step_begin; step < step_end; ++step) {
     const int64_t lo = d * step;
     // torsion_module.py:987-990: the LAST chunk ends at num_active_str, not at N
@@ -338,11 +339,22 @@ static void level_chunks(const int64_t *fm, int64_t N, int64_t k, int64_t d, int
     }
     if (edges.empty()) continue;
     chunk_rejects(edges, len, scratch, rejects);
-    for (int64_t r : rejects) mask_out[r + lo] = 0;  // chunks own disjoint row ranges
+    for (int64_t r : rejects) out.push_back(r + lo);
   }
 }
 
-// the whole ladder: first_match[i] = min{j > i : similar(i, j)} or -1
+// The whole ladder: first_match[i] = min{j > i : similar(i, j)} or -1.
+//
+// What a chunk rejects depends on first_match alone: the reference's inner loops never look at
+// final_mask (masked structures keep taking part, torsion_module.py:997-1018).  Only two things depend
+// on the levels before: whether a level runs at all (5 k < num_active_str, :976) and the length of
+// its LAST chunk (:987-990).  So every non-last chunk of every level that can possibly run is
+// worked out up front, all levels at once, on the host threads (largest chunks first: the single
+// 840 000-structure chunk of k = 2 at 1.7 M structures is the critical path, everything else fits beside
+// it); then the levels are walked in order, applying a level's rejects if it runs and doing its
+// last chunk -- usually empty or tiny, since num_active_str has long fallen below its start -- on the spot.
+// (One level after the other, threads over the chunks of a level: 0.32 s at 1.7 M structures, of which the
+// levels k <= 20 with their few huge chunks took 0.24 s on one to five threads.)
 int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out) {
   static const double kl[] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};
   for (int64_t i = 0; i < N; ++i) mask_out[i] = 1;
@@ -354,33 +366,83 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
     if (t >= 1 && t <= 64) hw = (unsigned)t;
   }
   const bool debug = getenv("FC_DEBUG") != nullptr;
-  for (double kd : kl) {
-    const int64_t k = (int64_t)kd;
-    const auto t_level = std::chrono::steady_clock::now();
-    int64_t num_active = 0;
-    for (int64_t i = 0; i < N; ++i) num_active += mask_out[i];
-    if (!(k == 1 || 5 * k < num_active)) continue;
+  const auto t_all = std::chrono::steady_clock::now();
+  struct Task {
+    int level;                 // index into kl
+    int64_t k, d, step_begin, step_end, cost;
+    std::vector<int64_t> rejects;
+  };
+  std::vector<Task> tasks;
+  for (int li = 0; li < (int)(sizeof(kl) / sizeof(kl[0])); ++li) {
+    const int64_t k = (int64_t)kl[li];
+    if (!(k == 1 || 5 * k < N)) continue;  // num_active <= N: the level can never run
+    if (k == 1) continue;                  // its only chunk is a last chunk
     const int64_t d = N / k;
-    // chunks are independent: host threads over them at every level (one thread per chunk at the
-    // coarse end of the ladder; the single chunk of k = 1 stays serial)
-    const int64_t nthreads = (N >= 100000) ? std::min<int64_t>((int64_t)hw, k) : 1;
-    if (nthreads == 1) {
-      level_chunks(fm, N, k, d, num_active, 0, k, mask_out);
+    if (d <= 1) continue;
+    // non-last chunks [0, k - 1), cut into tasks of about 2^17 structures (a huge chunk is a task of its own)
+    const int64_t per = std::max<int64_t>(1, (int64_t)(131072 / d));
+    for (int64_t b = 0; b < k - 1; b += per) {
+      const int64_t e = std::min<int64_t>(k - 1, b + per);
+      tasks.push_back(Task{li, k, d, b, e, (e - b) * d, {}});
+    }
+  }
+  std::vector<size_t> order(tasks.size());
+  for (size_t t = 0; t < order.size(); ++t) order[t] = t;
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tasks[a].cost > tasks[b].cost; });
+  {
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+      ChunkScratch scratch;
+      while (true) {
+        const size_t q = next.fetch_add(1);
+        if (q >= order.size()) break;
+        Task &t = tasks[order[q]];
+        // a non-last chunk never uses num_active: pass N
+        level_chunks(fm, N, t.k, t.d, N, t.step_begin, t.step_end, scratch, t.rejects);
+      }
+    };
+    const unsigned nthreads = (N >= 2000 && tasks.size() > 1) ? std::min<size_t>(hw, tasks.size()) : 1;
+    if (nthreads <= 1) {
+      worker();
     } else {
       std::vector<std::thread> pool;
-      const int64_t per = (k + nthreads - 1) / nthreads;
-      for (int64_t t = 0; t < nthreads; ++t) {
-        const int64_t b = t * per, e = std::min<int64_t>(k, (t + 1) * per);
-        if (b >= e) break;
-        pool.emplace_back(level_chunks, fm, N, k, d, num_active, b, e, mask_out);
-      }
+      for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(worker);
       for (auto &th : pool) th.join();
     }
-    if (debug)
-      fprintf(stderr, "[fc] tfd ladder k=%lld: %lld active in, %lld threads, %.1f ms\n", (long long)k,
-              (long long)num_active, (long long)nthreads,
-              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_level).count());
   }
+  if (debug)
+    fprintf(stderr, "[fc] tfd ladder: %zu speculative tasks on %u threads, %.1f ms\n", tasks.size(), hw,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
+  // the levels in order
+  ChunkScratch scratch;
+  std::vector<int64_t> last;
+  size_t ti = 0;  // tasks are grouped by level in creation order
+  int64_t num_active = N;  // kept up to date as flags go 1 -> 0
+  auto reject = [&](int64_t r) {
+    num_active -= mask_out[r];
+    mask_out[r] = 0;
+  };
+  for (int li = 0; li < (int)(sizeof(kl) / sizeof(kl[0])); ++li) {
+    const int64_t k = (int64_t)kl[li];
+    const bool runs = (k == 1 || 5 * k < num_active);
+    const size_t t_begin = ti;
+    while (ti < tasks.size() && tasks[ti].level == li) ++ti;
+    if (!runs) continue;
+    const int64_t d = N / k;
+    // the last chunk first reads nothing but first_match either, so the order of application within
+    // the level does not matter: all rejects of a level come from the mask-independent chunk graphs
+    last.clear();
+    const int64_t active_in = num_active;
+    level_chunks(fm, N, k, d, active_in, k - 1, k, scratch, last);
+    for (size_t t = t_begin; t < ti; ++t)
+      for (int64_t r : tasks[t].rejects) reject(r);
+    for (int64_t r : last) reject(r);
+    if (debug)
+      fprintf(stderr, "[fc] tfd ladder k=%lld: %lld active in\n", (long long)k, (long long)active_in);
+  }
+  if (debug)
+    fprintf(stderr, "[fc] tfd ladder total %.1f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
   return FC_OK;
 }
 
