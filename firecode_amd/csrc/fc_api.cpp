@@ -552,6 +552,7 @@ static int ensemble_twin(fc_ensemble *ens, fc_ensemble **out) {
     t->N = ens->N, t->A = ens->A, t->Npad = ens->Npad, t->W = ens->W;
     t->Xs.alias(ens->Xs), t->Xa.alias(ens->Xa), t->G.alias(ens->G);
     if (ens->xsf_valid) t->Xsf.alias(ens->Xsf), t->sub.alias(ens->sub), t->xsf_valid = true;
+    if (ens->xh_valid) t->Xh.alias(ens->Xh), t->xh_valid = true, t->xh_scale = ens->xh_scale;
     t->g_max = ens->g_max;
     FC_TRY(t->counters.reserve(kCounters * sizeof(uint64_t)));
     ens->twin = t.release();
@@ -2366,7 +2367,7 @@ int fc_prune_conventions(int drop_later) {
 
 int fc_screen_select(int kind) {
   FC_API_LOCK;
-  FC_REQUIRE(kind == 0 || kind == 32 || kind == 64, "kind must be 0 (automatic), 32 or 64");
+  FC_REQUIRE(kind == 0 || kind == 16 || kind == 32 || kind == 64, "kind must be 0 (automatic), 16, 32 or 64");
   screen_select(kind);
   return FC_OK;
 }

@@ -188,6 +188,9 @@ struct fc_ensemble {
   fc::DevBuf sub;              // [Npad][8] floats: stage-1 subset statistics per conformer (made with Xsf)
   fc::DevBuf unitq;            // queue of the 16 x 32 units the subset stage could not rule out
   bool xsf_valid = false;
+  fc::DevBuf Xh;               // split-half copy of Xs for the f16-matrix-pipe screen (made on first use)
+  bool xh_valid = false;
+  double xh_scale = 0.0;       // the power of two Xh was made with
   double g_max = -1.0;         // largest G (host copy, found on first use): sizes the fp32 screen's band
   // prune workspace (allocated on first use, kept for later calls)
   fc::DevBuf bits;             // rows_local * W uint64

@@ -576,6 +576,11 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
                       double *__restrict__ rmsd_out = nullptr, const unsigned long long *__restrict__ gate = nullptr,
                       double *__restrict__ maxdev_out = nullptr) {
   constexpr bool VALUES = MODE != 0;  // 1: rmsd values (Newton), 2: (rmsd, maxdev) by explicit difference
+  // sub-tiles (16 columns) per unit: two share the row operands in the screens; the complete-alignment
+  // mode takes one at a time -- its epilogue (four rotations, an atom pass) needs the registers the second
+  // set of 36 accumulator doubles would hold (256 VGPRs + 220 B of scratch with two: 5.17 ms per 10^4 x 10^4)
+  constexpr int NT = MODE == 2 ? 1 : 2;
+  constexpr int NU = 4 / NT;
   // behind a speculative fp32 screen: run only when k_screen_verdict asked for it
   if (gate != nullptr && *gate == 0ull) return;
   extern __shared__ double lds[];
@@ -691,18 +696,18 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
     row_offsets(it, voff);
 
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      const int cs0 = half * 2;
-      if (j0 + (cs0 + 2) * 16 - 1 <= ib) {  // both sub-tiles at or below the diagonal
+    for (int half = 0; half < NU; ++half) {
+      const int cs0 = half * NT;
+      if (j0 + (cs0 + NT) * 16 - 1 <= ib) {  // the unit's sub-tiles at or below the diagonal
         if (!VALUES && lane < 16 && ib + lane < N) {
           bits16[((lrow0 + lane) * W + jt) * 4 + cs0] = 0;
           bits16[((lrow0 + lane) * W + jt) * 4 + cs0 + 1] = 0;
         }
         continue;
       }
-      d4_t acc[2][9];
+      d4_t acc[NT][9];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 9; ++e) acc[t][e] = d4_t{0.0, 0.0, 0.0, 0.0};
 
@@ -712,26 +717,26 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
       // after its 18 MFMAs have issued, two full k-steps ahead of its use --
       // column operands (LDS) in two sets, one k-step ahead.
       const double *__restrict__ lb0 = lds + cs0 * 32 + boff;
-      double b0[2][3], b1[2][3];
+      double b0[NT][3], b1[NT][3];
       const int KSe = KS;
       auto fetch_a = [&](double (&a)[3], int sx) {
         fetch_a_at(a, voff, sx);  // past the end: harmless re-read, replaced by the prefetch below
       };
-      auto fetch_b = [&](double (&b)[2][3], int sx) {
+      auto fetch_b = [&](double (&b)[NT][3], int sx) {
         const int sl = sx < KS ? sx : KS - 1;
         const double *__restrict__ lb_s = lb0 + sl * (12 * TC);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int c = 0; c < 3; ++c) b[t][c] = lb_s[c * (4 * TC) + t * 32];
       };
-      auto mma = [&](const double (&a)[3], const double (&b)[2][3]) {
+      auto mma = [&](const double (&a)[3], const double (&b)[NT][3]) {
 #pragma unroll
         for (int x = 0; x < 3; ++x)
 #pragma unroll
           for (int y = 0; y < 3; ++y)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
               acc[t][x * 3 + y] =
                   __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[t][y], acc[t][x * 3 + y], 0, 0, 0);
       };
@@ -758,8 +763,8 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
       }
 #undef FC_KSTEP
       {  // request the next unit's first three k-steps now; they land during the epilogue
-        const int nit = half == 0 ? it : it + NW;
-        const bool more = half == 0 || ((nit < it_last) && (i0 + (int64_t)nit * 16 < N) &&
+        const int nit = half < NU - 1 ? it : it + NW;
+        const bool more = half < NU - 1 || ((nit < it_last) && (i0 + (int64_t)nit * 16 < N) &&
                                         !(j0 + TC - 1 <= i0 + (int64_t)nit * 16));
         if (more) {
           unsigned vn[3];
@@ -775,7 +780,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
       // epilogue: lane owns pairs (ib + kq + 4r, j0 + cs*16 + l15), r = 0..3
       const int n32 = (int)N, ib32 = (int)ib;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int cs = cs0 + t;
         const int j = (int)j0 + cs * 16 + l15;
         const double Gq = ldsG[cs * 16 + l15];
@@ -1365,11 +1370,20 @@ k_screen_units_f32(const float *__restrict__ Xsf, const double *__restrict__ G, 
     __builtin_amdgcn_sched_barrier(0);
     fetch(a2, b2, 2);
     __builtin_amdgcn_sched_barrier(0);
-    for (int s0 = 0; s0 < KS; s0 += 3) {
-      if (s0 < KS) { mma(a0, b0); fetch(a0, b0, s0 + 3); }
-      if (s0 + 1 < KS) { mma(a1, b1); fetch(a1, b1, s0 + 4); }
-      if (s0 + 2 < KS) { mma(a2, b2); fetch(a2, b2, s0 + 5); }
+    // whole rounds of three k-steps without a branch inside (with a guard per k-step the compiler merges
+    // the "skipped" paths into its wait counts and drains the load counter in front of every MFMA group:
+    // 111 us for this kernel where the matrix work is 58 us); loads past the last k-step re-read it
+    int s0 = 0;
+    for (; s0 + 3 <= KS; s0 += 3) {
+      mma(a0, b0);
+      fetch(a0, b0, s0 + 3);
+      mma(a1, b1);
+      fetch(a1, b1, s0 + 4);
+      mma(a2, b2);
+      fetch(a2, b2, s0 + 5);
     }
+    if (s0 < KS) mma(a0, b0);
+    if (s0 + 1 < KS) mma(a1, b1);
     const int ib32 = (int)ib;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1416,6 +1430,259 @@ __global__ void k_screen_density_verdict(unsigned long long *__restrict__ counte
     counters[15] = dense ? 1ull : 0ull;
     if (dense) counters[13] = 0ull;
   }
+}
+
+// ---------------------------------------------------------------------------
+// k_simbits_screen_mfma_h2 -- the single-precision screen with the covariance on the HALF-precision
+// matrix pipe (v_mfma_f32_16x16x32_f16: 16x the rate of the f32 instruction) at single-precision
+// accuracy: every coordinate is split into two halfs, x * 2^e = hi + lo (+ at most 2^-22 |x|), and
+//     B = sum hi hi^T + sum hi lo^T + sum lo hi^T        (lo lo^T <= 2^-22 s is left to the bound)
+// costs three f16 products instead of one f32 product at a sixteenth of the rate each: 54 instructions
+// of 16 cycles per 16 x 16 pairs and 64 atoms against 117 of 32 cycles for the f32 kernel (50 atoms).
+// What is left is the polynomial epilogue, which is the same (kabsch_may_be_below_f32 on the fp32
+// accumulators, proven bounds: kabsch_h2_bounds), as are the tiling, the item table, the staging
+// queues and the outputs.  The screen stays a FILTER: what it lets through is decided by the fp64 refine.
+//   * operands: Xh, halfs in the instruction's own operand layout -- run q = ((s*2 + part)*3 + c)*4 + kq
+//     holds for every conformer n the 8 halfs of atoms s*32 + kq*8 + 0..7 (part 0 = hi, 1 = lo) of
+//     coordinate c: [q][n][8]; lane (kq, l15) of a row or column sub-tile reads ONE 16-byte piece per
+//     (s, part, c), 16 lanes 256 contiguous bytes;
+//   * column tile: 24 KS2 runs of 64 x 16 B by LDS-DMA (one 1-KiB instruction each), read back with
+//     conflict-free ds_read_b128;
+//   * row operands: all 6 KS2 pieces of a 16-row tile in registers, loaded once per row tile (its four
+//     16-column sub-tiles use them, one at a time: 9 accumulators), the next row tile's requested behind the
+//     last MFMA of this one;
+//   * order of accumulation: the cross terms of ALL k-steps first (their sum is <= 2^-10 s, what the
+//     matrix pipe does to it is far below the bound), then the hi hi^T terms -- KS2 instructions whose
+//     accumulator is of the order of the result (tools/ubench_mfma_f16_numerics.hip: the instruction
+//     aligns its 32 products and C to the largest, keeps 1 to 3 bits below that one's last place,
+//     truncates the rest and rounds the sum to nearest: <= 36 u (|C| + sum |a b|) per instruction);
+//   * the accumulators hold 2^2e B: G and the threshold are scaled by 2^2e (exact), the polynomial test
+//     is homogeneous.
+// KS2 = k-steps of 32 atoms (template: everything unrolled, operand arrays in registers).
+// ---------------------------------------------------------------------------
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+#ifndef FC_H2_WGS
+#define FC_H2_WGS 3
+#endif
+template <int KS2, bool BITS>
+__global__ void __launch_bounds__(256, (KS2 <= 2 ? FC_H2_WGS : 2))
+k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__ G, int64_t N, int64_t Npad,
+                         float half_A_thr2, float tiny_floor, float scale2, KabschF32Bounds bd, int IB, int64_t rank,
+                         int64_t world, uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
+                         unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
+                         unsigned long long Q, const uint64_t *__restrict__ item_table, unsigned long long n_items) {
+  extern __shared__ double lds_raw[];
+  constexpr int NW = 4, TC = 64;
+  constexpr int n_runs = KS2 * 24;
+  h8_t *__restrict__ lds8 = reinterpret_cast<h8_t *>(lds_raw);  // [run][64 columns]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float *__restrict__ ldsG = reinterpret_cast<float *>(lds8 + n_runs * TC);  // 2^2e G/2 as fp32: [TC columns | IB rows]
+  uint64_t *__restrict__ stageQ = reinterpret_cast<uint64_t *>(ldsG + TC + IB);  // (IB is a multiple of 32)
+  uint32_t *__restrict__ stageW = reinterpret_cast<uint32_t *>(stageQ + kStagePairsF32);
+  unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWordsF32);  // [pairs, words]
+  const unsigned long long b = blockIdx.x;
+  if (b >= n_items) return;
+  int64_t jt, lb;
+  int it_first = 0, it_last = IB >> 4;
+  if (item_table != nullptr) {
+    const uint64_t it = item_table[b];
+    lb = (int64_t)((it >> 32) & 0x7fffffffull);
+    jt = (int64_t)(it & 0x7fffffffull);
+    if (it & (1ull << 31)) it_last = IB >> 5;
+    if (it & (1ull << 63)) it_first = IB >> 5;
+  } else {
+    const int64_t NT = Npad >> 6;
+    jt = (int64_t)(b % (unsigned long long)NT);
+    lb = (int64_t)(b / (unsigned long long)NT);
+  }
+  const int64_t j0 = jt * TC;
+  const int64_t i0 = global_block(lb, rank, world) * IB;
+  if (i0 >= N) return;            // block-uniform
+  if (j0 + TC - 1 <= i0) return;  // nothing above the diagonal in this item
+
+  {  // column tile by LDS-DMA: one 1-KiB instruction per run
+    for (int q = wv; q < n_runs; q += NW) {
+      const h8_t *src = Xh + ((int64_t)q * Npad + j0 + lane);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(lds8 + q * TC), 16, 0, 0);
+    }
+    for (int idx = tid; idx < TC + IB; idx += NW * 64) {
+      const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
+      ldsG[idx] = g < Npad ? (float)(0.5 * G[g]) * scale2 : 0.f;
+    }
+    for (int idx = tid; idx < kStagePairsF32; idx += NW * 64) stageQ[idx] = ~0ull;
+    if (tid < kStageWordsF32) stageW[tid] = ~0u;
+    if (tid < 2) stageN[tid] = 0u;
+    __syncthreads();
+  }
+  const int kq = lane >> 4, l15 = lane & 15;
+  uint16_t *bits16 = reinterpret_cast<uint16_t *>(bits);
+  const int n32 = (int)N;
+
+  // row operands of one 16-row tile: [k-step][hi | lo][coordinate]
+  h8_t ra[KS2][2][3];
+  auto fetch_rows = [&](int it_) {
+    const unsigned vo = (unsigned)((int64_t)kq * Npad + i0 + (int64_t)it_ * 16 + l15);
+#pragma unroll
+    for (int s = 0; s < KS2; ++s)
+#pragma unroll
+      for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const h8_t *__restrict__ base = Xh + (int64_t)(((s * 2 + part) * 3 + c) * 4) * Npad;  // wave-uniform
+          ra[s][part][c] = base[vo];
+        }
+  };
+  auto tile_exists = [&](int it_) {
+    const int64_t ib_ = i0 + (int64_t)it_ * 16;
+    return it_ < it_last && ib_ < N && !(j0 + TC - 1 <= ib_);
+  };
+  const h8_t *__restrict__ lcol = lds8 + kq * TC + l15;  // + run * (4 TC) + sub-tile * 16
+
+  int it = it_first + wv;
+  if (tile_exists(it)) fetch_rows(it);
+  for (; tile_exists(it); it += NW) {
+    const int64_t ib = i0 + (int64_t)it * 16;
+    const int64_t lrow0 = lb * IB + (int64_t)it * 16;
+    const int ib32 = (int)ib;
+    unsigned nz = 0;  // lanes 0..15: OR of the 16-bit pieces written for row ib + lane
+    // one 16 x 16 sub-tile at a time: the row operands stay in registers, so a wider unit would share nothing
+#pragma unroll 1
+    for (int cs = 0; cs < 4; ++cs) {
+      if (j0 + (cs + 1) * 16 - 1 <= ib) {  // at or below the diagonal (never the last sub-tile)
+        if (BITS && lane < 16 && ib + lane < N) bits16[((lrow0 + lane) * W + jt) * 4 + cs] = 0;
+        continue;
+      }
+      f4_t acc[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) acc[e] = f4_t{0.f, 0.f, 0.f, 0.f};
+      const h8_t *__restrict__ lc = lcol + cs * 16;
+      // cross terms of every k-step first
+#pragma unroll
+      for (int s = 0; s < KS2; ++s)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) {
+          const h8_t bh = lc[(((s * 2 + 0) * 3 + y) * 4) * TC];
+          const h8_t bl = lc[(((s * 2 + 1) * 3 + y) * 4) * TC];
+#pragma unroll
+          for (int x = 0; x < 3; ++x) {
+            acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[s][0][x], bl, acc[x * 3 + y], 0, 0, 0);
+            acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[s][1][x], bh, acc[x * 3 + y], 0, 0, 0);
+          }
+        }
+      // then hi x hi
+#pragma unroll
+      for (int s = 0; s < KS2; ++s)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) {
+          const h8_t bh = lc[(((s * 2 + 0) * 3 + y) * 4) * TC];
+#pragma unroll
+          for (int x = 0; x < 3; ++x)
+            acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[s][0][x], bh, acc[x * 3 + y], 0, 0, 0);
+        }
+      // the next row tile's operands are requested now: they land during the epilogue
+      if (cs == 3 && tile_exists(it + NW)) fetch_rows(it + NW);
+      // epilogue: lane owns pairs (ib + 4 kq + r, j0 + cs*16 + l15), r = 0..3
+      const int j = (int)j0 + cs * 16 + l15;
+      const float Gq = ldsG[cs * 16 + l15];
+      uint64_t mr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ib32 + 4 * kq + r;
+        const float Gp = ldsG[TC + it * 16 + 4 * kq + r];
+        float B9[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) B9[e] = acc[e][r];
+        bool may = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd, Gp + Gq, tiny_floor);
+        may = may && (j > i) && (j < n32) && (i < n32);
+        mr[r] = __ballot(may);
+        stage_pairs<kStagePairsF32>(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+      }
+      if (BITS && lane < 16 && ib32 + lane < n32) {
+        const int rr = lane & 3;
+        const uint64_t mine = rr == 0 ? mr[0] : rr == 1 ? mr[1] : rr == 2 ? mr[2] : mr[3];
+        const unsigned piece = (unsigned)((mine >> (16 * (lane >> 2))) & 0xffffull);
+        bits16[((lrow0 + lane) * W + jt) * 4 + cs] = (uint16_t)piece;
+        nz |= piece;
+      }
+    }
+    if (BITS) {  // queue the non-empty words of this row tile for the exact refine
+      const bool has = lane < 16 && nz != 0;
+      const uint64_t mw = __ballot(has);
+      if (mw != 0) {  // wave-uniform
+        const unsigned n = (unsigned)__popcll(mw);
+        const uint32_t word = (uint32_t)((lrow0 + lane) * W + jt);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(stageN + 1, n);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        const unsigned rank_in = (unsigned)__popcll(mw & ((1ull << lane) - 1ull));
+        if (base + n <= (unsigned)kStageWordsF32) {
+          if (has) stageW[base + rank_in] = word;
+        } else {  // no room: straight to the global queue
+          unsigned long long gbase = 0;
+          if (lane == 0) gbase = atomicAdd(&counters[4], (unsigned long long)n);
+          gbase = __shfl(gbase, 0);
+          if (has) cand[gbase + rank_in] = word;
+        }
+      }
+    }
+  }
+  // publish what the workgroup staged: one global atomic per queue
+  __syncthreads();
+  if (wv == 0) {
+    const int used_q = min((int)stageN[0], kStagePairsF32), used_w = min((int)stageN[1], kStageWordsF32);
+    for (int c0 = 0; c0 < used_q; c0 += 64) {
+      const uint64_t e = c0 + lane < kStagePairsF32 ? stageQ[c0 + lane] : ~0ull;
+      const bool valid = e != ~0ull;
+      const uint64_t mv = __ballot(valid);
+      if (mv != 0) {
+        unsigned long long gbase = 0;
+        if (lane == 0) gbase = atomicAdd(&counters[6], (unsigned long long)__popcll(mv));
+        gbase = __shfl(gbase, 0);
+        if (valid) {
+          const unsigned long long slot = gbase + (unsigned long long)__popcll(mv & ((1ull << lane) - 1ull));
+          if (slot < Q) pairq[slot] = e;
+        }
+      }
+    }
+    for (int c0 = 0; c0 < used_w; c0 += 64) {
+      const uint32_t wq = c0 + lane < kStageWordsF32 ? stageW[c0 + lane] : ~0u;
+      const bool valid = wq != ~0u;
+      const uint64_t mv = __ballot(valid);
+      if (mv != 0) {
+        unsigned long long gbase = 0;
+        if (lane == 0) gbase = atomicAdd(&counters[4], (unsigned long long)__popcll(mv));
+        gbase = __shfl(gbase, 0);
+        if (valid) cand[gbase + (unsigned long long)__popcll(mv & ((1ull << lane) - 1ull))] = wq;
+      }
+    }
+  }
+}
+
+// Xs (fp64, [(a*3+c)*Npad + n], A4 atoms) -> Xh: the split-half operand layout of the kernel above.
+// One thread per (run-without-part, conformer): 8 atoms of one coordinate.  x * scale (a power of two:
+// exact) = hi + lo + d with hi = half(x scale), lo = half(x scale - hi) (the difference is exact in fp64):
+// |d| <= 2^-22 (1 + 2^-12) |x scale| or, where lo is subnormal, <= 2^-25 (conversions through fp32
+// round twice: covered by the 2^-12).
+__global__ void __launch_bounds__(256)
+k_f64_to_h2(const double *__restrict__ Xs, int64_t Npad, int A4, int KS2, double scale, h8_t *__restrict__ Xh) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y;  // (s*3 + c)*4 + kq
+  if (n >= Npad) return;
+  const int kq = r & 3, c = (r >> 2) % 3, s = (r >> 2) / 3;
+  h8_t hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int a = s * 32 + kq * 8 + j;
+    const double x = a < A4 ? Xs[(int64_t)(a * 3 + c) * Npad + n] * scale : 0.0;
+    const _Float16 h = (_Float16)(float)x;
+    hi[j] = h;
+    lo[j] = (_Float16)(float)(x - (double)h);
+  }
+  Xh[(int64_t)(((s * 2 + 0) * 3 + c) * 4 + kq) * Npad + n] = hi;
+  Xh[(int64_t)(((s * 2 + 1) * 3 + c) * 4 + kq) * Npad + n] = lo;
 }
 
 // per-conformer statistics of the stage-1 atom subset (the atoms of the even k-steps of the prepared
@@ -2202,6 +2469,7 @@ int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_
                        e->Xa.as<double>(), gmax_bits, conf_idx_dev);
   }
   e->xsf_valid = false;
+  e->xh_valid = false;
   e->g_max = -1.0;
   return check_launch("k_prep");
 }
@@ -2224,10 +2492,10 @@ int launch_matrix_exact(const fc_ensemble *e, double *rmsd_dev, double *maxdev_d
 }
 
 
-// which screen the last launch_simbits_screen used: 32 (fp32 MFMA), 64 (fp64 MFMA), 1 (VALU), 0 (none yet)
+// which screen the last launch_simbits_screen used: 16 (split-half f16 MFMA), 32 (fp32 MFMA), 64 (fp64 MFMA), 1 (VALU), 0 (none yet)
 static int g_last_screen = 0;
 int last_screen_kind() { return g_last_screen; }
-// fc_screen_select: 0 = automatic (FC_SCREEN_F32 / band estimate), 32 / 64 = that screen whatever the band
+// fc_screen_select: 0 = automatic (FC_SCREEN_F32 / FC_SCREEN_H2 / band estimate), 16 / 32 / 64 = that screen whatever the band
 static int g_screen_forced = 0;
 void screen_select(int kind) { g_screen_forced = kind; }
 
@@ -2322,10 +2590,48 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
       // Default: the single-precision screen (fp32 MFMA + bounded fp32 polynomial; candidates are
       // decided by the exact fp64 refine either way).  FC_SCREEN_F32=0, a timeline build's probe,
       // or so many atoms that the proven bounds stop being small select the fp64 screen below.
-      const char *f32_env = g_screen_forced == 64 ? "0" : g_screen_forced == 32 ? "2" : getenv("FC_SCREEN_F32");
+      const char *f32_env = g_screen_forced == 64 ? "0" : (g_screen_forced == 32 || g_screen_forced == 16) ? "2" : getenv("FC_SCREEN_F32");
       const int64_t A4 = (e->A + 3) / 4 * 4;
-      const KabschF32Bounds bd = kabsch_f32_bounds(A4);
-      bool use_f32 = !(f32_env && f32_env[0] == '0') && dbg == nullptr && bd.p0 < 2.0e-3f && e->row_block % 64 == 0;
+      auto ensure_gmax = [&]() -> int {
+        if (e->g_max >= 0.0) return FC_OK;
+        auto *cnt_max = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
+        FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
+        hipLaunchKernelGGL(k_max_nonneg, dim3((unsigned)std::min<int64_t>(ceil_div(e->Npad, 256), 256)), dim3(256), 0,
+                           ctx().stream, e->G.as<double>(), e->Npad, cnt_max);
+        FC_TRY(check_launch("k_max_nonneg"));
+        unsigned long long bits_max = 0;
+        FC_TRY(d2h(&bits_max, cnt_max, sizeof bits_max));
+        FC_TRY(sync());
+        FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
+        std::memcpy(&e->g_max, &bits_max, sizeof(double));
+        return FC_OK;
+      };
+      // The split-half kernel (f16 matrix pipe at single-precision accuracy) takes the place of the fp32-MFMA
+      // kernel where it applies: at most 128 atoms, a finite non-zero largest norm to take the scale from.
+      // FC_SCREEN_H2=0 / fc_screen_select(32): the fp32-MFMA kernel; fc_screen_select(16): this one whatever the band.
+      static const int h2_env = [] {
+        const char *v = getenv("FC_SCREEN_H2");
+        return v ? atoi(v) : 1;
+      }();
+      const int64_t KS2 = (e->A + 31) / 32;
+      bool use_h2 = false;
+      double h2_scale = 1.0;
+      const bool f32_allowed = !(f32_env && f32_env[0] == '0') && dbg == nullptr && e->row_block % 64 == 0;
+      if (f32_allowed && h2_env != 0 && g_screen_forced != 32 && KS2 <= 4 &&
+          (uint64_t)(24 * KS2) * (uint64_t)e->Npad < (1ull << 32)) {
+        FC_TRY(ensure_gmax());
+        if (e->g_max > 0.0 && std::isfinite(e->g_max)) {
+          // largest |coordinate| <= sqrt(g_max): scaled into [2^12, 2^13] (halfs reach 65504; s^4 stays in fp32)
+          int ex = 0;
+          (void)std::frexp(std::sqrt(e->g_max), &ex);  // sqrt(g_max) = m 2^ex, m in [0.5, 1)
+          h2_scale = std::ldexp(1.0, 13 - ex);
+          const double s2 = h2_scale * h2_scale;
+          use_h2 = std::isfinite((float)(0.5 * A_thr2 * s2)) && (float)(0.5 * A_thr2 * s2) > 0.f;
+        }
+      }
+      const KabschF32Bounds bd = use_h2 ? kabsch_h2_bounds(KS2) : kabsch_f32_bounds(A4);
+      bool use_f32 = f32_allowed && bd.p0 < 2.0e-3f;
+      if (g_screen_forced == 16 && !use_h2) return set_error(FC_E_INVALID, "fc_screen_select(16): the split-half screen does not apply to this ensemble");
       bool speculative = f32_env && f32_env[0] == '3';  // FC_SCREEN_F32=3: always with the verdict
       if (use_f32 && !(f32_env && (f32_env[0] == '2' || f32_env[0] == '3'))) {  // FC_SCREEN_F32=2 / 3: no matter how wide the band
         // Band of mean square deviations above the threshold that the bounded fp32 test cannot
@@ -2334,23 +2640,52 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         // f_i s of B, 1.3 for a chain, 2.4 for a ball; 1 assumed).  Large structures with a
         // tight threshold make it wide -- many candidates for the exact refine -- so the fp64
         // screen takes those at once; in between, k_screen_verdict decides on the device.
-        if (e->g_max < 0.0) {
-          auto *cnt_max = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
-          FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
-          hipLaunchKernelGGL(k_max_nonneg, dim3((unsigned)std::min<int64_t>(ceil_div(e->Npad, 256), 256)), dim3(256), 0,
-                             ctx().stream, e->G.as<double>(), e->Npad, cnt_max);
-          FC_TRY(check_launch("k_max_nonneg"));
-          unsigned long long bits_max = 0;
-          FC_TRY(d2h(&bits_max, cnt_max, sizeof bits_max));
-          FC_TRY(sync());
-          FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
-          std::memcpy(&e->g_max, &bits_max, sizeof(double));
-        }
+        FC_TRY(ensure_gmax());
         const double band = (double)bd.p0 * 2.0 * e->g_max / (double)e->A;
         use_f32 = band <= 1.0 * thr2_margin;  // beyond: the fp64 screen at once
         speculative = band > 0.1 * thr2_margin;  // narrow band: not worth the verdict's ~10 us
       }
-      if (use_f32) {
+      if (use_f32 && use_h2) {
+        const size_t lds_h = (size_t)KS2 * 24 * 1024 + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32;
+        if (lds_h > kLdsLimit) return set_error(FC_E_LIMIT, "split-half screen: row block of %lld rows does not fit LDS", (long long)e->row_block);
+        if (!e->xh_valid || e->xh_scale != h2_scale) {
+          FC_TRY(e->Xh.reserve((size_t)KS2 * 24 * (size_t)e->Npad * 16));
+          hipLaunchKernelGGL(k_f64_to_h2, dim3((unsigned)ceil_div(e->Npad, 256), (unsigned)(KS2 * 12)), dim3(256), 0, ctx().stream,
+                             e->Xs.as<double>(), e->Npad, (int)A4, (int)KS2, h2_scale, e->Xh.as<h8_t>());
+          FC_TRY(check_launch("k_f64_to_h2"));
+          e->xh_valid = true;
+          e->xh_scale = h2_scale;
+        }
+        const double s2 = h2_scale * h2_scale;
+        const float hthr = (float)(0.5 * A_thr2 * s2);
+        const float tiny_floor = std::max(4.0f * hthr, (float)e->A);
+#define FC_LAUNCH_H2(KS2_, BITS_)                                                                                       \
+  do {                                                                                                                  \
+    const void *fn_ = reinterpret_cast<const void *>(k_simbits_screen_mfma_h2<KS2_, BITS_>);                            \
+    if (lds_h > 64 * 1024) FC_HIP_TRY(hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h)); \
+    hipLaunchKernelGGL((k_simbits_screen_mfma_h2<KS2_, BITS_>), mgrid, dim3(256), lds_h, ctx().stream, e->Xh.as<h8_t>(), \
+                       e->G.as<double>(), e->N, e->Npad, hthr, tiny_floor, (float)s2, bd, (int)e->row_block, e->rank,   \
+                       e->world, e->bits.as<uint64_t>(), e->W, e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),    \
+                       (unsigned long long)e->pairq_cap, item_table_dev, n_items);                                      \
+  } while (0)
+#define FC_LAUNCH_H2_K(BITS_)                  \
+  switch (KS2) {                               \
+    case 1: FC_LAUNCH_H2(1, BITS_); break;     \
+    case 2: FC_LAUNCH_H2(2, BITS_); break;     \
+    case 3: FC_LAUNCH_H2(3, BITS_); break;     \
+    default: FC_LAUNCH_H2(4, BITS_); break;    \
+  }
+        if (e->lean) {
+          FC_LAUNCH_H2_K(false)
+        } else {
+          FC_LAUNCH_H2_K(true)
+        }
+#undef FC_LAUNCH_H2_K
+#undef FC_LAUNCH_H2
+        FC_TRY(check_launch("k_simbits_screen_mfma_h2"));
+        mark_main();
+        g_last_screen = 16;
+      } else if (use_f32) {
         // Subset stage (lean prunes only).  Measured on one box, screen kernels alone on the chip:
         // 10^4 x 50: 0.432 ms (subset stage 0.31 + per-unit kernel 0.10 + verdict and gated launches)
         // against 0.462 ms single-stage; 3*10^4 x 80: 4.77 ms against 6.81 ms (two workgroups per CU there);
@@ -2432,6 +2767,8 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         FC_TRY(check_launch("k_simbits_screen_mfma_f32"));
         mark_main();
         g_last_screen = 32;
+      }
+      if (use_f32) {
         if (!speculative) return FC_OK;
         // speculative: the verdict kernel decides on the device whether the fp64 screen below
         // has to redo the launch (k_screen_verdict); its workgroups return at once otherwise

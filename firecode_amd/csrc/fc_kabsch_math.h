@@ -211,11 +211,14 @@ inline KabschF32Bounds kabsch_f32_bounds(int64_t A4) {
 // the lean kernel passes the UNcentred half-norm sum of the subset, s_u >= s: its accumulators hold
 // uncentred sums (entry error eta * s_u) from which a rank-one centring term is subtracted, so in units
 // of s_u: |b|_F <= s / s_u <= 1, l <= 1 and every derivative bound above holds a fortiori.
+// tiny_floor: pairs with s at or below it go to the exact path untested (the plain test passes
+// 4 * half_A_thr2: a structure that small against the threshold cannot be screened; the split-half kernel
+// passes the larger of that and the scale its absolute error term needs).
 __device__ __forceinline__ bool kabsch_may_be_below_f32(const float (&B)[9], float s, float half_A_thr2,
-                                                        const KabschF32Bounds &bd, float s_bound) {
+                                                        const KabschF32Bounds &bd, float s_bound, float tiny_floor) {
 #pragma clang fp contract(fast)
   const float L = s - half_A_thr2;
-  const bool tiny = !(4.0f * half_A_thr2 < s);  // tiny structure w.r.t. threshold: cannot be screened
+  const bool tiny = !(tiny_floor < s);
   const float Sxx = B[0], Sxy = B[1], Sxz = B[2];
   const float Syx = B[3], Syy = B[4], Syz = B[5];
   const float Szx = B[6], Szy = B[7], Szz = B[8];
@@ -236,6 +239,29 @@ __device__ __forceinline__ bool kabsch_may_be_below_f32(const float (&B)[9], flo
   // NaN and overflow (inf or NaN coordinates, s^4 beyond fp32) fail every `>`: the pair goes
   // to the exact path; so does an underflow of s^4 to zero
   return tiny | !(P2 > bd.p2 * s2) | !(P1 > bd.p1 * (s2 * s)) | !(P0 > bd.p0 * (s2 * s2));
+}
+__device__ __forceinline__ bool kabsch_may_be_below_f32(const float (&B)[9], float s, float half_A_thr2,
+                                                        const KabschF32Bounds &bd, float s_bound) {
+  return kabsch_may_be_below_f32(B, s, half_A_thr2, bd, s_bound, 4.0f * half_A_thr2);
+}
+
+// Bounds for the split-half kernel (k_simbits_screen_mfma_h2): the covariance is accumulated by
+// v_mfma_f32_16x16x32_f16 from coordinates held as hi + lo halfs, scaled by a power of two.  In units
+// of s (scaled), u = 2^-24, entry error of b = B / s:
+//   representation  x = hi + lo + d, |d| <= 2^-22 (1 + 2^-12) |x|  ->  sum (|dp||q| + |p||dq|) <= 8.01 u s;
+//                   where lo is subnormal |d| <= 2^-25 instead: <= 2^-25 (sum |p| + sum |q|)
+//                   <= 2^-24 sqrt(A s) <= u s  for s >= A  (the kernel's tiny_floor sends smaller s to the exact path)
+//   lo lo^T left out: |lo| <= 2^-11 (1 + 2^-11) |x|                     ->  <= 4.01 u s
+//   matrix pipe     per instruction <= 36 u (|C| + sum |a b|) (measured model, tools/ubench_mfma_f16_numerics.hip:
+//                   products and C aligned to the largest, 1..3 bits kept below its last place, the rest truncated,
+//                   one rounding to nearest): KS2 hi-hi instructions on an accumulator <= (1 + 2^-9) s, after
+//                   2 KS2 cross-term instructions on one <= 2^-10 (1 + 2^-9) s                ->  <= (36.1 KS2 + 0.1 KS2) u s
+//   scaling         G/2 to float and its product with 2^2e: inside the `+ u` and the 4 u on L of the f32 analysis
+// and from there on the analysis of kabsch_f32_bounds (same polynomial, same evaluation roundings).
+inline KabschF32Bounds kabsch_h2_bounds(int64_t KS2) {
+  const double u = 5.9604644775390625e-08, db = (8.01 + 1.0 + 4.01 + 36.2 * (double)KS2) * u + u;
+  return {(float)(2.0 * (45.0 * db + 172.0 * u)), (float)(2.0 * (9.5 * db + 46.0 * u)),
+          (float)(2.0 * (6.0 * db + 52.0 * u))};
 }
 
 // Largest eigenvalue of the quaternion matrix by Newton's iteration on its

@@ -467,14 +467,17 @@ int fc_prune_rmsd_many(fc_ensemble *const *ens, int64_t n, double max_rmsd, doub
  * resident ensemble and returns HIP-event times (ms, per rep) of the
  * dominant kernel and of the whole step measured on the library's stream.  The kernel time is
  * the mean over every 8th prune (FC_BENCH_EVENT_STRIDE): the event pair costs the stream ~14 us. */
-/* Arithmetic of the all-pairs screen the last prune launched: 32 = fp32 matrix pipe + bounded fp32
- * polynomial (default where its undecidable band is narrow), 64 = fp64 matrix pipe (FC_SCREEN_F32=0,
- * large structures with tight thresholds), 1 = VALU kernel, 0 = none yet.  Results do not depend on
- * it: every pair a screen lets through is decided by the exact fp64 refine. */
+/* Arithmetic of the all-pairs screen the last prune launched: 16 = single-precision covariance on the
+ * half-precision matrix pipe (coordinates split into two halfs, three f16 products) + bounded fp32
+ * polynomial (default where its undecidable band is narrow and the structure has at most 128 atoms),
+ * 32 = the same on the fp32 matrix pipe (FC_SCREEN_H2=0, more than 128 atoms), 64 = fp64 matrix pipe
+ * (FC_SCREEN_F32=0, large structures with tight thresholds), 1 = VALU kernel, 0 = none yet.  Results do
+ * not depend on it: every pair a screen lets through is decided by the exact fp64 refine. */
 int fc_screen_last_kind(void);
-/* Choice of the all-pairs screen for the prunes that follow: 0 = automatic (default), 32 = the
- * single-precision screen whatever its band, 64 = the fp64 screen (the reference's arithmetic in
- * every kernel of the step).  Process-wide; results never depend on it. */
+/* Choice of the all-pairs screen for the prunes that follow: 0 = automatic (default), 16 / 32 = that
+ * single-precision screen whatever its band (16: FC_E_INVALID from the prune when it does not apply),
+ * 64 = the fp64 screen (the reference's arithmetic in every kernel of the step).  Process-wide;
+ * results never depend on it. */
 int fc_screen_select(int kind);
 int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
                         double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,

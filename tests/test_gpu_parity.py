@@ -221,7 +221,7 @@ def test_fp32_screen_far_from_the_origin(fc, monkeypatch):
         from firecode_amd import _lib
 
         # which screen was launched (first): forced by the knob, fp64 by the launcher's own band estimate here
-        assert _lib.screen_last_kind() == {"0": 64, "2": 32, "3": 32, None: 64}[mode]
+        assert _lib.screen_last_kind() in {"0": (64,), "2": (16, 32), "3": (16, 32), None: (64,)}[mode]
     assert np.array_equal(out["0"][0], out["2"][0]) and np.array_equal(out["0"][0], out[None][0])
     assert np.array_equal(out["0"][0], out["3"][0])
     assert out["0"][1] == out["2"][1] == out["3"][1] == out[None][1]
@@ -230,7 +230,7 @@ def test_fp32_screen_far_from_the_origin(fc, monkeypatch):
     Xc, _, _ = syn.synthetic_ensemble(300, 50, seed=5)
     with fc.DeviceEnsemble(Xc, center=True) as ens:
         ens.simbits(0.5, 1.0)
-    assert _lib.screen_last_kind() == 32
+    assert _lib.screen_last_kind() in (16, 32)
 
 
 def test_refine_word_queue_fallback(fc, monkeypatch):
