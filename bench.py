@@ -46,6 +46,7 @@ if ROOT not in sys.path:
 MAX_RMSD = 0.5
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 PEAK_F32_MFMA, PEAK_F64_MFMA = 157.3, 78.6  # TFLOP/s dense (same guide)
+PEAK_F16_MFMA = 2500.0  # TFLOP/s dense, f16 / bf16 (same guide: ~2.5 PF)
 FLOPS_PER_ALIGNMENT = lambda a: 53 * a + 600  # noqa: E731  SURVEY 8d "algorithmic flops" of one complete alignment
 
 
@@ -156,6 +157,31 @@ def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, wo
     `achieved` keeps counting the full covariance per pair -- the work a one-stage screen does --
     and `executed_frac` gives what was actually issued to the matrix pipe."""
     kind = _lib.screen_last_kind()
+    if kind == 16:
+        # split-half screen: three f16 products (hi hi^T, hi lo^T, lo hi^T) over atoms padded to 32 give the
+        # covariance at single-precision accuracy; the work issued to the f16 matrix pipe is what `achieved` counts
+        a32 = (n_atoms + 31) // 32 * 32
+        flops = 3 * 2 * 9 * a32
+        tflops = owned_pairs * flops / (kernel_ms * 1e-3) / 1e12
+        eq = owned_pairs * 2 * 9 * ((n_atoms + 3) // 4 * 4) / (kernel_ms * 1e-3) / 1e12
+        traffic, src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_screen_h2.json")
+        if traffic_file and world == 1 and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+            src = "from_file: " + os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes of an earlier run of this kernel, not of this run)"
+        return {"bound": "mfma", "kernel": "k_simbits_screen_mfma_h2", "achieved": tflops, "peak": PEAK_F16_MFMA,
+                "unit": "TFLOP/s", "frac": tflops / PEAK_F16_MFMA, "traffic": traffic, "traffic_source": src,
+                "kernel_ms": kernel_ms, "flops_per_pair": flops, "dtype": "f16x2",
+                "fp32_equivalent": {"what": "the same covariance counted as ONE fp32 product per pair (atoms padded to 4), "
+                                            "against the fp32 matrix-pipe peak the round-1 kernel was priced on",
+                                    "achieved": eq, "peak": PEAK_F32_MFMA, "frac": eq / PEAK_F32_MFMA},
+                "valu_share": {"what": "the bounded fp32 polynomial (~75 vector instructions per pair) is what is left beside "
+                                       "the matrix work: lane-instructions per second against the fp32 vector FMA rate",
+                               "achieved_tera_lane_instr_per_s": owned_pairs * 75 / (kernel_ms * 1e-3) / 1e12,
+                               "peak": PEAK_F32_MFMA / 2, "frac": owned_pairs * 75 / (kernel_ms * 1e-3) / 1e12 / (PEAK_F32_MFMA / 2)},
+                "two_stage": None,
+                "note": "frac = f16 flops issued to the matrix pipe (3 products x 2 x 9 x atoms padded to 32 per pair) / time / "
+                        "2.5 PFLOP/s; the kernel is bound by the sum of that and of the vector epilogue (valu_share)"}
     f32 = kind == 32
     peak = PEAK_F32_MFMA if f32 else PEAK_F64_MFMA
     a4 = (n_atoms + 3) // 4 * 4
@@ -357,8 +383,8 @@ def run_prune(args, workload, fc, _lib, fdist, syn, rank, world, sharded, barrie
     out["roofline"]["kernel_ms_source"] = ("HIP events on the kernel's stream around every %sth launch of the timed region "
                                            "(an event pair costs the stream ~14 us; FC_BENCH_EVENT_STRIDE=1 times all)"
                                            % os.environ.get("FC_BENCH_EVENT_STRIDE", "8")) + ("" if world == 1 else "; rank 0's launches")
-    f32 = out["roofline"]["dtype"] == "f32"
-    out["dtype"] = "f32 screen + f64 exact refine" if f32 else "f64"
+    out["dtype"] = {"f32": "f32 screen + f64 exact refine", "f16x2": "f16x2 screen (split-half, fp32-accurate) + f64 exact refine",
+                    "f64": "f64"}[out["roofline"]["dtype"]]
     bytes_per_alignment = 2 * n_atoms * 24 + 16
     achieved = owned * bytes_per_alignment / (t_kernel_ms * 1e-3) / 1e9
     # the north star's view: algorithmic bytes (two conformers in, rmsd + maxdev out) against the
@@ -444,7 +470,7 @@ def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_at
         "workload": f"{n_conf} x {n_atoms}, continuous RMSD distribution (6 collective modes, ~1.5 % of the pairs below "
                     f"{MAX_RMSD} A, smooth density across the threshold): the case the clustered ensemble does not exercise",
         "ms_per_step": sc, "value": pairs_total / (sc * 1e-3), "screen_kernel_ms": kc,
-        "screen": "f32" if kind_c == 32 else "f64", "candidates_refined": int(stc[1]), "similar_pairs": int(stc[2]),
+        "screen": {16: "f16x2", 32: "f32"}.get(kind_c, "f64"), "candidates_refined": int(stc[1]), "similar_pairs": int(stc[2]),
         "survivors": int(mc.sum())}
     # (e) BASELINE's second metric as SURVEY 8d words it: host arrays in -> mask out, H2D / D2H included
     fc.pruner.prune_by_rmsd(coords[:2000], atoms, MAX_RMSD)

@@ -121,6 +121,8 @@ _SIGNATURES = {
     "fc_ensemble_twin": [_ens, C.POINTER(_ens)],
     "fc_prune_rmsd_begin_split_async": [_ens, _f64, _f64, _i64, _i64, _i64, C.c_void_p, C.c_int],
     "fc_screen_last_kind": [],
+    "fc_debug_mfma_f16_model": [_i64, _p_i64, _p_f64],
+    "fc_debug_h2_covariance": [_ens, _i64, _i64, C.POINTER(C.c_float), _p_f64, _p_f64],
     "fc_comm_unique_id": [_p_u8],
     "fc_comm_init": [_i64, _i64, _p_u8],
     "fc_comm_destroy": [],

@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include "fc_common.h"
+#include "fc_kabsch_math.h"
 
 namespace fc {
 
@@ -19,6 +20,9 @@ int launch_matrix_exact(const fc_ensemble *, double *, double *);
 int launch_rmsd_values(fc_ensemble *, double, double *, double *);
 void screen_select(int);
 int launch_simbits_screen(fc_ensemble *, double);
+int ensure_h2_operands(fc_ensemble *, double *);
+int launch_h2_cov_tile(const fc_ensemble *, int64_t, int64_t, float *);
+int h2_model_report(int64_t, int64_t *, double *);
 int launch_simbits_refine(fc_ensemble *, double, double, const double *, double);
 int launch_align_to_first(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
 int launch_alignment_matrices(const double *, const double *, int64_t, int64_t, double *);
@@ -2363,6 +2367,33 @@ int fc_prune_conventions(int drop_later) {
   FC_API_LOCK;
   prune_conventions_set(drop_later);
   return FC_OK;
+}
+
+int fc_debug_mfma_f16_model(int64_t trials, int64_t *flags_out, double *worst_out) {
+  FC_API_LOCK;
+  FC_REQUIRE(flags_out && worst_out && trials >= 0 && trials <= (1 << 24), "NULL output or trials outside 0..2^24");
+  FC_TRY(ensure_init());
+  return h2_model_report(trials, flags_out, worst_out);
+}
+
+int fc_debug_h2_covariance(fc_ensemble *ens, int64_t ib, int64_t jb, float *B_out, double *scale_out, double *entry_bound_out) {
+  FC_API_LOCK;
+  FC_REQUIRE(ens && B_out && scale_out && entry_bound_out, "NULL argument");
+  FC_REQUIRE(ib >= 0 && jb >= 0 && ib % 16 == 0 && jb % 16 == 0 && ib + 16 <= ens->Npad && jb + 16 <= ens->Npad,
+             "tile origin must be a multiple of 16 inside the padded ensemble");
+  FC_TRY(ensure_init());
+  FC_REQUIRE(ens->epoch == ctx().epoch, "ensemble belongs to a context that was shut down");
+  double scale = 0.0;
+  FC_TRY(ensure_h2_operands(ens, &scale));
+  *scale_out = scale;
+  const int64_t KS2 = (ens->A + 31) / 32;
+  *entry_bound_out = kabsch_h2_entry_bound(KS2);
+  if (scale == 0.0) return FC_OK;  // does not apply (more than 128 atoms, degenerate norms)
+  DevBuf out;
+  FC_TRY(out.reserve(256 * 9 * sizeof(float)));
+  FC_TRY(launch_h2_cov_tile(ens, ib, jb, out.as<float>()));
+  FC_TRY(d2h(B_out, out.p, 256 * 9 * sizeof(float)));
+  return sync();
 }
 
 int fc_screen_select(int kind) {

@@ -1,0 +1,216 @@
+// fc_h2_check.hip -- what the split-half screen (k_simbits_screen_mfma_h2, fc_kabsch.hip) assumes about
+// v_mfma_f32_16x16x32_f16, checked ON THE DEVICE THAT RUNS IT before the kernel is used at all:
+//   (a) fp16 subnormal inputs are honoured;
+//   (b) the 32 products and C are summed with ONE rounding to nearest, not one per addition;
+//   (c) products / C below the largest of them keep at least the largest one's last place (2^-24 of it,
+//       relative; the hardware measured here keeps 1 to 3 bits more);
+//   (d) on random and on adversarial data (wide exponent spread, one dominating product per row, a
+//       dominating C, mixed signs) |D - exact| <= kH2InstrBound u (|C| + sum |a b|), u = 2^-24.
+// kabsch_h2_bounds (fc_kabsch_math.h) charges kH2InstrBound = 36 u per instruction; if any check fails the
+// launcher keeps to the fp32-MFMA screen.  Also here: the 16 x 16 tile of covariances exactly as the screen
+// accumulates them (same instructions, same order), for the tests that compare them with fp64 arithmetic.
+// The reference has no counterpart: this is test and safety infrastructure of the screen, not a FIRECODE row.
+#include "fc_common.h"
+#include "fc_kabsch_math.h"
+
+namespace fc {
+
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kModelPatterns = 8;
+
+// one wavefront.  flags[p] = 1 when pattern p behaves as assumed; worst[0] = largest |D - exact| / (u mag)
+// over `trials` random 16 x 16 x 32 products (five input families, see `family` below).
+__global__ void __launch_bounds__(64) k_mfma_f16_model(int trials, unsigned *__restrict__ flags, float *__restrict__ worst) {
+  __shared__ float sA[16 * 32], sB[32 * 16];
+  const int lane = threadIdx.x, kq = lane >> 4, l15 = lane & 15;
+  const float two24 = 16777216.0f;
+  // element (0, 0): A[0][k] sits in the lanes with l15 == 0 (k = 8 kq + j), B[k][0] likewise, C[0][0] in lane 0 reg 0
+  auto probe = [&](auto a_of_k, auto b_of_k, float c) -> float {
+    h8_t a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kq * 8 + j;
+      a[j] = l15 == 0 ? (_Float16)a_of_k(k) : (_Float16)0.f;
+      b[j] = l15 == 0 ? (_Float16)b_of_k(k) : (_Float16)0.f;
+    }
+    f4_t cc = f4_t{lane == 0 ? c : 0.f, 0.f, 0.f, 0.f};
+    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, cc, 0, 0, 0);
+    return __shfl(cc[0], 0);
+  };
+  float r[kModelPatterns];
+  // (a) subnormal inputs: 2^-24 (smallest fp16 subnormal) * 2^14 = 2^-10
+  r[0] = probe([](int k) { return k == 0 ? 5.9604644775390625e-08f : 0.f; }, [](int k) { return k == 0 ? 16384.f : 0.f; }, 0.f);
+  // (b) C = 2^24 and 32 products of 1: 2^24 + 32 (a rounding per addition would leave 2^24)
+  r[1] = probe([](int) { return 1.f; }, [](int) { return 1.f; }, two24) - two24;
+  // (c) C = 2^24 and 32 products of 1/4: + 8 -- two places below C's last one still count
+  r[2] = probe([](int) { return 0.25f; }, [](int) { return 1.f; }, two24) - two24;
+  // (c') one product of 2^24 and 31 of 1 (the same lanes' products included): + 31, rounded to even: + 32
+  r[3] = probe([](int k) { return k == 0 ? 4096.f : 1.f; }, [](int k) { return k == 0 ? 4096.f : 1.f; }, 0.f) - two24;
+  // rounding to nearest, both signs
+  r[4] = probe([](int k) { return k == 0 ? 3.f : 0.f; }, [](int k) { return k == 0 ? 1.f : 0.f; }, two24) - two24;
+  r[5] = probe([](int k) { return k == 0 ? -3.f : 0.f; }, [](int k) { return k == 0 ? 1.f : 0.f; }, -two24) + two24;
+  // products only: 32 x (2^12 * 2^12 = 2^24) and the largest finite halfs
+  r[6] = probe([](int) { return 4096.f; }, [](int) { return 4096.f; }, 0.f);
+  r[7] = probe([](int k) { return k == 0 ? 65504.f : 0.f; }, [](int k) { return k == 0 ? 65504.f : 0.f; }, 0.f);
+  if (lane == 0) {
+    flags[0] = r[0] == 0.0009765625f;
+    flags[1] = r[1] == 32.f;
+    flags[2] = r[2] == 8.f;
+    flags[3] = r[3] == 32.f || r[3] == 30.f;  // 31 to nearest (ties either way)
+    flags[4] = r[4] == 4.f;
+    flags[5] = r[5] == -4.f;
+    flags[6] = r[6] == 32.f * two24;
+    flags[7] = r[7] == 65504.f * 65504.f;
+  }
+  // (d) random and adversarial data against fp64 (a product of two halfs and a sum of 33 such terms over
+  // less than 2^40 of dynamic range are exact in fp64)
+  unsigned long long st = 0x9E3779B97F4A7C15ull * (unsigned long long)(lane + 1);
+  auto rnd = [&]() -> float {  // uniform in [0, 1)
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    return (float)(unsigned)(st >> 40) * (1.0f / 16777216.0f);
+  };
+  float w = 0.f;
+  for (int t = 0; t < trials; ++t) {
+    const int family = t % 5;  // 0: same sign and size, 1: mixed signs, 2: 12 binades of spread, 3: one dominating product per row, 4: dominating C
+    h8_t a, b;
+    const int big_k = (int)(rnd() * 32.f) & 31;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = rnd(), y = rnd();
+      if (family != 0) x = 2.f * x - 1.f, y = 2.f * y - 1.f;
+      if (family == 2 || family == 3) {
+        x = ldexpf(x, -((int)(rnd() * 12.f)));
+        y = ldexpf(y, -((int)(rnd() * 12.f)));
+      }
+      x *= 100.f, y *= 100.f;
+      // (the row's dominating product: its k is drawn per lane, so only some rows get one -- both cases are wanted)
+      if (family == 3 && kq * 8 + j == big_k) x = 30000.f, y = (rnd() < 0.5f ? -1.f : 1.f) * 30000.f;
+      a[j] = (_Float16)x;
+      b[j] = (_Float16)y;
+    }
+    f4_t c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = family == 4 ? (rnd() - 0.5f) * 4.0e8f : family == 3 ? (rnd() - 0.5f) * 10.f : rnd() * 1.0e3f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sA[l15 * 32 + kq * 8 + j] = (float)a[j];
+      sB[(kq * 8 + j) * 16 + l15] = (float)b[j];
+    }
+    __syncthreads();
+    const f4_t d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 4 * kq + q, col = l15;
+      double exact = (double)c[q], mag = fabs((double)c[q]);
+      for (int k = 0; k < 32; ++k) {
+        const double p = (double)sA[row * 32 + k] * (double)sB[k * 16 + col];
+        exact += p;
+        mag += fabs(p);
+      }
+      const float e = (float)(fabs((double)d[q] - exact) / (mag * 5.9604644775390625e-08));
+      w = e > w ? e : w;  // NaN never wins
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(w, off);
+    w = o > w ? o : w;
+  }
+  if (lane == 0) worst[0] = w;
+}
+
+// per device: 1 = the model holds, 0 = it does not (the split-half screen is not used), -1 = not checked yet
+static int g_model_ok = -1;
+static int g_model_device = -1;
+static unsigned g_model_flags[kModelPatterns];
+static float g_model_worst = -1.f;
+
+static int run_model_check(int trials, unsigned *flags_host, float *worst_host) {
+  DevBuf buf;
+  FC_TRY(buf.reserve(64));
+  hipLaunchKernelGGL(k_mfma_f16_model, dim3(1), dim3(64), 0, ctx().stream, trials, buf.as<unsigned>(),
+                     reinterpret_cast<float *>(buf.as<unsigned>() + kModelPatterns));
+  FC_TRY(check_launch("k_mfma_f16_model"));
+  unsigned host[kModelPatterns + 1];
+  FC_TRY(d2h(host, buf.p, sizeof host));
+  FC_TRY(sync());
+  std::memcpy(flags_host, host, kModelPatterns * sizeof(unsigned));
+  std::memcpy(worst_host, &host[kModelPatterns], sizeof(float));
+  return FC_OK;
+}
+
+// does this device's f16 matrix pipe behave as kabsch_h2_bounds assumes?  (one small launch and one wait,
+// once per device and process)
+int h2_model_ok(bool *ok) {
+  if (g_model_ok < 0 || g_model_device != ctx().device) {
+    FC_TRY(run_model_check(400, g_model_flags, &g_model_worst));
+    bool all = g_model_worst >= 0.f && g_model_worst <= 0.5f * (float)kH2InstrBound;
+    for (int p = 0; p < kModelPatterns; ++p) all = all && g_model_flags[p] == 1u;
+    g_model_ok = all ? 1 : 0;
+    g_model_device = ctx().device;
+    if (!all && getenv("FC_DEBUG")) fprintf(stderr, "[fc] f16 matrix-pipe model check failed: the fp32-MFMA screen stays in use\n");
+  }
+  *ok = g_model_ok == 1;
+  return FC_OK;
+}
+
+int h2_model_report(int64_t trials, int64_t *flags_out, double *worst_out) {
+  unsigned flags[kModelPatterns];
+  float worst = -1.f;
+  FC_TRY(run_model_check((int)trials, flags, &worst));
+  for (int p = 0; p < kModelPatterns; ++p) flags_out[p] = (int64_t)flags[p];
+  *worst_out = (double)worst;
+  return FC_OK;
+}
+
+// ---- the screen's accumulators for one 16 x 16 tile (rows ib.., columns jb..): out[(row*16 + col)*9 + e]
+template <int KS2>
+__global__ void __launch_bounds__(64)
+k_h2_cov_tile(const h8_t *__restrict__ Xh, int64_t Npad, int64_t ib, int64_t jb, float *__restrict__ out) {
+  const int lane = threadIdx.x, kq = lane >> 4, l15 = lane & 15;
+  auto piece = [&](int s, int part, int c, int64_t n) { return Xh[(int64_t)(((s * 2 + part) * 3 + c) * 4 + kq) * Npad + n]; };
+  f4_t acc[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) acc[e] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < KS2; ++s)
+#pragma unroll
+    for (int y = 0; y < 3; ++y) {
+      const h8_t bh = piece(s, 0, y, jb + l15), bl = piece(s, 1, y, jb + l15);
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(piece(s, 0, x, ib + l15), bl, acc[x * 3 + y], 0, 0, 0);
+        acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(piece(s, 1, x, ib + l15), bh, acc[x * 3 + y], 0, 0, 0);
+      }
+    }
+#pragma unroll
+  for (int s = 0; s < KS2; ++s)
+#pragma unroll
+    for (int y = 0; y < 3; ++y) {
+      const h8_t bh = piece(s, 0, y, jb + l15);
+#pragma unroll
+      for (int x = 0; x < 3; ++x)
+        acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(piece(s, 0, x, ib + l15), bh, acc[x * 3 + y], 0, 0, 0);
+    }
+#pragma unroll
+  for (int e = 0; e < 9; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[((4 * kq + r) * 16 + l15) * 9 + e] = acc[e][r];
+}
+
+int launch_h2_cov_tile(const fc_ensemble *e, int64_t ib, int64_t jb, float *out_dev) {
+  const int64_t KS2 = (e->A + 31) / 32;
+  const h8_t *xh = e->Xh.as<h8_t>();
+  switch (KS2) {
+    case 1: hipLaunchKernelGGL(k_h2_cov_tile<1>, dim3(1), dim3(64), 0, ctx().stream, xh, e->Npad, ib, jb, out_dev); break;
+    case 2: hipLaunchKernelGGL(k_h2_cov_tile<2>, dim3(1), dim3(64), 0, ctx().stream, xh, e->Npad, ib, jb, out_dev); break;
+    case 3: hipLaunchKernelGGL(k_h2_cov_tile<3>, dim3(1), dim3(64), 0, ctx().stream, xh, e->Npad, ib, jb, out_dev); break;
+    case 4: hipLaunchKernelGGL(k_h2_cov_tile<4>, dim3(1), dim3(64), 0, ctx().stream, xh, e->Npad, ib, jb, out_dev); break;
+    default: return set_error(FC_E_INVALID, "the split-half layout holds at most 128 atoms");
+  }
+  return check_launch("k_h2_cov_tile");
+}
+
+}  // namespace fc

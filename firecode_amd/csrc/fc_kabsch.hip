@@ -2499,6 +2499,30 @@ int last_screen_kind() { return g_last_screen; }
 static int g_screen_forced = 0;
 void screen_select(int kind) { g_screen_forced = kind; }
 
+int h2_model_ok(bool *ok);  // fc_h2_check.hip
+
+// makes e->Xh for the scale the split-half screen would use; scale_out = 0: the screen does not apply
+int ensure_h2_operands(fc_ensemble *e, double *scale_out) {
+  *scale_out = 0.0;
+  const int64_t KS2 = (e->A + 31) / 32, A4 = (e->A + 3) / 4 * 4;
+  if (KS2 > 4 || (uint64_t)(24 * KS2) * (uint64_t)e->Npad >= (1ull << 32)) return FC_OK;
+  if (!(e->g_max > 0.0) || !std::isfinite(e->g_max)) return FC_OK;
+  // largest |coordinate| <= sqrt(g_max): scaled into [2^12, 2^13] (halfs reach 65504; s^4 stays in fp32)
+  int ex = 0;
+  (void)std::frexp(std::sqrt(e->g_max), &ex);  // sqrt(g_max) = m 2^ex, m in [0.5, 1)
+  const double scale = std::ldexp(1.0, 13 - ex);
+  if (!e->xh_valid || e->xh_scale != scale) {
+    FC_TRY(e->Xh.reserve((size_t)KS2 * 24 * (size_t)e->Npad * 16));
+    hipLaunchKernelGGL(k_f64_to_h2, dim3((unsigned)ceil_div(e->Npad, 256), (unsigned)(KS2 * 12)), dim3(256), 0, ctx().stream,
+                       e->Xs.as<double>(), e->Npad, (int)A4, (int)KS2, scale, e->Xh.as<h8_t>());
+    FC_TRY(check_launch("k_f64_to_h2"));
+    e->xh_valid = true;
+    e->xh_scale = scale;
+  }
+  *scale_out = scale;
+  return FC_OK;
+}
+
 int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   // Context::mark_after_screen: recorded once, right behind the main screen kernel of this launch
   bool marked = false;
@@ -2524,18 +2548,27 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
     const size_t lds_m = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)e->row_block) * sizeof(double) + kStageBytes;
     const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32);
     const bool two_blocks_fit = 2 * lds_m <= kLdsLimit;
-    if (!want_valu && fits32 && lds_m <= kLdsLimit && e->row_block % (two_blocks_fit ? 64 : 128) == 0) {
+    // the fp64 matrix-pipe screen needs its column tile in LDS (up to ~100 atoms); the single-precision
+    // screens reach further (fp32 tile: half the bytes; split-half: 128 atoms) and then run without the
+    // fp64 screen behind them -- no speculative mode, and a band too wide for them means the VALU screen
+    const bool mfma64_ok = fits32 && lds_m <= kLdsLimit && e->row_block % (two_blocks_fit ? 64 : 128) == 0;
+    const int64_t A4s = (e->A + 3) / 4 * 4, KS2s = (e->A + 31) / 32;
+    const bool single_ok = fits32 && e->row_block % 64 == 0 &&
+                           ((size_t)A4s * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32 <= kLdsLimit ||
+                            (KS2s <= 4 && (size_t)KS2s * 24 * 1024 + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32 <= kLdsLimit));
+    bool done = true;  // false: the matrix-pipe path declined, the VALU screen below takes the launch
+    auto mfma_path = [&]() -> int {
       auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
       const bool two_blocks = 2 * lds_m <= kLdsLimit;
       const void *fn = two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4>)
                                   : reinterpret_cast<const void *>(k_simbits_screen_mfma<8>);
-      if (lds_m > 64 * 1024) {
+      if (mfma64_ok && lds_m > 64 * 1024) {
         hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
         if (err != hipSuccess)
           return set_error(FC_E_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", lds_m,
                            hipGetErrorString(err));
       }
-      if (getenv("FC_DEBUG")) {
+      if (mfma64_ok && getenv("FC_DEBUG")) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, two_blocks ? 256 : 512, lds_m);
         fprintf(stderr, "[fc] screen_mfma<%d>: LDS %zu B, occupancy API says %d blocks/CU\n",
@@ -2549,7 +2582,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         const char *v = getenv("FC_SCREEN_V2");
         use_v2 = (v && v[0] == '1') ? 1 : 0;
       }
-      const bool want_v2 = use_v2 && two_blocks && e->row_block == 128;
+      const bool want_v2 = use_v2 && mfma64_ok && two_blocks && e->row_block == 128;
       FC_TRY(screen_item_table(e, NT, n_lblocks, /*halves=*/!want_v2));
       if (e->item_total > 0) {
         n_items = (unsigned long long)e->item_total;
@@ -2617,20 +2650,24 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
       bool use_h2 = false;
       double h2_scale = 1.0;
       const bool f32_allowed = !(f32_env && f32_env[0] == '0') && dbg == nullptr && e->row_block % 64 == 0;
+      if (!mfma64_ok && !f32_allowed) {
+        done = false;
+        return FC_OK;
+      }
       if (f32_allowed && h2_env != 0 && g_screen_forced != 32 && KS2 <= 4 &&
           (uint64_t)(24 * KS2) * (uint64_t)e->Npad < (1ull << 32)) {
         FC_TRY(ensure_gmax());
-        if (e->g_max > 0.0 && std::isfinite(e->g_max)) {
-          // largest |coordinate| <= sqrt(g_max): scaled into [2^12, 2^13] (halfs reach 65504; s^4 stays in fp32)
-          int ex = 0;
-          (void)std::frexp(std::sqrt(e->g_max), &ex);  // sqrt(g_max) = m 2^ex, m in [0.5, 1)
-          h2_scale = std::ldexp(1.0, 13 - ex);
+        bool model_ok = false;
+        FC_TRY(h2_model_ok(&model_ok));  // this device's f16 matrix pipe behaves as kabsch_h2_bounds assumes (checked once)
+        if (model_ok) {
+          FC_TRY(ensure_h2_operands(e, &h2_scale));
           const double s2 = h2_scale * h2_scale;
-          use_h2 = std::isfinite((float)(0.5 * A_thr2 * s2)) && (float)(0.5 * A_thr2 * s2) > 0.f;
+          use_h2 = h2_scale > 0.0 && std::isfinite((float)(0.5 * A_thr2 * s2)) && (float)(0.5 * A_thr2 * s2) > 0.f;
         }
       }
       const KabschF32Bounds bd = use_h2 ? kabsch_h2_bounds(KS2) : kabsch_f32_bounds(A4);
-      bool use_f32 = f32_allowed && bd.p0 < 2.0e-3f;
+      const size_t lds_f32_tile = (size_t)A4 * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) * 6 + kStageBytesF32;
+      bool use_f32 = f32_allowed && bd.p0 < 2.0e-3f && (use_h2 || lds_f32_tile <= kLdsLimit);
       if (g_screen_forced == 16 && !use_h2) return set_error(FC_E_INVALID, "fc_screen_select(16): the split-half screen does not apply to this ensemble");
       bool speculative = f32_env && f32_env[0] == '3';  // FC_SCREEN_F32=3: always with the verdict
       if (use_f32 && !(f32_env && (f32_env[0] == '2' || f32_env[0] == '3'))) {  // FC_SCREEN_F32=2 / 3: no matter how wide the band
@@ -2645,17 +2682,16 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         use_f32 = band <= 1.0 * thr2_margin;  // beyond: the fp64 screen at once
         speculative = band > 0.1 * thr2_margin;  // narrow band: not worth the verdict's ~10 us
       }
+      if (!mfma64_ok) {
+        if (!use_f32) {  // no fp64 matrix-pipe screen to fall back on at this size
+          done = false;
+          return FC_OK;
+        }
+        speculative = false;
+      }
       if (use_f32 && use_h2) {
         const size_t lds_h = (size_t)KS2 * 24 * 1024 + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32;
         if (lds_h > kLdsLimit) return set_error(FC_E_LIMIT, "split-half screen: row block of %lld rows does not fit LDS", (long long)e->row_block);
-        if (!e->xh_valid || e->xh_scale != h2_scale) {
-          FC_TRY(e->Xh.reserve((size_t)KS2 * 24 * (size_t)e->Npad * 16));
-          hipLaunchKernelGGL(k_f64_to_h2, dim3((unsigned)ceil_div(e->Npad, 256), (unsigned)(KS2 * 12)), dim3(256), 0, ctx().stream,
-                             e->Xs.as<double>(), e->Npad, (int)A4, (int)KS2, h2_scale, e->Xh.as<h8_t>());
-          FC_TRY(check_launch("k_f64_to_h2"));
-          e->xh_valid = true;
-          e->xh_scale = h2_scale;
-        }
         const double s2 = h2_scale * h2_scale;
         const float hthr = (float)(0.5 * A_thr2 * s2);
         const float tiny_floor = std::max(4.0f * hthr, (float)e->A);
@@ -2810,6 +2846,10 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
       }
 #endif
       return FC_OK;
+    };
+    if (!want_valu && (mfma64_ok || single_ok)) {
+      FC_TRY(mfma_path());
+      if (done) return FC_OK;
     }
   }
 #define FC_LAUNCH_SCREEN(LDSFLAG, TI_, NW_, SMEM)                                                   \

@@ -258,8 +258,10 @@ __device__ __forceinline__ bool kabsch_may_be_below_f32(const float (&B)[9], flo
 //                   2 KS2 cross-term instructions on one <= 2^-10 (1 + 2^-9) s                ->  <= (36.1 KS2 + 0.1 KS2) u s
 //   scaling         G/2 to float and its product with 2^2e: inside the `+ u` and the 4 u on L of the f32 analysis
 // and from there on the analysis of kabsch_f32_bounds (same polynomial, same evaluation roundings).
+constexpr double kH2InstrBound = 36.0;  // u (|C| + sum |a b|) per v_mfma_f32_16x16x32_f16; checked on the device by fc_h2_check.hip
+inline double kabsch_h2_entry_bound(int64_t KS2) { return (8.01 + 1.0 + 4.01 + (kH2InstrBound + 0.2) * (double)KS2) * 5.9604644775390625e-08; }
 inline KabschF32Bounds kabsch_h2_bounds(int64_t KS2) {
-  const double u = 5.9604644775390625e-08, db = (8.01 + 1.0 + 4.01 + 36.2 * (double)KS2) * u + u;
+  const double u = 5.9604644775390625e-08, db = kabsch_h2_entry_bound(KS2) + u;
   return {(float)(2.0 * (45.0 * db + 172.0 * u)), (float)(2.0 * (9.5 * db + 46.0 * u)),
           (float)(2.0 * (6.0 * db + 52.0 * u))};
 }

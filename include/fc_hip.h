@@ -479,6 +479,19 @@ int fc_screen_last_kind(void);
  * 64 = the fp64 screen (the reference's arithmetic in every kernel of the step).  Process-wide;
  * results never depend on it. */
 int fc_screen_select(int kind);
+/* Checks of what the split-half screen (kind 16) assumes, for the tests -- no FIRECODE call maps to them.
+ * fc_debug_mfma_f16_model: runs the model check of v_mfma_f32_16x16x32_f16 the library runs itself before it
+ * uses that screen: flags_out[0..7] = 1 where the pattern behaves as assumed (subnormal inputs honoured, one
+ * rounding to nearest per instruction, the largest addend's last place kept for the others, exact large
+ * products); worst_out = largest |D - exact| / (2^-24 (|C| + sum |a b|)) over `trials` random and adversarial
+ * 16 x 16 x 32 products -- the error bounds charge 36 per instruction.
+ * fc_debug_h2_covariance: the 16 x 16 tile of covariances (rows ib.., columns jb.., multiples of 16) exactly
+ * as that screen accumulates them: B_out[(row*16 + col)*9 + 3x + y] = scale^2 sum_a p_ax q_ay; entry_bound_out
+ * = the bound on |B_out / scale^2 - B| / s the screen's polynomial bounds start from (s = (Gp + Gq)/2).
+ * scale_out = 0 (B_out untouched): the screen does not apply to this ensemble. */
+int fc_debug_mfma_f16_model(int64_t trials, int64_t *flags_out, double *worst_out);
+int fc_debug_h2_covariance(fc_ensemble *ens, int64_t ib, int64_t jb, float *B_out, double *scale_out,
+                           double *entry_bound_out);
 int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
                         double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
                         int64_t *stats);

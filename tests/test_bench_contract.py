@@ -36,6 +36,7 @@ def test_bench_prints_one_contract_line(sharded):
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     # the arithmetic of the dominant kernel decides the label; the decisions themselves are fp64 either way
     assert (d["dtype"], d["roofline"]["dtype"], d["roofline"]["peak"]) in (
+        ("f16x2 screen (split-half, fp32-accurate) + f64 exact refine", "f16x2", 2500.0),
         ("f32 screen + f64 exact refine", "f32", 157.3), ("f64", "f64", 78.6))
     assert "workload" in d["config"] and d["survivor_count_ok"] is True and d["survivors_are_last_cluster_members"] is True
     assert d["config"]["baseline_config"] == "configs[1]" and "pair decisions" in d["config"]["value_counts"]

@@ -184,20 +184,35 @@ def test_fp32_screen_and_fp64_screen_give_the_same_similarity_bits(fc, monkeypat
     for t in picks:
         ref = np.triu((R0 < t) & (D0 < 2 * t), 1)
         got = {}
-        for mode in ("0", "2", "3"):
-            monkeypatch.setenv("FC_SCREEN_F32", mode)
-            with fc.DeviceEnsemble(X, center=True) as ens:
-                bits, grey = ens.simbits(t, 2 * t)
-                mask, stats = ens.prune(t, 2 * t)
+        from firecode_amd import _lib
+
+        # "2" / "3": the single-precision screen of the launcher's choice (split-half f16 pipe at these sizes),
+        # alone / with the verdict; "k16" / "k32": each of the two single-precision kernels by name
+        for mode in ("0", "2", "3", "k16", "k32"):
+            if mode.startswith("k"):
+                monkeypatch.delenv("FC_SCREEN_F32", raising=False)
+                _lib.screen_select(int(mode[1:]))
+            else:
+                monkeypatch.setenv("FC_SCREEN_F32", mode)
+            try:
+                with fc.DeviceEnsemble(X, center=True) as ens:
+                    bits, grey = ens.simbits(t, 2 * t)
+                    kind_bits = _lib.screen_last_kind()
+                    mask, stats = ens.prune(t, 2 * t)
+                    kind_lean = _lib.screen_last_kind()
+            finally:
+                _lib.screen_select(0)
+            if mode.startswith("k"):
+                assert kind_bits == kind_lean == int(mode[1:])
             got[mode] = (unpack_bits(bits, n), grey, mask, int(stats[2]))
-        for mode in ("2", "3"):
+        for mode in ("2", "3", "k16", "k32"):
             assert np.array_equal(got["0"][0], got[mode][0]) and got["0"][1] == got[mode][1]
             assert np.array_equal(got["0"][2], got[mode][2]) and got["0"][3] == got[mode][3]
         if t == thr:  # off-threshold by construction: the oracle's own arithmetic agrees as well
             assert np.abs(near - thr).min() > 1e-7
             assert np.array_equal(got["2"][0], ref)
             assert np.array_equal(got["2"][2], o.greedy_prune_from_matrix(ref | ref.T))
-    monkeypatch.delenv("FC_SCREEN_F32")
+    monkeypatch.delenv("FC_SCREEN_F32", raising=False)
 
 
 def test_fp32_screen_far_from_the_origin(fc, monkeypatch):

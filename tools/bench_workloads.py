@@ -101,7 +101,7 @@ def prune80():
         "workload": f"cfg4 shape on one GPU: {n} conformers x {A} atoms all-pairs RMSD prune",
         "pairs": pairs, "kernel_ms": tk, "step_ms": ts, "alignments_per_s": pairs / (ts * 1e-3),
         "survivors": int(mask.sum()), "expected": int(len(np.unique(asg))),
-        "screen": "fp32 MFMA" if fc._lib.screen_last_kind() == 32 else "fp64 MFMA",
+        "screen": {16: "f16x2 MFMA (split-half)", 32: "fp32 MFMA"}.get(fc._lib.screen_last_kind(), "fp64 MFMA"),
         "roofline_mfma_frac": pairs * 2 * 9 * 80 / (tk * 1e-3) / (157.3e12 if fc._lib.screen_last_kind() == 32 else 78.6e12),
     }))
 
