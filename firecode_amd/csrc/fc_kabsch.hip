@@ -1502,21 +1502,6 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
   if (i0 >= N) return;            // block-uniform
   if (j0 + TC - 1 <= i0) return;  // nothing above the diagonal in this item
 
-  {  // column tile by LDS-DMA: one 1-KiB instruction per run
-    for (int q = wv; q < n_runs; q += NW) {
-      const h8_t *src = Xh + ((int64_t)q * Npad + j0 + lane);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)(lds8 + q * TC), 16, 0, 0);
-    }
-    for (int idx = tid; idx < TC + IB; idx += NW * 64) {
-      const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
-      ldsG[idx] = g < Npad ? (float)(0.5 * G[g]) * scale2 : 0.f;
-    }
-    for (int idx = tid; idx < kStagePairsF32; idx += NW * 64) stageQ[idx] = ~0ull;
-    if (tid < kStageWordsF32) stageW[tid] = ~0u;
-    if (tid < 2) stageN[tid] = 0u;
-    __syncthreads();
-  }
   const int kq = lane >> 4, l15 = lane & 15;
   uint16_t *bits16 = reinterpret_cast<uint16_t *>(bits);
   const int n32 = (int)N;
@@ -1539,10 +1524,25 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
     const int64_t ib_ = i0 + (int64_t)it_ * 16;
     return it_ < it_last && ib_ < N && !(j0 + TC - 1 <= ib_);
   };
-  const h8_t *__restrict__ lcol = lds8 + kq * TC + l15;  // + run * (4 TC) + sub-tile * 16
-
+  // the first row tile's operands travel while the column tile is filled
   int it = it_first + wv;
   if (tile_exists(it)) fetch_rows(it);
+  {  // column tile by LDS-DMA: one 1-KiB instruction per run
+    for (int q = wv; q < n_runs; q += NW) {
+      const h8_t *src = Xh + ((int64_t)q * Npad + j0 + lane);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(lds8 + q * TC), 16, 0, 0);
+    }
+    for (int idx = tid; idx < TC + IB; idx += NW * 64) {
+      const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
+      ldsG[idx] = g < Npad ? (float)(0.5 * G[g]) * scale2 : 0.f;
+    }
+    for (int idx = tid; idx < kStagePairsF32; idx += NW * 64) stageQ[idx] = ~0ull;
+    if (tid < kStageWordsF32) stageW[tid] = ~0u;
+    if (tid < 2) stageN[tid] = 0u;
+    __syncthreads();
+  }
+  const h8_t *__restrict__ lcol = lds8 + kq * TC + l15;  // + run * (4 TC) + sub-tile * 16
   for (; tile_exists(it); it += NW) {
     const int64_t ib = i0 + (int64_t)it * 16;
     const int64_t lrow0 = lb * IB + (int64_t)it * 16;
@@ -1560,8 +1560,13 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
       for (int e = 0; e < 9; ++e) acc[e] = f4_t{0.f, 0.f, 0.f, 0.f};
       const h8_t *__restrict__ lc = lcol + cs * 16;
       // cross terms of every k-step first
+#ifdef FC_H2_ABLATE_K  // timing experiment only (results are wrong): one k-step of cross terms instead of everything
+      constexpr int KSX = 1;
+#else
+      constexpr int KSX = KS2;
+#endif
 #pragma unroll
-      for (int s = 0; s < KS2; ++s)
+      for (int s = 0; s < KSX; ++s)
 #pragma unroll
         for (int y = 0; y < 3; ++y) {
           const h8_t bh = lc[(((s * 2 + 0) * 3 + y) * 4) * TC];
@@ -1573,6 +1578,7 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
           }
         }
       // then hi x hi
+#ifndef FC_H2_ABLATE_K
 #pragma unroll
       for (int s = 0; s < KS2; ++s)
 #pragma unroll
@@ -1582,23 +1588,55 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
           for (int x = 0; x < 3; ++x)
             acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[s][0][x], bh, acc[x * 3 + y], 0, 0, 0);
         }
+#endif
       // the next row tile's operands are requested now: they land during the epilogue
       if (cs == 3 && tile_exists(it + NW)) fetch_rows(it + NW);
-      // epilogue: lane owns pairs (ib + 4 kq + r, j0 + cs*16 + l15), r = 0..3
+      // epilogue: lane owns pairs (ib + 4 kq + r, j0 + cs*16 + l15), r = 0..3.  The four polynomials in one
+      // straight line; what is rare (a pair for the three-test form, a sub-tile on the diagonal or at the end
+      // of the ensemble, a candidate to stage) sits behind ONE wave-uniform branch per sub-tile each
       const int j = (int)j0 + cs * 16 + l15;
       const float Gq = ldsG[cs * 16 + l15];
-      uint64_t mr[4];
+      bool may[4], redo[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = ib32 + 4 * kq + r;
         const float Gp = ldsG[TC + it * 16 + 4 * kq + r];
         float B9[9];
 #pragma unroll
         for (int e = 0; e < 9; ++e) B9[e] = acc[e][r];
-        bool may = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd, Gp + Gq, tiny_floor);
-        may = may && (j > i) && (j < n32) && (i < n32);
-        mr[r] = __ballot(may);
-        stage_pairs<kStagePairsF32>(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+#ifdef FC_H2_ABLATE_POLY  // timing experiment only (results are wrong): the K loop without the polynomial
+        may[r] = (B9[0] + B9[4] + B9[8]) * B9[1] * B9[2] * B9[3] * B9[5] * B9[6] * B9[7] == 12345.678f * (Gp + Gq);
+        redo[r] = false;
+#else
+        may[r] = kabsch_may_be_below_f32_2t(B9, Gp + Gq, half_A_thr2, bd, tiny_floor, redo[r]);
+#endif
+      }
+      if (__builtin_amdgcn_ballot_w64(redo[0] | redo[1] | redo[2] | redo[3]) != 0ull) {  // nearly collinear structures only
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float Gp = ldsG[TC + it * 16 + 4 * kq + r];
+          float B9[9];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) B9[e] = acc[e][r];
+          const bool may3 = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd, Gp + Gq, tiny_floor);
+          if (redo[r]) may[r] = may3;
+        }
+      }
+      // (strictly above the diagonal and inside the ensemble -- nearly every sub-tile -- no index test)
+      const bool interior = (int)j0 + cs * 16 > ib32 + 15 && (int)j0 + cs * 16 + 15 < n32 && ib32 + 15 < n32;
+      if (!interior) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ib32 + 4 * kq + r;
+          may[r] = may[r] && (j > i) && (j < n32) && (i < n32);
+        }
+      }
+      uint64_t mr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mr[r] = __builtin_amdgcn_ballot_w64(may[r]);
+      if ((mr[0] | mr[1] | mr[2] | mr[3]) != 0ull) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stage_pairs<kStagePairsF32>(mr[r], may[r], (unsigned)(ib32 + 4 * kq + r), (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
       }
       if (BITS && lane < 16 && ib32 + lane < n32) {
         const int rr = lane & 3;

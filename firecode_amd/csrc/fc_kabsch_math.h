@@ -245,6 +245,41 @@ __device__ __forceinline__ bool kabsch_may_be_below_f32(const float (&B)[9], flo
   return kabsch_may_be_below_f32(B, s, half_A_thr2, bd, s_bound, 4.0f * half_A_thr2);
 }
 
+// The same decision with TWO sign tests instead of three (the split-half kernel, whose matrix work is so
+// cheap that this polynomial is most of its time).  With singular values f1 >= f2 >= |f3| of B (f3 signed by
+// det B) the roots of P are  f1+f2+f3, f1-f2-f3, -f1+f2-f3, -f1-f2+f3:  the second largest is <= f1 <= |B|_F.
+// So  u = L^2 - |B|_F^2 > 0  (and L > 0: the tiny_floor)  puts three roots below L, P(L) then has the sign of
+// L - lambda_max, and  P(L) > 0  alone proves the pair dissimilar -- P' is not needed, P'' is replaced by u,
+// which it contains (|du| <= |dP''/4|: bd.p2 covers it).  u <= 0 happens to a dissimilar pair only when both
+// structures are nearly rank one (atoms on a line: |B|_F within A thr^2 / 2 of (Gp+Gq)/2): those pairs -- none
+// in an ensemble of three-dimensional molecules -- take the three-test form above.
+// Branch-free: returns the conservative verdict (u <= 0 counts as "may be similar") and reports in `redo` the
+// lanes that should take the three-test form instead (the caller does that behind ONE wave-uniform branch per
+// group of pairs: a branch per pair costs the wave a VALU -> SALU round trip each).
+__device__ __forceinline__ bool kabsch_may_be_below_f32_2t(const float (&B)[9], float s, float half_A_thr2,
+                                                           const KabschF32Bounds &bd, float tiny_floor, bool &redo) {
+#pragma clang fp contract(fast)
+  const float L = s - half_A_thr2;
+  const bool tiny = !(tiny_floor < s);
+  const float Sxx = B[0], Sxy = B[1], Sxz = B[2];
+  const float Syx = B[3], Syy = B[4], Syz = B[5];
+  const float Szx = B[6], Szy = B[7], Szz = B[8];
+  const float n2 = Sxx * Sxx + Sxy * Sxy + Sxz * Sxz + Syx * Syx + Syy * Syy + Syz * Syz +
+                   Szx * Szx + Szy * Szy + Szz * Szz;
+  const float uu = L * L - n2;
+  const float c00 = Syy * Szz - Syz * Szy, c01 = Syz * Szx - Syx * Szz, c02 = Syx * Szy - Syy * Szx;
+  const float c10 = Sxz * Szy - Sxy * Szz, c11 = Sxx * Szz - Sxz * Szx, c12 = Sxy * Szx - Sxx * Szy;
+  const float c20 = Sxy * Syz - Sxz * Syy, c21 = Sxz * Syx - Sxx * Syz, c22 = Sxx * Syy - Sxy * Syx;
+  const float detB = Sxx * c00 + Sxy * c01 + Sxz * c02;
+  const float e2 = c00 * c00 + c01 * c01 + c02 * c02 + c10 * c10 + c11 * c11 + c12 * c12 +
+                   c20 * c20 + c21 * c21 + c22 * c22;
+  const float P0 = uu * uu - 4.0f * (e2 + 2.0f * L * detB);
+  const float s2 = s * s;
+  const bool u_ok = uu > bd.p2 * s2;
+  redo = !u_ok & !tiny;
+  return tiny | !u_ok | !(P0 > bd.p0 * (s2 * s2));
+}
+
 // Bounds for the split-half kernel (k_simbits_screen_mfma_h2): the covariance is accumulated by
 // v_mfma_f32_16x16x32_f16 from coordinates held as hi + lo halfs, scaled by a power of two.  In units
 // of s (scaled), u = 2^-24, entry error of b = B / s:
