@@ -226,3 +226,94 @@ def test_subset_stage_is_conservative_and_inside_its_bounds(A, shape, thr):
         err = np.abs(g - r)[~tiny]
         assert err.max() <= bd, (name, err.max(), bd)
     del got
+
+
+# ---------------------------------------------------------------------------------------------
+# the split-half screen (k_simbits_screen_mfma_h2): its two-test polynomial and its operand split
+# ---------------------------------------------------------------------------------------------
+def _lambda_max(B):
+    """largest eigenvalue of Horn's quaternion matrix of each 3 x 3 covariance (float64, LAPACK)"""
+    K = np.empty((len(B), 4, 4))
+    Sxx, Sxy, Sxz = B[:, 0, 0], B[:, 0, 1], B[:, 0, 2]
+    Syx, Syy, Syz = B[:, 1, 0], B[:, 1, 1], B[:, 1, 2]
+    Szx, Szy, Szz = B[:, 2, 0], B[:, 2, 1], B[:, 2, 2]
+    K[:, 0, 0] = Sxx + Syy + Szz
+    K[:, 0, 1] = K[:, 1, 0] = Syz - Szy
+    K[:, 0, 2] = K[:, 2, 0] = Szx - Sxz
+    K[:, 0, 3] = K[:, 3, 0] = Sxy - Syx
+    K[:, 1, 1] = Sxx - Syy - Szz
+    K[:, 1, 2] = K[:, 2, 1] = Sxy + Syx
+    K[:, 1, 3] = K[:, 3, 1] = Szx + Sxz
+    K[:, 2, 2] = -Sxx + Syy - Szz
+    K[:, 2, 3] = K[:, 3, 2] = Syz + Szy
+    K[:, 3, 3] = -Sxx - Syy + Szz
+    return np.linalg.eigvalsh(K)
+
+
+def test_two_sign_tests_decide_like_three():
+    """kabsch_may_be_below_f32_2t: u = L^2 - |B|_F^2 > 0 and P(L) > 0 prove lambda_max < L (three roots are below
+    |B|_F then); checked in float64 on random, rank-deficient, nearly collinear and reflected covariances,
+    with L swept across every root"""
+    rng = np.random.default_rng(123)
+    n = 40000
+    B = rng.normal(size=(n, 3, 3))
+    B[: n // 4] *= np.array([1.0, 0.3, 0.02])[None, None, :]           # anisotropic
+    u1, v1 = rng.normal(size=(2, n // 8, 3))
+    B[n // 4: n // 4 + n // 8] = u1[:, :, None] * v1[:, None, :] + 1e-3 * rng.normal(size=(n // 8, 3, 3))  # nearly rank one
+    B[n // 2: n // 2 + n // 8, :, 2] *= -1.0                            # reflections
+    ev = _lambda_max(B)                                                 # ascending: ev[:, 3] is lambda_max
+    n2 = (B * B).sum(axis=(1, 2))
+    # second-largest root never exceeds the Frobenius norm (what the two-test form rests on)
+    assert np.all(ev[:, 2] <= np.sqrt(n2) * (1 + 1e-12))
+    for f in (0.2, 0.7, 0.95, 0.999, 1.001, 1.05, 1.5, 3.0):
+        for ref in (ev[:, 3], ev[:, 2], np.sqrt(n2)):
+            L = np.abs(ref) * f + 1e-9
+            s = np.ones(n)
+            P0, P1, P2 = poly(B, s, L, np.float64)
+            uu = L * L - n2
+            proven_2t = (uu > 0) & (P0 > 0)
+            proven_3t = (P0 > 0) & (P1 > 0) & (P2 > 0)
+            truth = ev[:, 3] < L
+            margin = np.abs(ev[:, 3] - L) > 1e-9 * np.maximum(1.0, np.abs(L))  # away from the root itself
+            assert not np.any(proven_2t & ~truth & margin)   # never claims a similar pair dissimilar
+            assert not np.any(proven_3t & ~truth & margin)
+            # where u > 0 the two forms agree; u <= 0 the kernel hands to the three-test form
+            assert np.array_equal((proven_2t & margin)[uu > 0], (proven_3t & margin)[uu > 0])
+
+
+def test_split_half_representation_error():
+    """x 2^e = hi + lo + d with |d| <= 2^-22 (1 + 2^-12) |x 2^e| or <= 2^-25 where lo is subnormal (k_f64_to_h2:
+    conversions through float32 round twice), and the covariance of the split operands -- products exact, the
+    lo lo^T term left out -- stays within (8.01 + 1 + 4.01) u s of the exact one: the representation part of
+    kabsch_h2_entry_bound (the matrix pipe's own part is checked on the GPU)"""
+    rng = np.random.default_rng(7)
+    for scale_pow, spread in ((0, 1.0), (5, 1.0), (-9, 1.0), (0, 1e-3)):
+        A = 50
+        x = rng.normal(scale=2.5, size=(3000, A, 3)) * spread
+        y = rng.normal(scale=2.5, size=(3000, A, 3))
+        x -= x.mean(axis=1, keepdims=True)
+        y -= y.mean(axis=1, keepdims=True)
+        x *= 2.0 ** scale_pow
+        y *= 2.0 ** scale_pow
+        gmax = max((x * x).sum(axis=(1, 2)).max(), (y * y).sum(axis=(1, 2)).max())
+        m, ex = np.frexp(np.sqrt(gmax))
+        sc = 2.0 ** (13 - ex)
+
+        def split(v):
+            vs = v * sc
+            hi = vs.astype(np.float32).astype(np.float16)
+            lo = (vs - hi.astype(np.float64)).astype(np.float32).astype(np.float16)
+            return vs, hi.astype(np.float64), lo.astype(np.float64)
+
+        xs, xh, xl = split(x)
+        ys, yh, yl = split(y)
+        assert np.abs(xh).max() <= 2.0 ** 13 * (1 + 2.0 ** -11)
+        d = np.abs(xs - xh - xl)
+        assert np.all(d <= np.maximum(2.0 ** -22 * (1 + 2.0 ** -12) * np.abs(xs), 2.0 ** -25))
+        B_exact = np.einsum("pax,pay->pxy", xs, ys)
+        B_split = (np.einsum("pax,pay->pxy", xh, yh) + np.einsum("pax,pay->pxy", xh, yl) + np.einsum("pax,pay->pxy", xl, yh))
+        s = 0.5 * ((xs * xs).sum(axis=(1, 2)) + (ys * ys).sum(axis=(1, 2)))
+        covered = s >= A  # the kernel's tiny_floor
+        err = np.abs(B_split - B_exact).max(axis=(1, 2)) / s
+        assert covered.all() or spread < 1.0
+        assert err[covered].max() <= (8.01 + 1.0 + 4.01) * U
