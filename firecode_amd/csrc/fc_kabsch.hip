@@ -1548,119 +1548,107 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
     __syncthreads();
   }
   const h8_t *__restrict__ lcol = lds8 + kq * TC + l15;  // + run * (4 TC) + sub-tile * 16
-#ifdef FC_H2_ABLATE_K  // timing experiment only (results are wrong): one k-step of cross terms instead of everything
-  constexpr int KSX = 1;
-#else
-  constexpr int KSX = KS2;
-#endif
-  // ---- the matrix work of one 16 x 16 sub-tile: cross terms of every k-step first, then hi x hi
-  auto mfma_block = [&](int cs, f4_t (&acc)[9]) {
-#pragma unroll
-    for (int e = 0; e < 9; ++e) acc[e] = f4_t{0.f, 0.f, 0.f, 0.f};
-    const h8_t *__restrict__ lc = lcol + cs * 16;
-#pragma unroll
-    for (int s = 0; s < KSX; ++s)
-#pragma unroll
-      for (int y = 0; y < 3; ++y) {
-        const h8_t bh = lc[(((s * 2 + 0) * 3 + y) * 4) * TC];
-        const h8_t bl = lc[(((s * 2 + 1) * 3 + y) * 4) * TC];
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-          acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[s][0][x], bl, acc[x * 3 + y], 0, 0, 0);
-          acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[s][1][x], bh, acc[x * 3 + y], 0, 0, 0);
-        }
-      }
-#ifndef FC_H2_ABLATE_K
-#pragma unroll
-    for (int s = 0; s < KS2; ++s)
-#pragma unroll
-      for (int y = 0; y < 3; ++y) {
-        const h8_t bh = lc[(((s * 2 + 0) * 3 + y) * 4) * TC];
-#pragma unroll
-        for (int x = 0; x < 3; ++x)
-          acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[s][0][x], bh, acc[x * 3 + y], 0, 0, 0);
-      }
-#endif
-  };
-  // ---- its four polynomials in one straight line: lane owns pairs (ib + 4 kq + r, j0 + cs*16 + l15), r = 0..3
-  auto poly_block = [&](int it_, int cs, const f4_t (&acc)[9], bool (&may)[4], bool (&redo)[4]) {
-    const float Gq = ldsG[cs * 16 + l15];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float Gp = ldsG[TC + it_ * 16 + 4 * kq + r];
-      float B9[9];
-#pragma unroll
-      for (int e = 0; e < 9; ++e) B9[e] = acc[e][r];
-#ifdef FC_H2_ABLATE_POLY  // timing experiment only (results are wrong): the K loop without the polynomial
-      may[r] = (B9[0] + B9[4] + B9[8]) * B9[1] * B9[2] * B9[3] * B9[5] * B9[6] * B9[7] == 12345.678f * (Gp + Gq);
-      redo[r] = false;
-#else
-      may[r] = kabsch_may_be_below_f32_2t(B9, Gp + Gq, half_A_thr2, bd, tiny_floor, redo[r]);
-#endif
-    }
-  };
-  // ---- what is rare sits behind ONE wave-uniform branch per sub-tile each: a pair for the three-test form, a
-  // sub-tile on the diagonal or at the end of the ensemble, a candidate to stage
-  auto finish = [&](int it_, int cs, const f4_t (&acc)[9], bool (&may)[4], const bool (&redo)[4], unsigned &nz) {
-    const int ib32 = (int)(i0 + (int64_t)it_ * 16);
-    const int64_t lrow0 = lb * IB + (int64_t)it_ * 16;
-    const int j = (int)j0 + cs * 16 + l15;
-    if (__builtin_amdgcn_ballot_w64(redo[0] | redo[1] | redo[2] | redo[3]) != 0ull) {  // nearly collinear structures only
-      const float Gq = ldsG[cs * 16 + l15];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float Gp = ldsG[TC + it_ * 16 + 4 * kq + r];
-        float B9[9];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) B9[e] = acc[e][r];
-        const bool may3 = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd, Gp + Gq, tiny_floor);
-        if (redo[r]) may[r] = may3;
-      }
-    }
-    // (strictly above the diagonal and inside the ensemble -- nearly every sub-tile -- no index test)
-    const bool interior = (int)j0 + cs * 16 > ib32 + 15 && (int)j0 + cs * 16 + 15 < n32 && ib32 + 15 < n32;
-    if (!interior) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = ib32 + 4 * kq + r;
-        may[r] = may[r] && (j > i) && (j < n32) && (i < n32);
-      }
-    }
-    uint64_t mr[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) mr[r] = __builtin_amdgcn_ballot_w64(may[r]);
-    if ((mr[0] | mr[1] | mr[2] | mr[3]) != 0ull) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        stage_pairs<kStagePairsF32>(mr[r], may[r], (unsigned)(ib32 + 4 * kq + r), (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
-    }
-    if (BITS && lane < 16 && ib32 + lane < n32) {
-      const int rr = lane & 3;
-      const uint64_t mine = rr == 0 ? mr[0] : rr == 1 ? mr[1] : rr == 2 ? mr[2] : mr[3];
-      const unsigned piece = (unsigned)((mine >> (16 * (lane >> 2))) & 0xffffull);
-      bits16[((lrow0 + lane) * W + jt) * 4 + cs] = (uint16_t)piece;
-      nz |= piece;
-    }
-  };
   for (; tile_exists(it); it += NW) {
     const int64_t ib = i0 + (int64_t)it * 16;
     const int64_t lrow0 = lb * IB + (int64_t)it * 16;
+    const int ib32 = (int)ib;
     unsigned nz = 0;  // lanes 0..15: OR of the 16-bit pieces written for row ib + lane
-    {
-      // one 16 x 16 sub-tile at a time: the row operands stay in registers, so a wider unit would share nothing
+    // one 16 x 16 sub-tile at a time: the row operands stay in registers, so a wider unit would share nothing
 #pragma unroll 1
-      for (int cs = 0; cs < 4; ++cs) {
-        if (j0 + (cs + 1) * 16 - 1 <= ib) {  // at or below the diagonal (never the last sub-tile)
-          if (BITS && lane < 16 && ib + lane < N) bits16[((lrow0 + lane) * W + jt) * 4 + cs] = 0;
-          continue;
+    for (int cs = 0; cs < 4; ++cs) {
+      if (j0 + (cs + 1) * 16 - 1 <= ib) {  // at or below the diagonal (never the last sub-tile)
+        if (BITS && lane < 16 && ib + lane < N) bits16[((lrow0 + lane) * W + jt) * 4 + cs] = 0;
+        continue;
+      }
+      f4_t acc[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) acc[e] = f4_t{0.f, 0.f, 0.f, 0.f};
+      const h8_t *__restrict__ lc = lcol + cs * 16;
+      // cross terms of every k-step first
+#ifdef FC_H2_ABLATE_K  // timing experiment only (results are wrong): one k-step of cross terms instead of everything
+      constexpr int KSX = 1;
+#else
+      constexpr int KSX = KS2;
+#endif
+#pragma unroll
+      for (int s = 0; s < KSX; ++s)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) {
+          const h8_t bh = lc[(((s * 2 + 0) * 3 + y) * 4) * TC];
+          const h8_t bl = lc[(((s * 2 + 1) * 3 + y) * 4) * TC];
+#pragma unroll
+          for (int x = 0; x < 3; ++x) {
+            acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[s][0][x], bl, acc[x * 3 + y], 0, 0, 0);
+            acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[s][1][x], bh, acc[x * 3 + y], 0, 0, 0);
+          }
         }
-        f4_t acc[9];
-        bool may[4], redo[4];
-        mfma_block(cs, acc);
-        // the next row tile's operands are requested now: they land during the epilogue
-        if (cs == 3 && tile_exists(it + NW)) fetch_rows(it + NW);
-        poly_block(it, cs, acc, may, redo);
-        finish(it, cs, acc, may, redo, nz);
+      // then hi x hi
+#ifndef FC_H2_ABLATE_K
+#pragma unroll
+      for (int s = 0; s < KS2; ++s)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) {
+          const h8_t bh = lc[(((s * 2 + 0) * 3 + y) * 4) * TC];
+#pragma unroll
+          for (int x = 0; x < 3; ++x)
+            acc[x * 3 + y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[s][0][x], bh, acc[x * 3 + y], 0, 0, 0);
+        }
+#endif
+      // the next row tile's operands are requested now: they land during the epilogue
+      if (cs == 3 && tile_exists(it + NW)) fetch_rows(it + NW);
+      // epilogue: lane owns pairs (ib + 4 kq + r, j0 + cs*16 + l15), r = 0..3.  The four polynomials in one
+      // straight line; what is rare (a pair for the three-test form, a sub-tile on the diagonal or at the end
+      // of the ensemble, a candidate to stage) sits behind ONE wave-uniform branch per sub-tile each
+      const int j = (int)j0 + cs * 16 + l15;
+      const float Gq = ldsG[cs * 16 + l15];
+      bool may[4], redo[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float Gp = ldsG[TC + it * 16 + 4 * kq + r];
+        float B9[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) B9[e] = acc[e][r];
+#ifdef FC_H2_ABLATE_POLY  // timing experiment only (results are wrong): the K loop without the polynomial
+        may[r] = (B9[0] + B9[4] + B9[8]) * B9[1] * B9[2] * B9[3] * B9[5] * B9[6] * B9[7] == 12345.678f * (Gp + Gq);
+        redo[r] = false;
+#else
+        may[r] = kabsch_may_be_below_f32_2t(B9, Gp + Gq, half_A_thr2, bd, tiny_floor, redo[r]);
+#endif
+      }
+      if (__builtin_amdgcn_ballot_w64(redo[0] | redo[1] | redo[2] | redo[3]) != 0ull) {  // nearly collinear structures only
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float Gp = ldsG[TC + it * 16 + 4 * kq + r];
+          float B9[9];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) B9[e] = acc[e][r];
+          const bool may3 = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd, Gp + Gq, tiny_floor);
+          if (redo[r]) may[r] = may3;
+        }
+      }
+      // (strictly above the diagonal and inside the ensemble -- nearly every sub-tile -- no index test)
+      const bool interior = (int)j0 + cs * 16 > ib32 + 15 && (int)j0 + cs * 16 + 15 < n32 && ib32 + 15 < n32;
+      if (!interior) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ib32 + 4 * kq + r;
+          may[r] = may[r] && (j > i) && (j < n32) && (i < n32);
+        }
+      }
+      uint64_t mr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mr[r] = __builtin_amdgcn_ballot_w64(may[r]);
+      if ((mr[0] | mr[1] | mr[2] | mr[3]) != 0ull) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stage_pairs<kStagePairsF32>(mr[r], may[r], (unsigned)(ib32 + 4 * kq + r), (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+      }
+      if (BITS && lane < 16 && ib32 + lane < n32) {
+        const int rr = lane & 3;
+        const uint64_t mine = rr == 0 ? mr[0] : rr == 1 ? mr[1] : rr == 2 ? mr[2] : mr[3];
+        const unsigned piece = (unsigned)((mine >> (16 * (lane >> 2))) & 0xffffull);
+        bits16[((lrow0 + lane) * W + jt) * 4 + cs] = (uint16_t)piece;
+        nz |= piece;
       }
     }
     if (BITS) {  // queue the non-empty words of this row tile for the exact refine
