@@ -1489,6 +1489,14 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
   unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWordsF32);  // [pairs, words]
   const unsigned long long b = blockIdx.x;
   if (b >= n_items) return;
+#ifdef FC_H2_TIMELINE  // tuning build (lean launches only: `bits` carries the stamp buffer): start / filled / end / where
+  unsigned long long *tl = BITS ? nullptr : reinterpret_cast<unsigned long long *>(bits);
+  if (tl && tid == 0) {
+    tl[(size_t)b * 4] = wall_clock64();
+    tl[(size_t)b * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |
+                            ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);  // HW_ID, XCC_ID
+  }
+#endif
   int64_t jt, lb;
   int it_first = 0, it_last = IB >> 4;
   if (item_table != nullptr) {
@@ -1546,6 +1554,9 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
     if (tid < kStageWordsF32) stageW[tid] = ~0u;
     if (tid < 2) stageN[tid] = 0u;
     __syncthreads();
+#ifdef FC_H2_TIMELINE
+    if (tl && tid == 0) tl[(size_t)b * 4 + 1] = wall_clock64();
+#endif
   }
   const h8_t *__restrict__ lcol = lds8 + kq * TC + l15;  // + run * (4 TC) + sub-tile * 16
   for (; tile_exists(it); it += NW) {
@@ -1595,7 +1606,9 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
         }
 #endif
       // the next row tile's operands are requested now: they land during the epilogue
+#ifndef FC_H2_ABLATE_ROWS  // timing experiment only (results are wrong): every row tile computed from the first one's operands
       if (cs == 3 && tile_exists(it + NW)) fetch_rows(it + NW);
+#endif
       // epilogue: lane owns pairs (ib + 4 kq + r, j0 + cs*16 + l15), r = 0..3.  The four polynomials in one
       // straight line; what is rare (a pair for the three-test form, a sub-tile on the diagonal or at the end
       // of the ensemble, a candidate to stage) sits behind ONE wave-uniform branch per sub-tile each
@@ -1674,6 +1687,9 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
   }
   // publish what the workgroup staged: one global atomic per queue
   __syncthreads();
+#ifdef FC_H2_TIMELINE
+  if (tl && tid == 0) tl[(size_t)b * 4 + 2] = wall_clock64();
+#endif
   if (wv == 0) {
     const int used_q = min((int)stageN[0], kStagePairsF32), used_w = min((int)stageN[1], kStageWordsF32);
     for (int c0 = 0; c0 < used_q; c0 += 64) {
@@ -1704,6 +1720,13 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
   }
 }
 
+// (Not kept: the same screen as RESIDENT workgroups -- grid = 3 per CU walking the item table with a stride, every
+// item taken as two 32-column halves so that the next half arrives by LDS-DMA in a second 24 KB buffer while this
+// one is computed: no wait for the column tile (16 % of a workgroup's 17 us, tools/h2_timeline_probe.py), no 1.4 us
+// between two workgroups on a CU slot.  Same results; 0.25 ms per launch against 0.177 ms (0.22 ms with 2 or 4
+// workgroups per CU): statically dealt items leave the slower CUs behind, the four waves meet at a barrier per
+// half, and the loop-carried state costs 68 spilled SGPRs and 40 B of scratch.  The hardware's own dispatch of
+// 6 753 short workgroups balances better than that.)
 // Xs (fp64, [(a*3+c)*Npad + n], A4 atoms) -> Xh: the split-half operand layout of the kernel above.
 // One thread per (run-without-part, conformer): 8 atoms of one coordinate.  x * scale (a power of two:
 // exact) = hi + lo + d with hi = half(x scale), lo = half(x scale - hi) (the difference is exact in fp64):
@@ -2754,6 +2777,18 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
     case 3: FC_LAUNCH_H2(3, BITS_); break;     \
     default: FC_LAUNCH_H2(4, BITS_); break;    \
   }
+#ifdef FC_H2_TIMELINE
+        static DevBuf tlbuf;
+        const bool h2_timeline = e->lean && getenv("FC_H2_TIMELINE_OUT") != nullptr;
+        uint64_t *const bits_saved = e->bits.as<uint64_t>();
+        if (h2_timeline) {
+          FC_TRY(tlbuf.reserve(n_items * 4 * sizeof(unsigned long long)));
+          FC_HIP_TRY(hipMemsetAsync(tlbuf.p, 0, n_items * 4 * sizeof(unsigned long long), ctx().stream));
+          e->bits.p = tlbuf.p;
+        } else if (e->lean) {
+          e->bits.p = nullptr;
+        }
+#endif
         if (e->lean) {
           FC_LAUNCH_H2_K(false)
         } else {
@@ -2761,6 +2796,18 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         }
 #undef FC_LAUNCH_H2_K
 #undef FC_LAUNCH_H2
+#ifdef FC_H2_TIMELINE
+        e->bits.p = bits_saved;
+        if (h2_timeline) {
+          std::vector<unsigned long long> h(n_items * 4);
+          FC_HIP_TRY(hipMemcpyAsync(h.data(), tlbuf.p, n_items * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx().stream));
+          FC_HIP_TRY(hipStreamSynchronize(ctx().stream));
+          if (FILE *f = fopen(getenv("FC_H2_TIMELINE_OUT"), "wb")) {
+            fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+            fclose(f);
+          }
+        }
+#endif
         FC_TRY(check_launch("k_simbits_screen_mfma_h2"));
         mark_main();
         g_last_screen = 16;
