@@ -1,6 +1,7 @@
 // fc_api.cpp -- the extern "C" surface of libfc_hip.so (include/fc_hip.h):
 // argument checks, host<->HBM staging, kernel sequencing.  No compute here.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <memory>
@@ -1946,9 +1947,16 @@ int fc_tfd_ladder_from_first_match(const int64_t *first_match, int64_t N, uint8_
   FC_REQUIRE(N >= 0, "bad shape");
   if (N == 0) return FC_OK;
   FC_REQUIRE(first_match && mask_out, "NULL pointer argument");
+  const auto t0 = std::chrono::steady_clock::now();
   for (int64_t i = 0; i < N; ++i)
     FC_REQUIRE(first_match[i] == -1 || (first_match[i] > i && first_match[i] < N), "first_match[%lld] invalid", (long long)i);
-  return tfd_ladder_from_first_match(first_match, N, mask_out);
+  const auto t1 = std::chrono::steady_clock::now();
+  const int rc = tfd_ladder_from_first_match(first_match, N, mask_out);
+  if (getenv("FC_DEBUG"))
+    fprintf(stderr, "[fc] fc_tfd_ladder_from_first_match: validation %.1f ms, ladder incl. tear-down %.1f ms\n",
+            std::chrono::duration<double, std::milli>(t1 - t0).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+  return rc;
 }
 
 int fc_tfd_prune(const double *tf, int64_t N, int64_t Q, double thresh, uint8_t *mask_out) {

@@ -171,6 +171,11 @@ void pyset_order_pairs(const int64_t *pairs, int64_t n, std::vector<int64_t> &ou
   s.for_each([&](int64_t key) { out.push_back(key); });
 }
 
+// helper threads of the component phase of a huge chunk and the smallest graph that gets them: set by
+// tfd_ladder_from_first_match on entry (FC_TFD_COMP_THREADS, FC_TFD_COMP_PAR_MIN: test knobs), read by its workers
+static unsigned g_comp_threads = 1;
+static int64_t g_comp_par_min = 100000;
+
 // ---- one chunk: matches (i_rel ascending) -> relative indices to reject -------
 // Scratch that survives across the ~10^5 chunks of a fine ladder level.
 struct ChunkScratch {
@@ -257,25 +262,28 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
   lap("adjacency");
   const int64_t n_nodes = (int64_t)w.nodes.size();
   w.seen.assign((size_t)n_nodes, 0);
-  int64_t n_seen = 0;
-  for (int64_t src = 0; src < n_nodes; ++src) {
-    if (w.seen[(size_t)src]) continue;
+  // One component: BFS from `src` (its earliest node in the graph's node order), the two Python sets, group[0],
+  // rejects.  Touches only this component's nodes: components are independent of one another, and networkx's
+  // early return of _plain_bfs (len(seen) == n) changes neither the content nor the insertion order of a set.
+  struct CompScratch {
+    PySetEmu comp, view;
+    std::vector<int64_t> members, level, next;
+  };
+  auto one_component = [&](int64_t src, CompScratch &cs, std::vector<int64_t> &rej) {
     // (2) networkx _plain_bfs: `seen` is a Python set filled in BFS order
-    w.comp.reset();
-    w.members.clear();
-    const int64_t limit = n_nodes - n_seen;
-    w.comp.add(w.nodes[(size_t)src], w.nodes[(size_t)src], int_eq);
-    w.members.push_back(src);
+    cs.comp.reset();
+    cs.members.clear();
+    cs.comp.add(w.nodes[(size_t)src], w.nodes[(size_t)src], int_eq);
+    cs.members.push_back(src);
     w.seen[(size_t)src] = 1;
-    w.level.assign(1, src);
-    bool full = (int64_t)w.members.size() == limit;
-    while (!w.level.empty() && !full) {
-      w.next.clear();
-      const size_t n_level = w.level.size();
+    cs.level.assign(1, src);
+    while (!cs.level.empty()) {
+      cs.next.clear();
+      const size_t n_level = cs.level.size();
       for (size_t li = 0; li < n_level; ++li) {
-        const int64_t v = w.level[li];
+        const int64_t v = cs.level[li];
         if (li + 3 < n_level) {  // neighbours of a node three places ahead: their flags and ids
-          const int64_t v3 = w.level[li + 3];
+          const int64_t v3 = cs.level[li + 3];
           for (int64_t rec = w.adj_head[(size_t)v3]; rec < w.adj_head[(size_t)v3 + 1]; ++rec) {
             __builtin_prefetch(&w.seen[(size_t)w.adj_next[(size_t)rec]], 1, 0);
             __builtin_prefetch(&w.nodes[(size_t)w.adj_next[(size_t)rec]], 0, 0);
@@ -286,33 +294,74 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
           if (!w.seen[(size_t)x]) {
             w.seen[(size_t)x] = 1;
             __builtin_prefetch(&w.adj_head[(size_t)x], 0, 0);  // read when x is expanded, one level on
-            w.comp.add(w.nodes[(size_t)x], w.nodes[(size_t)x], int_eq);
-            w.members.push_back(x);
-            w.next.push_back(x);
+            cs.comp.add(w.nodes[(size_t)x], w.nodes[(size_t)x], int_eq);
+            cs.members.push_back(x);
+            cs.next.push_back(x);
           }
         }
-        if ((int64_t)w.members.size() == limit) {
-          full = true;
-          break;
-        }
       }
-      w.level.swap(w.next);
+      cs.level.swap(cs.next);
     }
-    n_seen += (int64_t)w.members.size();
     // (3) group[0] of tuple(g.subgraph(c).nodes)
     int64_t first;
-    if (2 * (int64_t)w.members.size() < n_nodes) {
-      w.view.reset();  // show_nodes.nodes = set(nbunch_iter(c)): rebuilt in c's iteration order
-      w.comp.for_each([&](int64_t key) { w.view.add(key, key, int_eq); });
+    if (2 * (int64_t)cs.members.size() < n_nodes) {
+      cs.view.reset();  // show_nodes.nodes = set(nbunch_iter(c)): rebuilt in c's iteration order
+      cs.comp.for_each([&](int64_t key) { cs.view.add(key, key, int_eq); });
       first = -1;
-      w.view.for_each([&](int64_t key) {
+      cs.view.for_each([&](int64_t key) {
         if (first < 0) first = key;
       });
     } else {
       first = w.nodes[(size_t)src];  // atlas order: the BFS source is the component's earliest node
     }
-    for (int64_t p : w.members)
-      if (w.nodes[(size_t)p] != first) rejects.push_back(w.nodes[(size_t)p]);
+    for (int64_t p : cs.members)
+      if (w.nodes[(size_t)p] != first) rej.push_back(w.nodes[(size_t)p]);
+  };
+  const unsigned comp_threads = g_comp_threads;
+  const int64_t comp_par_min = g_comp_par_min;
+  if (comp_threads > 1 && n_nodes >= comp_par_min) {
+    // A huge chunk (the 840 000-structure chunk of k = 2 at 1.7 M structures is the critical path of the whole
+    // ladder): the sources first -- each component's earliest node = the root of a union-find that always
+    // hangs the later root under the earlier one -- then the components dealt to helper threads.
+    std::vector<int32_t> parent((size_t)n_nodes);
+    for (int64_t v = 0; v < n_nodes; ++v) parent[(size_t)v] = (int32_t)v;
+    auto find = [&](int32_t v) {
+      while (parent[(size_t)v] != v) {
+        parent[(size_t)v] = parent[(size_t)parent[(size_t)v]];  // path halving
+        v = parent[(size_t)v];
+      }
+      return v;
+    };
+    for (int64_t q = 0; q < n_ord; ++q) {
+      const int32_t ra = find((int32_t)w.adj_to[(size_t)q * 2]), rb = find((int32_t)w.adj_to[(size_t)q * 2 + 1]);
+      if (ra < rb) parent[(size_t)rb] = ra;
+      else if (rb < ra) parent[(size_t)ra] = rb;
+    }
+    std::vector<int32_t> sources;
+    for (int64_t v = 0; v < n_nodes; ++v)
+      if (parent[(size_t)v] == (int32_t)v) sources.push_back((int32_t)v);
+    lap("union-find");
+    std::atomic<size_t> next_src{0};
+    std::vector<std::vector<int64_t>> rej_t(comp_threads);
+    auto helper = [&](unsigned t) {
+      CompScratch cs;
+      constexpr size_t kBatch = 256;  // sources per grab
+      while (true) {
+        const size_t b0 = next_src.fetch_add(kBatch);
+        if (b0 >= sources.size()) break;
+        const size_t b1 = std::min(sources.size(), b0 + kBatch);
+        for (size_t i = b0; i < b1; ++i) one_component((int64_t)sources[i], cs, rej_t[t]);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < comp_threads; ++t) pool.emplace_back(helper, t);
+    helper(0);
+    for (auto &th : pool) th.join();
+    for (auto &r : rej_t) rejects.insert(rejects.end(), r.begin(), r.end());
+  } else {
+    CompScratch cs;
+    for (int64_t src = 0; src < n_nodes; ++src)
+      if (!w.seen[(size_t)src]) one_component(src, cs, rejects);
   }
   lap("components");
 }
@@ -365,14 +414,25 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
     const long t = std::strtol(v, nullptr, 10);
     if (t >= 1 && t <= 64) hw = (unsigned)t;
   }
+  g_comp_threads = std::min(hw, 8u);
+  if (const char *v = getenv("FC_TFD_COMP_THREADS")) {  // 1: always the sequential walk over the components
+    const long t = std::strtol(v, nullptr, 10);
+    if (t >= 1 && t <= 64) g_comp_threads = (unsigned)t;
+  }
+  g_comp_par_min = 100000;
+  if (const char *v = getenv("FC_TFD_COMP_PAR_MIN")) g_comp_par_min = (int64_t)std::strtoll(v, nullptr, 10);
   const bool debug = getenv("FC_DEBUG") != nullptr;
   const auto t_all = std::chrono::steady_clock::now();
+  // What a task rejects goes into ONE byte per structure and level (chunks of a level are disjoint index
+  // ranges, so workers never write the same byte): the 1.8*10^7 speculative rejects of 1.7 M structures
+  // held as index lists were 209 MB of vectors whose release alone cost 90-100 ms.
   struct Task {
     int level;                 // index into kl
     int64_t k, d, step_begin, step_end, cost;
-    std::vector<int64_t> rejects;
   };
   std::vector<Task> tasks;
+  constexpr int kLevels = (int)(sizeof(kl) / sizeof(kl[0]));
+  std::vector<uint8_t> level_rej[kLevels];
   for (int li = 0; li < (int)(sizeof(kl) / sizeof(kl[0])); ++li) {
     const int64_t k = (int64_t)kl[li];
     if (!(k == 1 || 5 * k < N)) continue;  // num_active <= N: the level can never run
@@ -383,8 +443,9 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
     const int64_t per = std::max<int64_t>(1, (int64_t)(131072 / d));
     for (int64_t b = 0; b < k - 1; b += per) {
       const int64_t e = std::min<int64_t>(k - 1, b + per);
-      tasks.push_back(Task{li, k, d, b, e, (e - b) * d, {}});
+      tasks.push_back(Task{li, k, d, b, e, (e - b) * d});
     }
+    level_rej[li].assign((size_t)(d * (k - 1)), 0);  // the non-last chunks cover [0, d (k - 1))
   }
   std::vector<size_t> order(tasks.size());
   for (size_t t = 0; t < order.size(); ++t) order[t] = t;
@@ -393,12 +454,16 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
     std::atomic<size_t> next{0};
     auto worker = [&]() {
       ChunkScratch scratch;
+      std::vector<int64_t> rej;
       while (true) {
         const size_t q = next.fetch_add(1);
         if (q >= order.size()) break;
-        Task &t = tasks[order[q]];
+        const Task &t = tasks[order[q]];
+        rej.clear();
         // a non-last chunk never uses num_active: pass N
-        level_chunks(fm, N, t.k, t.d, N, t.step_begin, t.step_end, scratch, t.rejects);
+        level_chunks(fm, N, t.k, t.d, N, t.step_begin, t.step_end, scratch, rej);
+        uint8_t *flags = level_rej[t.level].data();
+        for (int64_t r : rej) flags[r] = 1;
       }
     };
     const unsigned nthreads = (N >= 2000 && tasks.size() > 1) ? std::min<size_t>(hw, tasks.size()) : 1;
@@ -434,8 +499,18 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
     last.clear();
     const int64_t active_in = num_active;
     level_chunks(fm, N, k, d, active_in, k - 1, k, scratch, last);
-    for (size_t t = t_begin; t < ti; ++t)
-      for (int64_t r : tasks[t].rejects) reject(r);
+    (void)t_begin;
+    {  // branch-free over the bytes (vectorised by the compiler): a level rejects up to half of its range
+      const uint8_t *flags = level_rej[li].data();
+      const size_t n_flags = level_rej[li].size();
+      unsigned long long gone = 0;
+      for (size_t r = 0; r < n_flags; ++r) {
+        const uint8_t hit = (uint8_t)(mask_out[r] & flags[r]);
+        gone += hit;
+        mask_out[r] = (uint8_t)(mask_out[r] ^ hit);
+      }
+      num_active -= (int64_t)gone;
+    }
     for (int64_t r : last) reject(r);
     if (debug)
       fprintf(stderr, "[fc] tfd ladder k=%lld: %lld active in\n", (long long)k, (long long)active_in);

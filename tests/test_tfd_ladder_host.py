@@ -32,8 +32,15 @@ def test_ladder_from_first_match_equals_the_reference_loop(monkeypatch, n, q, se
     fm = _first_match(tf)
     ref = o.prune_tfd_from_tf_mat(tf, 10)
     assert 0 < ref.sum() < n
-    for threads in ("1", "3", "16"):
+    # threads over the chunks of a level; helper threads over the connected components inside a chunk (taken for
+    # huge chunks only: FC_TFD_COMP_PAR_MIN=0 sends every chunk down that path)
+    for threads, comp_threads, par_min in (("1", "1", None), ("3", "1", None), ("16", "8", None), ("1", "4", "0"), ("4", "3", "0")):
         monkeypatch.setenv("FC_TFD_THREADS", threads)
+        monkeypatch.setenv("FC_TFD_COMP_THREADS", comp_threads)
+        if par_min is None:
+            monkeypatch.delenv("FC_TFD_COMP_PAR_MIN", raising=False)
+        else:
+            monkeypatch.setenv("FC_TFD_COMP_PAR_MIN", par_min)
         m = np.zeros(n, dtype=np.uint8)
         L.call("fc_tfd_ladder_from_first_match", L.pi(fm), n, L.pb(m))
-        assert np.array_equal(m.astype(bool), ref), threads
+        assert np.array_equal(m.astype(bool), ref), (threads, comp_threads, par_min)
