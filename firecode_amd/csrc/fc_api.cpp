@@ -72,6 +72,7 @@ int launch_torsion_scan(const double *, int64_t, const int64_t *, int64_t, const
 int launch_torsion_fingerprint(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
 int launch_tfd_first_match(const double *, int64_t, int64_t, int64_t, double, int64_t *);
 int launch_transpose_pad(const double *, int64_t, int64_t, int64_t, double *);
+int launch_gather_transpose_pad(const double *, const double *, const int64_t *, int64_t, int64_t, int64_t, double *);
 int tfd_ladder_from_first_match(const int64_t *, int64_t, uint8_t *);
 void pyset_order_ints(const int64_t *, int64_t, std::vector<int64_t> &);
 void pyset_order_pairs(const int64_t *, int64_t, std::vector<int64_t> &);
@@ -1814,18 +1815,23 @@ int fc_string_embed(const double *m1, int64_t n1, int64_t A1, const double *cent
 }
 
 // ---- a17-a20 -----------------------------------------------------------------------
+// tfd_keep_out != nullptr (fc_torsion_scan_tfd): the fingerprints never leave the device -- the list
+// [starting structure] + [scanned conformers with at least one rotated bond] is TFD-pruned at once.
 static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsions, int64_t T,
                              const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
                              int64_t backoff_deg, const int64_t *quads, int64_t Q, double *coords_out,
-                             int64_t *rotated_bonds_out, double *tf_out) {
+                             int64_t *rotated_bonds_out, double *tf_out, double tfd_thresh = 0.0,
+                             uint8_t *tfd_keep_out = nullptr) {
   FC_REQUIRE(A >= 2 && T >= 1 && S >= 0 && Q >= 0, "bad shape");
   FC_REQUIRE(backoff_deg != 0, "backoff_deg must be non-zero");
   if (S == 0) return FC_OK;
   FC_REQUIRE(base && torsions && rotmasks && angles && rotated_bonds_out, "NULL pointer argument");
-  FC_REQUIRE(coords_out || tf_out, "nothing to compute: coords_out and tf_out are both NULL");
-  FC_REQUIRE(tf_out == nullptr || (quads != nullptr && Q >= 1), "fingerprints need quadruplets");
-  if (tf_out)
+  FC_REQUIRE(coords_out || tf_out || tfd_keep_out, "nothing to compute: coords_out and tf_out are both NULL");
+  const bool want_tf = tf_out != nullptr || tfd_keep_out != nullptr;
+  FC_REQUIRE(!want_tf || (quads != nullptr && Q >= 1), "fingerprints need quadruplets");
+  if (want_tf)
     for (int64_t k = 0; k < Q * 4; ++k) FC_REQUIRE(quads[k] >= 0 && quads[k] < A, "quadruplet index out of range");
+  if (tfd_keep_out && Q > 128) return set_error(FC_E_LIMIT, "Q=%lld fingerprints exceed 128 (NumPy's summation order changes there)", (long long)Q);
   if (4 * A * 24 > 160 * 1024 || A > 32767)
     return set_error(FC_E_LIMIT, "A=%lld too large for the LDS slice", (long long)A);
   // moving / rest index lists per torsion (torsion_module.py:907-915)
@@ -1852,7 +1858,7 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   FC_TRY(upload(da, angles, (size_t)S * T));
   if (coords_out) FC_TRY(dout.reserve((size_t)S * A * 3 * sizeof(double)));
   FC_TRY(drot.reserve((size_t)S * sizeof(int64_t)));
-  if (tf_out) {
+  if (want_tf) {
     FC_TRY(upload(dq, quads, (size_t)Q * 4));
     FC_TRY(dtf.reserve((size_t)S * Q * sizeof(double)));
   }
@@ -1860,11 +1866,35 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
                              dmv.as<int16_t>(), drs.as<int16_t>(), dnm.as<int32_t>(),
                              dnr.as<int32_t>(), da.as<int64_t>(), S, thresh, backoff_deg,
                              coords_out ? dout.as<double>() : nullptr, drot.as<int64_t>(),
-                             tf_out ? dq.as<int64_t>() : nullptr, Q, tf_out ? dtf.as<double>() : nullptr));
+                             want_tf ? dq.as<int64_t>() : nullptr, Q, want_tf ? dtf.as<double>() : nullptr));
   if (coords_out) FC_TRY(d2h(coords_out, dout.p, (size_t)S * A * 3 * sizeof(double)));
   if (tf_out) FC_TRY(d2h(tf_out, dtf.p, (size_t)S * Q * sizeof(double)));
   FC_TRY(d2h(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t)));
-  return sync();
+  FC_TRY(sync());
+  if (!tfd_keep_out) return FC_OK;
+  // rows of the TFD problem: the starting structure, then the scanned conformers that rotated a bond
+  std::vector<int64_t> kept;
+  kept.reserve((size_t)S);
+  for (int64_t sidx = 0; sidx < S; ++sidx)
+    if (rotated_bonds_out[sidx] != 0) kept.push_back(sidx);
+  const int64_t M = (int64_t)kept.size(), N = M + 1, Npad = ceil_div(N, 64) * 64;
+  DevBuf dtf0, didx, dT, dfm;
+  FC_TRY(dtf0.reserve((size_t)Q * sizeof(double)));
+  FC_TRY(launch_torsion_fingerprint(db.as<double>(), 1, A, dq.as<int64_t>(), Q, dtf0.as<double>()));
+  FC_TRY(upload(didx, kept.data(), (size_t)std::max<int64_t>(M, 1)));
+  FC_TRY(dT.reserve((size_t)Q * Npad * sizeof(double)));
+  FC_TRY(launch_gather_transpose_pad(dtf.as<double>(), dtf0.as<double>(), didx.as<int64_t>(), M, Q, Npad, dT.as<double>()));
+  FC_TRY(dfm.reserve((size_t)N * sizeof(int64_t)));
+  FC_TRY(launch_tfd_first_match(dT.as<double>(), N, Npad, Q, tfd_thresh, dfm.as<int64_t>()));
+  std::vector<int64_t> fm((size_t)N);
+  FC_TRY(d2h(fm.data(), dfm.p, (size_t)N * sizeof(int64_t)));
+  FC_TRY(sync());
+  std::vector<uint8_t> mask((size_t)N);
+  FC_TRY(tfd_ladder_from_first_match(fm.data(), N, mask.data()));
+  std::memset(tfd_keep_out, 0, (size_t)S + 1);
+  tfd_keep_out[0] = mask[0];
+  for (int64_t k = 0; k < M; ++k) tfd_keep_out[1 + kept[(size_t)k]] = mask[(size_t)k + 1];
+  return FC_OK;
 }
 
 int fc_torsion_scan(const double *base, int64_t A, const int64_t *torsions, int64_t T,
@@ -1884,6 +1914,19 @@ int fc_torsion_scan_fingerprints(const double *base, int64_t A, const int64_t *t
   FC_REQUIRE(S == 0 || tf_out != nullptr, "NULL pointer argument");
   return torsion_scan_impl(base, A, torsions, T, rotmasks, angles, S, thresh, backoff_deg, quads, Q, coords_out,
                            rotated_bonds_out, tf_out);
+}
+
+int fc_torsion_scan_tfd(const double *base, int64_t A, const int64_t *torsions, int64_t T, const uint8_t *rotmasks,
+                        const int64_t *angles, int64_t S, double thresh, int64_t backoff_deg, const int64_t *quads,
+                        int64_t Q, double tfd_thresh, int64_t *rotated_bonds_out, uint8_t *keep_out) {
+  FC_API_LOCK;
+  FC_REQUIRE(keep_out != nullptr, "NULL pointer argument");
+  if (S == 0) {  // the starting structure alone: nothing to compare it with
+    keep_out[0] = 1;
+    return FC_OK;
+  }
+  return torsion_scan_impl(base, A, torsions, T, rotmasks, angles, S, thresh, backoff_deg, quads, Q, nullptr,
+                           rotated_bonds_out, nullptr, tfd_thresh, keep_out);
 }
 
 int fc_torsion_fingerprint(const double *coords, int64_t N, int64_t A, const int64_t *quads,

@@ -800,6 +800,25 @@ int launch_transpose_pad(const double *in_dev, int64_t N, int64_t Q, int64_t Npa
   return check_launch("k_transpose_pad");
 }
 
+// the same with a row selection: out row 0 = `first` (Q values), out row 1 + k = in[idx[k]]; the rest zeros
+// (fc_torsion_scan_tfd: the fingerprints of a scan stay on the device, the starting structure leads the list)
+__global__ void __launch_bounds__(256)
+k_gather_transpose_pad(const double *__restrict__ in, const double *__restrict__ first, const int64_t *__restrict__ idx,
+                       int64_t M, int64_t Q, int64_t Npad, double *__restrict__ out) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= Npad) return;
+  const double *__restrict__ row = n == 0 ? first : (n <= M ? in + idx[n - 1] * Q : nullptr);
+  for (int64_t q = 0; q < Q; ++q) out[q * Npad + n] = row ? row[q] : 0.0;
+}
+
+int launch_gather_transpose_pad(const double *in_dev, const double *first_dev, const int64_t *idx_dev, int64_t M,
+                                int64_t Q, int64_t Npad, double *out_dev) {
+  if (Npad == 0 || Q == 0) return FC_OK;
+  hipLaunchKernelGGL(k_gather_transpose_pad, dim3((unsigned)ceil_div(Npad, 256)), dim3(256), 0, ctx().stream, in_dev,
+                     first_dev, idx_dev, M, Q, Npad, out_dev);
+  return check_launch("k_gather_transpose_pad");
+}
+
 int launch_tfd_first_match(const double *tfT_dev, int64_t N, int64_t Npad, int64_t Q, double thresh,
                            int64_t *fm_dev) {
   if (N == 0) return FC_OK;

@@ -44,6 +44,25 @@ def torsion_scan_fingerprints(base, torsions, masks, angles, quadruplets, thresh
     return (tf, rot, out) if want_coords else (tf, rot)
 
 
+def torsion_scan_tfd(base, torsions, masks, angles, quadruplets, thresh=1.5, backoff=5, tfd_thresh=10):
+    """``torsion_scan_fingerprints`` + ``prune_tfd_from_tf_mat`` on ``[base] + [conformers that rotated a
+    bond]`` in one call, fingerprints resident on the device (fc_torsion_scan_tfd).
+    Returns (rotated_bonds (S,), keep (S + 1,) bool: [0] = the starting structure)."""
+    base = L.f64(base)
+    tors = L.i64(torsions).reshape(-1, 4)
+    msk = L.u8(np.asarray(masks, dtype=bool)).reshape(tors.shape[0], -1)
+    ang = L.i64(angles).reshape(-1, tors.shape[0])
+    quads = L.i64(quadruplets).reshape(-1, 4)
+    A, T, S, Q = base.shape[0], tors.shape[0], ang.shape[0], quads.shape[0]
+    if base.ndim != 2 or base.shape[1] != 3 or msk.shape[1] != A or Q == 0:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "base (A, 3), masks (T, A) and at least one quadruplet expected")
+    rot = np.zeros(S, dtype=np.int64)
+    keep = np.zeros(S + 1, dtype=np.uint8)
+    L.call("fc_torsion_scan_tfd", L.pf(base), A, L.pi(tors), T, L.pb(msk), L.pi(ang), S, float(thresh), int(backoff),
+           L.pi(quads), Q, float(tfd_thresh), L.pi(rot), L.pb(keep))
+    return rot, keep.astype(bool)
+
+
 def torsion_comp_check(coords, torsion, mask, thresh=1.5, max_clashes=0):
     """firecode/torsion_module.py:894-918: rest-vs-moving clash count <= max_clashes."""
     X = L.f64(coords)
@@ -144,17 +163,14 @@ def clustered_csearch(coords, torsions, rotation_masks, n_out=100, thresh=1.5, s
     # Fingerprint every scanned conformer inside the scan kernel, TFD-prune on the (S, Q)
     # fingerprints, then generate coordinates only for the survivors -- the scan of 1.7 M
     # angle-sets would otherwise move 2 GB of conformers to the host to keep a few thousand.
-    tf, rot = torsion_scan_fingerprints(base, quads, rotation_masks, angles, quads, thresh=thresh)
-    kept = np.flatnonzero(rot != 0)
-    tf_all = np.concatenate([get_torsion_fingerprint(base, quads)[None], tf[kept]])
-    n_new = len(tf_all)  # the starting structure first, as the reference lists it (:858-861)
+    # ... and the fingerprints themselves stay on the device between the scan and the prune
+    rot, keep = torsion_scan_tfd(base, quads, rotation_masks, angles, quads, thresh=thresh, tfd_thresh=10)
+    n_new = 1 + int(np.count_nonzero(rot))  # the starting structure first, as the reference lists it (:858-861)
     if logfunction is not None:
         logfunction(f"> Group 1/1 - {len(torsions)} bonds, {[int(t[4]) for t in torsions]} n-folds, "
                     f"1 starting point = {len(angles)} conformers")
-    mask = prune_tfd_from_tf_mat(tf_all, 10)
-    survivors = np.flatnonzero(mask[1:])
-    pruned = torsion_scan(base, quads, rotation_masks, angles[kept[survivors]], thresh=thresh)[0]
-    if mask[0]:
+    pruned = torsion_scan(base, quads, rotation_masks, angles[np.flatnonzero(keep[1:])], thresh=thresh)[0]
+    if keep[0]:
         pruned = np.concatenate([base[None], pruned])
     output = list(pruned)
     if n_new > n_out:

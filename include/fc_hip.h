@@ -411,6 +411,15 @@ int fc_torsion_scan_fingerprints(const double *base, int64_t A, const int64_t *t
                                  const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
                                  int64_t backoff_deg, const int64_t *quads, int64_t Q, double *tf_out,
                                  int64_t *rotated_bonds_out, double *coords_out);
+/* fc_torsion_scan_fingerprints followed by the TFD prune of `[starting structure] + [scanned conformers
+ * with at least one rotated bond]`, the list clustered_csearch hands to prune_conformers_tfd
+ * (firecode/torsion_module.py:858-870, 957-1043) -- with the fingerprints never leaving the device
+ * (at 1.7 M angle-sets they are 107 MB each way).  keep_out: S + 1 bytes, [0] = the starting structure,
+ * [1 + s] = 1 when conformer s rotated a bond AND survived the prune.  Same mask as fc_tfd_prune on the
+ * same rows. */
+int fc_torsion_scan_tfd(const double *base, int64_t A, const int64_t *torsions, int64_t T, const uint8_t *rotmasks,
+                        const int64_t *angles, int64_t S, double thresh, int64_t backoff_deg, const int64_t *quads,
+                        int64_t Q, double tfd_thresh, int64_t *rotated_bonds_out, uint8_t *keep_out);
 
 /* ---- a20: torsion fingerprints and TFD similarity bits --
  * firecode/torsion_module.py:1046-1076.

@@ -102,6 +102,12 @@ def test_cfg3_full_scan_samples_and_tfd(fc):
     assert np.abs(tf[pick] - o.get_tf_mat(new[pick], torsions)).max() < 1e-9
     mask = fc.torsion_module.prune_tfd_from_tf_mat(tf, 10)
     assert 0 < mask.sum() < len(mask)
+    # the fused call of the csearch driver (fingerprints stay on the device) gives the same mask on the same rows
+    rot_f, keep_f = fc.torsion_module.torsion_scan_tfd(base, torsions, masks, angles, torsions, thresh=1.5, tfd_thresh=10)
+    assert np.array_equal(rot_f, rot)
+    expect = np.zeros(len(angles) + 1, dtype=bool)
+    expect[keep] = mask
+    assert np.array_equal(keep_f, expect)
     # (the reference's TFD pruning is not idempotent -- first-match graph, masked structures
     # keep participating -- so the checks are: a literal-oracle run on a slice, and)
     sl = tf[100000:100700]

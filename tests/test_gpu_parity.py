@@ -473,6 +473,29 @@ def test_scan_with_fingerprints_equals_two_passes(fc):
     assert np.abs(tf - o.get_tf_mat(o.torsion_scan(base, tors, masks, angles)[0], quads)).max() < 1e-9
 
 
+def test_scan_tfd_fused_equals_scan_then_prune(fc):
+    """fc_torsion_scan_tfd (fingerprints resident on the device between the scan and the TFD prune) == the two
+    calls with the fingerprints through the host, and == the oracle's literal loop on the same rows"""
+    for n_tors, stride, seed in ((4, 1, 37), (5, 3, 38)):
+        base, tors, masks = _chain_case(32, n_tors, seed=seed)
+        angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * n_tors)[::stride]
+        tf, rot = fc.torsion_module.torsion_scan_fingerprints(base, tors, masks, angles, tors)
+        kept = np.flatnonzero(rot != 0)
+        tf_all = np.concatenate([fc.torsion_module.get_torsion_fingerprint(base, tors)[None], tf[kept]])
+        mask = fc.torsion_module.prune_tfd_from_tf_mat(tf_all, 10)
+        rot2, keep = fc.torsion_module.torsion_scan_tfd(base, tors, masks, angles, tors, tfd_thresh=10)
+        assert np.array_equal(rot, rot2)
+        expect = np.zeros(len(angles) + 1, dtype=bool)
+        expect[0] = mask[0]
+        expect[1 + kept] = mask[1:]
+        assert np.array_equal(keep, expect) and 0 < keep.sum() < len(keep)
+        if len(tf_all) <= 2000:
+            assert np.array_equal(mask, o.prune_tfd_from_tf_mat(tf_all, 10))
+    # nothing rotates (every angle zero): the starting structure alone
+    rot0, keep0 = fc.torsion_module.torsion_scan_tfd(base, tors, masks, np.zeros((3, n_tors), dtype=np.int64), tors)
+    assert not rot0.any() and keep0.tolist() == [True, False, False, False]
+
+
 def test_clash_functions_on_the_reference_fixture_molecules(fc, golden):
     """count_clashes / fragment compenetration_check on the molecules of the reference's own test
     files, against the reference's own outputs"""

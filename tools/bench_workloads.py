@@ -61,31 +61,32 @@ def csearch():
         masks[t, c + 2:] = True
     angles = fc.utils.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * T)
     S = len(angles)
-    t0 = time.perf_counter()
-    tf, rot = fc.torsion_module.torsion_scan_fingerprints(base, torsions, masks, angles, torsions, thresh=1.5)
-    t_scan = time.perf_counter() - t0
-    kept = np.flatnonzero(rot != 0)
-    tf_all = np.concatenate([fc.torsion_module.get_torsion_fingerprint(base, torsions)[None], tf[kept]])
-    t2 = time.perf_counter()
-    tmask = fc.torsion_module.prune_tfd_from_tf_mat(tf_all, 10)
-    t_tfd = time.perf_counter() - t2
-    t1 = time.perf_counter()
-    surv = fc.torsion_module.torsion_scan(base, torsions, masks, angles[kept[np.flatnonzero(tmask[1:])]], thresh=1.5)[0]
-    if tmask[0]:
-        surv = np.concatenate([base[None], surv])
-    t_regen = time.perf_counter() - t1
-    t3 = time.perf_counter()
     atoms = np.array(["C"] * A)
-    _, rmask = fc.pruner.prune_by_rmsd(surv, atoms, 0.5)
-    t_rmsd = time.perf_counter() - t3
-    wall = time.perf_counter() - t0
+    runs = []
+    for run in range(2):  # the first run pays the one-time costs (device allocations, first touch of the host buffers)
+        t0 = time.perf_counter()
+        # scan with the fingerprints taken inside the kernel + TFD prune of [base] + [rotated conformers]; the
+        # fingerprints stay on the device between the two (fc_torsion_scan_tfd, what clustered_csearch calls)
+        rot, keep = fc.torsion_module.torsion_scan_tfd(base, torsions, masks, angles, torsions, thresh=1.5, tfd_thresh=10)
+        t_scan_tfd = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        surv = fc.torsion_module.torsion_scan(base, torsions, masks, angles[np.flatnonzero(keep[1:])], thresh=1.5)[0]
+        if keep[0]:
+            surv = np.concatenate([base[None], surv])
+        t_regen = time.perf_counter() - t1
+        t3 = time.perf_counter()
+        _, rmask = fc.pruner.prune_by_rmsd(surv, atoms, 0.5)
+        t_rmsd = time.perf_counter() - t3
+        runs.append({"s_scan_fingerprints_tfd_prune": t_scan_tfd, "s_rescan_survivors": t_regen, "s_rmsd_prune": t_rmsd,
+                     "s_total": time.perf_counter() - t0})
+    wall = runs[1]["s_total"]
     print(json.dumps({
         "workload": "cfg3 csearch: 8 rotatable bonds x 6-fold = 1 679 616 angle-sets, clash 1.5 A, back-off 5 deg, "
-                    "fingerprints taken inside the scan kernel, TFD prune (10 deg) on them, survivors re-scanned, "
-                    "RMSD prune (0.5 A)",
-        "angle_sets": S, "kept_after_scan": int(len(tf_all)), "after_tfd": int(tmask.sum()), "after_rmsd": int(rmask.sum()),
-        "s_scan_with_fingerprints": t_scan, "s_tfd_prune": t_tfd, "s_rescan_survivors": t_regen, "s_rmsd_prune": t_rmsd,
-        "s_total": wall, "conformers_per_s_scan": S / t_scan, "conformers_per_s_total": S / wall,
+                    "fingerprints taken inside the scan kernel and TFD-pruned (10 deg) without leaving the device, "
+                    "survivors re-scanned, RMSD prune (0.5 A)",
+        "angle_sets": S, "kept_after_scan": 1 + int(np.count_nonzero(rot)), "after_tfd": int(keep.sum()), "after_rmsd": int(rmask.sum()),
+        "first_run": runs[0], "second_run": runs[1],
+        "s_total": wall, "conformers_per_s_total": S / wall,
         "algorithmic_bytes_per_conformer": 2 * A * 24 + T * 4 + 1,
     }))
 
