@@ -70,7 +70,7 @@ int launch_torsion_scan(const double *, int64_t, const int64_t *, int64_t, const
                         const int16_t *, const int16_t *, const int32_t *, const int32_t *,
                         const int64_t *, int64_t, double, int64_t, double *, int64_t *, const int64_t *, int64_t, double *);
 int launch_torsion_fingerprint(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
-int launch_tfd_first_match(const double *, int64_t, int64_t, int64_t, double, int64_t *);
+int launch_tfd_first_match(const double *, int64_t, int64_t, int64_t, double, int64_t *, float *);
 int launch_transpose_pad(const double *, int64_t, int64_t, int64_t, double *);
 int launch_gather_transpose_pad(const double *, const double *, const int64_t *, int64_t, int64_t, int64_t, double *);
 int tfd_ladder_from_first_match(const int64_t *, int64_t, uint8_t *);
@@ -1885,7 +1885,9 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   FC_TRY(dT.reserve((size_t)Q * Npad * sizeof(double)));
   FC_TRY(launch_gather_transpose_pad(dtf.as<double>(), dtf0.as<double>(), didx.as<int64_t>(), M, Q, Npad, dT.as<double>()));
   FC_TRY(dfm.reserve((size_t)N * sizeof(int64_t)));
-  FC_TRY(launch_tfd_first_match(dT.as<double>(), N, Npad, Q, tfd_thresh, dfm.as<int64_t>()));
+  DevBuf dtfF;
+  FC_TRY(dtfF.reserve((size_t)std::min<int64_t>(Q, 8) * Npad * sizeof(float)));
+  FC_TRY(launch_tfd_first_match(dT.as<double>(), N, Npad, Q, tfd_thresh, dfm.as<int64_t>(), dtfF.as<float>()));
   std::vector<int64_t> fm((size_t)N);
   FC_TRY(d2h(fm.data(), dfm.p, (size_t)N * sizeof(int64_t)));
   FC_TRY(sync());
@@ -1980,7 +1982,9 @@ int fc_tfd_first_match(const double *tf, int64_t N, int64_t Q, double thresh, in
   FC_TRY(dT.reserve((size_t)std::max<int64_t>(Q, 1) * Npad * sizeof(double)));
   FC_TRY(launch_transpose_pad(draw.as<double>(), N, Q, Npad, dT.as<double>()));
   FC_TRY(dfm.reserve((size_t)N * sizeof(int64_t)));
-  FC_TRY(launch_tfd_first_match(dT.as<double>(), N, Npad, Q, thresh, dfm.as<int64_t>()));
+  DevBuf dtfF;
+  FC_TRY(dtfF.reserve((size_t)std::max<int64_t>(std::min<int64_t>(Q, 8), 1) * Npad * sizeof(float)));
+  FC_TRY(launch_tfd_first_match(dT.as<double>(), N, Npad, Q, thresh, dfm.as<int64_t>(), dtfF.as<float>()));
   FC_TRY(d2h(first_out, dfm.p, (size_t)N * sizeof(int64_t)));
   return sync();
 }

@@ -534,7 +534,9 @@ k_tfd_simbits(const double *__restrict__ tf, int64_t N, int Q, double thresh, in
 template <int QT>  // QT > 0: fingerprint length known at compile time (column kept in VGPRs)
 __global__ void __launch_bounds__(256)
 k_tfd_first_match(const double *__restrict__ tfT, int64_t N, int64_t Npad, int Qrt, double thresh,
-                  int64_t *__restrict__ first_match) {
+                  int64_t *__restrict__ first_match, const float *__restrict__ tfF, int64_t max_ahead,
+                  unsigned long long *__restrict__ left_count, int64_t *__restrict__ left_rows,
+                  int64_t *__restrict__ left_from) {
   const int Q = QT > 0 ? QT : Qrt;
   extern __shared__ double rows[];              // [64][Q]
   __shared__ long long best[64];
@@ -543,7 +545,8 @@ k_tfd_first_match(const double *__restrict__ tfT, int64_t N, int64_t Npad, int Q
   // pair whose partial sum already reaches the threshold cannot be similar; only pairs below
   // thresh + 0.01 (fp32 error of four terms <= 360: < 1e-4) get the exact fp64 sum in NumPy's order.
   // On a systematic scan one pair in ~10^3 passes, i.e. 19 wavefront-instructions in 20 skip the fp64 sum.
-  constexpr int QF = 4;
+  constexpr int QF = 8;  // (eight angles: in a systematic scan the first ones are EQUAL over long runs of columns,
+                         // with four every column of such a run went on to the fp64 sum)
   __shared__ float rowsF[64][QF];
   const int qf = Q < QF ? Q : QF;
   const float threshF = (float)thresh + 0.01f;
@@ -563,7 +566,12 @@ k_tfd_first_match(const double *__restrict__ tfT, int64_t N, int64_t Npad, int Q
   // with one open row covers 4096 columns per pair of barriers instead of 256.
   __shared__ int open_rows[64];
   int64_t jb = i0 + 1;
-  while (jb < N) {
+  // max_ahead > 0: the workgroup gives up max_ahead columns past its rows; what is still open then goes to
+  // the leftover list (row, first column not looked at) for k_tfd_first_match_rest.  A workgroup that walks
+  // the whole array for a row without a match is one latency-bound chain of ~3 000 windows: at 1.7 M
+  // structures that chain, not the arithmetic, was the kernel's 50 ms.
+  const int64_t j_stop = max_ahead > 0 ? (i0 + 64 + max_ahead < N ? i0 + 64 + max_ahead : N) : N;
+  while (jb < j_stop) {
     if (tid < 64) {  // wave 0: compact the open rows (ballot order = row order)
       const bool is_open = best[tid] == (long long)N;
       const uint64_t m = __ballot(is_open);
@@ -574,33 +582,91 @@ k_tfd_first_match(const double *__restrict__ tfT, int64_t N, int64_t Npad, int Q
     const int R = n_open;
     if (R == 0) break;
     const int cpt = R >= 32 ? 1 : R >= 16 ? 2 : R >= 8 ? 4 : R >= 4 ? 8 : 16;  // columns per thread
+    if (tfF != nullptr) {
+      // four columns per thread at a time, their pre-filter values requested TOGETHER: with one column per
+      // trip of a loop full of branches the loads are issued one latency after the other, and a workgroup
+      // down to its last open row (most of them, most of the time) is nothing but those latencies
+      for (int c0 = 0; c0 < cpt; c0 += 4) {
+        float cf4[4][QF];
+        int64_t j4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          j4[u] = jb + (int64_t)(c0 + u) * 256 + tid;
+          const bool on = c0 + u < cpt && j4[u] < N;
+          const int64_t jl = on ? j4[u] : N - 1;
+#pragma unroll
+          for (int q = 0; q < QF; ++q) cf4[u][q] = q < qf ? tfF[(int64_t)q * Npad + jl] : 0.f;
+          if (!on) j4[u] = -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t j = j4[u];
+          if (j < 0) continue;
+          for (int k = 0; k < R; ++k) {
+            const int r = open_rows[k];
+            const int64_t i = i0 + r;
+            if (j <= i) continue;
+            float part;
+            {
+              const float d = fabsf(rowsF[r][0] - cf4[u][0]);
+              part = fabsf(d - (d > 180.f ? 360.f : 0.f));
+            }
+            if (!(part < threshF)) continue;
+#pragma unroll
+            for (int q = 1; q < QF; ++q)
+              if (q < qf) {
+                const float d = fabsf(rowsF[r][q] - cf4[u][q]);
+                part += fabsf(d - (d > 180.f ? 360.f : 0.f));
+              }
+            if (!(part < threshF)) continue;
+            const double sum = tfd_sum(rows + r * Q, 1, tfT + j, Npad, Q);
+            if (sum < thresh) atomicMin(&best[r], (long long)j);
+          }
+        }
+      }
+    } else
     for (int c = 0; c < cpt; ++c) {
       const int64_t j = jb + (int64_t)c * 256 + tid;
       if (j < N) {
+        // tfF: single-precision copy of the first four angles (16 B per column instead of 8 Q): a workgroup
+        // whose last open row has no match reads every later column, and nearly every workgroup of a
+        // systematic scan has such a row -- the kernel is bound by that traffic, not by its arithmetic;
+        // the fp64 column is read only for the pairs the pre-filter lets through
         double cj[QT > 0 ? QT : 1];
-        if (QT > 0) {
+        if (QT > 0 && tfF == nullptr) {
 #pragma unroll
           for (int q = 0; q < QT; ++q) cj[q] = tfT[(int64_t)q * Npad + j];
         }
         float cf[QF];
 #pragma unroll
-        for (int q = 0; q < QF; ++q) cf[q] = q < qf ? (float)(QT > 0 ? cj[q < (QT > 0 ? QT : 1) ? q : 0] : tfT[(int64_t)q * Npad + j]) : 0.f;
+        for (int q = 0; q < QF; ++q)
+          cf[q] = q < qf ? (tfF != nullptr ? tfF[(int64_t)q * Npad + j]
+                                           : (float)(QT > 0 ? cj[q < (QT > 0 ? QT : 1) ? q : 0] : tfT[(int64_t)q * Npad + j]))
+                         : 0.f;
         for (int k = 0; k < R; ++k) {
           const int r = open_rows[k];
           const int64_t i = i0 + r;
           // a hit in an earlier window is final (the row is no longer in the list); hits inside
           // this window are resolved with atomicMin
           if (j <= i) continue;
-          float part = 0.f;
+          // the deltas are non-negative and fp32 addition is monotone: the partial sum after any prefix
+          // already decides.  In a systematic scan the first angles vary slowest -- whole windows of columns
+          // share them -- so the test on the first angle alone sends most WAVEFRONTS past the rest
+          float part;
+          {
+            const float d = fabsf(rowsF[r][0] - cf[0]);
+            part = fabsf(d - (d > 180.f ? 360.f : 0.f));
+          }
+          if (!(part < threshF)) continue;
 #pragma unroll
-          for (int q = 0; q < QF; ++q)
+          for (int q = 1; q < QF; ++q)
             if (q < qf) {
               const float d = fabsf(rowsF[r][q] - cf[q]);
               part += fabsf(d - (d > 180.f ? 360.f : 0.f));
             }
           if (!(part < threshF)) continue;
-          const double sum = (QT > 0) ? tfd_sum(rows + r * Q, 1, cj, 1, QT)
-                                      : tfd_sum(rows + r * Q, 1, tfT + j, Npad, Q);
+          const double sum = (QT > 0 && tfF == nullptr) ? tfd_sum(rows + r * Q, 1, cj, 1, QT)
+                                                        : tfd_sum(rows + r * Q, 1, tfT + j, Npad, Q);
           if (sum < thresh) atomicMin(&best[r], (long long)j);
         }
       }
@@ -608,7 +674,175 @@ k_tfd_first_match(const double *__restrict__ tfT, int64_t N, int64_t Npad, int Q
     jb += (int64_t)cpt * 256;
     __syncthreads();
   }
-  if (tid < 64 && i0 + tid < N) first_match[i0 + tid] = (best[tid] >= (long long)N) ? -1 : best[tid];
+  if (tid < 64 && i0 + tid < N) {
+    const bool open = best[tid] >= (long long)N;
+    first_match[i0 + tid] = open ? -1 : best[tid];
+    if (open && jb < N) {  // stopped at the look-ahead limit: somebody else scans [jb, N) for this row
+      const unsigned long long slot = atomicAdd(left_count, 1ull);
+      left_rows[slot] = i0 + tid;
+      left_from[slot] = jb;
+    }
+  }
+}
+
+// Bounding box of the first (up to) four angles over every window of 1024 columns: wlo / whi[q * n_win + w].
+__global__ void __launch_bounds__(256)
+k_tfd_window_bounds(const float *__restrict__ tfF, int64_t N, int64_t Npad, int qf, int64_t n_win,
+                    float *__restrict__ wlo, float *__restrict__ whi) {
+  __shared__ float slo[4][4], shi[4][4];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int64_t w = blockIdx.x, j0 = w * 1024;
+  for (int q = 0; q < qf; ++q) {
+    float lo = 1e30f, hi = -1e30f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t j = j0 + (int64_t)u * 256 + tid;
+      if (j < N) {
+        const float v = tfF[(int64_t)q * Npad + j];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, off));
+      hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    if (lane == 0) slo[q][wv] = lo, shi[q][wv] = hi;
+  }
+  __syncthreads();
+  if (tid < qf) {
+    wlo[(int64_t)tid * n_win + w] = fminf(fminf(slo[tid][0], slo[tid][1]), fminf(slo[tid][2], slo[tid][3]));
+    whi[(int64_t)tid * n_win + w] = fmaxf(fmaxf(shi[tid][0], shi[tid][1]), fmaxf(shi[tid][2], shi[tid][3]));
+  }
+}
+
+// The rows k_tfd_first_match gave up on (no match within its look-ahead), 64 of them per workgroup in list order,
+// against ONE chunk of columns: the rectangle (leftover rows) x (all later columns) cut into independent pieces,
+// first match = atomicMin over the pieces.  best[slot]: initialised to ~0, holds the smallest matching column.
+// Most of the rectangle is never looked at: a row takes part in a window of 1024 columns only if the window's
+// bounding box of the first angles comes within the threshold of its own (a lower bound of every column's TFD:
+// the distance of the row's angle to the window's interval, wrap-around included, summed over the angles).  In a
+// systematic scan the first angles vary slowest -- a window holds ONE value of each of the first three -- so a row
+// meets about one window in 6^3.
+template <int QT>
+__global__ void __launch_bounds__(256)
+k_tfd_first_match_rest(const double *__restrict__ tfT, const float *__restrict__ tfF, int64_t N, int64_t Npad, int Qrt,
+                       double thresh, const unsigned long long *__restrict__ left_count,
+                       const int64_t *__restrict__ left_rows, const int64_t *__restrict__ left_from, int64_t chunk,
+                       unsigned long long *__restrict__ best, const float *__restrict__ wlo,
+                       const float *__restrict__ whi, int64_t n_win) {
+  const int Q = QT > 0 ? QT : Qrt;
+  extern __shared__ double rows[];  // [64][Q]
+  constexpr int QF = 8, QB = 4;  // angles of the fp32 pre-filter / of the window boxes
+  __shared__ float rowsF[64][QF];
+  __shared__ long long row_i[64], row_from[64];
+  __shared__ unsigned long long wmask[64];  // per window of the chunk: the rows that take part
+  const int qf = Q < QF ? Q : QF, qb = Q < QB ? Q : QB;
+  const float threshF = (float)thresh + 0.01f;
+  const int tid = threadIdx.x;
+  const unsigned long long n_left = *left_count;
+  const unsigned long long g0 = (unsigned long long)blockIdx.x * 64ull;
+  if (g0 >= n_left) return;  // block-uniform
+  const int64_t c_lo = (int64_t)blockIdx.y * chunk, c_hi = c_lo + chunk < N ? c_lo + chunk : N;
+  __shared__ float blo[QB][64], bhi[QB][64];  // the chunk's window boxes
+  __shared__ long long from_min_s;
+  const int n_w = (int)((c_hi - c_lo + 1023) / 1024);  // <= 64 (chunk = 65536)
+  if (tid < 64) {
+    const bool on = g0 + tid < n_left;
+    row_i[tid] = on ? left_rows[g0 + tid] : -1;
+    const long long from = on ? left_from[g0 + tid] : (long long)N;
+    row_from[tid] = from;
+    wmask[tid] = 0ull;
+    long long fm_ = from;
+    for (int off = 32; off > 0; off >>= 1) {
+      const long long o = __shfl_xor(fm_, off);
+      fm_ = o < fm_ ? o : fm_;
+    }
+    if (tid == 0) from_min_s = fm_;
+  }
+  __syncthreads();
+  if (from_min_s >= (long long)c_hi) return;  // block-uniform: every row of the group starts behind this chunk
+  for (int k = tid; k < 64 * Q; k += 256) {
+    const int r = k / Q, q = k % Q;
+    rows[k] = row_i[r] >= 0 ? tfT[(int64_t)q * Npad + row_i[r]] : 0.0;
+    if (q < QF) rowsF[r][q] = (float)rows[k];
+  }
+  for (int t = tid; t < QB * n_w; t += 256) {
+    const int q = t / n_w, wl = t % n_w;
+    const bool have = q < qb;
+    blo[q][wl] = have ? wlo[(int64_t)q * n_win + (c_lo >> 10) + wl] : 0.f;
+    bhi[q][wl] = have ? whi[(int64_t)q * n_win + (c_lo >> 10) + wl] : 0.f;
+  }
+  __syncthreads();
+  // which rows meet which window: 64 windows x 64 rows, 16 tests per thread
+  for (int t = tid; t < 64 * n_w; t += 256) {
+    const int wl = t >> 6, r = t & 63;
+    const int64_t w = (c_lo >> 10) + wl, w_end = (w + 1) * 1024 < c_hi ? (w + 1) * 1024 : c_hi;
+    bool on = row_from[r] < (long long)w_end;
+    if (on) {
+      float lb = 0.f;
+      for (int q = 0; q < qb; ++q) {
+        const float a = rowsF[r][q], lo = blo[q][wl], hi = bhi[q][wl];
+        const float d0 = fmaxf(fmaxf(lo - a, a - hi), 0.f);
+        const float ap = a + 360.f, am = a - 360.f;
+        const float d1 = fmaxf(fmaxf(lo - ap, ap - hi), 0.f), d2 = fmaxf(fmaxf(lo - am, am - hi), 0.f);
+        lb += fminf(d0, fminf(d1, d2));
+      }
+      on = lb < threshF + 0.01f;  // (+ 0.01: roundings of the wrapped copies, far below it)
+    }
+    if (on) atomicOr(&wmask[wl], 1ull << r);
+  }
+  __syncthreads();
+  for (int wl = 0; wl < n_w; ++wl) {
+    unsigned long long m = wmask[wl];
+    if (m == 0ull) continue;  // block-uniform
+    const int64_t jb = c_lo + (int64_t)wl * 1024;
+    float cf4[4][QF];
+    int64_t j4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      j4[u] = jb + (int64_t)u * 256 + tid;
+      const bool on = j4[u] < c_hi;
+      const int64_t jl = on ? j4[u] : N - 1;
+#pragma unroll
+      for (int q = 0; q < QF; ++q) cf4[u][q] = q < qf ? tfF[(int64_t)q * Npad + jl] : 0.f;
+      if (!on) j4[u] = -1;
+    }
+    while (m) {  // the rows of this window, in row order (uniform loop)
+      const int r = __builtin_ctzll(m);
+      m &= m - 1ull;
+      const long long from = row_from[r];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t j = j4[u];
+        if (j < from) continue;  // (also j < 0: from > row >= 0; already looked at, or not later than the row)
+        float part;
+        {
+          const float d = fabsf(rowsF[r][0] - cf4[u][0]);
+          part = fabsf(d - (d > 180.f ? 360.f : 0.f));
+        }
+        if (!(part < threshF)) continue;
+#pragma unroll
+        for (int q = 1; q < QF; ++q)
+          if (q < qf) {
+            const float d = fabsf(rowsF[r][q] - cf4[u][q]);
+            part += fabsf(d - (d > 180.f ? 360.f : 0.f));
+          }
+        if (!(part < threshF)) continue;
+        const double sum = tfd_sum(rows + r * Q, 1, tfT + j, Npad, Q);
+        if (sum < thresh) atomicMin(&best[g0 + r], (unsigned long long)j);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_tfd_first_match_merge(const unsigned long long *__restrict__ left_count, const int64_t *__restrict__ left_rows,
+                        const unsigned long long *__restrict__ best, int64_t *__restrict__ first_match) {
+  const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  if (k >= *left_count) return;
+  const unsigned long long b = best[k];
+  first_match[left_rows[k]] = b == ~0ull ? -1 : (int64_t)b;
 }
 
 // ---------------------------------------------------------------------------
@@ -819,25 +1053,99 @@ int launch_gather_transpose_pad(const double *in_dev, const double *first_dev, c
   return check_launch("k_gather_transpose_pad");
 }
 
+// fp32 copy of the first (up to) four fingerprint-major rows for the pre-filter of k_tfd_first_match
+__global__ void __launch_bounds__(256)
+k_tfd_prefilter_copy(const double *__restrict__ tfT, int64_t n, float *__restrict__ tfF) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) tfF[i] = (float)tfT[i];
+}
+
+// tfF_scratch: min(Q, 8) * Npad floats owned by the caller until the stream has run the kernel (nullptr, or
+// FC_TFD_F32_COPY=0: the kernel reads the fp64 columns for its pre-filter as well)
 int launch_tfd_first_match(const double *tfT_dev, int64_t N, int64_t Npad, int64_t Q, double thresh,
-                           int64_t *fm_dev) {
+                           int64_t *fm_dev, float *tfF_scratch) {
   if (N == 0) return FC_OK;
   const dim3 grid((unsigned)ceil_div(N, 64)), block(256);
   const size_t lds = (size_t)64 * Q * sizeof(double);
+  // (the conversion rounds each angle to fp32 exactly as the kernel's own (float) of the fp64 value does)
+  const float *tfF_dev = nullptr;
+  static const bool use_copy = [] {
+    const char *v = getenv("FC_TFD_F32_COPY");
+    return !(v && v[0] == '0');
+  }();
+  if (use_copy && tfF_scratch != nullptr) {
+    const int64_t n = std::min<int64_t>(Q, 8) * Npad;
+    hipLaunchKernelGGL(k_tfd_prefilter_copy, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, tfT_dev, n,
+                       tfF_scratch);
+    FC_TRY(check_launch("k_tfd_prefilter_copy"));
+    tfF_dev = tfF_scratch;
+  }
+  // two phases for long arrays: bounded look-ahead per row block, then the rows still open against column
+  // chunks (FC_TFD_LOOKAHEAD: columns, 0 = one phase; needs the fp32 copy)
+  // (measured at 1.7 M structures, whole call incl. the upload: one phase 59 ms; look-ahead 4 096: 11.7 ms,
+  // 32 768: 15.8, 131 072: 16.3)
+  int64_t lookahead_env = 4096;
+  bool forced = false;
+  if (const char *v = getenv("FC_TFD_LOOKAHEAD")) lookahead_env = (int64_t)std::strtoll(v, nullptr, 10), forced = true;  // (per call: test knob)
+  const bool two_phase = tfF_dev != nullptr && lookahead_env > 0 && (forced ? N > 8 * lookahead_env : N >= 65536);
+  const int64_t max_ahead = two_phase ? lookahead_env : 0;
+  DevBuf left;  // [count | rows x N | from x N | best x N]: released to the pool at return, reused in stream order
+  unsigned long long *left_count = nullptr, *best_dev = nullptr;
+  int64_t *left_rows = nullptr, *left_from = nullptr;
+  if (two_phase) {
+    FC_TRY(left.reserve((size_t)(3 * N + 8) * sizeof(int64_t) + (size_t)(8 * ceil_div(N, 1024) + 16) * sizeof(float)));
+    left_count = left.as<unsigned long long>();
+    left_rows = reinterpret_cast<int64_t *>(left_count + 8);
+    left_from = left_rows + N;
+    best_dev = reinterpret_cast<unsigned long long *>(left_from + N);
+    FC_HIP_TRY(hipMemsetAsync(left_count, 0, 8 * sizeof(unsigned long long), ctx().stream));
+  }
 #define FC_FM(QT)                                                                                  \
   case QT:                                                                                         \
     hipLaunchKernelGGL(k_tfd_first_match<QT>, grid, block, lds, ctx().stream, tfT_dev, N, Npad,    \
-                       (int)Q, thresh, fm_dev);                                                    \
+                       (int)Q, thresh, fm_dev, tfF_dev, max_ahead, left_count, left_rows, left_from); \
     break;
   switch (Q) {
     FC_FM(1) FC_FM(2) FC_FM(3) FC_FM(4) FC_FM(5) FC_FM(6) FC_FM(7) FC_FM(8) FC_FM(9) FC_FM(10)
     FC_FM(11) FC_FM(12) FC_FM(13) FC_FM(14) FC_FM(15) FC_FM(16)
     default:
       hipLaunchKernelGGL(k_tfd_first_match<0>, grid, block, lds, ctx().stream, tfT_dev, N, Npad, (int)Q,
-                         thresh, fm_dev);
+                         thresh, fm_dev, tfF_dev, max_ahead, left_count, left_rows, left_from);
   }
 #undef FC_FM
-  return check_launch("k_tfd_first_match");
+  FC_TRY(check_launch("k_tfd_first_match"));
+  if (!two_phase) return FC_OK;
+  unsigned long long n_left = 0;
+  FC_TRY(d2h(&n_left, left_count, sizeof n_left));
+  FC_TRY(sync());
+  if (getenv("FC_DEBUG")) fprintf(stderr, "[fc] tfd first match: %llu of %lld rows open after a look-ahead of %lld columns\n", n_left, (long long)N, (long long)max_ahead);
+  if (n_left == 0) return FC_OK;
+  FC_HIP_TRY(hipMemsetAsync(best_dev, 0xff, (size_t)n_left * sizeof(unsigned long long), ctx().stream));
+  const int64_t chunk = 65536;
+  const dim3 rgrid((unsigned)ceil_div((int64_t)n_left, 64), (unsigned)ceil_div(N, chunk));
+  // bounding boxes of the pre-filter angles per window of 1024 columns (behind `best` in the same block)
+  const int64_t n_win = ceil_div(N, 1024);
+  const int qf4 = (int)std::min<int64_t>(Q, 4);
+  float *wlo = reinterpret_cast<float *>(best_dev + N), *whi = wlo + 4 * n_win;
+  hipLaunchKernelGGL(k_tfd_window_bounds, dim3((unsigned)n_win), block, 0, ctx().stream, tfF_dev, N, Npad, qf4, n_win, wlo, whi);
+  FC_TRY(check_launch("k_tfd_window_bounds"));
+#define FC_FMR(QT)                                                                                          \
+  case QT:                                                                                                  \
+    hipLaunchKernelGGL(k_tfd_first_match_rest<QT>, rgrid, block, lds, ctx().stream, tfT_dev, tfF_dev, N, Npad, \
+                       (int)Q, thresh, left_count, left_rows, left_from, chunk, best_dev, wlo, whi, n_win); \
+    break;
+  switch (Q) {
+    FC_FMR(1) FC_FMR(2) FC_FMR(3) FC_FMR(4) FC_FMR(5) FC_FMR(6) FC_FMR(7) FC_FMR(8) FC_FMR(9) FC_FMR(10)
+    FC_FMR(11) FC_FMR(12) FC_FMR(13) FC_FMR(14) FC_FMR(15) FC_FMR(16)
+    default:
+      hipLaunchKernelGGL(k_tfd_first_match_rest<0>, rgrid, block, lds, ctx().stream, tfT_dev, tfF_dev, N, Npad, (int)Q,
+                         thresh, left_count, left_rows, left_from, chunk, best_dev, wlo, whi, n_win);
+  }
+#undef FC_FMR
+  FC_TRY(check_launch("k_tfd_first_match_rest"));
+  hipLaunchKernelGGL(k_tfd_first_match_merge, dim3((unsigned)ceil_div((int64_t)n_left, 256)), block, 0, ctx().stream, left_count,
+                     left_rows, best_dev, fm_dev);
+  return check_launch("k_tfd_first_match_merge");
 }
 
 int launch_tfd_simbits(const double *tf_dev, int64_t N, int64_t Q, double thresh, int64_t row_begin,

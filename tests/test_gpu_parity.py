@@ -473,6 +473,36 @@ def test_scan_with_fingerprints_equals_two_passes(fc):
     assert np.abs(tf - o.get_tf_mat(o.torsion_scan(base, tors, masks, angles)[0], quads)).max() < 1e-9
 
 
+def test_tfd_first_match_two_phases(fc, monkeypatch):
+    """fc_tfd_first_match with a bounded look-ahead per row block and the rows still open handed to the
+    column-chunked kernel (the form long arrays take; forced here with a look-ahead of 64 ... 640 columns) ==
+    the one-phase kernel == a NumPy first-match, on fingerprints with many unmatched rows and far matches"""
+    from firecode_amd import _lib as L
+
+    rng = np.random.default_rng(61)
+    n, q = 6000, 5
+    centres = rng.uniform(-180, 180, size=(700, q))
+    tf = centres[rng.integers(0, len(centres), n)] + rng.normal(scale=1.5, size=(n, q))
+    tf[rng.integers(0, n, 300)] = rng.uniform(-180, 180, size=(300, q))  # rows without any partner
+    tf = (tf + 180) % 360 - 180
+    ref = np.full(n, -1, dtype=np.int64)
+    for i in range(n - 1):
+        d = np.abs(tf[i + 1:] - tf[i])
+        d = np.abs(d - (d > 180) * 360)
+        hit = np.flatnonzero(d.sum(axis=1) < 10)
+        if len(hit):
+            ref[i] = i + 1 + hit[0]
+    assert (ref < 0).sum() > 100 and ((ref - np.arange(n))[ref >= 0] > 1000).sum() > 50
+    for look in ("0", "64", "640", None):
+        if look is None:
+            monkeypatch.delenv("FC_TFD_LOOKAHEAD", raising=False)
+        else:
+            monkeypatch.setenv("FC_TFD_LOOKAHEAD", look)
+        fm = np.zeros(n, dtype=np.int64)
+        L.call("fc_tfd_first_match", L.pf(np.ascontiguousarray(tf)), n, q, 10.0, L.pi(fm))
+        assert np.array_equal(fm, ref), look
+
+
 def test_scan_tfd_fused_equals_scan_then_prune(fc):
     """fc_torsion_scan_tfd (fingerprints resident on the device between the scan and the TFD prune) == the two
     calls with the fingerprints through the host, and == the oracle's literal loop on the same rows"""

@@ -28,3 +28,8 @@ for rep in range(2):
     L.call("fc_tfd_ladder_from_first_match", L.pi(fm), N, L.pb(mask))
     t4 = time.perf_counter()
     print(json.dumps({"scan": t1 - t0, "host_concat": t2 - t1, "first_match_call": t3 - t2, "ladder_call": t4 - t3, "kept": int(mask.sum()), "matched": int((fm >= 0).sum())}))
+d = (fm - np.arange(N))[fm >= 0]
+print(json.dumps({"first_match_distance_quantiles": {str(q): int(np.quantile(d, q)) for q in (0.1, 0.5, 0.9, 0.99, 0.999, 1.0)},
+                  "mean_distance": float(d.mean()), "sum_distance": float(d.sum()), "unmatched": int((fm < 0).sum()),
+                  "unmatched_sum_remaining": float((N - np.flatnonzero(fm < 0)).sum()),
+                  "per_block_max_distance_sum": float(np.where(fm >= 0, fm - np.arange(N), N - np.arange(N))[: (N // 64) * 64].reshape(-1, 64).max(axis=1).sum())}))
