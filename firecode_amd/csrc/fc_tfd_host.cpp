@@ -136,6 +136,91 @@ struct PySetEmu {
   }
 };
 
+// The same set for 2-tuples given by index, with 4-byte slots: slot = index of the tuple (-1 = empty), its hash
+// read from the caller's array when a probe sequence or a rebuild needs it.  The iteration order of a set of 10^6
+// tuples is a walk through a table of 2^22 slots at random: 16 MB of table stay in the last-level cache where the
+// 64 MB of 16-byte entries did not.  UNIQUE: the caller guarantees distinct tuples (first-match edges: one per
+// row), so an occupied slot is always just a collision -- CPython would compare hash and contents and move on.
+struct PyTupleSetEmu {
+  std::vector<int32_t> table, spare;
+  size_t mask = 7, fill = 0, used_n = 0;
+  const int64_t *hashes = nullptr;
+  PyTupleSetEmu() : table(8, -1) {}
+  void reset(const int64_t *h) {
+    table.assign(8, -1);
+    mask = 7;
+    fill = used_n = 0;
+    hashes = h;
+  }
+  void prefetch(int64_t hash) const { __builtin_prefetch(&table[(size_t)hash & mask], 1, 0); }
+  static void insert_clean(std::vector<int32_t> &t, size_t mask, int32_t key, int64_t hash) {
+    size_t perturb = (size_t)hash;
+    size_t i = (size_t)hash & mask;
+    while (true) {
+      size_t e = i;
+      if (t[e] < 0) {
+        t[e] = key;
+        return;
+      }
+      if (i + 9 <= mask) {
+        for (int j = 0; j < 9; ++j) {
+          ++e;
+          if (t[e] < 0) {
+            t[e] = key;
+            return;
+          }
+        }
+      }
+      perturb >>= 5;
+      i = (i * 5 + 1 + perturb) & mask;
+    }
+  }
+  void resize(size_t minused) {
+    size_t newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    spare.assign(newsize, -1);
+    const size_t newmask = newsize - 1;
+    constexpr size_t kAhead = 16;
+    for (size_t s = 0; s <= mask; ++s) {
+      if (s + kAhead <= mask && table[s + kAhead] >= 0)
+        __builtin_prefetch(&spare[(size_t)hashes[table[s + kAhead]] & newmask], 1, 0);
+      if (table[s] >= 0) insert_clean(spare, newmask, table[s], hashes[table[s]]);
+    }
+    table.swap(spare);
+    mask = newmask;
+    fill = used_n;
+  }
+  // eq(existing_index, new_index): contents equal?  (never called when UNIQUE)
+  template <bool UNIQUE, class Eq>
+  bool add(int32_t key, Eq eq) {
+    const int64_t hash = hashes[key];
+    size_t perturb = (size_t)hash;
+    size_t i = (size_t)hash & mask;
+    while (true) {
+      size_t e = i;
+      int probes = (i + 9 <= mask) ? 9 : 0;
+      do {
+        if (table[e] < 0) {
+          table[e] = key;
+          ++fill;
+          ++used_n;
+          if (fill * 5 >= mask * 3) resize(used_n > 50000 ? used_n * 2 : used_n * 4);
+          return true;
+        }
+        if (!UNIQUE && hashes[table[e]] == hash && eq((int64_t)table[e], (int64_t)key)) return false;
+        ++e;
+      } while (probes--);
+      perturb >>= 5;
+      i = (i * 5 + 1 + perturb) & mask;
+    }
+  }
+  template <class F>
+  void for_each(F f) const {
+    for (size_t s = 0; s <= mask; ++s)
+      if (table[s] >= 0) f((int64_t)table[s]);
+  }
+};
+
 static inline bool int_eq(int64_t a, int64_t b) { return a == b; }
 
 // hash((a, b)) for non-negative Python ints a, b < 2^61 - 1  (hash(n) == n)
@@ -162,12 +247,21 @@ void pyset_order_ints(const int64_t *keys, int64_t n, std::vector<int64_t> &out)
 
 // iteration order (as indices into the input) of a set of 2-tuples inserted in order
 void pyset_order_pairs(const int64_t *pairs, int64_t n, std::vector<int64_t> &out) {
-  PySetEmu s;
   auto eq = [&](int64_t x, int64_t y) {
     return pairs[x * 2] == pairs[y * 2] && pairs[x * 2 + 1] == pairs[y * 2 + 1];
   };
-  for (int64_t k = 0; k < n; ++k) s.add(k, py_tuple2_hash(pairs[k * 2], pairs[k * 2 + 1]), eq);
   out.clear();
+  if (n < (int64_t)1 << 31) {  // the 4-byte-slot form the chunk graphs use (here with the equality test)
+    std::vector<int64_t> hashes((size_t)n);
+    for (int64_t k = 0; k < n; ++k) hashes[(size_t)k] = py_tuple2_hash(pairs[k * 2], pairs[k * 2 + 1]);
+    PyTupleSetEmu s;
+    s.reset(hashes.data());
+    for (int64_t k = 0; k < n; ++k) s.add<false>((int32_t)k, eq);
+    s.for_each([&](int64_t key) { out.push_back(key); });
+    return;
+  }
+  PySetEmu s;
+  for (int64_t k = 0; k < n; ++k) s.add(k, py_tuple2_hash(pairs[k * 2], pairs[k * 2 + 1]), eq);
   s.for_each([&](int64_t key) { out.push_back(key); });
 }
 
@@ -179,7 +273,8 @@ static int64_t g_comp_par_min = 100000;
 // ---- one chunk: matches (i_rel ascending) -> relative indices to reject -------
 // Scratch that survives across the ~10^5 chunks of a fine ladder level.
 struct ChunkScratch {
-  PySetEmu edge_set, comp, view;
+  PyTupleSetEmu edge_set;
+  PySetEmu comp, view;
   std::vector<int64_t> order, nodes, members, level, next, adj_head, adj_next, adj_to, adj_tail, hashes;
   std::vector<int64_t> pos_of;     // relative index -> position in `nodes` (valid when stamp matches)
   std::vector<int64_t> stamp;
@@ -197,18 +292,16 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
   const int64_t m = (int64_t)edges.size() / 2;
   if (m == 0) return;
   // (1) Graph(matches): edges arrive in the iteration order of the set of tuples
-  w.edge_set.reset();
   {
     const int64_t *pairs = edges.data();
-    auto eq = [&](int64_t x, int64_t y) {
-      return pairs[x * 2] == pairs[y * 2] && pairs[x * 2 + 1] == pairs[y * 2 + 1];
-    };
+    auto eq = [&](int64_t, int64_t) { return false; };  // the edges of a chunk are distinct: (i, first_match[i]), one per i
     constexpr int64_t kAhead = 12;
     w.hashes.resize((size_t)m);
     for (int64_t k = 0; k < m; ++k) w.hashes[(size_t)k] = py_tuple2_hash(pairs[k * 2], pairs[k * 2 + 1]);
+    w.edge_set.reset(w.hashes.data());
     for (int64_t k = 0; k < m; ++k) {
       if (k + kAhead < m) w.edge_set.prefetch(w.hashes[(size_t)(k + kAhead)]);
-      w.edge_set.add(k, w.hashes[(size_t)k], eq);
+      w.edge_set.add<true>((int32_t)k, eq);
     }
     w.order.clear();
     w.edge_set.for_each([&](int64_t key) { w.order.push_back(key); });
