@@ -276,8 +276,10 @@ struct ChunkScratch {
   PyTupleSetEmu edge_set;
   PySetEmu comp, view;
   std::vector<int64_t> order, nodes, members, level, next, adj_head, adj_next, adj_to, adj_tail, hashes;
-  std::vector<int64_t> pos_of;     // relative index -> position in `nodes` (valid when stamp matches)
-  std::vector<int64_t> stamp;
+  struct Slot {                    // relative index -> position in `nodes` (valid when the stamp matches): one 8-byte
+    int32_t stamp = -1, pos = 0;   // slot per structure, i.e. one cache line per look-up instead of two
+  };
+  std::vector<Slot> slot;
   std::vector<char> seen;
   int64_t generation = 0;
 };
@@ -307,17 +309,19 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
     w.edge_set.for_each([&](int64_t key) { w.order.push_back(key); });
   }
   lap("edge set");
-  if ((int64_t)w.pos_of.size() < chunk_len) {
-    w.pos_of.resize((size_t)chunk_len);
-    w.stamp.resize((size_t)chunk_len, -1);
+  if ((int64_t)w.slot.size() < chunk_len) w.slot.resize((size_t)chunk_len);
+  if (w.generation >= 0x7ffffff0) {  // stamps are 32 bits: start over (once per 2*10^9 chunks of one scratch)
+    for (auto &sl : w.slot) sl.stamp = -1;
+    w.generation = 0;
   }
-  const int64_t gen = ++w.generation;
+  const int32_t gen = (int32_t)++w.generation;
   w.nodes.clear();
   auto node_of = [&](int64_t v) {
-    if (w.stamp[(size_t)v] == gen) return w.pos_of[(size_t)v];
+    ChunkScratch::Slot &sl = w.slot[(size_t)v];
+    if (sl.stamp == gen) return (int64_t)sl.pos;
     const int64_t p = (int64_t)w.nodes.size();
-    w.stamp[(size_t)v] = gen;
-    w.pos_of[(size_t)v] = p;
+    sl.stamp = gen;
+    sl.pos = (int32_t)p;
     w.nodes.push_back(v);
     return p;
   };
@@ -330,10 +334,8 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
     if (q + 8 < n_ord) {
       const int64_t e8 = w.order[(size_t)(q + 8)];
       const int64_t u8 = edges[(size_t)e8 * 2], v8 = edges[(size_t)e8 * 2 + 1];
-      __builtin_prefetch(&w.stamp[(size_t)u8], 1, 0);
-      __builtin_prefetch(&w.pos_of[(size_t)u8], 1, 0);
-      __builtin_prefetch(&w.stamp[(size_t)v8], 1, 0);
-      __builtin_prefetch(&w.pos_of[(size_t)v8], 1, 0);
+      __builtin_prefetch(&w.slot[(size_t)u8], 1, 0);
+      __builtin_prefetch(&w.slot[(size_t)v8], 1, 0);
     }
     const int64_t e = w.order[(size_t)q];
     w.adj_to[(size_t)q * 2] = node_of(edges[e * 2]);
