@@ -146,3 +146,21 @@ def test_h2_screen_badly_scaled_and_degenerate_inputs(fc):
     assert np.array_equal(res[64], res[0])
     if 16 in res:
         assert np.array_equal(res[64], res[16])
+
+
+@pytest.mark.parametrize("a", [1, 2, 3, 5, 31, 32, 33, 63, 64, 65, 96, 97, 127, 128])
+def test_prune_masks_over_ragged_sizes_and_atom_counts(fc, a):
+    """prune_by_rmsd (default screen: split-half up to 128 atoms) against the oracle for conformer counts around
+    the tile edges (1 ... 193) and atom counts around the 32-atom k-steps"""
+    from oracle import cpu_ref as o
+
+    rng = np.random.default_rng(1000 + a)
+    atoms = np.array(["C"] * a)
+    for n in (1, 2, 15, 16, 17, 63, 64, 65, 127, 129, 193):
+        k = max(1, n // 3)
+        base = rng.normal(scale=2.0, size=(k, a, 3))
+        X = base[rng.integers(0, k, n)] + rng.normal(scale=0.02, size=(n, a, 3))
+        thr = 0.3
+        _, m = fc.pruner.prune_by_rmsd(X, atoms, thr)
+        _, ref = o.prune_by_rmsd(X, atoms, thr)
+        assert np.array_equal(m, ref), (a, n)
