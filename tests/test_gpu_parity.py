@@ -473,14 +473,15 @@ def test_scan_with_fingerprints_equals_two_passes(fc):
     assert np.abs(tf - o.get_tf_mat(o.torsion_scan(base, tors, masks, angles)[0], quads)).max() < 1e-9
 
 
-def test_tfd_first_match_two_phases(fc, monkeypatch):
+@pytest.mark.parametrize("q", [2, 5, 11])
+def test_tfd_first_match_two_phases(fc, monkeypatch, q):
     """fc_tfd_first_match with a bounded look-ahead per row block and the rows still open handed to the
     column-chunked kernel (the form long arrays take; forced here with a look-ahead of 64 ... 640 columns) ==
     the one-phase kernel == a NumPy first-match, on fingerprints with many unmatched rows and far matches"""
     from firecode_amd import _lib as L
 
-    rng = np.random.default_rng(61)
-    n, q = 6000, 5
+    rng = np.random.default_rng(61 + q)
+    n = 6000
     centres = rng.uniform(-180, 180, size=(700, q))
     tf = centres[rng.integers(0, len(centres), n)] + rng.normal(scale=1.5, size=(n, q))
     tf[rng.integers(0, n, 300)] = rng.uniform(-180, 180, size=(300, q))  # rows without any partner
@@ -493,6 +494,8 @@ def test_tfd_first_match_two_phases(fc, monkeypatch):
         if len(hit):
             ref[i] = i + 1 + hit[0]
     assert (ref < 0).sum() > 100 and ((ref - np.arange(n))[ref >= 0] > 1000).sum() > 50
+    # angles at the wrap-around (+-180) as well: the window boxes and the deltas have to agree there
+    assert (np.abs(tf) > 175).any()
     for look in ("0", "64", "640", None):
         if look is None:
             monkeypatch.delenv("FC_TFD_LOOKAHEAD", raising=False)
