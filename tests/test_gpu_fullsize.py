@@ -2,6 +2,8 @@
 size-independent properties and random samples recomputed by the oracle
 (the oracle cannot run these sizes whole)."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -102,6 +104,20 @@ def test_cfg3_full_scan_samples_and_tfd(fc):
     assert np.abs(tf[pick] - o.get_tf_mat(new[pick], torsions)).max() < 1e-9
     mask = fc.torsion_module.prune_tfd_from_tf_mat(tf, 10)
     assert 0 < mask.sum() < len(mask)
+    # first match at this size: bounded look-ahead + column chunks with window boxes (the default for long arrays)
+    # == the one-phase kernel
+    from firecode_amd import _lib as L
+
+    fms = {}
+    for look in ("0", None):
+        if look is None:
+            os.environ.pop("FC_TFD_LOOKAHEAD", None)
+        else:
+            os.environ["FC_TFD_LOOKAHEAD"] = look
+        fms[look] = np.zeros(len(tf), dtype=np.int64)
+        L.call("fc_tfd_first_match", L.pf(np.ascontiguousarray(tf)), len(tf), tf.shape[1], 10.0, L.pi(fms[look]))
+    os.environ.pop("FC_TFD_LOOKAHEAD", None)
+    assert np.array_equal(fms["0"], fms[None]) and (fms[None] < 0).sum() > 1000
     # the fused call of the csearch driver (fingerprints stay on the device) gives the same mask on the same rows
     rot_f, keep_f = fc.torsion_module.torsion_scan_tfd(base, torsions, masks, angles, torsions, thresh=1.5, tfd_thresh=10)
     assert np.array_equal(rot_f, rot)
