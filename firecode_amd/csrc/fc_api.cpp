@@ -8,6 +8,7 @@
 
 #include <map>
 #include <mutex>
+#include <thread>
 #include "fc_common.h"
 #include "fc_kabsch_math.h"
 
@@ -565,6 +566,56 @@ static int ensemble_twin(fc_ensemble *ens, fc_ensemble **out) {
   }
   *out = ens->twin;
   return FC_OK;
+}
+
+// rows of np.stack(np.meshgrid(*arrays), -1).reshape(-1, T) (firecode/utils.py:219-221): with the default
+// 'xy' indexing array #2 varies slowest, then #1, then #3 ... #T (fastest).  Written row by row, once, on
+// host threads: the NumPy expression makes T strided passes over the whole output (1.0-1.3 s for the
+// 1 679 616 x 8 grid of cfg3 -- five times the GPU pipeline it feeds).
+template <class V>
+static void cartesian_rows(const V *values, const int64_t *counts, int64_t T, V *out) {
+  std::vector<int64_t> first((size_t)T, 0);  // offset of array t in `values`
+  for (int64_t t = 1; t < T; ++t) first[(size_t)t] = first[(size_t)t - 1] + counts[t - 1];
+  // digit order, slowest first: 1, 0, 2, 3, ... (T == 1: just 0)
+  std::vector<int64_t> ord;
+  if (T >= 2) ord = {1, 0};
+  else ord = {0};
+  for (int64_t t = 2; t < T; ++t) ord.push_back(t);
+  int64_t rows = 1;
+  for (int64_t t = 0; t < T; ++t) rows *= counts[t];
+  if (rows == 0) return;
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 1;
+  const unsigned nthreads = (unsigned)std::min<int64_t>(std::min<unsigned>(hw, 16u), std::max<int64_t>(1, rows / 65536));
+  auto fill = [&](int64_t r0, int64_t r1) {
+    std::vector<int64_t> digit((size_t)T, 0);
+    int64_t rem = r0;
+    for (int64_t p = T - 1; p >= 0; --p) {  // mixed-radix digits of r0 in the order `ord`
+      const int64_t t = ord[(size_t)p];
+      digit[(size_t)t] = rem % counts[t];
+      rem /= counts[t];
+    }
+    for (int64_t r = r0; r < r1; ++r) {
+      V *row = out + r * T;
+      for (int64_t t = 0; t < T; ++t) row[t] = values[first[(size_t)t] + digit[(size_t)t]];
+      for (int64_t p = T - 1; p >= 0; --p) {  // + 1
+        const int64_t t = ord[(size_t)p];
+        if (++digit[(size_t)t] < counts[t]) break;
+        digit[(size_t)t] = 0;
+      }
+    }
+  };
+  if (nthreads <= 1) {
+    fill(0, rows);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const int64_t per = (rows + nthreads - 1) / nthreads;
+  for (unsigned k = 0; k < nthreads; ++k) {
+    const int64_t r0 = (int64_t)k * per, r1 = std::min<int64_t>(rows, r0 + per);
+    if (r0 < r1) pool.emplace_back(fill, r0, r1);
+  }
+  for (auto &th : pool) th.join();
 }
 
 }  // namespace fc
@@ -2034,6 +2085,36 @@ int fc_debug_pyset_order_pairs(const int64_t *pairs, int64_t n, int64_t *order_o
   pyset_order_pairs(pairs, n, o);
   for (size_t k = 0; k < o.size(); ++k) order_out[k] = o[k];
   *n_out = (int64_t)o.size();
+  return FC_OK;
+}
+
+int fc_cartesian_product_i64(const int64_t *values, const int64_t *counts, int64_t T, int64_t *out) {
+  FC_REQUIRE(T >= 1 && counts != nullptr, "at least one array");
+  int64_t rows = 1, total = 0;
+  for (int64_t t = 0; t < T; ++t) {
+    FC_REQUIRE(counts[t] >= 0, "negative length");
+    FC_REQUIRE(counts[t] == 0 || rows <= (int64_t)1 << 40, "product of the lengths too large");
+    rows *= counts[t];
+    total += counts[t];
+  }
+  if (rows == 0) return FC_OK;
+  FC_REQUIRE(values != nullptr && out != nullptr && total > 0, "NULL pointer argument");
+  cartesian_rows<int64_t>(values, counts, T, out);
+  return FC_OK;
+}
+
+int fc_cartesian_product_f64(const double *values, const int64_t *counts, int64_t T, double *out) {
+  FC_REQUIRE(T >= 1 && counts != nullptr, "at least one array");
+  int64_t rows = 1, total = 0;
+  for (int64_t t = 0; t < T; ++t) {
+    FC_REQUIRE(counts[t] >= 0, "negative length");
+    FC_REQUIRE(counts[t] == 0 || rows <= (int64_t)1 << 40, "product of the lengths too large");
+    rows *= counts[t];
+    total += counts[t];
+  }
+  if (rows == 0) return FC_OK;
+  FC_REQUIRE(values != nullptr && out != nullptr && total > 0, "NULL pointer argument");
+  cartesian_rows<double>(values, counts, T, out);
   return FC_OK;
 }
 

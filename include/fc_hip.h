@@ -456,6 +456,13 @@ int fc_debug_pyset_order_pairs(const int64_t *pairs, int64_t n, int64_t *order_o
 int fc_xyz_write(const char *path, const char *const *atoms, int64_t A, const double *coords,
                  int64_t N, const char *label, int mode);
 int fc_xyz_scan(const char *path, int64_t *N_out, int64_t *A_out);
+/* ---- cartesian_product (firecode/utils.py:219-221; callers torsion_module.py:484, 822) -------------------
+ * Rows of np.stack(np.meshgrid(*arrays), -1).reshape(-1, T): `values` = the T arrays one after the other
+ * (counts[t] entries each), out = (prod counts) x T, array #2 varying slowest, then #1, then #3 ... #T.
+ * Host code (threads), no device needed: the angle grid of a conformational search (1 679 616 x 8 at cfg3)
+ * is an INPUT of the scan kernels and costs NumPy 1 s.  FC_E_INVALID: T < 1, negative length. */
+int fc_cartesian_product_i64(const int64_t *values, const int64_t *counts, int64_t T, int64_t *out);
+int fc_cartesian_product_f64(const double *values, const int64_t *counts, int64_t T, double *out);
 int fc_xyz_read(const char *path, int64_t N, int64_t A, char *atoms_out, double *coords_out);
 
 /* ---- many ensembles in flight -------------------------------------------

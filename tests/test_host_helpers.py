@@ -106,3 +106,35 @@ def test_most_diverse_conformers_is_the_reference_draw():
     np.random.seed(99)
     out = most_diverse_conformers(5, S)
     assert all(np.array_equal(a, S[i]) for a, i in zip(out, idx))
+
+
+def test_cartesian_product_native_equals_numpy(golden):
+    """firecode_amd.utils.cartesian_product: integer and floating grids are written by the library's host code
+    (fc_cartesian_product_*), everything else by the reference's NumPy expression -- same rows, order, shape and
+    dtype as np.stack(np.meshgrid(*arrays), -1).reshape(-1, T) either way; golden vectors of the reference too"""
+    from firecode_amd.utils import cartesian_product
+
+    def ref(*arrays):
+        a = [np.asarray(x) for x in arrays]
+        return np.stack(np.meshgrid(*a), -1).reshape(-1, len(a))
+
+    assert np.array_equal(cartesian_product(range(3), range(2)), golden["cart_3_2"])
+    assert np.array_equal(cartesian_product((0, 180), (0, 120, 240), (0, 90, 180, 270), (0, 60, 120, 180, 240, 300)),
+                          golden["cart_angles"])
+    assert np.array_equal(cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 4), golden["cart_6x4"])
+    rng = np.random.default_rng(4)
+    cases = [
+        [(0, 60, 120, 180, 240, 300)] * 6,                                   # 46 656 x 6, the library's path
+        [np.arange(5000)], [np.arange(300), np.arange(50)],                   # one and two arrays
+        [np.linspace(0, 1, 70), np.arange(90), (1.5, 2.5, 3.5)],              # mixed -> float64
+        [np.arange(10, dtype=np.int32), np.arange(1000, dtype=np.int16), (True, False)],  # -> int32
+        [np.arange(70, dtype=np.uint8), np.arange(90, dtype=np.float32)],     # -> float32
+        [np.arange(100), np.array([], dtype=np.int64)],                       # an empty factor
+        [np.arange(6).reshape(2, 3), np.arange(2000)],                        # N-D input is flattened
+        [rng.integers(-5, 5, 17), rng.integers(0, 9, 23), rng.integers(0, 3, 19)],
+        [np.array(["a", "b"]), np.array(["x", "y", "z"])],                    # strings: NumPy path
+        [np.arange(3000, dtype=np.uint64), np.arange(3)],                     # uint64: NumPy path (no int64 detour)
+    ]
+    for arrays in cases:
+        mine, want = cartesian_product(*arrays), ref(*arrays)
+        assert mine.shape == want.shape and mine.dtype == want.dtype and np.array_equal(mine, want)

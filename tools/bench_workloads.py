@@ -59,12 +59,13 @@ def csearch():
     masks = np.zeros((T, A), dtype=bool)
     for t, c in enumerate(centres):
         masks[t, c + 2:] = True
-    angles = fc.utils.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * T)
-    S = len(angles)
+    S = 6 ** T
     atoms = np.array(["C"] * A)
     runs = []
     for run in range(2):  # the first run pays the one-time costs (device allocations, first touch of the host buffers)
         t0 = time.perf_counter()
+        angles = fc.utils.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * T)  # the grid is part of the search (:822)
+        t_grid = time.perf_counter() - t0
         # scan with the fingerprints taken inside the kernel + TFD prune of [base] + [rotated conformers]; the
         # fingerprints stay on the device between the two (fc_torsion_scan_tfd, what clustered_csearch calls)
         rot, keep = fc.torsion_module.torsion_scan_tfd(base, torsions, masks, angles, torsions, thresh=1.5, tfd_thresh=10)
@@ -77,7 +78,7 @@ def csearch():
         t3 = time.perf_counter()
         _, rmask = fc.pruner.prune_by_rmsd(surv, atoms, 0.5)
         t_rmsd = time.perf_counter() - t3
-        runs.append({"s_scan_fingerprints_tfd_prune": t_scan_tfd, "s_rescan_survivors": t_regen, "s_rmsd_prune": t_rmsd,
+        runs.append({"s_angle_grid": t_grid, "s_scan_fingerprints_tfd_prune": t_scan_tfd - t_grid, "s_rescan_survivors": t_regen, "s_rmsd_prune": t_rmsd,
                      "s_total": time.perf_counter() - t0})
     wall = runs[1]["s_total"]
     print(json.dumps({
