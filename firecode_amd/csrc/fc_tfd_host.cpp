@@ -576,7 +576,6 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
   // the levels in order
   ChunkScratch scratch;
   std::vector<int64_t> last;
-  size_t ti = 0;  // tasks are grouped by level in creation order
   int64_t num_active = N;  // kept up to date as flags go 1 -> 0
   auto reject = [&](int64_t r) {
     num_active -= mask_out[r];
@@ -585,8 +584,6 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
   for (int li = 0; li < (int)(sizeof(kl) / sizeof(kl[0])); ++li) {
     const int64_t k = (int64_t)kl[li];
     const bool runs = (k == 1 || 5 * k < num_active);
-    const size_t t_begin = ti;
-    while (ti < tasks.size() && tasks[ti].level == li) ++ti;
     if (!runs) continue;
     const int64_t d = N / k;
     // the last chunk first reads nothing but first_match either, so the order of application within
@@ -594,7 +591,6 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
     last.clear();
     const int64_t active_in = num_active;
     level_chunks(fm, N, k, d, active_in, k - 1, k, scratch, last);
-    (void)t_begin;
     {  // branch-free over the bytes (vectorised by the compiler): a level rejects up to half of its range
       const uint8_t *flags = level_rej[li].data();
       const size_t n_flags = level_rej[li].size();
