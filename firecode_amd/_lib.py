@@ -60,6 +60,7 @@ _SIGNATURES = {
     "fc_ensemble_rmsd_matrix": [_ens, _p_f64, _p_f64],
     "fc_ensemble_rmsd_values": [_ens, _p_f64, _p_f64],
     "fc_ensemble_rmsd_and_max_all": [_ens, _p_f64, _p_f64, _p_f64],
+    "fc_bench_rmsd_and_max_all": [_ens, _i64, _p_f64, _p_f64, _p_i64],
     "fc_screen_select": [C.c_int],
     "fc_prune_conventions": [C.c_int],
     "fc_prune_similarity": [_p_f64, _i64, _i64, _p_u8, _p_f64, C.c_int, _f64, C.c_int, _f64, _f64, _p_f64, _f64, _i64,
@@ -424,6 +425,14 @@ class DeviceEnsemble:
         ms = C.c_double(0)
         call("fc_ensemble_rmsd_and_max_all", self.handle, pf(r), pf(m), C.byref(ms))
         return r, m, ms.value
+
+    def bench_rmsd_and_max_all(self, reps=1):
+        """``reps`` complete all-pairs alignment passes, outputs resident ->
+        (mean kernel ms, total ms, stats [pairs, fix-up pairs, tiled])."""
+        k, t = C.c_double(0), C.c_double(0)
+        stats = np.zeros(3, dtype=np.int64)
+        call("fc_bench_rmsd_and_max_all", self.handle, int(reps), C.byref(k), C.byref(t), pi(stats))
+        return k.value, t.value, stats
 
     def simbits(self, max_rmsd, max_dev, energies=None, max_dE=0.0, row_begin=0, row_end=None):
         row_end = self.N if row_end is None else int(row_end)

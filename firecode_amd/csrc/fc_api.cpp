@@ -752,6 +752,11 @@ int fc_kabsch_rmsd_pairs(const double *coords, int64_t N, int64_t A, const uint8
 // all pairs, both outputs: covariance tiles on the fp64 matrix pipe, rotation + explicit rotated
 // difference in the epilogue (k_simbits_screen_mfma<.., 2>); structures beyond the LDS column tile
 // (A > 104) take the one-wave-per-row kernel.  Outputs may both be NULL (timing only).
+static bool rmsd_and_max_tiled(const fc_ensemble *ens) {
+  const size_t lds_m = ((size_t)((ens->A + 3) / 4) * 4 * 3 * 64 + 64 + 128) * sizeof(double) + 1024;
+  return lds_m <= (size_t)160 * 1024 && (uint64_t)((ens->A + 3) / 4 * 4) * 3 * (uint64_t)ens->Npad < (1ull << 32);
+}
+
 static int rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_out, double *ms_kernel) {
   FC_TRY(ensure_init());
   const int64_t N = ens->N;
@@ -761,15 +766,16 @@ static int rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_o
   const size_t bytes = (size_t)N * N * sizeof(double);
   FC_TRY(dr.reserve(bytes));
   FC_TRY(dm.reserve(bytes));
-  FC_HIP_TRY(hipMemsetAsync(dr.p, 0, bytes, c.stream));
-  FC_HIP_TRY(hipMemsetAsync(dm.p, 0, bytes, c.stream));
-  const size_t lds_m = ((size_t)((ens->A + 3) / 4) * 4 * 3 * 64 + 64 + 128) * sizeof(double) + 1024;
-  const bool tiled = lds_m <= (size_t)160 * 1024 &&
-                     (uint64_t)((ens->A + 3) / 4 * 4) * 3 * (uint64_t)ens->Npad < (1ull << 32);
+  const bool tiled = rmsd_and_max_tiled(ens);
   unsigned long long cnt[16] = {0};
   if (tiled) {
+    // the tiled kernel writes every (i, j >= i), exact zeros on the diagonal; the lower triangle is
+    // mirrored on the host below: nothing to clear (2 x 800 MB of memset per call at 10^4 conformers)
     FC_TRY(ensemble_shard(ens, 0, 1, 256));  // sizes the pair queue of the fix-up
     FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 16 * sizeof(uint64_t), c.stream));
+  } else {
+    FC_HIP_TRY(hipMemsetAsync(dr.p, 0, bytes, c.stream));
+    FC_HIP_TRY(hipMemsetAsync(dm.p, 0, bytes, c.stream));
   }
   FC_HIP_TRY(hipEventRecord(c.ev0, c.stream));
   if (tiled) FC_TRY(launch_rmsd_values(ens, 0.0, dr.as<double>(), dm.as<double>()));
@@ -786,6 +792,8 @@ static int rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_o
   }
   if (tiled && cnt[6] > (unsigned long long)ens->pairq_cap) {
     // more degenerate pairs than the fix-up queue holds: the plain kernel redoes the matrix
+    FC_HIP_TRY(hipMemsetAsync(dr.p, 0, bytes, c.stream));
+    FC_HIP_TRY(hipMemsetAsync(dm.p, 0, bytes, c.stream));
     FC_TRY(launch_matrix_exact(ens, dr.as<double>(), dm.as<double>()));
     if (rmsd_out) FC_TRY(d2h(rmsd_out, dr.p, bytes));
     if (maxdev_out) FC_TRY(d2h(maxdev_out, dm.p, bytes));
@@ -799,6 +807,68 @@ static int rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_o
   return FC_OK;
 }
 
+// bench hook: `reps` complete all-pairs alignment passes over the resident ensemble, enqueued back to
+// back on the library's stream (outputs: two dense (N, N) matrices that stay in HBM), one host wait.
+// ms_kernel_mean: HIP events around the dominant kernel (k_simbits_screen_mfma<., 2>) of every launch;
+// ms_total: first launch to the end of the last fix-up kernel.  stats[0] = pairs per pass,
+// stats[1] = pairs the last pass queued for the Jacobi fix-up, stats[2] = 1 when the tiled kernel ran.
+static int bench_rmsd_and_max_all(fc_ensemble *ens, int64_t reps, double *ms_kernel_mean, double *ms_total,
+                                  int64_t *stats) {
+  FC_TRY(ensure_init());
+  const int64_t N = ens->N;
+  FC_REQUIRE(N >= 2, "needs at least two conformers");
+  Context &c = ctx();
+  DevBuf dr, dm;
+  const size_t bytes = (size_t)N * N * sizeof(double);
+  FC_TRY(dr.reserve(bytes));
+  FC_TRY(dm.reserve(bytes));
+  const bool tiled = rmsd_and_max_tiled(ens);
+  if (tiled) FC_TRY(ensemble_shard(ens, 0, 1, 256));
+  std::vector<hipEvent_t> &ev = c.ev_pool;
+  while ((int64_t)ev.size() < 2 * reps + 2) {
+    hipEvent_t e = nullptr;
+    FC_HIP_TRY(hipEventCreate(&e));
+    ev.push_back(e);
+  }
+  FC_HIP_TRY(hipEventRecord(ev[2 * reps], c.stream));
+  for (int64_t r = 0; r < reps; ++r) {
+    if (tiled) {
+      FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 16 * sizeof(uint64_t), c.stream));
+      FC_HIP_TRY(hipEventRecord(ev[2 * r], c.stream));
+      c.mark_after_screen = ev[2 * r + 1];  // recorded right behind the tiled kernel, in front of the fix-up
+      const int rc = launch_rmsd_values(ens, 0.0, dr.as<double>(), dm.as<double>());
+      c.mark_after_screen = nullptr;
+      FC_TRY(rc);
+    } else {
+      FC_HIP_TRY(hipEventRecord(ev[2 * r], c.stream));
+      FC_TRY(launch_matrix_exact(ens, dr.as<double>(), dm.as<double>()));
+      FC_HIP_TRY(hipEventRecord(ev[2 * r + 1], c.stream));
+    }
+  }
+  FC_HIP_TRY(hipEventRecord(ev[2 * reps + 1], c.stream));
+  unsigned long long cnt[16] = {0};
+  if (tiled) FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
+  FC_TRY(sync());
+  double sum = 0.0;
+  for (int64_t r = 0; r < reps; ++r) {
+    float ms = 0.f;
+    FC_HIP_TRY(hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]));
+    sum += ms;
+  }
+  float tot = 0.f;
+  FC_HIP_TRY(hipEventElapsedTime(&tot, ev[2 * reps], ev[2 * reps + 1]));
+  if (ms_kernel_mean) *ms_kernel_mean = sum / (double)reps;
+  if (ms_total) *ms_total = tot;
+  if (stats) {
+    stats[0] = N * (N - 1) / 2;
+    stats[1] = (int64_t)cnt[6];
+    stats[2] = tiled ? 1 : 0;
+  }
+  if (tiled && cnt[6] > (unsigned long long)ens->pairq_cap)
+    return set_error(FC_E_LIMIT, "%llu degenerate pairs exceed the fix-up queue (%lld)", cnt[6], (long long)ens->pairq_cap);
+  return FC_OK;
+}
+
 int fc_ensemble_rmsd_matrix(fc_ensemble *ens, double *rmsd_out, double *maxdev_out) {
   FC_API_LOCK;
   FC_REQUIRE(ens && rmsd_out && maxdev_out, "NULL pointer argument");
@@ -809,6 +879,13 @@ int fc_ensemble_rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *max
   FC_API_LOCK;
   FC_REQUIRE(ens != nullptr, "ens is NULL");
   return rmsd_and_max_all(ens, rmsd_out, maxdev_out, ms_kernel);
+}
+
+int fc_bench_rmsd_and_max_all(fc_ensemble *ens, int64_t reps, double *ms_kernel_mean, double *ms_total,
+                              int64_t *stats) {
+  FC_API_LOCK;
+  FC_REQUIRE(ens != nullptr && reps >= 1 && reps <= 4096, "bad arguments");
+  return bench_rmsd_and_max_all(ens, reps, ms_kernel_mean, ms_total, stats);
 }
 
 int fc_ensemble_rmsd_values(fc_ensemble *ens, double *rmsd_out, double *ms_kernel) {

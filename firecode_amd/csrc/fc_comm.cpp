@@ -53,7 +53,8 @@ int load_rccl(Rccl &r) {
     if (!n || !*n) continue;
     r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (r.lib) break;
-    tried += std::string(n) + ": " + (dlerror() ? dlerror() : "?") + "; ";
+    const char *err = dlerror();  // ONE call: glibc clears the message when it is read
+    tried += std::string(n) + ": " + (err ? err : "?") + "; ";
   }
   if (!r.lib) return set_error(FC_E_NODEVICE, "RCCL is not available (%s)", tried.c_str());
 #define FC_SYM(field, name)                                                                     \

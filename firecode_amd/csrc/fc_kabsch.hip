@@ -663,7 +663,13 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 #endif
   }
   const int kq = lane >> 4, l15 = lane & 15;
-  const int boff = (kq >> 1) * (2 * TC) + (kq & 1) * 16 + l15;
+  // MODE 2 computes the tiles TRANSPOSED (column conformers as the instruction's first operand, D rows =
+  // columns of the pair matrix) and hands row m of the instruction the column 4 (m & 3) + (m >> 2) of the
+  // sub-tile: lane (kq, l15) then owns the pairs (row ib + l15, columns 4 kq + 0..3) -- ONE row conformer
+  // per lane (16 consecutive addresses per load instruction instead of four pairs of 4) and its four
+  // column conformers in 32 consecutive bytes of the LDS tile (see the epilogue)
+  const int lcol = MODE == 2 ? 4 * (l15 & 3) + (l15 >> 2) : l15;
+  const int boff = (kq >> 1) * (2 * TC) + (kq & 1) * 16 + lcol;
   uint16_t *bits16 = reinterpret_cast<uint16_t *>(bits);
 
   // Row operands of the first three k-steps of the NEXT unit (same rows for the second
@@ -737,8 +743,9 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
           for (int y = 0; y < 3; ++y)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-              acc[t][x * 3 + y] =
-                  __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[t][y], acc[t][x * 3 + y], 0, 0, 0);
+              acc[t][x * 3 + y] = MODE == 2
+                  ? __builtin_amdgcn_mfma_f64_16x16x4f64(b[t][y], a[x], acc[t][x * 3 + y], 0, 0, 0)
+                  : __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[t][y], acc[t][x * 3 + y], 0, 0, 0);
       };
       if (pre_it != it) {  // first unit of the wave, or the prediction below missed
         fetch_a_at(a0, voff, 0);
@@ -786,57 +793,103 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
         const double Gq = ldsG[cs * 16 + l15];
         uint64_t mr[4] = {0, 0, 0, 0};
         if (MODE == 2) {
-          // complete alignment (a4: rmsd_and_max): rotation of each of the lane's four pairs from its
-          // covariance (Newton eigenvalue + adjugate column), then ONE pass over the atoms for the
-          // four of them -- the column conformer from the LDS tile (shared by the four pairs), the
-          // four row conformers from L1/L2 (16 lanes read the same address) -- accumulating the
-          // explicit rotated difference, which is what the reference computes.  Pairs whose largest
-          // eigenvalue is not clearly simple are queued for k_pairs_fix (Jacobi sweeps).
-          // (two rows at a time: four rotations next to the 72 accumulator registers of the other
-          // sub-tile spill)
-          const double *__restrict__ qcol = lds + cs * 32 + l15;
+          // complete alignment (a4: rmsd_and_max); lane = (row ib + l15, columns 4 kq + r, r = 0..3).
+          // Step 1: the rotation of each of the lane's four pairs from its covariance, as a unit
+          // quaternion (Newton eigenvalue + adjugate column: kabsch_quaternion_qcp), then as -R.
+          // Step 2: ONE pass over the atoms accumulating the explicit rotated difference of the four
+          // pairs, which is what the reference computes: the row conformer's atom from L1/L2 (3 loads of 16
+          // consecutive doubles per atom and wave), the four column conformers' from the LDS tile (two
+          // 16-byte reads per coordinate), both requested one atom ahead of their use (ping-pong register
+          // sets), d = p - R q as three fused chains on -R.  (First version: lane = 4 rows x 1 column, the
+          // loop waiting on its own loads: 4.7 ms per 10^4 x 10^4; with the requests ahead 4.3 ms -- it was
+          // bound by its 138 M vector-memory instructions, one per 7.6 vector instructions.)
+          // Pairs whose largest eigenvalue is not clearly simple are queued for k_rmsd_fix_small (Jacobi).
+          const int i = ib32 + l15;
+          const int jb = (int)j0 + cs * 16 + 4 * kq;
+          const double Gp = ldsG[TC + it * 16 + l15];
+          double nR[4][9];
+          bool ok4[4];
 #pragma unroll
-          for (int rr = 0; rr < 2; ++rr) {
-            double R2[2][9];
-            bool ok2[2];
+          for (int r = 0; r < 4; ++r) {
+            const double Gq_r = ldsG[cs * 16 + 4 * kq + r];
+            double B9[9], Q4[4], R9[9];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int r = 2 * rr + u;
-              const double Gp = ldsG[TC + it * 16 + kq + 4 * r];
-              double B9[9];
+            for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
+            ok4[r] = kabsch_quaternion_qcp(B9, Gp + Gq_r, Q4);
+            if (!ok4[r]) Q4[0] = 1.0, Q4[1] = 0.0, Q4[2] = 0.0, Q4[3] = 0.0;
+            rotation_from_quaternion(Q4, R9);
 #pragma unroll
-              for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
-              ok2[u] = kabsch_rotation_qcp(B9, Gp + Gq, R2[u]);
+            for (int e = 0; e < 9; ++e) nR[r][e] = -R9[e];
+          }
+          typedef double d2_t __attribute__((ext_vector_type(2)));
+          const double *__restrict__ qcol = lds + cs * 32 + 4 * kq;
+          const double *__restrict__ prow = Xs + ib + l15;
+          const int A4 = 4 * KS;  // atoms padded to 4 with zeros: they add nothing
+          double ssq[4] = {0.0, 0.0, 0.0, 0.0}, mx[4] = {0.0, 0.0, 0.0, 0.0};
+          auto load_pq = [&](int a, double (&P)[3], d2_t (&Qv)[3][2]) {
+            const int al = a < A4 ? a : A4 - 1;  // past the end: harmless re-read, never used
+            const double *__restrict__ ql = qcol + (al >> 2) * (12 * TC) + ((al >> 1) & 1) * (2 * TC) + (al & 1) * 16;
+            const double *__restrict__ pa = prow + (int64_t)(al * 3) * Npad;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              Qv[c][0] = *reinterpret_cast<const d2_t *>(ql + c * (4 * TC));
+              Qv[c][1] = *reinterpret_cast<const d2_t *>(ql + c * (4 * TC) + 2);
+              P[c] = pa[(int64_t)c * Npad];
             }
-            double ssq[2] = {0.0, 0.0}, mx[2] = {0.0, 0.0};
-            const double *__restrict__ prow = Xs + ib + kq + 8 * rr;
-            for (int a = 0; a < A; ++a) {
-              const int sg = a >> 2, k = a & 3;
-              const double *__restrict__ ql = qcol + sg * (12 * TC) + (k >> 1) * (2 * TC) + (k & 1) * 16;
-              const double qx = ql[0], qy = ql[4 * TC], qz = ql[8 * TC];
-              const double *__restrict__ pa = prow + (int64_t)(a * 3) * Npad;
+          };
+          auto accumulate = [&](const double (&P)[3], const d2_t (&Qv)[3][2]) {
+#pragma clang fp contract(fast)
 #pragma unroll
-              for (int u = 0; u < 2; ++u) {
-                const double px = pa[4 * u], py = pa[Npad + 4 * u], pz = pa[2 * Npad + 4 * u];
-                const double dx = px - (R2[u][0] * qx + R2[u][1] * qy + R2[u][2] * qz);
-                const double dy = py - (R2[u][3] * qx + R2[u][4] * qy + R2[u][5] * qz);
-                const double dz = pz - (R2[u][6] * qx + R2[u][7] * qy + R2[u][8] * qz);
-                const double s2 = dx * dx + dy * dy + dz * dz;
-                ssq[u] += s2;
-                mx[u] = fmax(mx[u], s2);
+            for (int r = 0; r < 4; ++r) {
+              const double qx = Qv[0][r >> 1][r & 1], qy = Qv[1][r >> 1][r & 1], qz = Qv[2][r >> 1][r & 1];
+              const double dx = fma(nR[r][0], qx, fma(nR[r][1], qy, fma(nR[r][2], qz, P[0])));
+              const double dy = fma(nR[r][3], qx, fma(nR[r][4], qy, fma(nR[r][5], qz, P[1])));
+              const double dz = fma(nR[r][6], qx, fma(nR[r][7], qy, fma(nR[r][8], qz, P[2])));
+              const double s2 = fma(dz, dz, fma(dy, dy, dx * dx));
+              ssq[r] += s2;
+              mx[r] = fmax(mx[r], s2);
+            }
+          };
+          double PA[3], PB[3];
+          d2_t QA[3][2], QB[3][2];
+          load_pq(0, PA, QA);
+          // (the scheduling barriers keep the requests where they are written: the machine scheduler
+          // otherwise gathers the two sets' loads into one burst right in front of their first use)
+          for (int a = 0; a < A4; a += 2) {
+            load_pq(a + 1, PB, QB);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(PA, QA);
+            __builtin_amdgcn_sched_barrier(0);
+            load_pq(a + 2, PA, QA);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(PB, QB);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const bool row_in = i < n32;
+          double *__restrict__ ro = rmsd_out + (int64_t)i * N + jb;
+          double *__restrict__ mo = maxdev_out + (int64_t)i * N + jb;
+          const double dA = (double)A;
+          if (row_in && jb > i && jb + 3 < n32 && ((((int64_t)i * N) & 1) == 0)) {
+            // all four above the diagonal and inside, 16-byte aligned: two wide stores per matrix
+            *reinterpret_cast<d2_t *>(ro) = d2_t{sqrt(ssq[0] / dA), sqrt(ssq[1] / dA)};
+            *reinterpret_cast<d2_t *>(ro + 2) = d2_t{sqrt(ssq[2] / dA), sqrt(ssq[3] / dA)};
+            *reinterpret_cast<d2_t *>(mo) = d2_t{sqrt(mx[0]), sqrt(mx[1])};
+            *reinterpret_cast<d2_t *>(mo + 2) = d2_t{sqrt(mx[2]), sqrt(mx[3])};
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = jb + r;
+              if (row_in && j >= i && j < n32) {  // the diagonal too (exact zeros there: the outputs need no memset)
+                ro[r] = j == i ? 0.0 : sqrt(ssq[r] / dA);
+                mo[r] = j == i ? 0.0 : sqrt(mx[r]);
               }
             }
+          }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int i = ib32 + kq + 4 * (2 * rr + u);
-              const bool in = (j > i) && (j < n32) && (i < n32);
-              if (in) {
-                rmsd_out[(int64_t)i * N + j] = sqrt(ssq[u] / (double)A);
-                maxdev_out[(int64_t)i * N + j] = sqrt(mx[u]);
-              }
-              const bool redo = in && !ok2[u];
-              stage_pairs(__ballot(redo), redo, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
-            }
+          for (int r = 0; r < 4; ++r) {
+            const int j = jb + r;
+            const bool redo = row_in && (j > i) && (j < n32) && !ok4[r];
+            stage_pairs(__ballot(redo), redo, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
           }
           continue;
         }
@@ -2498,6 +2551,7 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
   }
 #undef FC_LAUNCH_VALUES
   FC_TRY(check_launch("k_simbits_screen_mfma<values>"));
+  if (ctx().mark_after_screen) (void)hipEventRecord(ctx().mark_after_screen, ctx().stream);  // bench hook: end of the tiled kernel
   hipLaunchKernelGGL(k_rmsd_fix_small, dim3((unsigned)(ctx().n_cu * 4)), dim3(256), 0, ctx().stream,
                      e->Xa.as<double>(), (int)e->A, e->N, e->pairq.as<uint64_t>(), cnt,
                      (unsigned long long)e->pairq_cap, rmsd_dev, maxdev_dev);

@@ -393,4 +393,119 @@ __host__ __device__ __forceinline__ bool kabsch_rotation_qcp(const double (&B)[9
   return true;
 }
 
+// Unit quaternion (w, x, y, z) of the optimal rotation, the form the complete-alignment epilogue of the
+// all-pairs kernel keeps per pair (four doubles instead of nine) -- same contract as kabsch_rotation_qcp
+// (false: eigenvalue not clearly simple or residual above 1e-12 of the matrix scale -> the caller queues
+// the pair for the Jacobi sweeps), a third of its instructions:
+//   * Newton's quotient through v_rcp_f64: the iteration's fixed point and its stopping test do not depend
+//     on how exactly the step is divided, only the step count does (the fp64 division is ~14 instructions);
+//   * the ten cofactors of the symmetric K - lambda I from the twelve 2 x 2 minors of its row pairs (0,1)
+//     and (2,3): 3 fused operations each instead of a 3 x 3 determinant;
+//   * 1/|q| by v_rsq_f64 and two Newton steps.
+// Everything here may fuse (the file is built -ffp-contract=off for the literal cdist arithmetic elsewhere).
+__host__ __device__ __forceinline__ double fc_rcp_approx(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcp(x);
+#else
+  return 1.0 / x;
+#endif
+}
+__host__ __device__ __forceinline__ double fc_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+#else
+  double y = 1.0 / sqrt(x);  // host build (tools / tests)
+#endif
+  const double hx = 0.5 * x;
+  y = y * (1.5 - hx * y * y);
+  y = y * (1.5 - hx * y * y);
+  return y;
+}
+
+__host__ __device__ __forceinline__ bool kabsch_quaternion_qcp(const double (&B)[9], double GpGq, double (&Q)[4],
+                                                               int *iterations = nullptr) {
+#pragma clang fp contract(fast)
+  // B[x][y] = sum p_x q_y; Horn's S_xy = sum q_x p_y = B[y][x]
+  const double Sxx = B[0], Sxy = B[3], Sxz = B[6];
+  const double Syx = B[1], Syy = B[4], Syz = B[7];
+  const double Szx = B[2], Szy = B[5], Szz = B[8];
+  const double n2 = Sxx * Sxx + Sxy * Sxy + Sxz * Sxz + Syx * Syx + Syy * Syy + Syz * Syz +
+                    Szx * Szx + Szy * Szy + Szz * Szz;
+  const double c00 = Syy * Szz - Syz * Szy, c01 = Syz * Szx - Syx * Szz, c02 = Syx * Szy - Syy * Szx;
+  const double c10 = Sxz * Szy - Sxy * Szz, c11 = Sxx * Szz - Sxz * Szx, c12 = Sxy * Szx - Sxx * Szy;
+  const double c20 = Sxy * Syz - Sxz * Syy, c21 = Sxz * Syx - Sxx * Syz, c22 = Sxx * Syy - Sxy * Syx;
+  const double detB = Sxx * c00 + Sxy * c01 + Sxz * c02;
+  const double e2 = c00 * c00 + c01 * c01 + c02 * c02 + c10 * c10 + c11 * c11 + c12 * c12 +
+                    c20 * c20 + c21 * c21 + c22 * c22;
+  const double C2 = -2.0 * n2, C1 = -8.0 * detB, C0 = n2 * n2 - 4.0 * e2;
+  // Newton from the upper bound (Gp + Gq)/2: monotone from above (Theobald's QCP)
+  double x = 0.5 * GpGq;
+  int it = 0;
+  for (; it < 64; ++it) {
+    const double x2 = x * x;
+    const double b = (x2 + C2) * x;
+    const double a = b + C1;
+    const double den = 2.0 * x2 * x + b + a;
+    if (den == 0.0) break;
+    const double delta = (a * x + C0) * fc_rcp_approx(den);
+    x -= delta;
+    if (fabs(delta) <= 4e-16 * fabs(x)) break;
+  }
+  if (iterations) *iterations = it + 1;
+  const double lam = x;
+  const double m00 = (Sxx + Syy + Szz) - lam, m01 = Syz - Szy, m02 = Szx - Sxz, m03 = Sxy - Syx;
+  const double m11 = (Sxx - Syy - Szz) - lam, m12 = Sxy + Syx, m13 = Szx + Sxz;
+  const double m22 = (-Sxx + Syy - Szz) - lam, m23 = Syz + Szy;
+  const double m33 = (-Sxx - Syy + Szz) - lam;
+  // 2 x 2 minors: L_ab of rows (2, 3), U_ab of rows (0, 1), columns a < b
+  const double L01 = m02 * m13 - m12 * m03, L02 = m02 * m23 - m22 * m03, L03 = m02 * m33 - m23 * m03;
+  const double L12 = m12 * m23 - m22 * m13, L13 = m12 * m33 - m23 * m13, L23 = m22 * m33 - m23 * m23;
+  const double U01 = m00 * m11 - m01 * m01, U02 = m00 * m12 - m02 * m01, U03 = m00 * m13 - m03 * m01;
+  const double U12 = m01 * m12 - m02 * m11, U13 = m01 * m13 - m03 * m11, U23 = m02 * m13 - m03 * m12;
+  (void)U23;
+  // cofactors (adjugate of the symmetric matrix, upper triangle)
+  const double a00 = m11 * L23 - m12 * L13 + m13 * L12;
+  const double a01 = -(m01 * L23 - m12 * L03 + m13 * L02);
+  const double a02 = m01 * L13 - m11 * L03 + m13 * L01;
+  const double a03 = -(m01 * L12 - m11 * L02 + m12 * L01);
+  const double a11 = m00 * L23 - m02 * L03 + m03 * L02;
+  const double a12 = -(m00 * L13 - m01 * L03 + m03 * L01);
+  const double a13 = m00 * L12 - m01 * L02 + m02 * L01;
+  const double a22 = m03 * U13 - m13 * U03 + m33 * U01;
+  const double a23 = -(m03 * U12 - m13 * U02 + m23 * U01);
+  const double a33 = m02 * U12 - m12 * U02 + m22 * U01;
+  double q0 = a00, q1 = a01, q2 = a02, q3 = a03, best = fabs(a00);
+  if (fabs(a11) > best) { best = fabs(a11); q0 = a01; q1 = a11; q2 = a12; q3 = a13; }
+  if (fabs(a22) > best) { best = fabs(a22); q0 = a02; q1 = a12; q2 = a22; q3 = a23; }
+  if (fabs(a33) > best) { best = fabs(a33); q0 = a03; q1 = a13; q2 = a23; q3 = a33; }
+  const double scale = fabs(lam) + fabs(Sxx) + fabs(Syy) + fabs(Szz) + fabs(m01) + fabs(m02) + fabs(m03) +
+                       fabs(m12) + fabs(m13) + fabs(m23);
+  const double nq = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+  if (!(best > 2e-3 * scale * scale * scale) || !(nq > 0.0)) return false;  // eigenvalue not clearly simple
+  const double nrm = fc_rsqrt(nq);
+  q0 *= nrm; q1 *= nrm; q2 *= nrm; q3 *= nrm;
+  const double r0 = m00 * q0 + m01 * q1 + m02 * q2 + m03 * q3;
+  const double r1 = m01 * q0 + m11 * q1 + m12 * q2 + m13 * q3;
+  const double r2 = m02 * q0 + m12 * q1 + m22 * q2 + m23 * q3;
+  const double r3 = m03 * q0 + m13 * q1 + m23 * q2 + m33 * q3;
+  if (!(fmax(fmax(fabs(r0), fabs(r1)), fmax(fabs(r2), fabs(r3))) <= 1e-12 * scale)) return false;
+  Q[0] = q0; Q[1] = q1; Q[2] = q2; Q[3] = q3;
+  return true;
+}
+
+// R (row-major) from a unit quaternion, same formulas as kabsch_rotation
+__host__ __device__ __forceinline__ void rotation_from_quaternion(const double (&Q)[4], double (&R)[9]) {
+#pragma clang fp contract(fast)
+  const double q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3];
+  R[0] = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3;
+  R[1] = 2.0 * (q1 * q2 - q0 * q3);
+  R[2] = 2.0 * (q1 * q3 + q0 * q2);
+  R[3] = 2.0 * (q1 * q2 + q0 * q3);
+  R[4] = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3;
+  R[5] = 2.0 * (q2 * q3 - q0 * q1);
+  R[6] = 2.0 * (q1 * q3 - q0 * q2);
+  R[7] = 2.0 * (q2 * q3 + q0 * q1);
+  R[8] = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
+}
+
 }  // namespace fc

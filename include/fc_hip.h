@@ -511,6 +511,15 @@ int fc_debug_h2_covariance(fc_ensemble *ens, int64_t ib, int64_t jb, float *B_ou
 int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
                         double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
                         int64_t *stats);
+/* `reps` complete all-pairs alignment passes (fc_ensemble_rmsd_and_max_all: the a4 contract of
+ * firecode/utils.py:499 for every pair, fp64) over the resident ensemble, enqueued back to back, the two
+ * dense (N, N) outputs staying in HBM; one host wait.  ms_kernel_mean: HIP events on the kernel's stream
+ * around the tiled kernel of every pass; ms_total: first launch to the end of the last pass (fix-up
+ * kernels included).  stats[3]: pairs per pass, pairs the last pass sent to the Jacobi fix-up, 1 when
+ * the tiled kernel ran (0: the one-wave-per-row kernel for structures beyond its LDS tile).
+ * FC_E_LIMIT: more degenerate pairs than the fix-up queue holds. */
+int fc_bench_rmsd_and_max_all(fc_ensemble *ens, int64_t reps, double *ms_kernel_mean, double *ms_total,
+                              int64_t *stats);
 /* (fc_bench_prune_rmsd writes EIGHT stats: [6] = 16 x 32-pair units the subset stage of the lean fp32
  * screen queued for the full test in the last prune, [7] = 1 when its sample found similarity dense
  * and the single-stage kernel did the launch) */
