@@ -823,18 +823,20 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
           }
           typedef double d2_t __attribute__((ext_vector_type(2)));
           const double *__restrict__ qcol = lds + cs * 32 + 4 * kq;
-          const double *__restrict__ prow = Xs + ib + l15;
+          const double *__restrict__ prow_u = Xs + ib;
+          const unsigned l15u = (unsigned)l15;
           const int A4 = 4 * KS;  // atoms padded to 4 with zeros: they add nothing
           double ssq[4] = {0.0, 0.0, 0.0, 0.0}, mx[4] = {0.0, 0.0, 0.0, 0.0};
           auto load_pq = [&](int a, double (&P)[3], d2_t (&Qv)[3][2]) {
             const int al = a < A4 ? a : A4 - 1;  // past the end: harmless re-read, never used
             const double *__restrict__ ql = qcol + (al >> 2) * (12 * TC) + ((al >> 1) & 1) * (2 * TC) + (al & 1) * 16;
-            const double *__restrict__ pa = prow + (int64_t)(al * 3) * Npad;
+            // wave-uniform base + the lane's 32-bit offset: the address arithmetic stays on the scalar unit
+            const double *__restrict__ pa = prow_u + (int64_t)(al * 3) * Npad;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               Qv[c][0] = *reinterpret_cast<const d2_t *>(ql + c * (4 * TC));
               Qv[c][1] = *reinterpret_cast<const d2_t *>(ql + c * (4 * TC) + 2);
-              P[c] = pa[(int64_t)c * Npad];
+              P[c] = (pa + (int64_t)c * Npad)[l15u];
             }
           };
           auto accumulate = [&](const double (&P)[3], const d2_t (&Qv)[3][2]) {
@@ -847,7 +849,8 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
               const double dz = fma(nR[r][6], qx, fma(nR[r][7], qy, fma(nR[r][8], qz, P[2])));
               const double s2 = fma(dz, dz, fma(dy, dy, dx * dx));
               ssq[r] += s2;
-              mx[r] = fmax(mx[r], s2);
+              // (fmax() first re-quiets its loop-carried operand: one more instruction per pair and atom)
+              asm("v_max_f64 %0, %1, %2" : "=v"(mx[r]) : "v"(mx[r]), "v"(s2));
             }
           };
           double PA[3], PB[3];
@@ -868,20 +871,20 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
           const bool row_in = i < n32;
           double *__restrict__ ro = rmsd_out + (int64_t)i * N + jb;
           double *__restrict__ mo = maxdev_out + (int64_t)i * N + jb;
-          const double dA = (double)A;
+          const double invA = 1.0 / (double)A;
           if (row_in && jb > i && jb + 3 < n32 && ((((int64_t)i * N) & 1) == 0)) {
             // all four above the diagonal and inside, 16-byte aligned: two wide stores per matrix
-            *reinterpret_cast<d2_t *>(ro) = d2_t{sqrt(ssq[0] / dA), sqrt(ssq[1] / dA)};
-            *reinterpret_cast<d2_t *>(ro + 2) = d2_t{sqrt(ssq[2] / dA), sqrt(ssq[3] / dA)};
-            *reinterpret_cast<d2_t *>(mo) = d2_t{sqrt(mx[0]), sqrt(mx[1])};
-            *reinterpret_cast<d2_t *>(mo + 2) = d2_t{sqrt(mx[2]), sqrt(mx[3])};
+            *reinterpret_cast<d2_t *>(ro) = d2_t{fc_sqrt_nonneg(ssq[0] * invA), fc_sqrt_nonneg(ssq[1] * invA)};
+            *reinterpret_cast<d2_t *>(ro + 2) = d2_t{fc_sqrt_nonneg(ssq[2] * invA), fc_sqrt_nonneg(ssq[3] * invA)};
+            *reinterpret_cast<d2_t *>(mo) = d2_t{fc_sqrt_nonneg(mx[0]), fc_sqrt_nonneg(mx[1])};
+            *reinterpret_cast<d2_t *>(mo + 2) = d2_t{fc_sqrt_nonneg(mx[2]), fc_sqrt_nonneg(mx[3])};
           } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int j = jb + r;
               if (row_in && j >= i && j < n32) {  // the diagonal too (exact zeros there: the outputs need no memset)
-                ro[r] = j == i ? 0.0 : sqrt(ssq[r] / dA);
-                mo[r] = j == i ? 0.0 : sqrt(mx[r]);
+                ro[r] = j == i ? 0.0 : fc_sqrt_nonneg(ssq[r] * invA);
+                mo[r] = j == i ? 0.0 : fc_sqrt_nonneg(mx[r]);
               }
             }
           }

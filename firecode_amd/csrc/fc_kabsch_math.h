@@ -422,6 +422,26 @@ __host__ __device__ __forceinline__ double fc_rsqrt(double x) {
   return y;
 }
 
+// sqrt of a non-negative finite double to within one unit in the last place: v_rsq_f64 and two coupled
+// Newton steps (the compiler's sqrt() is correctly rounded and twice as long); 0 -> 0
+__host__ __device__ __forceinline__ double fc_sqrt_nonneg(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang fp contract(fast)
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  const double d2 = fma(-g, g, x);
+  g = fma(d2, h, g);
+  return x > 0.0 ? g : 0.0;
+#else
+  return sqrt(x);
+#endif
+}
+
 __host__ __device__ __forceinline__ bool kabsch_quaternion_qcp(const double (&B)[9], double GpGq, double (&Q)[4],
                                                                int *iterations = nullptr) {
 #pragma clang fp contract(fast)
@@ -449,7 +469,9 @@ __host__ __device__ __forceinline__ bool kabsch_quaternion_qcp(const double (&B)
     if (den == 0.0) break;
     const double delta = (a * x + C0) * fc_rcp_approx(den);
     x -= delta;
-    if (fabs(delta) <= 4e-16 * fabs(x)) break;
+    // quadratic convergence: a step below 1e-9 |x| leaves an error below the last place (a multiple root,
+    // where that does not hold, fails the residual test below and goes to the Jacobi sweeps)
+    if (fabs(delta) <= 1e-9 * fabs(x)) break;
   }
   if (iterations) *iterations = it + 1;
   const double lam = x;
