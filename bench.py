@@ -1,34 +1,42 @@
 #!/usr/bin/env python
 """bench.py -- conformer-pair RMSD alignments/s (+ pruned ensembles/s) on MI355X.
 
+The line's top-level fields are the reference-precision measurement in SURVEY.md 8d's unit of work:
+
+  value / ms_per_step / dtype "f64" / roofline
+        COMPLETE fp64 alignments per second: a step = one pass of `rmsd_and_max` (firecode/utils.py:499:
+        two conformers in -> Kabsch RMSD AND max per-atom deviation of the explicit rotated difference out)
+        over EVERY pair of the HBM-resident ensemble (fc_bench_rmsd_and_max_all: covariance tiles on the fp64
+        matrix pipe, rotation and deviation pass per pair, two dense (N, N) fp64 outputs that stay in HBM).
+        K steps enqueued back to back, one host wait, bracketed by barrier + device synchronisation.
+        `roofline` = that pass's dominant kernel, k_simbits_screen_mfma<4, 2>, HIP events on its stream around
+        every launch of the timed region, against the fp64 peak by 8d's 53 A + 600 flop per alignment.
+
+Extra blocks of the same line (each with its own device timing, outside the timed region):
+
+  prune_path   the pruning step the reference's prune_by_rmsd performs on the same ensemble -- all-pairs
+               similarity DECISIONS (split-half f16 screen, fp64-exact refine of the candidates) + k-ladder ->
+               survivor mask, bit-identical to the fp64 oracle's: ms_per_step, pair_decisions_per_s,
+               pruned_ensembles_per_s, roofline of its screen kernel.  (Rounds 1-2 reported this as `value`.)
+  fp64_path    the same pruning step with the fp64 screen (the reference's arithmetic in every kernel).
+  config.secondary  an ensemble without cluster structure; its refine kernel has its own HBM roofline.
+  cpu_baseline the oracle's rmsd_and_max on a bounded sample, one host core.
+
 Workloads (BASELINE.json `configs`), chosen with --workload:
 
-  cfg2  configs[1]: 10 000-conformer x 50-atom float64 ensemble, all-pairs Kabsch RMSD + 0.5 A
-        greedy prune.  THE single-GPU workload (default when --gpus 1).  A step = one full pruning
-        pass over the HBM-resident ensemble: all-pairs similarity decisions (screen + exact fp64
-        refine) and the k-ladder replay -> survivor mask.  On N GPUs the conformer count grows as
-        sqrt(N) (weak scaling: pairs per GPU constant).
-  cfg4  configs[3]: 100 000-conformer x 80-atom ensemble sharded over the GPUs, one RCCL
-        all-gather (default when --gpus > 1).  Weak-scaling family through the named point:
-        n_conf = 100 000 * sqrt(N / 8), so every GPU owns 6.25e8 pairs at any N and N = 8 IS
-        configs[3]; the line also carries the family's N = 1 member measured on rank 0 in the
-        same run, which is what a scaling efficiency has to be computed against.
-  cfg5  configs[4]: bimolecular rigid embed, 500 x (500 N / 8) conformer pairs x 512
-        rototranslations, compenetration check; poses sharded by molecule-2 conformer, one
-        all-gather of the packed pass mask.
+  cfg2  configs[1]: 10 000-conformer x 50-atom float64 ensemble.  THE workload of `value` at every N
+        (default): on N GPUs the conformer count grows as sqrt(N) -- weak scaling, pairs per GPU constant,
+        rows of the pair matrix dealt to the ranks in snake order, no exchange for the alignments; the
+        prune_path of N > 1 exchanges the similar-pair lists with ONE RCCL all-gather.
+  cfg4  configs[3]: 100 000-conformer x 80-atom ensemble sharded over the GPUs, one RCCL all-gather:
+        weak-scaling family n_conf = 100 000 * sqrt(N / 8) (N = 8 IS configs[3]); reported as the block
+        `cfg4_family` of every N > 1 line, or alone with --workload cfg4.
+  cfg5  configs[4]: bimolecular rigid embed, 500 x (500 N / 8) conformer pairs x 512 rototranslations.
 
-What `value` counts (cfg2 / cfg4): PAIR DECISIONS per second -- every conformer pair of the step
-is decided exactly as the reference's fp64 Kabsch would decide it (bit-identical mask), but most
-pairs are ruled out by a conservative screen and only the candidates get a full fp64 alignment.
-The stricter readings are in the same line: `fp64_path` (the same step with the fp64 screen: the
-reference's arithmetic in every kernel), `alignments_complete_per_s` (rmsd AND max deviation of
-every pair from the explicit rotated difference, the a4 contract) and `rmsd_values_per_s`.
-
-N > 1: one process per GPU (`python -m torch.distributed.run ... bench.py --gpus N`; the ranks read
-RANK / LOCAL_RANK / WORLD_SIZE and never import torch), RCCL behind the library's C ABI
-(firecode_amd.dist.comm_init_from_env).  Every rank keeps the whole ensemble resident and owns the
-row blocks of the similarity matrix dealt in snake order; ONE all-gather of the ranks'
-similar-pair lists per prune, the k-ladder replayed on every rank.
+N > 1: `python bench.py --gpus N` starts N fresh rank processes itself (the parent never loads the library
+or touches a GPU) and relays rank 0's line; under an external launcher that sets RANK / LOCAL_RANK /
+WORLD_SIZE (python -m torch.distributed.run ...) the process is a rank.  The ranks never import torch: RCCL
+sits behind the library's C ABI (firecode_amd.dist.comm_init_from_env).
 """
 
 import argparse
@@ -233,17 +241,82 @@ def timed_prunes(ens, steps, warmup, sharded, overlap=True):
     return run
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` typed as is: start N fresh rank processes (this parent never imports the
+    library or touches a GPU), relay rank 0's single JSON line, exit non-zero if any rank does."""
+    import subprocess
+    import tempfile
+    import uuid
+
+    idfile = os.path.join(tempfile.gettempdir(), f"fc_comm_{uuid.uuid4().hex}.id")
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=rank_env(os.environ, r, n, idfile),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    line, failed = b"", None
+    try:
+        import selectors
+        sel = selectors.DefaultSelector()
+        sel.register(procs[0].stdout, selectors.EVENT_READ)
+        open_out = True
+        while True:
+            if open_out and sel.select(timeout=0.2):
+                chunk = os.read(procs[0].stdout.fileno(), 1 << 16)
+                if chunk:
+                    line += chunk
+                else:
+                    open_out = False
+                    sel.unregister(procs[0].stdout)
+            elif not open_out:
+                time.sleep(0.05)
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = bad[0]
+                break
+            if all(c == 0 for c in codes) and not open_out:
+                break
+    finally:
+        for p in procs:  # exactly the processes started here
+            if p.poll() is None and failed is not None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+        try:
+            os.remove(idfile)
+        except OSError:
+            pass
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}\n")
+        sys.exit(failed[1] if 0 < failed[1] < 256 else 1)
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+
+
+def rank_env(base, rank, world, idfile):
+    """Environment of rank `rank` of a self-spawned launch (what an external launcher would set)."""
+    env = dict(base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), FC_COMM_ID_FILE=idfile,
+               FC_BENCH_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.pop("FC_BENCH_FORCE_SPAWN", None)
+    return env
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: ~0.25 s of GPU time; a dozen steps end before the device reaches its steady clocks
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=("auto", "cfg2", "cfg4", "cfg5"), default="auto",
-                    help="auto = cfg2 on one GPU (BASELINE configs[1]), cfg4 on several (configs[3] at 8)")
+                    help="auto = cfg2 (BASELINE configs[1]; conformers x sqrt(n_gpus)) with the cfg4 family as an extra block on several GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="only the timed region (profile runs): no fp64_path / complete / secondary / host-in legs")
+                    help="only the timed region (profile runs): no prune_path / fp64_path / secondary / host-in legs")
     ap.add_argument("--cpu-baseline-configs", action="store_true",
                     help="only time the CPU oracle on samples of BASELINE configs 3 and 5 (no GPU needed) and exit")
     args = ap.parse_args()
@@ -252,14 +325,13 @@ def main():
                           "host_cores_visible": len(os.sched_getaffinity(0))}))
         return
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("FC_BENCH_FORCE_SPAWN") == "1"):
+        spawn_ranks(args.gpus)
+        return
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL, before the HSA runtime starts
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` "
-                     "(any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE)")
-        args.gpus = world
-    workload = args.workload if args.workload != "auto" else ("cfg2" if world == 1 else "cfg4")
+    args.gpus = world  # under a launcher the launch decides
+    workload = args.workload if args.workload != "auto" else "cfg2"
 
     # RCCL writes a version banner to fd 1 when a communicator is created; the contract is ONE JSON
     # line on stdout, so everything but that line goes to stderr
@@ -273,61 +345,191 @@ def main():
     from firecode_amd import synthetic as syn
 
     # FC_BENCH_FORCE_SHARDED=1: the multi-GPU code path (RCCL communicator of one rank) on a single GPU
-    sharded = world > 1 or workload == "cfg4" or os.environ.get("FC_BENCH_FORCE_SHARDED") == "1"
-    if sharded or workload == "cfg5":
+    comm = (world > 1 or workload in ("cfg4", "cfg5") or os.environ.get("FC_BENCH_FORCE_SHARDED") == "1"
+            or os.environ.get("FC_BENCH_SPAWNED") == "1")
+    if comm:
         rank, world, local_rank = fdist.comm_init_from_env()
     else:
         rank, local_rank = 0, 0
         fc.init(0)
 
     def barrier():
-        if sharded or workload == "cfg5":
+        if comm:
             _lib.comm_barrier()  # a 1-byte all-gather + device synchronisation on every rank
 
     def max_over_ranks(x):
-        if not (sharded or workload == "cfg5") or world == 1:
+        if not comm or world == 1:
             return float(x)
         g = _lib.allgather_mask(np.array([x], dtype=np.float64).view(np.uint8))
         return float(g.view(np.float64).max())
 
+    ctx = dict(args=args, fc=fc, _lib=_lib, fdist=fdist, syn=syn, rank=rank, world=world, comm=comm,
+               barrier=barrier, max_over_ranks=max_over_ranks)
     if workload == "cfg5":
         out = run_cfg5(args, fc, _lib, fdist, syn, rank, world, barrier, max_over_ranks)
+    elif workload == "cfg4":
+        out = run_prune_line(ctx, "cfg4")
     else:
-        out = run_prune(args, workload, fc, _lib, fdist, syn, rank, world, sharded, barrier, max_over_ranks)
+        out = run_alignments(ctx)
 
     if rank == 0:
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if sharded or workload == "cfg5":
+    if comm:
         _lib.comm_barrier()
         _lib.comm_destroy()
 
 
 # ----------------------------------------------------------------------------------------------
-# cfg2 / cfg4: all-pairs RMSD prune
+# the headline: complete fp64 alignments of all pairs (cfg2 family)
 # ----------------------------------------------------------------------------------------------
-def run_prune(args, workload, fc, _lib, fdist, syn, rank, world, sharded, barrier, max_over_ranks):
-    if workload == "cfg2":
-        n_atoms, seed = 50, 2
-        n_conf = int(round(10000 * np.sqrt(world)))
-        steps = 200 if args.steps is None else args.steps
-        warmup = 20 if args.warmup is None else args.warmup
-        what = (f"{n_conf}-conformer x {n_atoms}-atom ensemble, all-pairs Kabsch RMSD + {MAX_RMSD} A prune "
-                "(BASELINE configs[1]" + ("" if world == 1 else "; conformers scaled by sqrt(n_gpus): pairs per GPU constant") + ")")
-    else:
-        n_atoms, seed = 80, 6
-        n_conf = int(round(100000 * np.sqrt(world / 8.0)))
-        steps = 20 if args.steps is None else args.steps
-        warmup = 3 if args.warmup is None else args.warmup
-        what = (f"{n_conf}-conformer x {n_atoms}-atom ensemble sharded over {world} GPU(s), all-pairs Kabsch RMSD + "
-                f"{MAX_RMSD} A prune, one RCCL all-gather per prune (BASELINE configs[3] is the n_gpus = 8 member of "
-                "this weak-scaling family: n_conf = 100 000 * sqrt(n_gpus / 8), 6.25e8 pairs per GPU)")
+def complete_roofline(kernel_ms, owned_pairs, n_conf, n_atoms, world):
+    fl = FLOPS_PER_ALIGNMENT(n_atoms)
+    tflops = owned_pairs * fl / (kernel_ms * 1e-3) / 1e12
+    traffic, src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_complete.json")
+    if world == 1 and os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec.get("n_conformers") == n_conf and rec.get("n_atoms") == n_atoms:  # only the line's own workload
+            traffic = rec["traffic_bytes_per_launch"]
+            src = "from_file: " + os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes of an earlier run of this kernel on this workload)"
+    return {"bound": "mfma", "kernel": "k_simbits_screen_mfma<4, 2>", "achieved": tflops, "peak": PEAK_F64_MFMA,
+            "unit": "TFLOP/s", "frac": tflops / PEAK_F64_MFMA, "traffic": traffic, "traffic_source": src,
+            "kernel_ms": kernel_ms, "flops_per_alignment": fl, "dtype": "f64",
+            "note": "achieved = SURVEY 8d's algorithmic flops of one complete alignment (53 A + 600) x pairs of one launch / the "
+                    "kernel's mean HIP-event duration; peak = the fp64 rate of the matrix pipe, which on this chip is also the "
+                    "fp64 vector rate -- the kernel runs its covariance on the first and rotation + deviation pass on the second",
+            "kernel_ms_source": "HIP events on the kernel's stream around every launch of the timed region"
+                                + ("" if world == 1 else "; rank 0's launches")}
+
+
+def run_alignments(ctx):
+    args, fc, _lib, syn = ctx["args"], ctx["fc"], ctx["_lib"], ctx["syn"]
+    rank, world, barrier, max_over_ranks = ctx["rank"], ctx["world"], ctx["barrier"], ctx["max_over_ranks"]
+    n_atoms, seed = 50, 2
+    n_conf = int(round(10000 * np.sqrt(world)))
+    steps = 50 if args.steps is None else args.steps
+    warmup = 5 if args.warmup is None else args.warmup
+    what = (f"{n_conf}-conformer x {n_atoms}-atom ensemble, complete Kabsch alignment (rmsd + max deviation, fp64) of all pairs "
+            "(BASELINE configs[1]" + ("" if world == 1 else "; conformers scaled by sqrt(n_gpus): pairs per GPU constant, rows of "
+                                      "the pair matrix dealt to the ranks, no exchange") + ")")
     coords, atoms, assign = syn.synthetic_ensemble(n_conf, n_atoms, seed=seed)
     ens = fc.DeviceEnsemble(coords, center=True)  # resident in HBM from here on
     pairs_total = n_conf * (n_conf - 1) // 2
 
+    def run(n):
+        k = t = 0.0
+        st = None
+        done = 0
+        while done < n:
+            m = min(1024, n - done)
+            km, tm, st = ens.bench_rmsd_and_max_all(m)
+            k += km * m
+            t += tm
+            done += m
+        return k / n, t, st
+
+    run(2)  # output matrices, item table, event pool: outside the timed region whatever W is
+    if warmup:
+        run(warmup)
+    barrier()
+    t0 = time.perf_counter()
+    k_ms, dev_ms, st = run(steps)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    owned = int(st[0])
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "conformer-pair RMSD alignments/s",
+            "value": pairs_total * steps / elapsed,
+            "unit": "alignments/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": what, "baseline_config": "configs[1]", "n_conformers": n_conf, "n_atoms": n_atoms,
+                       "pairs_per_step": pairs_total, "pairs_per_step_rank0": owned,
+                       "value_counts": "complete alignments: for EVERY conformer pair of the step the optimal rotation (Kabsch), the "
+                                       "RMSD and the max per-atom deviation from the explicit rotated difference, all fp64 -- "
+                                       "the (rmsd, maxdev) contract of rmsd_and_max (firecode/utils.py:499); outputs: two dense "
+                                       "(N, N) fp64 matrices in HBM",
+                       "sharding": (f"row blocks of 128 of the pair matrix dealt in snake order over {world} ranks, every rank "
+                                    "keeps the whole ensemble and its rows of the outputs; no exchange") if world > 1 else "none (single GPU)",
+                       "host_sync": "once per batch of <= 1024 stream-ordered steps",
+                       "device_ms_per_step": dev_ms / steps},
+            "fixup_pairs_last_step": int(st[1]),
+        }
+        out["roofline"] = complete_roofline(k_ms, owned, n_conf, n_atoms, world)
+        bytes_per_alignment = 2 * n_atoms * 24 + 16
+        achieved = owned * bytes_per_alignment / (k_ms * 1e-3) / 1e9
+        out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_simbits_screen_mfma<4, 2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": out["roofline"]["traffic"],
+                               "algorithmic_bytes_per_alignment": bytes_per_alignment,
+                               "compulsory_bytes": n_conf * n_atoms * 24 + 16 * owned,
+                               "note": "the north star's view: SURVEY 8d's 2*A*24+16 B per alignment against the 8 TB/s roof; > 1 = a "
+                                       "staged tile of 64 conformers serves 128 partners; the compulsory traffic is the ensemble "
+                                       "once + the two output matrices"}
+
+    if world > 1:
+        # the family's n_gpus = 1 member (same pairs per GPU), on rank 0 alone, outside the timed region
+        if rank == 0:
+            c1, _, _ = syn.synthetic_ensemble(10000, n_atoms, seed=seed)
+            _lib.call("fc_debug_comm_loopback", 0, 1)  # rank 0 computes every row, as a single GPU does
+            try:
+                with fc.DeviceEnsemble(c1, center=True) as e1:
+                    e1.bench_rmsd_and_max_all(2)
+                    k1, t1, s1 = e1.bench_rmsd_and_max_all(min(steps, 20))
+            finally:
+                _lib.call("fc_debug_comm_loopback", -1, 0)
+            v1 = int(s1[0]) * min(steps, 20) / (t1 * 1e-3)
+            out["scaling_family_n1"] = {"n_conformers": 10000, "pairs_per_step": int(s1[0]), "kernel_ms": k1,
+                                        "ms_per_step": t1 / min(steps, 20), "value": v1,
+                                        "note": "the N = 1 member of the family (BASELINE configs[1] itself), measured on rank 0 in "
+                                                "this run while the other ranks wait (device time, first launch to last)"}
+            out["efficiency"] = out["value"] / (world * v1)
+        barrier()
+    if ctx["comm"]:
+        r_, w_ = _lib.comm_info()
+        if rank == 0:
+            out["ranks_seen"] = int(w_)
+
+    if not args.no_extras:
+        blk = prune_block(ctx, "cfg2", ens, coords, atoms, assign, n_conf, n_atoms, steps_default=200, warmup_default=20)
+        if rank == 0:
+            out["prune_path"] = blk
+            out["pruned_ensembles_per_s"] = blk["pruned_ensembles_per_s"]
+        if world > 1:
+            blk4 = run_prune_line(ctx, "cfg4", as_block=True)
+            if rank == 0:
+                out["cfg4_family"] = blk4
+        elif rank == 0:
+            extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_atoms, pairs_total)
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(coords)
+        out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# cfg2 / cfg4: all-pairs RMSD prune (pair decisions + ladder -> survivor mask)
+# ----------------------------------------------------------------------------------------------
+def prune_block(ctx, workload, ens, coords, atoms, assign, n_conf, n_atoms, steps_default, warmup_default, steps=None, warmup=None):
+    """K stream-ordered prunes of the resident ensemble, bracketed like the main region -> dict (rank 0) / None."""
+    _lib, rank, world = ctx["_lib"], ctx["rank"], ctx["world"]
+    barrier, max_over_ranks = ctx["barrier"], ctx["max_over_ranks"]
+    sharded = world > 1 or workload == "cfg4" or os.environ.get("FC_BENCH_FORCE_SHARDED") == "1"
+    steps = steps_default if steps is None else steps
+    warmup = warmup_default if warmup is None else warmup
+    pairs_total = n_conf * (n_conf - 1) // 2
     run = timed_prunes(ens, steps, warmup, sharded)
     barrier()
     t0 = time.perf_counter()
@@ -342,82 +544,87 @@ def run_prune(args, workload, fc, _lib, fdist, syn, rank, world, sharded, barrie
     elapsed = max_over_ranks(time.perf_counter() - t0)
     t_kernel_ms = tk / steps
     if rank != 0:
-        if workload == "cfg4" and world > 1:
-            barrier()  # rank 0 measures the family's single-GPU member meanwhile
         return None
-
-    out = {
-        "metric": "conformer-pair RMSD alignments/s",
-        "value": pairs_total * steps / elapsed,
-        "unit": "alignments/s",
-        "n_gpus": world,
-        "steps": steps,
-        "warmup": warmup,
-        "ms_per_step": 1e3 * elapsed / steps,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": what, "baseline_config": "configs[1]" if workload == "cfg2" else "configs[3]",
-                   "n_conformers": n_conf, "n_atoms": n_atoms, "max_rmsd": MAX_RMSD, "pairs_per_step": pairs_total,
-                   "value_counts": "pair decisions: every pair of the step decided as the reference's fp64 Kabsch "
-                                   "decides it (bit-identical mask); a conservative all-pairs screen rules most pairs "
-                                   "out, candidates get the full fp64 alignment (rmsd + max deviation).  Stricter "
-                                   "readings: fp64_path, alignments_complete_per_s, rmsd_values_per_s",
-                   "sharding": (f"row blocks of 128 dealt in snake order over {world} rank(s); one all-gather of "
-                                "similar-pair lists, ladder replayed on every rank") if sharded else "none (single GPU)",
-                   "comm": "RCCL through libfc_hip.so's C ABI (fc_comm_init / ncclAllGather), no PyTorch in the ranks"
-                           if sharded else "none",
-                   "host_sync": "once per batch of <= 512 stream-ordered steps (one pinned result slot each)",
-                   "untimed_before_warmup": "set-up (second workspace, streams, fp32 operand copy) and "
-                                            + os.environ.get("FC_BENCH_SETTLE_S", "0.15") + " s of the same prunes so that the "
-                                            "W + K steps run at the device's steady clocks",
-                   "step_overlap": "screens in order on one stream; refine" + (" + export + all-gather" if sharded else "")
-                                   + " + ladder + result copy of step r run beside the screen of step r+1 "
-                                     "(two workspaces over the same resident coordinates)"},
-        "pruned_ensembles_per_s": steps / elapsed,
+    roof = screen_roofline(_lib, t_kernel_ms, owned, n_atoms, traffic_file=(workload == "cfg2" and n_conf == 10000), world=world, stats=stats)
+    roof["kernel_ms_source"] = ("HIP events on the kernel's stream around every %sth launch of the timed region "
+                                "(an event pair costs the stream ~14 us; FC_BENCH_EVENT_STRIDE=1 times all)"
+                                % os.environ.get("FC_BENCH_EVENT_STRIDE", "8")) + ("" if world == 1 else "; rank 0's launches")
+    blk = {
+        "what": "prune_by_rmsd's step on the resident ensemble: all-pairs similarity decisions (conservative screen + exact fp64 "
+                "refine of the candidates) + k-ladder replay -> survivor mask, bit-identical to the fp64 oracle's",
+        "dtype": {"f32": "f32 screen + f64 exact refine", "f16x2": "f16x2 screen (split-half, fp32-accurate) + f64 exact refine",
+                  "f64": "f64"}[roof["dtype"]],
+        "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "pair_decisions_per_s": pairs_total * steps / elapsed, "pruned_ensembles_per_s": steps / elapsed,
+        "n_conformers": n_conf, "n_atoms": n_atoms, "max_rmsd": MAX_RMSD, "pairs_per_step": pairs_total,
+        "candidates_refined": int(stats[1]), "similar_pairs": int(stats[2]),
+        "sharding": (f"row blocks of 128 dealt in snake order over {world} rank(s); one all-gather of similar-pair lists, "
+                     "ladder replayed on every rank") if sharded else "none (single GPU)",
+        "comm": "RCCL through libfc_hip.so's C ABI (fc_comm_init / ncclAllGather), no PyTorch in the ranks" if sharded else "none",
+        "step_overlap": "screens in order on one stream; refine" + (" + export + all-gather" if sharded else "")
+                        + " + ladder + result copy of step r run beside the screen of step r+1 (two workspaces over the same "
+                          "resident coordinates); one host wait per batch of <= 512 steps",
+        "roofline": roof,
     }
-    out.update(mask_checks(mask, assign))
-    out["roofline"] = screen_roofline(_lib, t_kernel_ms, owned, n_atoms, world=world, stats=stats)
-    out["roofline"]["kernel_ms_source"] = ("HIP events on the kernel's stream around every %sth launch of the timed region "
-                                           "(an event pair costs the stream ~14 us; FC_BENCH_EVENT_STRIDE=1 times all)"
-                                           % os.environ.get("FC_BENCH_EVENT_STRIDE", "8")) + ("" if world == 1 else "; rank 0's launches")
-    out["dtype"] = {"f32": "f32 screen + f64 exact refine", "f16x2": "f16x2 screen (split-half, fp32-accurate) + f64 exact refine",
-                    "f64": "f64"}[out["roofline"]["dtype"]]
-    bytes_per_alignment = 2 * n_atoms * 24 + 16
-    achieved = owned * bytes_per_alignment / (t_kernel_ms * 1e-3) / 1e9
-    # the north star's view: algorithmic bytes (two conformers in, rmsd + maxdev out) against the
-    # 8 TB/s HBM roof; > 1 because a staged tile serves 64-256 partners
-    out["roofline_hbm"] = {"bound": "hbm", "kernel": out["roofline"]["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": out["roofline"]["traffic"],
-                           "algorithmic_bytes_per_alignment": bytes_per_alignment,
-                           "compulsory_bytes": n_conf * n_atoms * 24 + n_conf * ((n_conf + 63) // 64) * 8}
+    blk.update(mask_checks(mask, assign))
+    return blk
 
-    if workload == "cfg4" and world > 1:
-        # the family's n_gpus = 1 member (same pairs per GPU), on rank 0 alone, outside the timed region
-        n1 = int(round(100000 * np.sqrt(1 / 8.0)))
-        c1, _, a1 = syn.synthetic_ensemble(n1, n_atoms, seed=seed)
-        with fc.DeviceEnsemble(c1, center=True) as e1:
-            e1.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=2, want_mask=False)
-            _, s_ms, m1, _ = e1.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=min(steps, 20), want_mask=True)
-        p1 = n1 * (n1 - 1) // 2
-        out["scaling_family_n1"] = {"n_conformers": n1, "pairs_per_step": p1, "ms_per_step": s_ms,
-                                    "value": p1 / (s_ms * 1e-3), "survivor_count_ok": mask_checks(m1, a1)["survivor_count_ok"],
-                                    "note": "same kernels without the exchange, measured on rank 0 while the other ranks wait; "
-                                            "scaling efficiency of this line = value / (n_gpus * scaling_family_n1.value)"}
+
+def run_prune_line(ctx, workload, as_block=False):
+    """The cfg4 family (100 000 x sqrt(n_gpus / 8) conformers x 80 atoms, sharded prune with one all-gather): a line of
+    its own with --workload cfg4, the block `cfg4_family` of every N > 1 line otherwise."""
+    args, fc, _lib, syn = ctx["args"], ctx["fc"], ctx["_lib"], ctx["syn"]
+    rank, world, barrier = ctx["rank"], ctx["world"], ctx["barrier"]
+    n_atoms, seed = 80, 6
+    n_conf = int(round(100000 * np.sqrt(world / 8.0)))
+    steps = 20 if (args.steps is None or as_block) else args.steps
+    warmup = 3 if (args.warmup is None or as_block) else args.warmup
+    what = (f"{n_conf}-conformer x {n_atoms}-atom ensemble sharded over {world} GPU(s), all-pairs Kabsch RMSD + "
+            f"{MAX_RMSD} A prune, one RCCL all-gather per prune (BASELINE configs[3] is the n_gpus = 8 member of "
+            "this weak-scaling family: n_conf = 100 000 * sqrt(n_gpus / 8), 6.25e8 pairs per GPU)")
+    coords, atoms, assign = syn.synthetic_ensemble(n_conf, n_atoms, seed=seed)
+    with fc.DeviceEnsemble(coords, center=True) as ens:
+        blk = prune_block(ctx, "cfg4", ens, coords, atoms, assign, n_conf, n_atoms, 20, 3, steps=steps, warmup=warmup)
+    if rank == 0:
+        blk["workload"] = what
+    if world > 1:
+        if rank == 0:
+            # the family's n_gpus = 1 member (same pairs per GPU), on rank 0 alone
+            n1 = int(round(100000 * np.sqrt(1 / 8.0)))
+            c1, _, a1 = syn.synthetic_ensemble(n1, n_atoms, seed=seed)
+            with fc.DeviceEnsemble(c1, center=True) as e1:
+                e1.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=2, want_mask=False)
+                _, s_ms, m1, _ = e1.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=min(steps, 20), want_mask=True)
+            p1 = n1 * (n1 - 1) // 2
+            blk["scaling_family_n1"] = {"n_conformers": n1, "pairs_per_step": p1, "ms_per_step": s_ms,
+                                        "pair_decisions_per_s": p1 / (s_ms * 1e-3),
+                                        "survivor_count_ok": mask_checks(m1, a1)["survivor_count_ok"],
+                                        "note": "same kernels without the exchange, measured on rank 0 while the other ranks wait"}
+            blk["efficiency"] = blk["pair_decisions_per_s"] / (world * blk["scaling_family_n1"]["pair_decisions_per_s"])
         barrier()
-
-    if not args.no_extras and not sharded:
-        extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_atoms, pairs_total, steps, warmup)
-    if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(coords)
+    if rank != 0:
+        return None
+    if as_block:
+        return blk
+    out = {"metric": "conformer-pair RMSD pair decisions/s (prune_by_rmsd step)", "value": blk["pair_decisions_per_s"],
+           "unit": "pair decisions/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": blk["ms_per_step"],
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": blk["dtype"], "data": "synthetic",
+           "config": {"workload": what, "baseline_config": "configs[3]", "n_conformers": n_conf, "n_atoms": n_atoms,
+                      "max_rmsd": MAX_RMSD, "pairs_per_step": blk["pairs_per_step"],
+                      "value_counts": "pair decisions: every pair of the step decided as the reference's fp64 Kabsch decides it "
+                                      "(bit-identical mask); NOT complete alignments -- the default line (--workload cfg2) reports those"},
+           "pruned_ensembles_per_s": blk["pruned_ensembles_per_s"], "roofline": blk.pop("roofline"), "prune_path": blk}
+    if ctx["comm"]:
+        out["ranks_seen"] = int(_lib.comm_info()[1])
+    if "efficiency" in blk:
+        out["efficiency"] = blk["efficiency"]
     return out
 
 
-def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_atoms, pairs_total, steps, warmup):
+def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_atoms, pairs_total):
     """Everything below is OUTSIDE the timed region of `value`; each leg has its own device timing."""
-    # (a) the same step with the fp64 screen: the reference's arithmetic in every kernel
+    steps, warmup = 200, 20
+    # (a) the pruning step with the fp64 screen: the reference's arithmetic in every kernel
     _lib.screen_select(64)
     try:
         run = timed_prunes(ens, steps, warmup, False)
@@ -429,50 +636,43 @@ def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_at
             tk += k_ms * n
             done += n
         el = time.perf_counter() - t0
-        r64 = screen_roofline(_lib, tk / steps, pairs_total, n_atoms)
-        out["fp64_path"] = {"what": "the same K steps with fc_screen_select(64): fp64 MFMA screen, fp64 refine, ladder",
-                            "dtype": "f64", "ms_per_step": 1e3 * el / steps, "value": pairs_total * steps / el,
-                            "unit": "alignments/s (pair decisions, all arithmetic fp64)",
+        r64 = screen_roofline(_lib, tk / steps, pairs_total, n_atoms, traffic_file=False)
+        out["fp64_path"] = {"what": "prune_path's K steps with fc_screen_select(64): fp64 MFMA screen, fp64 refine, ladder",
+                            "dtype": "f64", "ms_per_step": 1e3 * el / steps, "pair_decisions_per_s": pairs_total * steps / el,
                             "pruned_ensembles_per_s": steps / el, "mask_equals_default_path": None, "roofline": r64}
     finally:
         _lib.screen_select(0)
     _, _, mask32, _ = ens.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=1, want_mask=True)
     out["fp64_path"]["mask_equals_default_path"] = bool(np.array_equal(mask32, mask64))
-    # (b) the a4 contract for every pair: (rmsd, maxdev) from the explicit rotated difference
-    ens.rmsd_and_max_all(want_matrices=False)
-    ms_c = min(ens.rmsd_and_max_all(want_matrices=False)[2] for _ in range(3))
-    fl = FLOPS_PER_ALIGNMENT(n_atoms)
-    out["alignments_complete_per_s"] = pairs_total / (ms_c * 1e-3)
-    out["alignments_complete"] = {
-        "what": "rmsd_and_max of ALL pairs (firecode/utils.py:499 contract): two conformers in -> (rmsd, max deviation) out, "
-                "fp64: covariance tiles on the fp64 matrix pipe, rotation + explicit rotated difference per pair; "
-                "dense (N, N) outputs stay in HBM",
-        "kernel": "k_simbits_screen_mfma<., 2> + k_rmsd_fix_small", "kernel_ms": ms_c, "dtype": "f64",
-        "roofline": {"bound": "mfma", "achieved": pairs_total * fl / (ms_c * 1e-3) / 1e12, "peak": PEAK_F64_MFMA,
-                     "unit": "TFLOP/s", "frac": pairs_total * fl / (ms_c * 1e-3) / 1e12 / PEAK_F64_MFMA,
-                     "flops_per_alignment": fl, "note": "SURVEY 8d algorithmic flops (53 A + 600) against the fp64 peak"},
-        "roofline_hbm": {"bound": "hbm", "achieved": pairs_total * (2 * n_atoms * 24 + 16) / (ms_c * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": pairs_total * (2 * n_atoms * 24 + 16) / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "note": "SURVEY 8d algorithmic 2*A*24+16 B per alignment; > 1 = tile reuse",
-                         "output_bytes_written": 2 * 8 * pairs_total}}
-    # (c) RMSD values only (no rotation)
+    # (b) RMSD values only (no rotation, no max deviation)
     ens.rmsd_values(want_matrix=False)
     values_ms = min(ens.rmsd_values(want_matrix=False)[1] for _ in range(3))
     out["rmsd_values_per_s"] = pairs_total / (values_ms * 1e-3)
-    # (d) an ensemble WITHOUT cluster structure: continuous RMSD distribution across the threshold
+    # (c) an ensemble WITHOUT cluster structure: continuous RMSD distribution across the threshold
     Xc = syn.continuous_ensemble(n_conf, n_atoms, seed=11, thr=MAX_RMSD)
     with fc.DeviceEnsemble(Xc, center=True) as ec:
         ec.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=2, want_mask=False)
-        kc, sc, mc, stc = ec.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=max(2, min(steps, 20)), want_mask=True)
+        kc, sc, mc, stc = ec.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=20, want_mask=True)
         kind_c = _lib.screen_last_kind()
-    out["config"]["secondary"] = {
+        refine = ec.bench_refine(MAX_RMSD, 2 * MAX_RMSD, reps=20) if hasattr(ec, "bench_refine") else None
+    sec = {
         "workload": f"{n_conf} x {n_atoms}, continuous RMSD distribution (6 collective modes, ~1.5 % of the pairs below "
                     f"{MAX_RMSD} A, smooth density across the threshold): the case the clustered ensemble does not exercise",
-        "ms_per_step": sc, "value": pairs_total / (sc * 1e-3), "screen_kernel_ms": kc,
+        "ms_per_step": sc, "pair_decisions_per_s": pairs_total / (sc * 1e-3), "screen_kernel_ms": kc,
         "screen": {16: "f16x2", 32: "f32"}.get(kind_c, "f64"), "candidates_refined": int(stc[1]), "similar_pairs": int(stc[2]),
         "survivors": int(mc.sum())}
-    # (e) BASELINE's second metric as SURVEY 8d words it: host arrays in -> mask out, H2D / D2H included
+    if refine is not None:
+        r_ms, n_cand = refine
+        bpa = 2 * n_atoms * 24 + 16
+        gbs = n_cand * bpa / (r_ms * 1e-3) / 1e9
+        sec["refine"] = {"kernel": "k_simbits_refine", "kernel_ms": r_ms, "candidates": int(n_cand),
+                         "alignments_per_s": n_cand / (r_ms * 1e-3),
+                         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                      "algorithmic_bytes_per_alignment": bpa, "traffic": None,
+                                      "note": "the kernel north_star describes: one exact fp64 alignment (rotation, rmsd, max deviation) "
+                                              "per queued candidate pair, both conformers fetched per pair; SURVEY 8d bytes against 8 TB/s"}}
+    out["config"]["secondary"] = sec
+    # (d) BASELINE's second metric as SURVEY 8d words it: host arrays in -> mask out, H2D / D2H included
     fc.pruner.prune_by_rmsd(coords[:2000], atoms, MAX_RMSD)
     ts = []
     for _ in range(5):

@@ -19,7 +19,7 @@ int launch_prep(const double *, int64_t, int64_t, const int32_t *, int64_t, int,
 int launch_pairs_exact(const fc_ensemble *, const int64_t *, const int64_t *, int64_t, double *,
                        double *, double *);
 int launch_matrix_exact(const fc_ensemble *, double *, double *);
-int launch_rmsd_values(fc_ensemble *, double, double *, double *);
+int launch_rmsd_values(fc_ensemble *, double, double *, double *, int64_t rank = 0, int64_t world = 1);
 void screen_select(int);
 int launch_simbits_screen(fc_ensemble *, double);
 int ensure_h2_operands(fc_ensemble *, double *);
@@ -823,6 +823,10 @@ static int bench_rmsd_and_max_all(fc_ensemble *ens, int64_t reps, double *ms_ker
   FC_TRY(dr.reserve(bytes));
   FC_TRY(dm.reserve(bytes));
   const bool tiled = rmsd_and_max_tiled(ens);
+  // under a communicator (or the loopback hook) a rank computes the rows dealt to it: the units shard with
+  // no exchange; every rank keeps its rows of the two matrices
+  const int64_t rank = comm_rank(), world = comm_world();
+  FC_REQUIRE(tiled || world == 1, "structures beyond the tiled kernel are not sharded");
   if (tiled) FC_TRY(ensemble_shard(ens, 0, 1, 256));
   std::vector<hipEvent_t> &ev = c.ev_pool;
   while ((int64_t)ev.size() < 2 * reps + 2) {
@@ -836,7 +840,7 @@ static int bench_rmsd_and_max_all(fc_ensemble *ens, int64_t reps, double *ms_ker
       FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 16 * sizeof(uint64_t), c.stream));
       FC_HIP_TRY(hipEventRecord(ev[2 * r], c.stream));
       c.mark_after_screen = ev[2 * r + 1];  // recorded right behind the tiled kernel, in front of the fix-up
-      const int rc = launch_rmsd_values(ens, 0.0, dr.as<double>(), dm.as<double>());
+      const int rc = launch_rmsd_values(ens, 0.0, dr.as<double>(), dm.as<double>(), rank, world);
       c.mark_after_screen = nullptr;
       FC_TRY(rc);
     } else {
@@ -860,7 +864,12 @@ static int bench_rmsd_and_max_all(fc_ensemble *ens, int64_t reps, double *ms_ker
   if (ms_kernel_mean) *ms_kernel_mean = sum / (double)reps;
   if (ms_total) *ms_total = tot;
   if (stats) {
-    stats[0] = N * (N - 1) / 2;
+    // pairs this rank computed: rows of its blocks of 128, columns right of the diagonal
+    int64_t own = 0;
+    const int64_t nb = ceil_div(N, (int64_t)128);
+    for (int64_t lb = 0, b; (b = global_block(lb, rank, world)) < nb; ++lb)
+      for (int64_t i = b * 128; i < std::min<int64_t>(N, (b + 1) * 128); ++i) own += N - 1 - i;
+    stats[0] = own;
     stats[1] = (int64_t)cnt[6];
     stats[2] = tiled ? 1 : 0;
   }

@@ -135,8 +135,8 @@ int fc_comm_unique_id(uint8_t *id_out) {
   FC_API_LOCK;
   FC_REQUIRE(id_out != nullptr, "id_out is NULL");
   static_assert(sizeof(ncclUniqueId) == FC_COMM_ID_BYTES, "FC_COMM_ID_BYTES must match ncclUniqueId");
+  FC_TRY(load_rccl(comm().api));  // first: the loader's own failure modes are testable without a device
   FC_TRY(ensure_init());
-  FC_TRY(load_rccl(comm().api));
   ncclUniqueId id;
   FC_NCCL_TRY(comm().api.GetUniqueId(&id));
   std::memcpy(id_out, &id, sizeof id);

@@ -2505,10 +2505,14 @@ static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks, bool
 // all-pairs RMSD values on the matrix pipe (world == 1 layout); rmsd_dev: (N, N), pre-zeroed.
 // maxdev_dev != nullptr: the complete alignment of every pair -- (rmsd, maxdev) from the explicit
 // rotated difference (MODE 2 of the kernel); pairs it could not rotate are redone by the fix-up.
-int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, double *maxdev_dev) {
+int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, double *maxdev_dev, int64_t rank,
+                       int64_t world) {
+  // rank / world: this launch covers the row blocks (of 128) dealt to `rank` in snake order -- the rows a
+  // rank of the multi-GPU bench owns; (0, 1) = the whole upper triangle
   const int64_t NT = e->Npad >> 6;
   const int64_t rb = 128;
-  const int64_t n_lblocks = ceil_div(e->N, rb);
+  const int64_t n_lblocks = local_block_count(ceil_div(e->N, rb), rank, world);
+  if (n_lblocks <= 0) return FC_OK;
   const size_t lds_m = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)rb) * sizeof(double) + kStageBytes;
   if (lds_m > kLdsLimit || NT == 0)
     return set_error(FC_E_LIMIT, "A=%lld atoms exceed the LDS column tile of the value kernel", (long long)e->A);
@@ -2529,7 +2533,7 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
   // one workgroup per upper-triangle item (see launch_simbits_screen); the value kernel uses
   // the world == 1 layout with its own row block, so it keeps its own table
   const int64_t saved_rank = e->rank, saved_world = e->world, saved_rb = e->row_block;
-  e->rank = 0; e->world = 1; e->row_block = rb;
+  e->rank = rank; e->world = world; e->row_block = rb;
   const int rc_tbl = screen_item_table(e, NT, n_lblocks);
   e->rank = saved_rank; e->world = saved_world; e->row_block = saved_rb;
   e->item_key[3] = -1;  // the table was built for rb, not for the ensemble's own sharding
@@ -2543,7 +2547,7 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
 #define FC_LAUNCH_VALUES(NW_, MODE_)                                                                      \
   hipLaunchKernelGGL((k_simbits_screen_mfma<NW_, MODE_>), grid, dim3(NW_ * 64), lds_m, ctx().stream,      \
                      e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,   \
-                     (int64_t)0, (int64_t)1, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),        \
+                     rank, world, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),                   \
                      (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev, nullptr, maxdev_dev)
   if (complete) {
     if (two_blocks) FC_LAUNCH_VALUES(4, 2);

@@ -39,6 +39,11 @@ def _id_file():
     explicit = os.environ.get("FC_COMM_ID_FILE")
     if explicit:
         return explicit
+    if not os.environ.get("MASTER_PORT") and not os.environ.get("TORCHELASTIC_RUN_ID"):
+        # srun / mpirun style launches: the ranks do not share a parent, so a name made of the parent's pid
+        # would differ from rank to rank and every rank but 0 would wait for the time-out
+        raise RuntimeError("several ranks without MASTER_PORT / TORCHELASTIC_RUN_ID: set FC_COMM_ID_FILE (a path every rank "
+                           "sees, new for each launch) or FC_COMM_ID (256 hex digits of fc_comm_unique_id)")
     import tempfile
 
     tag = "_".join([os.environ.get("MASTER_ADDR", "local").replace("/", "_"), os.environ.get("MASTER_PORT", "0"),
@@ -46,7 +51,7 @@ def _id_file():
     return os.path.join(tempfile.gettempdir(), f"fc_comm_{tag}.id")
 
 
-def comm_init_from_env(timeout_s=180.0):
+def comm_init_from_env(timeout_s=None):
     """Create the RCCL communicator of this launch from RANK / WORLD_SIZE / LOCAL_RANK and return
     (rank, world, local_rank).  Call it BEFORE any other GPU use in the process; it selects
     device LOCAL_RANK (``fc_init``).  Rank 0 makes the unique id (``fc_comm_unique_id``) and
@@ -56,6 +61,8 @@ def comm_init_from_env(timeout_s=180.0):
 
     from firecode_amd import _lib
 
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("FC_COMM_TIMEOUT_S", "180"))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the host driver supports nothing else

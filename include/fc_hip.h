@@ -515,8 +515,10 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
  * firecode/utils.py:499 for every pair, fp64) over the resident ensemble, enqueued back to back, the two
  * dense (N, N) outputs staying in HBM; one host wait.  ms_kernel_mean: HIP events on the kernel's stream
  * around the tiled kernel of every pass; ms_total: first launch to the end of the last pass (fix-up
- * kernels included).  stats[3]: pairs per pass, pairs the last pass sent to the Jacobi fix-up, 1 when
- * the tiled kernel ran (0: the one-wave-per-row kernel for structures beyond its LDS tile).
+ * kernels included).  stats[3]: pairs this rank computed per pass, pairs the last pass sent to the Jacobi
+ * fix-up, 1 when the tiled kernel ran (0: the one-wave-per-row kernel for structures beyond its LDS tile).
+ * Under a communicator (fc_comm_init) a rank computes the rows of the row blocks (of 128) dealt to it in
+ * snake order -- the units shard by row with no exchange -- and keeps its rows of the matrices.
  * FC_E_LIMIT: more degenerate pairs than the fix-up queue holds. */
 int fc_bench_rmsd_and_max_all(fc_ensemble *ens, int64_t reps, double *ms_kernel_mean, double *ms_total,
                               int64_t *stats);

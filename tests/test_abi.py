@@ -58,3 +58,22 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f"{f} imports the oracle"
                 assert "cpu_ref" not in src
+
+
+def test_rccl_loader_survives_a_name_that_does_not_load():
+    """fc_comm.cpp's loader tries FC_RCCL_LIB first and falls through to the standard names; a name that fails
+    to dlopen must cost an error string, not the process (dlerror() may be read once per failure).  Without a
+    device the call then ends in the library's ordinary no-device error."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from firecode_amd import _lib\n"
+            "try:\n"
+            "    _lib.comm_unique_id(); print('ID')\n"
+            "except _lib.FirecodeHipError as e:\n"
+            "    print('ERR', type(e).__name__)\n") % ROOT
+    env = dict(os.environ, FC_RCCL_LIB="/nonexistent/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert out.stdout.split()[0] in ("ID", "ERR")
