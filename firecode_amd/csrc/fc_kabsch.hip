@@ -802,7 +802,10 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
           // 16-byte reads per coordinate), both requested one atom ahead of their use (ping-pong register
           // sets), d = p - R q as three fused chains on -R.  (First version: lane = 4 rows x 1 column, the
           // loop waiting on its own loads: 4.7 ms per 10^4 x 10^4; with the requests ahead 4.3 ms -- it was
-          // bound by its 138 M vector-memory instructions, one per 7.6 vector instructions.)
+          // bound by its 138 M vector-memory instructions, one per 7.6 vector instructions; this layout
+          // 3.1 ms.  The fp64 MFMA and the fp64 vector instructions share the DP units on gfx950
+          // (SQ_VALU_MFMA_COEXEC_CYCLES = 0): a variant that issued the NEXT unit's covariance inside this
+          // atom pass -- one MFMA in front of every 28 vector instructions -- took 3.5 ms and was not kept.)
           // Pairs whose largest eigenvalue is not clearly simple are queued for k_rmsd_fix_small (Jacobi).
           const int i = ib32 + l15;
           const int jb = (int)j0 + cs * 16 + 4 * kq;
@@ -812,14 +815,12 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const double Gq_r = ldsG[cs * 16 + 4 * kq + r];
-            double B9[9], Q4[4], R9[9];
+            double B9[9], Q4[4];
 #pragma unroll
             for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
             ok4[r] = kabsch_quaternion_qcp(B9, Gp + Gq_r, Q4);
             if (!ok4[r]) Q4[0] = 1.0, Q4[1] = 0.0, Q4[2] = 0.0, Q4[3] = 0.0;
-            rotation_from_quaternion(Q4, R9);
-#pragma unroll
-            for (int e = 0; e < 9; ++e) nR[r][e] = -R9[e];
+            neg_rotation_from_quaternion(Q4, nR[r]);
           }
           typedef double d2_t __attribute__((ext_vector_type(2)));
           const double *__restrict__ qcol = lds + cs * 32 + 4 * kq;

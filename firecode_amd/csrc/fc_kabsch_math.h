@@ -530,4 +530,19 @@ __host__ __device__ __forceinline__ void rotation_from_quaternion(const double (
   R[8] = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
 }
 
+// -R of the same quaternion (the complete-alignment epilogue forms p - R q as fused chains on -R)
+__host__ __device__ __forceinline__ void neg_rotation_from_quaternion(const double (&Q)[4], double (&R)[9]) {
+#pragma clang fp contract(fast)
+  const double q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3];
+  R[0] = q2 * q2 + q3 * q3 - q0 * q0 - q1 * q1;
+  R[1] = -2.0 * (q1 * q2 - q0 * q3);
+  R[2] = -2.0 * (q1 * q3 + q0 * q2);
+  R[3] = -2.0 * (q1 * q2 + q0 * q3);
+  R[4] = q1 * q1 + q3 * q3 - q0 * q0 - q2 * q2;
+  R[5] = -2.0 * (q2 * q3 - q0 * q1);
+  R[6] = -2.0 * (q1 * q3 - q0 * q2);
+  R[7] = -2.0 * (q2 * q3 + q0 * q1);
+  R[8] = q1 * q1 + q2 * q2 - q0 * q0 - q3 * q3;
+}
+
 }  // namespace fc

@@ -15,6 +15,31 @@ from firecode_amd.pruner import prune_by_moment_of_inertia, prune_by_rmsd
 from firecode_amd.pt import pt
 
 
+_ENERGY = re.compile(r"-*\d+\.\d+")
+
+
+def _comment_line_energies(text, n_frames):
+    """The first decimal number of every frame's comment line (firecode/ensemble.py:58-98 reads the energies of
+    a multi-frame .xyz from there), frame by frame through the line list: count line, comment line, that many
+    atom lines.  A truncated last frame ends the walk (the reference swallows the end of the file the same way);
+    a comment line without a number raises ValueError (the reference then trips over the atom lines)."""
+    lines = text.splitlines()
+    out, k = [], 0
+    while k < len(lines) and len(out) < n_frames:
+        if not lines[k].strip():
+            k += 1
+            continue
+        n_atoms = int(lines[k])
+        if k + 1 >= len(lines):
+            break
+        found = _ENERGY.search(lines[k + 1])
+        if found is None:
+            raise ValueError(f"no energy in the comment line of frame {len(out)}: {lines[k + 1]!r}")
+        out.append(float(found.group()))
+        k += 2 + n_atoms
+    return out
+
+
 @dataclass
 class Ensemble:
     atoms: np.ndarray
@@ -33,27 +58,9 @@ class Ensemble:
         from firecode_amd._lib import xyz_read
 
         atoms, coords = xyz_read(file)
-        energies = []
-        if read_energies:
-            with Path(file).open() as f:
-                for num in f:
-                    try:
-                        if not num.strip():
-                            continue
-                        energies.append(float(next(re.finditer(r"-*\d+\.\d+", next(f))).group()))
-                        for _ in range(int(num)):
-                            next(f)
-                    except StopIteration:
-                        pass
-            energies = energies[: len(coords)]
-        return cls(
-            atoms=atoms,
-            coords=coords,
-            filename=str(file),
-            basename=Path(str(file)).stem,
-            atomnos=np.array([pt.number(letter) for letter in atoms]),
-            energies=np.array(energies),
-        )
+        energies = np.array(_comment_line_energies(Path(file).read_text(), len(coords)) if read_energies else [])
+        return cls(atoms=atoms, coords=coords, filename=str(file), basename=Path(str(file)).stem,
+                   atomnos=np.array([pt.number(letter) for letter in atoms]), energies=energies)
 
     def to_xyz(self, file):
         """firecode/ensemble.py:284-297 -- byte-identical text, written by the library."""
@@ -66,37 +73,34 @@ class Ensemble:
         return self.energies - np.min(self.energies)
 
     def apply_mask(self, attributes, mask):
-        """firecode/ensemble.py:175-183."""
-        for attr in attributes:
-            if hasattr(self, attr):
-                try:
-                    setattr(self, attr, getattr(self, attr)[mask])
-                except IndexError:
-                    pass
+        """firecode/ensemble.py:175-183: keep the masked entries of every named array that has one entry
+        per structure; attributes that are missing or of another length (empty ``energies``) stay as they are."""
+        mask = np.asarray(mask)
+        for name in attributes:
+            values = getattr(self, name, None)
+            if values is not None and (mask.dtype != bool or len(values) == len(mask)):
+                setattr(self, name, values[mask])
 
     def dynamic_energy_thr(self, kcal_thr=10.0, keep_min=0.1, verbose=True):
-        """firecode/ensemble.py:134-169."""
-        active = len(self.coords)
-        keep = np.count_nonzero(self.rel_energies < kcal_thr)
-        if keep / active > keep_min:
-            return kcal_thr
-        for thr in (energy for energy in self.rel_energies if energy > kcal_thr):
-            keep = np.count_nonzero(self.rel_energies < thr)
-            if keep / active > keep_min:
-                if verbose and self.logfunction is not None:
-                    self.logfunction(f"--> Dynamically adjusted energy threshold to {thr:.1f} kcal/mol to retain "
-                                     f"at least {(keep / active) * 100:.2f}% of structures.")
-                return float(thr)
-        return kcal_thr
+        """firecode/ensemble.py:134-169: ``kcal_thr`` if it keeps more than ``keep_min`` of the structures,
+        otherwise the first energy (in ensemble order) above it that does."""
+        from firecode_amd.refining import first_threshold_keeping
+
+        thr, kept = first_threshold_keeping(self.rel_energies, kcal_thr, keep_min)
+        if kept is not None and verbose and self.logfunction is not None:
+            self.logfunction(f"--> Dynamically adjusted energy threshold to {thr:.1f} kcal/mol to retain "
+                             f"at least {kept * 100:.2f}% of structures.")
+        return thr
 
     def energy_pruning(self, kcal_thr=10.0, verbose=True):
         """firecode/ensemble.py:117-132."""
         energy_thr = self.dynamic_energy_thr(kcal_thr, verbose=verbose)
-        mask = self.rel_energies < energy_thr
-        self.apply_mask(("coords", "energies"), mask)
-        if False in mask and verbose and self.logfunction is not None:
-            self.logfunction(f"Discarded {len(mask) - np.count_nonzero(mask)} candidates for energy "
-                             f"({np.count_nonzero(mask)} left, threshold {energy_thr:.1f} kcal/mol)")
+        keep = self.rel_energies < energy_thr
+        self.apply_mask(("coords", "energies"), keep)
+        n_kept = int(np.count_nonzero(keep))
+        if n_kept < len(keep) and verbose and self.logfunction is not None:
+            self.logfunction(f"Discarded {len(keep) - n_kept} candidates for energy "
+                             f"({n_kept} left, threshold {energy_thr:.1f} kcal/mol)")
 
     def sort_by_energy(self):
         order = np.argsort(self.energies)

@@ -40,19 +40,30 @@ def fitness_refining(structures, constrained_indices, constrained_distances, thr
     return mask
 
 
+def first_threshold_keeping(rel, kcal_thresh, keep_min):
+    """The rule shared by ensemble.py:134-169 and embedder.py:1365-1395 without their loop: ``kcal_thresh`` when
+    it keeps more than ``keep_min`` of the structures, else the first relative energy (in array order) above
+    it that does, else ``kcal_thresh`` -> (threshold, fraction kept by it or None when unchanged).  The number of
+    structures strictly below a candidate is its rank in the sorted energies: one sort, one searchsorted."""
+    rel = np.asarray(rel, dtype=np.float64)
+    n = len(rel)
+    if np.count_nonzero(rel < kcal_thresh) / n > keep_min:
+        return kcal_thresh, None
+    below = np.searchsorted(np.sort(rel), rel, side="left")
+    ok = (rel > kcal_thresh) & (below / n > keep_min)
+    if not ok.any():
+        return kcal_thresh, None
+    first = int(np.argmax(ok))
+    return float(rel[first]), below[first] / n
+
+
 def dynamic_energy_thr(energies, kcal_thresh=10.0, keep_min=0.1, logfunction=None):
     """embedder.py:1365-1395."""
-    rel = np.asarray(energies) - np.min(energies)
-    active = len(rel)
-    if np.count_nonzero(rel < kcal_thresh) / active > keep_min:
-        return kcal_thresh
-    for thr in (e for e in rel if e > kcal_thresh):
-        keep = np.count_nonzero(rel < thr)
-        if keep / active > keep_min:
-            _log(logfunction, f"--> Dynamically adjusted energy threshold to {thr:.1f} kcal/mol to retain at "
-                              f"least {(keep / active) * 100:.2f}% of structures.")
-            return float(thr)
-    return kcal_thresh
+    thr, kept = first_threshold_keeping(np.asarray(energies) - np.min(energies), kcal_thresh, keep_min)
+    if kept is not None:
+        _log(logfunction, f"--> Dynamically adjusted energy threshold to {thr:.1f} kcal/mol to retain at "
+                          f"least {kept * 100:.2f}% of structures.")
+    return thr
 
 
 def energy_pruning(energies, kcal_thresh=10.0, logfunction=None):

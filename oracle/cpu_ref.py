@@ -141,6 +141,35 @@ def rmsd_and_max_batch(P, Q, center=False):
     return np.sqrt(sq.sum(axis=1) / P.shape[1]), np.sqrt(sq).max(axis=1)
 
 
+def rotation_error_bound_batch(P, Q, center=False):
+    """How far two correct float64 evaluations of ``rmsd_and_max`` may differ in the MAX DEVIATION of a
+    pair (test infrastructure: the tolerance the GPU parity tests apply where the optimum is ill-conditioned;
+    no reference counterpart).  With the singular values f1 >= f2 >= |f3| of the covariance B (f3 signed by
+    det B) the optimal rotation moves by |dR| <= |dB| / (f2 + f3) to first order (the smallest gap of the
+    polar factor), two summation orders of B differ by |dB| <= 2 A eps sum |p||q| <= 2 A eps (Gp + Gq)/2, and
+    a rotation error dR moves an atom at radius r by r |dR|:
+
+        bound = (2 A + 8) eps (Gp + Gq)/2 / (f2 + f3) * r_max   (+ the caller's floor for plain rounding)
+
+    -> array (K,); inf where the rotation is not unique (f2 + f3 = 0: collinear structures, exact mirror
+    images).  The RMSD itself is stationary at the optimum: no such term there."""
+    P = np.array(P, dtype=np.float64)
+    Q = np.array(Q, dtype=np.float64)
+    if center:
+        P -= P.mean(axis=1, keepdims=True)
+        Q -= Q.mean(axis=1, keepdims=True)
+    B = np.einsum("kai,kaj->kij", P, Q)
+    f = np.linalg.svd(B, compute_uv=False)
+    gap = f[:, 1] + np.sign(np.linalg.det(B)) * f[:, 2]
+    S = 0.5 * ((P * P).sum(axis=(1, 2)) + (Q * Q).sum(axis=(1, 2)))
+    rmax = np.sqrt(np.maximum((P * P).sum(axis=2).max(axis=1), (Q * Q).sum(axis=2).max(axis=1)))
+    eps = np.finfo(np.float64).eps
+    with np.errstate(divide="ignore", invalid="ignore"):
+        bound = (2 * P.shape[1] + 8) * eps * S / gap * rmax
+    bound[~(gap > 1e-12 * S)] = np.inf
+    return bound
+
+
 def rmsd_similarity(ref, structures, rmsd_thr=0.5):
     """firecode/utils.py:494-504, literal."""
     for structure in structures:
@@ -891,3 +920,18 @@ def string_embed(m1, m2, centers1, orbvecs1, centers2, orbvecs2, angles, quadrup
                 ok.append(good)
                 acc.append(new)
     return np.array(ok), np.array(acc), np.array(poses)
+
+
+def dynamic_energy_thr(rel_energies, kcal_thr=10.0, keep_min=0.1):
+    """firecode/ensemble.py:134-169 (== embedder.py:1365-1395), literal: the loop over the energies above
+    ``kcal_thr`` in array order, returning the first that keeps more than ``keep_min`` of the structures."""
+    rel_energies = np.asarray(rel_energies, dtype=np.float64)
+    active = len(rel_energies)
+    keep = np.count_nonzero(rel_energies < kcal_thr)
+    if keep / active > keep_min:
+        return kcal_thr
+    for thr in (energy for energy in rel_energies if energy > kcal_thr):
+        keep = np.count_nonzero(rel_energies < thr)
+        if keep / active > keep_min:
+            return float(thr)
+    return kcal_thr

@@ -101,7 +101,7 @@ def test_cfg3_full_scan_samples_and_tfd(fc):
     new = np.concatenate([base[None], out])[keep]
     del out
     tf = fc.torsion_module.get_tf_mat(new, torsions)
-    assert np.abs(tf[pick] - o.get_tf_mat(new[pick], torsions)).max() < 1e-9
+    assert np.abs(tf[pick] - o.get_tf_mat(new[pick], torsions)).max() < TOL
     mask = fc.torsion_module.prune_tfd_from_tf_mat(tf, 10)
     assert 0 < mask.sum() < len(mask)
     # first match at this size: bounded look-ahead + column chunks with window boxes (the default for long arrays)

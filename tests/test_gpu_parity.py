@@ -27,11 +27,11 @@ def test_rmsd_and_max_pairs(fc):
     r, m = fc.rmsd.rmsd_and_max_batch(X, iu, ju, center=True)
     r0, m0 = o.rmsd_and_max_batch(X[iu], X[ju], center=True)
     assert np.abs(r - r0).max() < TOL
-    # similar pairs have a well-conditioned optimum: max deviation to 1e-10
-    close = r0 < 1.0
-    assert close.sum() > 50
-    assert np.abs(m - m0)[close].max() < TOL
-    assert np.abs(m - m0).max() < 1e-8
+    # max deviation: 1e-10, widened only by the pair's own conditioning (oracle.rotation_error_bound_batch:
+    # (2A + 8) eps (Gp + Gq)/2 / (f2 + f3) r_max -- how far two correct float64 evaluations may differ)
+    bound = o.rotation_error_bound_batch(X[iu], X[ju], center=True)
+    assert np.all(np.abs(m - m0) <= TOL + bound)
+    assert (bound < TOL).mean() > 0.99  # ... which is below the tolerance itself for nearly every pair
 
 
 def test_rmsd_and_max_single_no_center(fc):
@@ -316,7 +316,7 @@ def test_moments_and_moi_prune(fc):
     masses = np.array([o.MASSES_TABLE[a] for a in atoms])
     mom = fc.algebra.get_inertia_moments_batch(X, masses)
     mom0 = np.array([o.get_inertia_moments(x, masses) for x in X])
-    assert np.abs(mom - mom0).max() < 1e-9 * mom0.max()
+    assert np.abs(mom - mom0).max() < 1e-13 * mom0.max()  # amu A^2 of size 1e3..1e5: relative, ~500 eps (symmetric eigenvalues are perfectly conditioned)
     _, ref = o.prune_by_moment_of_inertia(X, atoms)
     _, mask = fc.pruner.prune_by_moment_of_inertia(X, atoms)
     assert np.array_equal(mask, ref)
@@ -470,7 +470,7 @@ def test_scan_with_fingerprints_equals_two_passes(fc):
     tf3, rot3, out3 = fc.torsion_module.torsion_scan_fingerprints(base, tors, masks, angles, quads, want_coords=True)
     assert np.array_equal(rot, rot2) and np.array_equal(rot, rot3) and np.array_equal(out, out3)
     assert np.array_equal(tf, fc.torsion_module.get_tf_mat(out, quads)) and np.array_equal(tf, tf3)
-    assert np.abs(tf - o.get_tf_mat(o.torsion_scan(base, tors, masks, angles)[0], quads)).max() < 1e-9
+    assert np.abs(tf - o.get_tf_mat(o.torsion_scan(base, tors, masks, angles)[0], quads)).max() < TOL
 
 
 @pytest.mark.parametrize("q", [2, 5, 11])
@@ -911,14 +911,14 @@ def test_trimolecular_cyclical_embed_vs_oracle(fc, seed, thresh, pairing):
                 continue
             n_run += 1
             _, _, _, d_ref, p_ref, a_ref = groups[key]
-            assert np.abs(det["directions"][j, v] - d_ref).max() < 1e-9
+            assert np.abs(det["directions"][j, v] - d_ref).max() < TOL
             assert np.array_equal(det["passed"][j, v], p_ref)
             assert np.array_equal(det["accepted"][j, v], a_ref)
     assert n_run == len(trace) and n_run > 0
     if pairing:
         assert 0 < n_run < 8 * len(det["jobs"])
     assert poses.shape == ref_poses.shape and len(poses) > 0
-    assert np.abs(poses - ref_poses).max() < 1e-9
+    assert np.abs(poses - ref_poses).max() < TOL
     assert np.array_equal(ci, ref_ci)
     if thresh < 1.0:  # the accept filter had something to reject
         assert det["passed"].sum() > det["accepted"].sum()
@@ -1130,7 +1130,7 @@ def test_bimolecular_cyclical_embed_driver_vs_oracle(fc, seed, thresh, delta, pa
     poses, ci = fc.embeds.cyclical_embed_bimolecular(mols, angles, pairings_table=table, clash_thresh=thresh,
                                                      max_norm_delta=delta)
     assert poses.shape == ref_poses.shape and len(poses) > 0
-    assert np.abs(poses - ref_poses).max() < 1e-9
+    assert np.abs(poses - ref_poses).max() < TOL
     assert np.array_equal(ci, ref_ci)
     n_jobs_all = 2 * 3 * 2 * 2
     if delta < 1.0:
@@ -1227,10 +1227,12 @@ def test_rmsd_and_max_all_pairs_tiled_kernel(fc):
     r0, d0 = o.rmsd_and_max_batch(X[iu], X[ju], center=True)
     assert np.abs(R[iu, ju] - r0).max() < TOL and np.array_equal(R, R2) and np.array_equal(D, D2)
     assert np.allclose(R, R.T) and np.all(np.diag(R) == 0) and np.allclose(D, D.T)
-    # the max deviation is only defined up to the choice among equally good rotations where the
-    # optimum is degenerate (collinear structure); everywhere else it matches
-    ok = (iu != 21) & (ju != 21)
-    assert np.abs(D[iu, ju] - d0)[ok].max() < 1e-8
+    # the max deviation is only defined up to the choice among equally good rotations where the optimum is
+    # degenerate (the collinear structure: bound = inf); everywhere else 1e-10 + the pair's conditioning bound
+    bound = o.rotation_error_bound_batch(X[iu], X[ju], center=True)
+    assert np.all(np.isinf(bound) == ((iu == 21) | (ju == 21)))
+    assert np.all(np.abs(D[iu, ju] - d0) <= TOL + bound)
+    assert (bound < TOL).mean() > 0.95
     assert R[4, 5] < 1e-12 and R[8, 9] < 1e-7
 
 

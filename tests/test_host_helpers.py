@@ -138,3 +138,32 @@ def test_cartesian_product_native_equals_numpy(golden):
     for arrays in cases:
         mine, want = cartesian_product(*arrays), ref(*arrays)
         assert mine.shape == want.shape and mine.dtype == want.dtype and np.array_equal(mine, want)
+
+
+def test_ensemble_energy_threshold_against_the_reference_vectors_and_the_literal_loop(golden):
+    """Ensemble.dynamic_energy_thr / energy_pruning (firecode/ensemble.py:117-169) without the reference's loop:
+    the vectors its own methods produced, and the literal loop on energies in RANDOM order (the rule returns
+    the first qualifying energy in array order, not the smallest), with ties and with nothing qualifying"""
+    from firecode_amd import refining
+    from firecode_amd.ensemble import Ensemble
+    from oracle import cpu_ref as o
+
+    en = np.asarray(golden["enp_energies"])
+    e = Ensemble(atoms=np.array(["C"] * 7), coords=np.zeros((len(en), 7, 3)), energies=en.copy(), logfunction=None)
+    assert e.dynamic_energy_thr(10.0, verbose=False) == float(golden["enp_thr10"])
+    assert e.dynamic_energy_thr(0.5, verbose=False) == float(golden["enp_thr0p5"])
+    e.energy_pruning(10.0, verbose=False)
+    assert len(e.coords) == int(golden["enp_kept10"]) == len(e.energies)
+    rng = np.random.default_rng(9)
+    for trial in range(300):
+        n = int(rng.integers(1, 40))
+        rel = np.round(rng.uniform(0, 30, size=n), 1 if trial % 2 else 6)   # one decimal: ties
+        rel[int(rng.integers(0, n))] = 0.0
+        thr, keep_min = float(rng.choice([0.05, 0.5, 3.0, 10.0, 40.0])), float(rng.choice([0.1, 0.5, 0.9]))
+        want = o.dynamic_energy_thr(rel, thr, keep_min)
+        assert refining.first_threshold_keeping(rel, thr, keep_min)[0] == want
+        msgs, shifted = [], rel + 5.0
+        want = o.dynamic_energy_thr(shifted - shifted.min(), thr, keep_min)
+        ens = Ensemble(atoms=np.array(["C"]), coords=np.zeros((n, 1, 3)), energies=shifted, logfunction=msgs.append)
+        assert ens.dynamic_energy_thr(thr, keep_min) == want and (len(msgs) == 1) == (want != thr)
+        assert refining.dynamic_energy_thr(shifted, thr, keep_min) == want

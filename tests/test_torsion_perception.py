@@ -1,11 +1,15 @@
-"""Host-side perception of locally symmetric torsions (firecode_amd/torsion_perception.py): the
-in-tree logic of firecode/torsion_module.py:69-269, 385-433 restated, over third-party graph
-helpers that are PARITY UNPINNED.  Checked on molecules whose answer chemistry dictates."""
+"""Host-side perception of locally symmetric torsions (firecode_amd/torsion_perception.py).  The product
+computes it its own way (flat tables, bridge search, colour refinement with an individualise-and-refine
+search); the checker is ``oracle/torsion_perception_ref.py``, the literal restatement of
+firecode/torsion_module.py:69-269, 385-433 (deepcopy + networkx).  Both must agree on the reference's
+fixture molecules and on random molecular graphs; a few molecules whose answer chemistry dictates are
+checked by hand.  The third-party graph helpers under both are PARITY UNPINNED."""
 
 import numpy as np
 import pytest
 
 from firecode_amd import torsion_perception as tp
+from oracle import torsion_perception_ref as ref
 
 nx = pytest.importorskip("networkx")
 
@@ -90,3 +94,117 @@ def test_graphize_and_perception_on_the_reference_fixture_molecule(golden):
     s = tp.symmetric_torsions(g, coords, atoms)
     assert len(s) == 2 and all(t[4] == 3 and g.nodes[t[2]]["atoms"] == "C" for t in s)
     assert tp.get_double_bonds_indices(coords, atoms) == []
+
+
+# ------------------------------------------------------------------------------------------
+# product == oracle
+# ------------------------------------------------------------------------------------------
+def _same_perception(g, coords=None, atoms=None):
+    """every public answer of the product against the literal restatement, on one graph"""
+    m = tp.MolGraph(g)
+    assert np.array_equal(tp.get_quadruplets(g), ref.get_quadruplets(g))
+    for n in g.nodes:
+        assert tp.get_sp_n(n, g) == ref.get_sp_n(n, g)
+        assert tp._is_free(n, g) == ref._is_free(n, g)
+        assert tp.is_ester_o(n, g) == ref.is_ester_o(n, g)
+        for mode in (-1, 0, 1, 2):
+            assert tp.is_amide_n(n, g, mode) == ref.is_amide_n(n, g, mode)
+    for u, v in g.edges:
+        if u == v:
+            continue
+        for i, root in ((u, v), (v, u)):
+            assert m.nondummy(i, root) == ref._is_nondummy(i, root, g), (i, root)
+    for keepdummy in (False, True):
+        for mode in ("csearch", "symmetry"):
+            mine = tp.get_torsions(g, keepdummy=keepdummy, mode=mode)
+            theirs = ref.get_torsions(g, keepdummy=keepdummy, mode=mode)
+            assert [(t.torsion, t.n_fold, t.get_angles()) for t in mine] == [(t.torsion, t.n_fold, t.get_angles()) for t in theirs]
+    for q in ref.get_quadruplets(g):
+        assert tp.Torsion(*q).in_cycle(g) == ref.Torsion(*q).in_cycle(g)
+    assert tp.symmetric_torsions(g, coords, atoms) == ref.symmetric_torsions(g, coords, atoms)
+    assert g.number_of_edges() == sum(len(x) for x in m.nbr.values()) // 2 + sum(1 for n in g.nodes if g.has_edge(n, n))
+
+
+@pytest.mark.parametrize("name", ["butane", "catalyst", "anti_to_gauche", "salt", "propane_ts", "c2h4_hyper"])
+def test_product_equals_oracle_on_the_reference_fixture_molecules(golden, name):
+    """the molecules of the reference's own test data (firecode/tests/**/*.xyz; catalyst.xyz is the 85-atom
+    input of its csearch test): graph from covalent radii, every perception answer compared"""
+    atoms = np.array([str(a) for a in golden[f"fx_{name}_atoms"]])
+    coords = np.asarray(golden[f"fx_{name}_coords"], dtype=float)
+    coords = coords[0] if coords.ndim == 3 else coords
+    g = tp.graphize(atoms, coords)
+    g_ref = ref.graphize(atoms, coords)
+    assert list(g.nodes) == list(g_ref.nodes) and sorted(map(sorted, g.edges)) == sorted(map(sorted, g_ref.edges))
+    assert all(g.nodes[n]["atoms"] == g_ref.nodes[n]["atoms"] for n in g.nodes)
+    assert tp.get_double_bonds_indices(coords, atoms) == ref.get_double_bonds_indices(coords, atoms)
+    _same_perception(g_ref, coords, atoms)   # the oracle's graph (its own adjacency order) ...
+    _same_perception(g, coords, atoms)       # ... and the product's
+
+
+def _random_molecule(rng, n_heavy, p_ring=0.15, hydrogens=True):
+    """a random organic-looking skeleton: heavy atoms attached one by one within valence, a few ring closures,
+    open valences filled with H (so that methyl / tBu / NMe2-like symmetric ends occur)"""
+    valence = {"C": 4, "N": 3, "O": 2, "S": 2, "F": 1, "Cl": 1}
+    sym, edges, free = [], [], []
+    for k in range(n_heavy):
+        el = rng.choice(["C", "C", "C", "C", "N", "O", "S", "F"] if k else ["C"])
+        if k:
+            open_ = [a for a in range(k) if free[a] > 0]
+            if not open_:
+                break
+            a = int(rng.choice(open_))
+            edges.append((a, k))
+            free[a] -= 1
+        sym.append(str(el))
+        free.append(valence[str(el)] - (1 if k else 0))
+    n = len(sym)
+    for _ in range(int(rng.binomial(n, p_ring))):
+        a, b = (int(x) for x in rng.choice(n, size=2, replace=False))
+        if free[a] > 0 and free[b] > 0 and (a, b) not in edges and (b, a) not in edges:
+            edges.append((a, b))
+            free[a] -= 1
+            free[b] -= 1
+    # unsaturation: leave some valences open instead of adding hydrogens
+    for a in range(n):
+        while hydrogens and free[a] > 0:
+            if rng.random() < 0.15:
+                free[a] -= 1
+                continue
+            sym.append("H")
+            edges.append((a, len(sym) - 1))
+            free[a] -= 1
+    order = rng.permutation(len(edges))  # adjacency order is part of the contract: shuffle it
+    return _graph(sym, [edges[k] if rng.random() < 0.5 else edges[k][::-1] for k in order])
+
+
+def test_product_equals_oracle_on_random_molecular_graphs():
+    rng = np.random.default_rng(2024)
+    n_sym = 0
+    for trial in range(150):
+        g = _random_molecule(rng, int(rng.integers(3, 22)), p_ring=0.0 if trial % 3 == 0 else 0.12)
+        _same_perception(g)
+        n_sym += len(tp.symmetric_torsions(g))
+    assert n_sym > 100  # the comparison is not vacuous
+
+
+def test_branch_isomorphism_is_exact_where_colour_refinement_alone_is_not():
+    """two branches that 1-dimensional colour refinement cannot tell apart -- a six-ring against two
+    three-rings, all carbons of degree two inside the branch -- hang off one carbon: NOT identical, so the
+    bond is a real (non-dummy) torsion; the individualise-and-refine stage decides it, as networkx does"""
+    sym = ["C", "C"] + ["C"] * 12
+    edges = [(0, 1)]
+    ring6 = list(range(2, 8))
+    tri_a, tri_b = [8, 9, 10], [11, 12, 13]
+    edges += [(ring6[k], ring6[(k + 1) % 6]) for k in range(6)]
+    edges += [(tri_a[k], tri_a[(k + 1) % 3]) for k in range(3)] + [(tri_b[k], tri_b[(k + 1) % 3]) for k in range(3)]
+    g = _graph(sym, edges)
+    m = tp.MolGraph(g)
+    assert m.isomorphic(tri_a, tri_b) and not m.isomorphic(ring6, tri_a + tri_b)
+    # attach the six-ring and ONE of the triangles... as whole branches of atom 1: ring6 vs (tri_a + bridge + tri_b)
+    g2 = _graph(sym + ["C"], edges + [(1, 2), (1, 8), (10, 14), (14, 11)])
+    assert tp.MolGraph(g2).nondummy(1, 0) == ref._is_nondummy(1, 0, g2) is True
+    # and two truly identical ring branches are dummy for both
+    sym3 = ["C", "C"] + ["C"] * 6
+    e3 = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 2), (1, 5), (5, 6), (6, 7), (7, 5)]
+    g3 = _graph(sym3, e3)
+    assert tp.MolGraph(g3).nondummy(1, 0) == ref._is_nondummy(1, 0, g3) is False
