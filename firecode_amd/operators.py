@@ -13,14 +13,16 @@ from time import perf_counter
 
 import numpy as np
 
-from firecode_amd.pruner import prune_by_moment_of_inertia, prune_by_rmsd
+from firecode_amd.pruner import prune_by_rmsd_rot_corr, prune_similarity
 from firecode_amd.utils import write_xyz
 
 
-def gpu_prune_operator(filename, embedder, moi=True, rmsd=True):
-    """Similarity-prune the ensemble of ``filename`` on the GPU (the prune triplet
-    the search operators end with, operators.py:613-632, without the size caps)
-    and write ``<basename>_gpu_pruned.xyz``."""
+def gpu_prune_operator(filename, embedder, moi=True, rmsd=True, rmsd_rot_corr=True):
+    """Similarity-prune the ensemble of ``filename`` on the GPU with the triplet the search operators end
+    with (firecode/operators.py:613-632): moment of inertia -> heavy-atom RMSD at ``options.rmsd`` -- both on
+    ONE upload of the coordinates (``prune_similarity``), without the reference's 5e4 cap on the RMSD stage --
+    then, below 1000 structures as there and when the molecule carries its bond graph (``mol.graph``), the
+    symmetry-corrected RMSD prune.  Writes ``<basename>_gpu_pruned.xyz``."""
     data = embedder.mols[filename]
     coords = np.asarray(data.coords, dtype=np.float64)
     embedder.log(f"--> GPU similarity pruning on {filename} ({len(coords)} structures)")
@@ -28,11 +30,15 @@ def gpu_prune_operator(filename, embedder, moi=True, rmsd=True):
     before = len(coords)
     debug = getattr(embedder, "debuglog", None)
     max_rmsd = embedder.options.rmsd if getattr(embedder.options, "rmsd", None) else 0.25
-    if moi:
-        coords, _ = prune_by_moment_of_inertia(coords, data.atoms, debugfunction=debug)
-    if rmsd:
-        coords, _ = prune_by_rmsd(coords, data.atoms, max_rmsd=max_rmsd, debugfunction=debug)
-    embedder.log(f"  Discarded {before - len(coords)} similar structures ({len(coords)} left, "
+    if moi or rmsd:
+        _, keep, counts = prune_similarity(coords, data.atoms, moi=moi, rmsd=rmsd, max_rmsd=max_rmsd)
+        coords = coords[keep]
+        if debug is not None:
+            debug(f"DEBUG: gpu_prune - MOI {int(counts[0])} -> {int(counts[1])}, RMSD -> {int(counts[2])} structures")
+    graph = getattr(data, "graph", None)
+    if rmsd and rmsd_rot_corr and graph is not None and len(coords) < 1e3:
+        coords, _ = prune_by_rmsd_rot_corr(coords, data.atoms, graph, max_rmsd=max_rmsd, debugfunction=debug)
+    embedder.log(f"  Discarded {before - len(coords)} RMSD-similar structures ({len(coords)} left, "
                  f"{perf_counter() - t0:.3f} s)\n")
     outname = data.basename + "_gpu_pruned.xyz"
     write_xyz(data.atoms, coords, outname, title="GPU-pruned conformer")

@@ -1188,6 +1188,57 @@ def test_gpu_prune_operator(fc, tmp_path, monkeypatch):
     assert ops.operate("mol.xyz", "gpu_prune", emb) == "mol.xyz"
 
 
+def test_gpu_prune_operator_runs_the_third_stage_with_the_molecule_graph(fc, tmp_path, monkeypatch):
+    """firecode/operators.py:613-632: MOI -> RMSD -> prune_by_rmsd_rot_corr(..., mol.graph, ...) below 1000
+    structures.  A chain ending in a tBu-like C(CH3)3 group whose conformers differ by 120-degree turns of that
+    group: the plain RMSD stage keeps them apart, the symmetry-corrected stage (given the graph) merges them."""
+    from types import SimpleNamespace
+
+    from firecode_amd import operators as ops
+    from firecode_amd import torsion_perception as tp
+
+    monkeypatch.chdir(tmp_path)
+    # C0-C1-C2-C3(-C4)(-C5)(-C6): tetrahedral quaternary carbon C3, three methyl carbons (heavy atoms only)
+    t = 1.54
+    c3 = np.array([0.0, 0.0, 0.0])
+    up = np.array([0.0, 0.0, 1.0])
+    ring = [np.array([np.cos(a), np.sin(a), 0.0]) for a in (0.3, 0.3 + 2 * np.pi / 3, 0.3 + 4 * np.pi / 3)]
+    methyls = [c3 + t * (0.3333 * up + 0.9428 * r) for r in ring]
+    base = np.array([c3 - 3 * t * up + np.array([1.2, 0.4, 0]), c3 - 2 * t * up + np.array([0.5, -0.3, 0]), c3 - t * up, c3] + methyls)
+    atoms = np.array(["C"] * 7)
+    rng = np.random.default_rng(5)
+    X = []
+    for k in range(12):
+        x = base + rng.normal(scale=0.01, size=base.shape)
+        # distort ONE methyl so that a plain 120-degree turn is not a relabelling the RMSD stage could undo
+        x[4] += np.array([0.0, 0.0, 0.35])
+        ang = (k % 3) * 2 * np.pi / 3
+        R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+        x[4:] = (x[4:] - c3) @ R.T + c3   # the tBu end turned about the C2-C3 axis
+        X.append(x @ _rot(rng).T + rng.normal(scale=3.0, size=3))
+    X = np.array(X)
+    g = tp.graphize(atoms, X[0])
+    assert g.number_of_edges() == 6 and any(t_[1:3] in ((2, 3), (3, 2)) for t_ in tp.symmetric_torsions(g))
+    logs = []
+    mol = SimpleNamespace(coords=X, atoms=atoms, basename="tbu", graph=g)
+    emb = SimpleNamespace(mols={"tbu.xyz": mol}, options=SimpleNamespace(rmsd=0.25, dryrun=False), log=logs.append, debuglog=logs.append)
+    out = ops.operate("tbu.xyz", "gpu_prune", emb)
+    _, c = fc._lib.xyz_read(tmp_path / out)
+    # oracle: the same three stages
+    _, m1 = o.prune_by_moment_of_inertia(X, atoms)
+    _, m2 = o.prune_by_rmsd(X[m1], atoms, 0.25)
+    tors = tp.symmetric_torsions(g, X[0], atoms)
+    quads = [t_[:4] for t_ in tors]
+    masks = [fc.pruner.rotation_mask(g, q, len(atoms)) for q in quads]  # == the reference's _get_rotation_mask (golden rotmask_out)
+    sets = [{2: (0, 180), 3: (0, 120, 240), 4: (0, 90, 180, 270), 6: (0, 60, 120, 180, 240, 300)}[t_[4]] for t_ in tors]
+    _, m3 = o.prune_by_rmsd_rot_corr(X[m1][m2], atoms, quads, masks, sets, max_rmsd=0.25)
+    assert len(c) == m3.sum() < m2.sum()            # the third stage removed structures the second kept
+    assert np.abs(c - np.round(X[m1][m2][m3], 6)).max() < 1e-6
+    mol.graph = None                                 # no graph: the first two stages only
+    out = ops.operate("tbu.xyz", "gpu_prune", emb)
+    assert len(fc._lib.xyz_read(tmp_path / out)[1]) == m2.sum()
+
+
 def test_rmsd_values_matrix(fc):
     """all-pairs RMSD values from the Newton / MFMA kernel (+ exact fix-up of tiny rmsd)"""
     X, atoms, asg = syn.synthetic_ensemble(700, 50, seed=81)
