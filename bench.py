@@ -654,7 +654,7 @@ def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_at
         ec.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=2, want_mask=False)
         kc, sc, mc, stc = ec.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=20, want_mask=True)
         kind_c = _lib.screen_last_kind()
-        refine = ec.bench_refine(MAX_RMSD, 2 * MAX_RMSD, reps=20) if hasattr(ec, "bench_refine") else None
+        refine = ec.bench_refine(MAX_RMSD, 2 * MAX_RMSD, reps=20)
     sec = {
         "workload": f"{n_conf} x {n_atoms}, continuous RMSD distribution (6 collective modes, ~1.5 % of the pairs below "
                     f"{MAX_RMSD} A, smooth density across the threshold): the case the clustered ensemble does not exercise",
@@ -665,7 +665,7 @@ def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_at
         r_ms, n_cand = refine
         bpa = 2 * n_atoms * 24 + 16
         gbs = n_cand * bpa / (r_ms * 1e-3) / 1e9
-        sec["refine"] = {"kernel": "k_simbits_refine", "kernel_ms": r_ms, "candidates": int(n_cand),
+        sec["refine"] = {"kernel": "k_refine_pairs", "kernel_ms": r_ms, "candidates": int(n_cand),
                          "alignments_per_s": n_cand / (r_ms * 1e-3),
                          "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_alignment": bpa, "traffic": None,

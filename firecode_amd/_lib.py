@@ -61,6 +61,7 @@ _SIGNATURES = {
     "fc_ensemble_rmsd_values": [_ens, _p_f64, _p_f64],
     "fc_ensemble_rmsd_and_max_all": [_ens, _p_f64, _p_f64, _p_f64],
     "fc_bench_rmsd_and_max_all": [_ens, _i64, _p_f64, _p_f64, _p_i64],
+    "fc_bench_refine": [_ens, _f64, _f64, _i64, _p_f64, _p_i64],
     "fc_screen_select": [C.c_int],
     "fc_prune_conventions": [C.c_int],
     "fc_prune_similarity": [_p_f64, _i64, _i64, _p_u8, _p_f64, C.c_int, _f64, C.c_int, _f64, _f64, _p_f64, _f64, _i64,
@@ -425,6 +426,12 @@ class DeviceEnsemble:
         ms = C.c_double(0)
         call("fc_ensemble_rmsd_and_max_all", self.handle, pf(r), pf(m), C.byref(ms))
         return r, m, ms.value
+
+    def bench_refine(self, max_rmsd, max_dev, reps=10):
+        """The exact refine alone over the candidate queue one screen leaves -> (mean kernel ms, candidates)."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        call("fc_bench_refine", self.handle, float(max_rmsd), float(max_dev), int(reps), C.byref(ms), C.byref(n))
+        return ms.value, n.value
 
     def bench_rmsd_and_max_all(self, reps=1):
         """``reps`` complete all-pairs alignment passes, outputs resident ->

@@ -2625,6 +2625,47 @@ int fc_screen_select(int kind) {
   return FC_OK;
 }
 
+int fc_bench_refine(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps, double *ms_refine,
+                    int64_t *n_candidates) {
+  FC_API_LOCK;
+  FC_REQUIRE(ens && reps >= 1 && reps <= 4096, "bad arguments");
+  FC_TRY(ensure_init());
+  FC_TRY(ensemble_shard(ens, 0, 1, default_row_block()));
+  Context &c = ctx();
+  // one screen fills the candidate-pair queue; then the exact refine alone, `reps` times over that queue
+  ens->lean = true;
+  FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, kCounters * sizeof(uint64_t), c.stream));
+  FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
+  std::vector<hipEvent_t> &ev = c.ev_pool;
+  while ((int64_t)ev.size() < 2 * reps) {
+    hipEvent_t e = nullptr;
+    FC_HIP_TRY(hipEventCreate(&e));
+    ev.push_back(e);
+  }
+  auto *cnt = reinterpret_cast<unsigned long long *>(ens->counters.p);
+  for (int64_t r = 0; r < reps; ++r) {
+    FC_HIP_TRY(hipMemsetAsync(cnt + 1, 0, 3 * sizeof(uint64_t), c.stream));  // refined / similar / grey
+    FC_HIP_TRY(hipEventRecord(ev[2 * r], c.stream));
+    FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
+    FC_HIP_TRY(hipEventRecord(ev[2 * r + 1], c.stream));
+  }
+  unsigned long long h[8] = {0};
+  FC_TRY(d2h(h, ens->counters.p, sizeof h));
+  FC_TRY(sync());
+  double sum = 0.0;
+  for (int64_t r = 0; r < reps; ++r) {
+    float ms = 0.f;
+    FC_HIP_TRY(hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]));
+    sum += ms;
+  }
+  if (ms_refine) *ms_refine = sum / (double)reps;
+  if (n_candidates) *n_candidates = (int64_t)h[1];
+  if (h[6] > (unsigned long long)ens->pairq_cap)
+    return set_error(FC_E_LIMIT, "the candidate-pair queue overflowed (%llu > %lld): this probe times the pair refine only",
+                     h[6], (long long)ens->pairq_cap);
+  return FC_OK;
+}
+
 int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
                         double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
                         int64_t *stats) {

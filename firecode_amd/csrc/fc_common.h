@@ -156,11 +156,13 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // A^2 added to max_rmsd^2 in the all-pairs screens (and in the refine's own early exit)
 constexpr double kScreenMargin = 1e-6;
 
-// uint64 words of fc_ensemble::counters: [0..10] queue lengths and flags, [16..) bucket fill
-// levels of the pair ladder, [11] "the fp64 screen has to run again" (k_screen_verdict),
+// uint64 words of fc_ensemble::counters: [0..10] queue lengths and flags, [11] "the fp64 screen has to run again" (k_screen_verdict),
 // [13] units queued by the subset stage of the lean fp32 screen, [15] its density verdict (1 = dense),
-// [63] scratch of the screen launcher
-constexpr size_t kCounters = 64;
+// [63] scratch of the screen launcher; [64 + 16 l] fill level of the pair ladder's bucket of level l -- ONE PER
+// 128-BYTE LINE: atomics on words of one line serialise at the memory side (18 level counters in three lines cost
+// k_pair_buckets 131 us on 7.6e5 similar pairs, one wave-wide atomic instruction per 64 pairs)
+constexpr size_t kCounters = 64 + 20 * 16;
+constexpr int kCntLevel = 64, kCntLevelStride = 16;
 
 // Row blocks of the bit matrix are dealt to ranks in snake order (0..W-1,
 // W-1..0, 0..W-1, ...): the work of a row block falls linearly with its index,

@@ -2178,6 +2178,136 @@ k_screen_rowsweep(const double *__restrict__ Xs, const double *__restrict__ G, i
 }
 
 // ---------------------------------------------------------------------------
+// k_refine_pairs: the exact fp64 decision of every queued candidate pair, ONE LANE PER PAIR on the
+// conformer-minor layout Xs (round 3; the pair mode of k_simbits_refine below is what it replaces).
+// The queue is written sub-tile by sub-tile of the screen (a ballot = up to 4 rows x 16 consecutive columns,
+// a workgroup's stage = one 128-row x 64-column item), so the 64 pairs of a wavefront name a handful of row
+// conformers and runs of consecutive column conformers: in Xs[(a*3 + c) * Npad + n] one load instruction then
+// touches 2-6 cache lines, where the 8-lanes-per-pair walk over the conformer-major copy touched 16-24
+// (192-byte pieces at a 24-byte lane stride) and spent 82 % of its wave cycles waiting (SQ_WAIT_ANY,
+// profiles/r03_pmc_secondary_before.txt: 0.73 ms for 8.9e5 candidates).  No shuffles, no group reductions:
+// covariance (9 fused multiply-adds per atom, operands one atom ahead), the fp64 screen polynomial, the rotation
+// as a quaternion (kabsch_quaternion_qcp; Jacobi sweeps where that declines), the explicit rotated difference on
+// -R, the decision -- all per lane.  Same outputs as the pair mode of k_simbits_refine: counters[1..3], simq, bits.
+// ---------------------------------------------------------------------------
+// counters words of the XCD-partitioned candidate queue (k_pairq_partition -> k_refine_pairs)
+__global__ void __launch_bounds__(256)
+k_refine_pairs(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N, int64_t Npad, int A,
+               double max_rmsd, double max_dev, const double *__restrict__ energies, double max_dE, int IB,
+               int64_t world, uint64_t *__restrict__ bits, int64_t W, unsigned long long *__restrict__ counters,
+               const uint64_t *__restrict__ pairq, unsigned long long Q, uint64_t *__restrict__ simq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const unsigned long long n_pairs = counters[6];
+  if (n_pairs > Q) return;  // the queue overflowed: the word queue (k_simbits_refine) holds the work
+  const int A2 = (A + 1) & ~1;  // Xs rows are padded to a multiple of 4 atoms with zeros
+  // (Splitting a long queue by column range into one part per XCD, each XCD drawing batches from its own part
+  // so that its 4 MB L2 sees an eighth of the column conformers, was built and measured on the 8.9e5-candidate
+  // ensemble: 0.62 ms + 0.08 ms for the split against 0.44 ms -- the parts interleave the row blocks that the
+  // screen's emission order keeps together.  Not kept.)
+  for (int64_t base = wave0 * 64; base < (int64_t)n_pairs; base += nwaves * 64) {
+    const bool on = base + lane < (int64_t)n_pairs;
+    const uint64_t e = pairq[on ? base + lane : base];
+    const unsigned i = (unsigned)(e >> 32), j = (unsigned)(e & 0xffffffffull);
+    double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_atom = [&](int a, double (&P)[3], double (&Qv)[3]) {
+      const int al = a < A2 ? a : A2 - 1;
+      const double *__restrict__ row = Xs + (int64_t)(al * 3) * Npad;  // wave-uniform
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        P[c] = (row + (int64_t)c * Npad)[i];
+        Qv[c] = (row + (int64_t)c * Npad)[j];
+      }
+    };
+    {
+      double PA[3], QA[3], PB[3], QB[3];
+      auto cov = [&](const double (&P)[3], const double (&Qv)[3]) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+          for (int y = 0; y < 3; ++y) B[x * 3 + y] = fma(P[x], Qv[y], B[x * 3 + y]);
+      };
+      load_atom(0, PA, QA);
+      for (int a = 0; a < A2; a += 2) {
+        load_atom(a + 1, PB, QB);
+        __builtin_amdgcn_sched_barrier(0);
+        cov(PA, QA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_atom(a + 2, PA, QA);
+        __builtin_amdgcn_sched_barrier(0);
+        cov(PB, QB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const double Gs = G[i] + G[j];
+    // the fp64 screen polynomial on this exact covariance first: the single-precision screens pass dissimilar
+    // pairs inside their band, and what the fp64 screen would have dropped needs neither a rotation nor a
+    // second pass over the atoms
+    const bool may = on && kabsch_may_be_below(B, Gs, (double)A * (max_rmsd * max_rmsd + kScreenMargin));
+    double ssq = 0.0, mx = 0.0;
+    if (__any(may)) {
+      double nR[9];
+      {
+        double Q4[4];
+        const bool fast = kabsch_quaternion_qcp(B, Gs, Q4);
+        if (__any(may && !fast)) {  // not clearly simple (symmetric or degenerate structures): the Jacobi sweeps
+          double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+          if (may && !fast) (void)kabsch_rotation(B, R);
+          if (fast) neg_rotation_from_quaternion(Q4, nR);
+          else
+#pragma unroll
+            for (int k = 0; k < 9; ++k) nR[k] = -R[k];
+        } else {
+          neg_rotation_from_quaternion(Q4, nR);
+        }
+      }
+      double PA[3], QA[3], PB[3], QB[3];
+      auto dev = [&](const double (&P)[3], const double (&Qv)[3]) {
+#pragma clang fp contract(fast)
+        const double dx = fma(nR[0], Qv[0], fma(nR[1], Qv[1], fma(nR[2], Qv[2], P[0])));
+        const double dy = fma(nR[3], Qv[0], fma(nR[4], Qv[1], fma(nR[5], Qv[2], P[1])));
+        const double dz = fma(nR[6], Qv[0], fma(nR[7], Qv[1], fma(nR[8], Qv[2], P[2])));
+        const double s2 = fma(dz, dz, fma(dy, dy, dx * dx));
+        ssq += s2;
+        asm("v_max_f64 %0, %0, %1" : "+v"(mx) : "v"(s2));
+      };
+      load_atom(0, PA, QA);
+      for (int a = 0; a < A2; a += 2) {
+        load_atom(a + 1, PB, QB);
+        __builtin_amdgcn_sched_barrier(0);
+        dev(PA, QA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_atom(a + 2, PA, QA);
+        __builtin_amdgcn_sched_barrier(0);
+        dev(PB, QB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    bool sim = false, grey = false;
+    if (on) {
+      const double r = sqrt(ssq / (double)A), m = sqrt(mx);
+      sim = may && (r < max_rmsd) && (m < max_dev);
+      grey = may && ((fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9));
+      if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
+      if (!sim && bits != nullptr) {
+        const int64_t lrow = (((int64_t)i / IB) / world) * IB + ((int64_t)i % IB);
+        atomicAnd(reinterpret_cast<unsigned long long *>(&bits[lrow * W + (j >> 6)]), ~(1ull << (j & 63)));
+      }
+    }
+    const uint64_t mo = __ballot(on), ms = __ballot(on && sim), mg = __ballot(on && grey);
+    unsigned long long sbase = 0;
+    if (lane == 0) {
+      atomicAdd(&counters[1], (unsigned long long)__popcll(mo));
+      if (ms) sbase = atomicAdd(&counters[2], (unsigned long long)__popcll(ms));
+      if (mg) atomicAdd(&counters[3], (unsigned long long)__popcll(mg));
+    }
+    sbase = __shfl(sbase, 0);
+    if (on && sim) simq[sbase + (unsigned long long)__popcll(ms & ((1ull << lane) - 1ull))] = e;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_simbits_refine: one wavefront per bit word; lane b re-evaluates pair
 // (row, jt*64+b) exactly if its screen bit is set and the word is rewritten
 // with the final decision  rmsd < max_rmsd && maxdev < max_dev
@@ -2196,6 +2326,8 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const unsigned long long n_pairs = counters[6];
+  if (n_pairs <= Q && IB < 0) return;  // IB < 0: k_refine_pairs has taken the pair queue (the launcher's default)
+  if (IB < 0) IB = -IB;
   if (n_pairs <= Q) {
     // pair mode: the queue is complete.  A wavefront takes 64 candidate pairs.  The two atom
     // passes (covariance, rotated difference) run with EIGHT lanes per pair, 8 pairs per
@@ -3035,11 +3167,29 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
 int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const double *energies_dev,
                           double max_dE) {
   if (e->rows_local * e->W == 0) return FC_OK;
-  // persistent-style grid: wavefronts stride over the candidate queue whose
-  // length the screen kernel left in counters[4] (same stream, no host sync)
+  // persistent-style grids: wavefronts stride over the candidate queues whose lengths the screen kernel
+  // left in the counters (same stream, no host sync).  The pair queue, when it did not overflow, is taken by
+  // k_refine_pairs (FC_REFINE_LANES=0: by the pair mode of k_simbits_refine, the kernel of rounds 1-2)
+  static const bool lanes = [] {
+    const char *v = getenv("FC_REFINE_LANES");
+    return !(v && atoi(v) == 0);
+  }();
+  if (lanes) {
+    static const int per_cu = [] {
+      const char *v = getenv("FC_REFINE_GRID");  // workgroups per CU (tuning knob)
+      const int k = v ? atoi(v) : 16;
+      return k >= 1 && k <= 64 ? k : 16;
+    }();
+    hipLaunchKernelGGL(k_refine_pairs, dim3((unsigned)(ctx().n_cu * per_cu)), dim3(256), 0, ctx().stream,
+                       e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, max_rmsd, max_dev, energies_dev,
+                       max_dE, (int)e->row_block, e->world, e->lean ? nullptr : e->bits.as<uint64_t>(), e->W,
+                       reinterpret_cast<unsigned long long *>(e->counters.p), e->pairq.as<uint64_t>(),
+                       (unsigned long long)e->pairq_cap, e->simq.as<uint64_t>());
+    FC_TRY(check_launch("k_refine_pairs"));
+  }
   hipLaunchKernelGGL(k_simbits_refine, dim3((unsigned)(ctx().n_cu * 16)), dim3(256), 0,
                      ctx().stream, e->Xs.as<double>(), e->Xa.as<double>(), e->N, e->Npad, (int)e->A,
-                     max_rmsd, max_dev, energies_dev, max_dE, (int)e->row_block, e->rank, e->world,
+                     max_rmsd, max_dev, energies_dev, max_dE, lanes ? -(int)e->row_block : (int)e->row_block, e->rank, e->world,
                      e->rows_local,
                      e->lean ? nullptr : e->bits.as<uint64_t>(), e->W, e->cand.as<uint32_t>(),
                      reinterpret_cast<unsigned long long *>(e->counters.p), e->pairq.as<uint64_t>(),

@@ -147,7 +147,7 @@ k_level_fused(const uint64_t *__restrict__ bits, int64_t W, const uint64_t *__re
 // appends, one atomic per wavefront and level -- so that the one-workgroup ladder kernel
 // below touches, at a level, only the pairs that matter at it: about 2 P visits in total
 // instead of n_ladder x P.  The last level (k = 1: one chunk, every pair) needs no bucket.
-// level_cnt = counters + 16; buckets: n_ladder regions of `cap` pairs.
+// level_cnt = counters + kCntLevel (one counter per 128-byte line); buckets: n_ladder regions of `cap` pairs.
 __global__ void __launch_bounds__(256)
 k_pair_buckets(const uint64_t *__restrict__ pairs, const unsigned long long *__restrict__ n_pairs_ptr,
                unsigned long long cap, int64_t N, const int64_t *__restrict__ ladder, int n_ladder,
@@ -186,7 +186,7 @@ k_pair_buckets(const uint64_t *__restrict__ pairs, const unsigned long long *__r
     }
     // ONE atomic instruction reserves the wavefront's slots in every bucket: lane l asks for level l
     unsigned long long my_at = 0;
-    if (my_cnt) my_at = atomicAdd(&level_cnt[lane], my_cnt);
+    if (my_cnt) my_at = atomicAdd(&level_cnt[lane * kCntLevelStride], my_cnt);
     for (int l = 0; l < n_ladder; ++l) {
       const bool same = (mine >> l) & 1u;
       const uint64_t m = __ballot(same);
@@ -227,7 +227,7 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint64_t *__restrict__ 
     if (tid < 16) mask_out[W + tid] = tid == 9 ? 0ull : counters[tid];
     return;
   }
-  if (tid < 32) s_level_cnt[tid] = tid < n_ladder ? counters[16 + tid] : 0ull;  // one round trip, not one per level
+  if (tid < 32) s_level_cnt[tid] = tid < n_ladder ? counters[kCntLevel + kCntLevelStride * tid] : 0ull;  // one round trip, not one per level
   unsigned long long *cur = lm, *nxt = lm + W;
   for (int64_t w = tid; w < W; w += 1024) {
     const int64_t lo = w * 64;
@@ -967,9 +967,9 @@ int launch_ladder_pairs(const uint64_t *pairs_dev, uint64_t *buckets_dev,
                         unsigned long long cand_cap, unsigned long long cap, int64_t N, int64_t W,
                         int64_t min_per_group, const int64_t *ladder_dev, int n_ladder,
                         uint64_t *mask_out_dev, unsigned long long *counters_dev) {
-  // counters_dev[16 .. 16 + n_ladder) = bucket fill levels (zero on entry: the caller's reset)
-  hipLaunchKernelGGL(k_pair_buckets, dim3((unsigned)(ctx().n_cu * 2)), dim3(256), 0, ctx().stream,
-                     pairs_dev, n_pairs_dev, cap, N, ladder_dev, n_ladder, buckets_dev, counters_dev + 16, n_cand_dev,
+  // counters_dev[kCntLevel + kCntLevelStride * l] = bucket fill levels (zero on entry: the caller's reset)
+  hipLaunchKernelGGL(k_pair_buckets, dim3((unsigned)(ctx().n_cu * 8)), dim3(256), 0, ctx().stream,
+                     pairs_dev, n_pairs_dev, cap, N, ladder_dev, n_ladder, buckets_dev, counters_dev + kCntLevel, n_cand_dev,
                      cand_cap);
   FC_TRY(check_launch("k_pair_buckets"));
   const size_t lds = (size_t)2 * W * sizeof(uint64_t);

@@ -511,6 +511,12 @@ int fc_debug_h2_covariance(fc_ensemble *ens, int64_t ib, int64_t jb, float *B_ou
 int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps,
                         double *ms_simbits_kernel, double *ms_step, uint8_t *mask_out,
                         int64_t *stats);
+/* The exact refine of the prune alone: one all-pairs screen fills the candidate-pair queue of the resident
+ * ensemble, then `reps` launches of the refine over that queue (k_refine_pairs: one exact fp64 alignment --
+ * covariance, rotation, rmsd, max deviation, decision -- per queued pair), HIP events around each.
+ * ms_refine: mean; n_candidates: pairs per launch.  FC_E_LIMIT when the pair queue overflowed. */
+int fc_bench_refine(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t reps, double *ms_refine,
+                    int64_t *n_candidates);
 /* `reps` complete all-pairs alignment passes (fc_ensemble_rmsd_and_max_all: the a4 contract of
  * firecode/utils.py:499 for every pair, fp64) over the resident ensemble, enqueued back to back, the two
  * dense (N, N) outputs staying in HBM; one host wait.  ms_kernel_mean: HIP events on the kernel's stream
