@@ -5,9 +5,10 @@
 //   (c) products / C below the largest of them keep at least the largest one's last place (2^-24 of it,
 //       relative; the hardware measured here keeps 1 to 3 bits more);
 //   (d) on random and on adversarial data (wide exponent spread, one dominating product per row, a
-//       dominating C, mixed signs) |D - exact| <= kH2InstrBound u (|C| + sum |a b|), u = 2^-24.
-// kabsch_h2_bounds (fc_kabsch_math.h) charges kH2InstrBound = 36 u per instruction; if any check fails the
-// launcher keeps to the fp32-MFMA screen.  Also here: the 16 x 16 tile of covariances exactly as the screen
+//       dominating C, mixed signs) |D - exact| <= kH2InstrTripwire u (|C| + sum |a b|), u = 2^-24.
+// kabsch_h2_bounds (fc_kabsch_math.h) charges kH2InstrBound = 66 u per instruction -- an order-independent bound
+// of any 33-addend fp32 sum, which needs none of (b)-(d); the checks stay as a tripwire (18 u; 5.4 u measured): if
+// any fails the launcher keeps to the fp32-MFMA screen.  Also here: the 16 x 16 tile of covariances exactly as the screen
 // accumulates them (same instructions, same order), for the tests that compare them with fp64 arithmetic.
 // The reference has no counterpart: this is test and safety infrastructure of the screen, not a FIRECODE row.
 #include "fc_common.h"
@@ -146,7 +147,7 @@ static int run_model_check(int trials, unsigned *flags_host, float *worst_host) 
 int h2_model_ok(bool *ok) {
   if (g_model_ok < 0 || g_model_device != ctx().device) {
     FC_TRY(run_model_check(400, g_model_flags, &g_model_worst));
-    bool all = g_model_worst >= 0.f && g_model_worst <= 0.5f * (float)kH2InstrBound;
+    bool all = g_model_worst >= 0.f && g_model_worst <= (float)kH2InstrTripwire;
     for (int p = 0; p < kModelPatterns; ++p) all = all && g_model_flags[p] == 1u;
     g_model_ok = all ? 1 : 0;
     g_model_device = ctx().device;

@@ -2191,6 +2191,8 @@ k_screen_rowsweep(const double *__restrict__ Xs, const double *__restrict__ G, i
 // -R, the decision -- all per lane.  Same outputs as the pair mode of k_simbits_refine: counters[1..3], simq, bits.
 // ---------------------------------------------------------------------------
 // counters words of the XCD-partitioned candidate queue (k_pairq_partition -> k_refine_pairs)
+constexpr unsigned long long kRefineLanesMin = 1ull << 17;  // pairs: below, the 8-lanes-per-pair form is faster (latency)
+
 __global__ void __launch_bounds__(256)
 k_refine_pairs(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N, int64_t Npad, int A,
                double max_rmsd, double max_dev, const double *__restrict__ energies, double max_dE, int IB,
@@ -2201,6 +2203,10 @@ k_refine_pairs(const double *__restrict__ Xs, const double *__restrict__ G, int6
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const unsigned long long n_pairs = counters[6];
   if (n_pairs > Q) return;  // the queue overflowed: the word queue (k_simbits_refine) holds the work
+  // a short queue is a latency problem, not a bandwidth one: 2*10^4 pairs are 312 wavefronts here, each walking
+  // 2 x 50 atoms of dependent loads (106 us), where the 8-lanes-per-pair walk of k_simbits_refine spreads them
+  // over four times as many (56 us) -- it keeps the queues below kRefineLanesMin pairs
+  if (n_pairs <= kRefineLanesMin) return;
   const int A2 = (A + 1) & ~1;  // Xs rows are padded to a multiple of 4 atoms with zeros
   // (Splitting a long queue by column range into one part per XCD, each XCD drawing batches from its own part
   // so that its 4 MB L2 sees an eighth of the column conformers, was built and measured on the 8.9e5-candidate
@@ -2326,7 +2332,7 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const unsigned long long n_pairs = counters[6];
-  if (n_pairs <= Q && IB < 0) return;  // IB < 0: k_refine_pairs has taken the pair queue (the launcher's default)
+  if (n_pairs <= Q && n_pairs > kRefineLanesMin && IB < 0) return;  // IB < 0: k_refine_pairs takes the long pair queues
   if (IB < 0) IB = -IB;
   if (n_pairs <= Q) {
     // pair mode: the queue is complete.  A wavefront takes 64 candidate pairs.  The two atom

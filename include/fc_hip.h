@@ -500,7 +500,8 @@ int fc_screen_select(int kind);
  * uses that screen: flags_out[0..7] = 1 where the pattern behaves as assumed (subnormal inputs honoured, one
  * rounding to nearest per instruction, the largest addend's last place kept for the others, exact large
  * products); worst_out = largest |D - exact| / (2^-24 (|C| + sum |a b|)) over `trials` random and adversarial
- * 16 x 16 x 32 products -- the error bounds charge 36 per instruction.
+ * 16 x 16 x 32 products -- the error bounds charge 66 per instruction (an order-independent bound of a 33-addend
+ * fp32 sum); the library refuses the screen on a device where this probe exceeds 18.
  * fc_debug_h2_covariance: the 16 x 16 tile of covariances (rows ib.., columns jb.., multiples of 16) exactly
  * as that screen accumulates them: B_out[(row*16 + col)*9 + 3x + y] = scale^2 sum_a p_ax q_ay; entry_bound_out
  * = the bound on |B_out / scale^2 - B| / s the screen's polynomial bounds start from (s = (Gp + Gq)/2).

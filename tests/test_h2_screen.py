@@ -24,7 +24,7 @@ def test_f16_matrix_pipe_model(fc):
     worst = C.c_double(-1.0)
     _lib.call("fc_debug_mfma_f16_model", 20000, _lib.pi(flags), C.byref(worst))
     assert flags.tolist() == [1] * 8, flags
-    # the bounds charge 36 u (|C| + sum |a b|) per instruction; the library refuses the screen above half of that
+    # the bounds charge 66 u (|C| + sum |a b|) per instruction (order-independent); the library refuses the screen above 18 u
     assert 0.0 <= worst.value <= 18.0, worst.value
 
 
@@ -63,7 +63,7 @@ def test_h2_covariance_within_its_bound(fc, n, a, seed, kind):
     with fc.DeviceEnsemble(X, center=center) as ens:
         for ib, jb in [(0, 0), (0, 16), (16, 48), ((n // 16 - 1) * 16, (n // 16 - 1) * 16), (32, 0)]:
             B, scale, bound = _cov_tile(fc, ens, ib, jb)
-            assert scale > 0.0 and bound < 200 * U
+            assert scale > 0.0 and bound <= (13.02 + 66.4 * ((a + 31) // 32)) * U * (1 + 1e-12)  # kabsch_h2_entry_bound
             assert 2.0 ** 24 <= G.max() * scale * scale <= 2.0 ** 26 * (1 + 1e-12)
             ref = np.einsum("iax,jay->ijxy", Xc[ib:ib + 16], Xc[jb:jb + 16])
             s = 0.5 * (G[ib:ib + 16, None] + G[None, jb:jb + 16])

@@ -1,0 +1,39 @@
+"""tools/r03_pmc_json.py SUMMARY.txt KERNEL_SUBSTRING OUT.json key=value... -- one kernel's line of a
+tools/pmc_summary.py file as a json record with the corrected fabric-side traffic (MI355X_MICROARCH.md, HBM:
+FETCH_SIZE counts wide coalesced reads at 1/2 -> doubled; WRITE_SIZE exact; both in KiB)."""
+import ast
+import json
+import sys
+
+summary, needle, out = sys.argv[1:4]
+extra = dict(kv.split("=", 1) for kv in sys.argv[4:])
+rec = None
+for line in open(summary):
+    if needle in line and "{" in line:
+        rec = ast.literal_eval(line[line.index("{"): line.rindex("}") + 1])
+        name = line.split("{")[0].split(None, 1)[1].strip()
+        launches = int(line.rsplit("launches=", 1)[1])
+        break
+if rec is None:
+    sys.exit(f"no kernel matching {needle!r} in {summary}")
+fetch_b, write_b = rec.get("FETCH_SIZE", 0.0) * 1024, rec.get("WRITE_SIZE", 0.0) * 1024
+d = {"kernel": name, "launches_profiled": launches, "source": summary,
+     "FETCH_SIZE_KiB": rec.get("FETCH_SIZE"), "WRITE_SIZE_KiB": rec.get("WRITE_SIZE"),
+     "correction": "gfx950: FETCH_SIZE counts wide coalesced reads at 1/2 (MI355X_MICROARCH.md, HBM) -> doubled, as that "
+                   "guide prescribes for 16-byte-per-lane reads; this kernel also issues 8-byte loads (uncalibrated width: "
+                   "the doubled figure is an upper bound); WRITE_SIZE is exact for its 16-byte stores; the counters sit on the "
+                   "L2's fabric side, Infinity-Cache hits included: an upper bound on HBM bytes",
+     "traffic_bytes_per_launch": int(2 * fetch_b + write_b),
+     "tcc_hit_rate": rec["TCC_HIT_sum"] / (rec["TCC_HIT_sum"] + rec["TCC_MISS_sum"]) if "TCC_HIT_sum" in rec else None}
+for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
+          "SQ_INSTS_VMEM_WR", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY",
+          "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES"):
+    if k in rec:
+        d[k] = rec[k]
+for k, v in extra.items():
+    try:
+        d[k] = int(v)
+    except ValueError:
+        d[k] = v
+json.dump(d, open(out, "w"), indent=1)
+print(json.dumps(d)[:600])
