@@ -74,9 +74,10 @@ int launch_torsion_fingerprint(const double *, int64_t, int64_t, const int64_t *
 int launch_tfd_first_match(const double *, int64_t, int64_t, int64_t, double, int64_t *, float *);
 int launch_transpose_pad(const double *, int64_t, int64_t, int64_t, double *);
 int launch_gather_transpose_pad(const double *, const double *, const int64_t *, int64_t, int64_t, int64_t, double *);
-int tfd_ladder_from_first_match(const int64_t *, int64_t, uint8_t *);
+int tfd_ladder_from_first_match(const int64_t *, int64_t, uint8_t *, const int64_t *fm_dev = nullptr);
 void pyset_order_ints(const int64_t *, int64_t, std::vector<int64_t> &);
 void pyset_order_pairs(const int64_t *, int64_t, std::vector<int64_t> &);
+int pyset_order_pairs_device(const int64_t *, int64_t, int64_t *);
 int xyz_write(const char *, const char *const *, int64_t, const double *, int64_t, const char *, int);
 int xyz_read(const char *, int64_t *, int64_t *, char *, double *);
 int launch_embed_mol_transforms(const double *, int64_t, int64_t, const int64_t *, int, const double *,
@@ -2018,6 +2019,7 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   DevBuf dtf0, didx, dT, dfm;
   FC_TRY(dtf0.reserve((size_t)Q * sizeof(double)));
   FC_TRY(launch_torsion_fingerprint(db.as<double>(), 1, A, dq.as<int64_t>(), Q, dtf0.as<double>()));
+  if (M == 0) kept.push_back(0);  // nothing rotated a bond: one defined entry for the (unused) index upload
   FC_TRY(upload(didx, kept.data(), (size_t)std::max<int64_t>(M, 1)));
   FC_TRY(dT.reserve((size_t)Q * Npad * sizeof(double)));
   FC_TRY(launch_gather_transpose_pad(dtf.as<double>(), dtf0.as<double>(), didx.as<int64_t>(), M, Q, Npad, dT.as<double>()));
@@ -2029,7 +2031,7 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   FC_TRY(d2h(fm.data(), dfm.p, (size_t)N * sizeof(int64_t)));
   FC_TRY(sync());
   std::vector<uint8_t> mask((size_t)N);
-  FC_TRY(tfd_ladder_from_first_match(fm.data(), N, mask.data()));
+  FC_TRY(tfd_ladder_from_first_match(fm.data(), N, mask.data(), dfm.as<int64_t>()));
   std::memset(tfd_keep_out, 0, (size_t)S + 1);
   tfd_keep_out[0] = mask[0];
   for (int64_t k = 0; k < M; ++k) tfd_keep_out[1 + kept[(size_t)k]] = mask[(size_t)k + 1];
@@ -2135,7 +2137,15 @@ int fc_tfd_ladder_from_first_match(const int64_t *first_match, int64_t N, uint8_
   for (int64_t i = 0; i < N; ++i)
     FC_REQUIRE(first_match[i] == -1 || (first_match[i] > i && first_match[i] < N), "first_match[%lld] invalid", (long long)i);
   const auto t1 = std::chrono::steady_clock::now();
-  const int rc = tfd_ladder_from_first_match(first_match, N, mask_out);
+  // with a device at hand the coarse levels' chunk graphs are built there (a pure host function otherwise: the
+  // CPU tests call it without a GPU)
+  DevBuf dfm;
+  const int64_t *fm_dev = nullptr;
+  if (ctx().ready && N >= 131072) {
+    FC_TRY(upload(dfm, first_match, (size_t)N));
+    fm_dev = dfm.as<int64_t>();
+  }
+  const int rc = tfd_ladder_from_first_match(first_match, N, mask_out, fm_dev);
   if (getenv("FC_DEBUG"))
     fprintf(stderr, "[fc] fc_tfd_ladder_from_first_match: validation %.1f ms, ladder incl. tear-down %.1f ms\n",
             std::chrono::duration<double, std::milli>(t1 - t0).count(),
@@ -2150,7 +2160,7 @@ int fc_tfd_prune(const double *tf, int64_t N, int64_t Q, double thresh, uint8_t 
   FC_REQUIRE(mask_out != nullptr, "NULL pointer argument");
   std::vector<int64_t> fm((size_t)N);
   FC_TRY(fc_tfd_first_match(tf, N, Q, thresh, fm.data()));
-  return tfd_ladder_from_first_match(fm.data(), N, mask_out);
+  return fc_tfd_ladder_from_first_match(fm.data(), N, mask_out);
 }
 
 int fc_debug_pyset_order_ints(const int64_t *keys, int64_t n, int64_t *order_out, int64_t *n_out) {
@@ -2162,6 +2172,13 @@ int fc_debug_pyset_order_ints(const int64_t *keys, int64_t n, int64_t *order_out
   for (size_t k = 0; k < o.size(); ++k) order_out[k] = o[k];
   *n_out = (int64_t)o.size();
   return FC_OK;
+}
+
+int fc_debug_pyset_order_pairs_device(const int64_t *pairs, int64_t n, int64_t *order_out) {
+  FC_API_LOCK;
+  FC_REQUIRE(n >= 0 && (n == 0 || (pairs && order_out)), "bad arguments");
+  FC_TRY(ensure_init());
+  return pyset_order_pairs_device(pairs, n, order_out);
 }
 
 int fc_debug_pyset_order_pairs(const int64_t *pairs, int64_t n, int64_t *order_out, int64_t *n_out) {

@@ -176,6 +176,20 @@ inline int64_t local_block_count(int64_t n_gblocks, int64_t rank, int64_t world)
   return n;
 }
 
+// Host view of one coarse TFD ladder level's chunk graphs (all non-last chunks), built on the device
+// (fc_tfd_gpu.hip) and read by the component phase of fc_tfd_host.cpp.
+struct TfdLevelGraph {
+  int n_chunks = 0;
+  int64_t d = 0;
+  std::vector<int64_t> ebase, nbase, sbase;                  // per chunk (+1): edges, nodes, component sources before it
+  // level-wide arrays in COMPONENT-MAJOR node order: component j = nodes [sources[j], sources[j + 1]) led by its earliest
+  // node (graph order); nodes[v] = relative index in its chunk; neighbours of v = adj_next[adj_head[v] .. adj_head[v + 1])
+  // (level-wide node numbers) in insertion order
+  std::vector<int32_t> nodes, adj_head, adj_next, sources;
+  std::vector<int32_t> left;  // components the device left to the host (flags mode: those above its size cap)
+};
+int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevelGraph &out, uint8_t *flags_out = nullptr);
+
 }  // namespace fc
 
 // ---- resident ensemble -----------------------------------------------------------

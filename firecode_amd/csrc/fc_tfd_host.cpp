@@ -461,6 +461,145 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
   lap("components");
 }
 
+// ---- component phase of a level whose chunk graphs came from the device (fc_tfd_gpu.hip) --------------------------
+// The device delivers the nodes in component-major order: component = one contiguous block led by its earliest node
+// (graph order), so most components need neither a search nor a set:
+//   * a component of at least half the chunk's graph keeps its earliest node (the atlas branch of networkx's FilterAtlas);
+//   * otherwise group[0] is the first element of a Python set of the members' relative indices -- small non-negative
+//     ints hash to themselves, so when the members' residues modulo the set's final table size are all different every
+//     one sits in its home slot whatever the insertion order, and the first one is the smallest residue;
+//   * only components with two members in one home slot need the reference's insertion orders: breadth-first search
+//     over the insertion-ordered neighbour lists and the two set emulations, as in one_component above.
+// flags[rel] = 1 for every rejected structure of the chunk.
+static inline int64_t pyset_final_size(int64_t n_keys) {  // slots of a set that received n_keys distinct keys one by one
+  uint64_t mask = 7;
+  for (;;) {
+    const int64_t trigger = (int64_t)((mask * 3 + 4) / 5);
+    if (trigger > n_keys) return (int64_t)mask + 1;
+    const uint64_t minused = trigger > 50000 ? 2 * (uint64_t)trigger : 4 * (uint64_t)trigger;
+    uint64_t newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    mask = newsize - 1;
+    if (trigger == n_keys) return (int64_t)mask + 1;
+  }
+}
+
+struct GraphCompScratch {
+  PySetEmu comp, view;
+  std::vector<int32_t> members, level, next;
+  std::vector<char> seen;
+  std::vector<uint64_t> bits;
+  int64_t n_search = 0;
+};
+
+static void graph_component(const TfdLevelGraph &g, int64_t s0, int64_t s1, int64_t chunk_nodes, GraphCompScratch &cs,
+                            uint8_t *flags) {
+  const int32_t *nodes = g.nodes.data();
+  const int64_t size = s1 - s0;
+  int64_t first = -1;
+  if (2 * size >= chunk_nodes) {
+    first = nodes[s0];
+  } else {
+    const int64_t T = pyset_final_size(size);
+    const size_t words = (size_t)((T + 63) >> 6);
+    if (cs.bits.size() < words) cs.bits.resize(words);
+    std::fill(cs.bits.begin(), cs.bits.begin() + (std::ptrdiff_t)words, 0ull);
+    int64_t best = T;
+    bool clean = true;
+    for (int64_t v = s0; v < s1; ++v) {
+      const int64_t r = (int64_t)nodes[v] & (T - 1);
+      uint64_t &w = cs.bits[(size_t)(r >> 6)];
+      const uint64_t bit = 1ull << (r & 63);
+      if (w & bit) {
+        clean = false;
+        break;
+      }
+      w |= bit;
+      if (r < best) {
+        best = r;
+        first = nodes[v];
+      }
+    }
+    if (!clean) {
+      // the reference's orders: _plain_bfs from the earliest node over the insertion-ordered neighbour lists ...
+      ++cs.n_search;
+      const int32_t *head = g.adj_head.data(), *adj = g.adj_next.data();
+      cs.seen.assign((size_t)size, 0);
+      cs.comp.reset();
+      cs.comp.add(nodes[s0], nodes[s0], int_eq);
+      cs.seen[0] = 1;
+      cs.level.assign(1, (int32_t)s0);
+      while (!cs.level.empty()) {
+        cs.next.clear();
+        for (const int32_t v : cs.level)
+          for (int32_t rec = head[v]; rec < head[v + 1]; ++rec) {
+            const int32_t x = adj[rec];
+            if (!cs.seen[(size_t)(x - s0)]) {
+              cs.seen[(size_t)(x - s0)] = 1;
+              cs.comp.add(nodes[x], nodes[x], int_eq);
+              cs.next.push_back(x);
+            }
+          }
+        cs.level.swap(cs.next);
+      }
+      // ... then show_nodes.nodes = set(nbunch_iter(c)), iterated: its first element
+      cs.view.reset();
+      cs.comp.for_each([&](int64_t key) { cs.view.add(key, key, int_eq); });
+      first = -1;
+      cs.view.for_each([&](int64_t key) {
+        if (first < 0) first = key;
+      });
+    }
+  }
+  for (int64_t v = s0; v < s1; ++v)
+    if (nodes[v] != first) flags[nodes[v]] = 1;
+}
+
+// all non-last chunks of one level from the device-built graphs -> level_flags[absolute index] = 1 for rejects
+// only_left: just the components the device left over (g.left), one job each
+static void level_rejects_from_graph(const TfdLevelGraph &g, unsigned threads, uint8_t *level_flags, int64_t *n_search_out,
+                                     bool only_left = false) {
+  if (g.nodes.empty()) return;
+  struct Job { int chunk; int64_t j0, j1; };
+  std::vector<Job> jobs;
+  if (only_left) {
+    for (const int32_t j : g.left) {
+      const int64_t s0 = g.sources[(size_t)j];
+      const int c = (int)(std::upper_bound(g.nbase.begin(), g.nbase.end(), s0) - g.nbase.begin()) - 1;
+      jobs.push_back(Job{c, j, (int64_t)j + 1});
+    }
+  } else {
+    for (int c = 0; c < g.n_chunks; ++c) {
+      const int64_t j0 = g.sbase[(size_t)c], j1 = g.sbase[(size_t)c + 1];
+      for (int64_t b = j0; b < j1; b += 2048) jobs.push_back(Job{c, b, std::min(j1, b + 2048)});
+    }
+  }
+  std::atomic<size_t> next{0};
+  std::atomic<int64_t> searched{0};
+  auto worker = [&]() {
+    GraphCompScratch cs;
+    while (true) {
+      const size_t q = next.fetch_add(1);
+      if (q >= jobs.size()) break;
+      const Job &jb = jobs[q];
+      const int64_t chunk_nodes = g.nbase[(size_t)jb.chunk + 1] - g.nbase[(size_t)jb.chunk];
+      uint8_t *flags = level_flags + (int64_t)jb.chunk * g.d;
+      for (int64_t j = jb.j0; j < jb.j1; ++j)
+        graph_component(g, g.sources[(size_t)j], g.sources[(size_t)j + 1], chunk_nodes, cs, flags);
+    }
+    searched += cs.n_search;
+  };
+  if (threads <= 1 || jobs.size() <= 1) {
+    worker();
+  } else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto &th : pool) th.join();
+  }
+  if (n_search_out) *n_search_out = searched.load();
+}
+
 // chunks [step_begin, step_end) of one ladder level; chunks are independent.  The rejects go to `out`
 // as absolute indices (the caller applies them when -- and if -- the level runs).
 static void level_chunks(const int64_t *fm, int64_t N, int64_t k, int64_t d, int64_t num_active,
@@ -499,7 +638,9 @@ static void level_chunks(const int64_t *fm, int64_t N, int64_t k, int64_t d, int
 // last chunk -- usually empty or tiny, since num_active_str has long fallen below its start -- on the spot.
 // (One level after the other, threads over the chunks of a level: 0.32 s at 1.7 M structures, of which the
 // levels k <= 20 with their few huge chunks took 0.24 s on one to five threads.)
-int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out) {
+// fm_dev (may be nullptr): the same array on the device -- the chunk graphs of the coarse levels (chunks of at least
+// kGpuChunkMin structures) are then built there (fc_tfd_gpu.hip) while the host threads work on the fine levels.
+int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out, const int64_t *fm_dev) {
   static const double kl[] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};
   for (int64_t i = 0; i < N; ++i) mask_out[i] = 1;
   unsigned hw = std::thread::hardware_concurrency();
@@ -528,19 +669,30 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
   std::vector<Task> tasks;
   constexpr int kLevels = (int)(sizeof(kl) / sizeof(kl[0]));
   std::vector<uint8_t> level_rej[kLevels];
+  std::vector<int> gpu_levels;
+  bool use_gpu = fm_dev != nullptr;
+  if (const char *v = getenv("FC_TFD_GPU")) use_gpu = use_gpu && atoi(v) != 0;  // 0: everything on the host (A/B, tests)
+  bool gpu_components = true;  // FC_TFD_GPU_COMPONENTS=0: the component phase on host threads, from the device's graphs
+  if (const char *v = getenv("FC_TFD_GPU_COMPONENTS")) gpu_components = atoi(v) != 0;
+  int64_t gpu_chunk_min = 65536;
+  if (const char *v = getenv("FC_TFD_GPU_CHUNK_MIN")) gpu_chunk_min = std::max<int64_t>(2, std::strtoll(v, nullptr, 10));
   for (int li = 0; li < (int)(sizeof(kl) / sizeof(kl[0])); ++li) {
     const int64_t k = (int64_t)kl[li];
     if (!(k == 1 || 5 * k < N)) continue;  // num_active <= N: the level can never run
     if (k == 1) continue;                  // its only chunk is a last chunk
     const int64_t d = N / k;
     if (d <= 1) continue;
+    level_rej[li].assign((size_t)(d * (k - 1)), 0);  // the non-last chunks cover [0, d (k - 1))
+    if (use_gpu && d >= gpu_chunk_min) {  // a coarse level: its chunk graphs come from the device
+      gpu_levels.push_back(li);
+      continue;
+    }
     // non-last chunks [0, k - 1), cut into tasks of about 2^17 structures (a huge chunk is a task of its own)
     const int64_t per = std::max<int64_t>(1, (int64_t)(131072 / d));
     for (int64_t b = 0; b < k - 1; b += per) {
       const int64_t e = std::min<int64_t>(k - 1, b + per);
       tasks.push_back(Task{li, k, d, b, e, (e - b) * d});
     }
-    level_rej[li].assign((size_t)(d * (k - 1)), 0);  // the non-last chunks cover [0, d (k - 1))
   }
   std::vector<size_t> order(tasks.size());
   for (size_t t = 0; t < order.size(); ++t) order[t] = t;
@@ -562,13 +714,42 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out)
       }
     };
     const unsigned nthreads = (N >= 2000 && tasks.size() > 1) ? std::min<size_t>(hw, tasks.size()) : 1;
-    if (nthreads <= 1) {
+    std::vector<std::thread> pool;
+    if (nthreads > 1 || !gpu_levels.empty())
+      for (unsigned t = 0; t < std::max(1u, nthreads); ++t) pool.emplace_back(worker);
+    else
       worker();
-    } else {
-      std::vector<std::thread> pool;
-      for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(worker);
-      for (auto &th : pool) th.join();
+    // meanwhile, on this thread: the coarse levels' graphs from the device, their component phase on helper threads
+    int gpu_rc = FC_OK;
+    for (int li : gpu_levels) {
+      TfdLevelGraph g;
+      const auto t_g = std::chrono::steady_clock::now();
+      gpu_rc = tfd_level_graph_device(fm_dev, N, (int64_t)kl[li], g, gpu_components ? level_rej[li].data() : nullptr);
+      if (gpu_rc != FC_OK) break;
+      const auto t_c = std::chrono::steady_clock::now();
+      int64_t n_search = 0;
+      if (!gpu_components) level_rejects_from_graph(g, g_comp_threads, level_rej[li].data(), &n_search);
+      else if (!g.left.empty()) level_rejects_from_graph(g, g_comp_threads, level_rej[li].data(), &n_search, true);
+      if (debug && !gpu_components && !g.sources.empty()) {
+        int64_t big = 0, big_nodes = 0, huge = 0, huge_nodes = 0, mx = 0;
+        for (size_t j = 0; j + 1 < g.sources.size(); ++j) {
+          const int64_t sz = g.sources[j + 1] - g.sources[j];
+          if (sz > 64) ++big, big_nodes += sz;
+          if (sz > 1024) ++huge, huge_nodes += sz;
+          mx = std::max(mx, sz);
+        }
+        fprintf(stderr, "[fc]   component sizes: > 64 nodes: %lld (%lld nodes), > 1024: %lld (%lld nodes), largest %lld\n",
+                (long long)big, (long long)big_nodes, (long long)huge, (long long)huge_nodes, (long long)mx);
+      }
+      if (debug)
+        fprintf(stderr, "[fc] tfd ladder k=%lld on the device: %.1f ms (%zu components, %zu of them left to the host: %lld searched), "
+                        "host components %.1f ms\n",
+                (long long)kl[li], std::chrono::duration<double, std::milli>(t_c - t_g).count(),
+                g.sources.empty() ? (size_t)0 : g.sources.size() - 1, g.left.size(), (long long)n_search,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c).count());
     }
+    for (auto &th : pool) th.join();
+    if (gpu_rc != FC_OK) return gpu_rc;
   }
   if (debug)
     fprintf(stderr, "[fc] tfd ladder: %zu speculative tasks on %u threads, %.1f ms\n", tasks.size(), hw,

@@ -445,6 +445,9 @@ int fc_tfd_prune(const double *tf, int64_t N, int64_t Q, double thresh, uint8_t 
  * set of 2-tuples (returned as indices into the input) */
 int fc_debug_pyset_order_ints(const int64_t *keys, int64_t n, int64_t *order_out, int64_t *n_out);
 int fc_debug_pyset_order_pairs(const int64_t *pairs, int64_t n, int64_t *order_out, int64_t *n_out);
+/* the same order for n DISTINCT pairs computed on the device (fc_tfd_gpu.hip: staged priority first-fit, what the
+ * coarse levels of the TFD ladder use); order_out: n indices.  Test hook. */
+int fc_debug_pyset_order_pairs_device(const int64_t *pairs, int64_t n, int64_t *order_out);
 
 /* ---- a1: the .xyz wire format (host code; firecode/ensemble.py:58-98, 284-297;
  * firecode/utils.py:105-116).  atoms: A C strings.  mode 0 = Ensemble.to_xyz text

@@ -1,0 +1,98 @@
+"""The device half of the TFD ladder's coarse levels (csrc/fc_tfd_gpu.hip) against the host emulation of
+CPython's sets (csrc/fc_tfd_host.cpp, itself checked against the running interpreter in
+tests/test_pyset_emulation.py): the iteration order of a set of 2-tuples by staged priority first-fit."""
+
+import numpy as np
+import pytest
+
+from firecode_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _orders(pairs):
+    pairs = np.ascontiguousarray(pairs, dtype=np.int64)
+    n = len(pairs)
+    host = np.zeros(n, dtype=np.int64)
+    n_out = np.zeros(1, dtype=np.int64)
+    _lib.call("fc_debug_pyset_order_pairs", _lib.pi(pairs), n, _lib.pi(host), _lib.pi(n_out))
+    assert n_out[0] == n
+    dev = np.zeros(n, dtype=np.int64)
+    _lib.call("fc_debug_pyset_order_pairs_device", _lib.pi(pairs), n, _lib.pi(dev))
+    return host, dev
+
+
+@pytest.mark.parametrize("n", [1, 4, 5, 6, 18, 19, 20, 76, 77, 78, 307, 5000, 49999, 50000, 50001, 78643, 78644, 200000, 840000])
+def test_tuple_set_order_first_match_like_pairs(fc, n):
+    """(i, j > i) pairs, one per i, as the chunk graphs have them -- sizes on both sides of every growth step of a
+    small set (5, 19, 77, ...) and of the 50 000 rule"""
+    rng = np.random.default_rng(n)
+    i = np.arange(n, dtype=np.int64)
+    gap = np.where(rng.random(n) < 0.7, rng.integers(1, 40, n), rng.integers(1, max(2, n), n))
+    pairs = np.stack([i, i + gap], axis=1)
+    host, dev = _orders(pairs)
+    assert np.array_equal(host, dev)
+
+
+def test_tuple_set_order_adversarial_hashes(fc):
+    """pairs chosen so that many share their low hash bits (long probe chains, perturbation jumps) and a strided
+    arrival order"""
+    from firecode_amd import _lib as L
+
+    rng = np.random.default_rng(5)
+    cand = np.stack([rng.integers(0, 1 << 20, 400000), rng.integers(0, 1 << 20, 400000)], axis=1).astype(np.int64)
+    cand = np.unique(cand, axis=0)
+    # keep the pairs whose tuple hash falls into 1/64 of the residues mod 2^16: heavy clustering in every table size
+    P1, P2, P5 = 11400714785074694791, 14029467366897019727, 2870177450012600261
+    M = (1 << 64) - 1
+    acc = np.full(len(cand), P5, dtype=np.uint64)
+    for k in range(2):
+        acc = (acc + cand[:, k].astype(np.uint64) * np.uint64(P2)) & np.uint64(M)
+        acc = ((acc << np.uint64(31)) | (acc >> np.uint64(33))) & np.uint64(M)
+        acc = (acc * np.uint64(P1)) & np.uint64(M)
+    acc = (acc + np.uint64(2 ^ (P5 ^ 3527539))) & np.uint64(M)
+    keep = cand[(acc & np.uint64(0xFC00)) == 0]
+    assert len(keep) > 3000
+    rng.shuffle(keep)
+    host, dev = _orders(keep)
+    assert np.array_equal(host, dev)
+
+
+def _random_first_match(rng, n, kind):
+    """first_match[i] = -1 or some j > i, in the shapes the ladder meets: neighbours, long jumps, chains, stars"""
+    i = np.arange(n, dtype=np.int64)
+    if kind == "near":
+        j = i + rng.integers(1, 40, n)
+    elif kind == "mixed":
+        j = i + np.where(rng.random(n) < 0.6, rng.integers(1, 50, n), rng.integers(1, n, n))
+    elif kind == "stars":   # many structures share their match: large in-degree
+        hubs = np.sort(rng.choice(n, size=max(2, n // 300), replace=False))
+        j = hubs[np.minimum(np.searchsorted(hubs, i + 1), len(hubs) - 1)]
+    else:                    # "chain": i -> i + 1 in long runs
+        j = i + 1
+    fm = np.where((j > i) & (j < n) & (rng.random(n) < 0.97), j, -1).astype(np.int64)
+    fm[-1] = -1
+    return fm
+
+
+@pytest.mark.parametrize("n,kind,seed", [(140000, "near", 1), (300000, "mixed", 2), (700000, "stars", 3), (262144, "chain", 4),
+                                          (1679611, "mixed", 5), (131072, "mixed", 6), (1000003, "near", 7)])
+def test_ladder_mask_is_the_same_with_device_built_chunk_graphs(fc, monkeypatch, n, kind, seed):
+    """fc_tfd_ladder_from_first_match with the coarse levels' chunk graphs built on the device (default with a GPU)
+    == the all-host ladder (FC_TFD_GPU=0), whose group[0] bookkeeping is pinned to CPython / networkx by the golden
+    masks and tests/test_pyset_emulation.py; also with a lower chunk threshold, so that more levels go to the device"""
+    rng = np.random.default_rng(seed)
+    fm = _random_first_match(rng, n, kind)
+    masks = {}
+    for label, env in (("host", {"FC_TFD_GPU": "0"}), ("device", {}), ("device_fine", {"FC_TFD_GPU_CHUNK_MIN": "1000"}),
+                       ("device_graphs_host_components", {"FC_TFD_GPU_COMPONENTS": "0", "FC_TFD_GPU_CHUNK_MIN": "20000"})):
+        for k in ("FC_TFD_GPU", "FC_TFD_GPU_CHUNK_MIN", "FC_TFD_GPU_COMPONENTS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = np.zeros(n, dtype=np.uint8)
+        _lib.call("fc_tfd_ladder_from_first_match", _lib.pi(fm), n, _lib.pb(m))
+        masks[label] = m
+    for label in ("device", "device_fine", "device_graphs_host_components"):
+        assert np.array_equal(masks["host"], masks[label]), label
+    assert 0 < masks["host"].sum() < n
