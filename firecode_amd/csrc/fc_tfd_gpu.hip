@@ -28,6 +28,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -696,6 +698,15 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
   hipStream_t st = ctx().stream;
   Scratch scr;
   const dim3 block(256), igrid((unsigned)ceil_div(n_items + 1, 256));
+  static const bool dbg = getenv("FC_DEBUG") != nullptr && getenv("FC_TFD_LAPS") != nullptr;
+  auto T0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!dbg) return;
+    (void)hipStreamSynchronize(st);
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[fc]     k=%lld %s %.2f ms\n", (long long)k, what, std::chrono::duration<double, std::milli>(t - T0).count());
+    T0 = t;
+  };
   DevBuf d_valid, d_par, d_escan, d_ebase, d_rank, d_hash, d_first, d_qpos;
   FC_TRY(d_valid.reserve((size_t)(n_items + 1) * sizeof(int32_t)));
   FC_TRY(d_par.reserve((size_t)n_items * sizeof(int32_t)));
@@ -724,6 +735,7 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
   // (1) the edge order: iteration order of each chunk's set of (i_rel, j_rel) tuples
   FC_TRY(pyset_orders_device(d_valid.as<int32_t>(), d_rank.as<int32_t>(), d_hash.as<int64_t>(), n_items, d, n_chunks, m,
                              d_ebase.as<int64_t>(), d_qpos.as<int32_t>(), nullptr, scr));
+  lap("edges + set orders");
   // (2) node numbers = ranks of first appearance along the edge order
   const int64_t n_times = 2 * M;
   DevBuf d_isfirst, d_nscan, d_node_of, d_nodes;
@@ -751,6 +763,7 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
     FC_TRY(sync());
   }
   const int64_t n_nodes = out.nbase[(size_t)n_chunks];
+  lap("node numbers");
   // (3) components: pointer jumping to the tree roots (a first-match graph is a forest: one out-edge per node, to a
   // later one), the earliest node of every tree, then the COMPONENT-MAJOR node order -- the host's component phase
   // walks each component in one contiguous block instead of hopping through a 10^6-node array in hash order
@@ -794,6 +807,7 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
   hipLaunchKernelGGL(k_lvl_comp_starts, dim3((unsigned)ceil_div(n_nodes, 256)), block, 0, st, d_isstart.as<int32_t>(), d_sscan.as<int32_t>(),
                      n_nodes, d_starts.as<int32_t>());
   FC_TRY(check_launch("k_lvl_comp_starts"));
+  lap("components, component-major order");
   // (4) neighbour lists in insertion order, in the new node numbers: records sorted by (node, time)
   DevBuf d_keys, d_keys2, d_vals, d_vals2, d_head;
   FC_TRY(d_keys.reserve((size_t)n_times * sizeof(uint64_t)));
@@ -826,6 +840,7 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
     FC_TRY(sync());
   }
   const int64_t n_src = out.sbase[(size_t)n_chunks];
+  lap("adjacency");
   if (flags_out != nullptr) {
     DevBuf d_need, d_soff, d_scratch, d_flags, d_left;
     static const int64_t size_cap = [] {
@@ -857,6 +872,7 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
     FC_TRY(d2h(flags_out, d_flags.p, (size_t)n_items));
     FC_TRY(d2h(&n_left, d_left.p, sizeof(int32_t)));
     FC_TRY(sync());
+    lap("device components + flags down");
     out.left.clear();
     if (n_left == 0) {
       out.sources.assign((size_t)n_src + 1, 0);  // (only the count is reported)
@@ -875,6 +891,7 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
   FC_TRY(d2h(out.adj_next.data(), d_vals2.p, (size_t)n_times * sizeof(int32_t)));
   FC_TRY(d2h(out.sources.data(), d_starts.p, (size_t)n_src * sizeof(int32_t)));
   FC_TRY(sync());
+  lap("graph arrays down");
   out.sources[(size_t)n_src] = (int32_t)n_nodes;  // sentinel: component j = nodes [sources[j], sources[j + 1])
   return FC_OK;
 }

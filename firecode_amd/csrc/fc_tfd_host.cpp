@@ -22,6 +22,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -674,7 +675,7 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
   if (const char *v = getenv("FC_TFD_GPU")) use_gpu = use_gpu && atoi(v) != 0;  // 0: everything on the host (A/B, tests)
   bool gpu_components = true;  // FC_TFD_GPU_COMPONENTS=0: the component phase on host threads, from the device's graphs
   if (const char *v = getenv("FC_TFD_GPU_COMPONENTS")) gpu_components = atoi(v) != 0;
-  int64_t gpu_chunk_min = 65536;
+  int64_t gpu_chunk_min = 1000;
   if (const char *v = getenv("FC_TFD_GPU_CHUNK_MIN")) gpu_chunk_min = std::max<int64_t>(2, std::strtoll(v, nullptr, 10));
   for (int li = 0; li < (int)(sizeof(kl) / sizeof(kl[0])); ++li) {
     const int64_t k = (int64_t)kl[li];
@@ -721,33 +722,32 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
       worker();
     // meanwhile, on this thread: the coarse levels' graphs from the device, their component phase on helper threads
     int gpu_rc = FC_OK;
+    // the host's share of a level (its large components) runs on a helper thread while the device builds the next
+    // level: two graph holders used in turn, kept across calls (their arrays are tens of MB: fresh pages every level
+    // cost more than the copies)
+    static TfdLevelGraph holders[2];
+    std::thread left_worker[2];
+    int turn = 0;
     for (int li : gpu_levels) {
-      TfdLevelGraph g;
+      if (left_worker[turn].joinable()) left_worker[turn].join();
+      TfdLevelGraph &g = holders[turn];
       const auto t_g = std::chrono::steady_clock::now();
       gpu_rc = tfd_level_graph_device(fm_dev, N, (int64_t)kl[li], g, gpu_components ? level_rej[li].data() : nullptr);
       if (gpu_rc != FC_OK) break;
       const auto t_c = std::chrono::steady_clock::now();
-      int64_t n_search = 0;
-      if (!gpu_components) level_rejects_from_graph(g, g_comp_threads, level_rej[li].data(), &n_search);
-      else if (!g.left.empty()) level_rejects_from_graph(g, g_comp_threads, level_rej[li].data(), &n_search, true);
-      if (debug && !gpu_components && !g.sources.empty()) {
-        int64_t big = 0, big_nodes = 0, huge = 0, huge_nodes = 0, mx = 0;
-        for (size_t j = 0; j + 1 < g.sources.size(); ++j) {
-          const int64_t sz = g.sources[j + 1] - g.sources[j];
-          if (sz > 64) ++big, big_nodes += sz;
-          if (sz > 1024) ++huge, huge_nodes += sz;
-          mx = std::max(mx, sz);
-        }
-        fprintf(stderr, "[fc]   component sizes: > 64 nodes: %lld (%lld nodes), > 1024: %lld (%lld nodes), largest %lld\n",
-                (long long)big, (long long)big_nodes, (long long)huge, (long long)huge_nodes, (long long)mx);
-      }
+      uint8_t *flags = level_rej[li].data();
+      if (!gpu_components) level_rejects_from_graph(g, g_comp_threads, flags, nullptr);
+      else if (!g.left.empty())
+        left_worker[turn] = std::thread([&g, flags]() { level_rejects_from_graph(g, std::min(g_comp_threads, 4u), flags, nullptr, true); });
       if (debug)
-        fprintf(stderr, "[fc] tfd ladder k=%lld on the device: %.1f ms (%zu components, %zu of them left to the host: %lld searched), "
-                        "host components %.1f ms\n",
+        fprintf(stderr, "[fc] tfd ladder k=%lld on the device: %.1f ms (%zu components, %zu of them left to host threads)%s\n",
                 (long long)kl[li], std::chrono::duration<double, std::milli>(t_c - t_g).count(),
-                g.sources.empty() ? (size_t)0 : g.sources.size() - 1, g.left.size(), (long long)n_search,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c).count());
+                g.sources.empty() ? (size_t)0 : g.sources.size() - 1, g.left.size(),
+                gpu_components ? "" : "; component phase on the host");
+      turn ^= 1;
     }
+    for (auto &th : left_worker)
+      if (th.joinable()) th.join();
     for (auto &th : pool) th.join();
     if (gpu_rc != FC_OK) return gpu_rc;
   }
