@@ -51,6 +51,7 @@ _SIGNATURES = {
     "fc_device_count": [],
     "fc_init": [C.c_int],
     "fc_shutdown": [],
+    "fc_warmup": [],
     "fc_device_info": [C.c_char_p, _i64, _p_i64, _p_i64],
     "fc_ensemble_create": [_p_f64, _i64, _i64, _p_u8, C.c_int, C.POINTER(_ens)],
     "fc_ensemble_destroy": [_ens],
@@ -343,6 +344,11 @@ def allgather_mask(mask_u8):
     out = np.zeros((world, m.shape[0]), dtype=np.uint8)
     call("fc_allgather_mask", pb(m), int(m.shape[0]), pb(out))
     return out
+
+
+def warmup():
+    """Load every translation unit's device code and prime the buffer pool now (fc_warmup)."""
+    call("fc_warmup")
 
 
 def memory_trim():

@@ -78,6 +78,14 @@ int tfd_ladder_from_first_match(const int64_t *, int64_t, uint8_t *, const int64
 void pyset_order_ints(const int64_t *, int64_t, std::vector<int64_t> &);
 void pyset_order_pairs(const int64_t *, int64_t, std::vector<int64_t> &);
 int pyset_order_pairs_device(const int64_t *, int64_t, int64_t *);
+int warm_clash();
+int warm_embed();
+int warm_embed3();
+int warm_torsion();
+int warm_prune();
+int warm_h2_check();
+int warm_kabsch();
+int warm_tfd_gpu();
 int xyz_write(const char *, const char *const *, int64_t, const double *, int64_t, const char *, int);
 int xyz_read(const char *, int64_t *, int64_t *, char *, double *);
 int launch_embed_mol_transforms(const double *, int64_t, int64_t, const int64_t *, int, const double *,
@@ -647,6 +655,25 @@ int fc_shutdown(void) {
 }
 
 const char *fc_last_error(void) { return last_error().c_str(); }
+
+int fc_warmup(void) {
+  FC_API_LOCK;
+  FC_TRY(ensure_init());
+  FC_TRY(warm_clash());
+  FC_TRY(warm_embed());
+  FC_TRY(warm_embed3());
+  FC_TRY(warm_torsion());
+  FC_TRY(warm_prune());
+  FC_TRY(warm_h2_check());
+  FC_TRY(warm_kabsch());
+  FC_TRY(warm_tfd_gpu());
+  // the buffers a first large call would otherwise take from the runtime one by one (0.2 - 1 ms each): through the pool once
+  {
+    DevBuf warm[6];
+    for (DevBuf &b : warm) FC_TRY(b.reserve((size_t)64 << 20));
+  }
+  return sync();
+}
 
 int fc_memory_trim(void) {
   FC_API_LOCK;

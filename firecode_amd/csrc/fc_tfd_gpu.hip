@@ -926,4 +926,12 @@ int pyset_order_pairs_device(const int64_t *pairs_host, int64_t n, int64_t *orde
   return FC_OK;
 }
 
+// fc_warmup(): the first launch from a translation unit makes the runtime load that unit's code object (milliseconds);
+// a no-op launch moves that cost out of the first real call
+__global__ void k_warm_tfd_gpu() {}
+int warm_tfd_gpu() {
+  hipLaunchKernelGGL(k_warm_tfd_gpu, dim3(1), dim3(64), 0, ctx().stream);
+  return check_launch("k_warm_tfd_gpu");
+}
+
 }  // namespace fc

@@ -623,4 +623,12 @@ int launch_torsion_fingerprint(const double *coords_dev, int64_t N, int64_t A,
   return check_launch("k_torsion_fingerprint");
 }
 
+// fc_warmup(): the first launch from a translation unit makes the runtime load that unit's code object (milliseconds);
+// a no-op launch moves that cost out of the first real call
+__global__ void k_warm_torsion() {}
+int warm_torsion() {
+  hipLaunchKernelGGL(k_warm_torsion, dim3(1), dim3(64), 0, ctx().stream);
+  return check_launch("k_warm_torsion");
+}
+
 }  // namespace fc

@@ -49,6 +49,11 @@ int fc_device_count(void);
 int fc_init(int device);
 int fc_shutdown(void);
 const char *fc_last_error(void);
+/* Optional: pays the one-time costs of a process now instead of inside its first calls -- the HIP runtime loads a
+ * translation unit's device code at that unit's first launch (a few ms each, ~0.1 s over the library) and the first
+ * large call takes its device buffers from the runtime one by one.  For long-running callers and for timing runs;
+ * fc_init stays lazy and cheap (FIRECODE calls from short-lived pool workers, embedder.py:116-120). */
+int fc_warmup(void);
 /* Enqueue everything on the caller's HIP stream (a hipStream_t, e.g. the stream a
  * collective library orders itself against) instead of the library's own non-blocking
  * stream; NULL switches back.  The previous stream is drained first.  The legacy null
