@@ -157,7 +157,22 @@ def mask_checks(mask, assign):
             "survivors_are_last_cluster_members": bool(np.array_equal(np.flatnonzero(mask), np.sort(last)))}
 
 
-def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, world=1, stats=None):
+def pmc_traffic(files, n_conf, n_atoms, world=1):
+    """`roofline.traffic` from a kept rocprofv3 --pmc summary -- only when that file's workload IS the line's
+    (same conformers x atoms, one GPU); otherwise null."""
+    if world != 1 or n_conf is None:
+        return None, None
+    for name in files:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            rec = json.load(open(path))
+            if rec.get("n_conformers") == n_conf and rec.get("n_atoms") == n_atoms:
+                return rec["traffic_bytes_per_launch"], ("from_file: profiles/" + name + " (rocprofv3 --pmc passes of an earlier run of "
+                                                          "this kernel on this workload, not of this run)")
+    return None, None
+
+
+def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, world=1, stats=None, n_conf=None):
     """Dominant kernel of the prune = the all-pairs screen, on the matrix pipe.
     achieved = MFMA flops of the all-pairs covariance (9 entries x K = atoms padded to 4, per pair) /
     HIP-event time of the screen kernels.  The lean fp32 screen runs in two stages (subset of the
@@ -172,11 +187,8 @@ def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, wo
         flops = 3 * 2 * 9 * a32
         tflops = owned_pairs * flops / (kernel_ms * 1e-3) / 1e12
         eq = owned_pairs * 2 * 9 * ((n_atoms + 3) // 4 * 4) / (kernel_ms * 1e-3) / 1e12
-        traffic, src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_screen_h2.json")
-        if traffic_file and world == 1 and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-            src = "from_file: " + os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes of an earlier run of this kernel, not of this run)"
+        traffic, src = pmc_traffic(("r03_pmc_screen_h2.json", "r03_pmc_screen_h2_cfg4_member.json"), n_conf if traffic_file else None,
+                                   n_atoms, world)
         return {"bound": "mfma", "kernel": "k_simbits_screen_mfma_h2", "achieved": tflops, "peak": PEAK_F16_MFMA,
                 "unit": "TFLOP/s", "frac": tflops / PEAK_F16_MFMA, "traffic": traffic, "traffic_source": src,
                 "kernel_ms": kernel_ms, "flops_per_pair": flops, "dtype": "f16x2",
@@ -205,11 +217,7 @@ def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, wo
                   "executed_frac": executed / (kernel_ms * 1e-3) / 1e12 / peak,
                   "kernels": "k_simbits_screen_mfma_f32<4, false, true> (subset stage, sample + rest) + "
                              "k_screen_density_verdict + k_screen_units_f32 (full test per queued unit)"}
-    traffic, src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_screen_f32.json" if f32 else "r02_pmc_screen_f64.json")
-    if traffic_file and world == 1 and os.path.exists(pmc):
-        traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-        src = "from_file: " + os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes of an earlier run of this kernel, not of this run)"
+    traffic, src = None, None  # (no round-3 counter passes of the fp32 / fp64 screens: profiles/r02_pmc_screen_f32|f64.json are round 2's)
     return {"bound": "mfma", "kernel": "k_simbits_screen_mfma_f32" if f32 else "k_simbits_screen_mfma",
             "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": traffic,
             "traffic_source": src, "kernel_ms": kernel_ms, "flops_per_pair": flops, "dtype": "f32" if f32 else "f64",
@@ -388,13 +396,7 @@ def main():
 def complete_roofline(kernel_ms, owned_pairs, n_conf, n_atoms, world):
     fl = FLOPS_PER_ALIGNMENT(n_atoms)
     tflops = owned_pairs * fl / (kernel_ms * 1e-3) / 1e12
-    traffic, src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_complete.json")
-    if world == 1 and os.path.exists(pmc):
-        rec = json.load(open(pmc))
-        if rec.get("n_conformers") == n_conf and rec.get("n_atoms") == n_atoms:  # only the line's own workload
-            traffic = rec["traffic_bytes_per_launch"]
-            src = "from_file: " + os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes of an earlier run of this kernel on this workload)"
+    traffic, src = pmc_traffic(("r03_pmc_complete.json",), n_conf, n_atoms, world)
     return {"bound": "mfma", "kernel": "k_simbits_screen_mfma<4, 2>", "achieved": tflops, "peak": PEAK_F64_MFMA,
             "unit": "TFLOP/s", "frac": tflops / PEAK_F64_MFMA, "traffic": traffic, "traffic_source": src,
             "kernel_ms": kernel_ms, "flops_per_alignment": fl, "dtype": "f64",
@@ -545,7 +547,7 @@ def prune_block(ctx, workload, ens, coords, atoms, assign, n_conf, n_atoms, step
     t_kernel_ms = tk / steps
     if rank != 0:
         return None
-    roof = screen_roofline(_lib, t_kernel_ms, owned, n_atoms, traffic_file=(workload == "cfg2" and n_conf == 10000), world=world, stats=stats)
+    roof = screen_roofline(_lib, t_kernel_ms, owned, n_atoms, world=world, stats=stats, n_conf=n_conf)
     roof["kernel_ms_source"] = ("HIP events on the kernel's stream around every %sth launch of the timed region "
                                 "(an event pair costs the stream ~14 us; FC_BENCH_EVENT_STRIDE=1 times all)"
                                 % os.environ.get("FC_BENCH_EVENT_STRIDE", "8")) + ("" if world == 1 else "; rank 0's launches")
@@ -668,7 +670,9 @@ def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_at
         sec["refine"] = {"kernel": "k_refine_pairs", "kernel_ms": r_ms, "candidates": int(n_cand),
                          "alignments_per_s": n_cand / (r_ms * 1e-3),
                          "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                      "algorithmic_bytes_per_alignment": bpa, "traffic": None,
+                                      "algorithmic_bytes_per_alignment": bpa,
+                                      "traffic": pmc_traffic(("r03_pmc_refine.json",), n_conf, n_atoms)[0],
+                                      "traffic_source": pmc_traffic(("r03_pmc_refine.json",), n_conf, n_atoms)[1],
                                       "note": "the kernel north_star describes: one exact fp64 alignment (rotation, rmsd, max deviation) "
                                               "per queued candidate pair, both conformers fetched per pair; SURVEY 8d bytes against 8 TB/s"}}
     out["config"]["secondary"] = sec
