@@ -225,14 +225,16 @@ static void context_teardown() {
   Context &c = ctx();
   if (!c.ready) return;
   (void)hipStreamSynchronize(c.stream);
-  for (hipStream_t s : {c.s_screen, c.s_lane[0], c.s_lane[1], c.s_comm})
+  for (hipStream_t s : {c.s_screen, c.s_lane[0], c.s_lane[1], c.s_lane[2], c.s_comm})
     if (s) {
       (void)hipStreamSynchronize(s);
       (void)hipStreamDestroy(s);
     }
-  c.s_screen = c.s_lane[0] = c.s_lane[1] = c.s_comm = nullptr;
+  c.s_screen = c.s_lane[0] = c.s_lane[1] = c.s_lane[2] = c.s_comm = nullptr;
   for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
   c.ev_pool.clear();
+  for (hipEvent_t e : c.ev_dep_pool) (void)hipEventDestroy(e);
+  c.ev_dep_pool.clear();
   for (hipEvent_t *e : {&c.ev0, &c.ev1, &c.ev2, &c.ev3, &c.ev_reset, &c.ev_screened, &c.ev_comm[0], &c.ev_comm[1]})
     if (*e) {
       (void)hipEventDestroy(*e);
@@ -295,6 +297,7 @@ int side_streams() {
   FC_HIP_TRY(hipStreamCreateWithPriority(&c.s_screen, hipStreamNonBlocking, least));
   FC_HIP_TRY(hipStreamCreateWithPriority(&c.s_lane[0], hipStreamNonBlocking, greatest));
   FC_HIP_TRY(hipStreamCreateWithPriority(&c.s_lane[1], hipStreamNonBlocking, greatest));
+  FC_HIP_TRY(hipStreamCreateWithPriority(&c.s_lane[2], hipStreamNonBlocking, greatest));
   FC_HIP_TRY(hipStreamCreateWithPriority(&c.s_comm, hipStreamNonBlocking, greatest));
   FC_HIP_TRY(hipEventCreateWithFlags(&c.ev_reset, hipEventDisableTiming));
   FC_HIP_TRY(hipEventCreateWithFlags(&c.ev_screened, hipEventDisableTiming));
@@ -2277,23 +2280,33 @@ int fc_xyz_read(const char *path, int64_t N, int64_t A, char *atoms_out, double 
 // between two prunes (~45 us of sync wake-up and launch latency on an idle GPU).
 //
 // overlap: all screens go, in order, to one stream, so two screens never share the chip and
-// their event durations stay those of a kernel that has the matrix pipes to itself; the ~80 us
-// of refine, level buckets, ladder and result copy of prune r go to stream r&1 of two others
-// and run beside the screen of prune r+1.  A workspace may therefore appear again only an even
-// number of places later (same lane: ordered on that lane's stream); fc_prune_rmsd_many passes
-// distinct ensembles, the bench hook alternates an ensemble and its twin.
+// their event durations stay those of a kernel that has the matrix pipes to itself; verdict,
+// refine, level buckets, ladder and result copy of prune r (eight small launches: ~110 us alone,
+// up to 250 us beside a screen that holds every workgroup slot) go to stream r % kPruneLanes of
+// three others and run beside the screens of prunes r+1 and r+2 -- with two lanes that chain,
+// not the screen, set the pace (0.202 ms per prune at a 0.165 ms screen).  A workspace may
+// therefore appear again only a multiple of kPruneLanes places later (same lane: ordered on that
+// lane's stream); fc_prune_rmsd_many passes distinct ensembles, the bench hook cycles through an
+// ensemble and its twins.
 // The caller reads the slots with ladder_collect(work[r], r, ..., stride).
+constexpr int kPruneLanes = 3;
 static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, double max_dev,
                           int64_t min_per_group, bool overlap, int64_t stride, double *screen_ms_sum,
                           double *total_ms) {
   Context &c = ctx();
   std::vector<hipEvent_t> &ev = c.ev_pool;  // 4 per prune: around the screen kernel, counters reset, screen phase done
-  while ((int64_t)ev.size() < 4 * n + 4) {
+  while ((int64_t)ev.size() < 4 * n + 2 + kPruneLanes) {
     hipEvent_t e = nullptr;
     FC_HIP_TRY(hipEventCreate(&e));
     ev.push_back(e);
   }
   hipEvent_t const ev_begin = ev[4 * n], ev_end = ev[4 * n + 1];
+  std::vector<hipEvent_t> &dep = c.ev_dep_pool;  // 2 per prune: counters reset -> screen, screen -> rest of the prune
+  while ((int64_t)dep.size() < 2 * n) {
+    hipEvent_t e = nullptr;
+    FC_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    dep.push_back(e);
+  }
   FC_TRY(pinned_reserve((size_t)n * (size_t)stride * sizeof(uint64_t)));
   static const int64_t stride_ev = [] {
     const char *v = getenv("FC_BENCH_EVENT_STRIDE");
@@ -2308,21 +2321,23 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
   } restore{c, home};
   const bool lanes = overlap && n > 1;
   if (lanes) FC_TRY(side_streams());
-  hipStream_t const s_screen = c.s_screen, s_lane[2] = {c.s_lane[0], c.s_lane[1]};
+  hipStream_t const s_screen = c.s_screen, s_lane[kPruneLanes] = {c.s_lane[0], c.s_lane[1], c.s_lane[2]};
   // everything enqueued here is ordered behind what the home stream already holds (also what
   // makes pool blocks released by earlier calls safe to reuse on the other streams)
   FC_HIP_TRY(hipEventRecord(ev_begin, home));
   if (lanes)
-    for (hipStream_t s : {s_screen, s_lane[0], s_lane[1]}) FC_HIP_TRY(hipStreamWaitEvent(s, ev_begin, 0));
+    for (hipStream_t s : {s_screen, s_lane[0], s_lane[1], s_lane[2]}) FC_HIP_TRY(hipStreamWaitEvent(s, ev_begin, 0));
+  auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_enqueue0 = now_s();
   for (int64_t r = 0; r < n; ++r) {
     fc_ensemble *e = work[r];
-    hipStream_t const tail = lanes ? s_lane[r & 1] : home, scr = lanes ? s_screen : home;
+    hipStream_t const tail = lanes ? s_lane[r % kPruneLanes] : home, scr = lanes ? s_screen : home;
     c.stream = tail;
     FC_TRY(ensemble_shard(e, 0, 1, default_row_block()));
     FC_HIP_TRY(hipMemsetAsync(e->counters.p, 0, kCounters * sizeof(uint64_t), tail));
     if (lanes) {
-      FC_HIP_TRY(hipEventRecord(ev[4 * r + 2], tail));
-      FC_HIP_TRY(hipStreamWaitEvent(scr, ev[4 * r + 2], 0));
+      FC_HIP_TRY(hipEventRecord(dep[2 * r], tail));
+      FC_HIP_TRY(hipStreamWaitEvent(scr, dep[2 * r], 0));
     }
     c.stream = scr;
     // timing events around the screen kernel of every `stride`-th prune only: the pair costs the
@@ -2331,12 +2346,22 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
     const bool timed = screen_ms_sum != nullptr && r % stride_ev == 0;
     if (timed) FC_HIP_TRY(hipEventRecord(ev[4 * r], scr));
     c.mark_after_screen = timed ? ev[4 * r + 1] : nullptr;  // the launcher records it right behind the screen kernel
+    // with lanes the launcher itself moves to the tail stream behind its main kernel: verdict and gated fp64 screen
+    // run there (27 us between two screens on the screen stream otherwise: tools/step_gaps.py)
+    c.after_main_stream = lanes ? tail : nullptr;
+    c.after_main_event = lanes ? dep[2 * r + 1] : nullptr;
+    c.optimistic_screen = lanes;
     const int rc_screen = launch_simbits_screen(e, max_rmsd * max_rmsd + kScreenMargin);
     c.mark_after_screen = nullptr;
+    c.after_main_stream = nullptr;
+    c.after_main_event = nullptr;
+    c.optimistic_screen = false;
+    const bool moved = c.stream == tail;
+    c.stream = scr;
     FC_TRY(rc_screen);
-    if (lanes) {  // the rest of the prune waits for the whole screen phase (verdict, gated fp64 screen)
-      FC_HIP_TRY(hipEventRecord(ev[4 * r + 3], scr));
-      FC_HIP_TRY(hipStreamWaitEvent(tail, ev[4 * r + 3], 0));
+    if (lanes && !moved) {  // (a launch that ended before its main kernel: nothing to move)
+      FC_HIP_TRY(hipEventRecord(dep[2 * r + 1], scr));
+      FC_HIP_TRY(hipStreamWaitEvent(tail, dep[2 * r + 1], 0));
     }
     c.stream = tail;
     FC_TRY(launch_simbits_refine(e, max_rmsd, max_dev, nullptr, 0.0));
@@ -2345,8 +2370,11 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
                          e->simq.as<uint64_t>(), false, true, r, stride));
   }
   c.stream = home;
-  if (lanes)  // the home stream ends behind the last prune of either lane
-    for (int l = 0; l < 2; ++l) {
+  if (getenv("FC_DEBUG") && n > 8)
+    fprintf(stderr, "[fc] prune_pipeline: %lld prunes enqueued in %.3f ms of host time (%.1f us each)\n", (long long)n,
+            1e3 * (now_s() - t_enqueue0), 1e6 * (now_s() - t_enqueue0) / (double)n);
+  if (lanes)  // the home stream ends behind the last prune of every lane
+    for (int l = 0; l < kPruneLanes; ++l) {
       FC_HIP_TRY(hipEventRecord(ev[4 * n + 2 + l], s_lane[l]));
       FC_HIP_TRY(hipStreamWaitEvent(home, ev[4 * n + 2 + l], 0));
     }
@@ -2727,15 +2755,16 @@ int fc_bench_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, int64
   }();
   const bool lanes = two_lanes && reps > 1;
   const int64_t stride = ens->W + 16;
-  if (lanes && !ens->twin) {
+  fc_ensemble *ws[kPruneLanes] = {ens, ens, ens};
+  if (lanes) {
+    const bool fresh = !ens->twin || !ens->twin->twin;
+    for (int l = 1; l < kPruneLanes; ++l) FC_TRY(ensemble_twin(ws[l - 1], &ws[l]));  // a chain of twins over the same coordinates
     // one whole prune per workspace on the home stream: every grow-only buffer reaches its
     // size here, so no block changes hands while several streams are in flight
-    fc_ensemble *both[2] = {ens, nullptr};
-    FC_TRY(ensemble_twin(ens, &both[1]));
-    FC_TRY(prune_pipeline(both, 2, max_rmsd, max_dev, 20, false, stride, nullptr, nullptr));
+    if (fresh) FC_TRY(prune_pipeline(ws, kPruneLanes, max_rmsd, max_dev, 20, false, stride, nullptr, nullptr));
   }
   std::vector<fc_ensemble *> work((size_t)reps);
-  for (int64_t r = 0; r < reps; ++r) work[(size_t)r] = (lanes && (r & 1)) ? ens->twin : ens;
+  for (int64_t r = 0; r < reps; ++r) work[(size_t)r] = ws[lanes ? r % kPruneLanes : 0];
   double t_kernel = 0.0, total = 0.0;
   FC_TRY(prune_pipeline(work.data(), reps, max_rmsd, max_dev, 20, lanes, stride, &t_kernel, &total));
   int64_t levels = 0, survivors = 0;

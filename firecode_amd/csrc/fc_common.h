@@ -51,6 +51,14 @@ struct Context {
   // when set, launch_simbits_screen records it right behind its main kernel (the fp32 screen is
   // followed by a verdict kernel and a gated fp64 screen that a timing of the kernel must not include)
   hipEvent_t mark_after_screen = nullptr;
+  // pipelined prunes: what follows the main screen kernel of a launch (verdict, gated fp64 screen) goes to this stream,
+  // ordered behind the kernel by this event, so that the screen stream holds nothing but screens
+  hipStream_t after_main_stream = nullptr;
+  // pipelined prunes: a speculative screen whose verdict is "redo in fp64" is not redone in place (the gated fp64
+  // launch would queue its 6 753 workgroups behind the next prune's screen: 170 us on the lane) -- the verdict empties
+  // the queues and sets counters[12], the pair ladder declines, and the caller redoes that prune synchronously
+  bool optimistic_screen = false;
+  hipEvent_t after_main_event = nullptr;
   int n_cu = 0;
   size_t hbm = 0;
   char name[128] = {0};
@@ -59,8 +67,9 @@ struct Context {
   size_t pinned_bytes = 0;
   // side streams and events of the pipelined prunes (prune_pipeline, the sharded steps): created on
   // first use by side_streams(), destroyed by fc_shutdown and when fc_init moves to another device
-  hipStream_t s_screen = nullptr, s_lane[2] = {nullptr, nullptr}, s_comm = nullptr;
+  hipStream_t s_screen = nullptr, s_lane[3] = {nullptr, nullptr, nullptr}, s_comm = nullptr;
   std::vector<hipEvent_t> ev_pool;
+  std::vector<hipEvent_t> ev_dep_pool;  // ordering only (hipEventDisableTiming)
   hipEvent_t ev_reset = nullptr, ev_screened = nullptr, ev_comm[2] = {nullptr, nullptr};
   // incremented by every (re)initialisation: an fc_ensemble remembers the epoch it was built in and
   // is refused afterwards (its buffers and workspaces belong to the context that is gone)

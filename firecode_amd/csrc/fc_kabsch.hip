@@ -1671,7 +1671,7 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
       // of the ensemble, a candidate to stage) sits behind ONE wave-uniform branch per sub-tile each
       const int j = (int)j0 + cs * 16 + l15;
       const float Gq = ldsG[cs * 16 + l15];
-      bool may[4], redo[4];
+      uint64_t mr[4], rdm[4];  // per r: lanes whose pair may be similar / lanes that need the three-test form
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float Gp = ldsG[TC + it * 16 + 4 * kq + r];
@@ -1679,21 +1679,23 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
 #pragma unroll
         for (int e = 0; e < 9; ++e) B9[e] = acc[e][r];
 #ifdef FC_H2_ABLATE_POLY  // timing experiment only (results are wrong): the K loop without the polynomial
-        may[r] = (B9[0] + B9[4] + B9[8]) * B9[1] * B9[2] * B9[3] * B9[5] * B9[6] * B9[7] == 12345.678f * (Gp + Gq);
-        redo[r] = false;
+        mr[r] = __builtin_amdgcn_ballot_w64((B9[0] + B9[4] + B9[8]) * B9[1] * B9[2] * B9[3] * B9[5] * B9[6] * B9[7] ==
+                                            12345.678f * (Gp + Gq));
+        rdm[r] = 0;
 #else
-        may[r] = kabsch_may_be_below_f32_2t(B9, Gp + Gq, half_A_thr2, bd, tiny_floor, redo[r]);
+        mr[r] = kabsch_may_be_below_f32_2t_wave(B9, Gp + Gq, half_A_thr2, bd, tiny_floor, rdm[r]);
 #endif
       }
-      if (__builtin_amdgcn_ballot_w64(redo[0] | redo[1] | redo[2] | redo[3]) != 0ull) {  // nearly collinear structures only
+      if ((rdm[0] | rdm[1] | rdm[2] | rdm[3]) != 0ull) {  // nearly collinear structures only
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float Gp = ldsG[TC + it * 16 + 4 * kq + r];
           float B9[9];
 #pragma unroll
           for (int e = 0; e < 9; ++e) B9[e] = acc[e][r];
-          const bool may3 = kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd, Gp + Gq, tiny_floor);
-          if (redo[r]) may[r] = may3;
+          const uint64_t m3 =
+              __builtin_amdgcn_ballot_w64(kabsch_may_be_below_f32(B9, Gp + Gq, half_A_thr2, bd, Gp + Gq, tiny_floor));
+          mr[r] = (mr[r] & ~rdm[r]) | (m3 & rdm[r]);
         }
       }
       // (strictly above the diagonal and inside the ensemble -- nearly every sub-tile -- no index test)
@@ -1702,16 +1704,14 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = ib32 + 4 * kq + r;
-          may[r] = may[r] && (j > i) && (j < n32) && (i < n32);
+          mr[r] &= __builtin_amdgcn_ballot_w64((j > i) && (j < n32) && (i < n32));
         }
       }
-      uint64_t mr[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mr[r] = __builtin_amdgcn_ballot_w64(may[r]);
       if ((mr[0] | mr[1] | mr[2] | mr[3]) != 0ull) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          stage_pairs<kStagePairsF32>(mr[r], may[r], (unsigned)(ib32 + 4 * kq + r), (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+          stage_pairs<kStagePairsF32>(mr[r], ((mr[r] >> lane) & 1ull) != 0ull, (unsigned)(ib32 + 4 * kq + r), (unsigned)j,
+                                      stageQ, stageN, pairq, Q, counters, lane);
       }
       if (BITS && lane < 16 && ib32 + lane < n32) {
         const int rr = lane & 3;
@@ -1841,14 +1841,15 @@ k_subset_stats(const double *__restrict__ Xs, int64_t Npad, int A, float *__rest
 // more than `max_false` candidates, 256 of them (spread over the queue) are put through the fp64
 // polynomial on their exact covariance; if the candidates that fail it, scaled to the whole
 // queue, exceed `max_false`, counters[11] := 1 and the queues are reset -- the gated fp64 screen
-// behind this kernel then redoes the launch.  Otherwise counters[11] := 0 and the fp64 screen's
+// behind this kernel then redoes the launch (optimistic: counters[12] := 1 instead and no such launch follows; the
+// pair ladder declines and the caller redoes the prune).  Otherwise counters[11] := 0 and the fp64 screen's
 // workgroups return at once.  Results do not depend on the verdict (both screens only ever add
 // candidates); time is bounded by fp32 screen + fp64 screen whatever the data look like.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_screen_verdict(const double *__restrict__ Xa, const double *__restrict__ G, int A, double A_thr2,
                  const uint64_t *__restrict__ pairq, unsigned long long Q, unsigned long long max_false,
-                 unsigned long long *__restrict__ counters) {
+                 unsigned long long *__restrict__ counters, int optimistic) {
   const unsigned long long n = counters[6];
   if (n <= max_false) {  // block-uniform
     if (threadIdx.x == 0) counters[11] = 0ull;
@@ -1874,8 +1875,9 @@ k_screen_verdict(const double *__restrict__ Xa, const double *__restrict__ G, in
   if (threadIdx.x == 0) {
     const double est_false = (double)n * (1.0 - (double)passed / (double)sampled);
     const bool redo = est_false > (double)max_false;
-    counters[11] = redo ? 1ull : 0ull;
+    counters[11] = (redo && !optimistic) ? 1ull : 0ull;
     if (redo) counters[4] = 0ull, counters[6] = 0ull;
+    if (redo && optimistic) counters[12] = 1ull;  // no fp64 launch behind this one: the pair ladder declines (Context::optimistic_screen)
   }
 }
 
@@ -2794,6 +2796,11 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   bool marked = false;
   auto mark_main = [&]() {
     if (!marked && ctx().mark_after_screen) (void)hipEventRecord(ctx().mark_after_screen, ctx().stream);
+    if (!marked && ctx().after_main_stream && ctx().after_main_event) {  // the rest of this launch: on the caller's other stream
+      (void)hipEventRecord(ctx().after_main_event, ctx().stream);
+      (void)hipStreamWaitEvent(ctx().after_main_stream, ctx().after_main_event, 0);
+      ctx().stream = ctx().after_main_stream;
+    }
     marked = true;
   };
   const int64_t NT = e->Npad >> 6;
@@ -3104,8 +3111,9 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         const auto max_false = (unsigned long long)std::max(1024.0, 0.015 * ((double)A4 / 52.0) * owned_pairs);
         hipLaunchKernelGGL(k_screen_verdict, dim3(1), dim3(256), 0, ctx().stream, e->Xa.as<double>(),
                            e->G.as<double>(), (int)e->A, A_thr2, e->pairq.as<uint64_t>(),
-                           (unsigned long long)e->pairq_cap, max_false, cnt);
+                           (unsigned long long)e->pairq_cap, max_false, cnt, ctx().optimistic_screen ? 1 : 0);
         FC_TRY(check_launch("k_screen_verdict"));
+        if (ctx().optimistic_screen) return FC_OK;
         gate = cnt + 11;
       }
       if (two_blocks)
@@ -3193,7 +3201,12 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
                        (unsigned long long)e->pairq_cap, e->simq.as<uint64_t>());
     FC_TRY(check_launch("k_refine_pairs"));
   }
-  hipLaunchKernelGGL(k_simbits_refine, dim3((unsigned)(ctx().n_cu * 16)), dim3(256), 0,
+  static const int per_cu8 = [] {
+    const char *v = getenv("FC_REFINE_GRID8");  // workgroups per CU of the 8-lanes-per-pair kernel (tuning knob)
+    const int k = v ? atoi(v) : 16;
+    return k >= 1 && k <= 64 ? k : 16;
+  }();
+  hipLaunchKernelGGL(k_simbits_refine, dim3((unsigned)(ctx().n_cu * per_cu8)), dim3(256), 0,
                      ctx().stream, e->Xs.as<double>(), e->Xa.as<double>(), e->N, e->Npad, (int)e->A,
                      max_rmsd, max_dev, energies_dev, max_dE, lanes ? -(int)e->row_block : (int)e->row_block, e->rank, e->world,
                      e->rows_local,

@@ -280,6 +280,37 @@ __device__ __forceinline__ bool kabsch_may_be_below_f32_2t(const float (&B)[9], 
   return tiny | !u_ok | !(P0 > bd.p0 * (s2 * s2));
 }
 
+// The two-test form for a whole wavefront: every comparison is read as a 64-lane mask straight from the compare
+// instruction (it writes a scalar register pair anyway) and the verdicts are combined by scalar logic -- no
+// per-lane booleans to keep in vector registers across the rare branches (the compiler packed them into bytes:
+// ~22 vector instructions per 16 x 16 sub-tile of a kernel bound by vector issue).  Same comparisons, same NaN
+// behaviour as kabsch_may_be_below_f32_2t: a failed `>` counts as "may be similar".  All 64 lanes must be active.
+__device__ __forceinline__ uint64_t kabsch_may_be_below_f32_2t_wave(const float (&B)[9], float s, float half_A_thr2,
+                                                                    const KabschF32Bounds &bd, float tiny_floor,
+                                                                    uint64_t &redo) {
+#pragma clang fp contract(fast)
+  const float L = s - half_A_thr2;
+  const float Sxx = B[0], Sxy = B[1], Sxz = B[2];
+  const float Syx = B[3], Syy = B[4], Syz = B[5];
+  const float Szx = B[6], Szy = B[7], Szz = B[8];
+  const float n2 = Sxx * Sxx + Sxy * Sxy + Sxz * Sxz + Syx * Syx + Syy * Syy + Syz * Syz +
+                   Szx * Szx + Szy * Szy + Szz * Szz;
+  const float uu = L * L - n2;
+  const float c00 = Syy * Szz - Syz * Szy, c01 = Syz * Szx - Syx * Szz, c02 = Syx * Szy - Syy * Szx;
+  const float c10 = Sxz * Szy - Sxy * Szz, c11 = Sxx * Szz - Sxz * Szx, c12 = Sxy * Szx - Sxx * Szy;
+  const float c20 = Sxy * Syz - Sxz * Syy, c21 = Sxz * Syx - Sxx * Syz, c22 = Sxx * Syy - Sxy * Syx;
+  const float detB = Sxx * c00 + Sxy * c01 + Sxz * c02;
+  const float e2 = c00 * c00 + c01 * c01 + c02 * c02 + c10 * c10 + c11 * c11 + c12 * c12 +
+                   c20 * c20 + c21 * c21 + c22 * c22;
+  const float P0 = uu * uu - 4.0f * (e2 + 2.0f * L * detB);
+  const float s2 = s * s;
+  const uint64_t not_tiny = __builtin_amdgcn_ballot_w64(tiny_floor < s);
+  const uint64_t u_ok = __builtin_amdgcn_ballot_w64(uu > bd.p2 * s2);
+  const uint64_t p_ok = __builtin_amdgcn_ballot_w64(P0 > bd.p0 * (s2 * s2));
+  redo = ~u_ok & not_tiny;
+  return ~(not_tiny & u_ok & p_ok);
+}
+
 // Bounds for the split-half kernel (k_simbits_screen_mfma_h2): the covariance is accumulated by
 // v_mfma_f32_16x16x32_f16 from coordinates held as hi + lo halfs, scaled by a power of two.  In units
 // of s (scaled), u = 2^-24, entry error of b = B / s:

@@ -222,7 +222,7 @@ k_ladder_pairs(const uint64_t *__restrict__ pairs, const uint64_t *__restrict__ 
   __shared__ unsigned long long s_level_cnt[32];
   const int tid = threadIdx.x;
   const unsigned long long P = *n_pairs_ptr;
-  if ((n_cand_ptr != nullptr && *n_cand_ptr > cand_cap) || P > cap) {
+  if ((n_cand_ptr != nullptr && *n_cand_ptr > cand_cap) || P > cap || counters[12] != 0ull) {  // [12]: the screen's verdict asked for a redo
     if (tid == 0) counters[9] = 0;
     if (tid < 16) mask_out[W + tid] = tid == 9 ? 0ull : counters[tid];
     return;

@@ -241,6 +241,19 @@ def test_fp32_screen_far_from_the_origin(fc, monkeypatch):
     assert np.array_equal(out["0"][0], out["3"][0])
     assert out["0"][1] == out["2"][1] == out["3"][1] == out[None][1]
     assert out["0"][0].any()
+    # the same verdict inside a pipeline of prunes (three lanes): no fp64 launch in place -- the verdict empties the
+    # queues, the pair ladder declines, the call redoes the prune synchronously; same mask as the fp64 screen's
+    masks = {}
+    for mode in ("0", "3"):
+        monkeypatch.setenv("FC_SCREEN_F32", mode)
+        with fc.DeviceEnsemble(X, center=False) as ens:
+            _, _, masks[mode], st = ens.bench_prune(0.5, 1.0, reps=7, want_mask=True)
+            _, _, again, _ = ens.bench_prune(0.5, 1.0, reps=4, want_mask=True)
+            assert np.array_equal(masks[mode], again)
+    assert np.array_equal(masks["0"], masks["3"]) and 0 < masks["0"].sum() < len(X)
+    S = out["0"][0]
+    assert np.array_equal(masks["0"], o.greedy_prune_from_matrix(S | S.T))
+    monkeypatch.delenv("FC_SCREEN_F32")
     # a compact, centred ensemble of the bench's kind: the launcher takes the single-precision screen
     Xc, _, _ = syn.synthetic_ensemble(300, 50, seed=5)
     with fc.DeviceEnsemble(Xc, center=True) as ens:
