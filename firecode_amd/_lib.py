@@ -110,6 +110,7 @@ _SIGNATURES = {
     "fc_torsion_scan_fingerprints": [_p_f64, _i64, _p_i64, _i64, _p_u8, _p_i64, _i64, _f64, _i64, _p_i64, _i64,
                                      _p_f64, _p_i64, _p_f64],
     "fc_torsion_scan_tfd": [_p_f64, _i64, _p_i64, _i64, _p_u8, _p_i64, _i64, _f64, _i64, _p_i64, _i64, _f64, _p_i64, _p_u8],
+    "fc_torsion_scan_tfd_grid": [_p_f64, _i64, _p_i64, _i64, _p_u8, _p_i64, _p_i64, _f64, _i64, _p_i64, _i64, _f64, _p_i64, _p_u8],
     "fc_torsion_fingerprint": [_p_f64, _i64, _i64, _p_i64, _i64, _p_f64],
     "fc_tfd_simbits": [_p_f64, _i64, _i64, _f64, _i64, _i64, _p_u64],
     "fc_tfd_first_match": [_p_f64, _i64, _i64, _f64, _p_i64],

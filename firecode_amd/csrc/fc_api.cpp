@@ -70,6 +70,7 @@ int launch_embed_poses_clash(const double *, int64_t, const double *, int64_t, c
 int launch_torsion_scan(const double *, int64_t, const int64_t *, int64_t, const uint8_t *,
                         const int16_t *, const int16_t *, const int32_t *, const int32_t *,
                         const int64_t *, int64_t, double, int64_t, double *, int64_t *, const int64_t *, int64_t, double *);
+int launch_angle_grid(const int64_t *, const int64_t *, const int64_t *, int64_t, int64_t, int64_t *);
 int launch_torsion_fingerprint(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
 int launch_tfd_first_match(const double *, int64_t, int64_t, int64_t, double, int64_t *, float *);
 int launch_transpose_pad(const double *, int64_t, int64_t, int64_t, double *);
@@ -144,7 +145,7 @@ struct Pool {
   std::mutex mu;
   std::multimap<size_t, void *> free_blocks;  // capacity -> block
   size_t cached = 0;
-  size_t limit = (size_t)2048 << 20;
+  size_t limit = (size_t)8192 << 20;
   bool limit_read = false;
 };
 Pool &pool() {
@@ -670,6 +671,7 @@ int fc_warmup(void) {
   FC_TRY(warm_h2_check());
   FC_TRY(warm_kabsch());
   FC_TRY(warm_tfd_gpu());
+  FC_TRY(tfd_level_streams(3));  // the TFD ladder's helper streams (hardware queues: several ms each on first use)
   // the buffers a first large call would otherwise take from the runtime one by one (0.2 - 1 ms each): through the pool once
   {
     DevBuf warm[6];
@@ -1989,11 +1991,14 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
                              const uint8_t *rotmasks, const int64_t *angles, int64_t S, double thresh,
                              int64_t backoff_deg, const int64_t *quads, int64_t Q, double *coords_out,
                              int64_t *rotated_bonds_out, double *tf_out, double tfd_thresh = 0.0,
-                             uint8_t *tfd_keep_out = nullptr) {
+                             uint8_t *tfd_keep_out = nullptr, const int64_t *grid_values = nullptr,
+                             const int64_t *grid_counts = nullptr) {
+  // grid_values / grid_counts (with angles == nullptr): the angle-sets are the rows of cartesian_product over the T
+  // value lists, generated on the device (k_angle_grid)
   FC_REQUIRE(A >= 2 && T >= 1 && S >= 0 && Q >= 0, "bad shape");
   FC_REQUIRE(backoff_deg != 0, "backoff_deg must be non-zero");
   if (S == 0) return FC_OK;
-  FC_REQUIRE(base && torsions && rotmasks && angles && rotated_bonds_out, "NULL pointer argument");
+  FC_REQUIRE(base && torsions && rotmasks && (angles || (grid_values && grid_counts)) && rotated_bonds_out, "NULL pointer argument");
   FC_REQUIRE(coords_out || tf_out || tfd_keep_out, "nothing to compute: coords_out and tf_out are both NULL");
   const bool want_tf = tf_out != nullptr || tfd_keep_out != nullptr;
   FC_REQUIRE(!want_tf || (quads != nullptr && Q >= 1), "fingerprints need quadruplets");
@@ -2023,7 +2028,19 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   FC_TRY(upload(drs, rs.data(), rs.size()));
   FC_TRY(upload(dnm, nmv.data(), nmv.size()));
   FC_TRY(upload(dnr, nrs.data(), nrs.size()));
-  FC_TRY(upload(da, angles, (size_t)S * T));
+  if (angles) {
+    FC_TRY(upload(da, angles, (size_t)S * T));
+  } else {
+    std::vector<int64_t> first((size_t)T, 0);
+    for (int64_t t = 1; t < T; ++t) first[(size_t)t] = first[(size_t)t - 1] + grid_counts[t - 1];
+    DevBuf dval, dfirst, dcnt;
+    FC_TRY(upload(dval, grid_values, (size_t)(first[(size_t)T - 1] + grid_counts[T - 1])));
+    FC_TRY(upload(dfirst, first.data(), (size_t)T));
+    FC_TRY(upload(dcnt, grid_counts, (size_t)T));
+    FC_TRY(da.reserve((size_t)S * T * sizeof(int64_t)));
+    FC_TRY(launch_angle_grid(dval.as<int64_t>(), dfirst.as<int64_t>(), dcnt.as<int64_t>(), T, S, da.as<int64_t>()));
+    FC_TRY(sync());  // (`first` and the three small buffers end here)
+  }
   if (coords_out) FC_TRY(dout.reserve((size_t)S * A * 3 * sizeof(double)));
   FC_TRY(drot.reserve((size_t)S * sizeof(int64_t)));
   if (want_tf) {
@@ -2098,6 +2115,25 @@ int fc_torsion_scan_tfd(const double *base, int64_t A, const int64_t *torsions, 
   }
   return torsion_scan_impl(base, A, torsions, T, rotmasks, angles, S, thresh, backoff_deg, quads, Q, nullptr,
                            rotated_bonds_out, nullptr, tfd_thresh, keep_out);
+}
+
+int fc_torsion_scan_tfd_grid(const double *base, int64_t A, const int64_t *torsions, int64_t T, const uint8_t *rotmasks,
+                             const int64_t *values, const int64_t *counts, double thresh, int64_t backoff_deg,
+                             const int64_t *quads, int64_t Q, double tfd_thresh, int64_t *rotated_bonds_out, uint8_t *keep_out) {
+  FC_API_LOCK;
+  FC_REQUIRE(keep_out != nullptr && counts != nullptr && values != nullptr && T >= 1, "NULL pointer argument");
+  int64_t S = 1;
+  for (int64_t t = 0; t < T; ++t) {
+    FC_REQUIRE(counts[t] >= 0, "counts[%lld] is negative", (long long)t);
+    FC_REQUIRE(counts[t] == 0 || S <= ((int64_t)1 << 40) / std::max<int64_t>(counts[t], 1), "the grid has more than 2^40 rows");
+    S *= counts[t];
+  }
+  if (S == 0) {  // the starting structure alone: nothing to compare it with
+    keep_out[0] = 1;
+    return FC_OK;
+  }
+  return torsion_scan_impl(base, A, torsions, T, rotmasks, nullptr, S, thresh, backoff_deg, quads, Q, nullptr,
+                           rotated_bonds_out, nullptr, tfd_thresh, keep_out, values, counts);
 }
 
 int fc_torsion_fingerprint(const double *coords, int64_t N, int64_t A, const int64_t *quads,

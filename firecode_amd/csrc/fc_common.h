@@ -80,6 +80,7 @@ struct Context {
 // after the other.  Recursive: entry points are also used as building blocks of others.
 std::recursive_mutex &api_mutex();
 #define FC_API_LOCK std::lock_guard<std::recursive_mutex> fc_api_lock_guard(::fc::api_mutex())
+int tfd_level_streams(int n);  // fc_tfd_host.cpp: the ladder's helper streams, created once
 int side_streams();  // creates Context::s_screen / s_lane / s_comm and the ordering events once
 int pinned_reserve(size_t bytes);  // grows ctx().pinned
 Context &ctx();
@@ -93,10 +94,31 @@ int ensure_init();  // lazy init on device 0 (or the one given to fc_init)
 // enqueue on ONE stream (fc_stream_set drains the old one), and every multi-stream region
 // (prune_pipeline, the sharded steps) starts behind an event recorded on that stream, ends with a
 // wait on all its side streams, and sizes its grow-only buffers before it forks.
-// FC_POOL_MB caps what is kept (default 2048, 0 = no caching); fc_memory_trim() empties it.
+// FC_POOL_MB caps what is kept (default 8192 of the 288 GB, 0 = no caching); fc_memory_trim() empties it.
 void *pool_take(size_t n, size_t *capacity);  // nullptr when the device is out of memory
 void pool_give(void *p, size_t capacity);
 void pool_trim();
+
+// One block that a job carves its many temporaries from (bump pointer, 256-byte pieces) instead of taking each from the
+// pool: a cold pool pays a hipMalloc per buffer (0.2 - 1 ms; a TFD ladder level has ~45), a block is one.  Active for
+// the calling thread between ArenaScope's constructor and destructor; DevBuf::reserve falls back to the pool when the
+// block is used up.  Pieces are views (never given back one by one): the block returns to the pool with the scope,
+// which the job ends only behind its last kernel.
+struct DevArena {
+  char *base = nullptr;
+  size_t size = 0, used = 0;
+  void *take(size_t n) {
+    const size_t need = (n + 255) & ~(size_t)255;
+    if (!base || used + need > size) return nullptr;
+    void *q = base + used;
+    used += need;
+    return q;
+  }
+};
+inline DevArena *&thread_arena() {
+  static thread_local DevArena *a = nullptr;
+  return a;
+}
 
 struct DevBuf {
   void *p = nullptr;
@@ -129,6 +151,15 @@ struct DevBuf {
     if (n <= bytes && p) return FC_OK;
     release();
     if (n == 0) n = 8;
+    if (DevArena *a = thread_arena()) {
+      if (void *q = a->take(n)) {
+        p = q;
+        bytes = (n + 255) & ~(size_t)255;
+        epoch = ctx().epoch;
+        owned = false;
+        return FC_OK;
+      }
+    }
     size_t cap = 0;
     p = pool_take(n, &cap);
     if (!p) return set_error(FC_E_NOMEM, "device allocation of %zu bytes failed", n);
@@ -140,18 +171,53 @@ struct DevBuf {
   T *as() const { return static_cast<T *>(p); }
 };
 
+struct ArenaScope {  // declare BEFORE the buffers that are to come from it (destroyed after them)
+  DevBuf block;
+  DevArena arena;
+  DevArena *prev = nullptr;
+  bool active = false;
+  int begin(size_t bytes) {
+    prev = thread_arena();
+    thread_arena() = nullptr;  // the block itself comes from the pool
+    const int rc = block.reserve(bytes);
+    if (rc != FC_OK) {
+      thread_arena() = prev;
+      return rc;
+    }
+    arena.base = static_cast<char *>(block.p), arena.size = block.bytes, arena.used = 0;
+    thread_arena() = &arena;
+    active = true;
+    return FC_OK;
+  }
+  ~ArenaScope() {
+    if (active) thread_arena() = prev;
+  }
+};
+
+// The stream a helper thread enqueues on (nullptr: the context's).  Set only by code that runs several independent
+// device jobs from threads of its own inside ONE API call (the TFD ladder's coarse levels): each job's stream starts
+// behind an event on the context's stream, and a job synchronises its stream before it releases a pool block.
+inline hipStream_t &thread_stream_override() {
+  static thread_local hipStream_t s = nullptr;
+  return s;
+}
+inline hipStream_t cur_stream() {
+  hipStream_t s = thread_stream_override();
+  return s ? s : ctx().stream;
+}
+
 inline int h2d(void *dst, const void *src, size_t n) {
   if (n == 0) return FC_OK;
-  FC_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, ctx().stream));
+  FC_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, cur_stream()));
   return FC_OK;
 }
 inline int d2h(void *dst, const void *src, size_t n) {
   if (n == 0) return FC_OK;
-  FC_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, ctx().stream));
+  FC_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, cur_stream()));
   return FC_OK;
 }
 inline int sync() {
-  FC_HIP_TRY(hipStreamSynchronize(ctx().stream));
+  FC_HIP_TRY(hipStreamSynchronize(cur_stream()));
   return FC_OK;
 }
 inline int check_launch(const char *what) {
@@ -196,6 +262,11 @@ struct TfdLevelGraph {
   // (level-wide node numbers) in insertion order
   std::vector<int32_t> nodes, adj_head, adj_next, sources;
   std::vector<int32_t> left;  // components the device left to the host (flags mode: those above its size cap)
+  // flags mode: the arrays above hold ONLY the left components (compact numbering, CSR concatenated: left = 0 .. n - 1,
+  // component j = nodes [sources[j], sources[j + 1])), left_chunk[j] = the chunk component j lives in, n_components = the
+  // level's component count (for the log)
+  std::vector<int32_t> left_chunk;
+  int64_t n_components = 0;
 };
 int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevelGraph &out, uint8_t *flags_out = nullptr);
 

@@ -31,9 +31,33 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "fc_common.h"
+
+// In this file a function that fails half-way drains its stream before it returns: its buffers go back to the pool on the
+// way out, and their next user may be a job on ANOTHER stream (the ladder's levels run side by side), which stream
+// order would not protect.  On success every function here ends with its own synchronisation.
+#undef FC_TRY
+#define FC_TRY(expr)                                  \
+  do {                                                \
+    int _rc = (expr);                                 \
+    if (_rc != FC_OK) {                               \
+      (void)hipStreamSynchronize(::fc::cur_stream()); \
+      return _rc;                                     \
+    }                                                 \
+  } while (0)
+#undef FC_HIP_TRY
+#define FC_HIP_TRY(expr)                                                                                          \
+  do {                                                                                                            \
+    hipError_t _e = (expr);                                                                                       \
+    if (_e != hipSuccess) {                                                                                       \
+      (void)hipStreamSynchronize(::fc::cur_stream());                                                             \
+      return ::fc::set_error(_e == hipErrorOutOfMemory ? FC_E_NOMEM : FC_E_HIP, "%s failed: %s (%s:%d)", #expr,   \
+                             hipGetErrorString(_e), __FILE__, __LINE__);                                          \
+    }                                                                                                             \
+  } while (0)
 
 namespace fc {
 
@@ -196,14 +220,24 @@ k_set_order(const unsigned long long *__restrict__ buf0, const unsigned long lon
 
 struct Scratch {  // temporary storage of the scans / sorts (grow-only)
   DevBuf tmp;
-  int reserve(size_t n) { return tmp.reserve(n); }
+  std::vector<std::unique_ptr<DevBuf>> retired;  // outgrown blocks: kernels in flight may still use them, so they go back
+                                                 // to the pool with the Scratch (behind its owner's synchronisation)
+  int reserve(size_t n) {
+    if (n <= tmp.bytes && tmp.p) return FC_OK;
+    if (tmp.p) {
+      retired.emplace_back(new DevBuf);
+      retired.back()->p = tmp.p, retired.back()->bytes = tmp.bytes, retired.back()->epoch = tmp.epoch, retired.back()->owned = tmp.owned;
+      tmp.p = nullptr, tmp.bytes = 0;
+    }
+    return tmp.reserve(n);
+  }
 };
 
 int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, Scratch &scr) {
   size_t bytes = 0;
-  FC_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, ctx().stream));
+  FC_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, cur_stream()));
   FC_TRY(scr.reserve(bytes));
-  FC_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scr.tmp.p, bytes, in, out, (int)n, ctx().stream));
+  FC_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scr.tmp.p, bytes, in, out, (int)n, cur_stream()));
   return FC_OK;
 }
 
@@ -250,7 +284,7 @@ int pyset_orders_device(const int32_t *valid, const int32_t *rank, const int64_t
   FC_TRY(d_pos.reserve((size_t)n_items * sizeof(uint32_t)));
   FC_TRY(d_occ.reserve((size_t)(total + 1) * sizeof(int32_t)));
   FC_TRY(d_occ_scan.reserve((size_t)(total + 1) * sizeof(int32_t)));
-  hipStream_t st = ctx().stream;
+  hipStream_t st = cur_stream();
   const dim3 igrid((unsigned)ceil_div(n_items, 256)), block(256);
   uint32_t max_final = 0;
   for (uint32_t f : fin_size) max_final = std::max(max_final, f);
@@ -683,6 +717,51 @@ k_lvl_components(const int32_t *__restrict__ nodes, const int32_t *__restrict__ 
 
 // flags_out != nullptr: the component phase runs on the device too and flags_out[i] = 1 for every structure a
 // non-last chunk of the level rejects (d (k - 1) bytes); the graph arrays are then not downloaded.
+// The components the device left to the host (more than size_cap nodes), cut out of the level's arrays: sizes ...
+__global__ void __launch_bounds__(256)
+k_left_sizes(const int32_t *__restrict__ left, int n_left, const int32_t *__restrict__ starts, int64_t n_src, int64_t n_nodes,
+             const int32_t *__restrict__ head, const int64_t *__restrict__ nbase, int n_chunks, int32_t *__restrict__ cnt_nodes,
+             int32_t *__restrict__ cnt_adj, int32_t *__restrict__ chunk_of) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j > n_left) return;
+  if (j == n_left) {  // (the scans run over n_left + 1 entries)
+    cnt_nodes[j] = 0, cnt_adj[j] = 0;
+    return;
+  }
+  const int32_t c = left[j];
+  const int64_t s0 = starts[c], s1 = (int64_t)c + 1 < n_src ? (int64_t)starts[c + 1] : n_nodes;
+  cnt_nodes[j] = (int32_t)(s1 - s0);
+  cnt_adj[j] = head[s1] - head[s0];
+  int lo = 0, hi = n_chunks;  // largest chunk with nbase[chunk] <= s0
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (nbase[mid] <= s0) lo = mid;
+    else hi = mid;
+  }
+  chunk_of[j] = lo;
+}
+// ... and contents, in compact numbering: block j copies component j (nodes, neighbour-list heads, neighbours)
+__global__ void __launch_bounds__(256)
+k_left_gather(const int32_t *__restrict__ left, int n_left, const int32_t *__restrict__ starts, int64_t n_src, int64_t n_nodes,
+              const int32_t *__restrict__ nodes, const int32_t *__restrict__ head, const int32_t *__restrict__ adj,
+              const int32_t *__restrict__ off_nodes, const int32_t *__restrict__ off_adj, int32_t *__restrict__ c_nodes,
+              int32_t *__restrict__ c_head, int32_t *__restrict__ c_adj) {
+  const int j = blockIdx.x;
+  if (j >= n_left) return;
+  const int32_t c = left[j];
+  const int64_t s0 = starts[c], s1 = (int64_t)c + 1 < n_src ? (int64_t)starts[c + 1] : n_nodes;
+  const int32_t a0 = head[s0], a1 = head[s1];
+  const int32_t on = off_nodes[j], oa = off_adj[j];
+  for (int64_t i = threadIdx.x; i < s1 - s0; i += 256) {
+    c_nodes[on + i] = nodes[s0 + i];
+    c_head[on + i] = oa + (head[s0 + i] - a0);
+  }
+  for (int32_t e = threadIdx.x; e < a1 - a0; e += 256) c_adj[oa + e] = (int32_t)((int64_t)adj[a0 + e] - s0 + on);
+  if (threadIdx.x == 0 && j == n_left - 1) c_head[on + (s1 - s0)] = oa + (a1 - a0);  // the closing entry of the last list
+}
+
+// One level's chunk graphs (and, with flags_out, its component phase) on cur_stream().  Levels are independent: the
+// ladder runs several at a time from threads of its own, each on its own stream (thread_stream_override).
 int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevelGraph &out, uint8_t *flags_out) {
   const int64_t d = N / k;
   const int n_chunks = (int)(k - 1);
@@ -693,9 +772,15 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
   out.nbase.assign((size_t)n_chunks + 1, 0);
   out.sbase.assign((size_t)n_chunks + 1, 0);
   out.nodes.clear(); out.adj_head.clear(); out.adj_next.clear(); out.sources.clear();
+  out.left.clear(); out.left_chunk.clear();  // (holders are reused: nothing of the previous level may survive an early return)
+  out.n_components = 0;
   if (n_chunks <= 0 || n_items <= 0) return FC_OK;
   if (n_items >= (1ll << 30)) return set_error(FC_E_LIMIT, "level too large for the device graph builder");
-  hipStream_t st = ctx().stream;
+  hipStream_t st = cur_stream();
+  // every temporary of the level from one block: ~200 B per item for the arrays below plus the set tables (24 B per
+  // slot, up to 6.7 slots per key); what does not fit comes from the pool as before
+  ArenaScope arena;
+  FC_TRY(arena.begin((size_t)n_items * 400 + ((size_t)32 << 20)));
   Scratch scr;
   const dim3 block(256), igrid((unsigned)ceil_div(n_items + 1, 256));
   static const bool dbg = getenv("FC_DEBUG") != nullptr && getenv("FC_TFD_LAPS") != nullptr;
@@ -841,12 +926,16 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
   }
   const int64_t n_src = out.sbase[(size_t)n_chunks];
   lap("adjacency");
+  DevBuf d_need, d_soff, d_scratch, d_flags, d_left;  // (function scope: copies from them are still in flight below)
+  DevBuf d_lcn, d_lca, d_lon, d_loa, d_lchunk, d_cnodes, d_chead, d_cadj;
   if (flags_out != nullptr) {
-    DevBuf d_need, d_soff, d_scratch, d_flags, d_left;
     static const int64_t size_cap = [] {
       const char *v = getenv("FC_TFD_DEV_COMP_MAX");  // components above this many nodes go to the host threads
-      const long long k = v ? std::strtoll(v, nullptr, 10) : 256;
-      return (int64_t)(k >= 4 ? k : 256);
+      // 256 .. 4096 measured at 1.7 M structures (largest component there: 3 837 nodes): 1024 leaves the three finest
+      // device levels nothing to send down (their graph arrays are ~20 MB each, first touched by the first call) at the same
+      // steady time as 256; 1536 and above make the longest lane of the component kernel the critical path
+      const long long k = v ? std::strtoll(v, nullptr, 10) : 1024;
+      return (int64_t)(k >= 4 ? k : 1024);
     }();
     FC_TRY(d_need.reserve((size_t)(n_src + 1) * sizeof(int32_t)));
     FC_TRY(d_soff.reserve((size_t)(n_src + 1) * sizeof(int32_t)));
@@ -874,14 +963,52 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
     FC_TRY(sync());
     lap("device components + flags down");
     out.left.clear();
-    if (n_left == 0) {
-      out.sources.assign((size_t)n_src + 1, 0);  // (only the count is reported)
-      return FC_OK;
-    }
+    out.left_chunk.clear();
+    out.n_components = n_src;
+    out.sources.assign(1, 0);
+    if (n_left == 0) return FC_OK;
+    // ... and the host's walk over those components needs THEIR nodes and neighbour lists only (at 1.7 M structures a
+    // few dozen components of up to 3 837 nodes out of 1.6 M nodes: kilobytes instead of the level's 20 MB of arrays)
+    FC_TRY(d_lcn.reserve((size_t)(n_left + 1) * sizeof(int32_t)));
+    FC_TRY(d_lca.reserve((size_t)(n_left + 1) * sizeof(int32_t)));
+    FC_TRY(d_lon.reserve((size_t)(n_left + 1) * sizeof(int32_t)));
+    FC_TRY(d_loa.reserve((size_t)(n_left + 1) * sizeof(int32_t)));
+    FC_TRY(d_lchunk.reserve((size_t)(n_left + 1) * sizeof(int32_t)));
+    hipLaunchKernelGGL(k_left_sizes, dim3((unsigned)ceil_div((int64_t)n_left + 1, 256)), block, 0, st, d_left.as<int32_t>() + 1, (int)n_left,
+                       d_starts.as<int32_t>(), n_src, n_nodes, d_head.as<int32_t>(), d_nbase.as<int64_t>(), n_chunks,
+                       d_lcn.as<int32_t>(), d_lca.as<int32_t>(), d_lchunk.as<int32_t>());
+    FC_TRY(check_launch("k_left_sizes"));
+    FC_TRY(exclusive_scan_i32(d_lcn.as<int32_t>(), d_lon.as<int32_t>(), (int64_t)n_left + 1, scr));
+    FC_TRY(exclusive_scan_i32(d_lca.as<int32_t>(), d_loa.as<int32_t>(), (int64_t)n_left + 1, scr));
+    int32_t tot_nodes = 0, tot_adj = 0;
+    FC_TRY(d2h(&tot_nodes, d_lon.as<int32_t>() + n_left, sizeof(int32_t)));
+    FC_TRY(d2h(&tot_adj, d_loa.as<int32_t>() + n_left, sizeof(int32_t)));
+    FC_TRY(sync());
+    FC_TRY(d_cnodes.reserve((size_t)std::max(tot_nodes, 1) * sizeof(int32_t)));
+    FC_TRY(d_chead.reserve(((size_t)tot_nodes + 1) * sizeof(int32_t)));
+    FC_TRY(d_cadj.reserve((size_t)std::max(tot_adj, 1) * sizeof(int32_t)));
+    hipLaunchKernelGGL(k_left_gather, dim3((unsigned)n_left), block, 0, st, d_left.as<int32_t>() + 1, (int)n_left, d_starts.as<int32_t>(),
+                       n_src, n_nodes, d_nodes2.as<int32_t>(), d_head.as<int32_t>(), d_vals2.as<int32_t>(), d_lon.as<int32_t>(),
+                       d_loa.as<int32_t>(), d_cnodes.as<int32_t>(), d_chead.as<int32_t>(), d_cadj.as<int32_t>());
+    FC_TRY(check_launch("k_left_gather"));
     out.left.resize((size_t)n_left);
-    FC_TRY(d2h(out.left.data(), d_left.as<int32_t>() + 1, (size_t)n_left * sizeof(int32_t)));
-    // ... and the graph arrays for the host's walk over those components
+    for (int32_t j = 0; j < n_left; ++j) out.left[(size_t)j] = j;
+    out.left_chunk.resize((size_t)n_left);
+    out.nodes.resize((size_t)tot_nodes);
+    out.adj_head.resize((size_t)tot_nodes + 1);
+    out.adj_next.resize((size_t)tot_adj);
+    out.sources.resize((size_t)n_left + 1);
+    FC_TRY(d2h(out.left_chunk.data(), d_lchunk.p, (size_t)n_left * sizeof(int32_t)));
+    FC_TRY(d2h(out.nodes.data(), d_cnodes.p, (size_t)tot_nodes * sizeof(int32_t)));
+    FC_TRY(d2h(out.adj_head.data(), d_chead.p, ((size_t)tot_nodes + 1) * sizeof(int32_t)));
+    FC_TRY(d2h(out.adj_next.data(), d_cadj.p, (size_t)tot_adj * sizeof(int32_t)));
+    FC_TRY(d2h(out.sources.data(), d_lon.p, ((size_t)n_left + 1) * sizeof(int32_t)));
+    FC_TRY(sync());
+    lap("left components down");
+    return FC_OK;
   }
+  out.left_chunk.clear();
+  out.n_components = n_src;
   out.nodes.resize((size_t)n_nodes);
   out.adj_head.resize((size_t)n_nodes + 1);
   out.adj_next.resize((size_t)n_times);
@@ -912,7 +1039,7 @@ int pyset_order_pairs_device(const int64_t *pairs_host, int64_t n, int64_t *orde
   FC_TRY(deb.reserve(2 * sizeof(int64_t)));
   const int64_t eb[2] = {0, n};
   FC_TRY(h2d(deb.p, eb, sizeof eb));
-  hipLaunchKernelGGL(k_pair_hashes, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, dp.as<int64_t>(), n,
+  hipLaunchKernelGGL(k_pair_hashes, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, cur_stream(), dp.as<int64_t>(), n,
                      dh.as<int64_t>(), dv.as<int32_t>(), dr.as<int32_t>());
   FC_TRY(check_launch("k_pair_hashes"));
   Scratch scr;
@@ -930,7 +1057,7 @@ int pyset_order_pairs_device(const int64_t *pairs_host, int64_t n, int64_t *orde
 // a no-op launch moves that cost out of the first real call
 __global__ void k_warm_tfd_gpu() {}
 int warm_tfd_gpu() {
-  hipLaunchKernelGGL(k_warm_tfd_gpu, dim3(1), dim3(64), 0, ctx().stream);
+  hipLaunchKernelGGL(k_warm_tfd_gpu, dim3(1), dim3(64), 0, cur_stream());
   return check_launch("k_warm_tfd_gpu");
 }
 

@@ -23,6 +23,8 @@
 #include <algorithm>
 #include <atomic>
 #include <memory>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -566,7 +568,8 @@ static void level_rejects_from_graph(const TfdLevelGraph &g, unsigned threads, u
   if (only_left) {
     for (const int32_t j : g.left) {
       const int64_t s0 = g.sources[(size_t)j];
-      const int c = (int)(std::upper_bound(g.nbase.begin(), g.nbase.end(), s0) - g.nbase.begin()) - 1;
+      const int c = !g.left_chunk.empty() ? (int)g.left_chunk[(size_t)j]  // (compact arrays: the device says which chunk)
+                                          : (int)(std::upper_bound(g.nbase.begin(), g.nbase.end(), s0) - g.nbase.begin()) - 1;
       jobs.push_back(Job{c, j, (int64_t)j + 1});
     }
   } else {
@@ -627,6 +630,25 @@ static void level_chunks(const int64_t *fm, int64_t N, int64_t k, int64_t d, int
   }
 }
 
+// Streams (and graph holders) of the helper threads that run the coarse levels side by side; created on first use or by
+// fc_warmup (a stream is a hardware queue: several ms each), dropped with the context they were created in.
+constexpr int kLevelStreamsMax = 8;
+static hipStream_t g_lvl_stream[kLevelStreamsMax] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+static hipEvent_t g_lvl_begin = nullptr;
+static uint64_t g_lvl_epoch = 0;
+static TfdLevelGraph g_lvl_holders[kLevelStreamsMax];
+int tfd_level_streams(int n) {
+  if (g_lvl_epoch != ctx().epoch) {  // (what an earlier context created went with its device)
+    for (auto &st : g_lvl_stream) st = nullptr;
+    g_lvl_begin = nullptr;
+    g_lvl_epoch = ctx().epoch;
+  }
+  if (!g_lvl_begin) FC_HIP_TRY(hipEventCreateWithFlags(&g_lvl_begin, hipEventDisableTiming));
+  for (int w = 0; w < n && w < kLevelStreamsMax; ++w)
+    if (!g_lvl_stream[w]) FC_HIP_TRY(hipStreamCreateWithFlags(&g_lvl_stream[w], hipStreamNonBlocking));
+  return FC_OK;
+}
+
 // The whole ladder: first_match[i] = min{j > i : similar(i, j)} or -1.
 //
 // What a chunk rejects depends on first_match alone: the reference's inner loops never look at
@@ -643,7 +665,7 @@ static void level_chunks(const int64_t *fm, int64_t N, int64_t k, int64_t d, int
 // kGpuChunkMin structures) are then built there (fc_tfd_gpu.hip) while the host threads work on the fine levels.
 int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out, const int64_t *fm_dev) {
   static const double kl[] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};
-  for (int64_t i = 0; i < N; ++i) mask_out[i] = 1;
+  std::memset(mask_out, 1, (size_t)N);
   unsigned hw = std::thread::hardware_concurrency();
   if (hw == 0) hw = 1;
   if (hw > 16) hw = 16;
@@ -669,13 +691,13 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
   };
   std::vector<Task> tasks;
   constexpr int kLevels = (int)(sizeof(kl) / sizeof(kl[0]));
-  std::vector<uint8_t> level_rej[kLevels];
+  static std::vector<uint8_t> level_rej[kLevels];  // kept across calls (callers hold the API lock): 17 x N bytes of fresh pages cost ~7 ms at 1.7 M
   std::vector<int> gpu_levels;
   bool use_gpu = fm_dev != nullptr;
   if (const char *v = getenv("FC_TFD_GPU")) use_gpu = use_gpu && atoi(v) != 0;  // 0: everything on the host (A/B, tests)
   bool gpu_components = true;  // FC_TFD_GPU_COMPONENTS=0: the component phase on host threads, from the device's graphs
   if (const char *v = getenv("FC_TFD_GPU_COMPONENTS")) gpu_components = atoi(v) != 0;
-  int64_t gpu_chunk_min = 1000;
+  int64_t gpu_chunk_min = 300;  // (1000 .. 30 measured at 1.7 M structures: 300 is where the host threads and the device finish together)
   if (const char *v = getenv("FC_TFD_GPU_CHUNK_MIN")) gpu_chunk_min = std::max<int64_t>(2, std::strtoll(v, nullptr, 10));
   for (int li = 0; li < (int)(sizeof(kl) / sizeof(kl[0])); ++li) {
     const int64_t k = (int64_t)kl[li];
@@ -695,6 +717,34 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
       tasks.push_back(Task{li, k, d, b, e, (e - b) * d});
     }
   }
+  // (streams and events of the coarse levels' helpers first: nothing below may return while threads are running)
+  TfdLevelGraph *const holders = g_lvl_holders;
+  hipStream_t *const lvl_stream = g_lvl_stream;
+  int n_lvl_streams = 3;
+  if (const char *v = getenv("FC_TFD_GPU_STREAMS")) n_lvl_streams = (int)std::min<long>(kLevelStreamsMax, std::max<long>(1, std::strtol(v, nullptr, 10)));
+  n_lvl_streams = (int)std::min<size_t>((size_t)n_lvl_streams, std::max<size_t>(gpu_levels.size(), 1));
+  int gpu_rc = FC_OK;
+  std::string gpu_err;
+  if (!gpu_levels.empty()) {
+    FC_TRY(tfd_level_streams(n_lvl_streams));
+    FC_HIP_TRY(hipEventRecord(g_lvl_begin, ctx().stream));
+    for (int w = 0; w < n_lvl_streams; ++w) FC_HIP_TRY(hipStreamWaitEvent(lvl_stream[w], g_lvl_begin, 0));
+  }
+  // the LAST chunk of the first level that runs is known up front as well (num_active = N there): at 1.7 M structures
+  // it is the remainder N - d (k - 1) = 79 619 structures of k = 200 000, 8 ms on one thread if left to the walk below
+  int first_level = -1;
+  std::vector<int64_t> first_last;
+  for (int li = 0; li < kLevels; ++li) {
+    const int64_t k = (int64_t)kl[li];
+    if (k == 1 || 5 * k < N) {
+      first_level = li;
+      break;
+    }
+  }
+  if (first_level >= 0) tasks.push_back(Task{first_level, (int64_t)kl[first_level], N / (int64_t)kl[first_level], -1, -1, N - (N / (int64_t)kl[first_level]) * ((int64_t)kl[first_level] - 1)});
+  if (debug)
+    fprintf(stderr, "[fc] tfd ladder: set up (flag arrays, tasks, level streams) at %.1f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
   std::vector<size_t> order(tasks.size());
   for (size_t t = 0; t < order.size(); ++t) order[t] = t;
   std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tasks[a].cost > tasks[b].cost; });
@@ -708,48 +758,82 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
         if (q >= order.size()) break;
         const Task &t = tasks[order[q]];
         rej.clear();
+        if (t.step_begin < 0) {  // the first level's last chunk (one task: no other writes first_last)
+          level_chunks(fm, N, t.k, t.d, N, t.k - 1, t.k, scratch, first_last);
+          continue;
+        }
         // a non-last chunk never uses num_active: pass N
         level_chunks(fm, N, t.k, t.d, N, t.step_begin, t.step_end, scratch, rej);
         uint8_t *flags = level_rej[t.level].data();
         for (int64_t r : rej) flags[r] = 1;
       }
     };
-    const unsigned nthreads = (N >= 2000 && tasks.size() > 1) ? std::min<size_t>(hw, tasks.size()) : 1;
+    // (the helpers of the coarse levels wait for the device by polling: leave them a core each)
+    const unsigned hw_pool = gpu_levels.empty() ? hw : std::max(1u, hw > (unsigned)n_lvl_streams ? hw - (unsigned)n_lvl_streams : 1u);
+    const unsigned nthreads = (N >= 2000 && tasks.size() > 1) ? std::min<size_t>(hw_pool, tasks.size()) : 1;
     std::vector<std::thread> pool;
     if (nthreads > 1 || !gpu_levels.empty())
       for (unsigned t = 0; t < std::max(1u, nthreads); ++t) pool.emplace_back(worker);
     else
       worker();
-    // meanwhile, on this thread: the coarse levels' graphs from the device, their component phase on helper threads
-    int gpu_rc = FC_OK;
-    // the host's share of a level (its large components) runs on a helper thread while the device builds the next
-    // level: two graph holders used in turn, kept across calls (their arrays are tens of MB: fresh pages every level
-    // cost more than the copies)
-    static TfdLevelGraph holders[2];
-    std::thread left_worker[2];
-    int turn = 0;
-    for (int li : gpu_levels) {
-      if (left_worker[turn].joinable()) left_worker[turn].join();
-      TfdLevelGraph &g = holders[turn];
-      const auto t_g = std::chrono::steady_clock::now();
-      gpu_rc = tfd_level_graph_device(fm_dev, N, (int64_t)kl[li], g, gpu_components ? level_rej[li].data() : nullptr);
-      if (gpu_rc != FC_OK) break;
-      const auto t_c = std::chrono::steady_clock::now();
-      uint8_t *flags = level_rej[li].data();
-      if (!gpu_components) level_rejects_from_graph(g, g_comp_threads, flags, nullptr);
-      else if (!g.left.empty())
-        left_worker[turn] = std::thread([&g, flags]() { level_rejects_from_graph(g, std::min(g_comp_threads, 4u), flags, nullptr, true); });
-      if (debug)
-        fprintf(stderr, "[fc] tfd ladder k=%lld on the device: %.1f ms (%zu components, %zu of them left to host threads)%s\n",
-                (long long)kl[li], std::chrono::duration<double, std::milli>(t_c - t_g).count(),
-                g.sources.empty() ? (size_t)0 : g.sources.size() - 1, g.left.size(),
-                gpu_components ? "" : "; component phase on the host");
-      turn ^= 1;
+    // meanwhile: the coarse levels' graphs from the device.  The levels are independent of each other and each is a
+    // chain of ~40 short launches with five host round trips (sizes of the next arrays), so one level at a time leaves
+    // the device idle most of the time (4.3-5.2 ms per level, nine levels at 1.7 M structures): kLevelStreams helper
+    // threads take levels from a common counter, each enqueueing on a stream of its own (thread_stream_override) that
+    // starts behind everything the context's stream holds; a helper also walks the components its level left to the
+    // host (the few with more than FC_TFD_DEV_COMP_MAX nodes) before it takes the next level.  The graph holders are
+    // kept across calls (their arrays are tens of MB: fresh pages every level cost more than the copies).
+    std::atomic<size_t> next_level{0};
+    std::mutex err_mu;
+    auto level_worker = [&](int w) {
+      thread_stream_override() = lvl_stream[w];
+      TfdLevelGraph &g = holders[w];
+      while (true) {
+        const size_t q = next_level.fetch_add(1);
+        if (q >= gpu_levels.size()) break;
+        const int li = gpu_levels[q];
+        const auto t_g = std::chrono::steady_clock::now();
+        uint8_t *flags = level_rej[li].data();
+        const int rc = tfd_level_graph_device(fm_dev, N, (int64_t)kl[li], g, gpu_components ? flags : nullptr);
+        if (rc != FC_OK) {
+          std::lock_guard<std::mutex> lock(err_mu);
+          if (gpu_rc == FC_OK) gpu_rc = rc, gpu_err = last_error();  // (the message is the helper thread's own)
+          break;
+        }
+        const auto t_c = std::chrono::steady_clock::now();
+        if (!gpu_components) level_rejects_from_graph(g, std::min(g_comp_threads, 4u), flags, nullptr);
+        else if (!g.left.empty()) level_rejects_from_graph(g, std::min(g_comp_threads, 2u), flags, nullptr, true);
+        int64_t left_nodes = 0, left_max = 0;
+        if (debug)
+          for (const int32_t j : g.left) {
+            const int64_t sz = (int64_t)g.sources[(size_t)j + 1] - g.sources[(size_t)j];
+            left_nodes += sz;
+            left_max = std::max(left_max, sz);
+          }
+        if (debug)
+          fprintf(stderr, "[fc] tfd ladder k=%lld: %lld nodes in the components left to the host (largest %lld)\n", (long long)kl[li],
+                  (long long)left_nodes, (long long)left_max);
+        if (debug)
+          fprintf(stderr, "[fc] tfd ladder k=%lld on the device (stream %d): %.1f ms + %.1f ms on the host (%zu components, %zu of them left to host threads)%s\n",
+                  (long long)kl[li], w, std::chrono::duration<double, std::milli>(t_c - t_g).count(),
+                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c).count(),
+                  (size_t)g.n_components, g.left.size(),
+                  gpu_components ? "" : "; component phase on the host");
+      }
+      thread_stream_override() = nullptr;
+    };
+    {
+      std::vector<std::thread> lvl_pool;
+      if (!gpu_levels.empty())
+        for (int w = 1; w < n_lvl_streams; ++w) lvl_pool.emplace_back(level_worker, w);
+      if (!gpu_levels.empty()) level_worker(0);
+      for (auto &th : lvl_pool) th.join();
+      if (debug && !gpu_levels.empty())
+        fprintf(stderr, "[fc] tfd ladder: %zu coarse levels on %d streams done at %.1f ms\n", gpu_levels.size(), n_lvl_streams,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
     }
-    for (auto &th : left_worker)
-      if (th.joinable()) th.join();
     for (auto &th : pool) th.join();
-    if (gpu_rc != FC_OK) return gpu_rc;
+    if (gpu_rc != FC_OK) return set_error(gpu_rc, "%s", gpu_err.c_str());
   }
   if (debug)
     fprintf(stderr, "[fc] tfd ladder: %zu speculative tasks on %u threads, %.1f ms\n", tasks.size(), hw,
@@ -771,12 +855,25 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
     // the level does not matter: all rejects of a level come from the mask-independent chunk graphs
     last.clear();
     const int64_t active_in = num_active;
-    level_chunks(fm, N, k, d, active_in, k - 1, k, scratch, last);
+    if (li == first_level && active_in == N) last = first_last;
+    else level_chunks(fm, N, k, d, active_in, k - 1, k, scratch, last);
     {  // branch-free over the bytes (vectorised by the compiler): a level rejects up to half of its range
       const uint8_t *flags = level_rej[li].data();
       const size_t n_flags = level_rej[li].size();
       unsigned long long gone = 0;
-      for (size_t r = 0; r < n_flags; ++r) {
+      size_t r = 0;
+      for (; r + 8 <= n_flags; r += 8) {  // eight structures per step (bytes are 0 / 1: a set bit is a rejected structure)
+        uint64_t m8, f8;
+        std::memcpy(&m8, mask_out + r, 8);
+        std::memcpy(&f8, flags + r, 8);
+        const uint64_t hit = m8 & f8;
+        if (hit) {
+          gone += (unsigned long long)__builtin_popcountll(hit);
+          m8 ^= hit;
+          std::memcpy(mask_out + r, &m8, 8);
+        }
+      }
+      for (; r < n_flags; ++r) {
         const uint8_t hit = (uint8_t)(mask_out[r] & flags[r]);
         gone += hit;
         mask_out[r] = (uint8_t)(mask_out[r] ^ hit);

@@ -623,6 +623,31 @@ int launch_torsion_fingerprint(const double *coords_dev, int64_t N, int64_t A,
   return check_launch("k_torsion_fingerprint");
 }
 
+// Rows of the reference's cartesian_product(*arrays) (firecode/utils.py:219-221: np.stack(np.meshgrid(*arrays), -1)
+// .reshape(-1, T) -- with the default 'xy' indexing array #2 varies slowest, then #1, then #3 ... #T, fastest) written where
+// the scan reads them: one thread per row, mixed-radix digits of the row number.  The 1 679 616 x 8 grid of cfg3 is
+// 107 MB: 9 ms to build on 16 host threads and ~12 ms to send; here it is never anywhere but in HBM.
+__global__ void __launch_bounds__(256)
+k_angle_grid(const int64_t *__restrict__ values, const int64_t *__restrict__ first, const int64_t *__restrict__ counts, int T,
+             int64_t S, int64_t *__restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= S) return;
+  int64_t rem = r;
+  for (int p = T - 1; p >= 0; --p) {  // digit order, slowest first: 1, 0, 2, 3, ... (T == 1: just 0)
+    const int t = T >= 2 ? (p == 0 ? 1 : (p == 1 ? 0 : p)) : 0;
+    const int64_t c = counts[t];
+    out[r * T + t] = values[first[t] + rem % c];
+    rem /= c;
+  }
+}
+int launch_angle_grid(const int64_t *values_dev, const int64_t *first_dev, const int64_t *counts_dev, int64_t T, int64_t S,
+                      int64_t *out_dev) {
+  if (S == 0) return FC_OK;
+  hipLaunchKernelGGL(k_angle_grid, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, ctx().stream, values_dev, first_dev, counts_dev,
+                     (int)T, S, out_dev);
+  return check_launch("k_angle_grid");
+}
+
 // fc_warmup(): the first launch from a translation unit makes the runtime load that unit's code object (milliseconds);
 // a no-op launch moves that cost out of the first real call
 __global__ void k_warm_torsion() {}

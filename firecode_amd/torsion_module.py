@@ -63,6 +63,33 @@ def torsion_scan_tfd(base, torsions, masks, angles, quadruplets, thresh=1.5, bac
     return rot, keep.astype(bool)
 
 
+def torsion_scan_tfd_grid(base, torsions, masks, values, quadruplets, thresh=1.5, backoff=5, tfd_thresh=10):
+    """``torsion_scan_tfd`` over ``cartesian_product(*values)`` -- ``values`` = one sequence of angles (degrees) per
+    torsion -- with the grid generated on the device in the reference's row order (fc_torsion_scan_tfd_grid; the
+    loop of firecode/torsion_module.py:822).  Row s of the result is row s of that product
+    (``firecode_amd.utils.cartesian_rows_at`` gives its angles).  Returns (rotated_bonds (S,), keep (S + 1,) bool)."""
+    base = L.f64(base)
+    tors = L.i64(torsions).reshape(-1, 4)
+    msk = L.u8(np.asarray(masks, dtype=bool)).reshape(tors.shape[0], -1)
+    quads = L.i64(quadruplets).reshape(-1, 4)
+    flat = [L.i64(np.asarray(v).reshape(-1)) for v in values]
+    A, T, Q = base.shape[0], tors.shape[0], quads.shape[0]
+    if len(flat) != T:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "one list of angles per torsion expected")
+    if base.ndim != 2 or base.shape[1] != 3 or msk.shape[1] != A or Q == 0:
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "base (A, 3), masks (T, A) and at least one quadruplet expected")
+    counts = np.array([len(v) for v in flat], dtype=np.int64)
+    S = int(np.prod(counts, dtype=object))
+    vals = np.ascontiguousarray(np.concatenate(flat)) if flat else np.zeros(0, dtype=np.int64)
+    if len(vals) == 0:
+        vals = np.zeros(1, dtype=np.int64)
+    rot = np.zeros(S, dtype=np.int64)
+    keep = np.zeros(S + 1, dtype=np.uint8)
+    L.call("fc_torsion_scan_tfd_grid", L.pf(base), A, L.pi(tors), T, L.pb(msk), L.pi(vals), L.pi(counts), float(thresh),
+           int(backoff), L.pi(quads), Q, float(tfd_thresh), L.pi(rot), L.pb(keep))
+    return rot, keep.astype(bool)
+
+
 def torsion_comp_check(coords, torsion, mask, thresh=1.5, max_clashes=0):
     """firecode/torsion_module.py:894-918: rest-vs-moving clash count <= max_clashes."""
     X = L.f64(coords)
@@ -154,22 +181,25 @@ def clustered_csearch(coords, torsions, rotation_masks, n_out=100, thresh=1.5, s
     reference's ``cartesian_product`` order, scans it on the GPU, keeps the
     starting structure plus every conformer with at least one rotated bond,
     TFD-prunes on the torsion quadruplets and subsamples to ``n_out``."""
-    from firecode_amd.utils import cartesian_product
+    from firecode_amd.utils import cartesian_rows_at
 
     n_fold_angles = {2: (0, 180), 3: (0, 120, 240), 4: (0, 90, 180, 270), 6: (0, 60, 120, 180, 240, 300)}
     quads = np.array([t[:4] for t in torsions], dtype=np.int64)
-    angles = cartesian_product(*[n_fold_angles[int(t[4])] for t in torsions])
+    values = [n_fold_angles[int(t[4])] for t in torsions]
+    n_sets = int(np.prod([len(v) for v in values], dtype=object))
     base = L.f64(coords)
     # Fingerprint every scanned conformer inside the scan kernel, TFD-prune on the (S, Q)
     # fingerprints, then generate coordinates only for the survivors -- the scan of 1.7 M
     # angle-sets would otherwise move 2 GB of conformers to the host to keep a few thousand.
     # ... and the fingerprints themselves stay on the device between the scan and the prune
-    rot, keep = torsion_scan_tfd(base, quads, rotation_masks, angles, quads, thresh=thresh, tfd_thresh=10)
+    # ... and neither does the grid of angle-sets exist anywhere but on the device (107 MB at 8 x 6-fold): the
+    # survivors' angles are recovered from their row numbers
+    rot, keep = torsion_scan_tfd_grid(base, quads, rotation_masks, values, quads, thresh=thresh, tfd_thresh=10)
     n_new = 1 + int(np.count_nonzero(rot))  # the starting structure first, as the reference lists it (:858-861)
     if logfunction is not None:
         logfunction(f"> Group 1/1 - {len(torsions)} bonds, {[int(t[4]) for t in torsions]} n-folds, "
-                    f"1 starting point = {len(angles)} conformers")
-    pruned = torsion_scan(base, quads, rotation_masks, angles[np.flatnonzero(keep[1:])], thresh=thresh)[0]
+                    f"1 starting point = {n_sets} conformers")
+    pruned = torsion_scan(base, quads, rotation_masks, cartesian_rows_at(values, np.flatnonzero(keep[1:])), thresh=thresh)[0]
     if keep[0]:
         pruned = np.concatenate([base[None], pruned])
     output = list(pruned)

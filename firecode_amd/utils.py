@@ -8,6 +8,21 @@ from firecode_amd.algebra import count_clashes_batch
 from firecode_amd.rmsd import rmsd_and_max_batch
 
 
+def cartesian_rows_at(arrays, rows):
+    """Rows ``rows`` of ``cartesian_product(*arrays)`` without building the product: the mixed-radix digits of a row
+    number in the reference's order (firecode/utils.py:219-221: array #2 slowest, then #1, then #3 ... #n)."""
+    flat = [np.asarray(a).reshape(-1) for a in arrays]
+    rows = np.asarray(rows, dtype=np.int64).reshape(-1)
+    T = len(flat)
+    out = np.empty((len(rows), T), dtype=np.result_type(*flat) if flat else np.float64)
+    order = ([1, 0] + list(range(2, T))) if T >= 2 else list(range(T))  # slowest first
+    rem = rows.copy()
+    for t in reversed(order):
+        out[:, t] = flat[t][rem % len(flat[t])]
+        rem //= len(flat[t])
+    return out
+
+
 def cartesian_product(*arrays):
     """firecode/utils.py:219-221: ``np.stack(np.meshgrid(*arrays), -1).reshape(-1, len(arrays))`` -- array #2
     varies slowest, then #1, then #3..#n.  Integer and floating inputs are written row by row by the library

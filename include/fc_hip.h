@@ -425,6 +425,14 @@ int fc_torsion_scan_fingerprints(const double *base, int64_t A, const int64_t *t
 int fc_torsion_scan_tfd(const double *base, int64_t A, const int64_t *torsions, int64_t T, const uint8_t *rotmasks,
                         const int64_t *angles, int64_t S, double thresh, int64_t backoff_deg, const int64_t *quads,
                         int64_t Q, double tfd_thresh, int64_t *rotated_bonds_out, uint8_t *keep_out);
+/* fc_torsion_scan_tfd over the whole n-fold grid of clustered_csearch (firecode/torsion_module.py:822: `for angles in
+ * cartesian_product(*rotations)`): values = the T value lists one after the other (counts[t] entries each, degrees), the
+ * S = prod counts angle-sets are the rows of the reference's cartesian_product (firecode/utils.py:219-221, array #2
+ * slowest, then #1, #3 ... #T) and are generated on the device -- at 8 x 6-fold the grid is 107 MB that otherwise is built
+ * on the host and sent.  rotated_bonds_out: S, keep_out: S + 1, row numbers = row numbers of that product. */
+int fc_torsion_scan_tfd_grid(const double *base, int64_t A, const int64_t *torsions, int64_t T, const uint8_t *rotmasks,
+                             const int64_t *values, const int64_t *counts, double thresh, int64_t backoff_deg,
+                             const int64_t *quads, int64_t Q, double tfd_thresh, int64_t *rotated_bonds_out, uint8_t *keep_out);
 
 /* ---- a20: torsion fingerprints and TFD similarity bits --
  * firecode/torsion_module.py:1046-1076.

@@ -542,6 +542,29 @@ def test_scan_tfd_fused_equals_scan_then_prune(fc):
     assert not rot0.any() and keep0.tolist() == [True, False, False, False]
 
 
+def test_scan_tfd_over_the_device_generated_grid(fc):
+    """fc_torsion_scan_tfd_grid (the n-fold grid generated on the device in cartesian_product's row order) == the same
+    call on the host-built grid, mixed n-folds included; cartesian_rows_at gives the rows back; clustered_csearch
+    (which uses both) returns what the scan of the host-built grid returns"""
+    for n_tors, folds, seed in ((4, (6, 6, 6, 6), 41), (5, (6, 2, 3, 4, 6), 42), (1, (6,), 43), (2, (3, 4), 44)):
+        base, tors, masks = _chain_case(32, n_tors, seed=seed)
+        values = [fc.torsion_module.N_FOLD_ANGLES[f] for f in folds]
+        angles = o.cartesian_product(*values)
+        assert np.array_equal(fc.utils.cartesian_rows_at(values, np.arange(len(angles))), angles)
+        rot, keep = fc.torsion_module.torsion_scan_tfd(base, tors, masks, angles, tors, tfd_thresh=10)
+        rot_g, keep_g = fc.torsion_module.torsion_scan_tfd_grid(base, tors, masks, values, tors, tfd_thresh=10)
+        assert np.array_equal(rot, rot_g) and np.array_equal(keep, keep_g) and keep.sum() >= 1
+    base, tors, masks = _chain_case(32, 4, seed=41)
+    t5 = [tuple(int(v) for v in t) + (6,) for t in tors]
+    got = fc.torsion_module.clustered_csearch(base, t5, masks, n_out=10 ** 6)
+    angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 4)
+    rot, keep = fc.torsion_module.torsion_scan_tfd(base, tors, masks, angles, tors, tfd_thresh=10)
+    want = fc.torsion_module.torsion_scan(base, tors, masks, angles[np.flatnonzero(keep[1:])])[0]
+    if keep[0]:
+        want = np.concatenate([base[None], want])
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
 def test_clash_functions_on_the_reference_fixture_molecules(fc, golden):
     """count_clashes / fragment compenetration_check on the molecules of the reference's own test
     files, against the reference's own outputs"""

@@ -80,19 +80,22 @@ def _random_first_match(rng, n, kind):
 def test_ladder_mask_is_the_same_with_device_built_chunk_graphs(fc, monkeypatch, n, kind, seed):
     """fc_tfd_ladder_from_first_match with the coarse levels' chunk graphs built on the device (default with a GPU)
     == the all-host ladder (FC_TFD_GPU=0), whose group[0] bookkeeping is pinned to CPython / networkx by the golden
-    masks and tests/test_pyset_emulation.py; also with a lower chunk threshold, so that more levels go to the device"""
+    masks and tests/test_pyset_emulation.py; also with a lower chunk threshold, so that more levels go to the device, and with one / five levels in flight
+    at a time (helper threads, a stream each)"""
     rng = np.random.default_rng(seed)
     fm = _random_first_match(rng, n, kind)
     masks = {}
-    for label, env in (("host", {"FC_TFD_GPU": "0"}), ("device", {}), ("device_fine", {"FC_TFD_GPU_CHUNK_MIN": "1000"}),
+    for label, env in (("host", {"FC_TFD_GPU": "0"}), ("device", {}), ("device_fine", {"FC_TFD_GPU_CHUNK_MIN": "40"}),
+                       ("device_one_stream", {"FC_TFD_GPU_STREAMS": "1", "FC_TFD_GPU_CHUNK_MIN": "1000"}),
+                       ("device_five_streams", {"FC_TFD_GPU_STREAMS": "5"}),
                        ("device_graphs_host_components", {"FC_TFD_GPU_COMPONENTS": "0", "FC_TFD_GPU_CHUNK_MIN": "20000"})):
-        for k in ("FC_TFD_GPU", "FC_TFD_GPU_CHUNK_MIN", "FC_TFD_GPU_COMPONENTS"):
+        for k in ("FC_TFD_GPU", "FC_TFD_GPU_CHUNK_MIN", "FC_TFD_GPU_COMPONENTS", "FC_TFD_GPU_STREAMS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         m = np.zeros(n, dtype=np.uint8)
         _lib.call("fc_tfd_ladder_from_first_match", _lib.pi(fm), n, _lib.pb(m))
         masks[label] = m
-    for label in ("device", "device_fine", "device_graphs_host_components"):
+    for label in ("device", "device_fine", "device_one_stream", "device_five_streams", "device_graphs_host_components"):
         assert np.array_equal(masks["host"], masks[label]), label
     assert 0 < masks["host"].sum() < n

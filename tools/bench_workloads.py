@@ -66,14 +66,20 @@ def csearch():
         fc._lib.warmup()  # fc_warmup: device code of every translation unit loaded, buffer pool primed (FC_CSEARCH_WARMUP=0: cold)
     for run in range(int(os.environ.get("FC_CSEARCH_RUNS", "2"))):  # the first run pays the one-time costs (device allocations, first touch of the host buffers)
         t0 = time.perf_counter()
-        angles = fc.utils.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * T)  # the grid is part of the search (:822)
-        t_grid = time.perf_counter() - t0
-        # scan with the fingerprints taken inside the kernel + TFD prune of [base] + [rotated conformers]; the
-        # fingerprints stay on the device between the two (fc_torsion_scan_tfd, what clustered_csearch calls)
-        rot, keep = fc.torsion_module.torsion_scan_tfd(base, torsions, masks, angles, torsions, thresh=1.5, tfd_thresh=10)
+        values = [(0, 60, 120, 180, 240, 300)] * T
+        if os.environ.get("FC_CSEARCH_HOST_GRID") == "1":  # A/B: the grid built on the host and sent (round 2)
+            angles = fc.utils.cartesian_product(*values)  # the grid is part of the search (:822)
+            t_grid = time.perf_counter() - t0
+            rot, keep = fc.torsion_module.torsion_scan_tfd(base, torsions, masks, angles, torsions, thresh=1.5, tfd_thresh=10)
+        else:
+            # the grid of angle-sets is generated on the device (fc_torsion_scan_tfd_grid, what clustered_csearch calls);
+            # scan with the fingerprints taken inside the kernel + TFD prune of [base] + [rotated conformers]; the
+            # fingerprints stay on the device between the two
+            t_grid = 0.0
+            rot, keep = fc.torsion_module.torsion_scan_tfd_grid(base, torsions, masks, values, torsions, thresh=1.5, tfd_thresh=10)
         t_scan_tfd = time.perf_counter() - t0
         t1 = time.perf_counter()
-        surv = fc.torsion_module.torsion_scan(base, torsions, masks, angles[np.flatnonzero(keep[1:])], thresh=1.5)[0]
+        surv = fc.torsion_module.torsion_scan(base, torsions, masks, fc.utils.cartesian_rows_at(values, np.flatnonzero(keep[1:])), thresh=1.5)[0]
         if keep[0]:
             surv = np.concatenate([base[None], surv])
         t_regen = time.perf_counter() - t1
@@ -84,7 +90,7 @@ def csearch():
                      "s_total": time.perf_counter() - t0})
     wall = runs[1]["s_total"]
     print(json.dumps({
-        "workload": "cfg3 csearch: 8 rotatable bonds x 6-fold = 1 679 616 angle-sets, clash 1.5 A, back-off 5 deg, "
+        "workload": "cfg3 csearch: 8 rotatable bonds x 6-fold = 1 679 616 angle-sets (grid generated on the device), clash 1.5 A, back-off 5 deg, "
                     "fingerprints taken inside the scan kernel and TFD-pruned (10 deg) without leaving the device, "
                     "survivors re-scanned, RMSD prune (0.5 A)",
         "angle_sets": S, "kept_after_scan": 1 + int(np.count_nonzero(rot)), "after_tfd": int(keep.sum()), "after_rmsd": int(rmask.sum()),
