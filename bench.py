@@ -355,24 +355,53 @@ def main():
     # FC_BENCH_FORCE_SHARDED=1: the multi-GPU code path (RCCL communicator of one rank) on a single GPU
     comm = (world > 1 or workload in ("cfg4", "cfg5") or os.environ.get("FC_BENCH_FORCE_SHARDED") == "1"
             or os.environ.get("FC_BENCH_SPAWNED") == "1")
+    # Rank coordination of the timed regions (barrier, max over ranks): the RCCL communicator where there is one.  The
+    # headline path has no data-path collective, so a communicator that cannot be created on some node must not take the
+    # measurement with it: the ranks then agree through files (firecode_amd.dist.HostRendezvous), shard by logical rank,
+    # and the blocks that DO exchange data (sharded prune, cfg4 / cfg5 families) are reported as skipped with the reason.
+    rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    rv = fdist.HostRendezvous(rank, world) if world > 1 else None
+    comm_error = None
     if comm:
-        rank, world, local_rank = fdist.comm_init_from_env()
+        fc.init(local_rank)  # a missing device is not a communicator problem: it ends the launch here, with its own message
+        try:
+            rank, world, local_rank = fdist.comm_init_from_env()
+        except Exception as exc:  # noqa: BLE001 -- whatever it was, every rank has to learn of it
+            if world == 1:
+                raise
+            comm_error = f"{type(exc).__name__}: {exc}"
+        if rv is not None:
+            oks = rv.allgather(b"\x01" if comm_error is None else b"\x00" + comm_error.encode()[:400])
+            bad = [(r, o[1:].decode(errors="replace")) for r, o in enumerate(oks) if o[:1] != b"\x01"]
+            if bad:
+                if comm_error is None:
+                    _lib.comm_destroy()
+                comm_error = "; ".join(f"rank {r}: {m}" for r, m in bad)
+                comm = False
+                fc.init(local_rank)  # (a missing device is not a communicator problem: this raises and the launch fails)
+                if workload in ("cfg4", "cfg5"):
+                    raise RuntimeError("the cfg4 / cfg5 lines exchange data between the ranks and need the RCCL communicator: " + comm_error)
+                _lib.call("fc_debug_comm_loopback", rank, world)  # logical rank / world for the row-block dealing, no exchange
+                sys.stderr.write(f"bench.py: rank {rank}: no RCCL communicator ({comm_error}); ranks coordinated through files\n")
     else:
-        rank, local_rank = 0, 0
         fc.init(0)
 
     def barrier():
         if comm:
             _lib.comm_barrier()  # a 1-byte all-gather + device synchronisation on every rank
+        elif rv is not None:
+            rv.barrier()  # (every bench hook returns behind its own device synchronisation)
 
     def max_over_ranks(x):
-        if not comm or world == 1:
+        if world == 1:
             return float(x)
+        if not comm:
+            return rv.max(x)
         g = _lib.allgather_mask(np.array([x], dtype=np.float64).view(np.uint8))
         return float(g.view(np.float64).max())
 
     ctx = dict(args=args, fc=fc, _lib=_lib, fdist=fdist, syn=syn, rank=rank, world=world, comm=comm,
-               barrier=barrier, max_over_ranks=max_over_ranks)
+               barrier=barrier, max_over_ranks=max_over_ranks, comm_error=comm_error)
     if workload == "cfg5":
         out = run_cfg5(args, fc, _lib, fdist, syn, rank, world, barrier, max_over_ranks)
     elif workload == "cfg4":
@@ -381,6 +410,9 @@ def main():
         out = run_alignments(ctx)
 
     if rank == 0:
+        if world > 1:
+            out["rank_coordination"] = ("RCCL communicator (fc_comm_barrier, fc_allgather_mask)" if comm else
+                                        "files (firecode_amd.dist.HostRendezvous); no RCCL communicator: " + str(comm_error))
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
@@ -388,6 +420,8 @@ def main():
     if comm:
         _lib.comm_barrier()
         _lib.comm_destroy()
+    if rv is not None:
+        rv.close()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -491,7 +525,10 @@ def run_alignments(ctx):
                     e1.bench_rmsd_and_max_all(2)
                     k1, t1, s1 = e1.bench_rmsd_and_max_all(min(steps, 20))
             finally:
-                _lib.call("fc_debug_comm_loopback", -1, 0)
+                if ctx["comm"]:
+                    _lib.call("fc_debug_comm_loopback", -1, 0)
+                else:
+                    _lib.call("fc_debug_comm_loopback", rank, world)  # (no communicator: back to this rank's logical share)
             v1 = int(s1[0]) * min(steps, 20) / (t1 * 1e-3)
             out["scaling_family_n1"] = {"n_conformers": 10000, "pairs_per_step": int(s1[0]), "kernel_ms": k1,
                                         "ms_per_step": t1 / min(steps, 20), "value": v1,
@@ -503,8 +540,13 @@ def run_alignments(ctx):
         r_, w_ = _lib.comm_info()
         if rank == 0:
             out["ranks_seen"] = int(w_)
+    elif world > 1 and rank == 0:
+        out["ranks_seen"] = world  # (every rank answered the file rendezvous)
 
-    if not args.no_extras:
+    if not args.no_extras and world > 1 and not ctx["comm"]:
+        if rank == 0:
+            out["prune_path"] = {"skipped": "the sharded prune exchanges its similar-pair lists over RCCL; " + str(ctx["comm_error"])}
+    elif not args.no_extras:
         blk = prune_block(ctx, "cfg2", ens, coords, atoms, assign, n_conf, n_atoms, steps_default=200, warmup_default=20)
         if rank == 0:
             out["prune_path"] = blk

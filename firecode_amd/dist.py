@@ -51,6 +51,97 @@ def _id_file():
     return os.path.join(tempfile.gettempdir(), f"fc_comm_{tag}.id")
 
 
+class HostRendezvous:
+    """Barrier and all-gather of a few bytes between the ranks of ONE NODE through files next to the id file
+    (``_id_file()``): what a bench needs to bracket a timed region (barrier, max over ranks) when the measured path
+    has no data-path collective -- independent of the RCCL communicator, so that a communicator that cannot be
+    created does not take the measurement with it.  Every call is collective and numbered; a rank removes its own
+    files two calls later (nobody can still be reading them then)."""
+
+    def __init__(self, rank, world, base=None, timeout_s=None, poll_s=0.0005):
+        self.rank, self.world, self.n = int(rank), int(world), 0
+        self.base = (base or _id_file()) + ".rv"
+        self.timeout_s = float(os.environ.get("FC_COMM_TIMEOUT_S", "180")) if timeout_s is None else float(timeout_s)
+        self.poll_s = poll_s
+        self._mine = []
+
+    def _path(self, n, rank):
+        return f"{self.base}.{n}.{rank}"
+
+    def allgather(self, payload=b""):
+        """bytes from every rank, in rank order"""
+        import time
+
+        n = self.n
+        self.n += 1
+        if self.world == 1:
+            return [bytes(payload)]
+        path = self._path(n, self.rank)
+        tmp = f"{path}.tmp"
+        with open(tmp, "wb") as fh:
+            fh.write(b"\x01" + bytes(payload))  # never empty: a file that exists is complete (rename is atomic)
+        os.replace(tmp, path)
+        self._mine.append(path)
+        out, t0 = [None] * self.world, time.monotonic()
+        while any(o is None for o in out):
+            for r in range(self.world):
+                if out[r] is None:
+                    try:
+                        with open(self._path(n, r), "rb") as fh:
+                            data = fh.read()
+                        if data[:1] == b"\x01":
+                            out[r] = data[1:]
+                    except OSError:
+                        pass
+            if any(o is None for o in out):
+                if time.monotonic() - t0 > self.timeout_s:
+                    missing = [r for r in range(self.world) if out[r] is None]
+                    raise TimeoutError(f"rank {self.rank}: ranks {missing} did not reach rendezvous {n} within {self.timeout_s:.0f} s")
+                time.sleep(self.poll_s)
+        while len(self._mine) > 2:  # everybody has passed call n - 1, hence read the files of call n - 2
+            try:
+                os.remove(self._mine.pop(0))
+            except OSError:
+                pass
+        return out
+
+    def barrier(self):
+        self.allgather(b"")
+
+    def max(self, x):
+        import struct
+
+        return max(struct.unpack("<d", b)[0] for b in self.allgather(struct.pack("<d", float(x))))
+
+    def close(self):
+        """collective, last call: every rank passes one more barrier and says so in a file of its own; rank 0, the last
+        reader, waits for those and removes every file of this rendezvous (a rank cannot remove its own last file:
+        somebody may still be reading it)"""
+        import glob
+        import time
+
+        if self.world == 1:
+            return
+        self.barrier()
+        if self.rank != 0:
+            path = f"{self.base}.bye.{self.rank}"
+            with open(path + ".tmp", "wb") as fh:
+                fh.write(b"\x01")
+            os.replace(path + ".tmp", path)
+            return
+        t0 = time.monotonic()
+        while not all(os.path.exists(f"{self.base}.bye.{r}") for r in range(1, self.world)):
+            if time.monotonic() - t0 > self.timeout_s:
+                break  # (a rank that died after the barrier: leave its files, remove the rest)
+            time.sleep(self.poll_s)
+        for path in glob.glob(glob.escape(self.base) + ".*"):
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+        self._mine = []
+
+
 def comm_init_from_env(timeout_s=None):
     """Create the RCCL communicator of this launch from RANK / WORLD_SIZE / LOCAL_RANK and return
     (rank, world, local_rank).  Call it BEFORE any other GPU use in the process; it selects

@@ -111,6 +111,48 @@ def test_bench_self_spawn_world_one_and_missing_device():
         assert "rank 1 exited" in out.stderr and "device" in out.stderr.lower() and "launch with" not in out.stderr
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device_agree_through_files(tmp_path):
+    """Two bench ranks started the way a launcher starts them (RANK / WORLD_SIZE / id file), both on device 0: the id file
+    rendezvous and ncclCommInitRank run for real; RCCL refuses two ranks on one device, so the ranks fall back to the file
+    rendezvous for barrier and max -- the headline path has no exchange -- shard the pair matrix by logical rank and rank 0
+    prints the one line (or RCCL accepts and the line says so)."""
+    idfile = str(tmp_path / "two.id")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+                   FC_COMM_ID_FILE=idfile, FC_COMM_TIMEOUT_S="120", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                                       "--no-cpu-baseline", "--no-extras"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs[0][1][-1500:] + outs[1][1][-1500:]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
+    assert len(lines) == 1 and outs[1][0].strip() == ""
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["n_conformers"] == 14142 and 0 < d["config"]["pairs_per_step_rank0"] < d["config"]["pairs_per_step"]
+    assert d["rank_coordination"].startswith(("files", "RCCL")) and 0 < d["efficiency"] < 1.2
+    assert not list(tmp_path.glob("two.id.rv.*"))  # the rendezvous cleaned up after itself
+
+
+def test_host_rendezvous_three_processes(tmp_path):
+    """firecode_amd.dist.HostRendezvous: all-gather / max / barrier between three processes, files removed at the end"""
+    code = (
+        "import sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from firecode_amd.dist import HostRendezvous\n"
+        f"r = int(sys.argv[1]); rv = HostRendezvous(r, 3, base={str(tmp_path / 'rv')!r}, timeout_s=60)\n"
+        "for i in range(40):\n"
+        "    g = rv.allgather(bytes([r, i]))\n"
+        "    assert [x[0] for x in g] == [0, 1, 2] and all(x[1] == i for x in g)\n"
+        "assert rv.max(1.5 * r) == 3.0\n"
+        "rv.barrier(); rv.close(); print('ok', r)\n")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, text=True) for r in range(3)]
+    assert [p.communicate(timeout=120)[0].strip() for p in procs] == ["ok 0", "ok 1", "ok 2"]
+    assert not list(tmp_path.iterdir())
+
+
 def test_bench_spawn_environment():
     import bench
 
