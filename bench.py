@@ -172,6 +172,42 @@ def pmc_traffic(files, n_conf, n_atoms, world=1):
     return None, None
 
 
+def pmc_held_clock(files, n_conf, n_atoms, frac, world=1):
+    """The clock the chip held under this kernel in the kept counter run (GRBM_GUI_ACTIVE / 8 / kernel time: MI355X_MICROARCH.md,
+    DVFS give-back) and what `frac` -- priced, as the rules say, at the 2.4 GHz peak -- comes to at that clock; None when
+    there is no such record for this workload."""
+    if world != 1 or n_conf is None:
+        return None
+    for name in files:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            rec = json.load(open(path))
+            if rec.get("n_conformers") == n_conf and rec.get("n_atoms") == n_atoms and rec.get("effective_clock_GHz"):
+                ghz = float(rec["effective_clock_GHz"])
+                return {"held_clock_GHz": ghz, "frac_of_the_peak_at_that_clock": frac * 2.4 / ghz,
+                        "source": "profiles/" + name + " (GRBM_GUI_ACTIVE / 8 / mean kernel duration of the kernel-trace run of the same "
+                                  "command; an earlier profiled run, not this one; reads high on dispatches shorter than ~0.3 ms)"}
+    return None
+
+
+def pmc_issue_cycles(files, n_conf, n_atoms, world=1):
+    """Issue-model cycles per 16 x 16 sub-tile and wave of the split-half screen from the kept counter run: MFMAs per sub-tile
+    = 27 per k-step of 32 atoms; the other vector instructions = (SQ_INSTS_VALU - SQ_INSTS_MFMA) / sub-tiles."""
+    if world != 1 or n_conf is None:
+        return None
+    for name in files:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            rec = json.load(open(path))
+            if rec.get("n_conformers") == n_conf and rec.get("n_atoms") == n_atoms and rec.get("SQ_INSTS_MFMA"):
+                per = 27 * ((n_atoms + 31) // 32)
+                subtiles = rec["SQ_INSTS_MFMA"] / per
+                valu = (rec["SQ_INSTS_VALU"] - rec["SQ_INSTS_MFMA"]) / subtiles
+                return {"mfma_per_subtile": per, "other_vector_instructions_per_subtile": valu, "matrix_pipe": per * 16,
+                        "issue": per * 8 + valu * 4, "source": "profiles/" + name}
+    return None
+
+
 def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, world=1, stats=None, n_conf=None):
     """Dominant kernel of the prune = the all-pairs screen, on the matrix pipe.
     achieved = MFMA flops of the all-pairs covariance (9 entries x K = atoms padded to 4, per pair) /
@@ -200,6 +236,13 @@ def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, wo
                                "achieved_tera_lane_instr_per_s": owned_pairs * 75 / (kernel_ms * 1e-3) / 1e12,
                                "peak": PEAK_F32_MFMA / 2, "frac": owned_pairs * 75 / (kernel_ms * 1e-3) / 1e12 / (PEAK_F32_MFMA / 2)},
                 "two_stage": None,
+                "clock": pmc_held_clock(("r03_pmc_screen_h2.json", "r03_pmc_screen_h2_cfg4_member.json"), n_conf if traffic_file else None,
+                                        n_atoms, tflops / PEAK_F16_MFMA, world),
+                "issue_model": {"what": "tools/ubench_issue_model.hip (profiles/r03_issue_model_f16mfma_valu*.txt): one SIMD issues a "
+                                        "v_mfma_f32_16x16x32_f16 in 8 and an fp32 vector instruction in ~4 of its cycles, whichever "
+                                        "waves they come from and however they are interleaved; the matrix pipe is busy 16 per MFMA",
+                                "cycles_per_16x16_subtile": pmc_issue_cycles(("r03_pmc_screen_h2.json", "r03_pmc_screen_h2_cfg4_member.json"),
+                                                                             n_conf if traffic_file else None, n_atoms, world)},
                 "note": "frac = f16 flops issued to the matrix pipe (3 products x 2 x 9 x atoms padded to 32 per pair) / time / "
                         "2.5 PFLOP/s; the kernel is bound by the sum of that and of the vector epilogue (valu_share)"}
     f32 = kind == 32
@@ -434,6 +477,7 @@ def complete_roofline(kernel_ms, owned_pairs, n_conf, n_atoms, world):
     return {"bound": "mfma", "kernel": "k_simbits_screen_mfma<4, 2>", "achieved": tflops, "peak": PEAK_F64_MFMA,
             "unit": "TFLOP/s", "frac": tflops / PEAK_F64_MFMA, "traffic": traffic, "traffic_source": src,
             "kernel_ms": kernel_ms, "flops_per_alignment": fl, "dtype": "f64",
+            "clock": pmc_held_clock(("r03_pmc_complete.json",), n_conf, n_atoms, tflops / PEAK_F64_MFMA, world),
             "note": "achieved = SURVEY 8d's algorithmic flops of one complete alignment (53 A + 600) x pairs of one launch / the "
                     "kernel's mean HIP-event duration; peak = the fp64 rate of the matrix pipe, which on this chip is also the "
                     "fp64 vector rate -- the kernel runs its covariance on the first and rotation + deviation pass on the second",

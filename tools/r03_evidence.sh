@@ -19,12 +19,12 @@ bench)
 pmc)
   say "PMC passes: complete alignment kernel (tools/time_complete.py 10000 50 5)"
   bash tools/r03_pmc.sh $O/pmc_complete r03 tools/time_complete.py 10000 50 5 > $O/pmc_complete.log 2>&1
-  python3 tools/r03_pmc_json.py $O/pmc_complete/pmc_summary.txt "k_simbits_screen_mfma<4, 2>" $O/pmc_complete.json n_conformers=10000 n_atoms=50 workload="BASELINE configs[1]: 10000 x 50, fc_bench_rmsd_and_max_all"
+  python3 tools/r03_pmc_json.py $O/pmc_complete/pmc_summary.txt "k_simbits_screen_mfma<4, 2>" $O/pmc_complete.json stats=$O/pmc_complete/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="BASELINE configs[1]: 10000 x 50, fc_bench_rmsd_and_max_all"
   ;;
 secondary)
   say "PMC passes + stats: continuous-RMSD ensemble (tools/secondary_probe.py), kernels one after another"
   FC_BENCH_LANES=1 bash tools/r03_pmc.sh $O/pmc_secondary r03sec tools/secondary_probe.py 10 > $O/pmc_secondary.log 2>&1
-  python3 tools/r03_pmc_json.py $O/pmc_secondary/pmc_summary.txt "k_refine_pairs" $O/pmc_refine.json n_conformers=10000 n_atoms=50 workload="continuous RMSD distribution, 894764 candidate pairs per launch"
+  python3 tools/r03_pmc_json.py $O/pmc_secondary/pmc_summary.txt "k_refine_pairs" $O/pmc_refine.json stats=$O/pmc_secondary/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="continuous RMSD distribution, 894764 candidate pairs per launch"
   python3 tools/secondary_probe.py 20 > $O/secondary_overlapped.json 2>/dev/null
   ;;
 cfg4)
@@ -33,7 +33,7 @@ cfg4)
   python3 tools/r03_pmc_json.py $O/pmc_cfg4/pmc_summary.txt "k_simbits_screen_mfma_h2" $O/pmc_screen_h2_cfg4.json n_conformers=35355 n_atoms=80 workload="cfg4 family, n_gpus = 1 member"
   say "PMC passes: prune path at cfg2"
   bash tools/r03_pmc.sh $O/pmc_prune r03prune tools/prune_probe.py 10000 50 2 100 > $O/pmc_prune.log 2>&1
-  python3 tools/r03_pmc_json.py $O/pmc_prune/pmc_summary.txt "k_simbits_screen_mfma_h2" $O/pmc_screen_h2.json n_conformers=10000 n_atoms=50 workload="BASELINE configs[1], prune path"
+  python3 tools/r03_pmc_json.py $O/pmc_prune/pmc_summary.txt "k_simbits_screen_mfma_h2" $O/pmc_screen_h2.json stats=$O/pmc_prune/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="BASELINE configs[1], prune path"
   ;;
 workloads)
   say "workloads under rocprof"

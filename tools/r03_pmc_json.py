@@ -30,6 +30,20 @@ for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INST
           "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES"):
     if k in rec:
         d[k] = rec[k]
+stats_csv = extra.pop("stats", None)
+if "GRBM_GUI_ACTIVE" in rec:
+    d["GRBM_GUI_ACTIVE"] = rec["GRBM_GUI_ACTIVE"]
+if stats_csv and "GRBM_GUI_ACTIVE" in rec:
+    # the clock the chip held while this kernel ran (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE is summed over the
+    # 8 XCDs; divided by the kernel's mean duration in the kernel-trace run of the same command (reads high below ~0.3 ms)
+    import csv
+
+    for row in csv.DictReader(open(stats_csv)):
+        if needle in row["Name"]:
+            avg_ns = float(row["AverageNs"])
+            d["kernel_avg_ns_trace_run"] = avg_ns
+            d["effective_clock_GHz"] = rec["GRBM_GUI_ACTIVE"] / 8.0 / avg_ns
+            break
 for k, v in extra.items():
     try:
         d[k] = int(v)
