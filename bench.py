@@ -590,16 +590,26 @@ def run_alignments(ctx):
     if not args.no_extras and world > 1 and not ctx["comm"]:
         if rank == 0:
             out["prune_path"] = {"skipped": "the sharded prune exchanges its similar-pair lists over RCCL; " + str(ctx["comm_error"])}
+    elif not args.no_extras and world > 1:
+        # the blocks that exchange data between the ranks: whatever goes wrong in them -- the same on every rank, the calls
+        # are collective -- must not take the headline measurement above with it
+        try:
+            blk = prune_block(ctx, "cfg2", ens, coords, atoms, assign, n_conf, n_atoms, steps_default=200, warmup_default=20)
+            if rank == 0:
+                out["prune_path"] = blk
+                out["pruned_ensembles_per_s"] = blk["pruned_ensembles_per_s"]
+            blk4 = run_prune_line(ctx, "cfg4", as_block=True)
+            if rank == 0:
+                out["cfg4_family"] = blk4
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write(f"bench.py: rank {rank}: extra blocks failed: {type(exc).__name__}: {exc}\n")
+            if rank == 0:
+                out["extras_error"] = f"{type(exc).__name__}: {exc}"
     elif not args.no_extras:
         blk = prune_block(ctx, "cfg2", ens, coords, atoms, assign, n_conf, n_atoms, steps_default=200, warmup_default=20)
         if rank == 0:
             out["prune_path"] = blk
             out["pruned_ensembles_per_s"] = blk["pruned_ensembles_per_s"]
-        if world > 1:
-            blk4 = run_prune_line(ctx, "cfg4", as_block=True)
-            if rank == 0:
-                out["cfg4_family"] = blk4
-        elif rank == 0:
             extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_atoms, pairs_total)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(coords)
