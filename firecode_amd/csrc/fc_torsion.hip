@@ -21,13 +21,15 @@ namespace fc {
 
 double sq_threshold_lt(double t);  // fc_clash.hip
 
-// rot_mat_from_pointer: scalar-last quaternion [sin(a/2) n, cos(a/2)] -> matrix
-__device__ __forceinline__ void rot_from_axis_angle(double ax, double ay, double az,
-                                                    double angle_deg, double (&M)[9]) {
+// rot_mat_from_pointer: scalar-last quaternion [sin(a/2) n, cos(a/2)] -> matrix.  The sine and cosine of the half
+// angle depend on the angle alone: callers that apply the same angle again and again (the 5-degree back-off of the
+// scan: up to 60 steps per torsion) take them once (half_angle_sincos) -- same function, same argument, same bits.
+__device__ __forceinline__ void half_angle_sincos(double angle_deg, double &sn, double &cs) {
   double a2 = angle_deg / 2.0;
   a2 *= 3.141592653589793 / 180.0;
-  double sn, cs;
   sincos(a2, &sn, &cs);
+}
+__device__ __forceinline__ void rot_from_axis_sincos(double ax, double ay, double az, double sn, double cs, double (&M)[9]) {
   const double nrm = sqrt((ax * ax + ay * ay) + az * az);
   const double q1 = sn * (ax / nrm), q2 = sn * (ay / nrm), q3 = sn * (az / nrm), q0 = cs;
   M[0] = 2.0 * (q0 * q0 + q1 * q1) - 1.0;
@@ -40,13 +42,20 @@ __device__ __forceinline__ void rot_from_axis_angle(double ax, double ay, double
   M[7] = 2.0 * (q2 * q3 + q0 * q1);
   M[8] = 2.0 * (q0 * q0 + q3 * q3) - 1.0;
 }
+__device__ __forceinline__ void rot_from_axis_angle(double ax, double ay, double az,
+                                                    double angle_deg, double (&M)[9]) {
+  double sn, cs;
+  half_angle_sincos(angle_deg, sn, cs);
+  rot_from_axis_sincos(ax, ay, az, sn, cs, M);
+}
 
-// rotate the atoms flagged in `mv` (bit per atom, up to 4 words = 256 atoms)
-__device__ __forceinline__ void rotate_masked(double *x, int A, const uint8_t *mask, int i2, int i3,
-                                              double angle, int lane) {
+// rotate the atoms flagged in `mask` about the i2 - i3 bond (origin i3) by the angle whose half-angle sine / cosine are
+// given.  MaskPtr: global memory, or the level's copy in LDS (k_ts_level)
+template <class MaskPtr>
+__device__ __forceinline__ void rotate_masked_sc(double *x, int A, MaskPtr mask, int i2, int i3, double sn, double cs, int lane) {
   const double cx = x[i3 * 3], cy = x[i3 * 3 + 1], cz = x[i3 * 3 + 2];
   double M[9];
-  rot_from_axis_angle(x[i2 * 3] - cx, x[i2 * 3 + 1] - cy, x[i2 * 3 + 2] - cz, angle, M);
+  rot_from_axis_sincos(x[i2 * 3] - cx, x[i2 * 3 + 1] - cy, x[i2 * 3 + 2] - cz, sn, cs, M);
   __builtin_amdgcn_wave_barrier();
   for (int a = lane; a < A; a += 64) {
     if (mask[a]) {
@@ -58,17 +67,29 @@ __device__ __forceinline__ void rotate_masked(double *x, int A, const uint8_t *m
   }
   __builtin_amdgcn_wave_barrier();
 }
+__device__ __forceinline__ void rotate_masked(double *x, int A, const uint8_t *mask, int i2, int i3,
+                                              double angle, int lane) {
+  double sn, cs;
+  half_angle_sincos(angle, sn, cs);
+  rotate_masked_sc(x, A, mask, i2, i3, sn, cs, lane);
+}
 
 // true when no (rest, moving) pair is closer than thresh (max_clashes = 0 is
 // the only value the reference ever passes: torsion_module.py:827,838)
-__device__ __forceinline__ bool comp_check(const double *x, const int16_t *mv, int nmv,
-                                           const int16_t *rs, int nrs, double thr2, int lane) {
+// pre_r / pre_m (may be nullptr): the lane's (rest, moving) atom of the first kPrePairs rounds of 64 pairs, worked out once by
+// a caller that checks the same torsion again and again (k_ts_level: one torsion per launch)
+constexpr int kPrePairs = 4;
+template <class IdxPtr>
+__device__ __forceinline__ bool comp_check(const double *x, IdxPtr mv, int nmv, IdxPtr rs, int nrs, double thr2, int lane,
+                                           const int *pre_r = nullptr, const int *pre_m = nullptr) {
   bool hit = false;
   const int total = nmv * nrs;
   for (int p0 = 0; p0 < total; p0 += 64) {
     const int p = p0 + lane;
     if (p < total) {
-      const int r = rs[p / nmv], m = mv[p % nmv];
+      int r, m;
+      if (pre_r != nullptr && p0 < kPrePairs * 64) r = pre_r[p0 >> 6], m = pre_m[p0 >> 6];
+      else r = rs[p / nmv], m = mv[p % nmv];
       const double dx = x[r * 3] - x[m * 3], dy = x[r * 3 + 1] - x[m * 3 + 1],
                    dz = x[r * 3 + 2] - x[m * 3 + 2];
       const double d2 = ((dx * dx) + dy * dy) + dz * dz;
@@ -98,6 +119,48 @@ __device__ __forceinline__ double dihedral_deg(const double *p0, const double *p
   return atan2(yy, xx) * (180.0 / 3.141592653589793);
 }
 
+// One torsion step of the scan (torsion_module.py:826-846): rotate by `angle`; on a clash step back by `backoff` degrees up
+// to angle // backoff times until the clash is gone.  Returns 1 when the bond ends up rotated.
+template <class MaskPtr, class IdxPtr>
+__device__ __forceinline__ int torsion_step(double *x, int A, MaskPtr mask, IdxPtr mv, int nm, IdxPtr rs, int nr, int i2, int i3,
+                                            int angle, int backoff, double thr2, int lane, const int *pre_r = nullptr,
+                                            const int *pre_m = nullptr) {
+  double sn, cs;
+  half_angle_sincos((double)angle, sn, cs);
+  rotate_masked_sc(x, A, mask, i2, i3, sn, cs, lane);
+  if (comp_check(x, mv, nm, rs, nr, thr2, lane, pre_r, pre_m)) return 1;
+  int steps = angle / backoff;  // Python floor division: range(angle // backoff)
+  if ((angle % backoff != 0) && ((angle < 0) != (backoff < 0))) --steps;
+  if (steps <= 0) return 0;
+  half_angle_sincos((double)(-backoff), sn, cs);  // once for all the steps
+  if (!mask[i2] && !mask[i3]) {
+    // the two axis atoms stay where they are, so every step applies the SAME matrix about the same point: built once
+    // (from the same numbers by the same operations: the steps' coordinates keep their bits)
+    const double cx = x[i3 * 3], cy = x[i3 * 3 + 1], cz = x[i3 * 3 + 2];
+    double M[9];
+    rot_from_axis_sincos(x[i2 * 3] - cx, x[i2 * 3 + 1] - cy, x[i2 * 3 + 2] - cz, sn, cs, M);
+    for (int b = 0; b < steps; ++b) {
+      __builtin_amdgcn_wave_barrier();
+      for (int a = lane; a < A; a += 64) {
+        if (mask[a]) {
+          const double px = x[a * 3] - cx, py = x[a * 3 + 1] - cy, pz = x[a * 3 + 2] - cz;
+          x[a * 3] = ((M[0] * px + M[1] * py) + M[2] * pz) + cx;
+          x[a * 3 + 1] = ((M[3] * px + M[4] * py) + M[5] * pz) + cy;
+          x[a * 3 + 2] = ((M[6] * px + M[7] * py) + M[8] * pz) + cz;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (comp_check(x, mv, nm, rs, nr, thr2, lane, pre_r, pre_m)) return 1;
+    }
+    return 0;
+  }
+  for (int b = 0; b < steps; ++b) {
+    rotate_masked_sc(x, A, mask, i2, i3, sn, cs, lane);
+    if (comp_check(x, mv, nm, rs, nr, thr2, lane, pre_r, pre_m)) return 1;
+  }
+  return 0;
+}
+
 __global__ void __launch_bounds__(256)
 k_torsion_scan(const double *__restrict__ base, int A, const int64_t *__restrict__ torsions, int T,
                const uint8_t *__restrict__ rotmasks, const int16_t *__restrict__ mv_idx,
@@ -123,21 +186,7 @@ k_torsion_scan(const double *__restrict__ base, int A, const int64_t *__restrict
       const int16_t *mv = mv_idx + (size_t)t * A;
       const int16_t *rs = rs_idx + (size_t)t * A;
       const int nm = n_mv[t], nr = n_rs[t];
-      rotate_masked(x, A, mask, i2, i3, (double)angle, lane);
-      if (!comp_check(x, mv, nm, rs, nr, thr2, lane)) {
-        // Python floor division: range(angle // backoff)
-        int steps = angle / backoff;
-        if ((angle % backoff != 0) && ((angle < 0) != (backoff < 0))) --steps;
-        for (int b = 0; b < steps; ++b) {
-          rotate_masked(x, A, mask, i2, i3, (double)(-backoff), lane);
-          if (comp_check(x, mv, nm, rs, nr, thr2, lane)) {
-            ++rot;
-            break;
-          }
-        }
-      } else {
-        ++rot;
-      }
+      rot += torsion_step(x, A, mask, mv, nm, rs, nr, i2, i3, angle, backoff, thr2, lane);
     }
     if (out != nullptr) {
       double *o = out + sidx * (int64_t)A * 3;
@@ -436,10 +485,25 @@ k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ t
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
   const int t = level;
   const int i2 = (int)torsions[t * 4 + 1], i3 = (int)torsions[t * 4 + 2];
-  const uint8_t *mask = rotmasks + (size_t)t * A;
-  const int16_t *mv = mv_idx + (size_t)t * A;
-  const int16_t *rs = rs_idx + (size_t)t * A;
   const int nm = n_mv[t], nr = n_rs[t];
+  // the level's ONE torsion: its rotation mask and its moving / rest index lists are read in every step of every
+  // back-off loop (up to 60 per node) -- from LDS, not through the vector cache
+  int16_t *mv = reinterpret_cast<int16_t *>(s + (size_t)4 * A * 3);
+  int16_t *rs = mv + A;
+  uint8_t *mask = reinterpret_cast<uint8_t *>(rs + A);
+  for (int k = threadIdx.x; k < A; k += 256) {
+    mv[k] = mv_idx[(size_t)t * A + k];
+    rs[k] = rs_idx[(size_t)t * A + k];
+    mask[k] = rotmasks[(size_t)t * A + k];
+  }
+  __syncthreads();
+  int pre_r[kPrePairs], pre_m[kPrePairs];  // this lane's pairs of the first rounds of every clash check of the level
+#pragma unroll
+  for (int q = 0; q < kPrePairs; ++q) {
+    const int p = q * 64 + lane;
+    pre_r[q] = p < nm * nr ? rs[p / nm] : 0;
+    pre_m[q] = p < nm * nr ? mv[p % nm] : 0;
+  }
   const bool last = level == T - 1;
   for (int64_t node = wave0; node < M; node += nwaves) {
     const int i = first[node];
@@ -448,22 +512,7 @@ k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ t
     __builtin_amdgcn_wave_barrier();
     int rot = level == 0 ? 0 : rot_prev[nid_prev[i] - 1];
     const int angle = (int)angles[(int64_t)row[i] * T + t];
-    if (angle != 0) {
-      rotate_masked(x, A, mask, i2, i3, (double)angle, lane);
-      if (!comp_check(x, mv, nm, rs, nr, thr2, lane)) {
-        int steps = angle / backoff;  // Python floor division: range(angle // backoff)
-        if ((angle % backoff != 0) && ((angle < 0) != (backoff < 0))) --steps;
-        for (int b = 0; b < steps; ++b) {
-          rotate_masked(x, A, mask, i2, i3, (double)(-backoff), lane);
-          if (comp_check(x, mv, nm, rs, nr, thr2, lane)) {
-            ++rot;
-            break;
-          }
-        }
-      } else {
-        ++rot;
-      }
-    }
+    if (angle != 0) rot += torsion_step(x, A, mask, mv, nm, rs, nr, i2, i3, angle, backoff, thr2, lane, pre_r, pre_m);
     if (!last) {
       double *o = state + node * (int64_t)A * 3;
       for (int k = lane; k < A * 3; k += 64) o[k] = x[k];
@@ -567,7 +616,7 @@ static int torsion_scan_tree(const double *base_dev, int64_t A, const int64_t *t
                        dfirst.as<int>());
     const int64_t nodes = bound[(size_t)level];
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(nodes, 4), (int64_t)ctx().n_cu * 32));
-    hipLaunchKernelGGL(k_ts_level, dim3((unsigned)blocks), dim3(256), (size_t)4 * A * 3 * sizeof(double), st, base_dev,
+    hipLaunchKernelGGL(k_ts_level, dim3((unsigned)blocks), dim3(256), (size_t)4 * A * 3 * sizeof(double) + (size_t)A * 5 + 16, st, base_dev,
                        (int)A, torsions_dev, (int)T, level, rotmasks_dev, mv_dev, rs_dev, nmv_dev, nrs_dev, angles_dev, S,
                        thr2, (int)backoff, drow2.as<uint32_t>(), nid_prev.as<int>(), nid.as<int>(), dfirst.as<int>(),
                        dstate[(level & 1) ^ 1].as<double>(), drotn[(level & 1) ^ 1].as<int>(), dstate[level & 1].as<double>(),
