@@ -71,6 +71,7 @@ int launch_torsion_scan(const double *, int64_t, const int64_t *, int64_t, const
                         const int16_t *, const int16_t *, const int32_t *, const int32_t *,
                         const int64_t *, int64_t, double, int64_t, double *, int64_t *, const int64_t *, int64_t, double *);
 int launch_angle_grid(const int64_t *, const int64_t *, const int64_t *, int64_t, int64_t, int64_t *);
+int launch_select_rotated(const int64_t *, int64_t, int64_t *, int64_t *, DevBuf &);
 int launch_torsion_fingerprint(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
 int launch_tfd_first_match(const double *, int64_t, int64_t, int64_t, double, int64_t *, float *);
 int launch_transpose_pad(const double *, int64_t, int64_t, int64_t, double *);
@@ -671,6 +672,7 @@ int fc_warmup(void) {
   FC_TRY(warm_h2_check());
   FC_TRY(warm_kabsch());
   FC_TRY(warm_tfd_gpu());
+  FC_TRY(side_streams());  // the pipelines' streams and ordering events
   FC_TRY(tfd_level_streams(3));  // the TFD ladder's helper streams (hardware queues: several ms each on first use)
   // the buffers a first large call would otherwise take from the runtime one by one (0.2 - 1 ms each): through the pool once
   {
@@ -2054,26 +2056,35 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
                              want_tf ? dq.as<int64_t>() : nullptr, Q, want_tf ? dtf.as<double>() : nullptr));
   if (coords_out) FC_TRY(d2h(coords_out, dout.p, (size_t)S * A * 3 * sizeof(double)));
   if (tf_out) FC_TRY(d2h(tf_out, dtf.p, (size_t)S * Q * sizeof(double)));
-  FC_TRY(d2h(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t)));
-  FC_TRY(sync());
-  if (!tfd_keep_out) return FC_OK;
-  // rows of the TFD problem: the starting structure, then the scanned conformers that rotated a bond
-  std::vector<int64_t> kept;
-  kept.reserve((size_t)S);
-  for (int64_t sidx = 0; sidx < S; ++sidx)
-    if (rotated_bonds_out[sidx] != 0) kept.push_back(sidx);
-  const int64_t M = (int64_t)kept.size(), N = M + 1, Npad = ceil_div(N, 64) * 64;
-  DevBuf dtf0, didx, dT, dfm;
+  if (!tfd_keep_out) {
+    FC_TRY(d2h(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t)));
+    return sync();
+  }
+  // rows of the TFD problem: the starting structure, then the scanned conformers that rotated a bond -- selected on the
+  // device (the counts are 13 MB at 1.7 M angle-sets: down, through a host loop and up again cost 6 ms in front of the
+  // first-match kernels; now the counts travel down BESIDE those kernels, on another stream)
+  DevBuf dtf0, didx, dT, dfm, dcount, dseltmp;
+  FC_TRY(didx.reserve((size_t)S * sizeof(int64_t)));
+  FC_TRY(dcount.reserve(sizeof(int64_t)));
+  FC_TRY(launch_select_rotated(drot.as<int64_t>(), S, didx.as<int64_t>(), dcount.as<int64_t>(), dseltmp));
+  int64_t M = 0;
+  FC_TRY(d2h(&M, dcount.p, sizeof(int64_t)));
+  FC_TRY(sync());  // (the scan is complete here)
+  const int64_t N = M + 1, Npad = ceil_div(N, 64) * 64;
   FC_TRY(dtf0.reserve((size_t)Q * sizeof(double)));
   FC_TRY(launch_torsion_fingerprint(db.as<double>(), 1, A, dq.as<int64_t>(), Q, dtf0.as<double>()));
-  if (M == 0) kept.push_back(0);  // nothing rotated a bond: one defined entry for the (unused) index upload
-  FC_TRY(upload(didx, kept.data(), (size_t)std::max<int64_t>(M, 1)));
   FC_TRY(dT.reserve((size_t)Q * Npad * sizeof(double)));
   FC_TRY(launch_gather_transpose_pad(dtf.as<double>(), dtf0.as<double>(), didx.as<int64_t>(), M, Q, Npad, dT.as<double>()));
   FC_TRY(dfm.reserve((size_t)N * sizeof(int64_t)));
   DevBuf dtfF;
   FC_TRY(dtfF.reserve((size_t)std::min<int64_t>(Q, 8) * Npad * sizeof(float)));
   FC_TRY(launch_tfd_first_match(dT.as<double>(), N, Npad, Q, tfd_thresh, dfm.as<int64_t>(), dtfF.as<float>()));
+  {  // the counts, while the first-match kernels run (the copy into the caller's pageable array keeps this thread busy,
+     // the device is not waiting for it)
+    FC_TRY(side_streams());
+    FC_HIP_TRY(hipMemcpyAsync(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t), hipMemcpyDeviceToHost, ctx().s_lane[0]));
+    FC_HIP_TRY(hipStreamSynchronize(ctx().s_lane[0]));
+  }
   std::vector<int64_t> fm((size_t)N);
   FC_TRY(d2h(fm.data(), dfm.p, (size_t)N * sizeof(int64_t)));
   FC_TRY(sync());
@@ -2081,7 +2092,10 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   FC_TRY(tfd_ladder_from_first_match(fm.data(), N, mask.data(), dfm.as<int64_t>()));
   std::memset(tfd_keep_out, 0, (size_t)S + 1);
   tfd_keep_out[0] = mask[0];
-  for (int64_t k = 0; k < M; ++k) tfd_keep_out[1 + kept[(size_t)k]] = mask[(size_t)k + 1];
+  int64_t k = 0;  // row k + 1 of the TFD problem = the k-th angle-set that rotated a bond
+  for (int64_t sidx = 0; sidx < S; ++sidx)
+    if (rotated_bonds_out[sidx] != 0) tfd_keep_out[1 + sidx] = mask[(size_t)++k];
+  if (k != M) return set_error(FC_E_HIP, "internal: device selection (%lld rows) and scan counts (%lld) disagree", (long long)M, (long long)k);
   return FC_OK;
 }
 

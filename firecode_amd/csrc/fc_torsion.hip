@@ -697,6 +697,22 @@ int launch_angle_grid(const int64_t *values_dev, const int64_t *first_dev, const
   return check_launch("k_angle_grid");
 }
 
+// indices of the non-zero entries of rot[0 .. S), in order, and their count (device): the rows clustered_csearch hands to
+// the TFD prune, selected where the scan left its counts
+struct RotNonZero {
+  __device__ __forceinline__ bool operator()(const int64_t &v) const { return v != 0; }
+};
+int launch_select_rotated(const int64_t *rot_dev, int64_t S, int64_t *idx_dev, int64_t *count_dev, DevBuf &tmp) {
+  if (S >= (1ll << 31)) return set_error(FC_E_LIMIT, "too many angle-sets for the device selection");
+  hipcub::CountingInputIterator<int64_t> ids(0);
+  hipcub::TransformInputIterator<bool, RotNonZero, const int64_t *> flags(rot_dev, RotNonZero());
+  size_t bytes = 0;
+  FC_HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, ids, flags, idx_dev, count_dev, (int)S, ctx().stream));
+  FC_TRY(tmp.reserve(bytes));
+  FC_HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, bytes, ids, flags, idx_dev, count_dev, (int)S, ctx().stream));
+  return FC_OK;
+}
+
 // fc_warmup(): the first launch from a translation unit makes the runtime load that unit's code object (milliseconds);
 // a no-op launch moves that cost out of the first real call
 __global__ void k_warm_torsion() {}
