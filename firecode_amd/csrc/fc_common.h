@@ -65,6 +65,16 @@ struct Context {
   // pinned host staging for small device->host results (truly asynchronous copies)
   void *pinned = nullptr;
   size_t pinned_bytes = 0;
+  // pinned pieces + events of the staged copies (d2h_staged / h2d_staged): one set per concurrent caller (the TFD
+  // ladder's helper threads copy side by side), handed out under stage_mu
+  struct StageSet {
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy = false;
+  };
+  static constexpr int kStageSets = 8;
+  StageSet stage[kStageSets];
+  std::mutex stage_mu;
   // side streams and events of the pipelined prunes (prune_pipeline, the sharded steps): created on
   // first use by side_streams(), destroyed by fc_shutdown and when fc_init moves to another device
   hipStream_t s_screen = nullptr, s_lane[3] = {nullptr, nullptr, nullptr}, s_comm = nullptr;
@@ -83,6 +93,8 @@ std::recursive_mutex &api_mutex();
 int tfd_level_streams(int n);  // fc_tfd_host.cpp: the ladder's helper streams, created once
 int side_streams();  // creates Context::s_screen / s_lane / s_comm and the ordering events once
 int pinned_reserve(size_t bytes);  // grows ctx().pinned
+// blocking copies through pinned pieces of the library's own (see h2d / d2h below); ordered behind what `st` holds
+int d2h_staged(void *dst, const void *src_dev, size_t n, hipStream_t st);
 Context &ctx();
 int ensure_init();  // lazy init on device 0 (or the one given to fc_init)
 
@@ -206,13 +218,26 @@ inline hipStream_t cur_stream() {
   return s ? s : ctx().stream;
 }
 
+// Host <-> device copies.  A DOWNLOAD of kStagedCopyMin bytes or more into pageable host memory goes through pinned
+// pieces of the library's own (d2h_staged: blocking): the runtime's path for such copies registers the caller's pages
+// with the driver, and when the caller later FREES that memory (a NumPy array, a std::vector: an munmap) the process's
+// queues stand still for 15-25 ms at a moment that has nothing to do with the copy (measured: every other cfg3 search
+// lost 22 ms in the kernel of the re-scan behind it; tools/rescan_probe.py).  Uploads do not show the effect and stay on
+// the runtime's path (FC_STAGED_UPLOADS=1: the pinned detour for them too); pinned host memory (the pipelines' result
+// slots) and small copies stay asynchronous.
+constexpr size_t kStagedCopyMin = (size_t)64 << 10;
+bool host_memory_is_pinned(const void *p);
+bool staged_uploads();  // FC_STAGED_UPLOADS (default below)
+int h2d_staged(void *dst_dev, const void *src, size_t n, hipStream_t st);
 inline int h2d(void *dst, const void *src, size_t n) {
   if (n == 0) return FC_OK;
+  if (n >= kStagedCopyMin && staged_uploads() && !host_memory_is_pinned(src)) return h2d_staged(dst, src, n, cur_stream());
   FC_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, cur_stream()));
   return FC_OK;
 }
 inline int d2h(void *dst, const void *src, size_t n) {
   if (n == 0) return FC_OK;
+  if (n >= kStagedCopyMin && !host_memory_is_pinned(dst)) return d2h_staged(dst, src, n, cur_stream());
   FC_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, cur_stream()));
   return FC_OK;
 }

@@ -27,3 +27,16 @@ for run in range(6):
     b = fc.torsion_module.torsion_scan(base, torsions, masks, ang, thresh=1.5)[0]
     t4 = time.perf_counter()
     print(json.dumps({"scan_tfd": round(t1 - t0, 4), "rows_at": round(t2 - t1, 4), "rescan_1": round(t3 - t2, 4), "rescan_2": round(t4 - t3, 4)}))
+
+# is it the library at all?  first touch of a fresh 4.6 MB NumPy array in this process, behind the same call
+for run in range(6):
+    rot, keep = fc.torsion_module.torsion_scan_tfd_grid(base, torsions, masks, values, torsions, thresh=1.5, tfd_thresh=10)
+    t0 = time.perf_counter()
+    x = np.empty((3859, 50, 3))
+    x.fill(1.0)
+    t1 = time.perf_counter()
+    y = np.empty((3859, 50, 3))
+    y.fill(1.0)
+    t2 = time.perf_counter()
+    print(json.dumps({"first_touch_4.6MB_ms": round(1e3 * (t1 - t0), 2), "again_ms": round(1e3 * (t2 - t1), 2)}))
+    del x, y
