@@ -527,7 +527,7 @@ k_lvl_comp_starts(const int32_t *__restrict__ is_start, const int32_t *__restric
 // (networkx's _plain_bfs order over the insertion-ordered neighbour lists, `seen` as a Python set of ints, the
 // sub-graph view's set rebuilt from it, its first element: group[0]).  Sequential per component by nature; the
 // components of a level are tens of thousands of independent small problems (largest ~4e3 nodes at 1.7 M structures).
-__device__ __forceinline__ uint32_t pyset_final_mask(int64_t n_keys) {
+__host__ __device__ __forceinline__ uint32_t pyset_final_mask(int64_t n_keys) {
   uint64_t mask = 7;
   for (;;) {
     const int64_t trigger = (int64_t)((mask * 3 + 4) / 5);
@@ -583,9 +583,11 @@ struct IntSet {  // a CPython set of distinct non-negative ints < 2^31 (hash(n) 
   }
 };
 
+constexpr int64_t kWaveCompMin = 19;  // (up to 18 members the residues fit one 64-bit word of a single lane)
 // scratch ints a component needs: queue + marks (size each) + two tables of its sets' final size
 __global__ void __launch_bounds__(256)
-k_lvl_comp_scratch(const int32_t *__restrict__ starts, int64_t n_src, int64_t n_nodes, int64_t size_cap, int32_t *__restrict__ need) {
+k_lvl_comp_scratch(const int32_t *__restrict__ starts, int64_t n_src, int64_t n_nodes, int64_t size_cap, int32_t *__restrict__ need,
+                   int32_t *__restrict__ mid_list, int32_t *__restrict__ mid_count) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j > n_src) return;
   if (j == n_src) {
@@ -594,6 +596,108 @@ k_lvl_comp_scratch(const int32_t *__restrict__ starts, int64_t n_src, int64_t n_
   }
   const int64_t s0 = starts[j], s1 = j + 1 < n_src ? starts[j + 1] : n_nodes, size = s1 - s0;
   need[j] = (size <= 4 || size > size_cap) ? 0 : (int32_t)(2 * size + 2 * ((int64_t)pyset_final_mask(size) + 1));
+  // components of kWaveCompMin .. size_cap nodes get a wavefront each (k_lvl_components_wave); order does not matter
+  if (size >= kWaveCompMin && size <= size_cap) mid_list[atomicAdd(mid_count, 1)] = (int32_t)j;
+}
+
+// the reference's orders by one lane: _plain_bfs from the component's earliest node over the insertion-ordered neighbour
+// lists into a set, then the set of that set's iteration: its first element.  scratch: queue | marks | two tables
+__device__ int32_t component_first_by_walk(const int32_t *__restrict__ nodes, const int32_t *__restrict__ head,
+                                           const int32_t *__restrict__ adj, int64_t s0, int64_t size, uint32_t fmask,
+                                           int32_t *__restrict__ scr) {
+  int32_t *q = scr, *mark = q + size, *A = mark + size, *B = A + ((int64_t)fmask + 1);
+  for (int64_t v = 0; v < size; ++v) mark[v] = 0;
+  IntSet comp;
+  comp.init(A, B);
+  q[0] = (int32_t)s0;
+  mark[0] = 1;
+  comp.add(nodes[s0]);
+  int64_t qt = 1;
+  for (int64_t qh = 0; qh < qt; ++qh) {
+    const int32_t v = q[qh];
+    for (int32_t rec = head[v]; rec < head[v + 1]; ++rec) {
+      const int32_t x = adj[rec];
+      if (!mark[x - s0]) {
+        mark[x - s0] = 1;
+        q[qt++] = x;
+        comp.add(nodes[x]);
+      }
+    }
+  }
+  int64_t n_ord = 0;  // the component set's iteration order (over the marks, no longer needed)
+  for (uint32_t sl = 0; sl <= comp.mask; ++sl)
+    if (comp.cur[sl] >= 0) mark[n_ord++] = comp.cur[sl];
+  IntSet view;
+  view.init(A, B);
+  for (int64_t k = 0; k < n_ord; ++k) view.add(mark[k]);
+  for (uint32_t sl = 0; sl <= view.mask; ++sl)
+    if (view.cur[sl] >= 0) return view.cur[sl];
+  return -1;
+}
+
+// One WAVEFRONT per component of kWaveCompMin .. size_cap nodes.  Almost all of them are "clean": no two members share a
+// residue modulo the final table size of the set the reference builds, and the kept node is then simply the member with
+// the smallest residue (the host's shortcut, fc_tfd_host.cpp graph_component) -- a bitmap of the residues in LDS filled
+// with atomicOr by 64 lanes and a minimum over the wavefront, instead of one lane walking up to 1 024 nodes through
+// tables in global memory (which made that lane's wavefront the tail of the whole launch: 6.4 ms at k = 5).  A component
+// with a collision is walked by lane 0 as before.
+__global__ void __launch_bounds__(256)
+k_lvl_components_wave(const int32_t *__restrict__ nodes, const int32_t *__restrict__ head, const int32_t *__restrict__ adj,
+                      const int32_t *__restrict__ starts, int64_t n_src, int64_t n_nodes, const int64_t *__restrict__ nbase,
+                      int n_chunks, int64_t d, const int32_t *__restrict__ soff, int32_t *__restrict__ scratch,
+                      uint8_t *__restrict__ flags, const int32_t *__restrict__ mid_list, const int32_t *__restrict__ mid_count,
+                      int words_per_wave) {
+  extern __shared__ uint32_t bm_all[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t *bm = bm_all + (size_t)wv * words_per_wave;
+  for (int64_t idx = (int64_t)blockIdx.x * 4 + wv; idx < (int64_t)*mid_count; idx += (int64_t)gridDim.x * 4) {  // wave-uniform
+    const int64_t j = mid_list[idx];
+    const int64_t s0 = starts[j], s1 = j + 1 < n_src ? starts[j + 1] : n_nodes, size = s1 - s0;
+    int lo = 0, hi = n_chunks;  // chunk of the component: nbase[c] <= s0 < nbase[c + 1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (nbase[mid] <= s0) lo = mid;
+      else hi = mid;
+    }
+    const int c = lo;
+    const int64_t chunk_nodes = nbase[c + 1] - nbase[c];
+    int32_t first = -1;
+    if (2 * size >= chunk_nodes) {
+      first = nodes[s0];  // FilterAtlas walks the whole graph's nodes: the component's earliest one comes first
+    } else {
+      const uint32_t fmask = pyset_final_mask(size);
+      const int words = (int)(((int64_t)fmask + 32) >> 5);
+      for (int w = lane; w < words; w += 64) bm[w] = 0u;
+      __builtin_amdgcn_wave_barrier();  // (LDS operations of one wavefront complete in order)
+      bool dirty = false;
+      unsigned long long best = ~0ull;  // (residue << 32) | node
+      for (int64_t v = s0 + lane; v < s1; v += 64) {
+        const int32_t node = nodes[v];
+        const uint32_t r = (uint32_t)node & fmask, bit = 1u << (r & 31);
+        const uint32_t old = atomicOr(&bm[r >> 5], bit);
+        dirty = dirty || ((old & bit) != 0u);
+        const unsigned long long key = ((unsigned long long)r << 32) | (unsigned long long)(uint32_t)node;
+        best = key < best ? key : best;
+      }
+      if (__ballot(dirty) == 0ull) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const unsigned long long o = __shfl_xor(best, off);
+          best = o < best ? o : best;
+        }
+        first = (int32_t)(uint32_t)(best & 0xffffffffull);
+      } else {
+        if (lane == 0) first = component_first_by_walk(nodes, head, adj, s0, size, fmask, scratch + soff[j]);
+        first = __shfl(first, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    uint8_t *__restrict__ f = flags + (int64_t)c * d;
+    for (int64_t v = s0 + lane; v < s1; v += 64) {
+      const int32_t node = nodes[v];
+      if (node != first) f[node] = 1;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(64)
@@ -613,6 +717,7 @@ k_lvl_components(const int32_t *__restrict__ nodes, const int32_t *__restrict__ 
   const int c = lo;
   const int64_t chunk_nodes = nbase[c + 1] - nbase[c];
   int32_t first = -1;
+  if (size >= kWaveCompMin && size <= size_cap) return;  // k_lvl_components_wave's
   if (2 * size >= chunk_nodes) {
     first = nodes[s0];  // FilterAtlas walks the whole graph's nodes: the component's earliest one comes first
   } else if (size > size_cap) {
@@ -675,36 +780,7 @@ k_lvl_components(const int32_t *__restrict__ nodes, const int32_t *__restrict__ 
         for (int k = 7; k >= 0; --k)
           if (t2[k] >= 0) first = t2[k];
       } else {
-        int32_t *q = scratch + soff[j], *mark = q + size, *A = mark + size, *B = A + ((int64_t)fmask + 1);
-        for (int64_t v = 0; v < size; ++v) mark[v] = 0;
-        IntSet comp;
-        comp.init(A, B);
-        q[0] = (int32_t)s0;
-        mark[0] = 1;
-        comp.add(nodes[s0]);
-        int64_t qt = 1;
-        for (int64_t qh = 0; qh < qt; ++qh) {
-          const int32_t v = q[qh];
-          for (int32_t rec = head[v]; rec < head[v + 1]; ++rec) {
-            const int32_t x = adj[rec];
-            if (!mark[x - s0]) {
-              mark[x - s0] = 1;
-              q[qt++] = x;
-              comp.add(nodes[x]);
-            }
-          }
-        }
-        int64_t n_ord = 0;  // the component set's iteration order (over the marks, no longer needed)
-        for (uint32_t sl = 0; sl <= comp.mask; ++sl)
-          if (comp.cur[sl] >= 0) mark[n_ord++] = comp.cur[sl];
-        IntSet view;
-        view.init(A, B);
-        for (int64_t k = 0; k < n_ord; ++k) view.add(mark[k]);
-        for (uint32_t sl = 0; sl <= view.mask; ++sl)
-          if (view.cur[sl] >= 0) {
-            first = view.cur[sl];
-            break;
-          }
+        first = component_first_by_walk(nodes, head, adj, s0, size, fmask, scratch + soff[j]);
       }
     }
   }
@@ -927,7 +1003,7 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
   const int64_t n_src = out.sbase[(size_t)n_chunks];
   lap("adjacency");
   DevBuf d_need, d_soff, d_scratch, d_flags, d_left;  // (function scope: copies from them are still in flight below)
-  DevBuf d_lcn, d_lca, d_lon, d_loa, d_lchunk, d_cnodes, d_chead, d_cadj;
+  DevBuf d_lcn, d_lca, d_lon, d_loa, d_lchunk, d_cnodes, d_chead, d_cadj, d_mid;
   if (flags_out != nullptr) {
     static const int64_t size_cap = [] {
       const char *v = getenv("FC_TFD_DEV_COMP_MAX");  // components above this many nodes go to the host threads
@@ -935,14 +1011,16 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
       // device levels nothing to send down (their graph arrays are ~20 MB each, first touched by the first call) at the same
       // steady time as 256; 1536 and above make the longest lane of the component kernel the critical path
       const long long k = v ? std::strtoll(v, nullptr, 10) : 1024;
-      return (int64_t)(k >= 4 ? k : 1024);
+      return (int64_t)(k >= 4 ? std::min<long long>(k, 16384) : 1024);  // (4 waves x one residue bitmap each in LDS)
     }();
     FC_TRY(d_need.reserve((size_t)(n_src + 1) * sizeof(int32_t)));
     FC_TRY(d_soff.reserve((size_t)(n_src + 1) * sizeof(int32_t)));
     FC_TRY(d_left.reserve((size_t)(n_src + 1) * sizeof(int32_t)));
     FC_HIP_TRY(hipMemsetAsync(d_left.p, 0, sizeof(int32_t), st));  // [0] = count, [1..] = component numbers
+    FC_TRY(d_mid.reserve((size_t)(n_nodes / kWaveCompMin + 2) * sizeof(int32_t)));  // [0] = count, [1..] = component numbers
+    FC_HIP_TRY(hipMemsetAsync(d_mid.p, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_lvl_comp_scratch, dim3((unsigned)ceil_div(n_src + 1, 256)), block, 0, st, d_starts.as<int32_t>(), n_src, n_nodes,
-                       size_cap, d_need.as<int32_t>());
+                       size_cap, d_need.as<int32_t>(), d_mid.as<int32_t>() + 1, d_mid.as<int32_t>());
     FC_TRY(check_launch("k_lvl_comp_scratch"));
     FC_TRY(exclusive_scan_i32(d_need.as<int32_t>(), d_soff.as<int32_t>(), n_src + 1, scr));
     int32_t total_need = 0;
@@ -957,6 +1035,16 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
                        d_soff.as<int32_t>(), d_scratch.as<int32_t>(), d_flags.as<uint8_t>(), size_cap, d_left.as<int32_t>() + 1,
                        d_left.as<int32_t>());
     FC_TRY(check_launch("k_lvl_components"));
+    {  // the components of kWaveCompMin .. size_cap nodes, a wavefront each (the list's length stays on the device)
+      const int words = (int)(((int64_t)pyset_final_mask(size_cap) + 32) >> 5);
+      const int64_t most = n_nodes / kWaveCompMin + 1;
+      const unsigned wgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(most, 4), (int64_t)ctx().n_cu * 16));
+      hipLaunchKernelGGL(k_lvl_components_wave, dim3(wgrid), dim3(256), (size_t)4 * words * sizeof(uint32_t), st, d_nodes2.as<int32_t>(),
+                         d_head.as<int32_t>(), d_vals2.as<int32_t>(), d_starts.as<int32_t>(), n_src, n_nodes, d_nbase.as<int64_t>(),
+                         n_chunks, d, d_soff.as<int32_t>(), d_scratch.as<int32_t>(), d_flags.as<uint8_t>(), d_mid.as<int32_t>() + 1,
+                         d_mid.as<int32_t>(), words);
+      FC_TRY(check_launch("k_lvl_components_wave"));
+    }
     int32_t n_left = 0;
     FC_TRY(d2h(flags_out, d_flags.p, (size_t)n_items));
     FC_TRY(d2h(&n_left, d_left.p, sizeof(int32_t)));

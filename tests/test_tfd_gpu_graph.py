@@ -99,3 +99,35 @@ def test_ladder_mask_is_the_same_with_device_built_chunk_graphs(fc, monkeypatch,
     for label in ("device", "device_fine", "device_one_stream", "device_five_streams", "device_graphs_host_components"):
         assert np.array_equal(masks["host"], masks[label]), label
     assert 0 < masks["host"].sum() < n
+
+
+def test_ladder_with_many_components_left_to_the_host(fc):
+    """FC_TFD_DEV_COMP_MAX is read once per process: a child interpreter with a cap of 48 nodes sends hundreds of
+    components per level down to the host threads (the compact copy of JUST those components, k_left_gather) -- same
+    mask as the all-host ladder"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
+        "import numpy as np\n"
+        "import firecode_amd as fc\n"
+        "from firecode_amd import _lib\n"
+        "from test_tfd_gpu_graph import _random_first_match\n"
+        "fc.init(0)\n"
+        "for n, kind, seed in ((300000, 'mixed', 2), (262144, 'chain', 4), (400000, 'stars', 3)):\n"
+        "    fm = _random_first_match(np.random.default_rng(seed), n, kind)\n"
+        "    out = {}\n"
+        "    for label, env in (('host', '0'), ('device', '1')):\n"
+        "        os.environ['FC_TFD_GPU'] = env\n"
+        "        m = np.zeros(n, dtype=np.uint8)\n"
+        "        _lib.call('fc_tfd_ladder_from_first_match', _lib.pi(fm), n, _lib.pb(m))\n"
+        "        out[label] = m\n"
+        "    assert np.array_equal(out['host'], out['device']) and 0 < out['host'].sum() < n, kind\n"
+        "print('ok')\n")
+    env = dict(os.environ, FC_TFD_DEV_COMP_MAX="48")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
