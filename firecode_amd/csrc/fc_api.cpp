@@ -351,10 +351,11 @@ struct StageLease {  // one set of pinned pieces for the duration of one staged 
 
 bool staged_uploads() {
   static const bool on = [] {
-    // measured: uploads through the runtime's own path leave nothing behind (a 107 MB array sent and freed per run: no
-    // stall) and are 0.12 ms per 12 MB faster than memcpy + DMA; only the downloads need the pinned detour
+    // measured (cfg3 search, ten runs per process, tools/rescan_probe.py): with uploads on the runtime's own path one run
+    // in three still lost 9-22 ms in the kernel behind the free of an uploaded array; with the pinned detour none did.
+    // Price: memcpy + DMA instead of DMA from the caller's pages, +0.12 ms per 12 MB (FC_STAGED_UPLOADS=0: direct)
     const char *v = getenv("FC_STAGED_UPLOADS");
-    return v ? atoi(v) != 0 : false;
+    return v ? atoi(v) != 0 : true;
   }();
   return on;
 }

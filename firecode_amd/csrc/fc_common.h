@@ -218,13 +218,13 @@ inline hipStream_t cur_stream() {
   return s ? s : ctx().stream;
 }
 
-// Host <-> device copies.  A DOWNLOAD of kStagedCopyMin bytes or more into pageable host memory goes through pinned
-// pieces of the library's own (d2h_staged: blocking): the runtime's path for such copies registers the caller's pages
-// with the driver, and when the caller later FREES that memory (a NumPy array, a std::vector: an munmap) the process's
-// queues stand still for 15-25 ms at a moment that has nothing to do with the copy (measured: every other cfg3 search
-// lost 22 ms in the kernel of the re-scan behind it; tools/rescan_probe.py).  Uploads do not show the effect and stay on
-// the runtime's path (FC_STAGED_UPLOADS=1: the pinned detour for them too); pinned host memory (the pipelines' result
-// slots) and small copies stay asynchronous.
+// Host <-> device copies.  A copy of kStagedCopyMin bytes or more from or to PAGEABLE host memory goes through pinned
+// pieces of the library's own (h2d_staged / d2h_staged: blocking): the runtime's path for such copies registers the
+// caller's pages with the driver, and when the caller later FREES that memory (a NumPy array, a std::vector: an munmap)
+// the process's queues stand still for 10-25 ms at a moment that has nothing to do with the copy (measured: every other
+// cfg3 search lost 22 ms in the kernel of the re-scan behind it; tools/rescan_probe.py).  Downloads showed it first, uploads
+// less often (one run in three); FC_STAGED_UPLOADS=0 puts uploads back on the runtime's path (0.12 ms per 12 MB faster).
+// Pinned host memory (the pipelines' result slots) and small copies stay asynchronous.
 constexpr size_t kStagedCopyMin = (size_t)64 << 10;
 bool host_memory_is_pinned(const void *p);
 bool staged_uploads();  // FC_STAGED_UPLOADS (default below)
