@@ -63,7 +63,7 @@ int fc_stream_set(void *hip_stream);
  * with events itself (the overlapped multi-GPU steps of firecode_amd/dist.py). */
 int fc_stream_use(void *hip_stream);
 /* Device temporaries of the entry points come from a caching pool (released blocks are kept
- * and reused; FC_POOL_MB caps what is kept, default 2048, 0 disables).  fc_memory_trim returns
+ * and reused; FC_POOL_MB caps what is kept, default 8192, 0 disables).  fc_memory_trim returns
  * the kept blocks to the HIP runtime; fc_shutdown does the same. */
 int fc_memory_trim(void);
 /* name, CU count and bytes of HBM of the active device (diagnostics) */
