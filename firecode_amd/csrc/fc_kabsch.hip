@@ -3190,9 +3190,12 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
   }();
   if (lanes) {
     static const int per_cu = [] {
-      const char *v = getenv("FC_REFINE_GRID");  // workgroups per CU (tuning knob)
-      const int k = v ? atoi(v) : 16;
-      return k >= 1 && k <= 64 ? k : 16;
+      // workgroups per CU (tuning knob).  The kernel waits for the memory system, not for lanes: alone it takes 0.45 / 0.49 /
+      // 0.47 ms for 9.45e5 pairs with 16 / 2 / 1 workgroups per CU; beside a screen, two per CU leave the screen the
+      // registers of the other SIMD slots: the overlapped step 0.80 -> 0.77 ms (tools/refine_alone_probe.py)
+      const char *v = getenv("FC_REFINE_GRID");
+      const int k = v ? atoi(v) : 2;
+      return k >= 1 && k <= 64 ? k : 2;
     }();
     hipLaunchKernelGGL(k_refine_pairs, dim3((unsigned)(ctx().n_cu * per_cu)), dim3(256), 0, ctx().stream,
                        e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, max_rmsd, max_dev, energies_dev,
