@@ -348,6 +348,27 @@ def spawn_ranks(n):
     sys.stdout.flush()
 
 
+def start_extras_guard(emit, rank, headline, seconds):
+    """Several ranks, blocks that exchange data over a communicator no round has seen on more than one device: if they do
+    not come back within `seconds`, every rank's own timer ends its process -- rank 0 after printing the line with the
+    headline measurement it already holds (`emit`).  Returns the timer (cancel it when the blocks are through)."""
+    import threading
+
+    def fire():
+        if rank == 0:
+            d = dict(headline)
+            d["extras_error"] = f"the exchanging extra blocks did not finish within {seconds} s; the ranks ended themselves"
+            emit(d)
+        sys.stderr.write(f"bench.py: rank {rank}: extra blocks timed out after {seconds} s\n")
+        sys.stderr.flush()
+        os._exit(0)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def rank_env(base, rank, world, idfile):
     """Environment of rank `rank` of a self-spawned launch (what an external launcher would set)."""
     env = dict(base)
@@ -430,21 +451,39 @@ def main():
         fc.init(0)
 
     def barrier():
-        if comm:
-            _lib.comm_barrier()  # a 1-byte all-gather + device synchronisation on every rank
-        elif rv is not None:
-            rv.barrier()  # (every bench hook returns behind its own device synchronisation)
+        # several ranks: through the files, whether or not there is a communicator -- the timed regions bracket device work
+        # that every bench hook has already synchronised, and the headline must not depend on a collective
+        if rv is not None:
+            rv.barrier()
+        elif comm:
+            _lib.comm_barrier()  # a 1-byte all-gather + device synchronisation (the 1-rank communicator of the forced modes)
 
     def max_over_ranks(x):
-        if world == 1:
-            return float(x)
-        if not comm:
-            return rv.max(x)
-        g = _lib.allgather_mask(np.array([x], dtype=np.float64).view(np.uint8))
-        return float(g.view(np.float64).max())
+        return float(x) if rv is None else rv.max(x)
+
+    import threading
+
+    emit_lock, emitted = threading.Lock(), [False]
+
+    def emit(line_dict):
+        """the ONE JSON line, once (rank 0)"""
+        with emit_lock:
+            if emitted[0] or rank != 0:
+                return
+            emitted[0] = True
+            if world > 1:
+                line_dict["rank_coordination"] = ("barrier / max over ranks through files (firecode_amd.dist.HostRendezvous); RCCL communicator " +
+                                                  ("up: used by the exchanging blocks" if comm else "NOT created: " + str(comm_error)))
+            sys.stdout.flush()
+            os.dup2(stdout_fd, 1)
+            print(json.dumps(line_dict), flush=True)
+            os.dup2(2, 1)
+
+    def guard_extras(headline, seconds):
+        return start_extras_guard(emit, rank, headline, seconds)
 
     ctx = dict(args=args, fc=fc, _lib=_lib, fdist=fdist, syn=syn, rank=rank, world=world, comm=comm,
-               barrier=barrier, max_over_ranks=max_over_ranks, comm_error=comm_error)
+               barrier=barrier, max_over_ranks=max_over_ranks, comm_error=comm_error, guard_extras=guard_extras)
     if workload == "cfg5":
         out = run_cfg5(args, fc, _lib, fdist, syn, rank, world, barrier, max_over_ranks)
     elif workload == "cfg4":
@@ -453,13 +492,7 @@ def main():
         out = run_alignments(ctx)
 
     if rank == 0:
-        if world > 1:
-            out["rank_coordination"] = ("RCCL communicator (fc_comm_barrier, fc_allgather_mask)" if comm else
-                                        "files (firecode_amd.dist.HostRendezvous); no RCCL communicator: " + str(comm_error))
-        sys.stdout.flush()
-        os.dup2(stdout_fd, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
+        emit(out)
     if comm:
         _lib.comm_barrier()
         _lib.comm_destroy()
@@ -593,6 +626,7 @@ def run_alignments(ctx):
     elif not args.no_extras and world > 1:
         # the blocks that exchange data between the ranks: whatever goes wrong in them -- the same on every rank, the calls
         # are collective -- must not take the headline measurement above with it
+        timer = ctx["guard_extras"](out if rank == 0 else {}, int(os.environ.get("FC_BENCH_EXTRAS_TIMEOUT_S", "300")))
         try:
             blk = prune_block(ctx, "cfg2", ens, coords, atoms, assign, n_conf, n_atoms, steps_default=200, warmup_default=20)
             if rank == 0:
@@ -605,6 +639,8 @@ def run_alignments(ctx):
             sys.stderr.write(f"bench.py: rank {rank}: extra blocks failed: {type(exc).__name__}: {exc}\n")
             if rank == 0:
                 out["extras_error"] = f"{type(exc).__name__}: {exc}"
+        finally:
+            timer.cancel()
     elif not args.no_extras:
         blk = prune_block(ctx, "cfg2", ens, coords, atoms, assign, n_conf, n_atoms, steps_default=200, warmup_default=20)
         if rank == 0:

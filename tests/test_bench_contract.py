@@ -132,7 +132,7 @@ def test_bench_two_ranks_on_one_device_agree_through_files(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["n_conformers"] == 14142 and 0 < d["config"]["pairs_per_step_rank0"] < d["config"]["pairs_per_step"]
-    assert d["rank_coordination"].startswith(("files", "RCCL")) and 0 < d["efficiency"] < 1.2
+    assert d["rank_coordination"].startswith("barrier / max over ranks through files") and 0 < d["efficiency"] < 1.2
     assert not list(tmp_path.glob("two.id.rv.*"))  # the rendezvous cleaned up after itself
 
 
@@ -151,6 +151,31 @@ def test_host_rendezvous_three_processes(tmp_path):
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, text=True) for r in range(3)]
     assert [p.communicate(timeout=120)[0].strip() for p in procs] == ["ok 0", "ok 1", "ok 2"]
     assert not list(tmp_path.iterdir())
+
+
+def test_bench_extras_guard_ends_a_hung_rank_with_the_headline():
+    """the timer around the exchanging extra blocks of an N > 1 run: rank 0 prints the line it holds, the process ends with 0"""
+    code = (
+        "import sys, time, json\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "def emit(d):\n"
+        "    print(json.dumps(d), flush=True)\n"
+        "t = bench.start_extras_guard(emit, int(sys.argv[1]), {'value': 1.5, 'n_gpus': 2}, 1)\n"
+        "time.sleep(30)\n"
+        "print('not reached')\n")
+    for rank, expect_line in ((0, True), (1, False)):
+        out = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=20)
+        assert out.returncode == 0 and "not reached" not in out.stdout and "timed out after 1 s" in out.stderr
+        if expect_line:
+            d = json.loads(out.stdout.strip())
+            assert d["value"] == 1.5 and "did not finish within 1 s" in d["extras_error"]
+        else:
+            assert out.stdout.strip() == ""
+    # cancelled in time: nothing happens
+    code2 = code.replace("time.sleep(30)", "t.cancel(); time.sleep(2)").replace("print('not reached')", "print('done')")
+    out = subprocess.run([sys.executable, "-c", code2, "0"], capture_output=True, text=True, timeout=20)
+    assert out.returncode == 0 and out.stdout.strip() == "done"
 
 
 def test_bench_spawn_environment():
