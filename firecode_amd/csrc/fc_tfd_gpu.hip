@@ -646,7 +646,7 @@ k_lvl_components_wave(const int32_t *__restrict__ nodes, const int32_t *__restri
                       const int32_t *__restrict__ starts, int64_t n_src, int64_t n_nodes, const int64_t *__restrict__ nbase,
                       int n_chunks, int64_t d, const int32_t *__restrict__ soff, int32_t *__restrict__ scratch,
                       uint8_t *__restrict__ flags, const int32_t *__restrict__ mid_list, const int32_t *__restrict__ mid_count,
-                      int words_per_wave) {
+                      int words_per_wave, int64_t dirty_walk_max, int32_t *__restrict__ left_list, int32_t *__restrict__ left_count) {
   extern __shared__ uint32_t bm_all[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t *bm = bm_all + (size_t)wv * words_per_wave;
@@ -686,6 +686,12 @@ k_lvl_components_wave(const int32_t *__restrict__ nodes, const int32_t *__restri
           best = o < best ? o : best;
         }
         first = (int32_t)(uint32_t)(best & 0xffffffffull);
+      } else if (size > dirty_walk_max) {
+        // a collision in a large component: the walk is sequential, a host core does a node in ~20 ns where a lane here
+        // needs ~1 us -- to the host's list (with the components above the cap); nothing flagged here
+        if (lane == 0) left_list[atomicAdd(left_count, 1)] = (int32_t)j;
+        __builtin_amdgcn_wave_barrier();
+        continue;
       } else {
         if (lane == 0) first = component_first_by_walk(nodes, head, adj, s0, size, fmask, scratch + soff[j]);
         first = __shfl(first, 0);
@@ -1035,6 +1041,14 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
                        d_soff.as<int32_t>(), d_scratch.as<int32_t>(), d_flags.as<uint8_t>(), size_cap, d_left.as<int32_t>() + 1,
                        d_left.as<int32_t>());
     FC_TRY(check_launch("k_lvl_components"));
+    static const int64_t dirty_walk_max = [] {
+      // components with a residue collision above this many nodes go to the host.  Default: none do -- at 1.7 M structures
+      // 900 - 4 900 components per level have a collision; walked by one lane each they are the 2.4 ms of this kernel,
+      // sent to two host threads (limit 64) they are 4 - 16 ms per level
+      const char *v = getenv("FC_TFD_DEV_DIRTY_MAX");
+      const long long k = v ? std::strtoll(v, nullptr, 10) : (1ll << 40);
+      return (int64_t)(k >= 19 ? k : (1ll << 40));
+    }();
     {  // the components of kWaveCompMin .. size_cap nodes, a wavefront each (the list's length stays on the device)
       const int words = (int)(((int64_t)pyset_final_mask(size_cap) + 32) >> 5);
       const int64_t most = n_nodes / kWaveCompMin + 1;
@@ -1042,7 +1056,7 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
       hipLaunchKernelGGL(k_lvl_components_wave, dim3(wgrid), dim3(256), (size_t)4 * words * sizeof(uint32_t), st, d_nodes2.as<int32_t>(),
                          d_head.as<int32_t>(), d_vals2.as<int32_t>(), d_starts.as<int32_t>(), n_src, n_nodes, d_nbase.as<int64_t>(),
                          n_chunks, d, d_soff.as<int32_t>(), d_scratch.as<int32_t>(), d_flags.as<uint8_t>(), d_mid.as<int32_t>() + 1,
-                         d_mid.as<int32_t>(), words);
+                         d_mid.as<int32_t>(), words, dirty_walk_max, d_left.as<int32_t>() + 1, d_left.as<int32_t>());
       FC_TRY(check_launch("k_lvl_components_wave"));
     }
     int32_t n_left = 0;
