@@ -584,6 +584,7 @@ struct IntSet {  // a CPython set of distinct non-negative ints < 2^31 (hash(n) 
 };
 
 constexpr int64_t kWaveCompMin = 19;  // (up to 18 members the residues fit one 64-bit word of a single lane)
+constexpr int64_t kLdsWalkInts = 2 * 306 + 2 * 512;  // LDS ints per wavefront for the walk of a component with a residue collision
 // scratch ints a component needs: queue + marks (size each) + two tables of its sets' final size
 __global__ void __launch_bounds__(256)
 k_lvl_comp_scratch(const int32_t *__restrict__ starts, int64_t n_src, int64_t n_nodes, int64_t size_cap, int32_t *__restrict__ need,
@@ -693,7 +694,12 @@ k_lvl_components_wave(const int32_t *__restrict__ nodes, const int32_t *__restri
         __builtin_amdgcn_wave_barrier();
         continue;
       } else {
-        if (lane == 0) first = component_first_by_walk(nodes, head, adj, s0, size, fmask, scratch + soff[j]);
+        // the walk's queue, marks and two tables in LDS when they fit (components of up to 306 nodes: tables of 512
+        // slots), in global scratch otherwise: a lane's dependent accesses cost ~0.1 us there against ~1 us
+        const int64_t need = 2 * size + 2 * ((int64_t)fmask + 1);
+        int32_t *scr = need <= kLdsWalkInts ? reinterpret_cast<int32_t *>(bm_all + (size_t)4 * words_per_wave) + (size_t)wv * kLdsWalkInts
+                                            : scratch + soff[j];
+        if (lane == 0) first = component_first_by_walk(nodes, head, adj, s0, size, fmask, scr);
         first = __shfl(first, 0);
       }
       __builtin_amdgcn_wave_barrier();
@@ -1042,18 +1048,19 @@ int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevel
                        d_left.as<int32_t>());
     FC_TRY(check_launch("k_lvl_components"));
     static const int64_t dirty_walk_max = [] {
-      // components with a residue collision above this many nodes go to the host.  Default: none do -- at 1.7 M structures
-      // 900 - 4 900 components per level have a collision; walked by one lane each they are the 2.4 ms of this kernel,
-      // sent to two host threads (limit 64) they are 4 - 16 ms per level
+      // components with a residue collision above this many nodes go to the host.  At 1.7 M structures 900 - 4 900
+      // components per level have a collision; up to 306 nodes their walk runs out of LDS (kLdsWalkInts), the 36 - 218
+      // larger ones per level were the tail of this kernel (4.4 - 5.1 -> 2.7 - 3.4 ms per level, + 0.5 - 3 ms on two host
+      // threads of the level's helper); a limit of 64 sends thousands down: 4 - 16 ms per level
       const char *v = getenv("FC_TFD_DEV_DIRTY_MAX");
-      const long long k = v ? std::strtoll(v, nullptr, 10) : (1ll << 40);
-      return (int64_t)(k >= 19 ? k : (1ll << 40));
+      const long long k = v ? std::strtoll(v, nullptr, 10) : 306;
+      return (int64_t)(k >= 19 ? k : 306);
     }();
     {  // the components of kWaveCompMin .. size_cap nodes, a wavefront each (the list's length stays on the device)
       const int words = (int)(((int64_t)pyset_final_mask(size_cap) + 32) >> 5);
       const int64_t most = n_nodes / kWaveCompMin + 1;
       const unsigned wgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(most, 4), (int64_t)ctx().n_cu * 16));
-      hipLaunchKernelGGL(k_lvl_components_wave, dim3(wgrid), dim3(256), (size_t)4 * words * sizeof(uint32_t), st, d_nodes2.as<int32_t>(),
+      hipLaunchKernelGGL(k_lvl_components_wave, dim3(wgrid), dim3(256), (size_t)4 * (words + kLdsWalkInts) * sizeof(uint32_t), st, d_nodes2.as<int32_t>(),
                          d_head.as<int32_t>(), d_vals2.as<int32_t>(), d_starts.as<int32_t>(), n_src, n_nodes, d_nbase.as<int64_t>(),
                          n_chunks, d, d_soff.as<int32_t>(), d_scratch.as<int32_t>(), d_flags.as<uint8_t>(), d_mid.as<int32_t>() + 1,
                          d_mid.as<int32_t>(), words, dirty_walk_max, d_left.as<int32_t>() + 1, d_left.as<int32_t>());
