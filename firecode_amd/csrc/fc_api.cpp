@@ -233,6 +233,7 @@ static void context_teardown() {
       (void)hipStreamDestroy(s);
     }
   c.s_screen = c.s_lane[0] = c.s_lane[1] = c.s_lane[2] = c.s_comm = nullptr;
+  tfd_level_streams_teardown();
   for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
   c.ev_pool.clear();
   for (hipEvent_t e : c.ev_dep_pool) (void)hipEventDestroy(e);

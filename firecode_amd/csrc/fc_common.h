@@ -91,6 +91,7 @@ struct Context {
 std::recursive_mutex &api_mutex();
 #define FC_API_LOCK std::lock_guard<std::recursive_mutex> fc_api_lock_guard(::fc::api_mutex())
 int tfd_level_streams(int n);  // fc_tfd_host.cpp: the ladder's helper streams, created once
+void tfd_level_streams_teardown();
 int side_streams();  // creates Context::s_screen / s_lane / s_comm and the ordering events once
 int pinned_reserve(size_t bytes);  // grows ctx().pinned
 // blocking copies through pinned pieces of the library's own (see h2d / d2h below); ordered behind what `st` holds

@@ -637,8 +637,19 @@ static hipStream_t g_lvl_stream[kLevelStreamsMax] = {nullptr, nullptr, nullptr, 
 static hipEvent_t g_lvl_begin = nullptr;
 static uint64_t g_lvl_epoch = 0;
 static TfdLevelGraph g_lvl_holders[kLevelStreamsMax];
+void tfd_level_streams_teardown() {  // context_teardown: the streams belong to the device being left
+  for (auto &st : g_lvl_stream) {
+    if (st) {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
+    st = nullptr;
+  }
+  if (g_lvl_begin) (void)hipEventDestroy(g_lvl_begin);
+  g_lvl_begin = nullptr;
+}
 int tfd_level_streams(int n) {
-  if (g_lvl_epoch != ctx().epoch) {  // (what an earlier context created went with its device)
+  if (g_lvl_epoch != ctx().epoch) {  // (a new context: context_teardown has destroyed what the old one created)
     for (auto &st : g_lvl_stream) st = nullptr;
     g_lvl_begin = nullptr;
     g_lvl_epoch = ctx().epoch;

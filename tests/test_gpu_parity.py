@@ -5,6 +5,8 @@ Bars (BASELINE.json north_star): integer / boolean results bit-exact;
 RMSD, max deviation and coordinates within 1e-10.
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -1336,8 +1338,26 @@ def test_context_lifecycle_and_threads(fc):
     ref = o.greedy_prune_from_matrix(S0)
     old = fc.DeviceEnsemble(X, center=True)
     old.bench_prune(0.5, 1.0, reps=4)            # side streams and the event pool exist now
+
+    def ladder(n=140000):                        # ... and the TFD ladder's helper streams and pinned staging pieces
+        rng = np.random.default_rng(9)
+        i = np.arange(n, dtype=np.int64)
+        fm = np.where(rng.random(n) < 0.9, i + rng.integers(1, 60, n), -1)
+        fm[fm >= n] = -1
+        out = {}
+        for env in ("1", "0"):
+            os.environ["FC_TFD_GPU"] = env
+            m = np.zeros(n, dtype=np.uint8)
+            _lib.call("fc_tfd_ladder_from_first_match", _lib.pi(fm), n, _lib.pb(m))
+            out[env] = m
+        os.environ.pop("FC_TFD_GPU")
+        assert np.array_equal(out["0"], out["1"]) and 0 < out["0"].sum() < n
+        return out["1"]
+
+    before = ladder()
     _lib.shutdown()
     _lib.init(0)
+    assert np.array_equal(ladder(), before)
     with pytest.raises(_lib.FirecodeHipInputError):
         old.prune(0.5, 1.0)
     old.close()
