@@ -135,9 +135,16 @@ def test_cartesian_product_native_equals_numpy(golden):
         [np.array(["a", "b"]), np.array(["x", "y", "z"])],                    # strings: NumPy path
         [np.arange(3000, dtype=np.uint64), np.arange(3)],                     # uint64: NumPy path (no int64 detour)
     ]
+    from firecode_amd.utils import cartesian_rows_at
+
     for arrays in cases:
         mine, want = cartesian_product(*arrays), ref(*arrays)
         assert mine.shape == want.shape and mine.dtype == want.dtype and np.array_equal(mine, want)
+        if len(want):  # rows of the product from their row numbers alone (what the device-generated grid leaves the host)
+            pick = rng.integers(0, len(want), 200)
+            got = cartesian_rows_at(arrays, pick)
+            assert got.shape == (200, want.shape[1]) and np.array_equal(got, want[pick])
+    assert np.array_equal(cartesian_rows_at(cases[0], np.arange(6 ** 6)), ref(*cases[0]))
 
 
 def test_ensemble_energy_threshold_against_the_reference_vectors_and_the_literal_loop(golden):
