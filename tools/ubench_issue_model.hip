@@ -20,6 +20,7 @@ typedef float vf_t;
 #endif
 
 #define MFMA(i) "v_mfma_f32_16x16x32_f16 %" #i ", %16, %17, %" #i "\n"
+#define MFMA32(i) "v_mfma_f32_32x32x16_f16 %" #i ", %4, %5, %" #i "\n"
 #if defined(UB_PK)  // two fp32 FMAs per lane and instruction
 #define VF(i) "v_pk_fma_f32 %" #i ", %" #i ", %18, %18\n"
 #elif defined(UB_VOP2)  // the 4-byte encoding most of the screen's polynomial uses
@@ -32,7 +33,7 @@ typedef float vf_t;
     "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])                  \
   : "v"(a), "v"(b), "v"(mf)
 
-enum Role { R_NONE = 0, R_M, R_V, R_I1, R_I2, R_I3, R_I4, R_I5, R_P };
+enum Role { R_NONE = 0, R_M, R_V, R_I1, R_I2, R_I3, R_I4, R_I5, R_P, R_P32, R_M32 };
 
 struct State {
   f4_t acc[8];
@@ -73,6 +74,12 @@ __device__ __forceinline__ void unit_I5(f4_t (&acc)[8], vf_t (&f)[8], h8_t a, h8
                            VF(12) VF(13) VF(14) VF(15) OPERANDS);
 }
 
+typedef float f16_t __attribute__((ext_vector_type(16)));
+// four independent 32 x 32 accumulators (64 registers), the 32x32x16 form of the same product
+__device__ __forceinline__ void unit_M32(f16_t (&acc32)[4], h8_t a, h8_t b) {
+  asm volatile(MFMA32(0) MFMA32(1) MFMA32(2) MFMA32(3) : "+v"(acc32[0]), "+v"(acc32[1]), "+v"(acc32[2]), "+v"(acc32[3]) : "v"(a), "v"(b));
+}
+
 __device__ __forceinline__ unsigned long long now() {
   unsigned long long t;
   asm volatile("s_memtime %0\ns_waitcnt lgkmcnt(0)" : "=s"(t));
@@ -91,6 +98,9 @@ __global__ void __launch_bounds__(1024) k_issue(Config cfg, unsigned long long w
   const int role = cfg.role[slot];
   f4_t acc[8];
   vf_t f[8];
+  f16_t acc32[4];
+  for (int i = 0; i < 4; ++i)
+    for (int k = 0; k < 16; ++k) acc32[i][k] = 0.f;
   h8_t a, b;
   for (int j = 0; j < 8; ++j) a[j] = (_Float16)(seed + j), b[j] = (_Float16)(seed - j);
   for (int i = 0; i < 8; ++i) acc[i] = f4_t{0.f, 0.f, 0.f, 0.f}, f[i] = vf_t(seed + i);
@@ -129,6 +139,20 @@ for (int rep = 0; rep < 16; ++rep)
 for (int rep = 0; rep < 16; ++rep)
 #pragma unroll
         for (int u = 0; u < 8; ++u) unit_I5(acc, f, a, b, mf);
+    } else if (role == R_M32) {
+      for (int rep = 0; rep < 16; ++rep)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) unit_M32(acc32, a, b);  // 64 MFMAs per rep; "unit" bookkeeping: 8 MFMAs
+    } else if (role == R_P32) {  // one 32 x 32 tile = 1024 pairs: 108 MFMAs of 32x32x16, then 4 x 268 v_fma_f32
+      for (int rep = 0; rep < 128; ++rep) {
+#pragma unroll
+        for (int u = 0; u < 27; ++u) unit_M32(acc32, a, b);
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int u = 0; u < 33; ++u) unit_V(acc, f, a, b, mf);
+          asm volatile(VF(8) VF(9) VF(10) VF(11) OPERANDS);
+        }
+      }
     } else if (role == R_P) {  // one "sub-tile": 54 MFMAs, then 268 v_fma_f32 (counted as ONE unit of 8 below: x8 keeps the bookkeeping uniform)
       for (int rep = 0; rep < 128; ++rep) {
 #pragma unroll
@@ -148,11 +172,12 @@ for (int rep = 0; rep < 16; ++rep)
   }
   float r = 0;
   for (int i = 0; i < 8; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + ((const float *)&f[i])[0];
+  for (int i = 0; i < 4; ++i) r += acc32[i][0] + acc32[i][15];
   if (r == 12345.678f) sink[0] = r;
 }
 
 static const char *role_name(int r) {
-  static const char *n[] = {"-", "M", "V", "I1", "I2", "I3", "I4", "I5", "P"};
+  static const char *n[] = {"-", "M", "V", "I1", "I2", "I3", "I4", "I5", "P", "P32", "M32"};
   return n[r];
 }
 static void per_unit(int r, int &mfma, int &valu) {
@@ -165,6 +190,8 @@ static void per_unit(int r, int &mfma, int &valu) {
     case R_I4: mfma = 8, valu = 32; break;
     case R_I5: mfma = 8, valu = 40; break;
     case R_P: mfma = 54, valu = 268; break;
+    case R_P32: mfma = 108, valu = 4 * 268; break;  // per 1024 pairs (R_P: per 256)
+    case R_M32: mfma = 8, valu = 0; break;
     default: mfma = valu = 0;
   }
 }
@@ -183,7 +210,7 @@ int main() {
       {R_I1},          {R_I2},          {R_I3},           {R_I4},                {R_I5},
       {R_I2, R_I2},    {R_I4, R_I4},    {R_I5, R_I5},     {R_I5, R_I5, R_I5},    {R_I2, R_V},
       {R_I2, R_V, R_V}, {R_P},          {R_P, R_P},       {R_P, R_P, R_P},       {R_P, R_P, R_P, R_P},
-      {R_I5, R_I5, R_I5, R_I5}};
+      {R_I5, R_I5, R_I5, R_I5}, {R_M32}, {R_M32, R_M32}, {R_M32, R_V}, {R_P32}, {R_P32, R_P32}, {R_P32, R_P32, R_P32}};
   printf("config | per SIMD: cycles per MFMA (all waves), cycles per v_fma_f32 (all waves) | matrix pipe busy (16/MFMA), issue sum (8/MFMA + 4/VALU; 2/VALU)\n");
   for (const auto &c : configs) {
     Config cfg;
