@@ -372,7 +372,10 @@ def start_extras_guard(emit, rank, headline, seconds):
 def rank_env(base, rank, world, idfile):
     """Environment of rank `rank` of a self-spawned launch (what an external launcher would set)."""
     env = dict(base)
-    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), FC_COMM_ID_FILE=idfile,
+    # FC_BENCH_SAME_DEVICE=1 (rehearsal on a one-GPU box): every rank on device 0 -- the launch, the rendezvous and
+    # ncclCommInitRank run for real, RCCL refuses the duplicate device, the ranks go on without a communicator
+    local = "0" if base.get("FC_BENCH_SAME_DEVICE") == "1" else str(rank)
+    env.update(RANK=str(rank), LOCAL_RANK=local, WORLD_SIZE=str(world), FC_COMM_ID_FILE=idfile,
                FC_BENCH_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.pop("FC_BENCH_FORCE_SPAWN", None)

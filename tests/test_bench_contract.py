@@ -136,6 +136,17 @@ def test_bench_two_ranks_on_one_device_agree_through_files(tmp_path):
     assert not list(tmp_path.glob("two.id.rv.*"))  # the rendezvous cleaned up after itself
 
 
+@pytest.mark.gpu
+def test_bench_gpus_3_as_typed_on_one_device():
+    """`python bench.py --gpus 3` as the driver types it, rehearsed on one device (FC_BENCH_SAME_DEVICE=1): the parent starts
+    three rank processes, relays rank 0's single line, exits 0; the ranks agree through files (RCCL refuses a duplicate device)"""
+    d = _run({"FC_BENCH_SAME_DEVICE": "1", "FC_COMM_TIMEOUT_S": "120"},
+             ["--gpus", "3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
+    assert d["n_gpus"] == 3 and d["ranks_seen"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["n_conformers"] == 17321 and 0 < d["efficiency"] < 1.2
+    assert "scaling_family_n1" in d and d["rank_coordination"].startswith("barrier / max over ranks through files")
+
+
 def test_host_rendezvous_three_processes(tmp_path):
     """firecode_amd.dist.HostRendezvous: all-gather / max / barrier between three processes, files removed at the end"""
     code = (
