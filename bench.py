@@ -404,6 +404,8 @@ def main():
         spawn_ranks(args.gpus)
         return
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL, before the HSA runtime starts
+    if os.environ.get("FC_BENCH_SAME_DEVICE") == "1":  # rehearsal of a launcher's N ranks on a one-GPU box (see rank_env)
+        os.environ["LOCAL_RANK"] = "0"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world  # under a launcher the launch decides
     workload = args.workload if args.workload != "auto" else "cfg2"

@@ -26,7 +26,7 @@ cp $S/bench_spawned_1rank.json $D/r03_bench_spawned_1rank.json
 cp $S/bench_forced_sharded_1rank.json $D/r03_bench_forced_sharded_1rank.json
 cp $S/bench_cfg4_n1.json $D/r03_bench_cfg4_family_n1.json
 cp $S/bench_cfg5_n1.json $D/r03_bench_cfg5_family_n1.json
-for f in cfg3_runs.json cfg3_runs_host_grid.json issue_model_f16mfma_valu.txt issue_model_f16mfma_valu_vop2.txt issue_model_f16mfma_valu_pk.txt two_ranks_one_device.txt two_ranks_one_device_rank0.json prune_step_timeline.txt; do
+for f in cfg3_runs.json cfg3_runs_host_grid.json issue_model_f16mfma_valu.txt issue_model_f16mfma_valu_vop2.txt issue_model_f16mfma_valu_pk.txt two_ranks_one_device.txt two_ranks_one_device_rank0.json prune_step_timeline.txt torchrun_2ranks_one_device.json; do
   [ -f $S/$f ] && cp $S/$f $D/r03_$f
 done
 ls -la $D | grep r03_ | wc -l

@@ -61,6 +61,8 @@ extra)
   say "two bench ranks on one device (id file rendezvous, ncclCommInitRank, file fallback)"
   timeout -k 10 400 bash tools/two_ranks_one_device.sh --no-extras > $O/two_ranks_one_device.txt 2>&1
   cp gpurun_out/two_r0.out $O/two_ranks_one_device_rank0.json 2>/dev/null
+  say "the driver's launch form, two ranks on one device"
+  FC_BENCH_SAME_DEVICE=1 FC_COMM_TIMEOUT_S=120 timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/torchrun_2ranks_one_device.json 2> $O/torchrun_2ranks_one_device.err
   say "timeline of steady-state prune steps"
   rocprofv3 --kernel-trace -d $O/prof_timeline --output-format csv -- python3 tools/prune_probe.py 10000 50 2 100 > $O/timeline_probe.json 2> $O/timeline.err
   python3 tools/step_timeline.py $(find $O/prof_timeline -name "*kernel_trace.csv" | head -1) 60 3 > $O/prune_step_timeline.txt 2>&1
