@@ -2202,6 +2202,7 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   int64_t M = 0;
   FC_TRY(d2h(&M, dcount.p, sizeof(int64_t)));
   FC_TRY(sync());  // (the scan is complete here)
+  lap("scan done, rows selected");
   const int64_t N = M + 1, Npad = ceil_div(N, 64) * 64;
   FC_TRY(dtf0.reserve((size_t)Q * sizeof(double)));
   FC_TRY(launch_torsion_fingerprint(db.as<double>(), 1, A, dq.as<int64_t>(), Q, dtf0.as<double>()));
@@ -2216,17 +2217,21 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
     FC_TRY(side_streams());
     FC_TRY(d2h_staged(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t), ctx().s_lane[0]));
   }
+  lap("first match enqueued, counts down");
   std::vector<int64_t> fm((size_t)N);
   FC_TRY(d2h(fm.data(), dfm.p, (size_t)N * sizeof(int64_t)));
   FC_TRY(sync());
+  lap("first match down");
   std::vector<uint8_t> mask((size_t)N);
   FC_TRY(tfd_ladder_from_first_match(fm.data(), N, mask.data(), dfm.as<int64_t>()));
+  lap("ladder");
   std::memset(tfd_keep_out, 0, (size_t)S + 1);
   tfd_keep_out[0] = mask[0];
   int64_t k = 0;  // row k + 1 of the TFD problem = the k-th angle-set that rotated a bond
   for (int64_t sidx = 0; sidx < S; ++sidx)
     if (rotated_bonds_out[sidx] != 0) tfd_keep_out[1 + sidx] = mask[(size_t)++k];
   if (k != M) return set_error(FC_E_HIP, "internal: device selection (%lld rows) and scan counts (%lld) disagree", (long long)M, (long long)k);
+  lap("keep mask assembled");
   return FC_OK;
 }
 
