@@ -708,7 +708,8 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
   if (const char *v = getenv("FC_TFD_GPU")) use_gpu = use_gpu && atoi(v) != 0;  // 0: everything on the host (A/B, tests)
   bool gpu_components = true;  // FC_TFD_GPU_COMPONENTS=0: the component phase on host threads, from the device's graphs
   if (const char *v = getenv("FC_TFD_GPU_COMPONENTS")) gpu_components = atoi(v) != 0;
-  int64_t gpu_chunk_min = 300;  // (1000 .. 30 measured at 1.7 M structures: 300 is where the host threads and the device finish together)
+  int64_t gpu_chunk_min = 150;  // (1000 .. 30 measured at 1.7 M structures: where the host threads and the device finish together -- 300 before the
+                                // wave-per-component kernel, 150 since)
   if (const char *v = getenv("FC_TFD_GPU_CHUNK_MIN")) gpu_chunk_min = std::max<int64_t>(2, std::strtoll(v, nullptr, 10));
   for (int li = 0; li < (int)(sizeof(kl) / sizeof(kl[0])); ++li) {
     const int64_t k = (int64_t)kl[li];
@@ -802,7 +803,7 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
       while (true) {
         const size_t q = next_level.fetch_add(1);
         if (q >= gpu_levels.size()) break;
-        const int li = gpu_levels[q];
+        const int li = gpu_levels[gpu_levels.size() - 1 - q];  // coarsest first: they take longest (largest components), the quick fine levels fill the end
         const auto t_g = std::chrono::steady_clock::now();
         uint8_t *flags = level_rej[li].data();
         const int rc = tfd_level_graph_device(fm_dev, N, (int64_t)kl[li], g, gpu_components ? flags : nullptr);
