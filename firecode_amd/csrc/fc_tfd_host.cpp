@@ -673,7 +673,7 @@ int tfd_level_streams(int n) {
 // (One level after the other, threads over the chunks of a level: 0.32 s at 1.7 M structures, of which the
 // levels k <= 20 with their few huge chunks took 0.24 s on one to five threads.)
 // fm_dev (may be nullptr): the same array on the device -- the chunk graphs of the coarse levels (chunks of at least
-// kGpuChunkMin structures) are then built there (fc_tfd_gpu.hip) while the host threads work on the fine levels.
+// gpu_chunk_min structures) are then built there (fc_tfd_gpu.hip), several levels at a time, while the host threads work on the fine levels.
 int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out, const int64_t *fm_dev) {
   static const double kl[] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};
   std::memset(mask_out, 1, (size_t)N);
