@@ -1497,7 +1497,7 @@ __global__ void k_screen_density_verdict(unsigned long long *__restrict__ counte
 // costs three f16 products instead of one f32 product at a sixteenth of the rate each: 54 instructions
 // of 16 cycles per 16 x 16 pairs and 64 atoms against 117 of 32 cycles for the f32 kernel (50 atoms).
 // What is left is the polynomial epilogue, which is the same (kabsch_may_be_below_f32 on the fp32
-// accumulators, proven bounds: kabsch_h2_bounds), as are the tiling, the item table, the staging
+// accumulators, bounds: kabsch_h2_bounds), as are the tiling, the item table, the staging
 // queues and the outputs.  The screen stays a FILTER: what it lets through is decided by the fp64 refine.
 //   * operands: Xh, halfs in the instruction's own operand layout -- run q = ((s*2 + part)*3 + c)*4 + kq
 //     holds for every conformer n the 8 halfs of atoms s*32 + kq*8 + 0..7 (part 0 = hi, 1 = lo) of
@@ -1510,9 +1510,10 @@ __global__ void k_screen_density_verdict(unsigned long long *__restrict__ counte
 //     last MFMA of this one;
 //   * order of accumulation: the cross terms of ALL k-steps first (their sum is <= 2^-10 s, what the
 //     matrix pipe does to it is far below the bound), then the hi hi^T terms -- KS2 instructions whose
-//     accumulator is of the order of the result (tools/ubench_mfma_f16_numerics.hip: the instruction
-//     aligns its 32 products and C to the largest, keeps 1 to 3 bits below that one's last place,
-//     truncates the rest and rounds the sum to nearest: <= 36 u (|C| + sum |a b|) per instruction);
+//     accumulator is of the order of the result.  Charged per instruction: 66 u (|C| + sum |a b|), a bound that holds
+//     for ANY order of the 33 additions (kabsch_h2_entry_bound, fc_kabsch_math.h); what the instruction is observed to do
+//     (tools/ubench_mfma_f16_numerics.hip: products and C aligned to the largest, 1 to 3 bits kept below that one's
+//     last place, the rest truncated, one rounding: <= 5.4 u seen) is only a tripwire at 18 u (fc_h2_check.hip);
 //   * the accumulators hold 2^2e B: G and the threshold are scaled by 2^2e (exact), the polynomial test
 //     is homogeneous.
 // KS2 = k-steps of 32 atoms (template: everything unrolled, operand arrays in registers).
