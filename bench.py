@@ -305,12 +305,11 @@ def spawn_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=rank_env(os.environ, r, n, idfile),
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    line, failed = b"", None
+    line, failed, open_out = b"", None, True
     try:
         import selectors
         sel = selectors.DefaultSelector()
         sel.register(procs[0].stdout, selectors.EVENT_READ)
-        open_out = True
         while True:
             if open_out and sel.select(timeout=0.2):
                 chunk = os.read(procs[0].stdout.fileno(), 1 << 16)
@@ -341,11 +340,20 @@ def spawn_ranks(n):
             os.remove(idfile)
         except OSError:
             pass
+    if failed is not None and open_out:  # whatever rank 0 had already printed survives a failing rank
+        try:
+            while True:
+                chunk = os.read(procs[0].stdout.fileno(), 1 << 16)
+                if not chunk:
+                    break
+                line += chunk
+        except OSError:
+            pass
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
     if failed is not None:
         sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}\n")
         sys.exit(failed[1] if 0 < failed[1] < 256 else 1)
-    sys.stdout.write(line.decode())
-    sys.stdout.flush()
 
 
 def start_extras_guard(emit, rank, headline, seconds):
@@ -361,7 +369,7 @@ def start_extras_guard(emit, rank, headline, seconds):
             emit(d)
         sys.stderr.write(f"bench.py: rank {rank}: extra blocks timed out after {seconds} s\n")
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(4)  # a hang is a failure: the launcher sees it, the line (with extras_error) is already out
 
     t = threading.Timer(seconds, fire)
     t.daemon = True
@@ -503,6 +511,8 @@ def main():
         _lib.comm_destroy()
     if rv is not None:
         rv.close()
+    if ctx.get("value_check_failed"):
+        sys.exit(3)  # the line is out (with value_check.ok false); a wrong number must not look like a measurement
 
 
 # ----------------------------------------------------------------------------------------------
@@ -523,6 +533,40 @@ def complete_roofline(kernel_ms, owned_pairs, n_conf, n_atoms, world):
                                 + ("" if world == 1 else "; rank 0's launches")}
 
 
+def value_check_pairs(n_conf, rank, world, fdist, n_pairs=2048, seed=1234):
+    """Pairs (i < j) of the rows THIS rank owns (row blocks of 128 in snake order): random ones, plus the corners of the
+    launch -- first / last owned rows, both sides of 16- / 128-row boundaries, the last (partial) column tile, the tip of
+    the triangle where the item table ends in half-row-block items."""
+    rng = np.random.default_rng(seed + rank)
+    rows = np.flatnonzero(fdist.owner_of_rows(n_conf, world, 128) == rank)
+    rows = rows[rows < n_conf - 1]
+    i = rng.choice(rows, n_pairs - 448)
+    j = rng.integers(i + 1, n_conf)
+    corner_rows = np.concatenate([rows[:16], rows[-16:], rows[(rows % 128 == 0) | (rows % 128 == 127)][:32],
+                                  rows[rows >= n_conf - 3000][::max(1, len(rows[rows >= n_conf - 3000]) // 48)][:48]])
+    ci = rng.choice(corner_rows, 448)
+    cj = np.where(rng.random(448) < 0.3, np.maximum(ci + 1, n_conf - 1 - rng.integers(0, 16, 448)),
+                  np.minimum(ci + 1 + rng.integers(0, 130, 448), n_conf - 1))
+    return np.concatenate([i, ci]).astype(np.int64), np.concatenate([j, cj]).astype(np.int64)
+
+
+def value_check(coords, iu, ju, r, d, tol=1e-10):
+    """The sampled elements of the last timed pass's outputs against the oracle's rmsd_and_max (the checker, after the
+    clock has stopped): rmsd within 1e-10; max deviation within 1e-10 + the pair's conditioning bound."""
+    from oracle import cpu_ref as o
+
+    r0, d0 = o.rmsd_and_max_batch(coords[iu], coords[ju], center=True)
+    bound = o.rotation_error_bound_batch(coords[iu], coords[ju], center=True)
+    err_r, err_d = np.abs(r - r0), np.abs(d - d0)
+    ok = bool(np.all(np.isfinite(r)) and np.all(np.isfinite(d)) and err_r.max() < tol and np.all(err_d <= tol + bound))
+    return {"pairs": int(len(iu)), "max_abs_err_rmsd": float(err_r.max()), "max_abs_err_maxdev": float(err_d.max()),
+            "tolerance": tol, "largest_conditioning_allowance": float(bound.max()), "ok": ok,
+            "what": "elements of the two (N, N) outputs as the LAST timed pass left them (fc_bench_rmsd_and_max_all_sampled: "
+                    "gathered on the device behind that pass, inside the timed region) against oracle.rmsd_and_max_batch "
+                    "(firecode/utils.py:494-504), compared after the clock stopped; rows owned by this rank incl. first / last "
+                    "rows, 16- / 128-row boundaries, the last column tile and the half-item tail of the item table"}
+
+
 def run_alignments(ctx):
     args, fc, _lib, syn = ctx["args"], ctx["fc"], ctx["_lib"], ctx["syn"]
     rank, world, barrier, max_over_ranks = ctx["rank"], ctx["world"], ctx["barrier"], ctx["max_over_ranks"]
@@ -537,27 +581,38 @@ def run_alignments(ctx):
     ens = fc.DeviceEnsemble(coords, center=True)  # resident in HBM from here on
     pairs_total = n_conf * (n_conf - 1) // 2
 
-    def run(n):
+    chk_i, chk_j = value_check_pairs(n_conf, rank, world, ctx["fdist"])
+    sampled = [None, None]
+
+    def run(n, sample=False):
         k = t = 0.0
         st = None
         done = 0
         while done < n:
             m = min(1024, n - done)
-            km, tm, st = ens.bench_rmsd_and_max_all(m)
+            if sample and done + m == n:  # the last batch: its last pass's outputs are read back at the sampled pairs
+                km, tm, st, sampled[0], sampled[1] = ens.bench_rmsd_and_max_all_sampled(chk_i, chk_j, m)
+            else:
+                km, tm, st = ens.bench_rmsd_and_max_all(m)
             k += km * m
             t += tm
             done += m
         return k / n, t, st
 
-    run(2)  # output matrices, item table, event pool: outside the timed region whatever W is
+    run(2, sample=True)  # output matrices, item table, event pool, sample buffers: outside the timed region whatever W is
     if warmup:
         run(warmup)
     barrier()
     t0 = time.perf_counter()
-    k_ms, dev_ms, st = run(steps)
+    k_ms, dev_ms, st = run(steps, sample=True)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     owned = int(st[0])
+    check = value_check(coords, chk_i, chk_j, sampled[0], sampled[1])
+    ranks_failed = int(round(max_over_ranks(0.0 if check["ok"] else 1.0)))
+    if not check["ok"]:
+        sys.stderr.write(f"bench.py: rank {rank}: value_check FAILED: {json.dumps(check)}\n")
+    ctx["value_check_failed"] = bool(ranks_failed)
 
     out = None
     if rank == 0:
@@ -585,6 +640,7 @@ def run_alignments(ctx):
                        "host_sync": "once per batch of <= 1024 stream-ordered steps",
                        "device_ms_per_step": dev_ms / steps},
             "fixup_pairs_last_step": int(st[1]),
+            "value_check": dict(check, all_ranks_ok=not ranks_failed),
         }
         out["roofline"] = complete_roofline(k_ms, owned, n_conf, n_atoms, world)
         bytes_per_alignment = 2 * n_atoms * 24 + 16

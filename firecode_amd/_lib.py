@@ -62,6 +62,7 @@ _SIGNATURES = {
     "fc_ensemble_rmsd_values": [_ens, _p_f64, _p_f64],
     "fc_ensemble_rmsd_and_max_all": [_ens, _p_f64, _p_f64, _p_f64],
     "fc_bench_rmsd_and_max_all": [_ens, _i64, _p_f64, _p_f64, _p_i64],
+    "fc_bench_rmsd_and_max_all_sampled": [_ens, _i64, _p_i64, _p_i64, _i64, _p_f64, _p_f64, _p_f64, _p_f64, _p_i64],
     "fc_bench_refine": [_ens, _f64, _f64, _i64, _p_f64, _p_i64],
     "fc_screen_select": [C.c_int],
     "fc_prune_conventions": [C.c_int],
@@ -448,6 +449,18 @@ class DeviceEnsemble:
         stats = np.zeros(3, dtype=np.int64)
         call("fc_bench_rmsd_and_max_all", self.handle, int(reps), C.byref(k), C.byref(t), pi(stats))
         return k.value, t.value, stats
+
+    def bench_rmsd_and_max_all_sampled(self, pair_i, pair_j, reps=1):
+        """``bench_rmsd_and_max_all`` + the elements (pair_i, pair_j) of the last pass's two output matrices
+        -> (mean kernel ms, total ms, stats, rmsd (P,), maxdev (P,))."""
+        pi_, pj_ = i64(pair_i), i64(pair_j)
+        P = int(pi_.shape[0])
+        r, m = np.empty(P), np.empty(P)
+        k, t = C.c_double(0), C.c_double(0)
+        stats = np.zeros(3, dtype=np.int64)
+        call("fc_bench_rmsd_and_max_all_sampled", self.handle, int(reps), pi(pi_), pi(pj_), P, pf(r), pf(m),
+             C.byref(k), C.byref(t), pi(stats))
+        return k.value, t.value, stats, r, m
 
     def simbits(self, max_rmsd, max_dev, energies=None, max_dE=0.0, row_begin=0, row_end=None):
         row_end = self.N if row_end is None else int(row_end)

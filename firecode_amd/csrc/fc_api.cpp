@@ -20,6 +20,8 @@ int launch_pairs_exact(const fc_ensemble *, const int64_t *, const int64_t *, in
                        double *, double *);
 int launch_matrix_exact(const fc_ensemble *, double *, double *);
 int launch_rmsd_values(fc_ensemble *, double, double *, double *, int64_t rank = 0, int64_t world = 1);
+int launch_gather_matrix_pairs(const double *, const double *, int64_t, const int64_t *, const int64_t *, int64_t,
+                               double *, double *);
 void screen_select(int);
 int launch_simbits_screen(fc_ensemble *, double);
 int ensure_h2_operands(fc_ensemble *, double *);
@@ -961,8 +963,10 @@ static int rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_o
 // ms_kernel_mean: HIP events around the dominant kernel (k_simbits_screen_mfma<., 2>) of every launch;
 // ms_total: first launch to the end of the last fix-up kernel.  stats[0] = pairs per pass,
 // stats[1] = pairs the last pass queued for the Jacobi fix-up, stats[2] = 1 when the tiled kernel ran.
+// sample_*: P elements (i, j) of the LAST pass's two output matrices, read back for the caller's checker
 static int bench_rmsd_and_max_all(fc_ensemble *ens, int64_t reps, double *ms_kernel_mean, double *ms_total,
-                                  int64_t *stats) {
+                                  int64_t *stats, const int64_t *sample_i = nullptr, const int64_t *sample_j = nullptr,
+                                  int64_t P = 0, double *sample_rmsd = nullptr, double *sample_maxdev = nullptr) {
   FC_TRY(ensure_init());
   const int64_t N = ens->N;
   FC_REQUIRE(N >= 2, "needs at least two conformers");
@@ -1024,6 +1028,18 @@ static int bench_rmsd_and_max_all(fc_ensemble *ens, int64_t reps, double *ms_ker
   }
   if (tiled && cnt[6] > (unsigned long long)ens->pairq_cap)
     return set_error(FC_E_LIMIT, "%llu degenerate pairs exceed the fix-up queue (%lld)", cnt[6], (long long)ens->pairq_cap);
+  if (P > 0) {  // behind the timed passes and their events: what the last pass left in the two matrices
+    DevBuf di, dj, sr, sm;
+    FC_TRY(upload(di, sample_i, (size_t)P));
+    FC_TRY(upload(dj, sample_j, (size_t)P));
+    FC_TRY(sr.reserve((size_t)P * sizeof(double)));
+    FC_TRY(sm.reserve((size_t)P * sizeof(double)));
+    FC_TRY(launch_gather_matrix_pairs(dr.as<double>(), dm.as<double>(), N, di.as<int64_t>(), dj.as<int64_t>(), P,
+                                      sr.as<double>(), sm.as<double>()));
+    FC_TRY(d2h(sample_rmsd, sr.p, (size_t)P * sizeof(double)));
+    FC_TRY(d2h(sample_maxdev, sm.p, (size_t)P * sizeof(double)));
+    FC_TRY(sync());
+  }
   return FC_OK;
 }
 
@@ -1044,6 +1060,18 @@ int fc_bench_rmsd_and_max_all(fc_ensemble *ens, int64_t reps, double *ms_kernel_
   FC_API_LOCK;
   FC_REQUIRE(ens != nullptr && reps >= 1 && reps <= 4096, "bad arguments");
   return bench_rmsd_and_max_all(ens, reps, ms_kernel_mean, ms_total, stats);
+}
+
+int fc_bench_rmsd_and_max_all_sampled(fc_ensemble *ens, int64_t reps, const int64_t *pair_i, const int64_t *pair_j,
+                                      int64_t P, double *rmsd_out, double *maxdev_out, double *ms_kernel_mean,
+                                      double *ms_total, int64_t *stats) {
+  FC_API_LOCK;
+  FC_REQUIRE(ens != nullptr && reps >= 1 && reps <= 4096, "bad arguments");
+  FC_REQUIRE(P >= 0 && (P == 0 || (pair_i && pair_j && rmsd_out && maxdev_out)), "NULL sample arrays");
+  for (int64_t p = 0; p < P; ++p)
+    FC_REQUIRE(pair_i[p] >= 0 && pair_i[p] < ens->N && pair_j[p] >= 0 && pair_j[p] < ens->N,
+               "sample pair %lld out of range", (long long)p);
+  return bench_rmsd_and_max_all(ens, reps, ms_kernel_mean, ms_total, stats, pair_i, pair_j, P, rmsd_out, maxdev_out);
 }
 
 int fc_ensemble_rmsd_values(fc_ensemble *ens, double *rmsd_out, double *ms_kernel) {
@@ -2229,7 +2257,13 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   tfd_keep_out[0] = mask[0];
   int64_t k = 0;  // row k + 1 of the TFD problem = the k-th angle-set that rotated a bond
   for (int64_t sidx = 0; sidx < S; ++sidx)
-    if (rotated_bonds_out[sidx] != 0) tfd_keep_out[1 + sidx] = mask[(size_t)++k];
+    if (rotated_bonds_out[sidx] != 0) {
+      if (k >= M) {  // (mask has M + 1 entries: never index past it, report below)
+        ++k;
+        break;
+      }
+      tfd_keep_out[1 + sidx] = mask[(size_t)++k];
+    }
   if (k != M) return set_error(FC_E_HIP, "internal: device selection (%lld rows) and scan counts (%lld) disagree", (long long)M, (long long)k);
   lap("keep mask assembled");
   return FC_OK;
@@ -2358,6 +2392,7 @@ int fc_tfd_ladder_from_first_match(const int64_t *first_match, int64_t N, uint8_
   DevBuf dfm;
   const int64_t *fm_dev = nullptr;
   if (ctx().ready && N >= 131072) {
+    FC_TRY(ensure_init());  // (the calling thread's current device: HIP keeps it per thread)
     FC_TRY(upload(dfm, first_match, (size_t)N));
     fm_dev = dfm.as<int64_t>();
   }

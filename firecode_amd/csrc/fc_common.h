@@ -202,9 +202,7 @@ struct ArenaScope {  // declare BEFORE the buffers that are to come from it (des
     active = true;
     return FC_OK;
   }
-  ~ArenaScope() {
-    if (active) thread_arena() = prev;
-  }
+  ~ArenaScope();  // (below cur_stream())
 };
 
 // The stream a helper thread enqueues on (nullptr: the context's).  Set only by code that runs several independent
@@ -217,6 +215,14 @@ inline hipStream_t &thread_stream_override() {
 inline hipStream_t cur_stream() {
   hipStream_t s = thread_stream_override();
   return s ? s : ctx().stream;
+}
+// Jobs run side by side on streams of their own (the TFD ladder's levels), so "the next taker of this block is ordered
+// behind me on the one stream" no longer holds: the block goes back to the pool only when everything the owning
+// thread enqueued has finished -- also on the early-return (error) paths, where kernels may still be writing to it.
+inline ArenaScope::~ArenaScope() {
+  if (!active) return;
+  thread_arena() = prev;
+  if (ctx().ready) (void)hipStreamSynchronize(cur_stream());
 }
 
 // Host <-> device copies.  A copy of kStagedCopyMin bytes or more from or to PAGEABLE host memory goes through pinned

@@ -2707,6 +2707,29 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
   return check_launch("k_rmsd_fix_small");
 }
 
+// elements (i, j) of the two dense (N, N) outputs of the complete-alignment pass, for the checkers
+// (bench value_check, full-size parity tests): the kernel writes the upper triangle + diagonal only,
+// so (i, j) with i > j reads (j, i)
+__global__ void __launch_bounds__(256)
+k_gather_matrix_pairs(const double *__restrict__ rmsd_m, const double *__restrict__ maxdev_m, int64_t N,
+                      const int64_t *__restrict__ pi, const int64_t *__restrict__ pj, int64_t P,
+                      double *__restrict__ rmsd_out, double *__restrict__ maxdev_out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int64_t i = pi[p], j = pj[p];
+  if (i > j) { const int64_t t = i; i = j; j = t; }
+  rmsd_out[p] = rmsd_m[i * N + j];
+  maxdev_out[p] = maxdev_m[i * N + j];
+}
+
+int launch_gather_matrix_pairs(const double *rmsd_m, const double *maxdev_m, int64_t N, const int64_t *pi_dev,
+                               const int64_t *pj_dev, int64_t P, double *rmsd_out, double *maxdev_out) {
+  if (P == 0) return FC_OK;
+  hipLaunchKernelGGL(k_gather_matrix_pairs, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, ctx().stream, rmsd_m,
+                     maxdev_m, N, pi_dev, pj_dev, P, rmsd_out, maxdev_out);
+  return check_launch("k_gather_matrix_pairs");
+}
+
 int launch_scatter_pairs(const uint64_t *pairs_dev, int64_t n_pairs, int64_t N, int64_t W,
                          uint64_t *bits_dev) {
   if (n_pairs == 0) return FC_OK;

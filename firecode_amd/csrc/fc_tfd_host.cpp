@@ -28,9 +28,37 @@
 #include <thread>
 #include <vector>
 
+#include <new>
+#include <system_error>
+
 #include "fc_common.h"
 
 namespace fc {
+
+// Helper threads of this file.  Two rules, both about std::terminate (= SIGABRT in the caller's process): a
+// std::thread that is still joinable when it is destroyed ends the process -- so the threads live in a holder whose
+// destructor joins, whatever way its scope is left -- and so does an exception that leaves a thread's function -- so
+// every thread body catches everything and reports through a flag of its pool.
+struct ThreadJoiner {
+  std::vector<std::thread> threads;
+  template <class F, class... Args>
+  bool start(F &&f, Args &&...args) {  // false: the system has no thread to give (the caller's own thread does the work)
+    try {
+      threads.emplace_back(std::forward<F>(f), std::forward<Args>(args)...);
+      return true;
+    } catch (const std::system_error &) {
+      return false;
+    } catch (const std::bad_alloc &) {
+      return false;
+    }
+  }
+  void join_all() {
+    for (auto &t : threads)
+      if (t.joinable()) t.join();
+    threads.clear();
+  }
+  ~ThreadJoiner() { join_all(); }
+};
 
 // ---- CPython set emulation ---------------------------------------------------
 struct PySetEmu {
@@ -440,21 +468,29 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
       if (parent[(size_t)v] == (int32_t)v) sources.push_back((int32_t)v);
     lap("union-find");
     std::atomic<size_t> next_src{0};
+    std::atomic<bool> failed{false};
     std::vector<std::vector<int64_t>> rej_t(comp_threads);
     auto helper = [&](unsigned t) {
-      CompScratch cs;
-      constexpr size_t kBatch = 256;  // sources per grab
-      while (true) {
-        const size_t b0 = next_src.fetch_add(kBatch);
-        if (b0 >= sources.size()) break;
-        const size_t b1 = std::min(sources.size(), b0 + kBatch);
-        for (size_t i = b0; i < b1; ++i) one_component((int64_t)sources[i], cs, rej_t[t]);
+      try {
+        CompScratch cs;
+        constexpr size_t kBatch = 256;  // sources per grab
+        while (!failed.load(std::memory_order_relaxed)) {
+          const size_t b0 = next_src.fetch_add(kBatch);
+          if (b0 >= sources.size()) break;
+          const size_t b1 = std::min(sources.size(), b0 + kBatch);
+          for (size_t i = b0; i < b1; ++i) one_component((int64_t)sources[i], cs, rej_t[t]);
+        }
+      } catch (...) {
+        failed = true;
       }
     };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < comp_threads; ++t) pool.emplace_back(helper, t);
-    helper(0);
-    for (auto &th : pool) th.join();
+    {
+      ThreadJoiner pool;
+      for (unsigned t = 1; t < comp_threads; ++t)
+        if (!pool.start(helper, t)) break;
+      helper(0);
+    }
+    if (failed.load()) throw std::bad_alloc();
     for (auto &r : rej_t) rejects.insert(rejects.end(), r.begin(), r.end());
   } else {
     CompScratch cs;
@@ -580,27 +616,32 @@ static void level_rejects_from_graph(const TfdLevelGraph &g, unsigned threads, u
   }
   std::atomic<size_t> next{0};
   std::atomic<int64_t> searched{0};
+  std::atomic<bool> failed{false};
   auto worker = [&]() {
-    GraphCompScratch cs;
-    while (true) {
-      const size_t q = next.fetch_add(1);
-      if (q >= jobs.size()) break;
-      const Job &jb = jobs[q];
-      const int64_t chunk_nodes = g.nbase[(size_t)jb.chunk + 1] - g.nbase[(size_t)jb.chunk];
-      uint8_t *flags = level_flags + (int64_t)jb.chunk * g.d;
-      for (int64_t j = jb.j0; j < jb.j1; ++j)
-        graph_component(g, g.sources[(size_t)j], g.sources[(size_t)j + 1], chunk_nodes, cs, flags);
+    try {  // (a thread body must not leak an exception: std::terminate)
+      GraphCompScratch cs;
+      while (!failed.load(std::memory_order_relaxed)) {
+        const size_t q = next.fetch_add(1);
+        if (q >= jobs.size()) break;
+        const Job &jb = jobs[q];
+        const int64_t chunk_nodes = g.nbase[(size_t)jb.chunk + 1] - g.nbase[(size_t)jb.chunk];
+        uint8_t *flags = level_flags + (int64_t)jb.chunk * g.d;
+        for (int64_t j = jb.j0; j < jb.j1; ++j)
+          graph_component(g, g.sources[(size_t)j], g.sources[(size_t)j + 1], chunk_nodes, cs, flags);
+      }
+      searched += cs.n_search;
+    } catch (...) {
+      failed = true;
     }
-    searched += cs.n_search;
   };
-  if (threads <= 1 || jobs.size() <= 1) {
+  {
+    ThreadJoiner pool;  // joins on every way out of this scope
+    if (threads > 1 && jobs.size() > 1)
+      for (unsigned t = 1; t < threads; ++t)
+        if (!pool.start(worker)) break;  // (no more threads to be had: the ones that exist share the jobs)
     worker();
-  } else {
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker);
-    worker();
-    for (auto &th : pool) th.join();
   }
+  if (failed.load()) throw std::bad_alloc();  // out of host memory in a helper: the ladder reports FC_E_NOMEM
   if (n_search_out) *n_search_out = searched.load();
 }
 
@@ -674,7 +715,7 @@ int tfd_level_streams(int n) {
 // levels k <= 20 with their few huge chunks took 0.24 s on one to five threads.)
 // fm_dev (may be nullptr): the same array on the device -- the chunk graphs of the coarse levels (chunks of at least
 // gpu_chunk_min structures) are then built there (fc_tfd_gpu.hip), several levels at a time, while the host threads work on the fine levels.
-int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out, const int64_t *fm_dev) {
+static int tfd_ladder_impl(const int64_t *fm, int64_t N, uint8_t *mask_out, const int64_t *fm_dev) {
   static const double kl[] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};
   std::memset(mask_out, 1, (size_t)N);
   unsigned hw = std::thread::hardware_concurrency();
@@ -702,7 +743,7 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
   };
   std::vector<Task> tasks;
   constexpr int kLevels = (int)(sizeof(kl) / sizeof(kl[0]));
-  static std::vector<uint8_t> level_rej[kLevels];  // kept across calls (callers hold the API lock): 17 x N bytes of fresh pages cost ~7 ms at 1.7 M
+  static std::vector<uint8_t> level_rej[kLevels];  // kept across calls (tfd_ladder_from_first_match holds the ladder's own lock): 17 x N bytes of fresh pages cost ~7 ms at 1.7 M
   std::vector<int> gpu_levels;
   bool use_gpu = fm_dev != nullptr;
   if (const char *v = getenv("FC_TFD_GPU")) use_gpu = use_gpu && atoi(v) != 0;  // 0: everything on the host (A/B, tests)
@@ -762,32 +803,44 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
   std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tasks[a].cost > tasks[b].cost; });
   {
     std::atomic<size_t> next{0};
+    std::atomic<bool> host_failed{false};  // a helper ran out of host memory (the only thing its body can throw)
     auto worker = [&]() {
-      ChunkScratch scratch;
-      std::vector<int64_t> rej;
-      while (true) {
-        const size_t q = next.fetch_add(1);
-        if (q >= order.size()) break;
-        const Task &t = tasks[order[q]];
-        rej.clear();
-        if (t.step_begin < 0) {  // the first level's last chunk (one task: no other writes first_last)
-          level_chunks(fm, N, t.k, t.d, N, t.k - 1, t.k, scratch, first_last);
-          continue;
+      try {
+        ChunkScratch scratch;
+        std::vector<int64_t> rej;
+        while (!host_failed.load(std::memory_order_relaxed)) {
+          const size_t q = next.fetch_add(1);
+          if (q >= order.size()) break;
+          const Task &t = tasks[order[q]];
+          rej.clear();
+          if (t.step_begin < 0) {  // the first level's last chunk (one task: no other writes first_last)
+            level_chunks(fm, N, t.k, t.d, N, t.k - 1, t.k, scratch, first_last);
+            continue;
+          }
+          // a non-last chunk never uses num_active: pass N
+          level_chunks(fm, N, t.k, t.d, N, t.step_begin, t.step_end, scratch, rej);
+          uint8_t *flags = level_rej[t.level].data();
+          for (int64_t r : rej) flags[r] = 1;
         }
-        // a non-last chunk never uses num_active: pass N
-        level_chunks(fm, N, t.k, t.d, N, t.step_begin, t.step_end, scratch, rej);
-        uint8_t *flags = level_rej[t.level].data();
-        for (int64_t r : rej) flags[r] = 1;
+      } catch (...) {
+        host_failed = true;
       }
     };
     // (the helpers of the coarse levels wait for the device by polling: leave them a core each)
     const unsigned hw_pool = gpu_levels.empty() ? hw : std::max(1u, hw > (unsigned)n_lvl_streams ? hw - (unsigned)n_lvl_streams : 1u);
     const unsigned nthreads = (N >= 2000 && tasks.size() > 1) ? std::min<size_t>(hw_pool, tasks.size()) : 1;
-    std::vector<std::thread> pool;
-    if (nthreads > 1 || !gpu_levels.empty())
-      for (unsigned t = 0; t < std::max(1u, nthreads); ++t) pool.emplace_back(worker);
-    else
+    // (from here to the end of this block helper threads are running: both holders join in their destructors, so no
+    // return, FC_TRY or exception below can leave a joinable std::thread behind -- that would be std::terminate)
+    ThreadJoiner pool;
+    bool own_worker = !(nthreads > 1 || !gpu_levels.empty());
+    if (!own_worker) {
+      for (unsigned t = 0; t < std::max(1u, nthreads); ++t)
+        if (!pool.start(worker)) break;
+      own_worker = pool.threads.empty();  // not one thread to be had: this thread does the host share itself, below
+    } else {
       worker();
+      own_worker = false;
+    }
     // meanwhile: the coarse levels' graphs from the device.  The levels are independent of each other and each is a
     // chain of ~40 short launches with five host round trips (sizes of the next arrays), so one level at a time leaves
     // the device idle most of the time (4.3-5.2 ms per level, nine levels at 1.7 M structures): kLevelStreams helper
@@ -797,10 +850,33 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
     // kept across calls (their arrays are tens of MB: fresh pages every level cost more than the copies).
     std::atomic<size_t> next_level{0};
     std::mutex err_mu;
+    auto level_fail = [&](int rc, const char *msg) {
+      std::lock_guard<std::mutex> lock(err_mu);
+      if (gpu_rc == FC_OK) gpu_rc = rc, gpu_err = msg;
+    };
+    const int device = ctx().device;
     auto level_worker = [&](int w) {
+     try {
+      // HIP's current device is PER THREAD and a fresh thread starts on device 0: without this a helper of a context on
+      // device d != 0 (every LOCAL_RANK > 0) would take pool blocks, events and pinned pieces on device 0 and launch
+      // on device d's streams over them
+      if (w != 0) {
+        const hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) {
+          level_fail(FC_E_HIP, (std::string("hipSetDevice in a TFD level helper: ") + hipGetErrorString(e)).c_str());
+          return;
+        }
+      }
       thread_stream_override() = lvl_stream[w];
+      struct Restore {
+        ~Restore() { thread_stream_override() = nullptr; }
+      } restore_stream;
       TfdLevelGraph &g = holders[w];
       while (true) {
+        {
+          std::lock_guard<std::mutex> lock(err_mu);
+          if (gpu_rc != FC_OK) break;  // another level failed: no point in starting the next one
+        }
         const size_t q = next_level.fetch_add(1);
         if (q >= gpu_levels.size()) break;
         const int li = gpu_levels[gpu_levels.size() - 1 - q];  // coarsest first: they take longest (largest components), the quick fine levels fill the end
@@ -808,8 +884,7 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
         uint8_t *flags = level_rej[li].data();
         const int rc = tfd_level_graph_device(fm_dev, N, (int64_t)kl[li], g, gpu_components ? flags : nullptr);
         if (rc != FC_OK) {
-          std::lock_guard<std::mutex> lock(err_mu);
-          if (gpu_rc == FC_OK) gpu_rc = rc, gpu_err = last_error();  // (the message is the helper thread's own)
+          level_fail(rc, last_error().c_str());  // (the message is the helper thread's own)
           break;
         }
         const auto t_c = std::chrono::steady_clock::now();
@@ -832,20 +907,31 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
                   (size_t)g.n_components, g.left.size(),
                   gpu_components ? "" : "; component phase on the host");
       }
-      thread_stream_override() = nullptr;
+     } catch (const std::bad_alloc &) {
+      level_fail(FC_E_NOMEM, "out of host memory in a TFD level helper");
+     } catch (...) {
+      level_fail(FC_E_HIP, "unexpected exception in a TFD level helper");
+     }
     };
     {
-      std::vector<std::thread> lvl_pool;
+      ThreadJoiner lvl_pool;
       if (!gpu_levels.empty())
-        for (int w = 1; w < n_lvl_streams; ++w) lvl_pool.emplace_back(level_worker, w);
+        for (int w = 1; w < n_lvl_streams; ++w)
+          if (!lvl_pool.start(level_worker, w)) break;  // (fewer helpers: the levels come from a common counter)
       if (!gpu_levels.empty()) level_worker(0);
-      for (auto &th : lvl_pool) th.join();
+      lvl_pool.join_all();
       if (debug && !gpu_levels.empty())
         fprintf(stderr, "[fc] tfd ladder: %zu coarse levels on %d streams done at %.1f ms\n", gpu_levels.size(), n_lvl_streams,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
     }
-    for (auto &th : pool) th.join();
-    if (gpu_rc != FC_OK) return set_error(gpu_rc, "%s", gpu_err.c_str());
+    if (own_worker) worker();
+    pool.join_all();
+    if (gpu_rc != FC_OK) {
+      // a level that failed half-way may have left kernels on its stream: nothing of this call may outlive it
+      for (int w = 0; w < n_lvl_streams; ++w) (void)hipStreamSynchronize(lvl_stream[w]);
+      return set_error(gpu_rc, "%s", gpu_err.c_str());
+    }
+    if (host_failed.load()) return set_error(FC_E_NOMEM, "out of host memory in the TFD ladder's host threads");
   }
   if (debug)
     fprintf(stderr, "[fc] tfd ladder: %zu speculative tasks on %u threads, %.1f ms\n", tasks.size(), hw,
@@ -900,6 +986,21 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
     fprintf(stderr, "[fc] tfd ladder total %.1f ms\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
   return FC_OK;
+}
+
+// The ladder keeps process-wide state across calls (the per-level flag arrays, the helpers' graph holders and streams):
+// one ladder at a time, under a lock of its own -- not merely "the callers hold the API lock".  No exception crosses
+// the C ABI: whatever the host side throws (std::bad_alloc is the only candidate) becomes an error code.
+int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out, const int64_t *fm_dev) {
+  static std::mutex ladder_mu;
+  std::lock_guard<std::mutex> lock(ladder_mu);
+  try {
+    return tfd_ladder_impl(fm, N, mask_out, fm_dev);
+  } catch (const std::bad_alloc &) {
+    return set_error(FC_E_NOMEM, "out of host memory in the TFD ladder (N = %lld)", (long long)N);
+  } catch (const std::exception &e) {
+    return set_error(FC_E_HIP, "TFD ladder: %s", e.what());
+  }
 }
 
 }  // namespace fc

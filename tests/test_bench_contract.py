@@ -165,7 +165,8 @@ def test_host_rendezvous_three_processes(tmp_path):
 
 
 def test_bench_extras_guard_ends_a_hung_rank_with_the_headline():
-    """the timer around the exchanging extra blocks of an N > 1 run: rank 0 prints the line it holds, the process ends with 0"""
+    """the timer around the exchanging extra blocks of an N > 1 run: rank 0 prints the line it holds, and every
+    rank ends NON-ZERO (a hang must not look like a green run: the launcher relays the line and fails)"""
     code = (
         "import sys, time, json\n"
         f"sys.path.insert(0, {ROOT!r})\n"
@@ -177,7 +178,7 @@ def test_bench_extras_guard_ends_a_hung_rank_with_the_headline():
         "print('not reached')\n")
     for rank, expect_line in ((0, True), (1, False)):
         out = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=20)
-        assert out.returncode == 0 and "not reached" not in out.stdout and "timed out after 1 s" in out.stderr
+        assert out.returncode == 4 and "not reached" not in out.stdout and "timed out after 1 s" in out.stderr
         if expect_line:
             d = json.loads(out.stdout.strip())
             assert d["value"] == 1.5 and "did not finish within 1 s" in d["extras_error"]

@@ -60,6 +60,126 @@ def test_cfg4_shape_80_atoms(fc):
     assert mask.sum() == K and len(np.unique(asg[mask])) == K
 
 
+def _headline_sample_pairs(n, rng, n_random=20000):
+    """Pairs (i < j) that reach every structural corner of the complete-alignment launch: every row of the
+    first and of the last row block (128 rows), rows on both sides of 16-, 64- and 128-row boundaries, columns in
+    the last (partial) column tile and on both sides of 64-column boundaries, the region of the half-row-block
+    items at the end of the item table (the last ~22 row blocks), and uniformly random pairs."""
+    rows = set(range(0, min(128, n - 1))) | set(range(max(0, (n - 1) // 128 * 128 - 2), n - 1))
+    for b in (16, 32, 48, 64, 112, 128, 256, 1024, (n // 256) * 128, (n // 128) * 128 - 128):
+        rows |= {r for r in (b - 2, b - 1, b, b + 1) if 0 <= r < n - 1}
+    for b in rng.integers(1, n // 128, 12):
+        rows |= {r for r in (int(b) * 128 - 1, int(b) * 128, int(b) * 128 + 15, int(b) * 128 + 16, int(b) * 128 + 63,
+                             int(b) * 128 + 64) if 0 <= r < n - 1}
+    iu, ju = [], []
+    last_tile = (n - 1) // 64 * 64
+    for i in sorted(rows):
+        cols = {i + 1, min(i + 2, n - 1), min(i + 3, n - 1), n - 1, n - 2}
+        cols |= {c for c in ((i // 64 + 1) * 64 - 1, (i // 64 + 1) * 64, (i // 16 + 1) * 16 - 1, (i // 16 + 1) * 16,
+                             last_tile - 1, last_tile, last_tile + 1) if i < c < n}
+        cols |= {int(c) for c in rng.integers(i + 1, n, 24)}
+        cols |= {int(c) for c in rng.integers(max(i + 1, last_tile), n, 4)}
+        for c in sorted(cols):
+            if c > i:
+                iu.append(i)
+                ju.append(c)
+    a = rng.integers(0, n, n_random)
+    b = rng.integers(0, n, n_random)
+    keep = a != b
+    iu += list(np.minimum(a, b)[keep])
+    ju += list(np.maximum(a, b)[keep])
+    # the tip of the triangle: the last 2 x 256 items of the launch are half-row-block items there
+    a = rng.integers(max(0, n - 3000), n, 4000)
+    b = rng.integers(max(0, n - 3000), n, 4000)
+    keep = a != b
+    iu += list(np.minimum(a, b)[keep])
+    ju += list(np.maximum(a, b)[keep])
+    return np.array(iu, dtype=np.int64), np.array(ju, dtype=np.int64)
+
+
+def _check_against_oracle(X, iu, ju, r, d):
+    """rmsd at 1e-10; max deviation at 1e-10 + the pair's own conditioning bound (oracle.rotation_error_bound_batch)"""
+    err_r, err_d, slack = 0.0, 0.0, 0.0
+    for k in range(0, len(iu), 8192):
+        sl = slice(k, k + 8192)
+        r0, d0 = o.rmsd_and_max_batch(X[iu[sl]], X[ju[sl]], center=True)
+        bound = o.rotation_error_bound_batch(X[iu[sl]], X[ju[sl]], center=True)
+        assert np.all(np.isfinite(bound))
+        assert np.abs(r[sl] - r0).max() < TOL
+        assert np.all(np.abs(d[sl] - d0) <= TOL + bound)
+        err_r = max(err_r, float(np.abs(r[sl] - r0).max()))
+        err_d = max(err_d, float(np.abs(d[sl] - d0).max()))
+        slack = max(slack, float(bound.max()))
+    return err_r, err_d, slack
+
+
+@pytest.mark.parametrize("n,n_atoms,seed", [(10000, 50, 2), (12010, 80, 4)])
+def test_complete_alignments_full_size_vs_oracle(fc, n, n_atoms, seed):
+    """The bench's `value` kernel at the sizes it is timed at, both variants: k_simbits_screen_mfma<4, 2>
+    (BASELINE configs[1]: 10 000 x 50, two workgroups per CU, half-row-block items at the end of the item table,
+    16 columns in the last column tile) and <8, 2> (A = 80: one workgroup per CU; 12 010 conformers: 58 columns in
+    the last tile, 106 rows in the last row block).  Both (N, N) outputs are downloaded whole: > 28 000 sampled
+    pairs against the oracle's rmsd_and_max (firecode/utils.py:494-504), symmetry, exact-zero diagonal, and
+    nothing outside what the kernel was asked for."""
+    X, atoms, asg = syn.synthetic_ensemble(n, n_atoms, seed=seed)
+    rng = np.random.default_rng(100 + n_atoms)
+    iu, ju = _headline_sample_pairs(n, rng)
+    assert len(iu) > 28000
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        R, D, ms = ens.rmsd_and_max_all()
+        # the bench's entry point (K passes, outputs resident) leaves the same numbers in the same places
+        _, _, st, r_b, d_b = ens.bench_rmsd_and_max_all_sampled(iu, ju, reps=2)
+    assert ms > 0 and int(st[0]) == n * (n - 1) // 2 and int(st[1]) == 0 and int(st[2]) == 1
+    assert np.all(np.diag(R) == 0) and np.all(np.diag(D) == 0)
+    for k in range(0, n, 2000):  # symmetric (the host mirrors the upper triangle), finite, non-negative
+        blk = R[k:k + 2000]
+        assert np.array_equal(blk, R[:, k:k + 2000].T) and np.array_equal(D[k:k + 2000], D[:, k:k + 2000].T)
+        assert np.isfinite(blk).all() and (blk >= 0).all() and np.isfinite(D[k:k + 2000]).all()
+        off = blk[np.arange(blk.shape[0])[:, None] + k != np.arange(n)[None, :]]
+        assert off.min() > 0  # no element left unwritten (a pooled buffer is not zeroed): distinct conformers differ
+        assert (D[k:k + 2000] >= blk * (1 - 1e-12)).all()  # the largest deviation is never below the rms one
+    r, d = R[iu, ju], D[iu, ju]
+    assert np.array_equal(r, r_b) and np.array_equal(d, d_b)
+    _check_against_oracle(X, iu, ju, r, d)
+    # the similarity decision from the two matrices reproduces the cluster structure of the whole ensemble
+    same = asg[:, None] == asg[None, :]
+    for k in range(0, n, 2000):
+        assert np.array_equal((R[k:k + 2000] < 0.5) & (D[k:k + 2000] < 1.0), same[k:k + 2000])
+
+
+@pytest.mark.parametrize("n,n_atoms,seed,worlds", [(10000, 50, 2, (2, 3, 8)), (6000, 80, 4, (2, 3))])
+def test_complete_alignments_logical_ranks_equal_single_gpu(fc, n, n_atoms, seed, worlds):
+    """What `bench.py --gpus N` measures: rank r computes the rows of the row blocks dealt to it in snake order
+    (launch_rmsd_values(..., rank, world)).  Played on one GPU through fc_debug_comm_loopback, every rank's
+    values on the rows it owns equal the single-GPU pass BIT FOR BIT, the owned pair counts add up, and the
+    single-GPU pass equals the oracle on the same samples."""
+    from firecode_amd import _lib
+    from firecode_amd import dist as fdist
+
+    X, atoms, _ = syn.synthetic_ensemble(n, n_atoms, seed=seed)
+    rng = np.random.default_rng(7 + n_atoms)
+    iu, ju = _headline_sample_pairs(n, rng, n_random=12000)
+    try:
+        with fc.DeviceEnsemble(X, center=True) as ens:
+            _, _, st1, r1, d1 = ens.bench_rmsd_and_max_all_sampled(iu, ju, reps=1)
+            assert int(st1[0]) == n * (n - 1) // 2
+            _check_against_oracle(X, iu, ju, r1, d1)
+            for world in worlds:
+                owner = fdist.owner_of_rows(n, world, 128)
+                owned_total, seen = 0, np.zeros(len(iu), dtype=bool)
+                for rk in range(world):
+                    _lib.call("fc_debug_comm_loopback", rk, world)
+                    mine = owner[iu] == rk
+                    _, _, st, r, d = ens.bench_rmsd_and_max_all_sampled(iu[mine], ju[mine], reps=1)
+                    assert np.array_equal(r, r1[mine]) and np.array_equal(d, d1[mine])
+                    assert int(st[0]) == int((n - 1 - np.flatnonzero(owner == rk)).sum()) and int(st[1]) == 0
+                    owned_total += int(st[0])
+                    seen |= mine
+                assert owned_total == n * (n - 1) // 2 and seen.all()
+    finally:
+        _lib.call("fc_debug_comm_loopback", -1, 0)
+
+
 def test_cfg5_full_pose_grid_samples(fc):
     """500 x 500 conformer pairs x 2 x 16 x 16 poses; 1 500 random poses recomputed"""
     n, A = 500, 40

@@ -101,6 +101,59 @@ def test_ladder_mask_is_the_same_with_device_built_chunk_graphs(fc, monkeypatch,
     assert 0 < masks["host"].sum() < n
 
 
+def test_ladder_components_at_and_above_every_device_capacity(fc, monkeypatch):
+    """Directed shapes for every size class of the device's component phase (fc_tfd_gpu.hip) in ONE first-match array:
+    a star with in-degree 1 600 and a chain of 3 000 nodes (above FC_TFD_DEV_COMP_MAX = 1 024: cut out and sent to the
+    host threads), a 401-node component with residue collisions (above the 306-node LDS walk: host list), a 200-node
+    one with collisions (walked by lane 0 out of LDS), a 60-node clean one (residue bitmap), 3- and 4-node components
+    with collisions (register tables), a star that is MORE than half of its chunk at the fine device levels (keeps its
+    earliest node) -- all == the all-host ladder.  (Round 3 saw one abort of an uncommitted tree on the random
+    'stars' shape, stderr not kept: DESIGN.md 5.3.)"""
+    n = 262144
+    rng = np.random.default_rng(11)
+    i = np.arange(n, dtype=np.int64)
+    fm = np.where(rng.random(n) < 0.5, i + rng.integers(1, 30, n), -1).astype(np.int64)
+    fm[fm >= n] = -1
+
+    def clear(lo, hi):
+        fm[lo:hi] = -1
+        back = (fm >= lo) & (fm < hi)
+        fm[back] = -1
+
+    clear(1000, 2700)
+    fm[1000:2600] = 2600                       # star, in-degree 1 600
+    clear(10000, 13100)
+    fm[10000:13000] = np.arange(10001, 13001)  # chain of 3 001 nodes
+    clear(30000, 30000 + 128 * 402)
+    fm[30000:30000 + 128 * 400:128] = 30000 + 128 * 400   # 401 nodes, residues collide modulo 2 048
+    clear(100000, 100000 + 128 * 201)
+    fm[100000:100000 + 128 * 199:128] = 100000 + 128 * 199  # 200 nodes, residues collide modulo 512
+    clear(140000, 140100)
+    fm[140000:140059] = 140059                 # 60 nodes, consecutive: clean
+    clear(150000, 150100)
+    fm[150000] = 150008
+    fm[150008] = 150016                        # 3 nodes, residues 0 modulo 8
+    fm[150040] = 150048
+    fm[150048] = 150056
+    fm[150056] = 150064                        # 4 nodes
+    clear(200000, 200260)
+    fm[200000:200255] = 200255                 # 256 nodes inside one chunk of the k = 1000 level (d = 262): > half
+    assert np.all((fm == -1) | ((fm > i) & (fm < n)))
+    masks = {}
+    for label, env in (("host", {"FC_TFD_GPU": "0"}), ("device", {}), ("device_fine", {"FC_TFD_GPU_CHUNK_MIN": "40"}),
+                       ("device_graphs_host_components", {"FC_TFD_GPU_COMPONENTS": "0"})):
+        for k in ("FC_TFD_GPU", "FC_TFD_GPU_CHUNK_MIN", "FC_TFD_GPU_COMPONENTS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = np.zeros(n, dtype=np.uint8)
+        _lib.call("fc_tfd_ladder_from_first_match", _lib.pi(fm), n, _lib.pb(m))
+        masks[label] = m
+    for label in ("device", "device_fine", "device_graphs_host_components"):
+        assert np.array_equal(masks["host"], masks[label]), label
+    assert 0 < masks["host"].sum() < n
+
+
 def test_ladder_with_many_components_left_to_the_host(fc):
     """FC_TFD_DEV_COMP_MAX is read once per process: a child interpreter with a cap of 48 nodes sends hundreds of
     components per level down to the host threads (the compact copy of JUST those components, k_left_gather) -- same
@@ -130,4 +183,36 @@ def test_ladder_with_many_components_left_to_the_host(fc):
         "print('ok')\n")
     env = dict(os.environ, FC_TFD_DEV_COMP_MAX="48")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_ladder_on_a_device_other_than_zero(fc):
+    """The ladder's helper threads are fresh std::threads: HIP's current device is per thread and starts at 0, so they
+    select the context's device themselves (fc_tfd_host.cpp level_worker).  Needs a second GPU: a child interpreter
+    runs fc.init(1) and a device ladder of 3e5 structures, mask == the all-host ladder."""
+    import os
+    import subprocess
+    import sys
+
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
+        "import numpy as np\n"
+        "import firecode_amd as fc\n"
+        "from firecode_amd import _lib\n"
+        "from test_tfd_gpu_graph import _random_first_match\n"
+        "fc.init(1)\n"
+        "fm = _random_first_match(np.random.default_rng(2), 300000, 'mixed')\n"
+        "out = {}\n"
+        "for label, env in (('host', '0'), ('device', '1')):\n"
+        "    os.environ['FC_TFD_GPU'] = env\n"
+        "    m = np.zeros(len(fm), dtype=np.uint8)\n"
+        "    _lib.call('fc_tfd_ladder_from_first_match', _lib.pi(fm), len(fm), _lib.pb(m))\n"
+        "    out[label] = m\n"
+        "assert np.array_equal(out['host'], out['device'])\n"
+        "print('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
