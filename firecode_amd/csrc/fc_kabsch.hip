@@ -818,27 +818,42 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
             double B9[9], Q4[4];
 #pragma unroll
             for (int e = 0; e < 9; ++e) B9[e] = acc[t][e][r];
-            ok4[r] = kabsch_quaternion_qcp(B9, Gp + Gq_r, Q4);
-            if (!ok4[r]) Q4[0] = 1.0, Q4[1] = 0.0, Q4[2] = 0.0, Q4[3] = 0.0;
+            ok4[r] = kabsch_quaternion_qcp_lean(B9, Gp + Gq_r, Q4);
+            if (!ok4[r]) Q4[0] = 1.0, Q4[1] = 0.0, Q4[2] = 0.0, Q4[3] = 0.0;  // (NaN must not reach the stores: the fix-up overwrites them)
             neg_rotation_from_quaternion(Q4, nR[r]);
           }
           typedef double d2_t __attribute__((ext_vector_type(2)));
           const double *__restrict__ qcol = lds + cs * 32 + 4 * kq;
           const double *__restrict__ prow_u = Xs + ib;
           const unsigned l15u = (unsigned)l15;
-          const int A4 = 4 * KS;  // atoms padded to 4 with zeros: they add nothing
+          // Atoms in rounds of two (ping-pong register sets), two rounds per k-group of four atoms; the zero rows that
+          // pad the atoms to a multiple of 4 for the MFMA k-steps add nothing and are not visited (50 atoms = 25
+          // rounds, not 26).  Addresses: three running scalar pointers for the row conformer's coordinate rows (advanced
+          // by three rows per atom; the lane adds its fixed 32-bit offset) and one LDS pointer per k-group with
+          // compile-time offsets inside it -- the first version recomputed both from the atom index: 26 scalar
+          // instructions per atom beside 56 vector ones, and a wave issues ONE instruction per turn whatever its kind.
+          const int n_rounds = (A + 1) >> 1, n_groups = n_rounds >> 1;
+          const bool odd_round = (n_rounds & 1) != 0;
           double ssq[4] = {0.0, 0.0, 0.0, 0.0}, mx[4] = {0.0, 0.0, 0.0, 0.0};
-          auto load_pq = [&](int a, double (&P)[3], d2_t (&Qv)[3][2]) {
-            const int al = a < A4 ? a : A4 - 1;  // past the end: harmless re-read, never used
-            const double *__restrict__ ql = qcol + (al >> 2) * (12 * TC) + ((al >> 1) & 1) * (2 * TC) + (al & 1) * 16;
-            // wave-uniform base + the lane's 32-bit offset: the address arithmetic stays on the scalar unit
-            const double *__restrict__ pa = prow_u + (int64_t)(al * 3) * Npad;
+          const int64_t Npad3 = 3 * Npad;
+          // wave-uniform: the next atom's three coordinate rows at row ib (scalar base + the lane's 32-bit offset is one
+          // addressing mode of the load; the compiler takes it only when it can see that the offset is small)
+          const double *__restrict__ pa0 = prow_u, *__restrict__ pa1 = prow_u + Npad, *__restrict__ pa2 = prow_u + 2 * Npad;
+          const double *__restrict__ qg = qcol;    // the current k-group of the LDS tile
+          auto load_pq = [&](auto u_, double (&P)[3], d2_t (&Qv)[3][2]) {
+            constexpr int u = decltype(u_)::value;  // position of the atom in its k-group
+            const double *__restrict__ ql = qg + ((u >> 1) & 1) * (2 * TC) + (u & 1) * 16;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               Qv[c][0] = *reinterpret_cast<const d2_t *>(ql + c * (4 * TC));
               Qv[c][1] = *reinterpret_cast<const d2_t *>(ql + c * (4 * TC) + 2);
-              P[c] = (pa + (int64_t)c * Npad)[l15u];
             }
+            P[0] = pa0[l15u];
+            P[1] = pa1[l15u];
+            P[2] = pa2[l15u];
+            pa0 += Npad3;
+            pa1 += Npad3;
+            pa2 += Npad3;
           };
           auto accumulate = [&](const double (&P)[3], const d2_t (&Qv)[3][2]) {
 #pragma clang fp contract(fast)
@@ -854,20 +869,40 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
               asm("v_max_f64 %0, %1, %2" : "=v"(mx[r]) : "v"(mx[r]), "v"(s2));
             }
           };
+          using U0 = std::integral_constant<int, 0>;
+          using U1 = std::integral_constant<int, 1>;
+          using U2 = std::integral_constant<int, 2>;
+          using U3 = std::integral_constant<int, 3>;
           double PA[3], PB[3];
           d2_t QA[3][2], QB[3][2];
-          load_pq(0, PA, QA);
+          load_pq(U0{}, PA, QA);
           // (the scheduling barriers keep the requests where they are written: the machine scheduler
           // otherwise gathers the two sets' loads into one burst right in front of their first use)
-          for (int a = 0; a < A4; a += 2) {
-            load_pq(a + 1, PB, QB);
+          for (int g = 0; g < n_groups; ++g) {
+            load_pq(U1{}, PB, QB);
             __builtin_amdgcn_sched_barrier(0);
             accumulate(PA, QA);
             __builtin_amdgcn_sched_barrier(0);
-            load_pq(a + 2, PA, QA);
+            load_pq(U2{}, PA, QA);
             __builtin_amdgcn_sched_barrier(0);
             accumulate(PB, QB);
             __builtin_amdgcn_sched_barrier(0);
+            load_pq(U3{}, PB, QB);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(PA, QA);
+            __builtin_amdgcn_sched_barrier(0);
+            qg += 12 * TC;
+            if (g + 1 < n_groups || odd_round) load_pq(U0{}, PA, QA);  // wave-uniform: nothing is read past the last atom row
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(PB, QB);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (odd_round) {  // the last two atoms (the second one may be a zero row)
+            load_pq(U1{}, PB, QB);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(PA, QA);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(PB, QB);
           }
           const bool row_in = i < n32;
           double *__restrict__ ro = rmsd_out + (int64_t)i * N + jb;
@@ -2658,7 +2693,8 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
   const size_t lds_m = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)rb) * sizeof(double) + kStageBytes;
   if (lds_m > kLdsLimit || NT == 0)
     return set_error(FC_E_LIMIT, "A=%lld atoms exceed the LDS column tile of the value kernel", (long long)e->A);
-  const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32);
+  const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32) &&
+                      (2 * (uint64_t)e->Npad + 16) * 8 < (1ull << 32);  // (the atom pass of MODE 2: byte offsets of three rows)
   if (!fits32) return set_error(FC_E_LIMIT, "ensemble too large for 32-bit operand offsets");
   auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
   const bool two_blocks = 2 * lds_m <= kLdsLimit;

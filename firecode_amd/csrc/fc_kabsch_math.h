@@ -554,6 +554,87 @@ __host__ __device__ __forceinline__ bool kabsch_quaternion_qcp(const double (&B)
   return true;
 }
 
+// The form the all-pairs complete-alignment kernel uses (k_simbits_screen_mfma<., 2>; every lane of the wavefront
+// active).  Same eigenvalue iteration and adjugate as kabsch_quaternion_qcp; what differs is instruction count --
+// that kernel is bound by fp64 issue, 4 rotations per lane and 16 x 16 sub-tile:
+//   * the Newton loop has a WAVE-UNIFORM trip count: every lane iterates until all 64 have converged (a lane at
+//     its fixed point moves by rounding noise).  The per-lane form cost two v_cndmask, an exec-mask update and a
+//     vector counter per iteration for nothing: the masked-off lanes' issue slots are spent either way;
+//   * "eigenvalue clearly simple" is tested against (3 |B|_F)^3 -- squared, |B|_F^2 is at hand from the characteristic
+//     polynomial -- instead of the cube of the sum of the absolute entries of K - lambda I (|lambda| <= sqrt(3) |B|_F,
+//     K's entries are sums and differences of B's: that sum lies in [|B|_F, 12 |B|_F], 2.5 - 4 |B|_F in practice):
+//     five multiplications instead of thirteen instructions, and like the original it follows the MATRIX, not
+//     (Gp + Gq)/2 (for unrelated structures |B|_F is far below that and a test against it declines every pair);
+//   * no residual test: with a converged simple eigenvalue the chosen adjugate column IS the eigenvector up to
+//     rounding amplified by 1 / (relative gap product) <= 1 / 2e-3; what the residual test caught beyond that was a
+//     Newton iteration that had not converged, which the returned flag now says directly (NaN included).
+// tools/qcp_host_check.cpp compares both forms with the Jacobi sweeps.
+__host__ __device__ __forceinline__ bool kabsch_quaternion_qcp_lean(const double (&B)[9], double GpGq, double (&Q)[4],
+                                                                    int *iterations = nullptr) {
+#pragma clang fp contract(fast)
+  const double Sxx = B[0], Sxy = B[3], Sxz = B[6];
+  const double Syx = B[1], Syy = B[4], Syz = B[7];
+  const double Szx = B[2], Szy = B[5], Szz = B[8];
+  const double n2 = Sxx * Sxx + Sxy * Sxy + Sxz * Sxz + Syx * Syx + Syy * Syy + Syz * Syz +
+                    Szx * Szx + Szy * Szy + Szz * Szz;
+  const double c00 = Syy * Szz - Syz * Szy, c01 = Syz * Szx - Syx * Szz, c02 = Syx * Szy - Syy * Szx;
+  const double c10 = Sxz * Szy - Sxy * Szz, c11 = Sxx * Szz - Sxz * Szx, c12 = Sxy * Szx - Sxx * Szy;
+  const double c20 = Sxy * Syz - Sxz * Syy, c21 = Sxz * Syx - Sxx * Syz, c22 = Sxx * Syy - Sxy * Syx;
+  const double detB = Sxx * c00 + Sxy * c01 + Sxz * c02;
+  const double e2 = c00 * c00 + c01 * c01 + c02 * c02 + c10 * c10 + c11 * c11 + c12 * c12 +
+                    c20 * c20 + c21 * c21 + c22 * c22;
+  const double C2 = -2.0 * n2, C1 = -8.0 * detB, C0 = n2 * n2 - 4.0 * e2;
+  const double S = 0.5 * GpGq;
+  double x = S, delta = 0.0;
+  int it = 0;
+  for (; it < 64; ++it) {
+    const double x2 = x * x;
+    const double b = (x2 + C2) * x;
+    const double a = b + C1;
+    const double den = 2.0 * x2 * x + b + a;
+    delta = (a * x + C0) * fc_rcp_approx(den);
+    x -= delta;
+    // NaN (den == 0: an all-zero padding conformer, an exact multiple root) counts as done here and fails below
+    const bool moving = fabs(delta) > 1e-9 * fabs(x);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_ballot_w64(moving) == 0ull) break;
+#else
+    if (!moving) break;
+#endif
+  }
+  if (iterations) *iterations = it + 1;
+  const bool converged = fabs(delta) <= 1e-9 * fabs(x);  // false for NaN
+  const double lam = x;
+  const double m00 = (Sxx + Syy + Szz) - lam, m01 = Syz - Szy, m02 = Szx - Sxz, m03 = Sxy - Syx;
+  const double m11 = (Sxx - Syy - Szz) - lam, m12 = Sxy + Syx, m13 = Szx + Sxz;
+  const double m22 = (-Sxx + Syy - Szz) - lam, m23 = Syz + Szy;
+  const double m33 = (-Sxx - Syy + Szz) - lam;
+  const double L01 = m02 * m13 - m12 * m03, L02 = m02 * m23 - m22 * m03, L03 = m02 * m33 - m23 * m03;
+  const double L12 = m12 * m23 - m22 * m13, L13 = m12 * m33 - m23 * m13, L23 = m22 * m33 - m23 * m23;
+  const double U01 = m00 * m11 - m01 * m01, U02 = m00 * m12 - m02 * m01, U03 = m00 * m13 - m03 * m01;
+  const double U12 = m01 * m12 - m02 * m11, U13 = m01 * m13 - m03 * m11;
+  const double a00 = m11 * L23 - m12 * L13 + m13 * L12;
+  const double a01 = -(m01 * L23 - m12 * L03 + m13 * L02);
+  const double a02 = m01 * L13 - m11 * L03 + m13 * L01;
+  const double a03 = -(m01 * L12 - m11 * L02 + m12 * L01);
+  const double a11 = m00 * L23 - m02 * L03 + m03 * L02;
+  const double a12 = -(m00 * L13 - m01 * L03 + m03 * L01);
+  const double a13 = m00 * L12 - m01 * L02 + m02 * L01;
+  const double a22 = m03 * U13 - m13 * U03 + m33 * U01;
+  const double a23 = -(m03 * U12 - m13 * U02 + m23 * U01);
+  const double a33 = m02 * U12 - m12 * U02 + m22 * U01;
+  double q0 = a00, q1 = a01, q2 = a02, q3 = a03, best = fabs(a00);
+  if (fabs(a11) > best) { best = fabs(a11); q0 = a01; q1 = a11; q2 = a12; q3 = a13; }
+  if (fabs(a22) > best) { best = fabs(a22); q0 = a02; q1 = a12; q2 = a22; q3 = a23; }
+  if (fabs(a33) > best) { best = fabs(a33); q0 = a03; q1 = a13; q2 = a23; q3 = a33; }
+  const double nq = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+  // best > 2e-3 (3 |B|_F)^3, squared: no square root
+  const bool simple = best * best > (2e-3 * 27.0) * (2e-3 * 27.0) * (n2 * n2) * n2;
+  const double nrm = fc_rsqrt(nq);
+  Q[0] = q0 * nrm; Q[1] = q1 * nrm; Q[2] = q2 * nrm; Q[3] = q3 * nrm;
+  return converged && simple && nq > 0.0;
+}
+
 // R (row-major) from a unit quaternion, same formulas as kabsch_rotation
 __host__ __device__ __forceinline__ void rotation_from_quaternion(const double (&Q)[4], double (&R)[9]) {
 #pragma clang fp contract(fast)

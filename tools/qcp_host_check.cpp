@@ -16,8 +16,8 @@ int main(int argc, char **argv) {
   std::normal_distribution<double> g(0.0, 1.0);
   std::vector<double> p(3 * A), q(3 * A);
   long hist[66] = {0};
-  double worst = 0.0;
-  long fail = 0;
+  double worst = 0.0, worst_lean = 0.0;
+  long fail = 0, fail_lean = 0, lean_only_ok = 0;
   for (int t = 0; t < trials; ++t) {
     double cp[3] = {0, 0, 0}, cq[3] = {0, 0, 0};
     // q = random rotation of p + noise
@@ -56,6 +56,16 @@ int main(int argc, char **argv) {
     int its = 0;
     const bool ok = fc::kabsch_quaternion_qcp(B, G, Q, &its);
     hist[std::min(its, 65)]++;
+    {  // the all-pairs kernel's form: no residual test, gap against (4 S)^3
+      double Ql[4], Rl[9];
+      const bool okl = fc::kabsch_quaternion_qcp_lean(B, G, Ql);
+      if (!okl) ++fail_lean;
+      else {
+        if (!ok) ++lean_only_ok;
+        fc::rotation_from_quaternion(Ql, Rl);
+        for (int e = 0; e < 9; ++e) worst_lean = std::max(worst_lean, std::fabs(Rl[e] - Rj[e]));
+      }
+    }
     if (!ok) { ++fail; continue; }
     fc::rotation_from_quaternion(Q, Rq);
     double R9[9];
@@ -66,6 +76,8 @@ int main(int argc, char **argv) {
     }
   }
   printf("A=%d trials=%d noise=%.2f: worst |R_new - R_jacobi| = %.3e, not-simple/residual fallbacks = %ld\n", A, trials, noise, worst, fail);
+  printf("lean form (kabsch_quaternion_qcp_lean): worst |R - R_jacobi| = %.3e, fallbacks = %ld, accepted where the full form declined = %ld\n",
+         worst_lean, fail_lean, lean_only_ok);
   printf("Newton steps histogram:");
   for (int i = 0; i < 66; ++i) if (hist[i]) printf(" %d:%ld", i, hist[i]);
   printf("\n");
