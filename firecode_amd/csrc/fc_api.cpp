@@ -522,6 +522,18 @@ static int ensemble_shard(fc_ensemble *e, int64_t rank, int64_t world, int64_t r
   }
   FC_TRY(e->pairq.reserve((size_t)e->pairq_cap * sizeof(uint64_t)));
   FC_TRY(e->simq.reserve((size_t)e->pairq_cap * sizeof(uint64_t)));
+  {  // buckets of the long-queue refine: (row buckets of 1 024) x (column tiles of 64), numbered supertile by supertile
+     // (8 column tiles of one row bucket; fc_kabsch.hip); sized here, before any pipeline forks
+    const int64_t n_rb = ceil_div(e->N, (int64_t)1024), n_sc = ceil_div(e->Npad >> 6, (int64_t)8);
+    const int64_t n_st = n_rb * n_sc, nb = n_st * 8;
+    e->bk_buckets = nb <= ((int64_t)1 << 22) ? nb : 0;  // one workgroup scans the counts; work items are bucket | piece << 24
+    if (e->bk_buckets > 0) {
+      FC_TRY(e->bk.reserve((size_t)(512 + 2 * nb + 1) * sizeof(int)));
+      FC_TRY(e->bk_off.reserve((size_t)((nb + 1) + (n_st + 1) + 8 * ((n_st + 7) / 8 + 1)) * sizeof(int)));  // offsets | supertile starts | per-XCD prefixes
+      FC_TRY(e->bk_list.reserve((size_t)(nb + e->pairq_cap / 512 + 1) * sizeof(int)));  // pieces of <= 512 pairs
+      FC_TRY(e->sortq.reserve((size_t)e->pairq_cap * sizeof(uint64_t)));
+    }
+  }
   FC_TRY(e->maskA.reserve((size_t)e->Npad));
   FC_TRY(e->maskB.reserve((size_t)e->Npad));
   FC_TRY(e->mbits.reserve((size_t)e->W * sizeof(uint64_t)));
@@ -662,12 +674,19 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
 
 // result of a deferred pair ladder (after the caller's synchronisation); false: the kernel
 // declined (queue overflow / list too long) and the prune has to be redone synchronously
-static bool ladder_collect(const fc_ensemble *e, int64_t slot, uint8_t *mask_out, int64_t *levels,
+// what a finished prune says about the length of this ensemble's candidate queue -> every workspace over its coordinates
+static void note_candidates(fc_ensemble *e, unsigned long long refined) {
+  int guard = 0;
+  for (fc_ensemble *w = e; w != nullptr && guard < 8; w = w->twin, ++guard) w->last_candidates = (int64_t)refined;
+}
+
+static bool ladder_collect(fc_ensemble *e, int64_t slot, uint8_t *mask_out, int64_t *levels,
                            int64_t *survivors, unsigned long long *counters_out, int64_t slot_stride = 0) {
   const int64_t N = e->N, W = e->W;
   const uint64_t *words = static_cast<const uint64_t *>(ctx().pinned) +
                           (size_t)slot * (size_t)(slot_stride > 0 ? slot_stride : W + 16);
   const uint64_t *cnt_host = words + W;
+  note_candidates(e, cnt_host[6]);  // (pairs the screen queued; valid also when the ladder declined)
   if (cnt_host[9] == 0) return false;
   int64_t alive = 0;
   for (int64_t w = 0; w < W; ++w) alive += __builtin_popcountll(words[w]);
@@ -1170,6 +1189,7 @@ int fc_rmsd_simbits(fc_ensemble *ens, double max_rmsd, double max_dev, const dou
   FC_TRY(d2h(all.data(), ens->bits.p, all.size() * sizeof(uint64_t)));
   FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
   FC_TRY(sync());
+  note_candidates(ens, cnt[6]);
   // words at or below the diagonal were never produced: define them as 0
   for (int64_t i = row_begin; i < row_end; ++i)
     for (int64_t w = 0; w < W; ++w)
@@ -1200,6 +1220,7 @@ int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const doubl
                        ens->simq.as<uint64_t>(), false, true);
   }
   FC_TRY(rc);
+  note_candidates(ens, cnt[6]);
   if (stats) {
     stats[0] = ens->N * (ens->N - 1) / 2;
     stats[1] = (int64_t)cnt[1];
@@ -2929,6 +2950,12 @@ int fc_bench_refine(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t r
   ens->lean = true;
   FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, kCounters * sizeof(uint64_t), c.stream));
   FC_TRY(launch_simbits_screen(ens, max_rmsd * max_rmsd + kScreenMargin));
+  {  // the launcher chooses the long-queue kernels from what the host last saw of this ensemble's queue
+    unsigned long long h0[8] = {0};
+    FC_TRY(d2h(h0, ens->counters.p, sizeof h0));
+    FC_TRY(sync());
+    note_candidates(ens, h0[6]);
+  }
   std::vector<hipEvent_t> &ev = c.ev_pool;
   while ((int64_t)ev.size() < 2 * reps) {
     hipEvent_t e = nullptr;
@@ -2942,9 +2969,15 @@ int fc_bench_refine(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t r
     FC_TRY(launch_simbits_refine(ens, max_rmsd, max_dev, nullptr, 0.0));
     FC_HIP_TRY(hipEventRecord(ev[2 * r + 1], c.stream));
   }
-  unsigned long long h[8] = {0};
+  unsigned long long h[32] = {0};
   FC_TRY(d2h(h, ens->counters.p, sizeof h));
   FC_TRY(sync());
+  if (getenv("FC_DEBUG") && h[22])  // (tuning build FC_RB_TIMELINE: sums over all launches since the counters were cleared)
+    fprintf(stderr, "[fc] refine buckets: %llu wave-items, %llu with pairs; mean ticks (100 MHz) staging %.1f, compute %.1f\n", h[22], h[23],
+            (double)h[20] / (double)h[22], (double)h[21] / (double)h[22]);
+  if (getenv("FC_DEBUG") && h[27])
+    fprintf(stderr, "[fc] refine buckets, wave 0 per item (%llu rounds): covariance pass %.1f ticks, polynomial + rotation %.1f, + deviation pass %.1f\n",
+            h[27], (double)h[26] / (double)h[27], (double)h[24] / (double)h[27], (double)h[25] / (double)h[27]);
   double sum = 0.0;
   for (int64_t r = 0; r < reps; ++r) {
     float ms = 0.f;

@@ -262,6 +262,9 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // A^2 added to max_rmsd^2 in the all-pairs screens (and in the refine's own early exit)
 constexpr double kScreenMargin = 1e-6;
+// candidate-pair queues longer than this go to the one-lane-per-pair refine kernels (k_refine_buckets / k_refine_pairs);
+// shorter ones are a latency problem and stay with the 8-lanes-per-pair walk of k_simbits_refine
+constexpr unsigned long long kRefineLanesMin = 1ull << 17;
 
 // uint64 words of fc_ensemble::counters: [0..10] queue lengths and flags, [11] "the fp64 screen has to run again" (k_screen_verdict),
 // [13] units queued by the subset stage of the lean fp32 screen, [15] its density verdict (1 = dense),
@@ -326,6 +329,16 @@ struct fc_ensemble {
   fc::DevBuf pairq;            // pairq_cap x uint64: queue of candidate pairs (i<<32 | j)
   int64_t pairq_cap = 0;
   fc::DevBuf simq;             // pairq_cap x uint64: exactly-similar pairs found by the refine
+  // the long-queue refine orders the candidates by (128-row block, 64-column tile) bucket first (fc_kabsch.hip,
+  // k_bucket_* / k_refine_buckets): control words + counts + scatter cursors | offsets | non-empty buckets | sorted queue
+  fc::DevBuf bk, bk_off, bk_list, sortq;
+  int64_t bk_buckets = 0;      // 0: too many buckets for the single-workgroup scan (the straight walk is used)
+  // Which long-queue refine to enqueue is a HOST decision made without a host wait: the bucket path is four launches and
+  // a memset that all return at once on a short queue -- 0.054 ms per step on the lanes of the pipelined prune of a
+  // clustered ensemble (0.190 -> 0.244 ms) -- so it is taken only when the last prune of these coordinates whose counters
+  // reached the host had a long queue.  Either choice is correct for any queue (the kernels gate themselves on the
+  // device-side length); -1: nothing seen yet.
+  int64_t last_candidates = -1;
   fc::DevBuf bits_full;        // N x W uint64: whole bit matrix rebuilt from gathered pairs
   fc::DevBuf item_table;       // screen items (lb << 32 | jt) that touch the upper triangle
   int64_t item_key[4] = {-1, -1, -1, -1}, item_total = 0;

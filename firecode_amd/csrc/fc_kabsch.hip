@@ -2229,7 +2229,6 @@ k_screen_rowsweep(const double *__restrict__ Xs, const double *__restrict__ G, i
 // -R, the decision -- all per lane.  Same outputs as the pair mode of k_simbits_refine: counters[1..3], simq, bits.
 // ---------------------------------------------------------------------------
 // counters words of the XCD-partitioned candidate queue (k_pairq_partition -> k_refine_pairs)
-constexpr unsigned long long kRefineLanesMin = 1ull << 17;  // pairs: below, the 8-lanes-per-pair form is faster (latency)
 
 __global__ void __launch_bounds__(256)
 k_refine_pairs(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N, int64_t Npad, int A,
@@ -2348,6 +2347,421 @@ k_refine_pairs(const double *__restrict__ Xs, const double *__restrict__ G, int6
     }
     sbase = __shfl(sbase, 0);
     if (on && sim) simq[sbase + (unsigned long long)__popcll(ms & ((1ull << lane) - 1ull))] = e;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The long candidate queues, BUCKET BY BUCKET (round 4; replaces the straight walk of k_refine_pairs above, which stays
+// as the FC_REFINE_BUCKETS=0 form).  k_refine_pairs fetched both conformers of every pair through the XCD's L2 twice
+// (covariance pass, deviation pass): 2.07 GB of fabric-side traffic per launch for a 12.5 MB ensemble at 9.45e5
+// candidates, L2 hit rate 0.7, 68 % of the wave cycles waiting on loads (profiles/r03_pmc_refine.json).  Here the queue
+// is first ordered by the (128-row block, 64-column tile) its pairs fall in -- a counting sort in three small launches:
+// k_bucket_count, k_bucket_scan, k_bucket_scatter -- and k_refine_buckets gives each non-empty bucket to one workgroup:
+// the bucket's COLUMN tile goes to LDS once (LDS-DMA, 512-byte rows [atom * 3 + c][64 columns]) and serves both passes
+// of all the bucket's pairs; the row conformers are 128 consecutive ones (1 KiB per coordinate row), read by every lane
+// of the workgroup and by the buckets of the same row block that follow on this XCD: L2 hits.  One lane per pair, the
+// arithmetic of k_refine_pairs unchanged (same functions, same order of operations: same bits).
+// Control block `bk` (int32): kBkCtrl control words (below), then the counts per bucket (n_buckets + 1), then the scatter
+// cursors (n_buckets); zeroed by the launcher.
+// ---------------------------------------------------------------------------
+// Order of the buckets (round 4, second step): SUPERTILE-major -- 8 row blocks x 8 column tiles (1 024 x 512 conformers,
+// 1.9 MB of coordinates at 50 atoms: half an XCD's L2) -- and k_refine_buckets hands the work items of supertile s to
+// the workgroups of XCD s mod 8 (HW_REG_XCC_ID picks the cursor a workgroup draws from first; any workgroup may draw
+// from any cursor, so nothing depends on where the hardware puts workgroups).  With buckets in plain row-block-major
+// order every staged column tile was new to its XCD's L2 (79 tiles of 80 KB per row block against 4 MB): 3.25 M L2
+// misses per launch, and the covariance pass -- the first touch of the row conformers, competing with those misses --
+// took 0.23 ms of the 0.51 while the identical loads of the deviation pass, L2 hits, were free.
+constexpr int kBkCtrl = 512;    // int32 words in front of the counts: [0] work items, [64 + 32 x] cursor of XCD x (a line each)
+// A bucket = 1 024 rows x 64 columns.  Only the COLUMN tile costs LDS (the rows are read from L2), so the rows of a
+// bucket can be many -- and have to be: what a CU can keep busy is (pairs of its resident tiles) / 64 wavefronts, and
+// with 128-row buckets (152 pairs at 1.9 % candidates) the two resident workgroups had 2 x 2.4 active wavefronts on
+// four SIMDs: every instruction latency exposed (~480 cycles per atom step whatever the loads did), 0.51 ms.
+constexpr int kBucketRows = 1024;
+constexpr int kSuper = 8;       // column tiles per supertile (one row bucket x 8 tiles = 1 024 x 512 conformers)
+
+struct BucketGeom {
+  unsigned NT, n_sc;            // column tiles, supertile columns = ceil(NT / 8)
+};
+__device__ __forceinline__ unsigned bucket_of(uint64_t e, BucketGeom g) {
+  const unsigned rb = (unsigned)(e >> 32) / (unsigned)kBucketRows, jt = (unsigned)(e & 0xffffffffull) >> 6;
+  return ((rb * g.n_sc + (jt >> 3)) << 3) | (jt & 7u);
+}
+
+// one atomic per distinct bucket of a wavefront's 64 queue entries (the queue comes in runs of one screen workgroup's
+// pairs: a wavefront usually names one or two buckets); want_pos: every lane also learns its place inside the run
+template <bool WANT_POS>
+__device__ __forceinline__ unsigned bucket_add_wave(bool on, unsigned b, int *__restrict__ counter_base, int lane) {
+  unsigned pos = 0;
+  uint64_t todo = __ballot(on);
+  while (todo != 0ull) {  // wave-uniform
+    const int leader = __builtin_ctzll(todo);
+    const unsigned bl = (unsigned)__builtin_amdgcn_readlane((int)b, leader);
+    const bool mine = on && b == bl;
+    const uint64_t m = __ballot(mine);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter_base + bl, (int)__popcll(m));
+    if (WANT_POS) {
+      base = __builtin_amdgcn_readlane(base, leader);
+      if (mine) pos = (unsigned)base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    todo &= ~m;
+  }
+  return pos;
+}
+
+__global__ void __launch_bounds__(256)
+k_bucket_count(const uint64_t *__restrict__ pairq, const unsigned long long *__restrict__ counters, unsigned long long Q,
+               BucketGeom geom, int *__restrict__ bk) {
+  const unsigned long long n_pairs = counters[6];
+  if (n_pairs > Q || n_pairs <= kRefineLanesMin) return;
+  const int lane = threadIdx.x & 63;
+  for (int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ll; p0 < (int64_t)n_pairs;
+       p0 += (int64_t)gridDim.x * blockDim.x) {
+    const bool on = p0 + lane < (int64_t)n_pairs;
+    const uint64_t e = pairq[on ? p0 + lane : p0];
+    (void)bucket_add_wave<false>(on, bucket_of(e, geom), bk + kBkCtrl, lane);
+  }
+}
+
+// ONE workgroup: exclusive scan of the bucket counts -> off[0 .. n_buckets]; the work items of k_refine_buckets --
+// a bucket in pieces of at most kBucketChunk pairs (one round of a workgroup: a bucket may hold 8 192 pairs, and one
+// workgroup walking those alone was the tail of the whole launch), encoded bucket | piece << 24, buckets ascending
+// (row block major: consecutive workgroups share their row block) -> list, their number -> bk[0]
+constexpr int kBucketChunk = 512;
+__global__ void __launch_bounds__(1024)
+k_bucket_scan(const unsigned long long *__restrict__ counters, unsigned long long Q, int64_t n_buckets, int *__restrict__ bk,
+              int *__restrict__ off, int *__restrict__ list, int *__restrict__ st_off, int *__restrict__ xoff, int n_st, int x_stride) {
+  const unsigned long long n_pairs = counters[6];
+  if (n_pairs > Q || n_pairs <= kRefineLanesMin) return;
+  __shared__ int s_sum[1024], s_cnt[1024];
+  const int t = threadIdx.x;
+  const int *__restrict__ cnt = bk + kBkCtrl;
+  // whole supertiles (8 buckets) per thread, so that a supertile's first work item is known to the thread that owns it
+  const int64_t per = ((n_buckets / kSuper + 1023) / 1024) * kSuper, b0 = (int64_t)t * per, b1 = b0 + per < n_buckets ? b0 + per : n_buckets;
+  int sum = 0, ne = 0;
+  for (int64_t b = b0; b < b1; ++b) {
+    const int c = cnt[b];
+    sum += c;
+    ne += (c + kBucketChunk - 1) / kBucketChunk;
+  }
+  s_sum[t] = sum;
+  s_cnt[t] = ne;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // inclusive scans of both
+    const int a = t >= d ? s_sum[t - d] : 0, c = t >= d ? s_cnt[t - d] : 0;
+    __syncthreads();
+    s_sum[t] += a;
+    s_cnt[t] += c;
+    __syncthreads();
+  }
+  int run = s_sum[t] - sum, place = s_cnt[t] - ne;
+  for (int64_t b = b0; b < b1; ++b) {
+    const int c = cnt[b];
+    if ((b & (kSuper - 1)) == 0) st_off[b / kSuper] = place;
+    off[b] = run;
+    for (int piece = 0; piece * kBucketChunk < c; ++piece) list[place++] = (int)b | (piece << 24);
+    run += c;
+  }
+  if (t == 1023) {
+    off[n_buckets] = s_sum[1023];
+    st_off[n_st] = s_cnt[1023];
+    bk[0] = s_cnt[1023];
+  }
+  __syncthreads();  // (one workgroup: its global writes above are visible to it behind the barrier)
+  // work items in front of each supertile WITHIN the sequence of its XCD (supertiles x, x + 8, x + 16, ...): xoff[x][r]
+  if (t < 8) {
+    int acc = 0, r = 0;
+    for (int sidx = t; sidx < n_st; sidx += 8, ++r) {
+      xoff[t * x_stride + r] = acc;
+      acc += st_off[sidx + 1] - st_off[sidx];
+    }
+    xoff[t * x_stride + r] = acc;  // total of XCD t (r = its number of supertiles)
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_bucket_scatter(const uint64_t *__restrict__ pairq, const unsigned long long *__restrict__ counters, unsigned long long Q,
+                 BucketGeom geom, int64_t n_buckets, int *__restrict__ bk, const int *__restrict__ off,
+                 uint64_t *__restrict__ sorted) {
+  const unsigned long long n_pairs = counters[6];
+  if (n_pairs > Q || n_pairs <= kRefineLanesMin) return;
+  const int lane = threadIdx.x & 63;
+  int *__restrict__ fill = bk + kBkCtrl + n_buckets + 1;
+  for (int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ll; p0 < (int64_t)n_pairs;
+       p0 += (int64_t)gridDim.x * blockDim.x) {
+    const bool on = p0 + lane < (int64_t)n_pairs;
+    const uint64_t e = pairq[on ? p0 + lane : p0];
+    const unsigned b = bucket_of(e, geom);
+    const unsigned pos = bucket_add_wave<true>(on, b, fill, lane);
+    if (on) sorted[(int64_t)off[b] + pos] = e;
+  }
+}
+
+__global__ void __launch_bounds__(kBucketChunk, 4)  // (second figure: wavefronts per SIMD -- two workgroups of eight per CU)
+k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N, int64_t Npad, int A,
+                 double max_rmsd, double max_dev, const double *__restrict__ energies, double max_dE, int IB,
+                 int64_t world, uint64_t *__restrict__ bits, int64_t W, unsigned long long *__restrict__ counters,
+                 unsigned long long Q, BucketGeom geom, int *__restrict__ bk, const int *__restrict__ off,
+                 const int *__restrict__ list, const int *__restrict__ st_off, const int *__restrict__ xoff, int n_st,
+                 int x_stride, const uint64_t *__restrict__ sorted, uint64_t *__restrict__ simq) {
+  extern __shared__ double lds[];  // [A4 * 3][64]: the bucket's column tile
+  __shared__ int s_next;
+  __shared__ int s_bin[kBucketRows];          // pairs per row of the block, then their exclusive scan
+  __shared__ uint64_t s_pairs[kBucketChunk];  // the item's pairs in row order
+  const unsigned long long n_pairs = counters[6];
+  if (n_pairs > Q || n_pairs <= kRefineLanesMin) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int A4 = (A + 3) & ~3;  // Xs rows are padded to a multiple of 4 atoms with zeros
+  const int n_rows = A4 * 3;    // even
+  const double A_thr2 = (double)A * (max_rmsd * max_rmsd + kScreenMargin);
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(63508) & 7u);  // HW_REG_XCC_ID: which XCD (and L2) this workgroup runs on
+  int turn = 0;  // XCD sequences tried so far: the own one first, then the others' leftovers
+  while (true) {
+    __syncthreads();  // everyone is done with the previous tile (and with s_next)
+    if (tid == 0) {
+      int item_at = -1;
+      while (turn < 8) {
+        const int x = (xcc + turn) & 7;
+        const int n_x = (n_st - x + 7) / 8;          // supertiles of XCD x
+        const int *__restrict__ xo = xoff + x * x_stride;
+        const int kx = atomicAdd(bk + 64 + 32 * x, 1);
+        if (n_x > 0 && kx < xo[n_x]) {
+          int lo = 0, hi = n_x;  // largest r with xo[r] <= kx
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (xo[mid] <= kx) lo = mid;
+            else hi = mid;
+          }
+          item_at = st_off[x + 8 * lo] + (kx - xo[lo]);
+          break;
+        }
+        ++turn;
+      }
+      s_next = item_at;
+    }
+    __syncthreads();
+    const int k = s_next;
+    if (k < 0) break;  // block-uniform: every sequence is exhausted
+#ifdef FC_RB_TIMELINE
+    const unsigned long long tl0 = wall_clock64();
+#endif
+    const unsigned item = (unsigned)list[k];
+    const unsigned b = item & 0xffffffu, piece = item >> 24;
+    const unsigned jt = (((b >> 3) % geom.n_sc) << 3) | (b & 7u);
+    const int64_t j0 = (int64_t)jt * 64;
+    // column tile by LDS-DMA: one instruction moves two 512-byte rows (lanes 0-31 the first, 32-63 the second)
+#ifdef FC_RB_NOSTAGE
+    for (int q = wv; q < 0; q += kBucketChunk / 64) {
+#else
+    for (int q = wv; q < n_rows / 2; q += kBucketChunk / 64) {
+#endif
+      const double *src = Xs + (int64_t)(2 * q + (lane >> 5)) * Npad + j0 + (lane & 31) * 2;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(lds + q * 128), 16, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the tile is in LDS
+    __syncthreads();
+#ifdef FC_RB_TIMELINE
+    const unsigned long long tl1 = wall_clock64();
+#endif
+    const int p_begin = off[b] + (int)piece * kBucketChunk, p_end = min(off[b + 1], p_begin + kBucketChunk);
+    // The item's pairs in ROW order (a counting sort over the 128 rows of the block, in LDS).  A lane reads its row
+    // conformer with per-lane addresses, and the address unit works through a wavefront's load 16 lanes at a time, one
+    // cycle per distinct 128-byte line of the group: with the pairs in arrival order a group's 16 rows lie anywhere in
+    // the block's 1 KiB (up to 8 lines: ~30 cycles per load instruction, 156 of them per pass -- that, not latency or
+    // L2 misses, was what the passes cost: prefetch depth 1 .. 12, supertile order, rows from LDS all left the 0.51 ms
+    // where they were); in row order 16 consecutive lanes name ~13 consecutive rows: one or two lines.
+    {
+      for (int r = tid; r < kBucketRows; r += kBucketChunk) s_bin[r] = 0;
+      __syncthreads();
+      const int p = p_begin + tid;
+      const bool have = p < p_end;
+      const uint64_t e_in = have ? sorted[p] : 0ull;
+      const int row = (int)((unsigned)(e_in >> 32) % (unsigned)kBucketRows);
+      int rank = 0;
+      if (have) rank = atomicAdd(&s_bin[row], 1);
+      __syncthreads();
+      if (wv == 0) {  // exclusive scan of the 1 024 bins: sixteen per lane
+        int c[16], tot = 0;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+          c[k2] = s_bin[16 * lane + k2];
+          tot += c[k2];
+        }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int up = __shfl_up(incl, d);
+          if (lane >= d) incl += up;
+        }
+        int run = incl - tot;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+          s_bin[16 * lane + k2] = run;
+          run += c[k2];
+        }
+      }
+      __syncthreads();
+      if (have) s_pairs[s_bin[row] + rank] = e_in;
+      __syncthreads();
+    }
+    const int n_item = p_end - p_begin;
+#ifdef FC_RB_NOCOMPUTE
+    for (int p0 = wv * 64; p0 < 0; p0 += kBucketChunk) {
+#else
+    for (int p0 = wv * 64; p0 < n_item; p0 += kBucketChunk) {  // (one round: a piece is at most kBucketChunk pairs)
+#endif
+      const bool on = p0 + lane < n_item;
+      const uint64_t e = s_pairs[on ? p0 + lane : p0];
+      const unsigned i = (unsigned)(e >> 32), j = (unsigned)(e & 0xffffffffull);
+      const double *__restrict__ qcol = lds + (j - (unsigned)j0);
+      double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      // Row operands come from L2 (~0.5-1 us under load), column operands from LDS: the row loads run kAhead atoms
+      // ahead of their use in a ring of register sets (with one atom ahead, as in k_refine_pairs, a pass of 50 atoms is
+      // a chain of 50 L2 round trips: 0.51 ms for 9.45e5 candidates, no better than the straight walk); the Xs rows
+      // beyond A are zeros up to a multiple of 4 atoms, and the passes run over all of them
+#ifndef FC_RB_AHEAD
+#define FC_RB_AHEAD 2
+#endif
+      constexpr int kAhead = FC_RB_AHEAD;
+      auto load_row = [&](int a, double (&P)[3]) {
+        const int al = a < A4 ? a : A4 - 1;  // past the end: harmless re-read, never used
+#ifdef FC_RB_ROWS_FROM_LDS  // tuning build (WRONG results): what the kernel costs without its global row loads
+#pragma unroll
+        for (int c = 0; c < 3; ++c) P[c] = lds[(al * 3 + c) * 64 + (i & 63)];
+#else
+        const double *__restrict__ row = Xs + (int64_t)(al * 3) * Npad;  // wave-uniform
+#pragma unroll
+        for (int c = 0; c < 3; ++c) P[c] = (row + (int64_t)c * Npad)[i];
+#endif
+      };
+      auto load_col = [&](int a, double (&Qv)[3]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Qv[c] = qcol[(a * 3 + c) * 64];
+      };
+      {
+        double P[kAhead][3], Qv[3];
+        auto cov = [&](const double (&Pp)[3], const double (&Qq)[3]) {
+#pragma unroll
+          for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y) B[x * 3 + y] = fma(Pp[x], Qq[y], B[x * 3 + y]);
+        };
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) load_row(u, P[u]);
+#ifdef FC_RB_NOPASS1
+        for (int a = 0; a < 4; a += kAhead) {
+#else
+        for (int a = 0; a < A4; a += kAhead) {
+#endif
+#pragma unroll
+          for (int u = 0; u < kAhead; ++u) {
+            if (kAhead > 4 && a + u >= A4) break;  // (A4 is a multiple of 4; wave-uniform)
+            load_col(a + u, Qv);
+            __builtin_amdgcn_sched_barrier(0);
+            cov(P[u], Qv);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(a + u + kAhead, P[u]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+#ifdef FC_RB_TIMELINE
+      const unsigned long long tp1 = wall_clock64();
+#endif
+      const double Gs = G[i] + G[j];
+      const bool may = on && kabsch_may_be_below(B, Gs, A_thr2);
+      double ssq = 0.0, mx = 0.0;
+      if (__any(may)) {
+        double nR[9];
+        {
+          double Q4[4];
+#ifdef FC_RB_NOJACOBI
+          (void)kabsch_quaternion_qcp(B, Gs, Q4);
+          const bool fast = true;
+#else
+          const bool fast = kabsch_quaternion_qcp(B, Gs, Q4);
+#endif
+          if (__any(may && !fast)) {  // not clearly simple (symmetric or degenerate structures): the Jacobi sweeps
+            double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            if (may && !fast) (void)kabsch_rotation(B, R);
+            if (fast) neg_rotation_from_quaternion(Q4, nR);
+            else
+#pragma unroll
+              for (int kk = 0; kk < 9; ++kk) nR[kk] = -R[kk];
+          } else {
+            neg_rotation_from_quaternion(Q4, nR);
+          }
+        }
+#ifdef FC_RB_TIMELINE
+        if (wv == 0 && lane == 0) atomicAdd(&counters[24], wall_clock64() - tp1);  // polynomial + rotation
+#endif
+        double P[kAhead][3], Qv[3];
+        auto dev = [&](const double (&Pp)[3], const double (&Qq)[3]) {
+#pragma clang fp contract(fast)
+          const double dx = fma(nR[0], Qq[0], fma(nR[1], Qq[1], fma(nR[2], Qq[2], Pp[0])));
+          const double dy = fma(nR[3], Qq[0], fma(nR[4], Qq[1], fma(nR[5], Qq[2], Pp[1])));
+          const double dz = fma(nR[6], Qq[0], fma(nR[7], Qq[1], fma(nR[8], Qq[2], Pp[2])));
+          const double s2 = fma(dz, dz, fma(dy, dy, dx * dx));
+          ssq += s2;
+          asm("v_max_f64 %0, %0, %1" : "+v"(mx) : "v"(s2));
+        };
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) load_row(u, P[u]);
+#ifdef FC_RB_NOPASS2
+        for (int a = 0; a < 4; a += kAhead) {
+#else
+        for (int a = 0; a < A4; a += kAhead) {
+#endif
+#pragma unroll
+          for (int u = 0; u < kAhead; ++u) {
+            if (kAhead > 4 && a + u >= A4) break;  // (A4 is a multiple of 4; wave-uniform)
+            load_col(a + u, Qv);
+            __builtin_amdgcn_sched_barrier(0);
+            dev(P[u], Qv);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(a + u + kAhead, P[u]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+#ifdef FC_RB_TIMELINE
+      if (wv == 0 && lane == 0) {
+        atomicAdd(&counters[25], wall_clock64() - tp1);  // polynomial + rotation + deviation pass
+        atomicAdd(&counters[26], tp1 - tl1);             // pair load + covariance pass (first round of the item)
+        atomicAdd(&counters[27], 1ull);
+      }
+#endif
+      bool sim = false, grey = false;
+      if (on) {
+        const double r = sqrt(ssq / (double)A), m = sqrt(mx);
+        sim = may && (r < max_rmsd) && (m < max_dev);
+        grey = may && ((fabs(r - max_rmsd) < 1e-9) || (r < max_rmsd && fabs(m - max_dev) < 1e-9));
+        if (energies != nullptr) sim = sim && (fabs(energies[i] - energies[j]) < max_dE);
+        if (!sim && bits != nullptr) {
+          const int64_t lrow = (((int64_t)i / IB) / world) * IB + ((int64_t)i % IB);
+          atomicAnd(reinterpret_cast<unsigned long long *>(&bits[lrow * W + (j >> 6)]), ~(1ull << (j & 63)));
+        }
+      }
+      const uint64_t mo = __ballot(on), ms = __ballot(on && sim), mg = __ballot(on && grey);
+      unsigned long long sbase = 0;
+      if (lane == 0) {
+        atomicAdd(&counters[1], (unsigned long long)__popcll(mo));
+        if (ms) sbase = atomicAdd(&counters[2], (unsigned long long)__popcll(ms));
+        if (mg) atomicAdd(&counters[3], (unsigned long long)__popcll(mg));
+      }
+      sbase = __shfl(sbase, 0);
+      if (on && sim) simq[sbase + (unsigned long long)__popcll(ms & ((1ull << lane) - 1ull))] = e;
+    }
+#ifdef FC_RB_TIMELINE  // tuning build: 100 MHz ticks spent staging / computing (per wavefront), items, wave-rounds
+    if (lane == 0 && wv == 0) {
+      const unsigned long long tl2 = wall_clock64();
+      atomicAdd(&counters[20], tl1 - tl0);
+      atomicAdd(&counters[21], tl2 - tl1);
+      atomicAdd(&counters[22], 1ull);
+      if (wv * 64 < n_item) atomicAdd(&counters[23], 1ull);
+    }
+#endif
   }
 }
 
@@ -3248,7 +3662,45 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
     const char *v = getenv("FC_REFINE_LANES");
     return !(v && atoi(v) == 0);
   }();
-  if (lanes) {
+  static const bool buckets = [] {
+    const char *v = getenv("FC_REFINE_BUCKETS");  // 0: the straight queue walk of k_refine_pairs (round 3)
+    return !(v && atoi(v) == 0);
+  }();
+  const size_t lds_bk = (size_t)(((e->A + 3) & ~(int64_t)3) * 3 * 64) * sizeof(double);
+  if (lanes && buckets && e->bk_buckets > 0 && lds_bk <= kLdsLimit && e->last_candidates > (int64_t)kRefineLanesMin) {
+    auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
+    const unsigned NT = (unsigned)(e->Npad >> 6);
+    const BucketGeom geom{NT, (NT + 7) / 8};
+    const int64_t nb = e->bk_buckets;
+    const int n_st = (int)(nb / 8), x_stride = (n_st + 7) / 8 + 1;
+    int *bk = e->bk.as<int>();
+    int *off = e->bk_off.as<int>(), *st_off = off + nb + 1, *xoff = st_off + n_st + 1;
+    FC_HIP_TRY(hipMemsetAsync(bk, 0, (size_t)(kBkCtrl + 2 * nb + 1) * sizeof(int), ctx().stream));
+    const unsigned g = (unsigned)(ctx().n_cu * 2);
+    hipLaunchKernelGGL(k_bucket_count, dim3(g), dim3(256), 0, ctx().stream, e->pairq.as<uint64_t>(), cnt,
+                       (unsigned long long)e->pairq_cap, geom, bk);
+    FC_TRY(check_launch("k_bucket_count"));
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, ctx().stream, cnt, (unsigned long long)e->pairq_cap, nb, bk,
+                       off, e->bk_list.as<int>(), st_off, xoff, n_st, x_stride);
+    FC_TRY(check_launch("k_bucket_scan"));
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(g), dim3(256), 0, ctx().stream, e->pairq.as<uint64_t>(), cnt,
+                       (unsigned long long)e->pairq_cap, geom, nb, bk, off, e->sortq.as<uint64_t>());
+    FC_TRY(check_launch("k_bucket_scatter"));
+    if (lds_bk > 64 * 1024)
+      FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_refine_buckets),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bk));
+    static const int per_cu_b = [] {
+      const char *v = getenv("FC_REFINE_GRID");
+      const int k = v ? atoi(v) : 2;
+      return k >= 1 && k <= 8 ? k : 2;
+    }();
+    hipLaunchKernelGGL(k_refine_buckets, dim3((unsigned)(ctx().n_cu * per_cu_b)), dim3(kBucketChunk), lds_bk, ctx().stream,
+                       e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, max_rmsd, max_dev, energies_dev,
+                       max_dE, (int)e->row_block, e->world, e->lean ? nullptr : e->bits.as<uint64_t>(), e->W, cnt,
+                       (unsigned long long)e->pairq_cap, geom, bk, off, e->bk_list.as<int>(), st_off, xoff, n_st, x_stride,
+                       e->sortq.as<uint64_t>(), e->simq.as<uint64_t>());
+    FC_TRY(check_launch("k_refine_buckets"));
+  } else if (lanes) {
     static const int per_cu = [] {
       // workgroups per CU (tuning knob).  The kernel waits for the memory system, not for lanes: alone it takes 0.45 / 0.49 /
       // 0.47 ms for 9.45e5 pairs with 16 / 2 / 1 workgroups per CU; beside a screen, two per CU leave the screen the

@@ -263,6 +263,38 @@ def test_fp32_screen_far_from_the_origin(fc, monkeypatch):
     assert _lib.screen_last_kind() in (16, 32)
 
 
+@pytest.mark.parametrize("n,a,seed,thr", [(2200, 30, 5, 0.75), (1500, 23, 9, 0.9)])
+def test_long_candidate_queue_refine_vs_oracle(fc, n, a, seed, thr):
+    """More than 2^17 candidates per prune: the queue is ordered by (128-row block, 64-column tile) bucket
+    (k_bucket_count / _scan / _scatter) and refined bucket by bucket with the column tile in LDS (k_refine_buckets;
+    odd atom count: padded row).  Every other test's queue is short enough for the 8-lanes-per-pair kernel.
+    Similarity bits (the refine's atomicAnd path), similar-pair count, grey count and masks with and without an
+    energy window against the oracle's all-pairs matrix."""
+    from firecode_amd._lib import unpack_bits
+
+    X = syn.continuous_ensemble(n, a, seed=seed)
+    atoms = np.array(["C"] * a)
+    S0, R0, D0 = o.rmsd_similarity_matrix(X, atoms, thr)
+    iu = np.triu_indices(n, 1)
+    assert np.abs(R0[iu] - thr).min() > 1e-9 and np.abs(D0[iu] - 2 * thr)[R0[iu] < thr].min() > 1e-9
+    en = np.random.default_rng(seed).uniform(0, 3, size=n)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        # the first call over these coordinates takes the straight queue walk (k_refine_pairs); from then on the library
+        # knows the queue is long and orders it by bucket first -- both forms, with and without the bit matrix
+        bits_w, grey_w = ens.simbits(thr, 2 * thr)
+        mask_w, stats_w = ens.prune(thr, 2 * thr)
+        bits, grey = ens.simbits(thr, 2 * thr)
+        mask, stats = ens.prune(thr, 2 * thr)
+        _, _, mask_p, stats_p = ens.bench_prune(thr, 2 * thr, reps=5, want_mask=True)  # ... and inside the pipelined prunes
+    assert int(stats[1]) > (1 << 17) and int(stats[2]) == int(np.triu(S0, 1).sum()) > (1 << 17)
+    assert np.array_equal(unpack_bits(bits, n), np.triu(S0, 1)) and grey == 0
+    assert np.array_equal(bits, bits_w) and grey_w == 0 and np.array_equal(mask, mask_w) and np.array_equal(stats[1:4], stats_w[1:4])
+    assert np.array_equal(mask, o.greedy_prune_from_matrix(S0)) and np.array_equal(mask_p, mask) and int(stats_p[2]) == int(stats[2])
+    _, mask_e = fc.pruner.prune_by_rmsd(X, atoms, thr, energies=en, max_dE=1.0)  # (sorts by energy, as the reference does)
+    assert np.array_equal(mask_e, o.greedy_prune_from_matrix(S0, energies=en, max_dE=1.0))
+    assert 0 < mask.sum() < mask_e.sum() < n
+
+
 def test_refine_word_queue_fallback(fc, monkeypatch):
     """pair queue too small -> the refine kernel must fall back to the word
     queue (sparse words: wave per pair; dense words: lane per pair)"""
