@@ -1,6 +1,7 @@
 // fc_api.cpp -- the extern "C" surface of libfc_hip.so (include/fc_hip.h):
 // argument checks, host<->HBM staging, kernel sequencing.  No compute here.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -16,6 +17,10 @@ namespace fc {
 
 // ---- launchers implemented in the .hip translation units --------------------
 int launch_prep(const double *, int64_t, int64_t, const int32_t *, int64_t, int, fc_ensemble *, const int32_t *);
+int launch_prep_begin(fc_ensemble *);
+bool prep_by_tiles(int64_t);
+int launch_prep_tiles(const double *, int64_t, int64_t, const int32_t *, int64_t, int, fc_ensemble *, const int32_t *, int64_t,
+                      int64_t);
 int launch_pairs_exact(const fc_ensemble *, const int64_t *, const int64_t *, int64_t, double *,
                        double *, double *);
 int launch_matrix_exact(const fc_ensemble *, double *, double *);
@@ -338,9 +343,10 @@ struct StageLease {  // one set of pinned pieces for the duration of one staged 
     for (int b = 0; b < 2; ++b) {
       if (!set->pin[b] && hipHostMalloc(&set->pin[b], kStagePiece, hipHostMallocDefault) != hipSuccess)
         return set_error(FC_E_NOMEM, "pinned staging memory: hipHostMalloc failed");
+    }
+    for (int b = 0; b < 4; ++b)
       if (!set->ev[b] && hipEventCreateWithFlags(&set->ev[b], hipEventDisableTiming) != hipSuccess)
         return set_error(FC_E_HIP, "hipEventCreate failed");
-    }
     return FC_OK;
   }
   ~StageLease() {
@@ -488,6 +494,17 @@ static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, c
   return FC_OK;
 }
 
+// Host arrays in (the drop-in call prune_by_rmsd(structures, ...)): the coordinates go through the pinned pieces like every
+// large upload from pageable memory (h2d_staged; fc_common.h says why the caller's pages are not handed to the runtime).
+// What that costs and what was tried against it (round 4; tools/pin_probe.py, tools/hostin_breakdown.py; 12 MB):
+// DMA from pinned memory 0.22 ms (54 GB/s), from the caller's pageable pages THE SAME 0.22 ms (the driver maps them; that
+// mapping is what later stalls the queues when the caller frees the array), memmove into pinned memory 0.24 ms on one
+// core -- piece by piece (3 x 4 MB, copy of piece k + 1 beside the DMA of piece k) 0.44 ms per ensemble with the
+// preparation kernel.  Built and not kept: ~2 MB pieces of whole 64-conformer tiles, each followed by its own preparation
+// launch -- on one stream every copy -> kernel -> copy hand-over between the copy engine and the compute queue costs
+// ~25 us (0.67 ms); with the copies on a stream of their own every extra piece costs ~10 us and every event ~7 us
+// (0.53 ms); the copy of each 4 MB piece split between this thread and a helper thread (0.41 ms: a thread per call
+// for 0.03 ms).
 static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const uint8_t *atom_mask,
                           int center, fc_ensemble *e) {
   DevBuf raw;

@@ -69,7 +69,7 @@ struct Context {
   // ladder's helper threads copy side by side), handed out under stage_mu
   struct StageSet {
     void *pin[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // [2], [3]: the half pieces of the pipelined ensemble upload
     bool busy = false;
   };
   static constexpr int kStageSets = 8;

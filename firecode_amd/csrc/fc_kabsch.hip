@@ -94,11 +94,12 @@ __global__ void __launch_bounds__(256)
 k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_t *__restrict__ sel,
             int64_t A, int center, int64_t Npad, double *__restrict__ Xs, double *__restrict__ G,
             double *__restrict__ Xa, unsigned long long *__restrict__ gmax_bits,
-            const int32_t *__restrict__ conf_idx) {  // conf_idx != nullptr: gather (the survivors of an earlier stage)
+            const int32_t *__restrict__ conf_idx,  // conf_idx != nullptr: gather (the survivors of an earlier stage)
+            int64_t tile0) {                       // first tile of this launch (an upload arrives in pieces)
   extern __shared__ double tile[];  // [64][A_all*3 + 1] (the +1 spreads the conformers over the banks)
   __shared__ double cen[64][3];
   const int tid = threadIdx.x;
-  const int64_t n0 = (int64_t)blockIdx.x * 64;
+  const int64_t n0 = ((int64_t)blockIdx.x + tile0) * 64;
   const int64_t row = A_all * 3, ld = row + 1;
   const int64_t n_here = (N - n0 < 64) ? (N - n0 > 0 ? N - n0 : 0) : 64;
   if (conf_idx == nullptr) {
@@ -3191,28 +3192,44 @@ int launch_scatter_pairs(const uint64_t *pairs_dev, int64_t n_pairs, int64_t N, 
 // ---------------------------------------------------------------------------
 // host-side launchers (called from fc_api.cpp)
 // ---------------------------------------------------------------------------
-int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_t *sel_dev,
-                int64_t A, int center, fc_ensemble *e, const int32_t *conf_idx_dev) {
-  // the largest G lands in the last counter word (zeroed here); ensemble_build reads it behind its own wait
+// the largest G lands in the last counter word (zeroed here); ensemble_build reads it behind its own wait
+int launch_prep_begin(fc_ensemble *e) {
   auto *gmax_bits = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
   FC_HIP_TRY(hipMemsetAsync(gmax_bits, 0, sizeof(unsigned long long), ctx().stream));
-  const size_t lds_tile = (size_t)64 * (size_t)(A_all * 3 + 1) * sizeof(double);
-  if (lds_tile + 2048 <= kLdsLimit && !getenv("FC_PREP_LANES")) {  // FC_PREP_LANES=1: the one-lane-per-conformer kernel
-    if (lds_tile > 64 * 1024)
-      FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_tile),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
-    hipLaunchKernelGGL(k_prep_tile, dim3((unsigned)(e->Npad / 64)), dim3(256), lds_tile, ctx().stream, coords_dev,
-                       N, A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
-                       e->Xa.as<double>(), gmax_bits, conf_idx_dev);
-  } else {
-    const int64_t blocks = ceil_div(e->Npad, 256);
-    hipLaunchKernelGGL(k_prep, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, coords_dev, N,
-                       A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
-                       e->Xa.as<double>(), gmax_bits, conf_idx_dev);
-  }
   e->xsf_valid = false;
   e->xh_valid = false;
   e->g_max = -1.0;
+  return FC_OK;
+}
+// whether the tile kernel (64 conformers per workgroup through LDS) applies: only it can take a range of tiles
+bool prep_by_tiles(int64_t A_all) {
+  const size_t lds_tile = (size_t)64 * (size_t)(A_all * 3 + 1) * sizeof(double);
+  return lds_tile + 2048 <= kLdsLimit && !getenv("FC_PREP_LANES");  // FC_PREP_LANES=1: the one-lane-per-conformer kernel
+}
+// tiles [tile0, tile0 + n_tiles) of 64 conformers (behind launch_prep_begin)
+int launch_prep_tiles(const double *coords_dev, int64_t N, int64_t A_all, const int32_t *sel_dev, int64_t A, int center,
+                      fc_ensemble *e, const int32_t *conf_idx_dev, int64_t tile0, int64_t n_tiles) {
+  if (n_tiles <= 0) return FC_OK;
+  auto *gmax_bits = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
+  const size_t lds_tile = (size_t)64 * (size_t)(A_all * 3 + 1) * sizeof(double);
+  if (lds_tile > 64 * 1024)
+    FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_tile),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
+  hipLaunchKernelGGL(k_prep_tile, dim3((unsigned)n_tiles), dim3(256), lds_tile, ctx().stream, coords_dev, N, A_all,
+                     sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(), e->Xa.as<double>(), gmax_bits,
+                     conf_idx_dev, tile0);
+  return check_launch("k_prep_tile");
+}
+int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_t *sel_dev,
+                int64_t A, int center, fc_ensemble *e, const int32_t *conf_idx_dev) {
+  FC_TRY(launch_prep_begin(e));
+  if (prep_by_tiles(A_all))
+    return launch_prep_tiles(coords_dev, N, A_all, sel_dev, A, center, e, conf_idx_dev, 0, e->Npad / 64);
+  auto *gmax_bits = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
+  const int64_t blocks = ceil_div(e->Npad, 256);
+  hipLaunchKernelGGL(k_prep, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, coords_dev, N,
+                     A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(),
+                     e->Xa.as<double>(), gmax_bits, conf_idx_dev);
   return check_launch("k_prep");
 }
 
