@@ -173,7 +173,7 @@ def most_diverse_conformers(n, structures, seed=None):
     return list(np.array(structures)[indices])
 
 
-def clustered_csearch(coords, torsions, rotation_masks, n_out=100, thresh=1.5, seed=None, logfunction=None):
+def clustered_csearch_core(coords, torsions, rotation_masks, n_out=100, thresh=1.5, seed=None, logfunction=None):
     """Numeric core of ``clustered_csearch`` (torsion_module.py:726-891) for one
     torsion group: ``torsions`` = sequence of (i1, i2, i3, i4, n_fold),
     ``rotation_masks`` = the matching ``_get_rotation_mask`` arrays (graph
@@ -211,8 +211,8 @@ def clustered_csearch(coords, torsions, rotation_masks, n_out=100, thresh=1.5, s
 N_FOLD_ANGLES = {2: (0, 180), 3: (0, 120, 240), 4: (0, 90, 180, 270), 6: (0, 60, 120, 180, 240, 300)}
 
 
-def random_csearch(coords, torsions, rotation_masks, n_out=100, max_tries=10000, rotations=None, thresh=1.5,
-                   seed=None, order=None, return_indices=False):
+def random_csearch_core(coords, torsions, rotation_masks, n_out=100, max_tries=10000, rotations=None, thresh=1.5,
+                        seed=None, order=None, return_indices=False):
     """Numeric core of ``random_csearch`` (torsion_module.py:436-571): the n-fold angle grid
     in ``cartesian_product`` order, optionally only the sets with exactly ``rotations``
     non-zero angles, SHUFFLED, then the same per-set dihedral scan as the clustered search;
@@ -254,3 +254,98 @@ def random_csearch(coords, torsions, rotation_masks, n_out=100, max_tries=10000,
     if return_indices:
         return structures, np.array(kept_idx, dtype=np.int64)
     return structures
+
+
+# ---- the reference's own signatures (firecode/torsion_module.py:354, 436-450, 726-742, 1046) --------------------------
+def _get_rotation_mask(graph, torsion):
+    """firecode/torsion_module.py:354-382: the atoms that rotate with i4 (reachable from i4 once the i2-i3 bond is
+    cut), i3 excluded; one entry per node of ``graph``."""
+    from firecode_amd.pruner import rotation_mask
+
+    return rotation_mask(graph, torsion)
+
+
+def _get_tf_mat(structures, quadruplets):
+    """firecode/torsion_module.py:1046-1053."""
+    return get_tf_mat(structures, quadruplets)
+
+
+def _torsion_rows(torsions, graph):
+    """duck-typed ``Torsion`` objects (``.torsion`` = (i1, i2, i3, i4), ``.n_fold``) -> the numeric cores' inputs:
+    (i1, i2, i3, i4, n_fold) rows and one rotation mask per torsion (this package's ``rotation_mask``)."""
+    rows, masks = [], []
+    for t in torsions:
+        quad = tuple(int(i) for i in t.torsion)
+        if int(t.n_fold) not in N_FOLD_ANGLES:
+            raise L.FirecodeHipInputError(L.FC_E_INVALID, f"torsion {quad}: n_fold {t.n_fold!r} has no angle set "
+                                                           "(firecode/torsion_module.py:139-145 knows 2, 3, 4, 6)")
+        rows.append(quad + (int(t.n_fold),))
+        masks.append(_get_rotation_mask(graph, quad))
+    return rows, np.array(masks, dtype=bool)
+
+
+def _log_torsions(logfunction, atoms, torsions, with_symbols):
+    if logfunction is None:
+        return
+    logfunction("\n> Torsion list: (indices: n-fold)")
+    for t, torsion in enumerate(torsions):
+        ids = [int(i) for i in torsion.torsion]
+        if with_symbols:
+            logfunction(" {:2s} - {:21s} : {}{}{}{} : {}-fold".format(str(t), str(ids), *[atoms[i] for i in ids], torsion.n_fold))
+        else:
+            logfunction(" {:3} - {:21s} : {}-fold".format(t, str(ids), torsion.n_fold))
+    central = sorted({int(i) for t in torsions for i in t.torsion[1:3]})
+    logfunction(f"\n> Rotable bonds ids: {' '.join(str(i) for i in central)}")
+
+
+def clustered_csearch(atoms, coords, torsions, graph, charge=0, mult=1, constrained_indices=None, n=100, n_out=100,
+                      title="test", logfunction=print, interactive_print=True, write_torsions=False, debug=False,
+                      seed=None):
+    """``clustered_csearch`` with the reference's signature (firecode/torsion_module.py:726-742; called at :697-710 with
+    ``Torsion`` objects from the perception step): one torsion group, its n-fold angle grid in ``cartesian_product``
+    order scanned on the GPU with the clash test and the 5-degree back-off, the starting structure plus every conformer
+    that rotated a bond TFD-pruned on the torsion quadruplets, ``most_diverse_conformers`` down to ``n_out``.
+    ``charge`` / ``mult`` / ``n`` / ``debug`` are accepted as in the reference (it does not use the first two either;
+    ``n`` only acts between torsion groups and the reference forms one group, :749).  ``write_torsions`` (VMD files)
+    is outside the hot path: not supported here.  ``seed`` (extra, keyword only in practice) fixes the final draw."""
+    import time
+
+    if write_torsions:
+        raise NotImplementedError("write_torsions (VMD / .xyz side files) is not part of the hot path")
+    t0 = time.perf_counter()
+    coords = L.f64(coords)
+    _log_torsions(logfunction, atoms, torsions, with_symbols=False)
+    if logfunction is not None:
+        logfunction(f"\n--> Clustered CSearch on {title}\n    - {len(torsions)} torsions in 1 group - {[len(torsions)]}")
+    rows, masks = _torsion_rows(torsions, graph)
+    out = clustered_csearch_core(coords, rows, masks, n_out=n_out, seed=seed, logfunction=logfunction)
+    if logfunction is not None:
+        share = len(out) / np.prod([int(t.n_fold) for t in torsions], dtype=float)
+        logfunction(f"  Selected the most diverse {len(out)} conformers, corresponding\n"
+                    f"  to about {round(100 * share, 2)} % of the total conformational space - CSearch time "
+                    f"{time.perf_counter() - t0:.3f} s")
+    return out
+
+
+def random_csearch(atoms, coords, torsions, graph, constrained_indices=None, n_out=100, max_tries=10000, rotations=None,
+                   title="test", logfunction=print, interactive_print=True, write_torsions=False, seed=None, order=None):
+    """``random_csearch`` with the reference's signature (firecode/torsion_module.py:436-450; called at :712-723): the
+    n-fold angle grid, optionally only the sets with exactly ``rotations`` non-zero angles, shuffled, scanned until
+    ``n_out`` sets rotated a bond (the reference's stop rule, ``max_tries`` quirk included).  The reference shuffles
+    with the global NumPy generator; ``seed`` / ``order`` (extras) fix the permutation."""
+    import time
+
+    if write_torsions:
+        raise NotImplementedError("write_torsions (VMD / .xyz side files) is not part of the hot path")
+    t0 = time.perf_counter()
+    coords = L.f64(coords)
+    _log_torsions(logfunction, atoms, torsions, with_symbols=True)
+    if logfunction is not None:
+        logfunction(f"\n--> Random dihedral CSearch on {title}\n    mode 2 (random) - {len(torsions)} torsions")
+    rows, masks = _torsion_rows(torsions, graph)
+    out = random_csearch_core(coords, rows, masks, n_out=n_out, max_tries=max_tries, rotations=rotations, seed=seed, order=order)
+    if logfunction is not None:
+        share = len(out) / np.prod([int(t.n_fold) for t in torsions], dtype=float)
+        logfunction(f"  Generated {len(out)} conformers, (est. {round(100 * share, 2)} % of the total conformational space) - "
+                    f"CSearch time {time.perf_counter() - t0:.3f} s")
+    return out

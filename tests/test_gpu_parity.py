@@ -479,12 +479,12 @@ def test_random_csearch_vs_oracle(fc):
         g = grid if rotations is None else grid[np.count_nonzero(grid, axis=1) == rotations]
         od = order[order < len(g)] if rotations is not None else order
         ref, ref_idx = o.random_csearch(base, tors, masks, g[od], n_out=n_out, max_tries=max_tries)
-        out, idx = fc.torsion_module.random_csearch(base, tors5, masks, n_out=n_out, max_tries=max_tries,
+        out, idx = fc.torsion_module.random_csearch_core(base, tors5, masks, n_out=n_out, max_tries=max_tries,
                                                     rotations=rotations, order=od, return_indices=True)
         assert np.array_equal(idx, ref_idx) and len(idx) > 0
         assert np.abs(out - ref).max() < TOL
     # seeded shuffle = RandomState(seed).shuffle of the grid
-    out = fc.torsion_module.random_csearch(base, tors5, masks, n_out=10, seed=3)
+    out = fc.torsion_module.random_csearch_core(base, tors5, masks, n_out=10, seed=3)
     g = grid.copy()
     np.random.RandomState(3).shuffle(g)
     ref, _ = o.random_csearch(base, tors, masks, g, n_out=10)
@@ -590,7 +590,7 @@ def test_scan_tfd_over_the_device_generated_grid(fc):
         assert np.array_equal(rot, rot_g) and np.array_equal(keep, keep_g) and keep.sum() >= 1
     base, tors, masks = _chain_case(32, 4, seed=41)
     t5 = [tuple(int(v) for v in t) + (6,) for t in tors]
-    got = fc.torsion_module.clustered_csearch(base, t5, masks, n_out=10 ** 6)
+    got = fc.torsion_module.clustered_csearch_core(base, t5, masks, n_out=10 ** 6)
     angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 4)
     rot, keep = fc.torsion_module.torsion_scan_tfd(base, tors, masks, angles, tors, tfd_thresh=10)
     want = fc.torsion_module.torsion_scan(base, tors, masks, angles[np.flatnonzero(keep[1:])])[0]
@@ -847,7 +847,7 @@ def test_refining_drivers(fc, golden):
 def test_clustered_csearch_driver(fc):
     base, tors, masks = _chain_case(26, 3, seed=73)
     torsions = [tuple(t) + (6,) for t in tors]
-    out = fc.torsion_module.clustered_csearch(base, torsions, masks, n_out=10_000)
+    out = fc.torsion_module.clustered_csearch_core(base, torsions, masks, n_out=10_000)
     # oracle pipeline: scan -> keep rotated -> TFD prune
     angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 3)
     sc, rot = o.torsion_scan(base, tors, masks, angles)
@@ -1226,7 +1226,7 @@ def test_string_embed_vs_oracle(fc, seed, thresh):
     v2[1, 0] = v1[1, 0] * 0.5      # exactly parallel to ref_vec: the 180-degree-about-z branch
     angles = np.arange(12) * 30.0
     quads = np.array([[0, 1, r1, 9 + r2], [1, r1, 9 + r2, 9 + 5], [r1, 9 + r2, 9 + 5, 9 + 6]])
-    poses, acc, ok = fc.embeds.string_embed(m1, c1, v1, m2, c2, v2, angles, quads, thresh=thresh)
+    poses, acc, ok = fc.embeds.string_embed_poses(m1, c1, v1, m2, c2, v2, angles, quads, thresh=thresh)
     ok0, acc0, poses0 = o.string_embed(m1, m2, c1, v1, c2, v2, angles, quads, thresh=thresh)
     assert np.array_equal(ok, ok0)
     assert np.array_equal(acc, acc0)
@@ -1514,3 +1514,132 @@ def test_torsion_scan_prefix_tree_equals_row_kernel(fc, monkeypatch, case):
     pick = rng.choice(len(angles), 60, replace=False)
     o_out, o_rot = o.torsion_scan(base, tors, masks, angles[pick], thresh=1.5)
     assert np.array_equal(rot[pick], o_rot) and np.abs(out[pick] - o_out).max() < TOL
+
+
+# ---------------------------------------------------------------- reference-signature adapters
+def test_csearch_adapters_with_the_reference_signatures(fc):
+    """clustered_csearch(atoms, coords, torsions, graph, ...) / random_csearch(...) as FIRECODE's csearch calls them
+    (firecode/torsion_module.py:697-723) with duck-typed Torsion objects: rotation masks from this package's
+    rotation_mask over the bond graph, output == the numeric core == the oracle pipeline; log lines through logfunction"""
+    import networkx as nx
+    from types import SimpleNamespace
+
+    base, tors, masks = _chain_case(26, 3, seed=73)
+    graph = nx.path_graph(26)
+    atoms = np.array(["C"] * 26)
+    torsions = [SimpleNamespace(torsion=tuple(int(i) for i in t), n_fold=6) for t in tors]
+    for t, m in zip(torsions, masks):
+        assert np.array_equal(fc.torsion_module._get_rotation_mask(graph, t.torsion), m)
+    log = []
+    out = fc.torsion_module.clustered_csearch(atoms, base, torsions, graph, constrained_indices=None, n=100, n_out=10_000,
+                                              title="chain", logfunction=log.append, interactive_print=False,
+                                              write_torsions=False, debug=False)
+    angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 3)
+    sc, rot = o.torsion_scan(base, tors, masks, angles)
+    ref, _ = o.prune_conformers_tfd(np.concatenate([base[None], sc[rot != 0]]), tors)
+    assert out.shape == ref.shape and np.abs(out - ref).max() < TOL
+    assert any("Clustered CSearch on chain" in line for line in log) and any("6-fold" in line for line in log)
+    # random search: the reference shuffles with the global generator; `order` fixes the permutation
+    perm = np.random.default_rng(5).permutation(len(angles))
+    got = fc.torsion_module.random_csearch(atoms, base, torsions, graph, n_out=25, title="chain", logfunction=None,
+                                           interactive_print=False, order=perm)
+    ref_r, _ = o.random_csearch(base, tors, masks, angles[perm], n_out=25)
+    assert got.shape == ref_r.shape and np.abs(got - ref_r).max() < TOL
+    with pytest.raises(NotImplementedError):
+        fc.torsion_module.clustered_csearch(atoms, base, torsions, graph, write_torsions=True, logfunction=None)
+    with pytest.raises(fc.FirecodeHipInputError):
+        fc.torsion_module.clustered_csearch(atoms, base, [SimpleNamespace(torsion=(0, 1, 2, 3), n_fold=5)], graph, logfunction=None)
+
+
+class _FakeEmbedder:
+    """what cyclical_embed / string_embed read from FIRECODE's Embedder (firecode/embedder.py), nothing more"""
+
+    def __init__(self, objects, angles, clash_thresh, pairings_table=None):
+        from types import SimpleNamespace
+
+        self.objects = objects
+        self.systematic_angles = angles
+        self.options = SimpleNamespace(clash_thresh=clash_thresh, debug=False)
+        self.pairings_table = pairings_table or {}
+        self.internal_constraints = []
+        self.ids = [len(m.coords[0]) for m in objects]
+        self.embed, self.candidates, self.lines = "cyclical", 0, []
+
+    def log(self, msg="", p=True):
+        self.lines.append(msg)
+
+
+def _hypermolecules(mols):
+    """Hypermolecule-shaped objects (coords, reactive_indices, pivots of Pivot-shaped objects, reactive_atoms_classes_dict)
+    from synthetic_trimolecular's dictionaries"""
+    from types import SimpleNamespace
+
+    out = []
+    for m in mols:
+        atoms_of = {int(c): int(i) for i, c in m["reactive_cumnums"].items()}
+        ratom = {int(i): SimpleNamespace(cumnum=int(c)) for i, c in m["reactive_cumnums"].items()}
+        pivots = [[SimpleNamespace(start=np.asarray(s), end=np.asarray(e), pivot=np.asarray(s) - np.asarray(e),
+                                   meanpoint=(np.asarray(s) + np.asarray(e)) / 2, start_atom=ratom[atoms_of[int(cs)]],
+                                   end_atom=ratom[atoms_of[int(ce)]]) for s, e, cs, ce in plist] for plist in m["pivots"]]
+        out.append(SimpleNamespace(coords=m["coords"], reactive_indices=m["reactive_indices"], pivots=pivots,
+                                   reactive_atoms_classes_dict={0: ratom}))
+    return out
+
+
+@pytest.mark.parametrize("n_mols", [2, 3])
+def test_cyclical_embed_adapter_with_the_reference_signature(fc, n_mols):
+    """cyclical_embed(embedder, max_norm_delta) (firecode/embeds.py:180): reads the embedder's molecules, angles, pairings
+    and clash threshold, sets embedder.constrained_indices, returns the poses of the numeric cores (which are checked
+    against the literal oracle elsewhere); raises ZeroCandidatesError when nothing fits"""
+    mols = syn.synthetic_trimolecular(n_conf=(2, 1, 2), n_atoms=(9, 12, 8), seed=3, pivots_per_conf=(1, 2, 1))[:n_mols]
+    if n_mols == 2:
+        angles = o.cartesian_product(range(6), range(6)) * 2 * 45 / 5 - 45
+        ref, ref_ci = fc.embeds.cyclical_embed_bimolecular(mols, angles, clash_thresh=0.9, max_norm_delta=5.0)
+    else:
+        angles = o.cartesian_product(range(3), range(3), range(3)) * 2 * 45 / 2 - 45
+        ref, ref_ci = fc.embeds.cyclical_embed_trimolecular(mols, angles, clash_thresh=0.9)
+    emb = _FakeEmbedder(_hypermolecules(mols), angles, 0.9)
+    poses = fc.embeds.cyclical_embed(emb, max_norm_delta=5.0)
+    assert len(poses) > 0 and np.array_equal(poses, ref) and np.array_equal(emb.constrained_indices, ref_ci)
+    assert any("embed" in line for line in emb.lines)
+    tight = _FakeEmbedder(_hypermolecules(mols), angles, 50.0)  # every pose clashes at 50 A
+    with pytest.raises(fc.embeds.ZeroCandidatesError):
+        fc.embeds.cyclical_embed(tight)
+
+
+def test_string_embed_adapter_with_the_reference_signature(fc):
+    """string_embed(embedder) (firecode/embeds.py:51): orbitals from mol.get_r_atoms(c)[0], quadruplets of the joined bond
+    graph, embedder.constrained_indices repeated per pose (:161-178)"""
+    import networkx as nx
+    from types import SimpleNamespace
+
+    from firecode_amd.torsion_perception import get_quadruplets
+
+    rng = np.random.default_rng(75)
+    skel1, skel2 = syn.synthetic_skeleton(9, rng), syn.synthetic_skeleton(7, rng)
+    m1 = skel1[None] + rng.normal(scale=0.05, size=(3, 9, 3))
+    m2 = skel2[None] + rng.normal(scale=0.05, size=(2, 7, 3))
+    r1, r2 = 2, 4
+    c1 = m1[:, [r1]] + 1.2 * (m1[:, [r1]] - m1.mean(axis=1, keepdims=True))
+    c2 = m2[:, [r2]] + 1.2 * (m2[:, [r2]] - m2.mean(axis=1, keepdims=True))
+    v1, v2 = c1 - m1[:, [r1]], c2 - m2[:, [r2]]
+
+    def mol(coords, centers, vecs, reactive, n):
+        g = nx.path_graph(n)
+        nx.set_node_attributes(g, {i: "C" for i in range(n)}, "atoms")
+        return SimpleNamespace(coords=coords, graph=g, reactive_indices=np.array([reactive]),
+                               get_r_atoms=lambda c: [SimpleNamespace(center=centers[c], orb_vecs=vecs[c])])
+
+    angles = np.arange(12) * 30.0
+    emb = _FakeEmbedder([mol(m1, c1, v1, r1, 9), mol(m2, c2, v2, r2, 7)], angles, 1.2)
+    poses = fc.embeds.string_embed(emb)
+    joined = nx.path_graph(9)
+    for a, b in nx.path_graph(7).edges():
+        joined.add_edge(a + 9, b + 9)
+    joined.add_edge(r1, 9 + r2)
+    nx.set_node_attributes(joined, {i: "C" for i in range(16)}, "atoms")
+    quads = get_quadruplets(joined)
+    ref, acc, ok = fc.embeds.string_embed_poses(m1, c1, v1, m2, c2, v2, angles, quads, thresh=1.2)
+    ok0, acc0, poses0 = o.string_embed(m1, m2, c1, v1, c2, v2, angles, quads, thresh=1.2)
+    assert len(quads) > 0 and len(poses) > 0 and np.array_equal(poses, ref) and np.abs(poses - poses0).max() < TOL
+    assert np.array_equal(emb.constrained_indices, np.array([[[r1, 9 + r2]]] * len(poses)))
