@@ -547,7 +547,7 @@ static int ensemble_shard(fc_ensemble *e, int64_t rank, int64_t world, int64_t r
     if (e->bk_buckets > 0) {
       FC_TRY(e->bk.reserve((size_t)(512 + 2 * nb + 1) * sizeof(int)));
       FC_TRY(e->bk_off.reserve((size_t)((nb + 1) + (n_st + 1) + 8 * ((n_st + 7) / 8 + 1)) * sizeof(int)));  // offsets | supertile starts | per-XCD prefixes
-      FC_TRY(e->bk_list.reserve((size_t)(nb + e->pairq_cap / 512 + 1) * sizeof(int)));  // pieces of <= 512 pairs
+      FC_TRY(e->bk_list.reserve((size_t)(nb + e->pairq_cap / 256 + 1) * sizeof(int)));  // pieces of <= 512 pairs (256 in tuning builds)
       FC_TRY(e->sortq.reserve((size_t)e->pairq_cap * sizeof(uint64_t)));
     }
   }

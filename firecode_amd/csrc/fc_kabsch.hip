@@ -2250,6 +2250,9 @@ k_refine_pairs(const double *__restrict__ Xs, const double *__restrict__ G, int6
   // so that its 4 MB L2 sees an eighth of the column conformers, was built and measured on the 8.9e5-candidate
   // ensemble: 0.62 ms + 0.08 ms for the split against 0.44 ms -- the parts interleave the row blocks that the
   // screen's emission order keeps together.  Not kept.)
+  // counters[1] / [3] (statistics) are added once per wavefront, at the end: with counters[2] they share one line, and a
+  // wavefront's two or three atomics per 64 pairs on it -- 3e4 per launch at 9.45e5 candidates -- serialise at the L2
+  unsigned long long acc_refined = 0, acc_grey = 0;
   for (int64_t base = wave0 * 64; base < (int64_t)n_pairs; base += nwaves * 64) {
     const bool on = base + lane < (int64_t)n_pairs;
     const uint64_t e = pairq[on ? base + lane : base];
@@ -2341,13 +2344,15 @@ k_refine_pairs(const double *__restrict__ Xs, const double *__restrict__ G, int6
     }
     const uint64_t mo = __ballot(on), ms = __ballot(on && sim), mg = __ballot(on && grey);
     unsigned long long sbase = 0;
-    if (lane == 0) {
-      atomicAdd(&counters[1], (unsigned long long)__popcll(mo));
-      if (ms) sbase = atomicAdd(&counters[2], (unsigned long long)__popcll(ms));
-      if (mg) atomicAdd(&counters[3], (unsigned long long)__popcll(mg));
-    }
+    acc_refined += (unsigned long long)__popcll(mo);
+    acc_grey += (unsigned long long)__popcll(mg);
+    if (lane == 0 && ms) sbase = atomicAdd(&counters[2], (unsigned long long)__popcll(ms));
     sbase = __shfl(sbase, 0);
     if (on && sim) simq[sbase + (unsigned long long)__popcll(ms & ((1ull << lane) - 1ull))] = e;
+  }
+  if (lane == 0) {
+    if (acc_refined) atomicAdd(&counters[1], acc_refined);
+    if (acc_grey) atomicAdd(&counters[3], acc_grey);
   }
 }
 
@@ -2428,7 +2433,13 @@ k_bucket_count(const uint64_t *__restrict__ pairq, const unsigned long long *__r
 // a bucket in pieces of at most kBucketChunk pairs (one round of a workgroup: a bucket may hold 8 192 pairs, and one
 // workgroup walking those alone was the tail of the whole launch), encoded bucket | piece << 24, buckets ascending
 // (row block major: consecutive workgroups share their row block) -> list, their number -> bk[0]
-constexpr int kBucketChunk = 512;
+#ifndef FC_RB_CHUNK
+#define FC_RB_CHUNK 512
+#endif
+#ifndef FC_RB_WPS
+#define FC_RB_WPS 3
+#endif
+constexpr int kBucketChunk = FC_RB_CHUNK;
 __global__ void __launch_bounds__(1024)
 k_bucket_scan(const unsigned long long *__restrict__ counters, unsigned long long Q, int64_t n_buckets, int *__restrict__ bk,
               int *__restrict__ off, int *__restrict__ list, int *__restrict__ st_off, int *__restrict__ xoff, int n_st, int x_stride) {
@@ -2498,7 +2509,7 @@ k_bucket_scatter(const uint64_t *__restrict__ pairq, const unsigned long long *_
   }
 }
 
-__global__ void __launch_bounds__(kBucketChunk, 4)  // (second figure: wavefronts per SIMD -- two workgroups of eight per CU)
+__global__ void __launch_bounds__(kBucketChunk, FC_RB_WPS)  // (second figure: wavefronts per SIMD; 3 = 168 registers, no spills: 0.320 ms against 0.332 with 4 and 37 spilled)
 k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N, int64_t Npad, int A,
                  double max_rmsd, double max_dev, const double *__restrict__ energies, double max_dE, int IB,
                  int64_t world, uint64_t *__restrict__ bits, int64_t W, unsigned long long *__restrict__ counters,
@@ -2509,6 +2520,9 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
   __shared__ int s_next;
   __shared__ int s_bin[kBucketRows];          // pairs per row of the block, then their exclusive scan
   __shared__ uint64_t s_pairs[kBucketChunk];  // the item's pairs in row order
+  __shared__ unsigned s_wsim[kBucketChunk / 64], s_won[kBucketChunk / 64], s_wgrey[kBucketChunk / 64];  // per wavefront of the item ...
+  __shared__ unsigned long long s_wbase[kBucketChunk / 64];  // ... and where each wavefront's go in simq
+  unsigned long long acc_refined = 0, acc_grey = 0;          // (thread 0) counters[1], [3]: added once, at the end
   const unsigned long long n_pairs = counters[6];
   if (n_pairs > Q || n_pairs <= kRefineLanesMin) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2607,6 +2621,10 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
       __syncthreads();
     }
     const int n_item = p_end - p_begin;
+    // what this wavefront found in the item: set inside the round below, published behind it
+    uint64_t e_mine = 0ull, ms_mine = 0ull;
+    unsigned n_on = 0, n_grey = 0;
+    bool sim_mine = false;
 #ifdef FC_RB_NOCOMPUTE
     for (int p0 = wv * 64; p0 < 0; p0 += kBucketChunk) {
 #else
@@ -2614,6 +2632,7 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
 #endif
       const bool on = p0 + lane < n_item;
       const uint64_t e = s_pairs[on ? p0 + lane : p0];
+      e_mine = e;
       const unsigned i = (unsigned)(e >> 32), j = (unsigned)(e & 0xffffffffull);
       const double *__restrict__ qcol = lds + (j - (unsigned)j0);
       double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -2622,7 +2641,7 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
       // a chain of 50 L2 round trips: 0.51 ms for 9.45e5 candidates, no better than the straight walk); the Xs rows
       // beyond A are zeros up to a multiple of 4 atoms, and the passes run over all of them
 #ifndef FC_RB_AHEAD
-#define FC_RB_AHEAD 2
+#define FC_RB_AHEAD 4
 #endif
       constexpr int kAhead = FC_RB_AHEAD;
       auto load_row = [&](int a, double (&P)[3]) {
@@ -2632,8 +2651,14 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
         for (int c = 0; c < 3; ++c) P[c] = lds[(al * 3 + c) * 64 + (i & 63)];
 #else
         const double *__restrict__ row = Xs + (int64_t)(al * 3) * Npad;  // wave-uniform
+#ifdef FC_RB_SAMEROW  // tuning build (WRONG results): every lane reads the first lane's row -- one line per load
+        const unsigned iu = (unsigned)__builtin_amdgcn_readfirstlane((int)i) + (unsigned)(lane & 15);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) P[c] = (row + (int64_t)c * Npad)[iu];
+#else
 #pragma unroll
         for (int c = 0; c < 3; ++c) P[c] = (row + (int64_t)c * Npad)[i];
+#endif
 #endif
       };
       auto load_col = [&](int a, double (&Qv)[3]) {
@@ -2744,16 +2769,36 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
           atomicAnd(reinterpret_cast<unsigned long long *>(&bits[lrow * W + (j >> 6)]), ~(1ull << (j & 63)));
         }
       }
-      const uint64_t mo = __ballot(on), ms = __ballot(on && sim), mg = __ballot(on && grey);
-      unsigned long long sbase = 0;
-      if (lane == 0) {
-        atomicAdd(&counters[1], (unsigned long long)__popcll(mo));
-        if (ms) sbase = atomicAdd(&counters[2], (unsigned long long)__popcll(ms));
-        if (mg) atomicAdd(&counters[3], (unsigned long long)__popcll(mg));
-      }
-      sbase = __shfl(sbase, 0);
-      if (on && sim) simq[sbase + (unsigned long long)__popcll(ms & ((1ull << lane) - 1ull))] = e;
+      ms_mine = __ballot(on && sim);
+      n_on = (unsigned)__popcll(__ballot(on));
+      n_grey = (unsigned)__popcll(__ballot(on && grey));
+      sim_mine = on && sim;
     }
+    // ONE atomic per item for the similar-pair slots, the two statistics once per workgroup at the end.  (A wavefront's
+    // own atomics on counters[1..3] -- one line, two or three per 64 pairs, 3e4 per launch at 9.45e5 candidates -- were
+    // what both long-queue kernels waited for: they serialise at the L2, ~12 ns each, 0.35 of the 0.48 ms, whatever the
+    // loads did and however many workgroups ran.)
+    if (lane == 0) {
+      s_wsim[wv] = (unsigned)__popcll(ms_mine);
+      s_won[wv] = n_on;
+      s_wgrey[wv] = n_grey;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned tot = 0;
+      for (int w = 0; w < kBucketChunk / 64; ++w) {
+        tot += s_wsim[w];
+        acc_refined += s_won[w];
+        acc_grey += s_wgrey[w];
+      }
+      unsigned long long at = tot ? atomicAdd(&counters[2], (unsigned long long)tot) : 0ull;
+      for (int w = 0; w < kBucketChunk / 64; ++w) {
+        s_wbase[w] = at;
+        at += s_wsim[w];
+      }
+    }
+    __syncthreads();
+    if (sim_mine) simq[s_wbase[wv] + (unsigned long long)__popcll(ms_mine & ((1ull << lane) - 1ull))] = e_mine;
 #ifdef FC_RB_TIMELINE  // tuning build: 100 MHz ticks spent staging / computing (per wavefront), items, wave-rounds
     if (lane == 0 && wv == 0) {
       const unsigned long long tl2 = wall_clock64();
@@ -2763,6 +2808,10 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
       if (wv * 64 < n_item) atomicAdd(&counters[23], 1ull);
     }
 #endif
+  }
+  if (tid == 0) {
+    if (acc_refined) atomicAdd(&counters[1], acc_refined);
+    if (acc_grey) atomicAdd(&counters[3], acc_grey);
   }
 }
 
