@@ -40,6 +40,9 @@ int launch_level(const uint64_t *, int64_t, const uint64_t *, const uint8_t *, u
                  int64_t, int64_t, int64_t, int64_t, int64_t);
 int launch_copy_bytes(const uint8_t *, uint8_t *, int64_t);
 int launch_mask_init(uint64_t *, int64_t, int64_t, int64_t);
+int launch_ladder_pairs_many(const uint64_t *, uint64_t *, const unsigned long long *, const unsigned long long *,
+                             unsigned long long, unsigned long long, int64_t, int64_t, int64_t, const int64_t *, const int64_t *,
+                             int, uint64_t *, uint64_t *, unsigned long long *);
 int launch_ladder_pairs(const uint64_t *, uint64_t *, const unsigned long long *, const unsigned long long *,
                         unsigned long long, unsigned long long, int64_t, int64_t, int64_t, const int64_t *,
                         int, uint64_t *, unsigned long long *);
@@ -650,10 +653,21 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
     const unsigned long long ladder_cap =
         std::min<unsigned long long>(kPairLadderCap, std::max<unsigned long long>(1024, (unsigned long long)N * (N - 1) / 2));
     FC_TRY(e->levelmask.reserve((size_t)ladder_cap * (size_t)n_lv * sizeof(uint64_t)));
-    FC_TRY(launch_ladder_pairs(pairs_dev, e->levelmask.as<uint64_t>(), cnt + 2,
-                               pairs_are_final ? nullptr : cnt + 6,
-                               (unsigned long long)e->pairq_cap, ladder_cap, N, W, min_per_group,
-                               e->ladder_k.as<int64_t>(), n_lv, mb + (size_t)n_lv * W, cnt));
+    // long lists: a launch per level over the whole chip instead of one workgroup (fc_prune.hip); a host decision from
+    // the last similar-pair count seen for these coordinates -- either form is correct for any list
+    static const bool many_ok = [] {
+      const char *v = getenv("FC_LADDER_MANY");  // 0: always the one-workgroup ladder
+      return !(v && atoi(v) == 0);
+    }();
+    if (many_ok && n_lv >= 2 && e->last_similar > ((int64_t)1 << 17))
+      FC_TRY(launch_ladder_pairs_many(pairs_dev, e->levelmask.as<uint64_t>(), cnt + 2, pairs_are_final ? nullptr : cnt + 6,
+                                      (unsigned long long)e->pairq_cap, ladder_cap, N, W, min_per_group,
+                                      e->ladder_k.as<int64_t>(), ks.data(), n_lv, mb, mb + (size_t)n_lv * W, cnt));
+    else
+      FC_TRY(launch_ladder_pairs(pairs_dev, e->levelmask.as<uint64_t>(), cnt + 2,
+                                 pairs_are_final ? nullptr : cnt + 6,
+                                 (unsigned long long)e->pairq_cap, ladder_cap, N, W, min_per_group,
+                                 e->ladder_k.as<int64_t>(), n_lv, mb + (size_t)n_lv * W, cnt));
     // mask words and the 16 counters behind them (written by the kernel): one copy
     FC_TRY(d2h(words, mb + (size_t)n_lv * W, (size_t)(W + 16) * sizeof(uint64_t)));
     if (defer_slot >= 0) return FC_OK;
@@ -692,9 +706,12 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
 // result of a deferred pair ladder (after the caller's synchronisation); false: the kernel
 // declined (queue overflow / list too long) and the prune has to be redone synchronously
 // what a finished prune says about the length of this ensemble's candidate queue -> every workspace over its coordinates
-static void note_candidates(fc_ensemble *e, unsigned long long refined) {
+static void note_candidates(fc_ensemble *e, unsigned long long refined, unsigned long long similar) {
   int guard = 0;
-  for (fc_ensemble *w = e; w != nullptr && guard < 8; w = w->twin, ++guard) w->last_candidates = (int64_t)refined;
+  for (fc_ensemble *w = e; w != nullptr && guard < 8; w = w->twin, ++guard) {
+    w->last_candidates = (int64_t)refined;
+    w->last_similar = (int64_t)similar;
+  }
 }
 
 static bool ladder_collect(fc_ensemble *e, int64_t slot, uint8_t *mask_out, int64_t *levels,
@@ -703,7 +720,7 @@ static bool ladder_collect(fc_ensemble *e, int64_t slot, uint8_t *mask_out, int6
   const uint64_t *words = static_cast<const uint64_t *>(ctx().pinned) +
                           (size_t)slot * (size_t)(slot_stride > 0 ? slot_stride : W + 16);
   const uint64_t *cnt_host = words + W;
-  note_candidates(e, cnt_host[6]);  // (pairs the screen queued; valid also when the ladder declined)
+  note_candidates(e, cnt_host[6], cnt_host[2]);  // (pairs the screen queued; valid also when the ladder declined)
   if (cnt_host[9] == 0) return false;
   int64_t alive = 0;
   for (int64_t w = 0; w < W; ++w) alive += __builtin_popcountll(words[w]);
@@ -1206,7 +1223,7 @@ int fc_rmsd_simbits(fc_ensemble *ens, double max_rmsd, double max_dev, const dou
   FC_TRY(d2h(all.data(), ens->bits.p, all.size() * sizeof(uint64_t)));
   FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
   FC_TRY(sync());
-  note_candidates(ens, cnt[6]);
+  note_candidates(ens, cnt[6], cnt[2]);
   // words at or below the diagonal were never produced: define them as 0
   for (int64_t i = row_begin; i < row_end; ++i)
     for (int64_t w = 0; w < W; ++w)
@@ -1237,7 +1254,7 @@ int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const doubl
                        ens->simq.as<uint64_t>(), false, true);
   }
   FC_TRY(rc);
-  note_candidates(ens, cnt[6]);
+  note_candidates(ens, cnt[6], cnt[2]);
   if (stats) {
     stats[0] = ens->N * (ens->N - 1) / 2;
     stats[1] = (int64_t)cnt[1];
@@ -2971,7 +2988,7 @@ int fc_bench_refine(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t r
     unsigned long long h0[8] = {0};
     FC_TRY(d2h(h0, ens->counters.p, sizeof h0));
     FC_TRY(sync());
-    note_candidates(ens, h0[6]);
+    note_candidates(ens, h0[6], ens->last_similar < 0 ? 0 : (unsigned long long)ens->last_similar);
   }
   std::vector<hipEvent_t> &ev = c.ev_pool;
   while ((int64_t)ev.size() < 2 * reps) {

@@ -339,6 +339,7 @@ struct fc_ensemble {
   // reached the host had a long queue.  Either choice is correct for any queue (the kernels gate themselves on the
   // device-side length); -1: nothing seen yet.
   int64_t last_candidates = -1;
+  int64_t last_similar = -1;   // ... and the same for the ladder's form (one workgroup / a launch per level): similar pairs last seen
   fc::DevBuf bits_full;        // N x W uint64: whole bit matrix rebuilt from gathered pairs
   fc::DevBuf item_table;       // screen items (lb << 32 | jt) that touch the upper triangle
   int64_t item_key[4] = {-1, -1, -1, -1}, item_total = 0;

@@ -1883,7 +1883,7 @@ k_subset_stats(const double *__restrict__ Xs, int64_t Npad, int A, float *__rest
 // workgroups return at once.  Results do not depend on the verdict (both screens only ever add
 // candidates); time is bounded by fp32 screen + fp64 screen whatever the data look like.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_screen_verdict(const double *__restrict__ Xa, const double *__restrict__ G, int A, double A_thr2,
                  const uint64_t *__restrict__ pairq, unsigned long long Q, unsigned long long max_false,
                  unsigned long long *__restrict__ counters, int optimistic) {
@@ -1894,19 +1894,29 @@ k_screen_verdict(const double *__restrict__ Xa, const double *__restrict__ G, in
   }
   const unsigned long long avail = n < Q ? n : Q;
   const unsigned long long sampled = avail < 256ull ? avail : 256ull;
+  // FOUR lanes per sampled pair (atoms a = sub, sub + 4, ...; the partial covariances meet by two shuffle steps): this
+  // kernel is one workgroup in front of the refine on its lane, and one lane walking 2 x 50 atoms of dependent loads
+  // took 50-90 us of every prune with a long queue
+  const unsigned sample = threadIdx.x >> 2, sub = threadIdx.x & 3u;
   int pass = 0;
-  if (threadIdx.x < sampled) {
-    const uint64_t pr = pairq[(unsigned long long)threadIdx.x * avail / sampled];
+  {
+    const bool on = sample < sampled;
+    const uint64_t pr = pairq[on ? (unsigned long long)sample * avail / sampled : 0ull];
     const int64_t i = (int64_t)(pr >> 32), j = (int64_t)(pr & 0xffffffffull);
     const double *__restrict__ p = Xa + i * (int64_t)A * 3, *__restrict__ q = Xa + j * (int64_t)A * 3;
     double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int a = 0; a < A; ++a) {
+    for (int a = (int)sub; a < A; a += 4) {
 #pragma unroll
       for (int x = 0; x < 3; ++x)
 #pragma unroll
         for (int y = 0; y < 3; ++y) B[x * 3 + y] = fma(p[a * 3 + x], q[a * 3 + y], B[x * 3 + y]);
     }
-    pass = kabsch_may_be_below(B, G[i] + G[j], A_thr2) ? 1 : 0;
+#pragma unroll
+    for (int e9 = 0; e9 < 9; ++e9) {
+      B[e9] += __shfl_xor(B[e9], 1);
+      B[e9] += __shfl_xor(B[e9], 2);
+    }
+    pass = (on && sub == 0 && kabsch_may_be_below(B, G[i] + G[j], A_thr2)) ? 1 : 0;
   }
   const int passed = __syncthreads_count(pass);
   if (threadIdx.x == 0) {
@@ -3649,7 +3659,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         // a false candidate costs ~1 ns (staging, one atom pass of the refine: tools/broad_probe.py), a second
         // screen in fp64 ~0.017 ns per owned pair at 52 padded atoms and in proportion to them beyond
         const auto max_false = (unsigned long long)std::max(1024.0, 0.015 * ((double)A4 / 52.0) * owned_pairs);
-        hipLaunchKernelGGL(k_screen_verdict, dim3(1), dim3(256), 0, ctx().stream, e->Xa.as<double>(),
+        hipLaunchKernelGGL(k_screen_verdict, dim3(1), dim3(1024), 0, ctx().stream, e->Xa.as<double>(),
                            e->G.as<double>(), (int)e->A, A_thr2, e->pairq.as<uint64_t>(),
                            (unsigned long long)e->pairq_cap, max_false, cnt, ctx().optimistic_screen ? 1 : 0);
         FC_TRY(check_launch("k_screen_verdict"));

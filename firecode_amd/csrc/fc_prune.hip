@@ -962,6 +962,196 @@ static int g_drop_later = 0;
 void prune_conventions_set(int drop_later) { g_drop_later = drop_later ? 1 : 0; }
 int prune_drop_later() { return g_drop_later; }
 
+// ---------------------------------------------------------------------------
+// The same ladder for LONG pair lists, on the whole chip (round 4).  k_ladder_pairs is ONE workgroup streaming every
+// level's bucket: 7.6e5 similar pairs (the ensemble without clusters of the bench's `secondary` block) are ~3 M pair
+// visits = 24 MB through one CU: 0.38 ms, with k_pair_buckets' 0.10 ms (one wave-wide atomic per 64 pairs on each
+// level's counter: 1.2e4 per counter, serialised at the L2) most of the lane's time per prune.  Here a level is a
+// launch: every workgroup takes the current mask into LDS, walks its share of the level's pairs with LDS atomics on a
+// private copy of the next mask and ANDs that copy into the global one; the LAST workgroup to finish (a ticket) flips
+// the current / next roles and resets the old current mask to all-ones -- what the next level ANDs into.  Whether a level
+// runs (min_per_group * k < active) every workgroup decides for itself from the same current mask.  State: counters[10]
+// = which of the two mask buffers is current, [11] = tickets, [8] = levels run.  Levels that cannot run at this N are
+// not launched.  Chosen on the host from the last similar-pair count seen for these coordinates (a launch per level costs
+// a short list more than the one-workgroup walk).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool ladder_declined(const unsigned long long *n_pairs_ptr, const unsigned long long *n_cand_ptr,
+                                                unsigned long long cand_cap, unsigned long long cap,
+                                                const unsigned long long *counters) {
+  return (n_cand_ptr != nullptr && *n_cand_ptr > cand_cap) || *n_pairs_ptr > cap || counters[12] != 0ull;
+}
+
+__global__ void __launch_bounds__(256)
+k_ladder_many_init(uint64_t *__restrict__ buf_a, uint64_t *__restrict__ buf_b, int64_t N, int64_t W,
+                   unsigned long long *__restrict__ counters) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w < W) {
+    const int64_t lo = w * 64;
+    buf_a[w] = (lo + 64 <= N) ? ~0ull : ((lo < N) ? ((1ull << (N - lo)) - 1ull) : 0ull);
+    buf_b[w] = ~0ull;
+  }
+  if (w == 0) counters[10] = 0ull, counters[11] = 0ull, counters[8] = 0ull;
+}
+
+constexpr int kLadderManyThreads = 1024;
+__global__ void __launch_bounds__(kLadderManyThreads)
+k_ladder_many_level(const uint64_t *__restrict__ src, const unsigned long long *__restrict__ n_src_ptr, int64_t k, int64_t N,
+                    int64_t W, int64_t min_per_group, uint64_t *__restrict__ buf_a, uint64_t *__restrict__ buf_b,
+                    unsigned long long *__restrict__ counters, int drop_later, const unsigned long long *__restrict__ n_pairs_ptr,
+                    const unsigned long long *__restrict__ n_cand_ptr, unsigned long long cand_cap, unsigned long long cap) {
+  extern __shared__ unsigned long long lm[];  // cur[W] | nxt[W]
+  __shared__ int s_count;
+  __shared__ unsigned s_last;
+  if (ladder_declined(n_pairs_ptr, n_cand_ptr, cand_cap, cap, counters)) return;
+  const int tid = threadIdx.x;
+  const unsigned long long which = counters[10];
+  uint64_t *__restrict__ cur_g = which ? buf_b : buf_a, *__restrict__ nxt_g = which ? buf_a : buf_b;
+  unsigned long long *cur = lm, *nxt = lm + W;
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+  int c = 0;
+  for (int64_t w = tid; w < W; w += kLadderManyThreads) {
+    const unsigned long long v = cur_g[w];
+    cur[w] = v;
+    nxt[w] = ~0ull;
+    c += __popcll(v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((tid & 63) == 0 && c) atomicAdd(&s_count, c);
+  __syncthreads();
+  if (!((k == 1) || (min_per_group * k < (int64_t)s_count))) return;  // the same decision in every workgroup
+  const unsigned long long n_src = *n_src_ptr;
+  const uint32_t n32 = (uint32_t)N;
+  for (unsigned long long p = (unsigned long long)blockIdx.x * kLadderManyThreads + tid; p < n_src; p += (unsigned long long)gridDim.x * kLadderManyThreads) {
+    const uint64_t e = src[p];
+    const uint32_t i = (uint32_t)(e >> 32), j = (uint32_t)(e & 0xffffffffull);
+    if (j > i && j < n32 && ((cur[i >> 6] >> (i & 63)) & 1ull) && ((cur[j >> 6] >> (j & 63)) & 1ull)) {
+      const uint32_t kill = drop_later ? j : i;
+      atomicAnd(&nxt[kill >> 6], ~(1ull << (kill & 63)));
+    }
+  }
+  __syncthreads();
+  for (int64_t w = tid; w < W; w += kLadderManyThreads) {
+    const unsigned long long v = blockIdx.x == 0 ? (nxt[w] & cur[w]) : nxt[w];  // (workgroup 0 carries the current mask over)
+    if (v != ~0ull) atomicAnd(reinterpret_cast<unsigned long long *>(&nxt_g[w]), v);
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&counters[11], 1ull) == (unsigned long long)gridDim.x - 1ull ? 1u : 0u;
+  __syncthreads();
+  if (s_last) {  // everyone else has read the current mask and added its part: swap the roles
+    for (int64_t w = tid; w < W; w += kLadderManyThreads) cur_g[w] = ~0ull;
+    if (tid == 0) {
+      counters[10] = 1ull - which;
+      counters[11] = 0ull;
+      counters[8] += 1ull;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_ladder_many_finish(const uint64_t *__restrict__ buf_a, const uint64_t *__restrict__ buf_b, int64_t W,
+                     uint64_t *__restrict__ mask_out, unsigned long long *__restrict__ counters,
+                     const unsigned long long *__restrict__ n_pairs_ptr, const unsigned long long *__restrict__ n_cand_ptr,
+                     unsigned long long cand_cap, unsigned long long cap) {
+  const int tid = threadIdx.x;
+  const bool declined = ladder_declined(n_pairs_ptr, n_cand_ptr, cand_cap, cap, counters);
+  if (!declined) {
+    const uint64_t *__restrict__ cur = counters[10] ? buf_b : buf_a;
+    for (int64_t w = tid; w < W; w += 256) mask_out[w] = cur[w];
+  }
+  __syncthreads();
+  if (tid == 0) counters[9] = declined ? 0ull : 1ull;
+  if (tid < 16) mask_out[W + tid] = tid == 9 ? (declined ? 0ull : 1ull) : counters[tid];  // ([8] = levels run, kept by the levels)
+}
+
+// k_pair_buckets for long lists: the slots of a level are reserved once per WORKGROUP of sixteen wavefronts (the
+// one-atomic-per-wavefront form serialises 1.2e4 atomics per level counter at 7.6e5 pairs: 0.10 ms)
+__global__ void __launch_bounds__(1024)
+k_pair_buckets_many(const uint64_t *__restrict__ pairs, const unsigned long long *__restrict__ n_pairs_ptr,
+                    unsigned long long cap, int64_t N, const int64_t *__restrict__ ladder, int n_ladder,
+                    uint64_t *__restrict__ buckets, unsigned long long *__restrict__ level_cnt,
+                    const unsigned long long *__restrict__ n_cand_ptr, unsigned long long cand_cap) {
+  __shared__ unsigned s_wcnt[16][32];
+  __shared__ unsigned long long s_base[32];
+  const unsigned long long P = *n_pairs_ptr;
+  if (P > cap) return;
+  if (n_cand_ptr != nullptr && *n_cand_ptr > cand_cap) return;
+  const uint32_t n32 = (uint32_t)N;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 1024ull;
+  for (unsigned long long base = (unsigned long long)blockIdx.x * 1024ull; base < P; base += stride) {  // block-uniform
+    const unsigned long long p = base + tid;
+    const uint64_t e = p < P ? pairs[p] : ~0ull;
+    const uint32_t i = (uint32_t)(e >> 32), j = (uint32_t)(e & 0xffffffffull);
+    const bool valid = j > i && j < n32;
+    uint32_t mine = 0;
+    for (int l = 0; l < n_ladder; ++l) {
+      const uint32_t k = (uint32_t)ladder[l];
+      bool same = false;
+      if (k != 1u) {
+        const uint32_t chunk = n32 / k;
+        if (valid && chunk != 0) {
+          uint32_t ci = i / chunk, cj = j / chunk;
+          if (ci > k - 1) ci = k - 1;
+          if (cj > k - 1) cj = k - 1;
+          same = ci == cj;
+        }
+      }
+      if (same) mine |= 1u << l;
+      const unsigned c = (unsigned)__popcll(__ballot(same));
+      if (lane == l) s_wcnt[wv][l] = c;
+    }
+    __syncthreads();
+    if (tid < n_ladder) {
+      unsigned tot = 0;
+      for (int w = 0; w < 16; ++w) tot += s_wcnt[w][tid];
+      s_base[tid] = tot ? atomicAdd(&level_cnt[tid * kCntLevelStride], (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
+    for (int l = 0; l < n_ladder; ++l) {
+      const bool same = (mine >> l) & 1u;
+      const uint64_t m = __ballot(same);
+      if (m == 0) continue;  // wave-uniform
+      unsigned before = 0;
+      for (int w = 0; w < wv; ++w) before += s_wcnt[w][l];
+      if (same) buckets[(unsigned long long)l * cap + s_base[l] + before + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = e;
+    }
+    __syncthreads();  // (the counts are overwritten by the next round)
+  }
+}
+
+int launch_ladder_pairs_many(const uint64_t *pairs_dev, uint64_t *buckets_dev, const unsigned long long *n_pairs_dev,
+                             const unsigned long long *n_cand_dev, unsigned long long cand_cap, unsigned long long cap,
+                             int64_t N, int64_t W, int64_t min_per_group, const int64_t *ladder_dev, const int64_t *ladder_host,
+                             int n_ladder, uint64_t *mask_bufs_dev, uint64_t *mask_out_dev, unsigned long long *counters_dev) {
+  hipStream_t st = ctx().stream;
+  hipLaunchKernelGGL(k_pair_buckets_many, dim3((unsigned)ctx().n_cu), dim3(1024), 0, st, pairs_dev, n_pairs_dev, cap, N,
+                     ladder_dev, n_ladder, buckets_dev, counters_dev + kCntLevel, n_cand_dev, cand_cap);
+  FC_TRY(check_launch("k_pair_buckets_many"));
+  uint64_t *buf_a = mask_bufs_dev, *buf_b = mask_bufs_dev + W;
+  hipLaunchKernelGGL(k_ladder_many_init, dim3((unsigned)ceil_div(W, 256)), dim3(256), 0, st, buf_a, buf_b, N, W, counters_dev);
+  FC_TRY(check_launch("k_ladder_many_init"));
+  const size_t lds = (size_t)2 * W * sizeof(uint64_t);
+  for (int l = 0; l < n_ladder; ++l) {
+    const int64_t k = ladder_host[l];
+    const uint64_t *src = k == 1 ? pairs_dev : buckets_dev + (unsigned long long)l * cap;
+    const unsigned long long *n_src = k == 1 ? n_pairs_dev : counters_dev + kCntLevel + kCntLevelStride * l;
+    static const unsigned many_grid = [] {
+      const char *v = getenv("FC_LADDER_MANY_GRID");  // workgroups per level launch (tuning knob)
+      const long g = v ? std::strtol(v, nullptr, 10) : 16;  // (2 .. 256 measured at 7.6e5 pairs: 16-32 best; many workgroups pay in global atomics and tickets)
+      return (unsigned)(g >= 1 && g <= 4096 ? g : 16);
+    }();
+    hipLaunchKernelGGL(k_ladder_many_level, dim3(many_grid), dim3(kLadderManyThreads), lds, st, src, n_src, k, N, W, min_per_group,
+                       buf_a, buf_b, counters_dev, g_drop_later, n_pairs_dev, n_cand_dev, cand_cap, cap);
+    FC_TRY(check_launch("k_ladder_many_level"));
+  }
+  hipLaunchKernelGGL(k_ladder_many_finish, dim3(1), dim3(256), 0, st, buf_a, buf_b, W, mask_out_dev, counters_dev, n_pairs_dev,
+                     n_cand_dev, cand_cap, cap);
+  return check_launch("k_ladder_many_finish");
+}
+
 int launch_ladder_pairs(const uint64_t *pairs_dev, uint64_t *buckets_dev,
                         const unsigned long long *n_pairs_dev, const unsigned long long *n_cand_dev,
                         unsigned long long cand_cap, unsigned long long cap, int64_t N, int64_t W,
