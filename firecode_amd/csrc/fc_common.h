@@ -266,7 +266,8 @@ constexpr double kScreenMargin = 1e-6;
 // shorter ones are a latency problem and stay with the 8-lanes-per-pair walk of k_simbits_refine
 constexpr unsigned long long kRefineLanesMin = 1ull << 17;
 
-// uint64 words of fc_ensemble::counters: [0..10] queue lengths and flags, [11] "the fp64 screen has to run again" (k_screen_verdict),
+// uint64 words of fc_ensemble::counters: [0..10] queue lengths and flags, [32] / [33] mask roles and tickets of the per-level pair
+// ladder, [34] / [35] passed samples and tickets of the screen verdict, [11] "the fp64 screen has to run again" (k_screen_verdict),
 // [13] units queued by the subset stage of the lean fp32 screen, [15] its density verdict (1 = dense),
 // [63] scratch of the screen launcher; [64 + 16 l] fill level of the pair ladder's bucket of level l -- ONE PER
 // 128-BYTE LINE: atomics on words of one line serialise at the memory side (18 level counters in three lines cost

@@ -1883,21 +1883,23 @@ k_subset_stats(const double *__restrict__ Xs, int64_t Npad, int A, float *__rest
 // workgroups return at once.  Results do not depend on the verdict (both screens only ever add
 // candidates); time is bounded by fp32 screen + fp64 screen whatever the data look like.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 k_screen_verdict(const double *__restrict__ Xa, const double *__restrict__ G, int A, double A_thr2,
                  const uint64_t *__restrict__ pairq, unsigned long long Q, unsigned long long max_false,
                  unsigned long long *__restrict__ counters, int optimistic) {
   const unsigned long long n = counters[6];
-  if (n <= max_false) {  // block-uniform
-    if (threadIdx.x == 0) counters[11] = 0ull;
+  if (n <= max_false) {  // uniform over the launch
+    if (threadIdx.x == 0 && blockIdx.x == 0) counters[11] = 0ull;
     return;
   }
   const unsigned long long avail = n < Q ? n : Q;
   const unsigned long long sampled = avail < 256ull ? avail : 256ull;
-  // FOUR lanes per sampled pair (atoms a = sub, sub + 4, ...; the partial covariances meet by two shuffle steps): this
-  // kernel is one workgroup in front of the refine on its lane, and one lane walking 2 x 50 atoms of dependent loads
-  // took 50-90 us of every prune with a long queue
-  const unsigned sample = threadIdx.x >> 2, sub = threadIdx.x & 3u;
+  // FOUR lanes per sampled pair (atoms a = sub, sub + 4, ...; the partial covariances meet by two shuffle steps) in FOUR
+  // workgroups of 256 threads: this kernel sits in front of the refine on its lane, and one lane walking 2 x 50 atoms of
+  // dependent loads took 50-90 us of every prune with a long queue.  (One workgroup of 1 024 threads does not find room
+  // on a CU beside the next prune's screen, whose workgroups hold two register sets per SIMD: it waited for a CU to
+  // drain, 0.03 ms per step of the pipelined prune.)  counters[34] / [35]: samples that passed / workgroups done.
+  const unsigned sample = blockIdx.x * 64u + (threadIdx.x >> 2), sub = threadIdx.x & 3u;
   int pass = 0;
   {
     const bool on = sample < sampled;
@@ -1918,13 +1920,20 @@ k_screen_verdict(const double *__restrict__ Xa, const double *__restrict__ G, in
     }
     pass = (on && sub == 0 && kabsch_may_be_below(B, G[i] + G[j], A_thr2)) ? 1 : 0;
   }
-  const int passed = __syncthreads_count(pass);
+  const int passed_here = __syncthreads_count(pass);
   if (threadIdx.x == 0) {
-    const double est_false = (double)n * (1.0 - (double)passed / (double)sampled);
-    const bool redo = est_false > (double)max_false;
-    counters[11] = (redo && !optimistic) ? 1ull : 0ull;
-    if (redo) counters[4] = 0ull, counters[6] = 0ull;
-    if (redo && optimistic) counters[12] = 1ull;  // no fp64 launch behind this one: the pair ladder declines (Context::optimistic_screen)
+    atomicAdd(&counters[34], (unsigned long long)passed_here);
+    __threadfence();
+    if (atomicAdd(&counters[35], 1ull) == (unsigned long long)gridDim.x - 1ull) {  // the last workgroup decides
+      const unsigned long long passed = atomicAdd(&counters[34], 0ull);
+      const double est_false = (double)n * (1.0 - (double)passed / (double)sampled);
+      const bool redo = est_false > (double)max_false;
+      counters[11] = (redo && !optimistic) ? 1ull : 0ull;
+      if (redo) counters[4] = 0ull, counters[6] = 0ull;
+      if (redo && optimistic) counters[12] = 1ull;  // no fp64 launch behind this one: the pair ladder declines (Context::optimistic_screen)
+      counters[34] = 0ull;
+      counters[35] = 0ull;
+    }
   }
 }
 
@@ -3659,7 +3668,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         // a false candidate costs ~1 ns (staging, one atom pass of the refine: tools/broad_probe.py), a second
         // screen in fp64 ~0.017 ns per owned pair at 52 padded atoms and in proportion to them beyond
         const auto max_false = (unsigned long long)std::max(1024.0, 0.015 * ((double)A4 / 52.0) * owned_pairs);
-        hipLaunchKernelGGL(k_screen_verdict, dim3(1), dim3(1024), 0, ctx().stream, e->Xa.as<double>(),
+        hipLaunchKernelGGL(k_screen_verdict, dim3(4), dim3(256), 0, ctx().stream, e->Xa.as<double>(),
                            e->G.as<double>(), (int)e->A, A_thr2, e->pairq.as<uint64_t>(),
                            (unsigned long long)e->pairq_cap, max_false, cnt, ctx().optimistic_screen ? 1 : 0);
         FC_TRY(check_launch("k_screen_verdict"));

@@ -970,8 +970,8 @@ int prune_drop_later() { return g_drop_later; }
 // launch: every workgroup takes the current mask into LDS, walks its share of the level's pairs with LDS atomics on a
 // private copy of the next mask and ANDs that copy into the global one; the LAST workgroup to finish (a ticket) flips
 // the current / next roles and resets the old current mask to all-ones -- what the next level ANDs into.  Whether a level
-// runs (min_per_group * k < active) every workgroup decides for itself from the same current mask.  State: counters[10]
-// = which of the two mask buffers is current, [11] = tickets, [8] = levels run.  Levels that cannot run at this N are
+// runs (min_per_group * k < active) every workgroup decides for itself from the same current mask.  State: counters[32]
+// = which of the two mask buffers is current, [33] = tickets, [8] = levels run.  Levels that cannot run at this N are
 // not launched.  Chosen on the host from the last similar-pair count seen for these coordinates (a launch per level costs
 // a short list more than the one-workgroup walk).
 // ---------------------------------------------------------------------------
@@ -990,7 +990,7 @@ k_ladder_many_init(uint64_t *__restrict__ buf_a, uint64_t *__restrict__ buf_b, i
     buf_a[w] = (lo + 64 <= N) ? ~0ull : ((lo < N) ? ((1ull << (N - lo)) - 1ull) : 0ull);
     buf_b[w] = ~0ull;
   }
-  if (w == 0) counters[10] = 0ull, counters[11] = 0ull, counters[8] = 0ull;
+  if (w == 0) counters[32] = 0ull, counters[33] = 0ull, counters[8] = 0ull;
 }
 
 constexpr int kLadderManyThreads = 1024;
@@ -1004,7 +1004,7 @@ k_ladder_many_level(const uint64_t *__restrict__ src, const unsigned long long *
   __shared__ unsigned s_last;
   if (ladder_declined(n_pairs_ptr, n_cand_ptr, cand_cap, cap, counters)) return;
   const int tid = threadIdx.x;
-  const unsigned long long which = counters[10];
+  const unsigned long long which = counters[32];
   uint64_t *__restrict__ cur_g = which ? buf_b : buf_a, *__restrict__ nxt_g = which ? buf_a : buf_b;
   unsigned long long *cur = lm, *nxt = lm + W;
   if (tid == 0) s_count = 0;
@@ -1038,13 +1038,13 @@ k_ladder_many_level(const uint64_t *__restrict__ src, const unsigned long long *
   }
   __threadfence();
   __syncthreads();
-  if (tid == 0) s_last = atomicAdd(&counters[11], 1ull) == (unsigned long long)gridDim.x - 1ull ? 1u : 0u;
+  if (tid == 0) s_last = atomicAdd(&counters[33], 1ull) == (unsigned long long)gridDim.x - 1ull ? 1u : 0u;
   __syncthreads();
   if (s_last) {  // everyone else has read the current mask and added its part: swap the roles
     for (int64_t w = tid; w < W; w += kLadderManyThreads) cur_g[w] = ~0ull;
     if (tid == 0) {
-      counters[10] = 1ull - which;
-      counters[11] = 0ull;
+      counters[32] = 1ull - which;
+      counters[33] = 0ull;
       counters[8] += 1ull;
     }
   }
@@ -1058,7 +1058,7 @@ k_ladder_many_finish(const uint64_t *__restrict__ buf_a, const uint64_t *__restr
   const int tid = threadIdx.x;
   const bool declined = ladder_declined(n_pairs_ptr, n_cand_ptr, cand_cap, cap, counters);
   if (!declined) {
-    const uint64_t *__restrict__ cur = counters[10] ? buf_b : buf_a;
+    const uint64_t *__restrict__ cur = counters[32] ? buf_b : buf_a;
     for (int64_t w = tid; w < W; w += 256) mask_out[w] = cur[w];
   }
   __syncthreads();
