@@ -643,9 +643,11 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
   if (pairs_dev != nullptr && lds_ok) {
     // sparse similarity (the usual case): the whole ladder is ONE launch over the pair list
     if (e->ladder_k_n != n_lv || e->ladder_k_mpg != min_per_group) {
+      // the source of the (asynchronous) copy lives with the ensemble: no host wait here -- a wait at this point sat
+      // between the refine and the ladder of every drop-in call (each creates its ensemble) and cost it ~45 us
+      e->ladder_k_host = ks;
       FC_TRY(e->ladder_k.reserve(ks.size() * sizeof(int64_t)));
-      FC_TRY(h2d(e->ladder_k.p, ks.data(), ks.size() * sizeof(int64_t)));
-      FC_TRY(sync());  // ks is a local: the copy must finish before it goes out of scope
+      FC_TRY(h2d(e->ladder_k.p, e->ladder_k_host.data(), ks.size() * sizeof(int64_t)));
       e->ladder_k_n = n_lv;
       e->ladder_k_mpg = min_per_group;
     }

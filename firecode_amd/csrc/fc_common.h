@@ -353,6 +353,7 @@ struct fc_ensemble {
   fc::DevBuf ladder;           // (levels+1) x W mask words of the fused single-GPU ladder
   fc::DevBuf ladder_k;         // the ladder values that can apply at this N (int64), for k_ladder_pairs
   fc::DevBuf levelmask;        // per similar pair: ladder levels at which it shares a chunk
+  std::vector<int64_t> ladder_k_host;  // source of ladder_k's upload
   int ladder_k_n = -1;
   int64_t ladder_k_mpg = -1;
   fc::DevBuf counters;         // 8 x uint64
