@@ -3752,7 +3752,15 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
     return !(v && atoi(v) == 0);
   }();
   const size_t lds_bk = (size_t)(((e->A + 3) & ~(int64_t)3) * 3 * 64) * sizeof(double);
-  if (lanes && buckets && e->bk_buckets > 0 && lds_bk <= kLdsLimit && e->last_candidates > (int64_t)kRefineLanesMin) {
+  // the column tile shares the CU's LDS with the kernel's own arrays (bins, sorted pairs, per-wavefront sums): 104 atoms
+  // are 156 KB of tile and do not fit beside them (tools/refine_stress.py found that launch refused)
+  static const size_t lds_bk_static = [] {
+    hipFuncAttributes fa{};
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_refine_buckets)) == hipSuccess ? (size_t)fa.sharedSizeBytes
+                                                                                                        : (size_t)(16 * 1024);
+  }();
+  if (lanes && buckets && e->bk_buckets > 0 && lds_bk + lds_bk_static <= kLdsLimit &&
+      e->last_candidates > (int64_t)kRefineLanesMin) {
     auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
     const unsigned NT = (unsigned)(e->Npad >> 6);
     const BucketGeom geom{NT, (NT + 7) / 8};

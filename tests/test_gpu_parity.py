@@ -263,11 +263,13 @@ def test_fp32_screen_far_from_the_origin(fc, monkeypatch):
     assert _lib.screen_last_kind() in (16, 32)
 
 
-@pytest.mark.parametrize("n,a,seed,thr", [(2200, 30, 5, 0.75), (1500, 23, 9, 0.9)])
+@pytest.mark.parametrize("n,a,seed,thr", [(2200, 30, 5, 0.75), (1500, 23, 9, 0.9), (1500, 100, 12, 0.9), (1500, 104, 11, 0.9)])
 def test_long_candidate_queue_refine_vs_oracle(fc, n, a, seed, thr):
     """More than 2^17 candidates per prune: the queue is ordered by (128-row block, 64-column tile) bucket
     (k_bucket_count / _scan / _scatter) and refined bucket by bucket with the column tile in LDS (k_refine_buckets;
-    odd atom count: padded row).  Every other test's queue is short enough for the 8-lanes-per-pair kernel.
+    odd atom count: padded row; 100 atoms: the largest column tile that fits LDS beside the kernel's own arrays; 104: the
+    tile alone would fit, tile + arrays do not, and the queue is walked as it lies).  Every other test's queue is short
+    enough for the 8-lanes-per-pair kernel.
     Similarity bits (the refine's atomicAnd path), similar-pair count, grey count and masks with and without an
     energy window against the oracle's all-pairs matrix."""
     from firecode_amd._lib import unpack_bits
