@@ -569,8 +569,12 @@ __host__ __device__ __forceinline__ bool kabsch_quaternion_qcp(const double (&B)
 //     rounding amplified by 1 / (relative gap product) <= 1 / 2e-3; what the residual test caught beyond that was a
 //     Newton iteration that had not converged, which the returned flag now says directly (NaN included).
 // tools/qcp_host_check.cpp compares both forms with the Jacobi sweeps.
-__host__ __device__ __forceinline__ bool kabsch_quaternion_qcp_lean(const double (&B)[9], double GpGq, double (&Q)[4],
-                                                                    int *iterations = nullptr) {
+// The three parts of it, so that a caller with several pairs per lane can run their Newton iterations in ONE loop
+// (independent chains side by side instead of one dependent chain at a time):
+struct QcpLeanPoly {
+  double C2, C1, C0, n2;  // lambda^4 + C2 lambda^2 + C1 lambda + C0;  n2 = |B|_F^2
+};
+__host__ __device__ __forceinline__ QcpLeanPoly qcp_lean_polynomial(const double (&B)[9]) {
 #pragma clang fp contract(fast)
   const double Sxx = B[0], Sxy = B[3], Sxz = B[6];
   const double Syx = B[1], Syy = B[4], Syz = B[7];
@@ -583,28 +587,28 @@ __host__ __device__ __forceinline__ bool kabsch_quaternion_qcp_lean(const double
   const double detB = Sxx * c00 + Sxy * c01 + Sxz * c02;
   const double e2 = c00 * c00 + c01 * c01 + c02 * c02 + c10 * c10 + c11 * c11 + c12 * c12 +
                     c20 * c20 + c21 * c21 + c22 * c22;
-  const double C2 = -2.0 * n2, C1 = -8.0 * detB, C0 = n2 * n2 - 4.0 * e2;
-  const double S = 0.5 * GpGq;
-  double x = S, delta = 0.0;
-  int it = 0;
-  for (; it < 64; ++it) {
-    const double x2 = x * x;
-    const double b = (x2 + C2) * x;
-    const double a = b + C1;
-    const double den = 2.0 * x2 * x + b + a;
-    delta = (a * x + C0) * fc_rcp_approx(den);
-    x -= delta;
-    // NaN (den == 0: an all-zero padding conformer, an exact multiple root) counts as done here and fails below
-    const bool moving = fabs(delta) > 1e-9 * fabs(x);
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (__builtin_amdgcn_ballot_w64(moving) == 0ull) break;
-#else
-    if (!moving) break;
-#endif
-  }
-  if (iterations) *iterations = it + 1;
-  const bool converged = fabs(delta) <= 1e-9 * fabs(x);  // false for NaN
-  const double lam = x;
+  return QcpLeanPoly{-2.0 * n2, -8.0 * detB, n2 * n2 - 4.0 * e2, n2};
+}
+// one Newton step from above; returns "this lane is still moving" (false for NaN: den == 0 -- an all-zero padding
+// conformer, an exact multiple root -- counts as done here and fails in qcp_lean_quaternion)
+__host__ __device__ __forceinline__ bool qcp_lean_step(const QcpLeanPoly &P, double &x, double &delta) {
+#pragma clang fp contract(fast)
+  const double x2 = x * x;
+  const double b = (x2 + P.C2) * x;
+  const double a = b + P.C1;
+  const double den = 2.0 * x2 * x + b + a;
+  delta = (a * x + P.C0) * fc_rcp_approx(den);
+  x -= delta;
+  return fabs(delta) > 1e-9 * fabs(x);
+}
+// (the adjugate column as it is, not normalised, and its squared length)
+__host__ __device__ __forceinline__ bool qcp_lean_quaternion_raw(const double (&B)[9], const QcpLeanPoly &P, double lam,
+                                                                 double delta, double (&Q)[4], double &nq_out) {
+#pragma clang fp contract(fast)
+  const double Sxx = B[0], Sxy = B[3], Sxz = B[6];
+  const double Syx = B[1], Syy = B[4], Syz = B[7];
+  const double Szx = B[2], Szy = B[5], Szz = B[8];
+  const bool converged = fabs(delta) <= 1e-9 * fabs(lam);  // false for NaN
   const double m00 = (Sxx + Syy + Szz) - lam, m01 = Syz - Szy, m02 = Szx - Sxz, m03 = Sxy - Syx;
   const double m11 = (Sxx - Syy - Szz) - lam, m12 = Sxy + Syx, m13 = Szx + Sxz;
   const double m22 = (-Sxx + Syy - Szz) - lam, m23 = Syz + Szy;
@@ -629,10 +633,60 @@ __host__ __device__ __forceinline__ bool kabsch_quaternion_qcp_lean(const double
   if (fabs(a33) > best) { best = fabs(a33); q0 = a03; q1 = a13; q2 = a23; q3 = a33; }
   const double nq = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
   // best > 2e-3 (3 |B|_F)^3, squared: no square root
-  const bool simple = best * best > (2e-3 * 27.0) * (2e-3 * 27.0) * (n2 * n2) * n2;
-  const double nrm = fc_rsqrt(nq);
-  Q[0] = q0 * nrm; Q[1] = q1 * nrm; Q[2] = q2 * nrm; Q[3] = q3 * nrm;
+  const bool simple = best * best > (2e-3 * 27.0) * (2e-3 * 27.0) * (P.n2 * P.n2) * P.n2;
+  Q[0] = q0; Q[1] = q1; Q[2] = q2; Q[3] = q3;
+  nq_out = nq;
   return converged && simple && nq > 0.0;
+}
+__host__ __device__ __forceinline__ bool qcp_lean_quaternion(const double (&B)[9], const QcpLeanPoly &P, double lam,
+                                                             double delta, double (&Q)[4]) {
+  double nq;
+  const bool ok = qcp_lean_quaternion_raw(B, P, lam, delta, Q, nq);
+  const double nrm = fc_rsqrt(nq);
+  Q[0] *= nrm; Q[1] *= nrm; Q[2] *= nrm; Q[3] *= nrm;
+  return ok;
+}
+
+__host__ __device__ __forceinline__ bool kabsch_quaternion_qcp_lean(const double (&B)[9], double GpGq, double (&Q)[4],
+                                                                    int *iterations = nullptr) {
+  const QcpLeanPoly P = qcp_lean_polynomial(B);
+  double x = 0.5 * GpGq, delta = 0.0;
+  int it = 0;
+  for (; it < 64; ++it) {
+    const bool moving = qcp_lean_step(P, x, delta);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_ballot_w64(moving) == 0ull) break;
+#else
+    if (!moving) break;
+#endif
+  }
+  if (iterations) *iterations = it + 1;
+  return qcp_lean_quaternion(B, P, x, delta, Q);
+}
+
+// four pairs of one lane: the Newton iterations of all four in one wave-uniform loop; the quaternions come back
+// NOT normalised with their squared lengths (neg_rotation_from_raw_quaternion divides once)
+__host__ __device__ __forceinline__ void kabsch_quaternion_qcp_lean4(const double (&B)[4][9], const double (&GpGq)[4],
+                                                                     double (&Q)[4][4], double (&nq)[4], bool (&ok)[4]) {
+  QcpLeanPoly P[4];
+  double x[4], delta[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    P[r] = qcp_lean_polynomial(B[r]);
+    x[r] = 0.5 * GpGq[r];
+  }
+  for (int it = 0; it < 64; ++it) {
+    bool moving = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) moving |= qcp_lean_step(P[r], x[r], delta[r]);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_ballot_w64(moving) == 0ull) break;
+#else
+    if (!moving) break;
+#endif
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ok[r] = qcp_lean_quaternion_raw(B[r], P[r], x[r], delta[r], Q[r], nq[r]);
 }
 
 // R (row-major) from a unit quaternion, same formulas as kabsch_rotation
@@ -663,6 +717,28 @@ __host__ __device__ __forceinline__ void neg_rotation_from_quaternion(const doub
   R[6] = -2.0 * (q1 * q3 - q0 * q2);
   R[7] = -2.0 * (q2 * q3 + q0 * q1);
   R[8] = q1 * q1 + q2 * q2 - q0 * q0 - q3 * q3;
+}
+
+// -R from a quaternion of squared length nq > 0 that is NOT normalised: R = I - (2 / nq) (...), one reciprocal
+// (v_rcp_f64 + two Newton steps) instead of the inverse square root and four scalings: 29 instructions against 42
+__host__ __device__ __forceinline__ void neg_rotation_from_raw_quaternion(const double (&Q)[4], double nq, double (&R)[9]) {
+#pragma clang fp contract(fast)
+  const double q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3];
+  double inv = fc_rcp_approx(nq);
+  inv = fma(fma(-nq, inv, 1.0), inv, inv);
+  inv = fma(fma(-nq, inv, 1.0), inv, inv);
+  const double t = inv + inv;
+  const double p11 = q1 * q1, p22 = q2 * q2;
+  R[0] = fma(t, fma(q3, q3, p22), -1.0);
+  R[4] = fma(t, fma(q3, q3, p11), -1.0);
+  R[8] = fma(t, p11 + p22, -1.0);
+  const double a12 = q1 * q2, a13 = q1 * q3, a23 = q2 * q3;
+  R[1] = t * fma(q0, q3, -a12);    // -2 (q1 q2 - q0 q3) / nq
+  R[3] = -t * fma(q0, q3, a12);    // -2 (q1 q2 + q0 q3) / nq
+  R[2] = -t * fma(q0, q2, a13);    // -2 (q1 q3 + q0 q2) / nq
+  R[6] = t * fma(q0, q2, -a13);    // -2 (q1 q3 - q0 q2) / nq
+  R[5] = t * fma(q0, q1, -a23);    // -2 (q2 q3 - q0 q1) / nq
+  R[7] = -t * fma(q0, q1, a23);    // -2 (q2 q3 + q0 q1) / nq
 }
 
 }  // namespace fc

@@ -16,7 +16,7 @@ int main(int argc, char **argv) {
   std::normal_distribution<double> g(0.0, 1.0);
   std::vector<double> p(3 * A), q(3 * A);
   long hist[66] = {0};
-  double worst = 0.0, worst_lean = 0.0;
+  double worst = 0.0, worst_lean = 0.0, worst_raw = 0.0;
   long fail = 0, fail_lean = 0, lean_only_ok = 0;
   for (int t = 0; t < trials; ++t) {
     double cp[3] = {0, 0, 0}, cq[3] = {0, 0, 0};
@@ -65,6 +65,17 @@ int main(int argc, char **argv) {
         fc::rotation_from_quaternion(Ql, Rl);
         for (int e = 0; e < 9; ++e) worst_lean = std::max(worst_lean, std::fabs(Rl[e] - Rj[e]));
       }
+      // ... as the kernel calls it: four pairs per lane (here four copies), -R from the column that is not normalised
+      double B4[4][9], G4[4] = {G, G, G, G}, Q44[4][4], nq4[4], nR[9];
+      bool ok4[4];
+      for (int r = 0; r < 4; ++r)
+        for (int e = 0; e < 9; ++e) B4[r][e] = B[e];
+      fc::kabsch_quaternion_qcp_lean4(B4, G4, Q44, nq4, ok4);
+      if (ok4[3] != okl) { printf("lean4 and lean disagree on acceptance\n"); return 1; }
+      if (okl) {
+        fc::neg_rotation_from_raw_quaternion(Q44[3], nq4[3], nR);
+        for (int e = 0; e < 9; ++e) worst_raw = std::max(worst_raw, std::fabs(-nR[e] - Rj[e]));
+      }
     }
     if (!ok) { ++fail; continue; }
     fc::rotation_from_quaternion(Q, Rq);
@@ -78,6 +89,7 @@ int main(int argc, char **argv) {
   printf("A=%d trials=%d noise=%.2f: worst |R_new - R_jacobi| = %.3e, not-simple/residual fallbacks = %ld\n", A, trials, noise, worst, fail);
   printf("lean form (kabsch_quaternion_qcp_lean): worst |R - R_jacobi| = %.3e, fallbacks = %ld, accepted where the full form declined = %ld\n",
          worst_lean, fail_lean, lean_only_ok);
+  printf("four-at-once form + rotation from the raw column: worst |R - R_jacobi| = %.3e\n", worst_raw);
   printf("Newton steps histogram:");
   for (int i = 0; i < 66; ++i) if (hist[i]) printf(" %d:%ld", i, hist[i]);
   printf("\n");
