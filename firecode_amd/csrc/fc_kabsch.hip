@@ -413,7 +413,10 @@ constexpr size_t kStageBytes = kStagePairs * 8 + kStageWords * 4 + 8;
 // area takes the candidates of an ensemble with ~4 % of similar pairs before it has to fall back
 // to one global atomic per ballot (measured on a 10^4 x 50 ensemble with a continuous RMSD
 // distribution, 1.7 % candidates: screen 4.3 ms with 48 slots)
-constexpr int kStagePairsF32 = 384;
+#ifndef FC_STAGE_PAIRS_F32
+#define FC_STAGE_PAIRS_F32 384
+#endif
+constexpr int kStagePairsF32 = FC_STAGE_PAIRS_F32;
 constexpr int kStageWordsF32 = 128;
 constexpr size_t kStageBytesF32 = kStagePairsF32 * 8 + kStageWordsF32 * 4 + 16 + 32 * 4;  // + counters + unit list
 
@@ -426,12 +429,34 @@ __device__ __forceinline__ void stage_pairs(uint64_t m, bool may, unsigned i, un
 #ifdef FC_ABLATE_PUSH
   return;
 #endif
+#ifdef FC_ABLATE_STAGE  // timing experiment only (candidates are lost; the decision stays alive through one LDS store)
+  if (lane == 0) scnt[2] = (unsigned)__popcll(m);
+  return;
+#endif
   const unsigned n = (unsigned)__popcll(m);
   unsigned base = 0;
   if (lane == 0) base = atomicAdd(scnt, n);
   base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
   if (base + n <= (unsigned)CAP) {
     if (may) sq[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = ((uint64_t)i << 32) | (uint64_t)j;
+  } else {
+#ifndef FC_ABLATE_OVERFLOW  // timing experiment only (candidates are lost)
+    push_pairs(m, may, i, j, pairq, Q, counters, lane);
+#endif
+  }
+}
+
+// The same with a staging region and a count PER WAVEFRONT: no LDS atomic, no wait for its result in front of the
+// store (k_simbits_screen_mfma_h2; the workgroup publishes all four regions with ONE global atomic at its end).
+template <int WCAP>
+__device__ __forceinline__ void stage_pairs_wave(uint64_t m, bool may, unsigned i, unsigned j, uint64_t *__restrict__ sq_wave,
+                                                 int &n_staged, uint64_t *__restrict__ pairq, unsigned long long Q,
+                                                 unsigned long long *__restrict__ counters, int lane) {
+  if (m == 0) return;  // wave-uniform
+  const int n = (int)__popcll(m);
+  if (n_staged + n <= WCAP) {
+    if (may) sq_wave[n_staged + (int)__popcll(m & ((1ull << lane) - 1ull))] = ((uint64_t)i << 32) | (uint64_t)j;
+    n_staged += n;
   } else {
     push_pairs(m, may, i, j, pairq, Q, counters, lane);
   }
@@ -1587,7 +1612,7 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
   float *__restrict__ ldsG = reinterpret_cast<float *>(lds8 + n_runs * TC);  // 2^2e G/2 as fp32: [TC columns | IB rows]
   uint64_t *__restrict__ stageQ = reinterpret_cast<uint64_t *>(ldsG + TC + IB);  // (IB is a multiple of 32)
   uint32_t *__restrict__ stageW = reinterpret_cast<uint32_t *>(stageQ + kStagePairsF32);
-  unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWordsF32);  // [pairs, words]
+  unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWordsF32);  // [-, words, -, - | pairs staged by wavefront 0..3 | queue base (64 bit)]
   const unsigned long long b = blockIdx.x;
   if (b >= n_items) return;
 #ifdef FC_H2_TIMELINE  // tuning build (lean launches only: `bits` carries the stamp buffer): start / filled / end / where
@@ -1651,7 +1676,6 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
       const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
       ldsG[idx] = g < Npad ? (float)(0.5 * G[g]) * scale2 : 0.f;
     }
-    for (int idx = tid; idx < kStagePairsF32; idx += NW * 64) stageQ[idx] = ~0ull;
     if (tid < kStageWordsF32) stageW[tid] = ~0u;
     if (tid < 2) stageN[tid] = 0u;
     __syncthreads();
@@ -1660,6 +1684,10 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
 #endif
   }
   const h8_t *__restrict__ lcol = lds8 + kq * TC + l15;  // + run * (4 TC) + sub-tile * 16
+  // candidates: a quarter of the staging area per wavefront, counted in a scalar register
+  constexpr int WCAP = kStagePairsF32 / NW;
+  uint64_t *__restrict__ sq_wave = stageQ + wv * WCAP;
+  int n_staged = 0;
   for (; tile_exists(it); it += NW) {
     const int64_t ib = i0 + (int64_t)it * 16;
     const int64_t lrow0 = lb * IB + (int64_t)it * 16;
@@ -1730,6 +1758,7 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
         mr[r] = kabsch_may_be_below_f32_2t_wave(B9, Gp + Gq, half_A_thr2, bd, tiny_floor, rdm[r]);
 #endif
       }
+#ifndef FC_ABLATE_REDO  // timing experiment only
       if ((rdm[0] | rdm[1] | rdm[2] | rdm[3]) != 0ull) {  // nearly collinear structures only
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1742,6 +1771,7 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
           mr[r] = (mr[r] & ~rdm[r]) | (m3 & rdm[r]);
         }
       }
+#endif
       // (strictly above the diagonal and inside the ensemble -- nearly every sub-tile -- no index test)
       const bool interior = (int)j0 + cs * 16 > ib32 + 15 && (int)j0 + cs * 16 + 15 < n32 && ib32 + 15 < n32;
       if (!interior) {
@@ -1754,8 +1784,8 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
       if ((mr[0] | mr[1] | mr[2] | mr[3]) != 0ull) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          stage_pairs<kStagePairsF32>(mr[r], ((mr[r] >> lane) & 1ull) != 0ull, (unsigned)(ib32 + 4 * kq + r), (unsigned)j,
-                                      stageQ, stageN, pairq, Q, counters, lane);
+          stage_pairs_wave<WCAP>(mr[r], ((mr[r] >> lane) & 1ull) != 0ull, (unsigned)(ib32 + 4 * kq + r), (unsigned)j, sq_wave,
+                                 n_staged, pairq, Q, counters, lane);
       }
       if (BITS && lane < 16 && ib32 + lane < n32) {
         const int rr = lane & 3;
@@ -1786,27 +1816,31 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
       }
     }
   }
-  // publish what the workgroup staged: one global atomic per queue
+  // publish what the workgroup staged.  Pairs: ONE global atomic for the four wavefronts' regions, every wavefront copies
+  // its own (round 4: 945 025 candidates of the continuous-RMSD ensemble cost the screen 142 of 302 us while wave 0
+  // flushed one shared region 64 entries and one returning atomic at a time behind an LDS atomic per ballot;
+  // ~12 ns per atomic on one address at the L2, the same bound the refine kernels met)
+  if (lane == 0) stageN[4 + wv] = (unsigned)n_staged;
   __syncthreads();
+  {
+    const unsigned c0 = stageN[4], c1 = stageN[5], c2 = stageN[6], c3 = stageN[7];
+    const unsigned total = c0 + c1 + c2 + c3;
+    if (total != 0u) {  // block-uniform
+      unsigned long long *gslot = reinterpret_cast<unsigned long long *>(stageN + 8);
+      if (tid == 0) *gslot = atomicAdd(&counters[6], (unsigned long long)total);
+      __syncthreads();
+      const unsigned long long gb = *gslot + (wv == 0 ? 0u : wv == 1 ? c0 : wv == 2 ? c0 + c1 : c0 + c1 + c2);
+      for (int idx = lane; idx < n_staged; idx += 64) {
+        const unsigned long long slot = gb + (unsigned long long)idx;
+        if (slot < Q) pairq[slot] = sq_wave[idx];
+      }
+    }
+  }
 #ifdef FC_H2_TIMELINE
   if (tl && tid == 0) tl[(size_t)b * 4 + 2] = wall_clock64();
 #endif
   if (wv == 0) {
-    const int used_q = min((int)stageN[0], kStagePairsF32), used_w = min((int)stageN[1], kStageWordsF32);
-    for (int c0 = 0; c0 < used_q; c0 += 64) {
-      const uint64_t e = c0 + lane < kStagePairsF32 ? stageQ[c0 + lane] : ~0ull;
-      const bool valid = e != ~0ull;
-      const uint64_t mv = __ballot(valid);
-      if (mv != 0) {
-        unsigned long long gbase = 0;
-        if (lane == 0) gbase = atomicAdd(&counters[6], (unsigned long long)__popcll(mv));
-        gbase = __shfl(gbase, 0);
-        if (valid) {
-          const unsigned long long slot = gbase + (unsigned long long)__popcll(mv & ((1ull << lane) - 1ull));
-          if (slot < Q) pairq[slot] = e;
-        }
-      }
-    }
+    const int used_w = min((int)stageN[1], kStageWordsF32);
     for (int c0 = 0; c0 < used_w; c0 += 64) {
       const uint32_t wq = c0 + lane < kStageWordsF32 ? stageW[c0 + lane] : ~0u;
       const bool valid = wq != ~0u;

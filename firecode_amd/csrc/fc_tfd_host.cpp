@@ -960,6 +960,18 @@ static int tfd_ladder_impl(const int64_t *fm, int64_t N, uint8_t *mask_out, cons
       const size_t n_flags = level_rej[li].size();
       unsigned long long gone = 0;
       size_t r = 0;
+      for (; r + 32 <= n_flags; r += 32) {  // 32 structures per step; most steps of most levels reject nothing new
+        uint64_t m8[4], f8[4];
+        std::memcpy(m8, mask_out + r, 32);
+        std::memcpy(f8, flags + r, 32);
+        const uint64_t h0 = m8[0] & f8[0], h1 = m8[1] & f8[1], h2 = m8[2] & f8[2], h3 = m8[3] & f8[3];
+        if ((h0 | h1) | (h2 | h3)) {
+          gone += (unsigned long long)(__builtin_popcountll(h0) + __builtin_popcountll(h1) + __builtin_popcountll(h2) +
+                                       __builtin_popcountll(h3));
+          m8[0] ^= h0, m8[1] ^= h1, m8[2] ^= h2, m8[3] ^= h3;
+          std::memcpy(mask_out + r, m8, 32);
+        }
+      }
       for (; r + 8 <= n_flags; r += 8) {  // eight structures per step (bytes are 0 / 1: a set bit is a rejected structure)
         uint64_t m8, f8;
         std::memcpy(&m8, mask_out + r, 8);
