@@ -297,6 +297,51 @@ def test_long_candidate_queue_refine_vs_oracle(fc, n, a, seed, thr):
     assert 0 < mask.sum() < mask_e.sum() < n
 
 
+def test_random_prunes_vs_oracle(fc):
+    """A seeded sweep the directed cases do not cover one by one: 2 - 700 conformers, 1 - 140 atoms (hydrogens mixed in:
+    the heavy-atom mask), clustered / continuous / unrelated / duplicated / planar / mirrored structures with random
+    rigid motions, random thresholds, with and without an energy window -- the mask of ``prune_by_rmsd`` against the
+    oracle's greedy ladder over its own all-pairs matrix.  A case with a pair within 1e-9 of a threshold is skipped
+    (the decision is then a matter of the last bits of two different solvers); at least 25 of the 36 must count."""
+    rng = np.random.default_rng(20261004)
+    counted = 0
+    for case in range(36):
+        n = int(rng.choice([2, 3, 5, 17, 63, 64, 65, 100, 129, 200, 257, 400, 511, 700]))
+        a = int(rng.choice([1, 2, 3, 4, 7, 16, 23, 33, 50, 64, 65, 97, 128, 140]))
+        kind = str(rng.choice(["clusters", "continuous", "random", "duplicates", "planar", "mirror"]))
+        seed = int(rng.integers(1 << 30))
+        if kind == "clusters" and a >= 3:
+            X = syn.synthetic_ensemble(max(n, 5), a, seed=seed)[0][:n]
+        elif kind == "continuous" and a >= 3:
+            X = syn.continuous_ensemble(n, a, seed=seed)
+        else:
+            X = rng.normal(scale=1.5, size=(n, a, 3))
+            if kind == "duplicates":
+                X[n // 2:] = X[: n - n // 2] + rng.normal(scale=0.02, size=(n - n // 2, a, 3))
+            elif kind == "planar":
+                X[:, :, 2] = 0.0
+                X[1::2] = X[0::2][: len(X[1::2])] + rng.normal(scale=0.05, size=(len(X[1::2]), a, 3)) * np.array([1.0, 1.0, 0.0])
+            elif kind == "mirror":
+                X[1::2] = X[0::2][: len(X[1::2])] * np.array([1.0, 1.0, -1.0])
+        X = np.einsum("nij,naj->nai", np.array([_rot(rng) for _ in range(n)]), X) + rng.normal(scale=3.0, size=(n, 1, 3))
+        atoms = np.where(rng.random(a) < 0.25, "H", "C")
+        if not (atoms != "H").any():
+            atoms[0] = "C"
+        thr = float(rng.choice([0.05, 0.25, 0.5, 1.0, 2.0]))
+        S0, R0, D0 = o.rmsd_similarity_matrix(X, atoms, thr)
+        iu = np.triu_indices(n, 1)
+        if np.abs(R0[iu] - thr).min() < 1e-9 or (np.abs(D0[iu] - 2 * thr)[R0[iu] < thr] < 1e-9).any():
+            continue
+        en = rng.uniform(0, 3, size=n) if rng.random() < 0.4 else None
+        ref = o.greedy_prune_from_matrix(S0, energies=en, max_dE=1.0) if en is not None else o.greedy_prune_from_matrix(S0)
+        kw = {"energies": en, "max_dE": 1.0} if en is not None else {}
+        pruned, mask = fc.pruner.prune_by_rmsd(X, atoms, thr, **kw)
+        assert np.array_equal(mask, ref), (case, n, a, kind, thr, en is not None)
+        assert pruned.shape == (int(ref.sum()), a, 3) and np.array_equal(pruned, X[ref])
+        counted += 1
+    assert counted >= 25
+
+
 def test_refine_word_queue_fallback(fc, monkeypatch):
     """pair queue too small -> the refine kernel must fall back to the word
     queue (sparse words: wave per pair; dense words: lane per pair)"""
