@@ -3552,7 +3552,19 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         // screen takes those at once; in between, k_screen_verdict decides on the device.
         FC_TRY(ensure_gmax());
         const double band = (double)bd.p0 * 2.0 * e->g_max / (double)e->A;
-        use_f32 = band <= 1.0 * thr2_margin;  // beyond: the fp64 screen at once
+        // Beyond kBandMax thresholds^2 the fp64 screen takes the launch at once.  (1.0 until round 4: 30 000 x 80 ensembles
+        // whose skeleton happened to be stretched -- radius of gyration 10.7 instead of 7.4 A: band 0.265 against 0.127 A^2
+        // at a threshold of 0.25 -- fell off that edge and took 11.7 instead of 2.3 ms per prune although not one of
+        // their pairs lies in the band.  Whether the band is POPULATED is what k_screen_verdict measures on the device;
+        // the bound only says how wide it is, and up to 4 thresholds^2 -- pairs below 2.2 x the rmsd threshold -- the
+        // speculative launch is the better bet: a verdict against it costs the split-half screen once, ~ 1/5 of the
+        // fp64 screen it then runs.)
+        static const double kBandMax = [] {
+          const char *v = getenv("FC_SCREEN_BAND_MAX");
+          const double x = v ? atof(v) : 4.0;
+          return x > 0.0 ? x : 4.0;
+        }();
+        use_f32 = band <= kBandMax * thr2_margin;
         speculative = band > 0.1 * thr2_margin;  // narrow band: not worth the verdict's ~10 us
       }
       if (!mfma64_ok) {

@@ -297,6 +297,31 @@ def test_long_candidate_queue_refine_vs_oracle(fc, n, a, seed, thr):
     assert 0 < mask.sum() < mask_e.sum() < n
 
 
+def test_wide_band_takes_the_speculative_screen(fc):
+    """An 80-atom skeleton that happens to be stretched (radius of gyration 10.7 A): the band of mean square deviations
+    the bounded single-precision test cannot decide is 0.265 A^2 -- wider than the squared threshold, and EMPTY in a
+    clustered ensemble.  Until round 4 such ensembles went to the fp64 screen at once (5 x the time); now the split-half
+    screen runs and the device-side verdict stays silent.  Mask against the oracle; then the same coordinates with a
+    band that IS populated (a continuous spread below 2.2 thresholds): whatever the verdict says, the mask is the oracle's."""
+    from firecode_amd import _lib
+
+    X, atoms, _ = syn.synthetic_ensemble(600, 80, seed=4)
+    G = ((X - X.mean(axis=1, keepdims=True)) ** 2).sum(axis=(1, 2)).max()
+    assert 0.25 < 2 * 1.1643e-3 * G / 80 < 1.0   # the band of kabsch_h2_bounds(3): between 1 and 4 squared thresholds
+    S0, R0, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        mask, stats = ens.prune(0.5, 1.0)
+        assert _lib.screen_last_kind() == 16
+    assert np.array_equal(mask, o.greedy_prune_from_matrix(S0)) and int(stats[1]) == int(np.triu(S0, 1).sum())
+    rng = np.random.default_rng(8)
+    Y = X[:1] + rng.normal(size=(600, 1, 1)) * rng.normal(scale=0.12, size=(1, 80, 3)) + rng.normal(scale=0.05, size=(600, 80, 3))
+    S1, R1, D1 = o.rmsd_similarity_matrix(Y, atoms, 0.5)
+    iu = np.triu_indices(600, 1)
+    assert np.abs(R1[iu] - 0.5).min() > 1e-9 and ((R1[iu] > 0.5) & (R1[iu] < 0.7)).sum() > 1000  # a populated band
+    _, mask1 = fc.pruner.prune_by_rmsd(Y, atoms, 0.5)
+    assert np.array_equal(mask1, o.greedy_prune_from_matrix(S1))
+
+
 def test_random_prunes_vs_oracle(fc):
     """A seeded sweep the directed cases do not cover one by one: 2 - 700 conformers, 1 - 140 atoms (hydrogens mixed in:
     the heavy-atom mask), clustered / continuous / unrelated / duplicated / planar / mirrored structures with random
