@@ -25,6 +25,7 @@ int launch_pairs_exact(const fc_ensemble *, const int64_t *, const int64_t *, in
                        double *, double *);
 int launch_matrix_exact(const fc_ensemble *, double *, double *);
 int launch_rmsd_values(fc_ensemble *, double, double *, double *, int64_t rank = 0, int64_t world = 1);
+int launch_mirror_upper(double *m_dev, int64_t N);
 int launch_gather_matrix_pairs(const double *, const double *, int64_t, const int64_t *, const int64_t *, int64_t,
                                double *, double *);
 void screen_select(int);
@@ -498,7 +499,8 @@ static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, c
 }
 
 // Host arrays in (the drop-in call prune_by_rmsd(structures, ...)): the coordinates go through the pinned pieces like every
-// large upload from pageable memory (h2d_staged; fc_common.h says why the caller's pages are not handed to the runtime).
+// large upload from pageable memory (h2d_staged; fc_common.h says why the caller's pages are not handed to the runtime,
+// nor registered by the library for the duration of the copy).
 // What that costs and what was tried against it (round 4; tools/pin_probe.py, tools/hostin_breakdown.py; 12 MB):
 // DMA from pinned memory 0.22 ms (54 GB/s), from the caller's pageable pages THE SAME 0.22 ms (the driver maps them; that
 // mapping is what later stalls the queues when the caller frees the array), memmove into pinned memory 0.24 ms on one
@@ -976,7 +978,7 @@ static int rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_o
   unsigned long long cnt[16] = {0};
   if (tiled) {
     // the tiled kernel writes every (i, j >= i), exact zeros on the diagonal; the lower triangle is
-    // mirrored on the host below: nothing to clear (2 x 800 MB of memset per call at 10^4 conformers)
+    // mirrored on the device below: nothing to clear (2 x 800 MB of memset per call at 10^4 conformers)
     FC_TRY(ensemble_shard(ens, 0, 1, 256));  // sizes the pair queue of the fix-up
     FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 16 * sizeof(uint64_t), c.stream));
   } else {
@@ -988,8 +990,6 @@ static int rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_o
   else FC_TRY(launch_matrix_exact(ens, dr.as<double>(), dm.as<double>()));
   FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
   if (tiled) FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
-  if (rmsd_out) FC_TRY(d2h(rmsd_out, dr.p, bytes));
-  if (maxdev_out) FC_TRY(d2h(maxdev_out, dm.p, bytes));
   FC_TRY(sync());
   if (ms_kernel) {
     float ms = 0.f;
@@ -997,20 +997,19 @@ static int rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_o
     *ms_kernel = ms;
   }
   if (tiled && cnt[6] > (unsigned long long)ens->pairq_cap) {
-    // more degenerate pairs than the fix-up queue holds: the plain kernel redoes the matrix
+    // more degenerate pairs than the fix-up queue holds (planar or collinear structures: every pair): the plain kernel
+    // redoes the matrix
     FC_HIP_TRY(hipMemsetAsync(dr.p, 0, bytes, c.stream));
     FC_HIP_TRY(hipMemsetAsync(dm.p, 0, bytes, c.stream));
     FC_TRY(launch_matrix_exact(ens, dr.as<double>(), dm.as<double>()));
-    if (rmsd_out) FC_TRY(d2h(rmsd_out, dr.p, bytes));
-    if (maxdev_out) FC_TRY(d2h(maxdev_out, dm.p, bytes));
-    FC_TRY(sync());
   }
-  for (int64_t i = 0; i < N && (rmsd_out || maxdev_out); ++i)
-    for (int64_t j = i + 1; j < N; ++j) {
-      if (rmsd_out) rmsd_out[j * N + i] = rmsd_out[i * N + j];
-      if (maxdev_out) maxdev_out[j * N + i] = maxdev_out[i * N + j];
-    }
-  return FC_OK;
+  // both kernels write the upper triangle and the diagonal: the lower one is mirrored on the device, then the matrices
+  // travel (the host's element loop took ~0.1 s per call at 10^4 conformers)
+  if (rmsd_out) FC_TRY(launch_mirror_upper(dr.as<double>(), N));
+  if (maxdev_out) FC_TRY(launch_mirror_upper(dm.as<double>(), N));
+  if (rmsd_out) FC_TRY(d2h(rmsd_out, dr.p, bytes));
+  if (maxdev_out) FC_TRY(d2h(maxdev_out, dm.p, bytes));
+  return sync();
 }
 
 // bench hook: `reps` complete all-pairs alignment passes over the resident ensemble, enqueued back to
@@ -1147,7 +1146,10 @@ int fc_ensemble_rmsd_values(fc_ensemble *ens, double *rmsd_out, double *ms_kerne
   FC_HIP_TRY(hipEventRecord(c.ev1, c.stream));
   unsigned long long cnt[16];
   FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
-  if (rmsd_out) FC_TRY(d2h(rmsd_out, dr.p, bytes));
+  if (rmsd_out) {  // (the lower triangle mirrored on the device, then one copy)
+    FC_TRY(launch_mirror_upper(dr.as<double>(), N));
+    FC_TRY(d2h(rmsd_out, dr.p, bytes));
+  }
   FC_TRY(sync());
   if (cnt[6] > (unsigned long long)ens->pairq_cap)
     return set_error(FC_E_LIMIT, "%llu pairs closer than 0.02 A exceed the fix-up queue (%lld): "
@@ -1157,9 +1159,6 @@ int fc_ensemble_rmsd_values(fc_ensemble *ens, double *rmsd_out, double *ms_kerne
     FC_HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
     *ms_kernel = ms;
   }
-  if (rmsd_out)
-    for (int64_t i = 0; i < N; ++i)
-      for (int64_t j = i + 1; j < N; ++j) rmsd_out[j * N + i] = rmsd_out[i * N + j];
   return FC_OK;
 }
 

@@ -248,6 +248,12 @@ inline int d2h(void *dst, const void *src, size_t n) {
   FC_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, cur_stream()));
   return FC_OK;
 }
+// (Round 4, built and taken out again: hipHostRegister -> DMA in place -> hipHostUnregister for copies of 4 MB and more.
+// 12 MB arrive in 0.29 ms instead of 0.37 and prune_by_rmsd(host arrays) takes 0.68-0.71 instead of 0.79 ms -- but memory
+// that has EVER been registered keeps the property that made the library copy in the first place: when the caller frees
+// it with an munmap, the next kernels wait 10-25 ms.  The cfg3 search, whose survivors' coordinates (4.6 MB) are a fresh
+// array per search, lost 12-25 ms in the re-scan of three searches out of ten; tools/hostin_fresh_probe.py does not show
+// it only because glibc stops returning a repeatedly allocated 12 MB block to the system.  tools/pin_probe_fresh.py.)
 inline int sync() {
   FC_HIP_TRY(hipStreamSynchronize(cur_stream()));
   return FC_OK;
