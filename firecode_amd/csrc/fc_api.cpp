@@ -479,6 +479,14 @@ static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, c
   FC_TRY(make_selection(atom_mask, A_all, sel));
   e->N = N;
   e->A = (int64_t)sel.size();
+  {  // (Context::hint_*: the last prune of an ensemble of this shape, scaled to this one's number of pairs)
+    const Context &c = ctx();
+    if (c.hint_A == e->A && c.hint_N >= 2 && N >= c.hint_N / 2 && N <= 2 * c.hint_N) {
+      const double scale = ((double)N * (double)N) / ((double)c.hint_N * (double)c.hint_N);
+      e->last_candidates = (int64_t)((double)c.hint_candidates * scale);
+      e->last_similar = (int64_t)((double)c.hint_similar * scale);
+    }
+  }
   e->Npad = ceil_div(std::max<int64_t>(N, 1), 64) * 64;
   e->W = e->Npad / 64;
   FC_TRY(e->Xs.reserve((size_t)((e->A + 3) / 4 * 4) * 3 * e->Npad * sizeof(double)));
@@ -716,6 +724,8 @@ static void note_candidates(fc_ensemble *e, unsigned long long refined, unsigned
     w->last_candidates = (int64_t)refined;
     w->last_similar = (int64_t)similar;
   }
+  Context &c = ctx();
+  c.hint_A = e->A, c.hint_N = e->N, c.hint_candidates = (int64_t)refined, c.hint_similar = (int64_t)similar;
 }
 
 static bool ladder_collect(fc_ensemble *e, int64_t slot, uint8_t *mask_out, int64_t *levels,

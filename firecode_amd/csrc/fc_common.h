@@ -45,6 +45,11 @@ int set_error(int code, const char *fmt, ...);
 struct Context {
   bool ready = false;
   int device = -1;
+  // what the last finished prune on this context saw (shape, candidate pairs, similar pairs): a FRESH ensemble of the same
+  // atom count and a comparable size starts from it, scaled by the number of pairs, instead of from "unknown" -- a caller
+  // that prunes one new ensemble after another (prune_by_rmsd on host arrays: a new fc_ensemble per call) would otherwise
+  // never get the long-queue forms of the refine and the ladder.  Speed only: every form gates itself on the device.
+  int64_t hint_A = -1, hint_N = 0, hint_candidates = 0, hint_similar = 0;
   hipStream_t stream = nullptr;      // the stream every launch and copy goes to
   hipStream_t own_stream = nullptr;  // the library's own; `stream` differs after fc_stream_set
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
