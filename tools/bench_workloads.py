@@ -112,7 +112,10 @@ def prune80():
         "pairs": pairs, "kernel_ms": tk, "step_ms": ts, "alignments_per_s": pairs / (ts * 1e-3),
         "survivors": int(mask.sum()), "expected": int(len(np.unique(asg))),
         "screen": {16: "f16x2 MFMA (split-half)", 32: "fp32 MFMA"}.get(fc._lib.screen_last_kind(), "fp64 MFMA"),
-        "roofline_mfma_frac": pairs * 2 * 9 * 80 / (tk * 1e-3) / (157.3e12 if fc._lib.screen_last_kind() == 32 else 78.6e12),
+        # flops issued to the matrix pipe per pair: split-half = three f16 products over atoms padded to 32, fp32 / fp64 = one
+        # product over the atoms; peaks 2.5 PFLOP/s f16, 157.3 TFLOP/s fp32, 78.6 TFLOP/s fp64
+        "roofline_mfma_frac": (pairs * 3 * 2 * 9 * 96 / (tk * 1e-3) / 2.5e15 if fc._lib.screen_last_kind() == 16 else
+                               pairs * 2 * 9 * 80 / (tk * 1e-3) / (157.3e12 if fc._lib.screen_last_kind() == 32 else 78.6e12)),
     }))
 
 
