@@ -238,6 +238,12 @@ inline ArenaScope::~ArenaScope() {
 // less often (one run in three); FC_STAGED_UPLOADS=0 puts uploads back on the runtime's path (0.12 ms per 12 MB faster).
 // Pinned host memory (the pipelines' result slots) and small copies stay asynchronous.
 constexpr size_t kStagedCopyMin = (size_t)64 << 10;
+// column tile of the long-queue refine's buckets: 2^kBucketColShift conformers (fc_kabsch.hip; ensemble_shard sizes the
+// bucket tables with it)
+#ifndef FC_RB_COLSHIFT
+#define FC_RB_COLSHIFT 6
+#endif
+constexpr int kBucketColShift = FC_RB_COLSHIFT;
 bool host_memory_is_pinned(const void *p);
 bool staged_uploads();  // FC_STAGED_UPLOADS (default below)
 int h2d_staged(void *dst_dev, const void *src, size_t n, hipStream_t st);

@@ -2449,7 +2449,7 @@ struct BucketGeom {
   unsigned NT, n_sc;            // column tiles, supertile columns = ceil(NT / 8)
 };
 __device__ __forceinline__ unsigned bucket_of(uint64_t e, BucketGeom g) {
-  const unsigned rb = (unsigned)(e >> 32) / (unsigned)kBucketRows, jt = (unsigned)(e & 0xffffffffull) >> 6;
+  const unsigned rb = (unsigned)(e >> 32) / (unsigned)kBucketRows, jt = (unsigned)(e & 0xffffffffull) >> kBucketColShift;
   return ((rb * g.n_sc + (jt >> 3)) << 3) | (jt & 7u);
 }
 
@@ -2576,7 +2576,8 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
                  unsigned long long Q, BucketGeom geom, int *__restrict__ bk, const int *__restrict__ off,
                  const int *__restrict__ list, const int *__restrict__ st_off, const int *__restrict__ xoff, int n_st,
                  int x_stride, const uint64_t *__restrict__ sorted, uint64_t *__restrict__ simq) {
-  extern __shared__ double lds[];  // [A4 * 3][64]: the bucket's column tile
+  extern __shared__ double lds[];  // [A4 * 3][TCB]: the bucket's column tile
+  constexpr int TCB = 1 << kBucketColShift;  // conformers per column tile
   __shared__ int s_next;
   __shared__ int s_bin[kBucketRows];          // pairs per row of the block, then their exclusive scan
   __shared__ uint64_t s_pairs[kBucketChunk];  // the item's pairs in row order
@@ -2623,14 +2624,16 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
     const unsigned item = (unsigned)list[k];
     const unsigned b = item & 0xffffffu, piece = item >> 24;
     const unsigned jt = (((b >> 3) % geom.n_sc) << 3) | (b & 7u);
-    const int64_t j0 = (int64_t)jt * 64;
-    // column tile by LDS-DMA: one instruction moves two 512-byte rows (lanes 0-31 the first, 32-63 the second)
+    const int64_t j0 = (int64_t)jt * TCB;
+    // column tile by LDS-DMA: one instruction moves 1 KiB = two 512-byte rows (lanes 0-31 the first, 32-63 the second; four
+    // rows of a 32-conformer tile)
+    constexpr int kRowsPer = 128 / TCB, kLanesPerRow = TCB / 2;
 #ifdef FC_RB_NOSTAGE
     for (int q = wv; q < 0; q += kBucketChunk / 64) {
 #else
-    for (int q = wv; q < n_rows / 2; q += kBucketChunk / 64) {
+    for (int q = wv; q < n_rows / kRowsPer; q += kBucketChunk / 64) {
 #endif
-      const double *src = Xs + (int64_t)(2 * q + (lane >> 5)) * Npad + j0 + (lane & 31) * 2;
+      const double *src = Xs + (int64_t)(kRowsPer * q + lane / kLanesPerRow) * Npad + j0 + (lane % kLanesPerRow) * 2;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                        (__attribute__((address_space(3))) void *)(lds + q * 128), 16, 0, 0);
     }
@@ -2708,7 +2711,7 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
         const int al = a < A4 ? a : A4 - 1;  // past the end: harmless re-read, never used
 #ifdef FC_RB_ROWS_FROM_LDS  // tuning build (WRONG results): what the kernel costs without its global row loads
 #pragma unroll
-        for (int c = 0; c < 3; ++c) P[c] = lds[(al * 3 + c) * 64 + (i & 63)];
+        for (int c = 0; c < 3; ++c) P[c] = lds[(al * 3 + c) * TCB + (i & (TCB - 1))];
 #else
         const double *__restrict__ row = Xs + (int64_t)(al * 3) * Npad;  // wave-uniform
 #ifdef FC_RB_SAMEROW  // tuning build (WRONG results): every lane reads the first lane's row -- one line per load
@@ -2723,7 +2726,7 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
       };
       auto load_col = [&](int a, double (&Qv)[3]) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Qv[c] = qcol[(a * 3 + c) * 64];
+        for (int c = 0; c < 3; ++c) Qv[c] = qcol[(a * 3 + c) * TCB];
       };
       {
         double P[kAhead][3], Qv[3];
@@ -3830,7 +3833,7 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
     const char *v = getenv("FC_REFINE_BUCKETS");  // 0: the straight queue walk of k_refine_pairs (round 3)
     return !(v && atoi(v) == 0);
   }();
-  const size_t lds_bk = (size_t)(((e->A + 3) & ~(int64_t)3) * 3 * 64) * sizeof(double);
+  const size_t lds_bk = (size_t)(((e->A + 3) & ~(int64_t)3) * 3 * (1 << kBucketColShift)) * sizeof(double);
   // the column tile shares the CU's LDS with the kernel's own arrays (bins, sorted pairs, per-wavefront sums): 104 atoms
   // are 156 KB of tile and do not fit beside them (tools/refine_stress.py found that launch refused)
   static const size_t lds_bk_static = [] {
@@ -3841,7 +3844,7 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
   if (lanes && buckets && e->bk_buckets > 0 && lds_bk + lds_bk_static <= kLdsLimit &&
       e->last_candidates > (int64_t)kRefineLanesMin) {
     auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
-    const unsigned NT = (unsigned)(e->Npad >> 6);
+    const unsigned NT = (unsigned)(e->Npad >> kBucketColShift);
     const BucketGeom geom{NT, (NT + 7) / 8};
     const int64_t nb = e->bk_buckets;
     const int n_st = (int)(nb / 8), x_stride = (n_st + 7) / 8 + 1;
