@@ -554,7 +554,7 @@ static int ensemble_shard(fc_ensemble *e, int64_t rank, int64_t world, int64_t r
   FC_TRY(e->simq.reserve((size_t)e->pairq_cap * sizeof(uint64_t)));
   {  // buckets of the long-queue refine: (row buckets of 1 024) x (column tiles of 64), numbered supertile by supertile
      // (8 column tiles of one row bucket; fc_kabsch.hip); sized here, before any pipeline forks
-    const int64_t n_rb = ceil_div(e->N, (int64_t)1024), n_sc = ceil_div(e->Npad >> kBucketColShift, (int64_t)8);
+    const int64_t n_rb = ceil_div(e->N, (int64_t)kBucketRows), n_sc = ceil_div(e->Npad >> kBucketColShift, (int64_t)8);
     const int64_t n_st = n_rb * n_sc, nb = n_st * 8;
     e->bk_buckets = nb <= ((int64_t)1 << 22) ? nb : 0;  // one workgroup scans the counts; work items are bucket | piece << 24
     if (e->bk_buckets > 0) {

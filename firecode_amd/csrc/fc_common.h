@@ -244,6 +244,10 @@ constexpr size_t kStagedCopyMin = (size_t)64 << 10;
 #define FC_RB_COLSHIFT 6
 #endif
 constexpr int kBucketColShift = FC_RB_COLSHIFT;
+#ifndef FC_RB_ROWS
+#define FC_RB_ROWS 1024
+#endif
+constexpr int kBucketRows = FC_RB_ROWS;  // rows of a bucket
 bool host_memory_is_pinned(const void *p);
 bool staged_uploads();  // FC_STAGED_UPLOADS (default below)
 int h2d_staged(void *dst_dev, const void *src, size_t n, hipStream_t st);

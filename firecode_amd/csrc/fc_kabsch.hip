@@ -2442,7 +2442,6 @@ constexpr int kBkCtrl = 512;    // int32 words in front of the counts: [0] work 
 // bucket can be many -- and have to be: what a CU can keep busy is (pairs of its resident tiles) / 64 wavefronts, and
 // with 128-row buckets (152 pairs at 1.9 % candidates) the two resident workgroups had 2 x 2.4 active wavefronts on
 // four SIMDs: every instruction latency exposed (~480 cycles per atom step whatever the loads did), 0.51 ms.
-constexpr int kBucketRows = 1024;
 constexpr int kSuper = 8;       // column tiles per supertile (one row bucket x 8 tiles = 1 024 x 512 conformers)
 
 struct BucketGeom {
@@ -2659,11 +2658,13 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
       int rank = 0;
       if (have) rank = atomicAdd(&s_bin[row], 1);
       __syncthreads();
-      if (wv == 0) {  // exclusive scan of the 1 024 bins: sixteen per lane
-        int c[16], tot = 0;
+      if (wv == 0) {  // exclusive scan of the bins (1 024: sixteen per lane)
+        constexpr int kPerLane = kBucketRows / 64;
+        static_assert(kBucketRows % 64 == 0 && kBucketRows >= 64, "bins are scanned by one wavefront");
+        int c[kPerLane], tot = 0;
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-          c[k2] = s_bin[16 * lane + k2];
+        for (int k2 = 0; k2 < kPerLane; ++k2) {
+          c[k2] = s_bin[kPerLane * lane + k2];
           tot += c[k2];
         }
         int incl = tot;
@@ -2674,8 +2675,8 @@ k_refine_buckets(const double *__restrict__ Xs, const double *__restrict__ G, in
         }
         int run = incl - tot;
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-          s_bin[16 * lane + k2] = run;
+        for (int k2 = 0; k2 < kPerLane; ++k2) {
+          s_bin[kPerLane * lane + k2] = run;
           run += c[k2];
         }
       }
