@@ -176,7 +176,7 @@ size_t size_class(size_t n) {
 }
 }  // namespace
 
-void *pool_take(size_t n, size_t *capacity) {
+void *pool_take(size_t n, size_t *capacity, bool any_larger) {
   Pool &P = pool();
   const size_t want = size_class(n);
   {
@@ -186,7 +186,7 @@ void *pool_take(size_t n, size_t *capacity) {
       P.limit_read = true;
     }
     auto it = P.free_blocks.lower_bound(want);
-    if (it != P.free_blocks.end() && it->first <= 2 * want) {  // never hand a huge block to a small request
+    if (it != P.free_blocks.end() && (any_larger || it->first <= 2 * want)) {  // never hand a huge block to a small LASTING request
       void *p = it->second;
       *capacity = it->first;
       P.cached -= it->first;

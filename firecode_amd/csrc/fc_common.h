@@ -113,7 +113,7 @@ int ensure_init();  // lazy init on device 0 (or the one given to fc_init)
 // (prune_pipeline, the sharded steps) starts behind an event recorded on that stream, ends with a
 // wait on all its side streams, and sizes its grow-only buffers before it forks.
 // FC_POOL_MB caps what is kept (default 8192 of the 288 GB, 0 = no caching); fc_memory_trim() empties it.
-void *pool_take(size_t n, size_t *capacity);  // nullptr when the device is out of memory
+void *pool_take(size_t n, size_t *capacity, bool any_larger = false);  // nullptr when the device is out of memory
 void pool_give(void *p, size_t capacity);
 void pool_trim();
 
@@ -164,8 +164,9 @@ struct DevBuf {
     epoch = o.epoch;
     owned = false;
   }
-  // grow-only allocation; contents are NOT preserved
-  int reserve(size_t n) {
+  // grow-only allocation; contents are NOT preserved.  any_larger: a transient block (ArenaScope) takes the smallest
+  // cached block that fits, however large, before a new hipMalloc
+  int reserve(size_t n, bool any_larger = false) {
     if (n <= bytes && p) return FC_OK;
     release();
     if (n == 0) n = 8;
@@ -179,7 +180,7 @@ struct DevBuf {
       }
     }
     size_t cap = 0;
-    p = pool_take(n, &cap);
+    p = pool_take(n, &cap, any_larger);
     if (!p) return set_error(FC_E_NOMEM, "device allocation of %zu bytes failed", n);
     bytes = cap;
     epoch = ctx().epoch;
@@ -197,7 +198,10 @@ struct ArenaScope {  // declare BEFORE the buffers that are to come from it (des
   int begin(size_t bytes) {
     prev = thread_arena();
     thread_arena() = nullptr;  // the block itself comes from the pool
-    const int rc = block.reserve(bytes);
+    // (a level's block is held for a few ms: in the FIRST ladder of a process the coarsest levels come first and leave
+    // blocks more than twice as large as the finer levels ask for -- with the pool's usual "at most 2 x" rule every
+    // level of the first search paid its own hipMalloc: 52 against 25 ms for the ladder)
+    const int rc = block.reserve(bytes, true);
     if (rc != FC_OK) {
       thread_arena() = prev;
       return rc;
