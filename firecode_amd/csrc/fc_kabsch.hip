@@ -1587,6 +1587,10 @@ __global__ void k_screen_density_verdict(unsigned long long *__restrict__ counte
 // KS2 = k-steps of 32 atoms (template: everything unrolled, operand arrays in registers).
 // ---------------------------------------------------------------------------
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+// k-steps of 32 atoms the split-half kernel is built for: 6 = 192 atoms, a 144 KB column tile, one workgroup per CU
+// (round 4; 4 = 128 atoms until then, larger structures on the fp32 matrix pipe: 1.7-2.3 ms per 7.2e7 pairs at 129-200
+// atoms against 0.74 at 128)
+constexpr int64_t kH2MaxKS2 = 6;
 #ifndef FC_H2_WGS
 #define FC_H2_WGS 3
 #endif
@@ -1596,7 +1600,7 @@ typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 // the phased order, and 667 against 629 ns at four: on gfx950 the vector work of a wave does not hide under its own
 // f16 MFMAs any better than under a sibling wave's; more resident waves is what helps.)
 template <int KS2, bool BITS>
-__global__ void __launch_bounds__(256, (KS2 <= 2 ? FC_H2_WGS : 2))
+__global__ void __launch_bounds__(256, (KS2 <= 2 ? FC_H2_WGS : KS2 <= 3 ? 2 : 1))  // (four k-steps and more: the column tile leaves one workgroup per CU anyway)
 k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__ G, int64_t N, int64_t Npad,
                          float half_A_thr2, float tiny_floor, float scale2, KabschF32Bounds bd, int IB, int64_t rank,
                          int64_t world, uint64_t *__restrict__ bits, int64_t W, uint32_t *__restrict__ cand,
@@ -3403,7 +3407,7 @@ int h2_model_ok(bool *ok);  // fc_h2_check.hip
 int ensure_h2_operands(fc_ensemble *e, double *scale_out) {
   *scale_out = 0.0;
   const int64_t KS2 = (e->A + 31) / 32, A4 = (e->A + 3) / 4 * 4;
-  if (KS2 > 4 || (uint64_t)(24 * KS2) * (uint64_t)e->Npad >= (1ull << 32)) return FC_OK;
+  if (KS2 > kH2MaxKS2 || (uint64_t)(24 * KS2) * (uint64_t)e->Npad >= (1ull << 32)) return FC_OK;
   if (!(e->g_max > 0.0) || !std::isfinite(e->g_max)) return FC_OK;
   // largest |coordinate| <= sqrt(g_max): scaled into [2^12, 2^13] (halfs reach 65504; s^4 stays in fp32)
   int ex = 0;
@@ -3458,7 +3462,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
     const int64_t A4s = (e->A + 3) / 4 * 4, KS2s = (e->A + 31) / 32;
     const bool single_ok = fits32 && e->row_block % 64 == 0 &&
                            ((size_t)A4s * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32 <= kLdsLimit ||
-                            (KS2s <= 4 && (size_t)KS2s * 24 * 1024 + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32 <= kLdsLimit));
+                            (KS2s <= kH2MaxKS2 && (size_t)KS2s * 24 * 1024 + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32 <= kLdsLimit));
     bool done = true;  // false: the matrix-pipe path declined, the VALU screen below takes the launch
     auto mfma_path = [&]() -> int {
       auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
@@ -3557,7 +3561,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         done = false;
         return FC_OK;
       }
-      if (f32_allowed && h2_env != 0 && g_screen_forced != 32 && KS2 <= 4 &&
+      if (f32_allowed && h2_env != 0 && g_screen_forced != 32 && KS2 <= kH2MaxKS2 &&
           (uint64_t)(24 * KS2) * (uint64_t)e->Npad < (1ull << 32)) {
         FC_TRY(ensure_gmax());
         bool model_ok = false;
@@ -3568,9 +3572,10 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
           use_h2 = h2_scale > 0.0 && std::isfinite((float)(0.5 * A_thr2 * s2)) && (float)(0.5 * A_thr2 * s2) > 0.f;
         }
       }
-      const KabschF32Bounds bd = use_h2 ? kabsch_h2_bounds(KS2) : kabsch_f32_bounds(A4);
+      KabschF32Bounds bd = use_h2 ? kabsch_h2_bounds(KS2) : kabsch_f32_bounds(A4);
       const size_t lds_f32_tile = (size_t)A4 * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) * 6 + kStageBytesF32;
-      bool use_f32 = f32_allowed && bd.p0 < 2.0e-3f && (use_h2 || lds_f32_tile <= kLdsLimit);
+      // (p0: 1.9e-3 at five, 2.2e-3 at six k-steps of the split-half kernel; the fp32 kernel reaches 2e-3 at ~370 atoms)
+      bool use_f32 = f32_allowed && bd.p0 < (use_h2 ? 2.5e-3f : 2.0e-3f) && (use_h2 || lds_f32_tile <= kLdsLimit);
       if (g_screen_forced == 16 && !use_h2) return set_error(FC_E_INVALID, "fc_screen_select(16): the split-half screen does not apply to this ensemble");
       bool speculative = f32_env && f32_env[0] == '3';  // FC_SCREEN_F32=3: always with the verdict
       if (use_f32 && !(f32_env && (f32_env[0] == '2' || f32_env[0] == '3'))) {  // FC_SCREEN_F32=2 / 3: no matter how wide the band
@@ -3596,6 +3601,19 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         }();
         use_f32 = band <= kBandMax * thr2_margin;
         speculative = band > 0.1 * thr2_margin;  // narrow band: not worth the verdict's ~10 us
+        if (!use_f32 && use_h2 && g_screen_forced != 16 && lds_f32_tile <= kLdsLimit) {
+          // the split-half bound is about twice the fp32 kernel's (66 u per 32 atoms against one u per atom): where its band
+          // is too wide and the fp32 kernel's is not -- 160 stretched atoms -- the fp32 matrix pipe is still 2.5 x faster
+          // than the vector screen that would take the launch otherwise
+          const KabschF32Bounds bf = kabsch_f32_bounds(A4);
+          const double band_f = (double)bf.p0 * 2.0 * e->g_max / (double)e->A;
+          if (bf.p0 < 2.0e-3f && band_f <= kBandMax * thr2_margin) {
+            use_h2 = false;
+            bd = bf;
+            use_f32 = true;
+            speculative = band_f > 0.1 * thr2_margin;
+          }
+        }
       }
       if (!mfma64_ok) {
         if (!use_f32) {  // no fp64 matrix-pipe screen to fall back on at this size
@@ -3624,7 +3642,9 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
     case 1: FC_LAUNCH_H2(1, BITS_); break;     \
     case 2: FC_LAUNCH_H2(2, BITS_); break;     \
     case 3: FC_LAUNCH_H2(3, BITS_); break;     \
-    default: FC_LAUNCH_H2(4, BITS_); break;    \
+    case 4: FC_LAUNCH_H2(4, BITS_); break;     \
+    case 5: FC_LAUNCH_H2(5, BITS_); break;     \
+    default: FC_LAUNCH_H2(6, BITS_); break;    \
   }
 #ifdef FC_H2_TIMELINE
         static DevBuf tlbuf;

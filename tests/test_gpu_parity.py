@@ -237,8 +237,10 @@ def test_fp32_screen_far_from_the_origin(fc, monkeypatch):
             out[mode] = (unpack_bits(bits, len(X)), grey)
         from firecode_amd import _lib
 
-        # which screen was launched (first): forced by the knob, fp64 by the launcher's own band estimate here
-        assert _lib.screen_last_kind() in {"0": (64,), "2": (16, 32), "3": (16, 32), None: (64,)}[mode]
+        # which screen was launched (first): forced by the knob; the launcher's own band estimate finds the split-half
+        # band (2.0 A^2) too wide and either takes the fp64 screen at once or, since the fp32 kernel's bound is tighter
+        # (0.7 A^2 here, below four squared thresholds), that kernel with the verdict behind it
+        assert _lib.screen_last_kind() in {"0": (64,), "2": (16, 32), "3": (16, 32), None: (64, 32)}[mode]
     assert np.array_equal(out["0"][0], out["2"][0]) and np.array_equal(out["0"][0], out[None][0])
     assert np.array_equal(out["0"][0], out["3"][0])
     assert out["0"][1] == out["2"][1] == out["3"][1] == out[None][1]
@@ -1196,10 +1198,12 @@ def test_sharded_scan_and_pose_grid_logical_ranks(fc):
 
 
 # ---------------------------------------------------------------- screen-kernel variants / odd shapes
-@pytest.mark.parametrize("n,a", [(2, 1), (3, 2), (70, 3), (130, 5), (200, 80), (150, 104), (140, 110), (90, 130)])
+@pytest.mark.parametrize("n,a", [(2, 1), (3, 2), (70, 3), (130, 5), (200, 80), (150, 104), (140, 110), (90, 130), (150, 160), (130, 192), (100, 193)])
 def test_prune_odd_shapes_and_all_screen_variants(fc, n, a):
-    """A <= 53: mfma<4>; 54..104: mfma<8> (one workgroup per CU); > 104: VALU screen
-    without LDS staging; plus tiny atom counts (K padded to 4) and tiny N"""
+    """Every size class of the screens behind prune_by_rmsd: the split-half kernel with 1 ... 6 k-steps of 32 atoms (up to
+    192 atoms; 4 and more: one workgroup per CU), the fp32 matrix pipe beyond (193), the fp64 kernels behind them
+    (mfma<4> up to 52 atoms, mfma<8> up to 104, the vector screen without an LDS tile above); tiny atom counts (K padded
+    to 4) and tiny N"""
     X, atoms, asg = syn.synthetic_ensemble(n, a, seed=90 + a, cluster_size=3)
     S0, R0, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
     ref = o.greedy_prune_from_matrix(S0)
