@@ -27,6 +27,7 @@ constexpr size_t kHalf = (size_t)96 << 20;          // bytes per buffer half (al
 constexpr size_t kHeader = 4096;
 struct Header {
   std::atomic<uint64_t> arrived[64];                 // calls completed by each rank (its piece of call k is written)
+  std::atomic<uint64_t> joined;                      // ranks that have mapped the file (ncclCommInitRank is collective)
 };
 struct StubComm {
   int rank = 0, world = 1;
@@ -67,6 +68,16 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
   close(fd);
   if (p == MAP_FAILED) return ncclSystemError;
   c->base = static_cast<char *>(p);
+  // collective, like the real one: return once every rank has joined.  (The callers rely on that -- rank 0 of
+  // firecode_amd.dist.comm_init_from_env removes the id file behind fc_comm_init; a stand-in that returned at once let
+  // rank 0 remove it before a slow rank had read it: one time-out in ~20 runs of tests/test_gpu_comm_stub.py.)
+  auto *h = reinterpret_cast<Header *>(c->base);
+  h->joined.fetch_add(1, std::memory_order_acq_rel);
+  const auto t0 = std::chrono::steady_clock::now();
+  while (h->joined.load(std::memory_order_acquire) < (uint64_t)nranks) {
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return ncclSystemError;
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
   *out = reinterpret_cast<ncclComm_t>(c);
   return ncclSuccess;
 }

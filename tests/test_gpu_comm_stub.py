@@ -77,8 +77,9 @@ def test_sharded_prune_across_rank_processes_on_one_device(stub_lib, tmp_path, w
                 if q.poll() is None:
                     q.kill()
             raise
-    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"rank {rank} ok" in so, f"rank {rank}: {se[-2500:]}"
+    bad = [f"rank {rank} (exit {p.returncode}): {se[-1500:]}" for rank, (p, (so, se)) in enumerate(zip(procs, outs))
+           if p.returncode != 0 or f"rank {rank} ok" not in so]
+    assert not bad, "\n".join(bad)  # (every rank's end: the first one to fail is usually not the one that caused it)
     res = [np.load(out + f"{r}.npz") for r in range(world)]
     ref = res[0]["ref"]
     assert 0 < ref.sum() == int(res[0]["clusters"]) < n
