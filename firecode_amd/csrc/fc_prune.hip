@@ -307,12 +307,10 @@ __global__ void __launch_bounds__(256)
 k_export_pairs(const uint64_t *__restrict__ simq, const unsigned long long *__restrict__ counters,
                unsigned long long cand_cap, int64_t cap, uint64_t *__restrict__ out) {
   const unsigned long long n = counters[2];
-  // [12]: this rank's speculative screen was voted down (k_screen_verdict emptied its queues; the rank will redo the prune):
-  // the other ranks must not take this rank's EMPTY list for its answer, nor take the pair path while this rank takes the
-  // per-level one -- the message says "none" and every rank declines together.  (Until round 4 only the queue overflow
-  // was announced: a verdict on one rank alone left the ranks with different masks and different numbers of collectives
-  // -- found as a rare time-out of tests/test_gpu_comm_stub.py's dense case, whose four-entry queue makes the verdict a
-  // four-sample estimate.)
+  // [12]: this rank's speculative screen was voted down in the "decline, redo later" mode of the single-GPU pipeline
+  // (Context::optimistic_screen; k_screen_verdict has emptied the queues).  The sharded pipeline redoes such a screen in
+  // place and never gets here with [12] set; should that change, the other ranks must not take this rank's EMPTY list
+  // for its answer, nor stay on the pair path while this rank leaves it: the message says "none", every rank declines.
   const bool overflow = counters[6] > cand_cap || counters[12] != 0ull;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

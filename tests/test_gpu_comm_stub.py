@@ -92,6 +92,72 @@ def test_sharded_prune_across_rank_processes_on_one_device(stub_lib, tmp_path, w
         assert sum(int(r["similar_local"]) for r in res) == int(res[0]["similar_all"])
 
 
+CHILD_VERDICT = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import firecode_amd as fc
+from firecode_amd import _lib, dist as fdist
+rank, world, _ = fdist.comm_init_from_env()
+rng = np.random.default_rng(77)
+bases = rng.normal(scale=2.5, size=(128, 1, 20, 3))                     # 128 shapes x 8 noisy copies: similar pairs only inside a shape
+X = (bases + rng.normal(scale=0.05, size=(128, 8, 20, 3))).reshape(1024, 20, 3)
+X[128:384] = bases[16] + rng.normal(scale=0.4, size=(256, 20, 3))      # row blocks 1 and 2 (rank 1's): a family ~1 A apart, none similar
+X = X + np.array([40.0, -25.0, 10.0])                                   # uncentred, far from the origin: a wide undecidable band
+expected = np.zeros(1024, dtype=bool)
+expected[7::8] = True                                                   # the last copy of every shape survives ...
+expected[128:384] = True                                                # ... and every member of the family
+with fc.DeviceEnsemble(X, center=False) as ens:
+    ref, _ = ens.prune(0.5, 1.0)                                         # this rank alone (FC_SCREEN_F32=3: verdict, fp64 redo in place)
+    assert np.array_equal(ref, expected)
+    mask, st = ens.prune_sharded(0.5, 1.0)
+    print("rank", rank, "pair path" if st[4] else "per-level path", flush=True)
+    _, _, mask_lanes, _ = ens.bench_prune_sharded(0.5, 1.0, reps=3, overlap=True)
+np.savez({out!r} + str(rank) + ".npz", ref=ref, mask=mask, mask_lanes=mask_lanes)
+_lib.comm_barrier()
+_lib.comm_destroy()
+print("rank", rank, "ok")
+"""
+
+
+def test_a_verdict_on_one_rank_only(stub_lib, tmp_path):
+    """The speculative single-precision screen is voted down by a kernel that samples the RANK'S OWN candidate queue.  Here
+    only rank 1's rows hold pairs inside the undecidable band (a family of 256 conformers ~1 A apart in row blocks 1 and 2,
+    everything else well-separated clusters; uncentred coordinates 48 A from the origin make the band ~2 A^2 wide;
+    FC_SCREEN_F32=3 takes the speculative screen whatever the band): rank 1 is voted down and redoes its rows with the
+    fp64 screen IN PLACE (the sharded pipeline does not use the single-GPU pipeline's "decline and redo later" mode),
+    rank 0 is not -- both stay on the pair path, one all-gather each, and every rank's mask is the known answer.  (Should
+    a declined screen ever reach the exchange, its message says "none" and every rank declines together: k_export_pairs.)"""
+    idfile = str(tmp_path / "comm.id")
+    out = str(tmp_path / "rank")
+    code = CHILD_VERDICT.format(root=ROOT, out=out)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", FC_COMM_ID_FILE=idfile, FC_RCCL_LIB=stub_lib,
+                   FC_COMM_TIMEOUT_S="60", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env["FC_SCREEN_F32"] = "3"  # the speculative screen with the verdict behind it, whatever the band (read once per process)
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            raise
+    bad = [f"rank {rank} (exit {p.returncode}): {se[-1500:]}" for rank, (p, (so, se)) in enumerate(zip(procs, outs))
+           if p.returncode != 0 or f"rank {rank} ok" not in so]
+    assert not bad, "\n".join(bad)
+    assert all("pair path" in so for so, _ in outs), [so for so, _ in outs]  # nobody fell back to the per-level exchange
+    res = [np.load(out + f"{r}.npz") for r in range(2)]
+    ref = res[0]["ref"]
+    assert ref.sum() == 96 + 256  # one survivor per remaining shape (the family replaced the copies of 32 shapes), every member of the family
+    for r in range(2):
+        for key in ("ref", "mask", "mask_lanes"):
+            assert np.array_equal(res[r][key], ref), (r, key)
+
+
 def test_bench_two_ranks_with_a_working_communicator(stub_lib):
     """`python bench.py --gpus 2` as typed, both ranks on device 0 (FC_BENCH_SAME_DEVICE=1) with the stand-in collective:
     the blocks that exchange data (prune_path, cfg4_family) run for real -- masks checked against the synthetic
