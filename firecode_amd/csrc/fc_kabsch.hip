@@ -462,6 +462,43 @@ __device__ __forceinline__ void stage_pairs_wave(uint64_t m, bool may, unsigned 
   }
 }
 
+// The fp64 screen has no LDS to spare (two workgroups of 80 KB per CU at 50 atoms leave 48 bytes): its 384 bytes of pair
+// staging hold 96 four-byte entries (row within the item << 6 | column within the tile), a share of them per wavefront,
+// counted in a scalar register; a wavefront whose share is full publishes it with ONE global atomic and starts over.
+// (Until round 4: 48 eight-byte entries shared through an LDS atomic, and one global atomic per 16-row ballot once
+// they were full -- 4.3 of the 4.96 ms of a prune of the continuous-RMSD ensemble on this screen.)
+__device__ __forceinline__ void flush_pairs_wave32(const uint32_t *__restrict__ sq_wave, int n_staged, unsigned i0, unsigned j0,
+                                                   uint64_t *__restrict__ pairq, unsigned long long Q,
+                                                   unsigned long long *__restrict__ counters, int lane) {
+  if (n_staged == 0) return;  // wave-uniform
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(&counters[6], (unsigned long long)n_staged);
+  base = __shfl(base, 0);
+  for (int idx = lane; idx < n_staged; idx += 64) {
+    const uint32_t e = sq_wave[idx];
+    const unsigned long long slot = base + (unsigned long long)idx;
+    if (slot < Q) pairq[slot] = ((uint64_t)(i0 + (e >> 6)) << 32) | (uint64_t)(j0 + (e & 63u));
+  }
+}
+template <int WCAP>
+__device__ __forceinline__ void stage_pairs_wave32(uint64_t m, bool may, unsigned i, unsigned j, unsigned i0, unsigned j0,
+                                                   uint32_t *__restrict__ sq_wave, int &n_staged,
+                                                   uint64_t *__restrict__ pairq, unsigned long long Q,
+                                                   unsigned long long *__restrict__ counters, int lane) {
+  if (m == 0) return;  // wave-uniform
+  const int n = (int)__popcll(m);
+  if (n > WCAP) {  // (more pairs in one ballot than a share holds)
+    push_pairs(m, may, i, j, pairq, Q, counters, lane);
+    return;
+  }
+  if (n_staged + n > WCAP) {
+    flush_pairs_wave32(sq_wave, n_staged, i0, j0, pairq, Q, counters, lane);
+    n_staged = 0;
+  }
+  if (may) sq_wave[n_staged + (int)__popcll(m & ((1ull << lane) - 1ull))] = ((i - i0) << 6) | (j - j0);
+  n_staged += n;
+}
+
 // ---------------------------------------------------------------------------
 // k_simbits_screen -- the dominant kernel of the pruning stage.
 //
@@ -657,6 +694,11 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
   const int64_t i0 = global_block(lb, rank, world) * IB;
   if (i0 >= N) return;               // block-uniform
   if (j0 + TC - 1 <= i0) return;     // nothing above the diagonal in this item
+  // MODE 0 (the screen): the pair staging area as four-byte entries, a share per wavefront (stage_pairs_wave32)
+  uint32_t *__restrict__ sq32_wave = reinterpret_cast<uint32_t *>(stageQ) + wv * (kStagePairs * 2 / NW);
+  int n_staged32 = 0;
+  (void)sq32_wave;
+  (void)n_staged32;
 
   {  // stage the column tile by LDS-DMA (global_load_lds_dwordx4): no VGPR staging, every
     // piece of a wave in flight at once.  The hardware writes lane l's 16 bytes at
@@ -984,7 +1026,11 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
           bool may = kabsch_may_be_below(B9, Gp + Gq, A_thr2);
           may = may && (j > i) && (j < n32) && (i < n32);
           mr[r] = __ballot(may);
-          stage_pairs(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
+          if constexpr (MODE == 0)
+            stage_pairs_wave32<kStagePairs * 2 / NW>(mr[r], may, (unsigned)i, (unsigned)j, (unsigned)i0, (unsigned)j0, sq32_wave,
+                                                     n_staged32, pairq, Q, counters, lane);
+          else
+            stage_pairs(mr[r], may, (unsigned)i, (unsigned)j, stageQ, stageN, pairq, Q, counters, lane);
         }
         // bit (16 kq' + c) of mr[r] belongs to row kq' + 4 r: lane l < 16 writes the piece of
         // row l = (l & 3) + 4 (l >> 2), one store per sub-tile instead of one per register
@@ -1020,13 +1066,14 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 #endif
     }
   }
-  // publish what the workgroup staged: one global atomic per queue
+  // publish what the workgroup staged: one global atomic per queue (the screen's pairs: per wavefront)
+  if constexpr (MODE == 0) flush_pairs_wave32(sq32_wave, n_staged32, (unsigned)i0, (unsigned)j0, pairq, Q, counters, lane);
   __syncthreads();
 #ifdef FC_TIMELINE
   if (!VALUES && tl && tid == 0) tl[(size_t)b * 4 + 2] = wall_clock64();
 #endif
   if (wv == 0) {
-    {
+    if constexpr (MODE != 0) {
       const uint64_t e = lane < kStagePairs ? stageQ[lane] : ~0ull;
       const bool valid = e != ~0ull;
       const uint64_t mv = __ballot(valid);
