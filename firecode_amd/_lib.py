@@ -120,6 +120,7 @@ _SIGNATURES = {
     "fc_debug_pyset_order_ints": [_p_i64, _i64, _p_i64, _p_i64],
     "fc_debug_pyset_order_pairs": [_p_i64, _i64, _p_i64, _p_i64],
     "fc_debug_pyset_order_pairs_device": [_p_i64, _i64, _p_i64],
+    "fc_debug_tfd_ladder_emulate": [_p_i64, _i64, _p_u8],
     "fc_xyz_write": [C.c_char_p, C.POINTER(C.c_char_p), _i64, _p_f64, _i64, C.c_char_p, C.c_int],
     "fc_xyz_scan": [C.c_char_p, _p_i64, _p_i64],
     "fc_cartesian_product_i64": [_p_i64, _p_i64, _i64, _p_i64],

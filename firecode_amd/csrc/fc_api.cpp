@@ -98,7 +98,8 @@ int warm_torsion();
 int warm_prune();
 int warm_h2_check();
 int warm_kabsch();
-int warm_tfd_gpu();
+int warm_tfd_ladder();
+int tfd_ladder_emulate_device(const int64_t *, int64_t, uint8_t *);
 int xyz_write(const char *, const char *const *, int64_t, const double *, int64_t, const char *, int);
 int xyz_read(const char *, int64_t *, int64_t *, char *, double *);
 int launch_embed_mol_transforms(const double *, int64_t, int64_t, const int64_t *, int, const double *,
@@ -244,7 +245,6 @@ static void context_teardown() {
       (void)hipStreamDestroy(s);
     }
   c.s_screen = c.s_lane[0] = c.s_lane[1] = c.s_lane[2] = c.s_comm = nullptr;
-  tfd_level_streams_teardown();
   for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
   c.ev_pool.clear();
   for (hipEvent_t e : c.ev_dep_pool) (void)hipEventDestroy(e);
@@ -854,9 +854,8 @@ int fc_warmup(void) {
   FC_TRY(warm_prune());
   FC_TRY(warm_h2_check());
   FC_TRY(warm_kabsch());
-  FC_TRY(warm_tfd_gpu());
+  FC_TRY(warm_tfd_ladder());
   FC_TRY(side_streams());  // the pipelines' streams and ordering events
-  FC_TRY(tfd_level_streams(3));  // the TFD ladder's helper streams (hardware queues: several ms each on first use)
   // the buffers a first large call would otherwise take from the runtime one by one (0.2 - 1 ms each): through the pool once
   {
     DevBuf warm[6];
@@ -2453,11 +2452,10 @@ int fc_tfd_ladder_from_first_match(const int64_t *first_match, int64_t N, uint8_
   for (int64_t i = 0; i < N; ++i)
     FC_REQUIRE(first_match[i] == -1 || (first_match[i] > i && first_match[i] < N), "first_match[%lld] invalid", (long long)i);
   const auto t1 = std::chrono::steady_clock::now();
-  // with a device at hand the coarse levels' chunk graphs are built there (a pure host function otherwise: the
-  // CPU tests call it without a GPU)
+  // with a device at hand the ladder runs there (a pure host function otherwise: the CPU tests call it without a GPU)
   DevBuf dfm;
   const int64_t *fm_dev = nullptr;
-  if (ctx().ready && N >= 131072) {
+  if (ctx().ready && N >= 20000) {
     FC_TRY(ensure_init());  // (the calling thread's current device: HIP keeps it per thread)
     FC_TRY(upload(dfm, first_match, (size_t)N));
     fm_dev = dfm.as<int64_t>();
@@ -2489,6 +2487,20 @@ int fc_debug_pyset_order_ints(const int64_t *keys, int64_t n, int64_t *order_out
   for (size_t k = 0; k < o.size(); ++k) order_out[k] = o[k];
   *n_out = (int64_t)o.size();
   return FC_OK;
+}
+
+int fc_debug_tfd_ladder_emulate(const int64_t *first_match, int64_t N, uint8_t *mask_out) {
+  FC_API_LOCK;
+  FC_REQUIRE(N >= 0, "bad shape");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(first_match && mask_out, "NULL pointer argument");
+  for (int64_t i = 0; i < N; ++i)
+    FC_REQUIRE(first_match[i] == -1 || (first_match[i] > i && first_match[i] < N), "first_match[%lld] invalid", (long long)i);
+  try {
+    return tfd_ladder_emulate_device(first_match, N, mask_out);
+  } catch (const std::bad_alloc &) {
+    return set_error(FC_E_NOMEM, "out of host memory");
+  }
 }
 
 int fc_debug_pyset_order_pairs_device(const int64_t *pairs, int64_t n, int64_t *order_out) {

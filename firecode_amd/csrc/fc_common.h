@@ -95,8 +95,6 @@ struct Context {
 // after the other.  Recursive: entry points are also used as building blocks of others.
 std::recursive_mutex &api_mutex();
 #define FC_API_LOCK std::lock_guard<std::recursive_mutex> fc_api_lock_guard(::fc::api_mutex())
-int tfd_level_streams(int n);  // fc_tfd_host.cpp: the ladder's helper streams, created once
-void tfd_level_streams_teardown();
 int side_streams();  // creates Context::s_screen / s_lane / s_comm and the ordering events once
 int pinned_reserve(size_t bytes);  // grows ctx().pinned
 // blocking copies through pinned pieces of the library's own (see h2d / d2h below); ordered behind what `st` holds
@@ -311,25 +309,6 @@ inline int64_t local_block_count(int64_t n_gblocks, int64_t rank, int64_t world)
   while (global_block(n, rank, world) < n_gblocks) ++n;  // strictly increasing in n
   return n;
 }
-
-// Host view of one coarse TFD ladder level's chunk graphs (all non-last chunks), built on the device
-// (fc_tfd_gpu.hip) and read by the component phase of fc_tfd_host.cpp.
-struct TfdLevelGraph {
-  int n_chunks = 0;
-  int64_t d = 0;
-  std::vector<int64_t> ebase, nbase, sbase;                  // per chunk (+1): edges, nodes, component sources before it
-  // level-wide arrays in COMPONENT-MAJOR node order: component j = nodes [sources[j], sources[j + 1]) led by its earliest
-  // node (graph order); nodes[v] = relative index in its chunk; neighbours of v = adj_next[adj_head[v] .. adj_head[v + 1])
-  // (level-wide node numbers) in insertion order
-  std::vector<int32_t> nodes, adj_head, adj_next, sources;
-  std::vector<int32_t> left;  // components the device left to the host (flags mode: those above its size cap)
-  // flags mode: the arrays above hold ONLY the left components (compact numbering, CSR concatenated: left = 0 .. n - 1,
-  // component j = nodes [sources[j], sources[j + 1])), left_chunk[j] = the chunk component j lives in, n_components = the
-  // level's component count (for the log)
-  std::vector<int32_t> left_chunk;
-  int64_t n_components = 0;
-};
-int tfd_level_graph_device(const int64_t *fm_dev, int64_t N, int64_t k, TfdLevelGraph &out, uint8_t *flags_out = nullptr);
 
 }  // namespace fc
 

@@ -1,0 +1,685 @@
+// fc_tfd_core.h -- the per-chunk and per-component routines of prune_conformers_tfd's k-ladder
+// (firecode/torsion_module.py:985-1041), written ONCE for the device and for the host.
+//
+// What the reference does per chunk: a Python set of first-match pairs (i_rel, j_rel) -> networkx.Graph(matches) ->
+// connected_components -> keep tuple(g.subgraph(c).nodes)[0] of every component.  Which node that is follows from
+// three CPython / networkx orders (fc_tfd_host.cpp's header); this file states them as data-parallel steps over a
+// GROUP of threads (one wavefront, one workgroup -- or one host thread, for the CPU tests and the fallbacks):
+//
+//   pyset_build     final slot of every key of a CPython set filled in a given arrival order (staged priority
+//                   first-fit, one stage per growth step: see fc_tfd_ladder.hip's header);
+//   chunk_front     one chunk of at most kChunkMax structures, everything in the group's local memory: tuple-set
+//                   slots of the edges, tree roots, component sizes and member lists; components of up to
+//                   kTinyMax nodes are finished on the spot (one lane each), larger ones are exported;
+//   tiny_first      group[0] of a component of up to kTinyMax nodes by one lane;
+//   comp_group_first  group[0] of a component of any size by a whole group: neighbour lists in edge order by
+//                   counting, breadth-first order level by level through prefix sums (a first-match graph is a
+//                   forest: every neighbour but the one a node was reached from is new), the two int sets by
+//                   pyset_build.
+//
+// Every loop over elements is `for (x = g.tid; x < n; x += g.size)`, every hand-over a g.sync(): with the host group
+// (tid 0, size 1) the same source runs sequentially -- tests/test_tfd_ladder_v2.py runs the whole ladder that way on the
+// CPU against the all-host ladder of fc_tfd_host.cpp.
+#pragma once
+
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define FC_HD __host__ __device__ __forceinline__
+#define FC_HDC __host__ __device__ constexpr
+#else
+#define FC_HD inline
+#define FC_HDC constexpr
+#endif
+
+namespace fc {
+namespace tfd {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint16_t kNone16 = 0xFFFFu;
+constexpr int kTinyMax = 18;       // components of up to this many nodes: sets of at most 32 slots, one lane each
+constexpr int kChunkMax = 4915;    // chunks of up to this many structures: tuple set of at most 8192 slots in local memory
+constexpr int kGroupCompMax = 4096;  // components of up to this many nodes: one workgroup (larger ones: the host)
+constexpr int kTinyScratch = 104;  // bytes of private scratch of tiny_first
+
+// number of slots - 1 of a CPython set that received n_keys distinct keys one by one (setobject.c: resize when
+// fill * 5 >= mask * 3, to the first power of two above 4 x used, 2 x above 50 000)
+FC_HD uint32_t pyset_final_mask(int64_t n_keys) {
+  uint64_t mask = 7;
+  for (;;) {
+    const int64_t trigger = (int64_t)((mask * 3 + 4) / 5);
+    if (trigger > n_keys) return (uint32_t)mask;
+    const uint64_t minused = trigger > 50000 ? 2 * (uint64_t)trigger : 4 * (uint64_t)trigger;
+    uint64_t newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    mask = newsize - 1;
+    if (trigger == n_keys) return (uint32_t)mask;
+  }
+}
+
+// growth stage s of a set that receives m keys: keys of arrival rank < n_cur live in a table of mask + 1 slots built
+// from the previous table (t_prev slots, keys of rank < n_prev, in slot order) followed by the later arrivals
+struct SetStage {
+  int64_t n_prev, n_cur;
+  uint32_t t_prev, mask;
+  bool exists;
+};
+FC_HD SetStage pyset_stage(int64_t m, int s) {
+  uint64_t mask = 7, t_prev = 0;
+  int64_t n_prev = 0;
+  for (int i = 0;; ++i) {
+    const int64_t trigger = (int64_t)((mask * 3 + 4) / 5);
+    if (i == s) return SetStage{n_prev, trigger > m ? m : trigger, (uint32_t)t_prev, (uint32_t)mask, m > 0};
+    if (trigger > m) return SetStage{0, 0, 0, 0, false};
+    n_prev = trigger;
+    t_prev = mask + 1;
+    const uint64_t minused = trigger > 50000 ? 2 * (uint64_t)trigger : 4 * (uint64_t)trigger;
+    uint64_t newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    mask = newsize - 1;
+  }
+}
+FC_HD int pyset_stage_count(int64_t m) {
+  int s = 0;
+  while (pyset_stage(m, s).exists) ++s;
+  return s;
+}
+
+// hash((a, b)) of two non-negative Python ints (tupleobject.c, xxHash-style)
+FC_HD int64_t tuple2_hash(uint64_t a, uint64_t b) {
+  const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P5 = 2870177450012600261ULL;
+  uint64_t acc = P5;
+  acc += a * P2;
+  acc = (acc << 31) | (acc >> 33);
+  acc *= P1;
+  acc += b * P2;
+  acc = (acc << 31) | (acc >> 33);
+  acc *= P1;
+  acc += 2ULL ^ (P5 ^ 3527539ULL);
+  return acc == (uint64_t)-1 ? 1546275796 : (int64_t)acc;
+}
+
+// CPython's probe sequence (setobject.c set_add_entry): slot i, the next LINEAR_PROBES = 9 slots when they fit below
+// the table's end, then i = (i * 5 + 1 + (perturb >>= 5)) & mask
+struct Probe {
+  uint64_t perturb, i;
+  uint32_t mask;
+  int j, lim;
+  FC_HD void start(int64_t hash, uint32_t mask_) {
+    mask = mask_;
+    perturb = (uint64_t)hash;
+    i = (uint64_t)hash & mask;
+    j = 0;
+    lim = (i + 9 <= mask) ? 9 : 0;
+  }
+  FC_HD uint32_t slot() const { return (uint32_t)(i + (uint64_t)j); }
+  FC_HD void next() {
+    if (j < lim) {
+      ++j;
+      return;
+    }
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+    j = 0;
+    lim = (i + 9 <= mask) ? 9 : 0;
+  }
+};
+
+// ---- the host group: one thread stands for the whole group ---------------------------------------------------------
+struct HostGroup {
+  int tid = 0, size = 1;
+  void sync() const {}
+  uint32_t atomic_min(uint32_t *p, uint32_t v) const {
+    const uint32_t o = *p;
+    if (v < o) *p = v;
+    return o;
+  }
+  uint32_t atomic_add(uint32_t *p, uint32_t v) const {
+    const uint32_t o = *p;
+    *p = o + v;
+    return o;
+  }
+  uint32_t atomic_or(uint32_t *p, uint32_t v) const {
+    const uint32_t o = *p;
+    *p = o | v;
+    return o;
+  }
+  uint32_t atomic_cas(uint32_t *p, uint32_t expect, uint32_t v) const {
+    const uint32_t o = *p;
+    if (o == expect) *p = v;
+    return o;
+  }
+  uint16_t atomic_add16(uint16_t *base, int idx, uint16_t v) const {
+    const uint16_t o = base[idx];
+    base[idx] = (uint16_t)(o + v);
+    return o;
+  }
+  uint32_t scan_excl(uint32_t v, uint32_t &total) const {
+    total = v;
+    return 0;
+  }
+  uint32_t reduce_sum(uint32_t v) const { return v; }
+  uint32_t reduce_or(uint32_t v) const { return v; }
+  uint64_t reduce_min64(uint64_t v) const { return v; }
+  bool in_first_wave() const { return true; }
+  HostGroup first_wave() const { return *this; }
+};
+
+// ---- a CPython set's final layout ---------------------------------------------------------------------------------------
+// ids [0, n_ids); rank[id] = arrival rank of the key (kNone16: not a key), m keys in all, hash(id) = its Python hash.
+// Out: pos[id] = the key's slot in the final table.  An open-addressing table filled by first-fit in a FIXED order is
+// the unique fixed point of "every key sits in the first slot of its probe sequence not held by a key of higher
+// priority", so the keys of a stage may be inserted in ANY order if a key that meets a slot held by a lower-priority
+// key takes it and carries the evicted key on along THAT key's sequence: one atomic minimum on (priority << 13 | id)
+// per probe.  Priorities of stage s: the slot in the table of stage s - 1 for the keys that were in it (a rebuild
+// re-inserts in slot order), table size + arrival rank for the rest.  ids < 8192, table of at most 8192 slots.
+template <class G, class HashF>
+FC_HD void pyset_build(G &g, int n_ids, const uint16_t *rank, int m, HashF hash, uint32_t *table, uint16_t *pos) {
+  uint32_t mask = 7, t_prev = 0;
+  int n_prev = 0;
+  for (;;) {
+    const int trigger = (int)((mask * 3u + 4u) / 5u);
+    const int n_cur = trigger > m ? m : trigger;
+    for (uint32_t s = (uint32_t)g.tid; s <= mask; s += (uint32_t)g.size) table[s] = kNone;
+    g.sync();
+    for (int x = g.tid; x < n_ids; x += g.size) {
+      const uint32_t r = rank[x];
+      if (r >= (uint32_t)n_cur) continue;
+      uint32_t me = ((r < (uint32_t)n_prev ? (uint32_t)pos[x] : t_prev + r) << 13) | (uint32_t)x;
+      Probe p;
+      p.start(hash(x), mask);
+      for (;;) {
+        const uint32_t s = p.slot();
+        const uint32_t old = g.atomic_min(&table[s], me);
+        if (old == kNone) break;
+        if (old > me) {  // this key outranks the slot's holder: the holder moves on along ITS sequence, behind slot s
+          me = old;
+          p.start(hash((int)(old & 0x1FFFu)), mask);
+          while (p.slot() != s) p.next();
+        }
+        p.next();
+      }
+    }
+    g.sync();
+    for (uint32_t s = (uint32_t)g.tid; s <= mask; s += (uint32_t)g.size) {
+      const uint32_t v = table[s];
+      if (v != kNone) pos[v & 0x1FFFu] = (uint16_t)s;
+    }
+    g.sync();
+    if (trigger > m) break;
+    n_prev = trigger;
+    t_prev = mask + 1;
+    const uint32_t minused = 4u * (uint32_t)trigger;  // (at most 4915 keys here: never the 2 x rule of large sets)
+    uint32_t newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    mask = newsize - 1;
+  }
+}
+
+// ---- group[0] of a component of at most kTinyMax nodes, by ONE lane -------------------------------------------------------
+// A.x(k): the member's index relative to its chunk (the Python int the reference's sets hold); A.par(k): the relative
+// index of its first match when that lies in the chunk, else A.x(k) itself; A.slot(k): the slot of the edge
+// (x, par) in the chunk's tuple set (any order-preserving number).  n_graph: nodes of the chunk's whole graph.
+template <class Acc>
+FC_HD uint32_t tiny_first(const Acc &A, int n, uint32_t n_graph, uint8_t *scr) {
+  int src = 0;
+  uint32_t best = kNone;
+  for (int k = 0; k < n; ++k)
+    if (A.par(k) != A.x(k) && A.slot(k) < best) best = A.slot(k), src = k;
+  // networkx FilterAtlas: a component of at least half the graph is listed in the GRAPH's node order -- its earliest
+  // node is the first endpoint of its earliest edge
+  if (2u * (uint32_t)n >= n_graph) return A.x(src);
+  const uint32_t fmask = n <= 4 ? 7u : 31u;
+  {  // no two members in one home slot: every member sits at home whatever the order, the first is the smallest residue
+    uint32_t seen = 0, bestr = 64, bx = 0;
+    bool clean = true;
+    for (int k = 0; k < n; ++k) {
+      const uint32_t r = A.x(k) & fmask;
+      if ((seen >> r) & 1u) {
+        clean = false;
+        break;
+      }
+      seen |= 1u << r;
+      if (r < bestr) bestr = r, bx = A.x(k);
+    }
+    if (clean) return bx;
+  }
+  // the reference's orders: _plain_bfs from the earliest node over the neighbour lists in edge order ...
+  uint8_t *q = scr, *frm = scr + 18, *tS = scr + 36, *tV = scr + 68;
+  q[0] = (uint8_t)src;
+  frm[0] = 0xFF;
+  int qt = 1;
+  for (int qh = 0; qh < qt; ++qh) {
+    const int v = q[qh], f = frm[qh];
+    const uint32_t xv = A.x(v), pv = A.par(v);
+    int64_t last = -1;
+    for (;;) {
+      uint32_t bkey = kNone;
+      int bk = -1;
+      for (int k = 0; k < n; ++k) {
+        if (k == v || k == f) continue;
+        uint32_t key;
+        if (A.par(k) == xv) key = A.slot(k);                   // a child of v: the edge is the child's
+        else if (pv != xv && A.x(k) == pv) key = A.slot(v);    // v's own first match
+        else continue;
+        if ((int64_t)key > last && key < bkey) bkey = key, bk = k;
+      }
+      if (bk < 0) break;
+      q[qt] = (uint8_t)bk;
+      frm[qt] = (uint8_t)v;
+      ++qt;
+      last = (int64_t)bkey;
+    }
+  }
+  // ... into a set of ints (hash(n) == n), then the set of that set's iteration (show_nodes), its first element
+  auto place = [&](uint8_t *t, uint32_t mask, int k) {
+    const uint64_t h = A.x(k);
+    uint64_t perturb = h, i = h & mask;
+    for (;;) {
+      const int lim = (i + 9 <= mask) ? 9 : 0;
+      for (int j = 0; j <= lim; ++j)
+        if (t[i + j] == 0xFF) {
+          t[i + j] = (uint8_t)k;
+          return;
+        }
+      perturb >>= 5;
+      i = (i * 5 + 1 + perturb) & mask;
+    }
+  };
+  uint32_t maskS = 7, maskV = 7;
+  auto add = [&](uint8_t *t, uint32_t &mask, int &fill, int k) {
+    place(t, mask, k);
+    ++fill;
+    if ((uint32_t)fill * 5u >= mask * 3u) {  // 8 -> 32 slots at the fifth key; 32 slots hold 18
+      uint8_t old[8];
+      for (int s = 0; s < 8; ++s) old[s] = t[s];
+      for (int s = 0; s < 32; ++s) t[s] = 0xFF;
+      mask = 31;
+      for (int s = 0; s < 8; ++s)
+        if (old[s] != 0xFF) place(t, mask, old[s]);
+    }
+  };
+  for (int s = 0; s < 32; ++s) tS[s] = 0xFF, tV[s] = 0xFF;
+  int fillS = 0, fillV = 0;
+  for (int i = 0; i < qt; ++i) add(tS, maskS, fillS, q[i]);
+  for (uint32_t s = 0; s <= maskS; ++s)
+    if (tS[s] != 0xFF) add(tV, maskV, fillV, tS[s]);
+  for (uint32_t s = 0; s <= maskV; ++s)
+    if (tV[s] != 0xFF) return A.x(tV[s]);
+  return A.x(src);
+}
+
+// ---- group[0] of a component of any size, by a whole group ----------------------------------------------------------------
+// Local memory of comp_group_first for a component of up to `cap` nodes (cap2 = the power of two >= 2 cap, tbl = slots of
+// the sets' final table): see comp_local_bytes.
+struct CompLocal {
+  uint32_t *X, *S;          // [cap] relative index, edge slot of every member
+  uint16_t *pl, *deg, *cur; // [cap] local parent (kNone16: none), degree, fill cursor (later: where a node was reached from)
+  uint16_t *head;           // [cap + 2] neighbour list offsets
+  uint16_t *adjU, *adjS;    // [2 cap] neighbours as they came / in edge order (adjU later: breadth-first order + ranks)
+  uint32_t *table;          // [max(tbl, cap2)] the parent look-up's hash map, then the sets' table
+};
+FC_HDC size_t comp_local_bytes(size_t cap, size_t tbl, size_t cap2) {
+  return cap * 8 + cap * 6 + (cap + 2) * 2 + cap * 8 + (tbl > cap2 ? tbl : cap2) * 4 + 64;
+}
+FC_HD void comp_local_carve(void *mem, size_t cap, size_t tbl, size_t cap2, CompLocal &L) {
+  const size_t t = tbl > cap2 ? tbl : cap2;
+  uint8_t *p = static_cast<uint8_t *>(mem);
+  L.table = reinterpret_cast<uint32_t *>(p), p += t * 4;
+  L.X = reinterpret_cast<uint32_t *>(p), p += cap * 4;
+  L.S = reinterpret_cast<uint32_t *>(p), p += cap * 4;
+  L.adjU = reinterpret_cast<uint16_t *>(p), p += cap * 4;
+  L.adjS = reinterpret_cast<uint16_t *>(p), p += cap * 4;
+  L.pl = reinterpret_cast<uint16_t *>(p), p += cap * 2;
+  L.deg = reinterpret_cast<uint16_t *>(p), p += cap * 2;
+  L.cur = reinterpret_cast<uint16_t *>(p), p += cap * 2;
+  L.head = reinterpret_cast<uint16_t *>(p);
+}
+
+// mx / mp / ms: the members' relative index, first match (relative; the member itself when it has none in the chunk)
+// and edge slot, in any order.  cap2: power of two >= 2 n (the hash map's size).  Returns the kept member's relative index.
+template <class G>
+FC_HD uint32_t comp_group_first(G &g, const CompLocal &L, const uint32_t *mx, const uint32_t *mp, const uint32_t *ms, int n,
+                                uint32_t n_graph, uint32_t cap2) {
+  for (int k = g.tid; k < n; k += g.size) L.X[k] = mx[k];
+  g.sync();
+  // the earliest edge's first endpoint: the component's earliest node in the graph's order, the search's source
+  uint64_t mine = ~0ull;
+  for (int k = g.tid; k < n; k += g.size)
+    if (mp[k] != mx[k]) {
+      const uint64_t key = ((uint64_t)ms[k] << 16) | (uint64_t)k;
+      mine = key < mine ? key : mine;
+    }
+  const int src = (int)(g.reduce_min64(mine) & 0xFFFFull);
+  if (2u * (uint32_t)n >= n_graph) return L.X[src];
+  const uint32_t fmask = pyset_final_mask(n);
+  {  // residues all different: the smallest one's member
+    const uint32_t words = (fmask + 32u) >> 5;
+    for (uint32_t w = (uint32_t)g.tid; w < words; w += (uint32_t)g.size) L.table[w] = 0u;
+    g.sync();
+    uint32_t dirty = 0;
+    uint64_t bestr = ~0ull;
+    for (int k = g.tid; k < n; k += g.size) {
+      const uint32_t r = L.X[k] & fmask, bit = 1u << (r & 31);
+      dirty |= (g.atomic_or(&L.table[r >> 5], bit) & bit) != 0u;
+      const uint64_t key = ((uint64_t)r << 32) | (uint64_t)L.X[k];
+      bestr = key < bestr ? key : bestr;
+    }
+    dirty = g.reduce_or(dirty);
+    bestr = g.reduce_min64(bestr);
+    g.sync();
+    if (!dirty) return (uint32_t)(bestr & 0xFFFFFFFFull);
+  }
+  // local parent of every member through a hash map relative index -> member
+  const uint32_t hmask = cap2 - 1;
+  for (uint32_t s = (uint32_t)g.tid; s < cap2; s += (uint32_t)g.size) L.table[s] = 0u;
+  g.sync();
+  for (int k = g.tid; k < n; k += g.size) {
+    uint32_t h = (L.X[k] * 2654435761u) & hmask;
+    while (g.atomic_cas(&L.table[h], 0u, (uint32_t)k + 1u) != 0u) h = (h + 1) & hmask;
+    L.deg[k] = 0;
+    L.cur[k] = 0;
+  }
+  g.sync();
+  for (int k = g.tid; k < n; k += g.size) {
+    L.S[k] = ms[k];
+    uint16_t p = kNone16;
+    if (mp[k] != mx[k]) {
+      uint32_t h = (mp[k] * 2654435761u) & hmask;
+      for (;;) {
+        const uint32_t e = L.table[h];
+        if (e == 0u) break;  // (cannot happen: a first match inside the chunk is a node of the same tree)
+        if (L.X[e - 1] == mp[k]) {
+          p = (uint16_t)(e - 1);
+          break;
+        }
+        h = (h + 1) & hmask;
+      }
+    }
+    L.pl[k] = p;
+  }
+  g.sync();
+  for (int k = g.tid; k < n; k += g.size)
+    if (L.pl[k] != kNone16) {
+      g.atomic_add16(L.deg, k, 1);
+      g.atomic_add16(L.deg, L.pl[k], 1);
+    }
+  g.sync();
+  {  // neighbour list offsets
+    uint32_t carry = 0;
+    for (int base = 0; base < n; base += g.size) {
+      const int k = base + g.tid;
+      const uint32_t v = k < n ? L.deg[k] : 0u;
+      uint32_t tot;
+      const uint32_t pre = g.scan_excl(v, tot);
+      if (k < n) L.head[k] = (uint16_t)(carry + pre);
+      carry += tot;
+    }
+    if (g.tid == 0) L.head[n] = (uint16_t)carry;
+  }
+  g.sync();
+  for (int k = g.tid; k < n; k += g.size)
+    if (L.pl[k] != kNone16) {
+      const int p = L.pl[k];
+      L.adjU[L.head[k] + g.atomic_add16(L.cur, k, 1)] = (uint16_t)p;
+      L.adjU[L.head[p] + g.atomic_add16(L.cur, p, 1)] = (uint16_t)k;
+    }
+  g.sync();
+  // neighbour lists in edge order (what networkx's adjacency dicts iterate): place = edges of the node with a smaller slot
+  const int n_rec = 2 * (n - 1);
+  for (int rec = g.tid; rec < n_rec; rec += g.size) {
+    int lo = 0, hi = n;  // the node of record rec: head[v] <= rec < head[v + 1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)L.head[mid] <= rec) lo = mid;
+      else hi = mid;
+    }
+    const int v = lo, w = L.adjU[rec];
+    const uint32_t key = (L.pl[v] == w) ? L.S[v] : L.S[w];
+    int place = 0;
+    for (int a = L.head[v]; a < (int)L.head[v + 1]; ++a) {
+      const int w2 = L.adjU[a];
+      place += ((L.pl[v] == w2) ? L.S[v] : L.S[w2]) < key;
+    }
+    L.adjS[L.head[v] + place] = (uint16_t)w;
+  }
+  g.sync();
+  // breadth-first order, level by level: every neighbour of a node except the one it was reached from is new.  The
+  // levels of these trees are many and narrow (hundreds of levels of a few nodes): ONE wavefront walks them (its
+  // hand-overs cost a few cycles where a workgroup barrier per level costs a microsecond), the others wait
+  uint16_t *bfs = L.adjU, *rank = L.adjU + n, *frm = L.cur, *pos = reinterpret_cast<uint16_t *>(L.S);
+  if (g.tid == 0) bfs[0] = (uint16_t)src, frm[src] = kNone16;
+  g.sync();
+  if (g.in_first_wave()) {
+    auto w = g.first_wave();
+    int lo = 0, hi = 1;
+    while (lo < hi) {
+      uint32_t carry = (uint32_t)hi;
+      for (int base = lo; base < hi; base += w.size) {
+        const int p = base + w.tid;
+        int v = 0, f = 0;
+        uint32_t c = 0;
+        if (p < hi) {
+          v = bfs[p];
+          f = frm[v];
+          c = (uint32_t)L.deg[v] - (f != kNone16 ? 1u : 0u);
+        }
+        uint32_t tot;
+        uint32_t o = carry + w.scan_excl(c, tot);
+        if (p < hi)
+          for (int a = L.head[v]; a < (int)L.head[v + 1]; ++a) {
+            const int x = L.adjS[a];
+            if (x != f) bfs[o++] = (uint16_t)x, frm[x] = (uint16_t)v;
+          }
+        carry += tot;
+      }
+      w.sync();
+      lo = hi;
+      hi = (int)carry;
+    }
+  }
+  g.sync();
+  for (int p = g.tid; p < n; p += g.size) rank[bfs[p]] = (uint16_t)p;
+  g.sync();
+  // the set the search fills ...
+  auto hash = [&](int k) { return (int64_t)L.X[k]; };
+  pyset_build(g, n, rank, n, hash, L.table, pos);
+  {  // ... and the set made from its iteration (slot order)
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base <= fmask; base += (uint32_t)g.size) {
+      const uint32_t s = base + (uint32_t)g.tid;
+      const uint32_t e = s <= fmask ? L.table[s] : kNone;
+      uint32_t tot;
+      const uint32_t pre = g.scan_excl(e != kNone, tot);
+      if (e != kNone) rank[e & 0x1FFFu] = (uint16_t)(carry + pre);
+      carry += tot;
+    }
+  }
+  g.sync();
+  pyset_build(g, n, rank, n, hash, L.table, pos);
+  uint64_t bestp = ~0ull;
+  for (int k = g.tid; k < n; k += g.size) {
+    const uint64_t key = ((uint64_t)pos[k] << 16) | (uint64_t)k;
+    bestp = key < bestp ? key : bestp;
+  }
+  const int first = (int)(g.reduce_min64(bestp) & 0xFFFFull);
+  return L.X[first];
+}
+
+// ---- one chunk of at most kChunkMax structures ---------------------------------------------------------------------------
+struct ChunkLocal {
+  uint16_t *jr, *root, *pos, *rank;  // [dpad] each
+  uint32_t *table;                   // [tbl]; later three uint16 arrays of dpad
+  uint8_t *mark;                     // [2 * ceil(dpad / 2)] graph-node marks; later the list of roots (uint16)
+  uint8_t *tiny;                     // [group size * kTinyScratch]
+};
+FC_HDC int chunk_dpad(int dmax) { return (dmax + 3) & ~3; }
+FC_HDC size_t chunk_local_bytes(int dmax, int tbl, int group) {
+  return (size_t)chunk_dpad(dmax) * 8 +
+         ((size_t)tbl * 4 < (size_t)chunk_dpad(dmax) * 6 ? (size_t)chunk_dpad(dmax) * 6 : (size_t)tbl * 4) +
+         (size_t)chunk_dpad(dmax) + (size_t)group * kTinyScratch + 16;
+}
+FC_HD void chunk_local_carve(void *mem, int dmax, int tbl, ChunkLocal &L) {
+  const size_t dp = (size_t)chunk_dpad(dmax);
+  size_t t = (size_t)tbl * 4;
+  if (t < dp * 6) t = dp * 6;
+  uint8_t *p = static_cast<uint8_t *>(mem);
+  L.table = reinterpret_cast<uint32_t *>(p), p += t;
+  L.jr = reinterpret_cast<uint16_t *>(p), p += dp * 2;
+  L.root = reinterpret_cast<uint16_t *>(p), p += dp * 2;
+  L.pos = reinterpret_cast<uint16_t *>(p), p += dp * 2;
+  L.rank = reinterpret_cast<uint16_t *>(p), p += dp * 2;
+  L.mark = p, p += dp;
+  L.tiny = p;
+}
+
+// where chunk_front leaves the components it does not finish itself
+struct CompRecord {
+  uint32_t t0;       // first item of the chunk (flags[t0 + relative index])
+  uint32_t moff;     // first member in mx / mp / ms
+  uint32_t n;        // members (0: empty record)
+  uint32_t n_graph;  // nodes of the chunk's graph
+};
+struct ChunkExport {
+  CompRecord *rec;         // this chunk's records: at most d / 19 of them
+  uint32_t *mx, *mp, *ms;  // this chunk's region of the member arrays: d entries each
+  uint32_t moff0;          // absolute index of mx[0]
+};
+
+// fm: first-match array (absolute indices, -1: none); the chunk = structures [lo, lo + d); flags[x] = 1 for every
+// structure the chunk rejects (tiny components); the others go to ex.  Returns the number of exported components.
+template <class G>
+FC_HD int chunk_front(G &g, const ChunkLocal &L, const int64_t *fm, int64_t lo, int d, uint32_t t0, uint8_t *flags,
+                      const ChunkExport &ex) {
+  const int dp = chunk_dpad(d);
+  int m = 0;
+  {
+    uint32_t carry = 0;
+    for (int base = 0; base < d; base += g.size) {
+      const int x = base + g.tid;
+      uint32_t v = 0;
+      if (x < d) {
+        const int64_t j = fm[lo + x];
+        v = (j >= 0 && j < lo + d) ? 1u : 0u;
+        L.jr[x] = v ? (uint16_t)(j - lo) : (uint16_t)x;
+      }
+      uint32_t tot;
+      const uint32_t pre = g.scan_excl(v, tot);
+      if (x < d) L.rank[x] = v ? (uint16_t)(carry + pre) : kNone16;
+      carry += tot;
+    }
+    m = (int)carry;
+  }
+  g.sync();
+  if (m == 0) return 0;
+  // (1) the edge order: slots of the chunk's set of (i_rel, j_rel) tuples, filled in ascending i_rel
+  if (m >= 2) {
+    pyset_build(g, d, L.rank, m, [&](int x) { return tuple2_hash((uint64_t)x, (uint64_t)L.jr[x]); }, L.table, L.pos);
+  } else {
+    for (int x = g.tid; x < d; x += g.size) L.pos[x] = 0;
+    g.sync();
+  }
+  // (2) tree roots by pointer jumping (a first-match graph is a forest: one edge per node, to a later one)
+  for (int x = g.tid; x < d; x += g.size) L.root[x] = L.jr[x];
+  g.sync();
+  {
+    int rounds = 1;
+    while ((1 << rounds) < d) ++rounds;
+    for (int r = 0; r <= rounds; ++r) {
+      for (int x = g.tid; x < d; x += g.size) L.root[x] = L.root[L.root[x]];
+      g.sync();
+    }
+  }
+  // (3) graph nodes, component sizes, members grouped by component
+  uint16_t *size = reinterpret_cast<uint16_t *>(L.table), *off = size + dp, *fill = off + dp, *lmem = L.rank;
+  uint16_t *rlist = reinterpret_cast<uint16_t *>(L.mark);
+  for (int x = g.tid; x < dp; x += g.size) L.mark[x] = 0, size[x] = 0, fill[x] = 0;
+  g.sync();
+  for (int x = g.tid; x < d; x += g.size)
+    if (L.jr[x] != x) L.mark[x] = 1, L.mark[L.jr[x]] = 1;
+  g.sync();
+  uint32_t ng = 0;
+  for (int x = g.tid; x < d; x += g.size)
+    if (L.mark[x]) {
+      ++ng;
+      g.atomic_add16(size, L.root[x], 1);
+    }
+  ng = g.reduce_sum(ng);
+  g.sync();
+  {
+    uint32_t carry = 0;
+    for (int base = 0; base < d; base += g.size) {
+      const int x = base + g.tid;
+      const bool is = x < d && L.root[x] == x && size[x] >= 2;
+      uint32_t tot;
+      const uint32_t pre = g.scan_excl(is ? (uint32_t)size[x] : 0u, tot);
+      if (is) off[x] = (uint16_t)(carry + pre);
+      carry += tot;
+    }
+  }
+  g.sync();
+  for (int x = g.tid; x < d; x += g.size)
+    if (L.mark[x]) {
+      const int r = L.root[x];
+      lmem[off[r] + g.atomic_add16(fill, r, 1)] = (uint16_t)x;
+    }
+  g.sync();
+  int nr = 0;
+  {
+    uint32_t carry = 0;
+    for (int base = 0; base < d; base += g.size) {
+      const int x = base + g.tid;
+      const bool is = x < d && L.root[x] == x && size[x] >= 2;
+      uint32_t tot;
+      const uint32_t pre = g.scan_excl(is ? 1u : 0u, tot);
+      // (the marks of the structures behind this sweep are still to be read by nobody: the member lists are complete)
+      if (is) fill[carry + pre] = (uint16_t)x;  // (fill is free again; rlist would overwrite marks this sweep has not passed)
+      carry += tot;
+    }
+    nr = (int)carry;
+  }
+  g.sync();
+  for (int c = g.tid; c < nr; c += g.size) rlist[c] = fill[c];
+  g.sync();
+  // (4) components: the tiny ones here, one lane each; the others exported
+  struct Acc {
+    const uint16_t *lm, *jr, *pos;
+    FC_HD uint32_t x(int k) const { return lm[k]; }
+    FC_HD uint32_t par(int k) const { return jr[lm[k]]; }
+    FC_HD uint32_t slot(int k) const { return pos[lm[k]]; }
+  };
+  uint16_t *biglist = fill;
+  int nexp = 0;
+  for (int base = 0; base < nr; base += g.size) {
+    const int ci = base + g.tid;
+    int r = 0, n = 0, o = 0;
+    if (ci < nr) r = rlist[ci], n = size[r], o = off[r];
+    const bool big = n > kTinyMax;
+    uint32_t tot;
+    const uint32_t pre = g.scan_excl(big ? 1u : 0u, tot);
+    g.sync();  // (biglist = fill: every lane has read its rlist / size / off entry)
+    if (big) biglist[nexp + (int)pre] = (uint16_t)r;
+    nexp += (int)tot;
+    if (n >= 2 && !big) {
+      const Acc A{lmem + o, L.jr, L.pos};
+      const uint32_t first = tiny_first(A, n, ng, L.tiny + (size_t)g.tid * kTinyScratch);
+      for (int k = 0; k < n; ++k)
+        if (lmem[o + k] != first) flags[lmem[o + k]] = 1;
+    }
+  }
+  g.sync();
+  for (int b = 0; b < nexp; ++b) {
+    const int r = biglist[b], n = size[r], o = off[r];
+    for (int k = g.tid; k < n; k += g.size) {
+      const int x = lmem[o + k];
+      ex.mx[o + k] = (uint32_t)x;
+      ex.mp[o + k] = (uint32_t)L.jr[x];
+      ex.ms[o + k] = (uint32_t)L.pos[x];
+    }
+    if (g.tid == 0) ex.rec[b] = CompRecord{t0, ex.moff0 + (uint32_t)o, (uint32_t)n, ng};
+  }
+  return nexp;
+}
+
+}  // namespace tfd
+}  // namespace fc

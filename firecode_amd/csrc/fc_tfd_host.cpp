@@ -32,6 +32,7 @@
 #include <system_error>
 
 #include "fc_common.h"
+#include "fc_tfd_core.h"
 
 namespace fc {
 
@@ -500,151 +501,6 @@ static void chunk_rejects(const std::vector<int64_t> &edges, int64_t chunk_len, 
   lap("components");
 }
 
-// ---- component phase of a level whose chunk graphs came from the device (fc_tfd_gpu.hip) --------------------------
-// The device delivers the nodes in component-major order: component = one contiguous block led by its earliest node
-// (graph order), so most components need neither a search nor a set:
-//   * a component of at least half the chunk's graph keeps its earliest node (the atlas branch of networkx's FilterAtlas);
-//   * otherwise group[0] is the first element of a Python set of the members' relative indices -- small non-negative
-//     ints hash to themselves, so when the members' residues modulo the set's final table size are all different every
-//     one sits in its home slot whatever the insertion order, and the first one is the smallest residue;
-//   * only components with two members in one home slot need the reference's insertion orders: breadth-first search
-//     over the insertion-ordered neighbour lists and the two set emulations, as in one_component above.
-// flags[rel] = 1 for every rejected structure of the chunk.
-static inline int64_t pyset_final_size(int64_t n_keys) {  // slots of a set that received n_keys distinct keys one by one
-  uint64_t mask = 7;
-  for (;;) {
-    const int64_t trigger = (int64_t)((mask * 3 + 4) / 5);
-    if (trigger > n_keys) return (int64_t)mask + 1;
-    const uint64_t minused = trigger > 50000 ? 2 * (uint64_t)trigger : 4 * (uint64_t)trigger;
-    uint64_t newsize = 8;
-    while (newsize <= minused) newsize <<= 1;
-    mask = newsize - 1;
-    if (trigger == n_keys) return (int64_t)mask + 1;
-  }
-}
-
-struct GraphCompScratch {
-  PySetEmu comp, view;
-  std::vector<int32_t> members, level, next;
-  std::vector<char> seen;
-  std::vector<uint64_t> bits;
-  int64_t n_search = 0;
-};
-
-static void graph_component(const TfdLevelGraph &g, int64_t s0, int64_t s1, int64_t chunk_nodes, GraphCompScratch &cs,
-                            uint8_t *flags) {
-  const int32_t *nodes = g.nodes.data();
-  const int64_t size = s1 - s0;
-  int64_t first = -1;
-  if (2 * size >= chunk_nodes) {
-    first = nodes[s0];
-  } else {
-    const int64_t T = pyset_final_size(size);
-    const size_t words = (size_t)((T + 63) >> 6);
-    if (cs.bits.size() < words) cs.bits.resize(words);
-    std::fill(cs.bits.begin(), cs.bits.begin() + (std::ptrdiff_t)words, 0ull);
-    int64_t best = T;
-    bool clean = true;
-    for (int64_t v = s0; v < s1; ++v) {
-      const int64_t r = (int64_t)nodes[v] & (T - 1);
-      uint64_t &w = cs.bits[(size_t)(r >> 6)];
-      const uint64_t bit = 1ull << (r & 63);
-      if (w & bit) {
-        clean = false;
-        break;
-      }
-      w |= bit;
-      if (r < best) {
-        best = r;
-        first = nodes[v];
-      }
-    }
-    if (!clean) {
-      // the reference's orders: _plain_bfs from the earliest node over the insertion-ordered neighbour lists ...
-      ++cs.n_search;
-      const int32_t *head = g.adj_head.data(), *adj = g.adj_next.data();
-      cs.seen.assign((size_t)size, 0);
-      cs.comp.reset();
-      cs.comp.add(nodes[s0], nodes[s0], int_eq);
-      cs.seen[0] = 1;
-      cs.level.assign(1, (int32_t)s0);
-      while (!cs.level.empty()) {
-        cs.next.clear();
-        for (const int32_t v : cs.level)
-          for (int32_t rec = head[v]; rec < head[v + 1]; ++rec) {
-            const int32_t x = adj[rec];
-            if (!cs.seen[(size_t)(x - s0)]) {
-              cs.seen[(size_t)(x - s0)] = 1;
-              cs.comp.add(nodes[x], nodes[x], int_eq);
-              cs.next.push_back(x);
-            }
-          }
-        cs.level.swap(cs.next);
-      }
-      // ... then show_nodes.nodes = set(nbunch_iter(c)), iterated: its first element
-      cs.view.reset();
-      cs.comp.for_each([&](int64_t key) { cs.view.add(key, key, int_eq); });
-      first = -1;
-      cs.view.for_each([&](int64_t key) {
-        if (first < 0) first = key;
-      });
-    }
-  }
-  for (int64_t v = s0; v < s1; ++v)
-    if (nodes[v] != first) flags[nodes[v]] = 1;
-}
-
-// all non-last chunks of one level from the device-built graphs -> level_flags[absolute index] = 1 for rejects
-// only_left: just the components the device left over (g.left), one job each
-static void level_rejects_from_graph(const TfdLevelGraph &g, unsigned threads, uint8_t *level_flags, int64_t *n_search_out,
-                                     bool only_left = false) {
-  if (g.nodes.empty()) return;
-  struct Job { int chunk; int64_t j0, j1; };
-  std::vector<Job> jobs;
-  if (only_left) {
-    for (const int32_t j : g.left) {
-      const int64_t s0 = g.sources[(size_t)j];
-      const int c = !g.left_chunk.empty() ? (int)g.left_chunk[(size_t)j]  // (compact arrays: the device says which chunk)
-                                          : (int)(std::upper_bound(g.nbase.begin(), g.nbase.end(), s0) - g.nbase.begin()) - 1;
-      jobs.push_back(Job{c, j, (int64_t)j + 1});
-    }
-  } else {
-    for (int c = 0; c < g.n_chunks; ++c) {
-      const int64_t j0 = g.sbase[(size_t)c], j1 = g.sbase[(size_t)c + 1];
-      for (int64_t b = j0; b < j1; b += 2048) jobs.push_back(Job{c, b, std::min(j1, b + 2048)});
-    }
-  }
-  std::atomic<size_t> next{0};
-  std::atomic<int64_t> searched{0};
-  std::atomic<bool> failed{false};
-  auto worker = [&]() {
-    try {  // (a thread body must not leak an exception: std::terminate)
-      GraphCompScratch cs;
-      while (!failed.load(std::memory_order_relaxed)) {
-        const size_t q = next.fetch_add(1);
-        if (q >= jobs.size()) break;
-        const Job &jb = jobs[q];
-        const int64_t chunk_nodes = g.nbase[(size_t)jb.chunk + 1] - g.nbase[(size_t)jb.chunk];
-        uint8_t *flags = level_flags + (int64_t)jb.chunk * g.d;
-        for (int64_t j = jb.j0; j < jb.j1; ++j)
-          graph_component(g, g.sources[(size_t)j], g.sources[(size_t)j + 1], chunk_nodes, cs, flags);
-      }
-      searched += cs.n_search;
-    } catch (...) {
-      failed = true;
-    }
-  };
-  {
-    ThreadJoiner pool;  // joins on every way out of this scope
-    if (threads > 1 && jobs.size() > 1)
-      for (unsigned t = 1; t < threads; ++t)
-        if (!pool.start(worker)) break;  // (no more threads to be had: the ones that exist share the jobs)
-    worker();
-  }
-  if (failed.load()) throw std::bad_alloc();  // out of host memory in a helper: the ladder reports FC_E_NOMEM
-  if (n_search_out) *n_search_out = searched.load();
-}
-
 // chunks [step_begin, step_end) of one ladder level; chunks are independent.  The rejects go to `out`
 // as absolute indices (the caller applies them when -- and if -- the level runs).
 static void level_chunks(const int64_t *fm, int64_t N, int64_t k, int64_t d, int64_t num_active,
@@ -671,53 +527,90 @@ static void level_chunks(const int64_t *fm, int64_t N, int64_t k, int64_t d, int
   }
 }
 
-// Streams (and graph holders) of the helper threads that run the coarse levels side by side; created on first use or by
-// fc_warmup (a stream is a hardware queue: several ms each), dropped with the context they were created in.
-constexpr int kLevelStreamsMax = 8;
-static hipStream_t g_lvl_stream[kLevelStreamsMax] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-static hipEvent_t g_lvl_begin = nullptr;
-static uint64_t g_lvl_epoch = 0;
-static TfdLevelGraph g_lvl_holders[kLevelStreamsMax];
-void tfd_level_streams_teardown() {  // context_teardown: the streams belong to the device being left
-  for (auto &st : g_lvl_stream) {
-    if (st) {
-      (void)hipStreamSynchronize(st);
-      (void)hipStreamDestroy(st);
+// ---- the levels in order ---------------------------------------------------------------------------------------------
+// level_flags[li] (may be nullptr / missing): one byte per structure of [0, d (k - 1)), 1 = a non-last chunk of level li
+// rejects it -- worked out beforehand from first_match alone (here on host threads, or on the device: fc_tfd_ladder.hip).
+// first_last_flags: the same for the LAST chunk of level first_level, [d (k - 1), N), known up front because the active
+// count is N there.  Every other last chunk ends at the active count of its moment (torsion_module.py:987-990) and is
+// done here, on the spot.  first_level == -2: mask_out already holds the mask after every level but k = 1; only that
+// level is applied.
+static const double kLadderK[] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};
+constexpr int kLadderLevels = (int)(sizeof(kLadderK) / sizeof(kLadderK[0]));
+
+int tfd_apply_levels_host(const int64_t *fm, int64_t N, const std::vector<const uint8_t *> &level_flags, int first_level,
+                          const uint8_t *first_last_flags, uint8_t *mask_out) {
+  const bool debug = getenv("FC_DEBUG") != nullptr;
+  ChunkScratch scratch;
+  std::vector<int64_t> last;
+  int64_t num_active = N;  // kept up to date as flags go 1 -> 0
+  if (first_level == -2) {
+    num_active = 0;
+    for (int64_t i = 0; i < N; ++i) num_active += mask_out[i];
+  } else {
+    std::memset(mask_out, 1, (size_t)N);
+  }
+  auto reject = [&](int64_t r) {
+    num_active -= mask_out[r];
+    mask_out[r] = 0;
+  };
+  for (int li = 0; li < kLadderLevels; ++li) {
+    const int64_t k = (int64_t)kLadderK[li];
+    if (first_level == -2 && k != 1) continue;
+    const bool runs = (k == 1 || 5 * k < num_active);
+    if (!runs) continue;
+    const int64_t d = N / k;
+    // the last chunk reads nothing but first_match either, so the order of application within
+    // the level does not matter: all rejects of a level come from the mask-independent chunk graphs
+    last.clear();
+    const int64_t active_in = num_active;
+    const bool have_first_last = li == first_level && active_in == N && first_last_flags != nullptr;
+    if (!have_first_last) level_chunks(fm, N, k, d, active_in, k - 1, k, scratch, last);
+    const uint8_t *flags = (size_t)li < level_flags.size() ? level_flags[(size_t)li] : nullptr;
+    if (flags != nullptr && k > 1) {  // branch-free over the bytes (vectorised by the compiler): a level rejects up to half of its range
+      const size_t n_flags = (size_t)(d * (k - 1));
+      unsigned long long gone = 0;
+      size_t r = 0;
+      for (; r + 32 <= n_flags; r += 32) {  // 32 structures per step; most steps of most levels reject nothing new
+        uint64_t m8[4], f8[4];
+        std::memcpy(m8, mask_out + r, 32);
+        std::memcpy(f8, flags + r, 32);
+        const uint64_t h0 = m8[0] & f8[0], h1 = m8[1] & f8[1], h2 = m8[2] & f8[2], h3 = m8[3] & f8[3];
+        if ((h0 | h1) | (h2 | h3)) {
+          gone += (unsigned long long)(__builtin_popcountll(h0) + __builtin_popcountll(h1) + __builtin_popcountll(h2) +
+                                       __builtin_popcountll(h3));
+          m8[0] ^= h0, m8[1] ^= h1, m8[2] ^= h2, m8[3] ^= h3;
+          std::memcpy(mask_out + r, m8, 32);
+        }
+      }
+      for (; r < n_flags; ++r) {
+        const uint8_t hit = (uint8_t)(mask_out[r] & flags[r]);
+        gone += hit;
+        mask_out[r] = (uint8_t)(mask_out[r] ^ hit);
+      }
+      num_active -= (int64_t)gone;
     }
-    st = nullptr;
+    if (have_first_last) {
+      const int64_t lo = d * (k - 1);
+      for (int64_t r = lo; r < N; ++r)
+        if (first_last_flags[r - lo]) reject(r);
+    }
+    for (int64_t r : last) reject(r);
+    if (debug) fprintf(stderr, "[fc] tfd ladder k=%lld: %lld active in\n", (long long)k, (long long)active_in);
   }
-  if (g_lvl_begin) (void)hipEventDestroy(g_lvl_begin);
-  g_lvl_begin = nullptr;
-}
-int tfd_level_streams(int n) {
-  if (g_lvl_epoch != ctx().epoch) {  // (a new context: context_teardown has destroyed what the old one created)
-    for (auto &st : g_lvl_stream) st = nullptr;
-    g_lvl_begin = nullptr;
-    g_lvl_epoch = ctx().epoch;
-  }
-  if (!g_lvl_begin) FC_HIP_TRY(hipEventCreateWithFlags(&g_lvl_begin, hipEventDisableTiming));
-  for (int w = 0; w < n && w < kLevelStreamsMax; ++w)
-    if (!g_lvl_stream[w]) FC_HIP_TRY(hipStreamCreateWithFlags(&g_lvl_stream[w], hipStreamNonBlocking));
   return FC_OK;
 }
 
-// The whole ladder: first_match[i] = min{j > i : similar(i, j)} or -1.
+// The whole ladder on the host: first_match[i] = min{j > i : similar(i, j)} or -1.
 //
 // What a chunk rejects depends on first_match alone: the reference's inner loops never look at
 // final_mask (masked structures keep taking part, torsion_module.py:997-1018).  Only two things depend
 // on the levels before: whether a level runs at all (5 k < num_active_str, :976) and the length of
 // its LAST chunk (:987-990).  So every non-last chunk of every level that can possibly run is
-// worked out up front, all levels at once, on the host threads (largest chunks first: the single
-// 840 000-structure chunk of k = 2 at 1.7 M structures is the critical path, everything else fits beside
-// it); then the levels are walked in order, applying a level's rejects if it runs and doing its
-// last chunk -- usually empty or tiny, since num_active_str has long fallen below its start -- on the spot.
-// (One level after the other, threads over the chunks of a level: 0.32 s at 1.7 M structures, of which the
-// levels k <= 20 with their few huge chunks took 0.24 s on one to five threads.)
-// fm_dev (may be nullptr): the same array on the device -- the chunk graphs of the coarse levels (chunks of at least
-// gpu_chunk_min structures) are then built there (fc_tfd_gpu.hip), several levels at a time, while the host threads work on the fine levels.
-static int tfd_ladder_impl(const int64_t *fm, int64_t N, uint8_t *mask_out, const int64_t *fm_dev) {
-  static const double kl[] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};
-  std::memset(mask_out, 1, (size_t)N);
+// worked out up front, all levels at once, on the host threads (largest chunks first), then the levels
+// are walked in order (tfd_apply_levels_host).  This is the reference the device ladder (fc_tfd_ladder.hip) is
+// tested against, what runs without a device and below kDeviceLadderMin structures, and the fallback when a device
+// capacity is exceeded.
+static int tfd_ladder_impl(const int64_t *fm, int64_t N, uint8_t *mask_out) {
   unsigned hw = std::thread::hardware_concurrency();
   if (hw == 0) hw = 1;
   if (hw > 16) hw = 16;
@@ -735,34 +628,25 @@ static int tfd_ladder_impl(const int64_t *fm, int64_t N, uint8_t *mask_out, cons
   const bool debug = getenv("FC_DEBUG") != nullptr;
   const auto t_all = std::chrono::steady_clock::now();
   // What a task rejects goes into ONE byte per structure and level (chunks of a level are disjoint index
-  // ranges, so workers never write the same byte): the 1.8*10^7 speculative rejects of 1.7 M structures
-  // held as index lists were 209 MB of vectors whose release alone cost 90-100 ms.
+  // ranges, so workers never write the same byte).
   struct Task {
-    int level;                 // index into kl
+    int level;  // index into kLadderK
     int64_t k, d, step_begin, step_end, cost;
   };
   std::vector<Task> tasks;
-  constexpr int kLevels = (int)(sizeof(kl) / sizeof(kl[0]));
-  static std::vector<uint8_t> level_rej[kLevels];  // kept across calls (tfd_ladder_from_first_match holds the ladder's own lock): 17 x N bytes of fresh pages cost ~7 ms at 1.7 M
-  std::vector<int> gpu_levels;
-  bool use_gpu = fm_dev != nullptr;
-  if (const char *v = getenv("FC_TFD_GPU")) use_gpu = use_gpu && atoi(v) != 0;  // 0: everything on the host (A/B, tests)
-  bool gpu_components = true;  // FC_TFD_GPU_COMPONENTS=0: the component phase on host threads, from the device's graphs
-  if (const char *v = getenv("FC_TFD_GPU_COMPONENTS")) gpu_components = atoi(v) != 0;
-  int64_t gpu_chunk_min = 150;  // (1000 .. 30 measured at 1.7 M structures: where the host threads and the device finish together -- 300 before the
-                                // wave-per-component kernel, 150 since)
-  if (const char *v = getenv("FC_TFD_GPU_CHUNK_MIN")) gpu_chunk_min = std::max<int64_t>(2, std::strtoll(v, nullptr, 10));
-  for (int li = 0; li < (int)(sizeof(kl) / sizeof(kl[0])); ++li) {
-    const int64_t k = (int64_t)kl[li];
+  static std::vector<uint8_t> level_rej[kLadderLevels];  // kept across calls (the ladder holds its own lock): fresh pages cost ~7 ms at 1.7 M
+  static std::vector<uint8_t> first_last_flags;
+  std::vector<const uint8_t *> level_flags((size_t)kLadderLevels, nullptr);
+  int first_level = -1;
+  for (int li = 0; li < kLadderLevels; ++li) {
+    const int64_t k = (int64_t)kLadderK[li];
     if (!(k == 1 || 5 * k < N)) continue;  // num_active <= N: the level can never run
-    if (k == 1) continue;                  // its only chunk is a last chunk
+    if (first_level < 0) first_level = li;
+    if (k == 1) continue;  // its only chunk is a last chunk
     const int64_t d = N / k;
     if (d <= 1) continue;
     level_rej[li].assign((size_t)(d * (k - 1)), 0);  // the non-last chunks cover [0, d (k - 1))
-    if (use_gpu && d >= gpu_chunk_min) {  // a coarse level: its chunk graphs come from the device
-      gpu_levels.push_back(li);
-      continue;
-    }
+    level_flags[(size_t)li] = level_rej[li].data();
     // non-last chunks [0, k - 1), cut into tasks of about 2^17 structures (a huge chunk is a task of its own)
     const int64_t per = std::max<int64_t>(1, (int64_t)(131072 / d));
     for (int64_t b = 0; b < k - 1; b += per) {
@@ -770,34 +654,14 @@ static int tfd_ladder_impl(const int64_t *fm, int64_t N, uint8_t *mask_out, cons
       tasks.push_back(Task{li, k, d, b, e, (e - b) * d});
     }
   }
-  // (streams and events of the coarse levels' helpers first: nothing below may return while threads are running)
-  TfdLevelGraph *const holders = g_lvl_holders;
-  hipStream_t *const lvl_stream = g_lvl_stream;
-  int n_lvl_streams = 3;
-  if (const char *v = getenv("FC_TFD_GPU_STREAMS")) n_lvl_streams = (int)std::min<long>(kLevelStreamsMax, std::max<long>(1, std::strtol(v, nullptr, 10)));
-  n_lvl_streams = (int)std::min<size_t>((size_t)n_lvl_streams, std::max<size_t>(gpu_levels.size(), 1));
-  int gpu_rc = FC_OK;
-  std::string gpu_err;
-  if (!gpu_levels.empty()) {
-    FC_TRY(tfd_level_streams(n_lvl_streams));
-    FC_HIP_TRY(hipEventRecord(g_lvl_begin, ctx().stream));
-    for (int w = 0; w < n_lvl_streams; ++w) FC_HIP_TRY(hipStreamWaitEvent(lvl_stream[w], g_lvl_begin, 0));
-  }
-  // the LAST chunk of the first level that runs is known up front as well (num_active = N there): at 1.7 M structures
-  // it is the remainder N - d (k - 1) = 79 619 structures of k = 200 000, 8 ms on one thread if left to the walk below
-  int first_level = -1;
+  // the LAST chunk of the first level that can run is known up front as well (num_active = N there)
   std::vector<int64_t> first_last;
-  for (int li = 0; li < kLevels; ++li) {
-    const int64_t k = (int64_t)kl[li];
-    if (k == 1 || 5 * k < N) {
-      first_level = li;
-      break;
-    }
+  bool have_first_last = false;
+  if (first_level >= 0 && (int64_t)kLadderK[first_level] > 1) {
+    const int64_t k = (int64_t)kLadderK[first_level], d = N / k;
+    tasks.push_back(Task{first_level, k, d, -1, -1, N - d * (k - 1)});
+    have_first_last = true;
   }
-  if (first_level >= 0) tasks.push_back(Task{first_level, (int64_t)kl[first_level], N / (int64_t)kl[first_level], -1, -1, N - (N / (int64_t)kl[first_level]) * ((int64_t)kl[first_level] - 1)});
-  if (debug)
-    fprintf(stderr, "[fc] tfd ladder: set up (flag arrays, tasks, level streams) at %.1f ms\n",
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
   std::vector<size_t> order(tasks.size());
   for (size_t t = 0; t < order.size(); ++t) order[t] = t;
   std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tasks[a].cost > tasks[b].cost; });
@@ -826,193 +690,242 @@ static int tfd_ladder_impl(const int64_t *fm, int64_t N, uint8_t *mask_out, cons
         host_failed = true;
       }
     };
-    // (the helpers of the coarse levels wait for the device by polling: leave them a core each)
-    const unsigned hw_pool = gpu_levels.empty() ? hw : std::max(1u, hw > (unsigned)n_lvl_streams ? hw - (unsigned)n_lvl_streams : 1u);
-    const unsigned nthreads = (N >= 2000 && tasks.size() > 1) ? std::min<size_t>(hw_pool, tasks.size()) : 1;
-    // (from here to the end of this block helper threads are running: both holders join in their destructors, so no
+    const unsigned nthreads = (N >= 2000 && tasks.size() > 1) ? (unsigned)std::min<size_t>(hw, tasks.size()) : 1;
+    // (from here to the end of this block helper threads are running: the holder joins in its destructor, so no
     // return, FC_TRY or exception below can leave a joinable std::thread behind -- that would be std::terminate)
     ThreadJoiner pool;
-    bool own_worker = !(nthreads > 1 || !gpu_levels.empty());
-    if (!own_worker) {
-      for (unsigned t = 0; t < std::max(1u, nthreads); ++t)
-        if (!pool.start(worker)) break;
-      own_worker = pool.threads.empty();  // not one thread to be had: this thread does the host share itself, below
-    } else {
-      worker();
-      own_worker = false;
-    }
-    // meanwhile: the coarse levels' graphs from the device.  The levels are independent of each other and each is a
-    // chain of ~40 short launches with five host round trips (sizes of the next arrays), so one level at a time leaves
-    // the device idle most of the time (4.3-5.2 ms per level, nine levels at 1.7 M structures): kLevelStreams helper
-    // threads take levels from a common counter, each enqueueing on a stream of its own (thread_stream_override) that
-    // starts behind everything the context's stream holds; a helper also walks the components its level left to the
-    // host (the few with more than FC_TFD_DEV_COMP_MAX nodes) before it takes the next level.  The graph holders are
-    // kept across calls (their arrays are tens of MB: fresh pages every level cost more than the copies).
-    std::atomic<size_t> next_level{0};
-    std::mutex err_mu;
-    auto level_fail = [&](int rc, const char *msg) {
-      std::lock_guard<std::mutex> lock(err_mu);
-      if (gpu_rc == FC_OK) gpu_rc = rc, gpu_err = msg;
-    };
-    const int device = ctx().device;
-    auto level_worker = [&](int w) {
-     try {
-      // HIP's current device is PER THREAD and a fresh thread starts on device 0: without this a helper of a context on
-      // device d != 0 (every LOCAL_RANK > 0) would take pool blocks, events and pinned pieces on device 0 and launch
-      // on device d's streams over them
-      if (w != 0) {
-        const hipError_t e = hipSetDevice(device);
-        if (e != hipSuccess) {
-          level_fail(FC_E_HIP, (std::string("hipSetDevice in a TFD level helper: ") + hipGetErrorString(e)).c_str());
-          return;
-        }
-      }
-      thread_stream_override() = lvl_stream[w];
-      struct Restore {
-        ~Restore() { thread_stream_override() = nullptr; }
-      } restore_stream;
-      TfdLevelGraph &g = holders[w];
-      while (true) {
-        {
-          std::lock_guard<std::mutex> lock(err_mu);
-          if (gpu_rc != FC_OK) break;  // another level failed: no point in starting the next one
-        }
-        const size_t q = next_level.fetch_add(1);
-        if (q >= gpu_levels.size()) break;
-        const int li = gpu_levels[gpu_levels.size() - 1 - q];  // coarsest first: they take longest (largest components), the quick fine levels fill the end
-        const auto t_g = std::chrono::steady_clock::now();
-        uint8_t *flags = level_rej[li].data();
-        const int rc = tfd_level_graph_device(fm_dev, N, (int64_t)kl[li], g, gpu_components ? flags : nullptr);
-        if (rc != FC_OK) {
-          level_fail(rc, last_error().c_str());  // (the message is the helper thread's own)
-          break;
-        }
-        const auto t_c = std::chrono::steady_clock::now();
-        if (!gpu_components) level_rejects_from_graph(g, std::min(g_comp_threads, 4u), flags, nullptr);
-        else if (!g.left.empty()) level_rejects_from_graph(g, std::min(g_comp_threads, 2u), flags, nullptr, true);
-        int64_t left_nodes = 0, left_max = 0;
-        if (debug)
-          for (const int32_t j : g.left) {
-            const int64_t sz = (int64_t)g.sources[(size_t)j + 1] - g.sources[(size_t)j];
-            left_nodes += sz;
-            left_max = std::max(left_max, sz);
-          }
-        if (debug)
-          fprintf(stderr, "[fc] tfd ladder k=%lld: %lld nodes in the components left to the host (largest %lld)\n", (long long)kl[li],
-                  (long long)left_nodes, (long long)left_max);
-        if (debug)
-          fprintf(stderr, "[fc] tfd ladder k=%lld on the device (stream %d): %.1f ms + %.1f ms on the host (%zu components, %zu of them left to host threads)%s\n",
-                  (long long)kl[li], w, std::chrono::duration<double, std::milli>(t_c - t_g).count(),
-                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c).count(),
-                  (size_t)g.n_components, g.left.size(),
-                  gpu_components ? "" : "; component phase on the host");
-      }
-     } catch (const std::bad_alloc &) {
-      level_fail(FC_E_NOMEM, "out of host memory in a TFD level helper");
-     } catch (...) {
-      level_fail(FC_E_HIP, "unexpected exception in a TFD level helper");
-     }
-    };
-    {
-      ThreadJoiner lvl_pool;
-      if (!gpu_levels.empty())
-        for (int w = 1; w < n_lvl_streams; ++w)
-          if (!lvl_pool.start(level_worker, w)) break;  // (fewer helpers: the levels come from a common counter)
-      if (!gpu_levels.empty()) level_worker(0);
-      lvl_pool.join_all();
-      if (debug && !gpu_levels.empty())
-        fprintf(stderr, "[fc] tfd ladder: %zu coarse levels on %d streams done at %.1f ms\n", gpu_levels.size(), n_lvl_streams,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
-    }
-    if (own_worker) worker();
+    for (unsigned t = 1; t < nthreads; ++t)
+      if (!pool.start(worker)) break;
+    worker();
     pool.join_all();
-    if (gpu_rc != FC_OK) {
-      // a level that failed half-way may have left kernels on its stream: nothing of this call may outlive it
-      for (int w = 0; w < n_lvl_streams; ++w) (void)hipStreamSynchronize(lvl_stream[w]);
-      return set_error(gpu_rc, "%s", gpu_err.c_str());
-    }
     if (host_failed.load()) return set_error(FC_E_NOMEM, "out of host memory in the TFD ladder's host threads");
   }
   if (debug)
-    fprintf(stderr, "[fc] tfd ladder: %zu speculative tasks on %u threads, %.1f ms\n", tasks.size(), hw,
+    fprintf(stderr, "[fc] tfd ladder (host): %zu speculative tasks on %u threads, %.1f ms\n", tasks.size(), hw,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
-  // the levels in order
-  ChunkScratch scratch;
-  std::vector<int64_t> last;
-  int64_t num_active = N;  // kept up to date as flags go 1 -> 0
-  auto reject = [&](int64_t r) {
-    num_active -= mask_out[r];
-    mask_out[r] = 0;
-  };
-  for (int li = 0; li < (int)(sizeof(kl) / sizeof(kl[0])); ++li) {
-    const int64_t k = (int64_t)kl[li];
-    const bool runs = (k == 1 || 5 * k < num_active);
-    if (!runs) continue;
-    const int64_t d = N / k;
-    // the last chunk first reads nothing but first_match either, so the order of application within
-    // the level does not matter: all rejects of a level come from the mask-independent chunk graphs
-    last.clear();
-    const int64_t active_in = num_active;
-    if (li == first_level && active_in == N) last = first_last;
-    else level_chunks(fm, N, k, d, active_in, k - 1, k, scratch, last);
-    {  // branch-free over the bytes (vectorised by the compiler): a level rejects up to half of its range
-      const uint8_t *flags = level_rej[li].data();
-      const size_t n_flags = level_rej[li].size();
-      unsigned long long gone = 0;
-      size_t r = 0;
-      for (; r + 32 <= n_flags; r += 32) {  // 32 structures per step; most steps of most levels reject nothing new
-        uint64_t m8[4], f8[4];
-        std::memcpy(m8, mask_out + r, 32);
-        std::memcpy(f8, flags + r, 32);
-        const uint64_t h0 = m8[0] & f8[0], h1 = m8[1] & f8[1], h2 = m8[2] & f8[2], h3 = m8[3] & f8[3];
-        if ((h0 | h1) | (h2 | h3)) {
-          gone += (unsigned long long)(__builtin_popcountll(h0) + __builtin_popcountll(h1) + __builtin_popcountll(h2) +
-                                       __builtin_popcountll(h3));
-          m8[0] ^= h0, m8[1] ^= h1, m8[2] ^= h2, m8[3] ^= h3;
-          std::memcpy(mask_out + r, m8, 32);
-        }
-      }
-      for (; r + 8 <= n_flags; r += 8) {  // eight structures per step (bytes are 0 / 1: a set bit is a rejected structure)
-        uint64_t m8, f8;
-        std::memcpy(&m8, mask_out + r, 8);
-        std::memcpy(&f8, flags + r, 8);
-        const uint64_t hit = m8 & f8;
-        if (hit) {
-          gone += (unsigned long long)__builtin_popcountll(hit);
-          m8 ^= hit;
-          std::memcpy(mask_out + r, &m8, 8);
-        }
-      }
-      for (; r < n_flags; ++r) {
-        const uint8_t hit = (uint8_t)(mask_out[r] & flags[r]);
-        gone += hit;
-        mask_out[r] = (uint8_t)(mask_out[r] ^ hit);
-      }
-      num_active -= (int64_t)gone;
-    }
-    for (int64_t r : last) reject(r);
-    if (debug)
-      fprintf(stderr, "[fc] tfd ladder k=%lld: %lld active in\n", (long long)k, (long long)active_in);
+  const uint8_t *flf = nullptr;
+  if (have_first_last) {
+    const int64_t k = (int64_t)kLadderK[first_level], lo = (N / k) * (k - 1);
+    first_last_flags.assign((size_t)(N - lo), 0);
+    for (int64_t r : first_last) first_last_flags[(size_t)(r - lo)] = 1;
+    flf = first_last_flags.data();
   }
+  FC_TRY(tfd_apply_levels_host(fm, N, level_flags, first_level, flf, mask_out));
   if (debug)
-    fprintf(stderr, "[fc] tfd ladder total %.1f ms\n",
+    fprintf(stderr, "[fc] tfd ladder (host) total %.1f ms\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
   return FC_OK;
 }
 
-// The ladder keeps process-wide state across calls (the per-level flag arrays, the helpers' graph holders and streams):
-// one ladder at a time, under a lock of its own -- not merely "the callers hold the API lock".  No exception crosses
-// the C ABI: whatever the host side throws (std::bad_alloc is the only candidate) becomes an error code.
-int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out, const int64_t *fm_dev) {
-  static std::mutex ladder_mu;
-  std::lock_guard<std::mutex> lock(ladder_mu);
+// The ladder keeps process-wide state across calls (the per-level flag arrays): one ladder at a time, under a lock of its
+// own -- not merely "the callers hold the API lock".  No exception crosses the C ABI: whatever the host side throws
+// (std::bad_alloc is the only candidate) becomes an error code.
+static std::mutex &ladder_mutex() {
+  static std::mutex mu;
+  return mu;
+}
+int tfd_ladder_host_only(const int64_t *fm, int64_t N, uint8_t *mask_out) {
+  std::lock_guard<std::mutex> lock(ladder_mutex());
   try {
-    return tfd_ladder_impl(fm, N, mask_out, fm_dev);
+    return tfd_ladder_impl(fm, N, mask_out);
   } catch (const std::bad_alloc &) {
     return set_error(FC_E_NOMEM, "out of host memory in the TFD ladder (N = %lld)", (long long)N);
   } catch (const std::exception &e) {
     return set_error(FC_E_HIP, "TFD ladder: %s", e.what());
   }
+}
+
+int tfd_ladder_device(const int64_t *fm_dev, const int64_t *fm_host, int64_t N, uint8_t *mask_out);  // fc_tfd_ladder.hip
+constexpr int64_t kDeviceLadderMin = 20000;  // below: a few hundred microseconds of host work, less than the device's launches
+
+// fm_dev (may be nullptr): the same array on the device -- the ladder then runs there (FC_TFD_GPU=0: on the host anyway)
+int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out, const int64_t *fm_dev) {
+  bool use_gpu = fm_dev != nullptr && N >= kDeviceLadderMin;
+  if (const char *v = getenv("FC_TFD_GPU")) use_gpu = use_gpu && atoi(v) != 0;
+  if (!use_gpu) return tfd_ladder_host_only(fm, N, mask_out);
+  try {
+    return tfd_ladder_device(fm_dev, fm, N, mask_out);
+  } catch (const std::bad_alloc &) {
+    return set_error(FC_E_NOMEM, "out of host memory in the TFD ladder (N = %lld)", (long long)N);
+  } catch (const std::exception &e) {
+    return set_error(FC_E_HIP, "TFD ladder: %s", e.what());
+  }
+}
+
+// ---- a component of any size on the host (the device leaves those above tfd::kGroupCompMax nodes) ---------------------------
+// mx / mp / ms: relative index, first match (the member itself when it has none in the chunk), slot of the edge in the
+// chunk's tuple set.  Same orders as chunk_rejects' one_component.
+uint32_t host_component_first_big(const uint32_t *mx, const uint32_t *mp, const uint32_t *ms, int64_t n, uint32_t n_graph) {
+  std::vector<int64_t> by_x((size_t)n);
+  for (int64_t k = 0; k < n; ++k) by_x[(size_t)k] = k;
+  std::sort(by_x.begin(), by_x.end(), [&](int64_t a, int64_t b) { return mx[a] < mx[b]; });
+  auto local_of = [&](uint32_t x) {
+    int64_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (mx[by_x[(size_t)mid]] <= x) lo = mid;
+      else hi = mid;
+    }
+    return by_x[(size_t)lo];
+  };
+  int64_t src = 0;
+  uint32_t best = 0xFFFFFFFFu;
+  std::vector<std::vector<std::pair<uint32_t, int64_t>>> adj((size_t)n);  // (edge slot, neighbour)
+  for (int64_t k = 0; k < n; ++k)
+    if (mp[k] != mx[k]) {
+      if (ms[k] < best) best = ms[k], src = k;
+      const int64_t p = local_of(mp[k]);
+      adj[(size_t)k].push_back({ms[k], p});
+      adj[(size_t)p].push_back({ms[k], k});
+    }
+  if (2 * (uint64_t)n >= (uint64_t)n_graph) return mx[src];
+  for (auto &a : adj) std::sort(a.begin(), a.end());
+  PySetEmu comp, view;
+  std::vector<char> seen((size_t)n, 0);
+  std::vector<int64_t> level(1, src), next;
+  seen[(size_t)src] = 1;
+  comp.add(mx[src], mx[src], int_eq);
+  while (!level.empty()) {
+    next.clear();
+    for (const int64_t v : level)
+      for (const auto &e : adj[(size_t)v])
+        if (!seen[(size_t)e.second]) {
+          seen[(size_t)e.second] = 1;
+          comp.add(mx[e.second], mx[e.second], int_eq);
+          next.push_back(e.second);
+        }
+    level.swap(next);
+  }
+  comp.for_each([&](int64_t key) { view.add(key, key, int_eq); });
+  int64_t first = -1;
+  view.for_each([&](int64_t key) {
+    if (first < 0) first = key;
+  });
+  return (uint32_t)first;
+}
+
+// ---- the device ladder's routines on the CPU (host group): what tests/test_tfd_ladder_v2.py compares with the ladder above -------
+// Chunks of at most kChunkMax structures go through chunk_front exactly as a wavefront runs it; larger ones get their
+// tuple-set slots from PyTupleSetEmu (the device's staged insertion is tested against it on its own) and their
+// components through the same tiny_first / comp_group_first / host_component_first_big the device's records reach.
+int tfd_ladder_emulate_device(const int64_t *fm, int64_t N, uint8_t *mask_out) {
+  using namespace tfd;
+  struct E { int li; int64_t k, lo, d, nch; };
+  std::vector<E> es;
+  int first_li = -1;
+  for (int li = 0; li < kLadderLevels; ++li) {
+    const int64_t k = (int64_t)kLadderK[li];
+    if (k == 1 || !(5 * k < N)) continue;
+    const int64_t d = N / k;
+    if (d <= 1) continue;
+    if (first_li < 0) {
+      first_li = li;
+      if (N - d * (k - 1) >= 2) es.push_back(E{li, k, d * (k - 1), N - d * (k - 1), 1});
+    }
+    es.push_back(E{li, k, 0, d, k - 1});
+  }
+  std::vector<std::vector<uint8_t>> eflags(es.size());
+  HostGroup g;
+  std::vector<uint8_t> local, clocal, tiny_scr((size_t)kTinyScratch);
+  std::vector<CompRecord> recs;
+  std::vector<uint32_t> mx, mp, ms;
+  auto solve_record = [&](const CompRecord &R, const uint32_t *x, const uint32_t *p, const uint32_t *s, uint8_t *flags) {
+    uint32_t first;
+    if (R.n <= (uint32_t)kTinyMax) {
+      struct Acc {
+        const uint32_t *a, *b, *c;
+        uint32_t x(int k) const { return a[k]; }
+        uint32_t par(int k) const { return b[k]; }
+        uint32_t slot(int k) const { return c[k]; }
+      };
+      first = tiny_first(Acc{x, p, s}, (int)R.n, R.n_graph, tiny_scr.data());
+    } else if (R.n <= (uint32_t)kGroupCompMax) {
+      const size_t cap = ((size_t)R.n + 3) & ~(size_t)3, tbl = (size_t)pyset_final_mask(R.n) + 1;
+      uint32_t cap2 = 64;
+      while (cap2 < 2u * R.n) cap2 <<= 1;
+      clocal.assign(comp_local_bytes(cap, tbl, cap2), 0);
+      CompLocal L;
+      comp_local_carve(clocal.data(), cap, tbl, cap2, L);
+      first = comp_group_first(g, L, x, p, s, (int)R.n, R.n_graph, cap2);
+    } else {
+      first = host_component_first_big(x, p, s, R.n, R.n_graph);
+    }
+    for (uint32_t k = 0; k < R.n; ++k)
+      if (x[k] != first) flags[x[k]] = 1;
+  };
+  PyTupleSetEmu edge_set;
+  for (size_t q = 0; q < es.size(); ++q) {
+    const E &e = es[q];
+    eflags[q].assign((size_t)(e.d * e.nch), 0);
+    for (int64_t c = 0; c < e.nch; ++c) {
+      const int64_t lo = e.lo + c * e.d;
+      uint8_t *flags = eflags[q].data() + c * e.d;
+      if (e.d <= kChunkMax) {
+        const int d = (int)e.d;
+        int tbl = (int)pyset_final_mask(d - 1) + 1;
+        local.assign(chunk_local_bytes(d, tbl, 1), 0);
+        ChunkLocal L;
+        chunk_local_carve(local.data(), d, tbl, L);
+        recs.assign((size_t)d / 16 + 2, CompRecord{0, 0, 0, 0});
+        mx.assign((size_t)d, 0), mp.assign((size_t)d, 0), ms.assign((size_t)d, 0);
+        const ChunkExport ex{recs.data(), mx.data(), mp.data(), ms.data(), 0};
+        const int nexp = chunk_front(g, L, fm, lo, d, 0u, flags, ex);
+        for (int b = 0; b < nexp; ++b) {
+          const CompRecord &R = recs[(size_t)b];
+          solve_record(R, mx.data() + R.moff, mp.data() + R.moff, ms.data() + R.moff, flags);
+        }
+        continue;
+      }
+      // a large chunk: slots from the reference emulation of the tuple set, roots by union-find
+      const int64_t d = e.d;
+      std::vector<int64_t> hashes;
+      std::vector<int32_t> edge_x;
+      std::vector<int64_t> par((size_t)d);
+      for (int64_t x = 0; x < d; ++x) {
+        const int64_t j = fm[lo + x];
+        par[(size_t)x] = (j >= 0 && j < lo + d) ? j - lo : x;
+        if (par[(size_t)x] != x) {
+          edge_x.push_back((int32_t)x);
+          hashes.push_back(py_tuple2_hash(x, par[(size_t)x]));
+        }
+      }
+      if (edge_x.empty()) continue;
+      edge_set.reset(hashes.data());
+      auto never = [](int64_t, int64_t) { return false; };
+      for (size_t k = 0; k < edge_x.size(); ++k) edge_set.add<true>((int32_t)k, never);
+      std::vector<uint32_t> slot((size_t)d, kNone);
+      for (size_t s = 0; s <= edge_set.mask; ++s)
+        if (edge_set.table[s] >= 0) slot[(size_t)edge_x[(size_t)edge_set.table[s]]] = (uint32_t)s;
+      std::vector<int64_t> root(par);
+      for (int64_t x = d - 1; x >= 0; --x) root[(size_t)x] = par[(size_t)x] == x ? x : root[(size_t)par[(size_t)x]];  // parents come later
+      std::vector<char> gnode((size_t)d, 0);
+      for (int32_t x : edge_x) gnode[(size_t)x] = 1, gnode[(size_t)par[(size_t)x]] = 1;
+      std::vector<uint32_t> size((size_t)d, 0), off((size_t)d + 1, 0), fill((size_t)d, 0);
+      uint32_t ng = 0;
+      for (int64_t x = 0; x < d; ++x)
+        if (gnode[(size_t)x]) ++ng, ++size[(size_t)root[(size_t)x]];
+      for (int64_t x = 0; x < d; ++x) off[(size_t)x + 1] = off[(size_t)x] + size[(size_t)x];
+      mx.assign((size_t)ng, 0), mp.assign((size_t)ng, 0), ms.assign((size_t)ng, 0);
+      for (int64_t x = d - 1; x >= 0; --x)  // (any order: the device fills through atomics)
+        if (gnode[(size_t)x]) {
+          const int64_t r = root[(size_t)x];
+          const uint32_t at = off[(size_t)r] + fill[(size_t)r]++;
+          mx[at] = (uint32_t)x, mp[at] = (uint32_t)par[(size_t)x], ms[at] = slot[(size_t)x];
+        }
+      for (int64_t r = 0; r < d; ++r)
+        if (size[(size_t)r] >= 2) {
+          const CompRecord R{0, off[(size_t)r], size[(size_t)r], ng};
+          solve_record(R, mx.data() + R.moff, mp.data() + R.moff, ms.data() + R.moff, flags);
+        }
+    }
+  }
+  std::vector<const uint8_t *> lf((size_t)kLadderLevels, nullptr);
+  const uint8_t *first_last = nullptr;
+  for (size_t q = 0; q < es.size(); ++q) {
+    if (es[q].lo == 0) lf[(size_t)es[q].li] = eflags[q].data();
+    else first_last = eflags[q].data();
+  }
+  return tfd_apply_levels_host(fm, N, lf, first_li, first_last, mask_out);
 }
 
 }  // namespace fc

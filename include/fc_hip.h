@@ -446,9 +446,11 @@ int fc_tfd_simbits(const double *tf, int64_t N, int64_t Q, double thresh, int64_
 /* prune_conformers_tfd at any N (firecode/torsion_module.py:957-1043):
  * fc_tfd_first_match: first_out[i] = min{ j > i : TFD-similar(i, j) } or -1 (GPU);
  * fc_tfd_ladder_from_first_match: the reference's k-ladder / match-graph /
- * "keep group[0]" bookkeeping replayed on the host from that array -- pure
- * host code (no device needed), bit-identical to the reference under CPython
- * >= 3.8 + networkx 3.x because it reproduces their set iteration order;
+ * "keep group[0]" bookkeeping replayed from that array -- bit-identical to the
+ * reference under CPython >= 3.8 + networkx 3.x because it reproduces their set
+ * iteration order.  With an initialised device and N >= 20000 the ladder runs
+ * there (fc_tfd_ladder.hip; FC_TFD_GPU=0: on the host anyway), otherwise it is
+ * pure host code (no device needed);
  * fc_tfd_prune = both. */
 int fc_tfd_first_match(const double *tf, int64_t N, int64_t Q, double thresh, int64_t *first_out);
 int fc_tfd_ladder_from_first_match(const int64_t *first_match, int64_t N, uint8_t *mask_out);
@@ -458,9 +460,12 @@ int fc_tfd_prune(const double *tf, int64_t N, int64_t Q, double thresh, uint8_t 
  * set of 2-tuples (returned as indices into the input) */
 int fc_debug_pyset_order_ints(const int64_t *keys, int64_t n, int64_t *order_out, int64_t *n_out);
 int fc_debug_pyset_order_pairs(const int64_t *pairs, int64_t n, int64_t *order_out, int64_t *n_out);
-/* the same order for n DISTINCT pairs computed on the device (fc_tfd_gpu.hip: staged priority first-fit, what the
+/* the same order for n DISTINCT pairs computed on the device (fc_tfd_ladder.hip: staged priority first-fit, what the
  * coarse levels of the TFD ladder use); order_out: n indices.  Test hook. */
 int fc_debug_pyset_order_pairs_device(const int64_t *pairs, int64_t n, int64_t *order_out);
+/* the device ladder's per-chunk and per-component routines (fc_tfd_core.h) run on the CPU by one host thread standing
+ * for a wavefront: same mask as fc_tfd_ladder_from_first_match.  Pure host code.  Test hook. */
+int fc_debug_tfd_ladder_emulate(const int64_t *first_match, int64_t N, uint8_t *mask_out);
 
 /* ---- a1: the .xyz wire format (host code; firecode/ensemble.py:58-98, 284-297;
  * firecode/utils.py:105-116).  atoms: A C strings.  mode 0 = Ensemble.to_xyz text

@@ -1,6 +1,7 @@
-"""The device half of the TFD ladder's coarse levels (csrc/fc_tfd_gpu.hip) against the host emulation of
-CPython's sets (csrc/fc_tfd_host.cpp, itself checked against the running interpreter in
-tests/test_pyset_emulation.py): the iteration order of a set of 2-tuples by staged priority first-fit."""
+"""The TFD ladder on the device (csrc/fc_tfd_ladder.hip + fc_tfd_core.h) against the host emulation of CPython's sets
+and networkx's orders (csrc/fc_tfd_host.cpp, itself checked against the running interpreter in
+tests/test_pyset_emulation.py and against the reference's loop by the golden masks): the iteration order of a set of
+2-tuples by staged priority first-fit, and whole ladders."""
 
 import numpy as np
 import pytest
@@ -75,40 +76,40 @@ def _random_first_match(rng, n, kind):
     return fm
 
 
-@pytest.mark.parametrize("n,kind,seed", [(140000, "near", 1), (300000, "mixed", 2), (700000, "stars", 3), (262144, "chain", 4),
-                                          (1679611, "mixed", 5), (131072, "mixed", 6), (1000003, "near", 7)])
-def test_ladder_mask_is_the_same_with_device_built_chunk_graphs(fc, monkeypatch, n, kind, seed):
-    """fc_tfd_ladder_from_first_match with the coarse levels' chunk graphs built on the device (default with a GPU)
-    == the all-host ladder (FC_TFD_GPU=0), whose group[0] bookkeeping is pinned to CPython / networkx by the golden
-    masks and tests/test_pyset_emulation.py; also with a lower chunk threshold, so that more levels go to the device, and with one / five levels in flight
-    at a time (helper threads, a stream each)"""
-    rng = np.random.default_rng(seed)
-    fm = _random_first_match(rng, n, kind)
-    masks = {}
-    for label, env in (("host", {"FC_TFD_GPU": "0"}), ("device", {}), ("device_fine", {"FC_TFD_GPU_CHUNK_MIN": "40"}),
-                       ("device_one_stream", {"FC_TFD_GPU_STREAMS": "1", "FC_TFD_GPU_CHUNK_MIN": "1000"}),
-                       ("device_five_streams", {"FC_TFD_GPU_STREAMS": "5"}),
-                       ("device_graphs_host_components", {"FC_TFD_GPU_COMPONENTS": "0", "FC_TFD_GPU_CHUNK_MIN": "20000"})):
-        for k in ("FC_TFD_GPU", "FC_TFD_GPU_CHUNK_MIN", "FC_TFD_GPU_COMPONENTS", "FC_TFD_GPU_STREAMS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+def _host_and_device(monkeypatch, fm):
+    n = len(fm)
+    out = {}
+    for label, env in (("host", "0"), ("device", "1")):
+        monkeypatch.setenv("FC_TFD_GPU", env)
         m = np.zeros(n, dtype=np.uint8)
         _lib.call("fc_tfd_ladder_from_first_match", _lib.pi(fm), n, _lib.pb(m))
-        masks[label] = m
-    for label in ("device", "device_fine", "device_one_stream", "device_five_streams", "device_graphs_host_components"):
-        assert np.array_equal(masks["host"], masks[label]), label
-    assert 0 < masks["host"].sum() < n
+        out[label] = m
+    monkeypatch.delenv("FC_TFD_GPU", raising=False)
+    return out["host"], out["device"]
 
 
-def test_ladder_components_at_and_above_every_device_capacity(fc, monkeypatch):
-    """Directed shapes for every size class of the device's component phase (fc_tfd_gpu.hip) in ONE first-match array:
-    a star with in-degree 1 600 and a chain of 3 000 nodes (above FC_TFD_DEV_COMP_MAX = 1 024: cut out and sent to the
-    host threads), a 401-node component with residue collisions (above the 306-node LDS walk: host list), a 200-node
-    one with collisions (walked by lane 0 out of LDS), a 60-node clean one (residue bitmap), 3- and 4-node components
-    with collisions (register tables), a star that is MORE than half of its chunk at the fine device levels (keeps its
-    earliest node) -- all == the all-host ladder.  (Round 3 saw one abort of an uncommitted tree on the random
-    'stars' shape, stderr not kept: DESIGN.md 5.3.)"""
+@pytest.mark.parametrize("n,kind,seed", [(25000, "near", 9), (140000, "near", 1), (300000, "mixed", 2), (700000, "stars", 3),
+                                          (262144, "chain", 4), (1679611, "mixed", 5), (131072, "mixed", 6), (1000003, "near", 7),
+                                          (60000, "stars", 8)])
+def test_ladder_mask_is_the_same_on_the_device(fc, monkeypatch, n, kind, seed):
+    """fc_tfd_ladder_from_first_match on the device (default with a GPU from 20 000 structures on) == the all-host ladder
+    (FC_TFD_GPU=0), whose group[0] bookkeeping is pinned to CPython / networkx by the golden masks and
+    tests/test_pyset_emulation.py.  'chain' and 'stars' hold components above 4 096 nodes: the device leaves those to
+    the host and the levels are then applied there from the device's flags."""
+    rng = np.random.default_rng(seed)
+    fm = _random_first_match(rng, n, kind)
+    host, dev = _host_and_device(monkeypatch, fm)
+    assert np.array_equal(host, dev)
+    assert 0 < host.sum() < n
+
+
+def test_ladder_components_of_every_device_size_class(fc, monkeypatch):
+    """Directed shapes for every size class of the device's component phase in ONE first-match array: a chain of 5 001
+    nodes (above 4 096: the host's), a star with in-degree 1 600 and a chain of 3 001 nodes (a workgroup each, tables
+    of 8 192 slots), a 401-node component with residue collisions (workgroup, 2 048 slots), a 200-node one with
+    collisions and a 60-node clean one (a wavefront each), a 30-node one with collisions, 3- and 4-node components with
+    collisions (one lane each), a star that is MORE than half of its chunk at a fine level (keeps its earliest node)
+    -- all == the all-host ladder."""
     n = 262144
     rng = np.random.default_rng(11)
     i = np.arange(n, dtype=np.int64)
@@ -130,6 +131,8 @@ def test_ladder_components_at_and_above_every_device_capacity(fc, monkeypatch):
     fm[100000:100000 + 128 * 199:128] = 100000 + 128 * 199  # 200 nodes, residues collide modulo 512
     clear(140000, 140100)
     fm[140000:140059] = 140059                 # 60 nodes, consecutive: clean
+    clear(145000, 145000 + 128 * 31)
+    fm[145000:145000 + 128 * 29:128] = 145000 + 128 * 29    # 30 nodes, residues collide modulo 128
     clear(150000, 150100)
     fm[150000] = 150008
     fm[150008] = 150016                        # 3 nodes, residues 0 modulo 8
@@ -138,58 +141,34 @@ def test_ladder_components_at_and_above_every_device_capacity(fc, monkeypatch):
     fm[150056] = 150064                        # 4 nodes
     clear(200000, 200260)
     fm[200000:200255] = 200255                 # 256 nodes inside one chunk of the k = 1000 level (d = 262): > half
+    clear(210000, 215100)
+    fm[210000:215000] = np.arange(210001, 215001)  # chain of 5 001 nodes
     assert np.all((fm == -1) | ((fm > i) & (fm < n)))
-    masks = {}
-    for label, env in (("host", {"FC_TFD_GPU": "0"}), ("device", {}), ("device_fine", {"FC_TFD_GPU_CHUNK_MIN": "40"}),
-                       ("device_graphs_host_components", {"FC_TFD_GPU_COMPONENTS": "0"})):
-        for k in ("FC_TFD_GPU", "FC_TFD_GPU_CHUNK_MIN", "FC_TFD_GPU_COMPONENTS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        m = np.zeros(n, dtype=np.uint8)
-        _lib.call("fc_tfd_ladder_from_first_match", _lib.pi(fm), n, _lib.pb(m))
-        masks[label] = m
-    for label in ("device", "device_fine", "device_graphs_host_components"):
-        assert np.array_equal(masks["host"], masks[label]), label
-    assert 0 < masks["host"].sum() < n
+    host, dev = _host_and_device(monkeypatch, fm)
+    assert np.array_equal(host, dev)
+    assert 0 < host.sum() < n
+    # the same array without the 5 001-node chain: nothing is left to the host, the levels are applied on the device
+    clear(210000, 215100)
+    host, dev = _host_and_device(monkeypatch, fm)
+    assert np.array_equal(host, dev)
 
 
-def test_ladder_with_many_components_left_to_the_host(fc):
-    """FC_TFD_DEV_COMP_MAX is read once per process: a child interpreter with a cap of 48 nodes sends hundreds of
-    components per level down to the host threads (the compact copy of JUST those components, k_left_gather) -- same
-    mask as the all-host ladder"""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, os\n"
-        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
-        "import numpy as np\n"
-        "import firecode_amd as fc\n"
-        "from firecode_amd import _lib\n"
-        "from test_tfd_gpu_graph import _random_first_match\n"
-        "fc.init(0)\n"
-        "for n, kind, seed in ((300000, 'mixed', 2), (262144, 'chain', 4), (400000, 'stars', 3)):\n"
-        "    fm = _random_first_match(np.random.default_rng(seed), n, kind)\n"
-        "    out = {}\n"
-        "    for label, env in (('host', '0'), ('device', '1')):\n"
-        "        os.environ['FC_TFD_GPU'] = env\n"
-        "        m = np.zeros(n, dtype=np.uint8)\n"
-        "        _lib.call('fc_tfd_ladder_from_first_match', _lib.pi(fm), n, _lib.pb(m))\n"
-        "        out[label] = m\n"
-        "    assert np.array_equal(out['host'], out['device']) and 0 < out['host'].sum() < n, kind\n"
-        "print('ok')\n")
-    env = dict(os.environ, FC_TFD_DEV_COMP_MAX="48")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+def test_ladder_whose_last_chunks_hold_edges(fc, monkeypatch):
+    """Few structures are rejected, so the LAST chunk of every level (which ends at the active count of its moment,
+    torsion_module.py:987-990) is long and holds edges: the device notices and the levels are applied on the host."""
+    n = 200000
+    rng = np.random.default_rng(21)
+    i = np.arange(n, dtype=np.int64)
+    fm = np.where(rng.random(n) < 0.02, i + rng.integers(1, 2000, n), -1).astype(np.int64)
+    fm[fm >= n] = -1
+    host, dev = _host_and_device(monkeypatch, fm)
+    assert np.array_equal(host, dev)
+    assert 0.9 * n < host.sum() < n
 
 
 def test_ladder_on_a_device_other_than_zero(fc):
-    """The ladder's helper threads are fresh std::threads: HIP's current device is per thread and starts at 0, so they
-    select the context's device themselves (fc_tfd_host.cpp level_worker).  Needs a second GPU: a child interpreter
-    runs fc.init(1) and a device ladder of 3e5 structures, mask == the all-host ladder."""
+    """Needs a second GPU: a child interpreter runs fc.init(1) and a device ladder of 3e5 structures, mask == the
+    all-host ladder."""
     import os
     import subprocess
     import sys
