@@ -88,6 +88,7 @@ int launch_tfd_first_match(const double *, int64_t, int64_t, int64_t, double, in
 int launch_transpose_pad(const double *, int64_t, int64_t, int64_t, double *);
 int launch_gather_transpose_pad(const double *, const double *, const int64_t *, int64_t, int64_t, int64_t, double *);
 int tfd_ladder_from_first_match(const int64_t *, int64_t, uint8_t *, const int64_t *fm_dev = nullptr);
+int tfd_ladder_from_device(const int64_t *fm_dev, int64_t, uint8_t *);
 void pyset_order_ints(const int64_t *, int64_t, std::vector<int64_t> &);
 void pyset_order_pairs(const int64_t *, int64_t, std::vector<int64_t> &);
 int pyset_order_pairs_device(const int64_t *, int64_t, int64_t *);
@@ -2311,12 +2312,8 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
     FC_TRY(d2h_staged(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t), ctx().s_lane[0]));
   }
   lap("first match enqueued, counts down");
-  std::vector<int64_t> fm((size_t)N);
-  FC_TRY(d2h(fm.data(), dfm.p, (size_t)N * sizeof(int64_t)));
-  FC_TRY(sync());
-  lap("first match down");
   std::vector<uint8_t> mask((size_t)N);
-  FC_TRY(tfd_ladder_from_first_match(fm.data(), N, mask.data(), dfm.as<int64_t>()));
+  FC_TRY(tfd_ladder_from_device(dfm.as<int64_t>(), N, mask.data()));
   lap("ladder");
   std::memset(tfd_keep_out, 0, (size_t)S + 1);
   tfd_keep_out[0] = mask[0];

@@ -113,6 +113,16 @@ struct Probe {
     lim = (i + 9 <= mask) ? 9 : 0;
   }
   FC_HD uint32_t slot() const { return (uint32_t)(i + (uint64_t)j); }
+  // the sequence of `hash` positioned AT slot s, which a key of that hash holds: a key sits at the first place of its
+  // sequence that it won (holders only ever get stronger), and that is nearly always inside its first linear window
+  FC_HD void start_at(int64_t hash, uint32_t mask_, uint32_t s) {
+    start(hash, mask_);
+    if ((uint64_t)s >= i && (uint64_t)s <= i + (uint64_t)lim) {
+      j = (int)((uint64_t)s - i);
+      return;
+    }
+    while (slot() != s) next();
+  }
   FC_HD void next() {
     if (j < lim) {
       ++j;
@@ -161,6 +171,7 @@ struct HostGroup {
   uint32_t reduce_sum(uint32_t v) const { return v; }
   uint32_t reduce_or(uint32_t v) const { return v; }
   uint64_t reduce_min64(uint64_t v) const { return v; }
+  uint32_t bcast(uint32_t v) const { return v; }
   bool in_first_wave() const { return true; }
   HostGroup first_wave() const { return *this; }
 };
@@ -194,8 +205,7 @@ FC_HD void pyset_build(G &g, int n_ids, const uint16_t *rank, int m, HashF hash,
         if (old == kNone) break;
         if (old > me) {  // this key outranks the slot's holder: the holder moves on along ITS sequence, behind slot s
           me = old;
-          p.start(hash((int)(old & 0x1FFFu)), mask);
-          while (p.slot() != s) p.next();
+          p.start_at(hash((int)(old & 0x1FFFu)), mask, s);
         }
         p.next();
       }
@@ -338,9 +348,29 @@ FC_HD void comp_local_carve(void *mem, size_t cap, size_t tbl, size_t cap2, Comp
 
 // mx / mp / ms: the members' relative index, first match (relative; the member itself when it has none in the chunk)
 // and edge slot, in any order.  cap2: power of two >= 2 n (the hash map's size).  Returns the kept member's relative index.
+#if defined(FC_TFD_STAMPS) && defined(__HIPCC__)
+// tuning build: cycles of the phases of the LARGEST component seen (tools/ladder_stamps.py reads g_tfd_stamps)
+static __device__ unsigned long long g_tfd_stamps[16];
+#endif
+#if defined(FC_TFD_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define FC_STAMP(i)                                                                                  \
+  do {                                                                                               \
+    if (g.tid == 0 && n >= 3000) {                                                                   \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                  \
+      atomicMax(&g_tfd_stamps[i], now_ - t_prev_);                                                   \
+      t_prev_ = now_;                                                                                \
+    }                                                                                                \
+  } while (0)
+#define FC_STAMP_BEGIN unsigned long long t_prev_ = __builtin_amdgcn_s_memtime()
+#else
+#define FC_STAMP(i) do { } while (0)
+#define FC_STAMP_BEGIN do { } while (0)
+#endif
+
 template <class G>
 FC_HD uint32_t comp_group_first(G &g, const CompLocal &L, const uint32_t *mx, const uint32_t *mp, const uint32_t *ms, int n,
                                 uint32_t n_graph, uint32_t cap2) {
+  FC_STAMP_BEGIN;
   for (int k = g.tid; k < n; k += g.size) L.X[k] = mx[k];
   g.sync();
   // the earliest edge's first endpoint: the component's earliest node in the graph's order, the search's source
@@ -370,6 +400,7 @@ FC_HD uint32_t comp_group_first(G &g, const CompLocal &L, const uint32_t *mx, co
     g.sync();
     if (!dirty) return (uint32_t)(bestr & 0xFFFFFFFFull);
   }
+  FC_STAMP(0);
   // local parent of every member through a hash map relative index -> member
   const uint32_t hmask = cap2 - 1;
   for (uint32_t s = (uint32_t)g.tid; s < cap2; s += (uint32_t)g.size) L.table[s] = 0u;
@@ -405,6 +436,7 @@ FC_HD uint32_t comp_group_first(G &g, const CompLocal &L, const uint32_t *mx, co
       g.atomic_add16(L.deg, L.pl[k], 1);
     }
   g.sync();
+  FC_STAMP(1);
   {  // neighbour list offsets
     uint32_t carry = 0;
     for (int base = 0; base < n; base += g.size) {
@@ -425,6 +457,7 @@ FC_HD uint32_t comp_group_first(G &g, const CompLocal &L, const uint32_t *mx, co
       L.adjU[L.head[p] + g.atomic_add16(L.cur, p, 1)] = (uint16_t)k;
     }
   g.sync();
+  FC_STAMP(2);
   // neighbour lists in edge order (what networkx's adjacency dicts iterate): place = edges of the node with a smaller slot
   const int n_rec = 2 * (n - 1);
   for (int rec = g.tid; rec < n_rec; rec += g.size) {
@@ -444,16 +477,91 @@ FC_HD uint32_t comp_group_first(G &g, const CompLocal &L, const uint32_t *mx, co
     L.adjS[L.head[v] + place] = (uint16_t)w;
   }
   g.sync();
+  FC_STAMP(3);
   // breadth-first order, level by level: every neighbour of a node except the one it was reached from is new.  The
   // levels of these trees are many and narrow (hundreds of levels of a few nodes): ONE wavefront walks them (its
   // hand-overs cost a few cycles where a workgroup barrier per level costs a microsecond), the others wait
   uint16_t *bfs = L.adjU, *rank = L.adjU + n, *frm = L.cur, *pos = reinterpret_cast<uint16_t *>(L.S);
+  uint64_t *nb = reinterpret_cast<uint64_t *>(L.table);  // (the table is free between the parent look-up and the sets)
+  for (int v = g.tid; v < n; v += g.size) {
+    const int a0 = L.head[v], dg = (int)L.head[v + 1] - a0;
+    uint64_t word = 0;
+    for (int q = 0; q < 4; ++q) word |= (uint64_t)(q < dg ? L.adjS[a0 + q] : (uint16_t)0xFFFFu) << (16 * q);
+    if (dg > 4) word = (word & 0x0000FFFFFFFFFFFFull) | (0xFFFEull << 48);
+    nb[v] = word;
+  }
   if (g.tid == 0) bfs[0] = (uint16_t)src, frm[src] = kNone16;
   g.sync();
   if (g.in_first_wave()) {
     auto w = g.first_wave();
     int lo = 0, hi = 1;
     while (lo < hi) {
+      if (hi - lo <= 4) {
+        // narrow levels (most of them, in trees that are thousands of levels deep): lane 0 walks on by itself until a
+        // level is wider, the level's nodes in registers and a node's first four neighbours in ONE 8-byte word -- one
+        // round trip to local memory per LEVEL, against a wave-wide prefix sum and a hand-over
+        if (w.tid == 0) {
+          int cnt = hi - lo;
+          uint16_t cv[4], cf[4];
+          for (int i = 0; i < 4; ++i)
+            if (i < cnt) cv[i] = bfs[lo + i], cf[i] = frm[cv[i]];
+          while (cnt > 0 && cnt <= 4) {
+            if (cnt == 1 && (uint16_t)(nb[cv[0]] >> 48) == 0xFFFFu) {
+              // a single node with at most three neighbours (the links of a chain): nothing to index dynamically
+              const int v = cv[0], f = cf[0];
+              const uint64_t word = nb[v];
+              const int x0 = (int)(word & 0xFFFFu), x1 = (int)((word >> 16) & 0xFFFFu), x2 = (int)((word >> 32) & 0xFFFFu);
+              int o = hi;
+              if (x0 != 0xFFFF && x0 != f) bfs[o++] = (uint16_t)x0, frm[x0] = (uint16_t)v;
+              if (x1 != 0xFFFF && x1 != f) bfs[o++] = (uint16_t)x1, frm[x1] = (uint16_t)v;
+              if (x2 != 0xFFFF && x2 != f) bfs[o++] = (uint16_t)x2, frm[x2] = (uint16_t)v;
+              const int c = o - hi;
+              lo = hi;
+              hi = o;
+              cnt = c;
+              if (x0 != 0xFFFF && x0 != f) cv[0] = (uint16_t)x0;  // (the next level in order: at most three nodes)
+              else if (x1 != 0xFFFF && x1 != f) cv[0] = (uint16_t)x1;
+              else cv[0] = (uint16_t)x2;
+              if (c >= 2) cv[1] = bfs[lo + 1];
+              if (c >= 3) cv[2] = bfs[lo + 2];
+              cf[0] = cf[1] = cf[2] = (uint16_t)v;
+              continue;
+            }
+            uint64_t nbv[4];
+            for (int i = 0; i < 4; ++i)
+              if (i < cnt) nbv[i] = nb[cv[i]];
+            int o = hi, ncnt = 0;
+            uint16_t nv[4], nf[4];
+            for (int i = 0; i < 4; ++i) {
+              if (i >= cnt) break;
+              const int v = cv[i], f = cf[i];
+              auto reach = [&](int x) {
+                if (x == f) return;
+                bfs[o++] = (uint16_t)x, frm[x] = (uint16_t)v;
+                if (ncnt < 4) nv[ncnt] = (uint16_t)x, nf[ncnt] = (uint16_t)v;
+                ++ncnt;
+              };
+              if ((uint16_t)(nbv[i] >> 48) == 0xFFFEu) {  // more than four neighbours: the list itself
+                for (int a = L.head[v]; a < (int)L.head[v + 1]; ++a) reach(L.adjS[a]);
+              } else {
+                for (int q = 0; q < 4; ++q) {
+                  const int x = (int)((nbv[i] >> (16 * q)) & 0xFFFFu);
+                  if (x == 0xFFFF) break;
+                  reach(x);
+                }
+              }
+            }
+            lo = hi;
+            hi = o;
+            cnt = ncnt;
+            for (int i = 0; i < 4; ++i) cv[i] = nv[i], cf[i] = nf[i];
+          }
+        }
+        w.sync();
+        lo = (int)w.bcast((uint32_t)lo);
+        hi = (int)w.bcast((uint32_t)hi);
+        continue;
+      }
       uint32_t carry = (uint32_t)hi;
       for (int base = lo; base < hi; base += w.size) {
         const int p = base + w.tid;
@@ -479,11 +587,13 @@ FC_HD uint32_t comp_group_first(G &g, const CompLocal &L, const uint32_t *mx, co
     }
   }
   g.sync();
+  FC_STAMP(4);
   for (int p = g.tid; p < n; p += g.size) rank[bfs[p]] = (uint16_t)p;
   g.sync();
   // the set the search fills ...
   auto hash = [&](int k) { return (int64_t)L.X[k]; };
   pyset_build(g, n, rank, n, hash, L.table, pos);
+  FC_STAMP(5);
   {  // ... and the set made from its iteration (slot order)
     uint32_t carry = 0;
     for (uint32_t base = 0; base <= fmask; base += (uint32_t)g.size) {
@@ -497,6 +607,7 @@ FC_HD uint32_t comp_group_first(G &g, const CompLocal &L, const uint32_t *mx, co
   }
   g.sync();
   pyset_build(g, n, rank, n, hash, L.table, pos);
+  FC_STAMP(6);
   uint64_t bestp = ~0ull;
   for (int k = g.tid; k < n; k += g.size) {
     const uint64_t key = ((uint64_t)pos[k] << 16) | (uint64_t)k;

@@ -752,6 +752,24 @@ int tfd_ladder_from_first_match(const int64_t *fm, int64_t N, uint8_t *mask_out,
   }
 }
 
+// the same for a caller that holds the array on the device only (the csearch pipeline): nothing is copied down that
+// the ladder does not need
+int tfd_ladder_from_device(const int64_t *fm_dev, int64_t N, uint8_t *mask_out) {
+  bool use_gpu = N >= kDeviceLadderMin;
+  if (const char *v = getenv("FC_TFD_GPU")) use_gpu = use_gpu && atoi(v) != 0;
+  try {
+    if (use_gpu) return tfd_ladder_device(fm_dev, nullptr, N, mask_out);
+    std::vector<int64_t> fm((size_t)N);
+    FC_TRY(d2h(fm.data(), fm_dev, (size_t)N * sizeof(int64_t)));
+    FC_TRY(sync());
+    return tfd_ladder_host_only(fm.data(), N, mask_out);
+  } catch (const std::bad_alloc &) {
+    return set_error(FC_E_NOMEM, "out of host memory in the TFD ladder (N = %lld)", (long long)N);
+  } catch (const std::exception &e) {
+    return set_error(FC_E_HIP, "TFD ladder: %s", e.what());
+  }
+}
+
 // ---- a component of any size on the host (the device leaves those above tfd::kGroupCompMax nodes) ---------------------------
 // mx / mp / ms: relative index, first match (the member itself when it has none in the chunk), slot of the edge in the
 // chunk's tuple set.  Same orders as chunk_rejects' one_component.

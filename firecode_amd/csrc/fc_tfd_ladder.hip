@@ -85,6 +85,7 @@ struct WaveGroup {
     }
     return v;
   }
+  __device__ uint32_t bcast(uint32_t v) const { return __shfl(v, 0); }  // lane 0's value
   __device__ bool in_first_wave() const { return true; }
   __device__ WaveGroup first_wave() const { return *this; }
 };
@@ -278,13 +279,15 @@ k_comp_block(const CompRecord *__restrict__ rec, const uint32_t *__restrict__ li
   }
 }
 
-// tiny components of the large chunks: a lane each, from the sharded lists k_c_classify filled
-__global__ void __launch_bounds__(256)
+// tiny components of the large chunks: a lane each, from the sharded lists k_c_classify filled (members read in place:
+// staged through LDS the kernel took twice as long -- a third of the wavefronts per CU)
+constexpr int kTinyBlock = 256;
+__global__ void __launch_bounds__(kTinyBlock)
 k_tiny_lists(const CompRecord *__restrict__ tiny, const uint32_t *__restrict__ tiny_count, int64_t shard_cap,
              const uint32_t *__restrict__ mx, const uint32_t *__restrict__ mp, const uint32_t *__restrict__ ms,
              uint8_t *__restrict__ flags) {
-  __shared__ uint8_t scr[256 * kTinyScratch];
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  __shared__ uint8_t scr[kTinyBlock * kTinyScratch];
+  const int64_t q = (int64_t)blockIdx.x * kTinyBlock + threadIdx.x;
   const int64_t shard = q / shard_cap, idx = q - shard * shard_cap;
   if (shard >= 8 || idx >= (int64_t)tiny_count[shard * 32]) return;
   const CompRecord R = tiny[shard * shard_cap + idx];
@@ -446,8 +449,7 @@ k_c_insert(Coarse C, int y_off, int y_count, int stage) {
         if (old == kEmpty64) break;
         if (old > me) {
           me = old;
-          p.start(C.hash[(uint32_t)old], D.mask);
-          while (p.slot() != s) p.next();
+          p.start_at(C.hash[(uint32_t)old], D.mask, s);
         }
         p.next();
       }
@@ -833,7 +835,26 @@ int tfd_ladder_device(const int64_t *fm_dev, const int64_t *fm_host, int64_t N, 
   const LadTab &T = P.T;
   hipStream_t st = cur_stream();
   FC_TRY(side_streams());
-  hipStream_t st2 = ctx().s_lane[0];
+  // side streams: the small-chunk entries (two streams: the workgroup-per-chunk launches are the long ones) beside the coarse
+  // passes, later the component kernels of the four size classes and the tiny components of the large chunks side by side
+  hipStream_t sA = ctx().s_lane[0], sB = ctx().s_lane[1], sC = ctx().s_lane[2], sD = ctx().s_screen;
+  std::vector<hipEvent_t> &evs = ctx().ev_dep_pool;
+  while (evs.size() < 10) {
+    hipEvent_t e = nullptr;
+    FC_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    evs.push_back(e);
+  }
+  struct JoinSide {  // nothing of this call may still run on a side stream when its buffers go back to the pool (error paths too)
+    hipStream_t s[4];
+    ~JoinSide() {
+      for (hipStream_t x : s) (void)hipStreamSynchronize(x);
+    }
+  } join_side{{sA, sB, sC, sD}};
+  auto order = [&](hipStream_t from, hipStream_t to, int ev) -> int {  // `to` continues behind what `from` holds now
+    FC_HIP_TRY(hipEventRecord(evs[(size_t)ev], from));
+    FC_HIP_TRY(hipStreamWaitEvent(to, evs[(size_t)ev], 0));
+    return FC_OK;
+  };
   // ---- buffers (one block) ----
   const int64_t I = P.I, Ic = P.Ic;
   const int64_t n_static = I / 16 + 1, dense_cap = Ic / 19 + 2, shard_cap = (ceil_div(std::max<int64_t>(Ic, 1), 256) + 7) / 8 * 256;
@@ -905,19 +926,17 @@ int tfd_ladder_device(const int64_t *fm_dev, const int64_t *fm_host, int64_t N, 
     O.host_list = c_host.as<CompRecord>(), O.n_host = small + 512, O.host_cap = host_cap;
     FC_TRY(pinned_reserve((size_t)(P.n_cc + 1) * 4 + P.ylist.size() * 2 + 4096));
   }
-  // the small-chunk entries go to a second stream, beside the coarse passes
-  FC_HIP_TRY(hipEventRecord(ctx().ev2, st));
-  FC_HIP_TRY(hipStreamWaitEvent(st2, ctx().ev2, 0));
+  FC_TRY(order(st, sA, 0));
+  FC_TRY(order(st, sB, 1));
   for (int q = 0; q < T.n; ++q) {
     if (T.coarse[q]) continue;
     const int64_t d = T.d[q];
-    if (d <= 19) FC_TRY((launch_chunk_front<19, 32, 4>(st2, fm_dev, T, q, flags, rec, mx, mp, ms)));
-    else if (d <= 77) FC_TRY((launch_chunk_front<77, 128, 4>(st2, fm_dev, T, q, flags, rec, mx, mp, ms)));
-    else if (d <= 307) FC_TRY((launch_chunk_front<307, 512, 4>(st2, fm_dev, T, q, flags, rec, mx, mp, ms)));
-    else if (d <= 1229) FC_TRY((launch_chunk_front<1229, 2048, 2>(st2, fm_dev, T, q, flags, rec, mx, mp, ms)));
-    else FC_TRY((launch_chunk_front_block<4915, 8192>(st2, fm_dev, T, q, flags, rec, mx, mp, ms)));
+    if (d <= 19) FC_TRY((launch_chunk_front<19, 32, 4>(sB, fm_dev, T, q, flags, rec, mx, mp, ms)));
+    else if (d <= 77) FC_TRY((launch_chunk_front<77, 128, 4>(sB, fm_dev, T, q, flags, rec, mx, mp, ms)));
+    else if (d <= 307) FC_TRY((launch_chunk_front<307, 512, 4>(sB, fm_dev, T, q, flags, rec, mx, mp, ms)));
+    else if (d <= 1229) FC_TRY((launch_chunk_front<1229, 2048, 2>(sB, fm_dev, T, q, flags, rec, mx, mp, ms)));
+    else FC_TRY((launch_chunk_front_block<4915, 8192>(sA, fm_dev, T, q, flags, rec, mx, mp, ms)));
   }
-  FC_HIP_TRY(hipEventRecord(ctx().ev3, st2));
   if (Ic > 0) {
     const dim3 block(256), igrid((unsigned)ceil_div(Ic, 256));
     std::memcpy(ctx().pinned, P.tstart.data(), (size_t)(P.n_cc + 1) * 4);
@@ -966,20 +985,28 @@ int tfd_ladder_device(const int64_t *fm_dev, const int64_t *fm_host, int64_t N, 
     FC_TRY(check_launch("k_c_classify"));
     hipLaunchKernelGGL(k_c_members, igrid, block, 0, st, fm_dev, TC, C, mx, mp, ms);
     FC_TRY(check_launch("k_c_members"));
-    hipLaunchKernelGGL(k_tiny_lists, dim3((unsigned)ceil_div(8 * shard_cap, 256)), block, 0, st, O.tiny, O.tiny_count, shard_cap, mx, mp, ms, flags);
+    FC_TRY(order(st, sD, 2));
+    hipLaunchKernelGGL(k_tiny_lists, dim3((unsigned)ceil_div(8 * shard_cap, kTinyBlock)), dim3(kTinyBlock), 0, sD, O.tiny, O.tiny_count, shard_cap, mx, mp, ms, flags);
     FC_TRY(check_launch("k_tiny_lists"));
   }
-  // ---- components of 19 .. 4096 nodes from both paths ----
-  FC_HIP_TRY(hipStreamWaitEvent(st, ctx().ev3, 0));
+  // ---- components of 19 .. 4096 nodes from both paths: the four classes side by side, the largest (longest) first ----
+  FC_TRY(order(sA, st, 3));
+  FC_TRY(order(sB, st, 4));
   {
     const int64_t n_rec_cap = n_static + dense_cap;
     uint32_t *lists = d_lists.as<uint32_t>(), *lcount = small + 640;  // (one counter per 128-byte line)
     hipLaunchKernelGGL(k_comp_lists, dim3((unsigned)ceil_div(n_rec_cap, 256)), dim3(256), 0, st, rec, n_static, small, lists, n_rec_cap, lcount);
     FC_TRY(check_launch("k_comp_lists"));
+    FC_HIP_TRY(hipEventRecord(evs[5], st));
+    for (hipStream_t s2 : {sA, sB, sC}) FC_HIP_TRY(hipStreamWaitEvent(s2, evs[5], 0));
+    FC_TRY((launch_comp<4096, 8192, 8192, true>(sA, rec, lists + 3 * n_rec_cap, lcount + 96, I / 1229 + 1, mx, mp, ms, flags)));
+    FC_TRY((launch_comp<1228, 2048, 4096, true>(sB, rec, lists + 2 * n_rec_cap, lcount + 64, I / 307 + 1, mx, mp, ms, flags)));
+    FC_TRY((launch_comp<308, 512, 1024, false>(sC, rec, lists + n_rec_cap, lcount + 32, I / 77 + 1, mx, mp, ms, flags)));
     FC_TRY((launch_comp<80, 128, 256, false>(st, rec, lists, lcount, I / 19 + 1, mx, mp, ms, flags)));
-    FC_TRY((launch_comp<308, 512, 1024, false>(st, rec, lists + n_rec_cap, lcount + 32, I / 77 + 1, mx, mp, ms, flags)));
-    FC_TRY((launch_comp<1228, 2048, 4096, true>(st, rec, lists + 2 * n_rec_cap, lcount + 64, I / 307 + 1, mx, mp, ms, flags)));
-    FC_TRY((launch_comp<4096, 8192, 8192, true>(st, rec, lists + 3 * n_rec_cap, lcount + 96, I / 1229 + 1, mx, mp, ms, flags)));
+    FC_TRY(order(sA, st, 6));
+    FC_TRY(order(sB, st, 7));
+    FC_TRY(order(sC, st, 8));
+    if (Ic > 0) FC_TRY(order(sD, st, 9));
   }
   // ---- the levels in order ----
   ApplyState *S = d_state.as<ApplyState>();
@@ -1117,6 +1144,17 @@ int pyset_order_pairs_device(const int64_t *pairs_host, int64_t n, int64_t *orde
   for (int64_t k = 0; k < n; ++k) order_out[k] = ord[(size_t)k];
   return FC_OK;
 }
+
+#if defined(FC_TFD_STAMPS)
+extern "C" int fc_debug_tfd_stamps(unsigned long long *out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(tfd::g_tfd_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(tfd::g_tfd_stamps), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 __global__ void k_warm_tfd_ladder() {}
 int warm_tfd_ladder() {
