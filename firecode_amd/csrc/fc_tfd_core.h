@@ -23,6 +23,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 
 #if defined(__HIPCC__)
 #define FC_HD __host__ __device__ __forceinline__
@@ -160,6 +161,9 @@ struct HostGroup {
     return o;
   }
   uint16_t atomic_add16(uint16_t *base, int idx, uint16_t v) const {
+    // (the device forms work on the 32-bit word that holds the counter: the array must start on a 4-byte boundary --
+    // checked here, where the CPU tests see it)
+    if (reinterpret_cast<uintptr_t>(base) & 3u) abort();
     const uint16_t o = base[idx];
     base[idx] = (uint16_t)(o + v);
     return o;
@@ -348,6 +352,153 @@ FC_HD void comp_local_carve(void *mem, size_t cap, size_t tbl, size_t cap2, Comp
 
 // mx / mp / ms: the members' relative index, first match (relative; the member itself when it has none in the chunk)
 // and edge slot, in any order.  cap2: power of two >= 2 n (the hash map's size).  Returns the kept member's relative index.
+
+// Breadth-first positions of a tree WITHOUT walking it level by level (trees of thousands of levels a few nodes wide: a
+// walk is a chain of dependent steps by one lane, however it is coded).  Root the tree at src and list every node's
+// children in the order of its neighbour list; then nodes of one depth stand in breadth-first order exactly as in
+// depth-first PREORDER (both are the lexicographic order of the child-index paths from the root), so
+//   position(w) = #{nodes of smaller depth} + #{nodes of the same depth and smaller preorder number}.
+// Depth and preorder number of every node are prefix sums along the Euler tour of the tree (+1 / -1 and 1 / 0 per arc
+// down / up): the tour is cut at about one arc per thread, every thread sums its piece, the pieces are chained, and a
+// second pass hands each node its numbers.  Local memory: nxt = 2 n uint16 in the table, depth / pre in L.S, the pieces'
+// sums over L.pl and L.deg (5 (g.size + 1) uint16: components of more than kWalkMax nodes only), rank out.
+constexpr int kWalkMax = 306;
+template <class G>
+FC_HD void bfs_rank_euler(G &g, const CompLocal &L, int n, int src, uint16_t *rank) {
+  uint16_t *up = L.cur, *nxt = reinterpret_cast<uint16_t *>(L.table);
+  uint16_t *depth = reinterpret_cast<uint16_t *>(L.S), *pre = depth + n;
+  const int narcs = 2 * (n - 1);
+  // (1) the parent of every node as seen from src: its first match, except along the path src -> old root, which turns round
+  for (int v = g.tid; v < n; v += g.size) up[v] = L.pl[v];
+  g.sync();
+  if (g.tid == 0) {
+    int v = src, prev = kNone16;
+    for (;;) {
+      const int nx = L.pl[v];
+      up[v] = (uint16_t)prev;
+      if (nx == kNone16) break;
+      prev = v;
+      v = nx;
+    }
+  }
+  g.sync();
+  // (2) the Euler tour: successor of every arc (v -> w), bit 15 = the arc goes down (w is a child of v)
+  const int a0 = L.head[src];
+  for (int a = g.tid; a < narcs; a += g.size) {
+    int lo = 0, hi = n;  // the arc's owner: head[v] <= a < head[v + 1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)L.head[mid] <= a) lo = mid;
+      else hi = mid;
+    }
+    const int v = lo, w = L.adjS[a];
+    const int w0 = L.head[w], w1 = L.head[w + 1], uw = up[w];
+    const bool down = uw == v;
+    int succ = -1;
+    if (down) {  // into w from its parent: on to w's first child, or straight back up from a leaf
+      for (int b = w0; b < w1; ++b)
+        if (L.adjS[b] != v) {
+          succ = b;
+          break;
+        }
+      if (succ < 0) succ = w0;
+    } else {  // back in w from its child v: on to the next child, or up to w's parent, or the tour ends (w is src)
+      int t = w0;
+      while (L.adjS[t] != v) ++t;
+      for (int b = t + 1; b < w1; ++b)
+        if (L.adjS[b] != uw) {
+          succ = b;
+          break;
+        }
+      if (succ < 0) {
+        if (uw == kNone16) succ = a;  // (the last arc: it points to itself)
+        else {
+          succ = w0;
+          while (L.adjS[succ] != uw) ++succ;
+        }
+      }
+    }
+    nxt[a] = (uint16_t)(succ | (down ? 0x8000 : 0));
+  }
+  g.sync();
+  // (3) pieces: a piece starts at a0 and at every arc whose number is a multiple of `stride`
+  const int stride = narcs > g.size ? (narcs + g.size - 1) / g.size : 1;
+  const int K = (narcs + stride - 1) / stride;  // regular pieces; the piece of a0 (when a0 is not one of them) is number K
+  const bool a0_extra = (a0 % stride) != 0;
+  int16_t *tot_d = reinterpret_cast<int16_t *>(L.pl), *off_d = tot_d + (g.size + 1);
+  uint16_t *tot_p = reinterpret_cast<uint16_t *>(off_d + (g.size + 1)), *off_p = tot_p + (g.size + 1), *nxts = off_p + (g.size + 1);
+  auto piece_of = [&](int a) { return a == a0 && a0_extra ? K : a / stride; };
+  auto starts_piece = [&](int a) { return a == a0 || a % stride == 0; };
+  auto walk = [&](int k, int a, bool second) {
+    int d = second ? (int)off_d[k] : 0, pp = second ? (int)off_p[k] : 0;
+    int nextp = kNone16;
+    for (;;) {
+      const int e = nxt[a], b = e & 0x7FFF;
+      if (e & 0x8000) {
+        ++d, ++pp;
+        if (second) {
+          const int w = L.adjS[a];
+          depth[w] = (uint16_t)d, pre[w] = (uint16_t)pp;
+        }
+      } else {
+        --d;
+      }
+      if (b == a) break;
+      a = b;
+      if (starts_piece(a)) {
+        nextp = piece_of(a);
+        break;
+      }
+    }
+    if (!second) tot_d[k] = (int16_t)d, tot_p[k] = (uint16_t)pp, nxts[k] = (uint16_t)nextp;
+  };
+  for (int k = g.tid; k < K; k += g.size) walk(k, k * stride, false);
+  if (g.tid == 0 && a0_extra) walk(K, a0, false);
+  g.sync();
+  if (g.tid == 0) {
+    int d = 0, pp = 0;
+    for (int k = piece_of(a0); k != kNone16; k = nxts[k]) {
+      off_d[k] = (int16_t)d, off_p[k] = (uint16_t)pp;
+      d += tot_d[k], pp += tot_p[k];
+    }
+    depth[src] = 0, pre[src] = 0;
+  }
+  g.sync();
+  for (int k = g.tid; k < K; k += g.size) walk(k, k * stride, true);
+  if (g.tid == 0 && a0_extra) walk(K, a0, true);
+  g.sync();
+  // (4) positions: nodes by depth (counting sort), inside a depth by preorder number
+  const int np = (n + 3) & ~1;  // (even: atomic_add16 works on the 32-bit word that holds the counter)
+  uint16_t *start = nxt, *fillc = start + np, *bucket = fillc + np;  // (the tour is no longer needed)
+  for (int d = g.tid; d < n + 2; d += g.size) start[d] = 0, fillc[d] = 0;
+  g.sync();
+  for (int v = g.tid; v < n; v += g.size) g.atomic_add16(fillc, depth[v], 1);
+  g.sync();
+  {
+    uint32_t carry = 0;
+    for (int base = 0; base < n + 1; base += g.size) {
+      const int d = base + g.tid;
+      const uint32_t c = d < n + 1 ? fillc[d] : 0u;
+      uint32_t tot;
+      const uint32_t prefix = g.scan_excl(c, tot);
+      if (d < n + 1) start[d] = (uint16_t)(carry + prefix);
+      carry += tot;
+    }
+  }
+  g.sync();
+  for (int d = g.tid; d < n + 1; d += g.size) fillc[d] = 0;
+  g.sync();
+  for (int v = g.tid; v < n; v += g.size) bucket[start[depth[v]] + g.atomic_add16(fillc, depth[v], 1)] = (uint16_t)v;
+  g.sync();
+  for (int v = g.tid; v < n; v += g.size) {
+    const int d = depth[v], b0 = start[d], b1 = start[d + 1], pv = pre[v];
+    int before = 0;
+    for (int b = b0; b < b1; ++b) before += pre[bucket[b]] < pv;
+    rank[v] = (uint16_t)(b0 + before);
+  }
+  g.sync();
+}
+
 #if defined(FC_TFD_STAMPS) && defined(__HIPCC__)
 // tuning build: cycles of the phases of the LARGEST component seen (tools/ladder_stamps.py reads g_tfd_stamps)
 static __device__ unsigned long long g_tfd_stamps[16];
@@ -362,7 +513,9 @@ static __device__ unsigned long long g_tfd_stamps[16];
     }                                                                                                \
   } while (0)
 #define FC_STAMP_BEGIN unsigned long long t_prev_ = __builtin_amdgcn_s_memtime()
+#define FC_COUNT(i, v) do { if (n >= 3000) atomicAdd(&g_tfd_stamps[i], (unsigned long long)(v)); } while (0)
 #else
+#define FC_COUNT(i, v) do { } while (0)
 #define FC_STAMP(i) do { } while (0)
 #define FC_STAMP_BEGIN do { } while (0)
 #endif
@@ -482,114 +635,123 @@ FC_HD uint32_t comp_group_first(G &g, const CompLocal &L, const uint32_t *mx, co
   // levels of these trees are many and narrow (hundreds of levels of a few nodes): ONE wavefront walks them (its
   // hand-overs cost a few cycles where a workgroup barrier per level costs a microsecond), the others wait
   uint16_t *bfs = L.adjU, *rank = L.adjU + n, *frm = L.cur, *pos = reinterpret_cast<uint16_t *>(L.S);
-  uint64_t *nb = reinterpret_cast<uint64_t *>(L.table);  // (the table is free between the parent look-up and the sets)
-  for (int v = g.tid; v < n; v += g.size) {
-    const int a0 = L.head[v], dg = (int)L.head[v + 1] - a0;
-    uint64_t word = 0;
-    for (int q = 0; q < 4; ++q) word |= (uint64_t)(q < dg ? L.adjS[a0 + q] : (uint16_t)0xFFFFu) << (16 * q);
-    if (dg > 4) word = (word & 0x0000FFFFFFFFFFFFull) | (0xFFFEull << 48);
-    nb[v] = word;
-  }
-  if (g.tid == 0) bfs[0] = (uint16_t)src, frm[src] = kNone16;
-  g.sync();
-  if (g.in_first_wave()) {
-    auto w = g.first_wave();
-    int lo = 0, hi = 1;
-    while (lo < hi) {
-      if (hi - lo <= 4) {
-        // narrow levels (most of them, in trees that are thousands of levels deep): lane 0 walks on by itself until a
-        // level is wider, the level's nodes in registers and a node's first four neighbours in ONE 8-byte word -- one
-        // round trip to local memory per LEVEL, against a wave-wide prefix sum and a hand-over
-        if (w.tid == 0) {
-          int cnt = hi - lo;
-          uint16_t cv[4], cf[4];
-          for (int i = 0; i < 4; ++i)
-            if (i < cnt) cv[i] = bfs[lo + i], cf[i] = frm[cv[i]];
-          while (cnt > 0 && cnt <= 4) {
-            if (cnt == 1 && (uint16_t)(nb[cv[0]] >> 48) == 0xFFFFu) {
-              // a single node with at most three neighbours (the links of a chain): nothing to index dynamically
-              const int v = cv[0], f = cf[0];
-              const uint64_t word = nb[v];
-              const int x0 = (int)(word & 0xFFFFu), x1 = (int)((word >> 16) & 0xFFFFu), x2 = (int)((word >> 32) & 0xFFFFu);
-              int o = hi;
-              if (x0 != 0xFFFF && x0 != f) bfs[o++] = (uint16_t)x0, frm[x0] = (uint16_t)v;
-              if (x1 != 0xFFFF && x1 != f) bfs[o++] = (uint16_t)x1, frm[x1] = (uint16_t)v;
-              if (x2 != 0xFFFF && x2 != f) bfs[o++] = (uint16_t)x2, frm[x2] = (uint16_t)v;
-              const int c = o - hi;
-              lo = hi;
-              hi = o;
-              cnt = c;
-              if (x0 != 0xFFFF && x0 != f) cv[0] = (uint16_t)x0;  // (the next level in order: at most three nodes)
-              else if (x1 != 0xFFFF && x1 != f) cv[0] = (uint16_t)x1;
-              else cv[0] = (uint16_t)x2;
-              if (c >= 2) cv[1] = bfs[lo + 1];
-              if (c >= 3) cv[2] = bfs[lo + 2];
-              cf[0] = cf[1] = cf[2] = (uint16_t)v;
-              continue;
-            }
-            uint64_t nbv[4];
+  if (n > kWalkMax) {
+    bfs_rank_euler(g, L, n, src, rank);
+    FC_STAMP(4);
+  } else {
+    uint64_t *nb = reinterpret_cast<uint64_t *>(L.table);  // (the table is free between the parent look-up and the sets)
+    for (int v = g.tid; v < n; v += g.size) {
+      const int a0 = L.head[v], dg = (int)L.head[v + 1] - a0;
+      uint64_t word = 0;
+      for (int q = 0; q < 4; ++q) word |= (uint64_t)(q < dg ? L.adjS[a0 + q] : (uint16_t)0xFFFFu) << (16 * q);
+      if (dg > 4) word = (word & 0x0000FFFFFFFFFFFFull) | (0xFFFEull << 48);
+      nb[v] = word;
+    }
+    if (g.tid == 0) bfs[0] = (uint16_t)src, frm[src] = kNone16;
+    g.sync();
+    FC_STAMP(7);
+    if (g.in_first_wave()) {
+      auto w = g.first_wave();
+      int lo = 0, hi = 1;
+      while (lo < hi) {
+        if (hi - lo <= 4) {
+          // narrow levels (most of them, in trees that are thousands of levels deep): lane 0 walks on by itself until a
+          // level is wider, the level's nodes in registers and a node's first four neighbours in ONE 8-byte word -- one
+          // round trip to local memory per LEVEL, against a wave-wide prefix sum and a hand-over
+          if (w.tid == 0) {
+            int cnt = hi - lo;
+            uint16_t cv[4], cf[4];
             for (int i = 0; i < 4; ++i)
-              if (i < cnt) nbv[i] = nb[cv[i]];
-            int o = hi, ncnt = 0;
-            uint16_t nv[4], nf[4];
-            for (int i = 0; i < 4; ++i) {
-              if (i >= cnt) break;
-              const int v = cv[i], f = cf[i];
-              auto reach = [&](int x) {
-                if (x == f) return;
-                bfs[o++] = (uint16_t)x, frm[x] = (uint16_t)v;
-                if (ncnt < 4) nv[ncnt] = (uint16_t)x, nf[ncnt] = (uint16_t)v;
-                ++ncnt;
-              };
-              if ((uint16_t)(nbv[i] >> 48) == 0xFFFEu) {  // more than four neighbours: the list itself
-                for (int a = L.head[v]; a < (int)L.head[v + 1]; ++a) reach(L.adjS[a]);
-              } else {
-                for (int q = 0; q < 4; ++q) {
-                  const int x = (int)((nbv[i] >> (16 * q)) & 0xFFFFu);
-                  if (x == 0xFFFF) break;
-                  reach(x);
+              if (i < cnt) cv[i] = bfs[lo + i], cf[i] = frm[cv[i]];
+            while (cnt > 0 && cnt <= 4) {
+              if (cnt == 1 && (uint16_t)(nb[cv[0]] >> 48) == 0xFFFFu) {
+                // a single node with at most three neighbours (the links of a chain): nothing to index dynamically
+                const int v = cv[0], f = cf[0];
+                const uint64_t word = nb[v];
+                const int x0 = (int)(word & 0xFFFFu), x1 = (int)((word >> 16) & 0xFFFFu), x2 = (int)((word >> 32) & 0xFFFFu);
+                int o = hi;
+                if (x0 != 0xFFFF && x0 != f) bfs[o++] = (uint16_t)x0, frm[x0] = (uint16_t)v;
+                if (x1 != 0xFFFF && x1 != f) bfs[o++] = (uint16_t)x1, frm[x1] = (uint16_t)v;
+                if (x2 != 0xFFFF && x2 != f) bfs[o++] = (uint16_t)x2, frm[x2] = (uint16_t)v;
+                FC_COUNT(8, 1);
+                const int c = o - hi;
+                lo = hi;
+                hi = o;
+                cnt = c;
+                if (x0 != 0xFFFF && x0 != f) cv[0] = (uint16_t)x0;  // (the next level in order: at most three nodes)
+                else if (x1 != 0xFFFF && x1 != f) cv[0] = (uint16_t)x1;
+                else cv[0] = (uint16_t)x2;
+                if (c >= 2) cv[1] = bfs[lo + 1];
+                if (c >= 3) cv[2] = bfs[lo + 2];
+                cf[0] = cf[1] = cf[2] = (uint16_t)v;
+                continue;
+              }
+              FC_COUNT(9, 1);
+              uint64_t nbv[4];
+              for (int i = 0; i < 4; ++i)
+                if (i < cnt) nbv[i] = nb[cv[i]];
+              int o = hi, ncnt = 0;
+              uint16_t nv[4], nf[4];
+              for (int i = 0; i < 4; ++i) {
+                if (i >= cnt) break;
+                const int v = cv[i], f = cf[i];
+                auto reach = [&](int x) {
+                  if (x == f) return;
+                  bfs[o++] = (uint16_t)x, frm[x] = (uint16_t)v;
+                  if (ncnt < 4) nv[ncnt] = (uint16_t)x, nf[ncnt] = (uint16_t)v;
+                  ++ncnt;
+                };
+                if ((uint16_t)(nbv[i] >> 48) == 0xFFFEu) {  // more than four neighbours: the list itself
+                  for (int a = L.head[v]; a < (int)L.head[v + 1]; ++a) reach(L.adjS[a]);
+                } else {
+                  for (int q = 0; q < 4; ++q) {
+                    const int x = (int)((nbv[i] >> (16 * q)) & 0xFFFFu);
+                    if (x == 0xFFFF) break;
+                    reach(x);
+                  }
                 }
               }
+              lo = hi;
+              hi = o;
+              cnt = ncnt;
+              for (int i = 0; i < 4; ++i) cv[i] = nv[i], cf[i] = nf[i];
             }
-            lo = hi;
-            hi = o;
-            cnt = ncnt;
-            for (int i = 0; i < 4; ++i) cv[i] = nv[i], cf[i] = nf[i];
           }
+          w.sync();
+          lo = (int)w.bcast((uint32_t)lo);
+          hi = (int)w.bcast((uint32_t)hi);
+          continue;
+        }
+        if (w.tid == 0) FC_COUNT(10, 1);
+        uint32_t carry = (uint32_t)hi;
+        for (int base = lo; base < hi; base += w.size) {
+          const int p = base + w.tid;
+          int v = 0, f = 0;
+          uint32_t c = 0;
+          if (p < hi) {
+            v = bfs[p];
+            f = frm[v];
+            c = (uint32_t)L.deg[v] - (f != kNone16 ? 1u : 0u);
+          }
+          uint32_t tot;
+          uint32_t o = carry + w.scan_excl(c, tot);
+          if (p < hi)
+            for (int a = L.head[v]; a < (int)L.head[v + 1]; ++a) {
+              const int x = L.adjS[a];
+              if (x != f) bfs[o++] = (uint16_t)x, frm[x] = (uint16_t)v;
+            }
+          carry += tot;
         }
         w.sync();
-        lo = (int)w.bcast((uint32_t)lo);
-        hi = (int)w.bcast((uint32_t)hi);
-        continue;
+        lo = hi;
+        hi = (int)carry;
       }
-      uint32_t carry = (uint32_t)hi;
-      for (int base = lo; base < hi; base += w.size) {
-        const int p = base + w.tid;
-        int v = 0, f = 0;
-        uint32_t c = 0;
-        if (p < hi) {
-          v = bfs[p];
-          f = frm[v];
-          c = (uint32_t)L.deg[v] - (f != kNone16 ? 1u : 0u);
-        }
-        uint32_t tot;
-        uint32_t o = carry + w.scan_excl(c, tot);
-        if (p < hi)
-          for (int a = L.head[v]; a < (int)L.head[v + 1]; ++a) {
-            const int x = L.adjS[a];
-            if (x != f) bfs[o++] = (uint16_t)x, frm[x] = (uint16_t)v;
-          }
-        carry += tot;
-      }
-      w.sync();
-      lo = hi;
-      hi = (int)carry;
     }
+    g.sync();
+    FC_STAMP(4);
+    for (int p = g.tid; p < n; p += g.size) rank[bfs[p]] = (uint16_t)p;
+    g.sync();
   }
-  g.sync();
-  FC_STAMP(4);
-  for (int p = g.tid; p < n; p += g.size) rank[bfs[p]] = (uint16_t)p;
-  g.sync();
   // the set the search fills ...
   auto hash = [&](int k) { return (int64_t)L.X[k]; };
   pyset_build(g, n, rank, n, hash, L.table, pos);

@@ -15,4 +15,4 @@ for rep in range(3):
     mask = np.zeros(N, dtype=np.uint8)
     L.call("fc_tfd_ladder_from_first_match", L.pi(fm), N, L.pb(mask))
     assert lib.fc_debug_tfd_stamps(out, 1) == 0
-    print([int(v) for v in out][:8])
+    print([int(v) for v in out][:12])
