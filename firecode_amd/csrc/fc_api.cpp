@@ -83,6 +83,7 @@ int launch_torsion_scan(const double *, int64_t, const int64_t *, int64_t, const
                         const int64_t *, int64_t, double, int64_t, double *, int64_t *, const int64_t *, int64_t, double *);
 int launch_angle_grid(const int64_t *, const int64_t *, const int64_t *, int64_t, int64_t, int64_t *);
 int launch_select_rotated(const int64_t *, int64_t, int64_t *, int64_t *, DevBuf &);
+int launch_rows_to_sets(const int64_t *, const int64_t *, int64_t, int64_t *);
 int launch_torsion_fingerprint(const double *, int64_t, int64_t, const int64_t *, int64_t, double *);
 int launch_tfd_first_match(const double *, int64_t, int64_t, int64_t, double, int64_t *, float *);
 int launch_transpose_pad(const double *, int64_t, int64_t, int64_t, double *);
@@ -2315,18 +2316,38 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   std::vector<uint8_t> mask((size_t)N);
   FC_TRY(tfd_ladder_from_device(dfm.as<int64_t>(), N, mask.data()));
   lap("ladder");
+  // keep flags: row r >= 1 of the TFD problem is the (r - 1)-th angle-set that rotated a bond, and the device still holds
+  // that list (didx).  The survivors are few (thousands of 1.7 M): their rows go up, their angle-sets come down -- a
+  // walk over all S counts on the host cost 0.7 ms
   std::memset(tfd_keep_out, 0, (size_t)S + 1);
   tfd_keep_out[0] = mask[0];
-  int64_t k = 0;  // row k + 1 of the TFD problem = the k-th angle-set that rotated a bond
-  for (int64_t sidx = 0; sidx < S; ++sidx)
-    if (rotated_bonds_out[sidx] != 0) {
-      if (k >= M) {  // (mask has M + 1 entries: never index past it, report below)
-        ++k;
-        break;
-      }
-      tfd_keep_out[1 + sidx] = mask[(size_t)++k];
+  std::vector<int64_t> rows;
+  {
+    const uint8_t *mb = mask.data();
+    int64_t r = 1;
+    for (; r + 8 <= N; r += 8) {
+      uint64_t w;
+      std::memcpy(&w, mb + r, 8);
+      if (!w) continue;
+      for (int b = 0; b < 8; ++b)
+        if (mb[r + b]) rows.push_back(r + b);
     }
-  if (k != M) return set_error(FC_E_HIP, "internal: device selection (%lld rows) and scan counts (%lld) disagree", (long long)M, (long long)k);
+    for (; r < N; ++r)
+      if (mb[r]) rows.push_back(r);
+  }
+  if (!rows.empty()) {
+    DevBuf drows, dsets;
+    FC_TRY(upload(drows, rows.data(), rows.size()));
+    FC_TRY(dsets.reserve(rows.size() * sizeof(int64_t)));
+    FC_TRY(launch_rows_to_sets(didx.as<int64_t>(), drows.as<int64_t>(), (int64_t)rows.size(), dsets.as<int64_t>()));
+    std::vector<int64_t> sets(rows.size());
+    FC_TRY(d2h(sets.data(), dsets.p, rows.size() * sizeof(int64_t)));
+    FC_TRY(sync());
+    for (const int64_t sidx : sets) {
+      if (sidx < 0 || sidx >= S) return set_error(FC_E_HIP, "internal: device selection returned angle-set %lld of %lld", (long long)sidx, (long long)S);
+      tfd_keep_out[1 + sidx] = 1;
+    }
+  }
   lap("keep mask assembled");
   return FC_OK;
 }

@@ -538,14 +538,17 @@ static const double kLadderK[] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000
 constexpr int kLadderLevels = (int)(sizeof(kLadderK) / sizeof(kLadderK[0]));
 
 int tfd_apply_levels_host(const int64_t *fm, int64_t N, const std::vector<const uint8_t *> &level_flags, int first_level,
-                          const uint8_t *first_last_flags, uint8_t *mask_out) {
+                          const uint8_t *first_last_flags, uint8_t *mask_out, int64_t active_known) {
   const bool debug = getenv("FC_DEBUG") != nullptr;
   ChunkScratch scratch;
   std::vector<int64_t> last;
   int64_t num_active = N;  // kept up to date as flags go 1 -> 0
   if (first_level == -2) {
-    num_active = 0;
-    for (int64_t i = 0; i < N; ++i) num_active += mask_out[i];
+    num_active = active_known;  // (the device counted while it applied the levels)
+    if (num_active < 0) {
+      num_active = 0;
+      for (int64_t i = 0; i < N; ++i) num_active += mask_out[i];
+    }
   } else {
     std::memset(mask_out, 1, (size_t)N);
   }
@@ -710,7 +713,7 @@ static int tfd_ladder_impl(const int64_t *fm, int64_t N, uint8_t *mask_out) {
     for (int64_t r : first_last) first_last_flags[(size_t)(r - lo)] = 1;
     flf = first_last_flags.data();
   }
-  FC_TRY(tfd_apply_levels_host(fm, N, level_flags, first_level, flf, mask_out));
+  FC_TRY(tfd_apply_levels_host(fm, N, level_flags, first_level, flf, mask_out, -1));
   if (debug)
     fprintf(stderr, "[fc] tfd ladder (host) total %.1f ms\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
@@ -943,7 +946,7 @@ int tfd_ladder_emulate_device(const int64_t *fm, int64_t N, uint8_t *mask_out) {
     if (es[q].lo == 0) lf[(size_t)es[q].li] = eflags[q].data();
     else first_last = eflags[q].data();
   }
-  return tfd_apply_levels_host(fm, N, lf, first_li, first_last, mask_out);
+  return tfd_apply_levels_host(fm, N, lf, first_li, first_last, mask_out, -1);
 }
 
 }  // namespace fc

@@ -37,7 +37,7 @@ namespace fc {
 using namespace tfd;
 
 int tfd_apply_levels_host(const int64_t *fm, int64_t N, const std::vector<const uint8_t *> &level_flags, int first_level,
-                          const uint8_t *first_last_flags, uint8_t *mask_out);                      // fc_tfd_host.cpp
+                          const uint8_t *first_last_flags, uint8_t *mask_out, int64_t active_known);  // fc_tfd_host.cpp
 uint32_t host_component_first_big(const uint32_t *mx, const uint32_t *mp, const uint32_t *ms, int64_t n, uint32_t n_graph);
 int tfd_ladder_host_only(const int64_t *fm, int64_t N, uint8_t *mask_out);
 
@@ -1055,14 +1055,14 @@ int tfd_ladder_device(const int64_t *fm_dev, const int64_t *fm_host, int64_t N, 
       if (T.lo[q] == 0) lf[(size_t)T.li[q]] = hflags.data() + T.ibase[q];
       else first_last = hflags.data() + T.ibase[q];
     }
-    return tfd_apply_levels_host(fmh(), N, lf, P.first_li, first_last, mask_out);
+    return tfd_apply_levels_host(fmh(), N, lf, P.first_li, first_last, mask_out, -1);
   }
   // the last level (k = 1): its only chunk is [0, active), the host's
   const int64_t act = hs.active_final;
   if (act >= 2) {
     FC_TRY(need_fm_host(act));
     std::vector<const uint8_t *> none;
-    FC_TRY(tfd_apply_levels_host(fmh(), N, none, -2, nullptr, mask_out));  // (-2: only the level k = 1, on the mask as it stands)
+    FC_TRY(tfd_apply_levels_host(fmh(), N, none, -2, nullptr, mask_out, act));  // (-2: only the level k = 1, on the mask as it stands)
   }
   if (debug) fprintf(stderr, "[fc] tfd ladder (device) total %.2f ms\n", ms_since());
   return FC_OK;

@@ -702,6 +702,18 @@ int launch_angle_grid(const int64_t *values_dev, const int64_t *first_dev, const
 struct RotNonZero {
   __device__ __forceinline__ bool operator()(const int64_t &v) const { return v != 0; }
 };
+// out[q] = idx[rows[q] - 1]: the angle-set behind row rows[q] >= 1 of the TFD problem (row 0 is the starting structure)
+__global__ void __launch_bounds__(256)
+k_rows_to_sets(const int64_t *__restrict__ idx, const int64_t *__restrict__ rows, int64_t n, int64_t *__restrict__ out) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q < n) out[q] = idx[rows[q] - 1];
+}
+int launch_rows_to_sets(const int64_t *idx_dev, const int64_t *rows_dev, int64_t n, int64_t *out_dev) {
+  if (n <= 0) return FC_OK;
+  hipLaunchKernelGGL(k_rows_to_sets, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, cur_stream(), idx_dev, rows_dev, n, out_dev);
+  return check_launch("k_rows_to_sets");
+}
+
 int launch_select_rotated(const int64_t *rot_dev, int64_t S, int64_t *idx_dev, int64_t *count_dev, DevBuf &tmp) {
   if (S >= (1ll << 31)) return set_error(FC_E_LIMIT, "too many angle-sets for the device selection");
   hipcub::CountingInputIterator<int64_t> ids(0);
