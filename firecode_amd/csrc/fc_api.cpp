@@ -14,6 +14,16 @@
 #include "fc_kabsch_math.h"
 
 namespace fc {
+struct LadderKs {
+  int n;
+  int64_t k[24];
+};
+__global__ void k_store_ladder_ks(LadderKs a, int64_t *__restrict__ out) {
+  if ((int)threadIdx.x < a.n) out[threadIdx.x] = a.k[threadIdx.x];
+}
+}  // namespace fc
+
+namespace fc {
 
 // ---- launchers implemented in the .hip translation units --------------------
 int launch_prep(const double *, int64_t, int64_t, const int32_t *, int64_t, int, fc_ensemble *, const int32_t *);
@@ -657,9 +667,15 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
     if (e->ladder_k_n != n_lv || e->ladder_k_mpg != min_per_group) {
       // the source of the (asynchronous) copy lives with the ensemble: no host wait here -- a wait at this point sat
       // between the refine and the ladder of every drop-in call (each creates its ensemble) and cost it ~45 us
+      // (the values travel as kernel arguments: an asynchronous copy out of a pageable vector could be overtaken by the next
+      // prune's reassignment of that vector, or by the ensemble's destruction)
       e->ladder_k_host = ks;
       FC_TRY(e->ladder_k.reserve(ks.size() * sizeof(int64_t)));
-      FC_TRY(h2d(e->ladder_k.p, e->ladder_k_host.data(), ks.size() * sizeof(int64_t)));
+      LadderKs args{};
+      args.n = (int)std::min<size_t>(ks.size(), 24);
+      for (int q = 0; q < args.n; ++q) args.k[q] = ks[(size_t)q];
+      hipLaunchKernelGGL(k_store_ladder_ks, dim3(1), dim3(32), 0, ctx().stream, args, e->ladder_k.as<int64_t>());
+      FC_TRY(check_launch("k_store_ladder_ks"));
       e->ladder_k_n = n_lv;
       e->ladder_k_mpg = min_per_group;
     }
@@ -721,8 +737,10 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
 // declined (queue overflow / list too long) and the prune has to be redone synchronously
 // what a finished prune says about the length of this ensemble's candidate queue -> every workspace over its coordinates
 static void note_candidates(fc_ensemble *e, unsigned long long refined, unsigned long long similar) {
+  // (every workspace of the chain, whichever lane the prune ran on: the choice of the refine's and the ladder's form must not
+  // depend on which lane finished last)
   int guard = 0;
-  for (fc_ensemble *w = e; w != nullptr && guard < 8; w = w->twin, ++guard) {
+  for (fc_ensemble *w = e->head ? e->head : e; w != nullptr && guard < 8; w = w->twin, ++guard) {
     w->last_candidates = (int64_t)refined;
     w->last_similar = (int64_t)similar;
   }
@@ -760,6 +778,8 @@ static int ensemble_twin(fc_ensemble *ens, fc_ensemble **out) {
     if (ens->xsf_valid) t->Xsf.alias(ens->Xsf), t->sub.alias(ens->sub), t->xsf_valid = true;
     if (ens->xh_valid) t->Xh.alias(ens->Xh), t->xh_valid = true, t->xh_scale = ens->xh_scale;
     t->g_max = ens->g_max;
+    t->head = ens->head ? ens->head : ens;
+    t->last_candidates = ens->last_candidates, t->last_similar = ens->last_similar;
     FC_TRY(t->counters.reserve(kCounters * sizeof(uint64_t)));
     ens->twin = t.release();
   }

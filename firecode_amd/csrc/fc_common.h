@@ -74,7 +74,7 @@ struct Context {
   // ladder's helper threads copy side by side), handed out under stage_mu
   struct StageSet {
     void *pin[2] = {nullptr, nullptr};
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // [2], [3]: the half pieces of the pipelined ensemble upload
+    hipEvent_t ev[2] = {nullptr, nullptr};  // one per pinned piece
     bool busy = false;
   };
   static constexpr int kStageSets = 8;
@@ -372,6 +372,7 @@ struct fc_ensemble {
   // second prune workspace over the same coordinates (Xs/Xa/G are views): lets the refine and
   // ladder of one prune run beside the screen of the next one (fc_bench_prune_rmsd)
   fc_ensemble *twin = nullptr;
+  fc_ensemble *head = nullptr;  // twins: the ensemble that owns the coordinates (nullptr on that ensemble itself)
   fc_ensemble() = default;
   fc_ensemble(const fc_ensemble &) = delete;
   fc_ensemble &operator=(const fc_ensemble &) = delete;

@@ -3909,8 +3909,14 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
     return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_refine_buckets)) == hipSuccess ? (size_t)fa.sharedSizeBytes
                                                                                                         : (size_t)(16 * 1024);
   }();
-  if (lanes && buckets && e->bk_buckets > 0 && lds_bk + lds_bk_static <= kLdsLimit &&
-      e->last_candidates > (int64_t)kRefineLanesMin) {
+  static const bool debug_form = getenv("FC_DEBUG") != nullptr;
+  const bool bucket_form = lanes && buckets && e->bk_buckets > 0 && lds_bk + lds_bk_static <= kLdsLimit &&
+                           e->last_candidates > (int64_t)kRefineLanesMin;
+  if (debug_form)  // (which kernels a measurement ran: the form is chosen from the last prune seen, not from this one)
+    fprintf(stderr, "[fc] refine form: %s (last prune seen: %lld candidates, %lld similar)\n",
+            bucket_form ? "bucket sort + k_refine_buckets" : (lanes ? "k_refine_pairs / k_simbits_refine" : "k_simbits_refine"),
+            (long long)e->last_candidates, (long long)e->last_similar);
+  if (bucket_form) {
     auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
     const unsigned NT = (unsigned)(e->Npad >> kBucketColShift);
     const BucketGeom geom{NT, (NT + 7) / 8};

@@ -550,7 +550,8 @@ int fc_bench_refine(fc_ensemble *ens, double max_rmsd, double max_dev, int64_t r
  * FC_E_LIMIT: more degenerate pairs than the fix-up queue holds. */
 int fc_bench_rmsd_and_max_all(fc_ensemble *ens, int64_t reps, double *ms_kernel_mean, double *ms_total,
                               int64_t *stats);
-/* The same passes, and behind them (outside every timed interval) the elements (pair_i[p], pair_j[p]),
+/* The same passes, and behind them (inside the call's wall-clock time -- about 0.1 ms -- but outside the HIP-event kernel
+ * times it reports) the elements (pair_i[p], pair_j[p]),
  * p < P, of the two output matrices as the LAST pass left them: what bench.py's `value_check` and the
  * full-size parity tests compare with the oracle's rmsd_and_max (firecode/utils.py:494-504: `(rmsd,
  * maxdev)` per pair).  Under a communicator only rows this rank owns hold values.  (i > j reads (j, i).) */
