@@ -303,6 +303,25 @@ def timed_prunes(ens, steps, warmup, sharded, overlap=True):
     return run
 
 
+def rehearsal_scale():
+    """FC_BENCH_REHEARSAL_SCALE (0 < s <= 1, default 1): conformer counts of every family times s -- a REHEARSAL of the
+    N-rank launch on one device (FC_BENCH_SAME_DEVICE=1), stated in the line as config.rehearsal_scale; its numbers are
+    not measurements."""
+    try:
+        s = float(os.environ.get("FC_BENCH_REHEARSAL_SCALE", "1"))
+    except ValueError:
+        s = 1.0
+    return s if 0.0 < s <= 1.0 else 1.0
+
+
+def fail_here(rank, where):
+    """FC_BENCH_FAIL_RANK="k:before" | "k:after": rank k raises before / after the communicator is up (the launcher's
+    exit codes under a failing rank are a test of their own)."""
+    spec = os.environ.get("FC_BENCH_FAIL_RANK")
+    if spec and spec == f"{rank}:{where}":
+        raise RuntimeError(f"FC_BENCH_FAIL_RANK: rank {rank} fails {where} the communicator is created")
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` typed as is: start N fresh rank processes (this parent never imports the
     library or touches a GPU), relay rank 0's single JSON line, exit non-zero if any rank does."""
@@ -450,6 +469,7 @@ def main():
     rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
     rv = fdist.HostRendezvous(rank, world) if world > 1 else None
     comm_error = None
+    fail_here(rank, "before")
     if comm:
         fc.init(local_rank)  # a missing device is not a communicator problem: it ends the launch here, with its own message
         try:
@@ -473,6 +493,7 @@ def main():
                 sys.stderr.write(f"bench.py: rank {rank}: no RCCL communicator ({comm_error}); ranks coordinated through files\n")
     else:
         fc.init(0)
+    fail_here(rank, "after")
 
     def barrier():
         # several ranks: through the files, whether or not there is a communicator -- the timed regions bracket device work
@@ -495,6 +516,9 @@ def main():
             if emitted[0] or rank != 0:
                 return
             emitted[0] = True
+            if rehearsal_scale() != 1.0 and isinstance(line_dict.get("config"), dict):
+                line_dict["config"]["rehearsal_scale"] = rehearsal_scale()
+                line_dict["config"]["rehearsal_note"] = "conformer counts scaled down for a launch rehearsal: NOT a measurement"
             if world > 1:
                 line_dict["rank_coordination"] = ("barrier / max over ranks through files (firecode_amd.dist.HostRendezvous); RCCL communicator " +
                                                   ("up: used by the exchanging blocks" if comm else "NOT created: " + str(comm_error)))
@@ -582,7 +606,7 @@ def run_alignments(ctx):
     args, fc, _lib, syn = ctx["args"], ctx["fc"], ctx["_lib"], ctx["syn"]
     rank, world, barrier, max_over_ranks = ctx["rank"], ctx["world"], ctx["barrier"], ctx["max_over_ranks"]
     n_atoms, seed = 50, 2
-    n_conf = int(round(10000 * np.sqrt(world)))
+    n_conf = int(round(10000 * np.sqrt(world) * rehearsal_scale()))
     steps = 50 if args.steps is None else args.steps
     warmup = 5 if args.warmup is None else args.warmup
     what = (f"{n_conf}-conformer x {n_atoms}-atom ensemble, complete Kabsch alignment (rmsd + max deviation, fp64) of all pairs "
@@ -667,7 +691,7 @@ def run_alignments(ctx):
     if world > 1:
         # the family's n_gpus = 1 member (same pairs per GPU), on rank 0 alone, outside the timed region
         if rank == 0:
-            c1, _, _ = syn.synthetic_ensemble(10000, n_atoms, seed=seed)
+            c1, _, _ = syn.synthetic_ensemble(int(round(10000 * rehearsal_scale())), n_atoms, seed=seed)
             _lib.call("fc_debug_comm_loopback", 0, 1)  # rank 0 computes every row, as a single GPU does
             try:
                 with fc.DeviceEnsemble(c1, center=True) as e1:
@@ -679,7 +703,7 @@ def run_alignments(ctx):
                 else:
                     _lib.call("fc_debug_comm_loopback", rank, world)  # (no communicator: back to this rank's logical share)
             v1 = int(s1[0]) * min(steps, 20) / (t1 * 1e-3)
-            out["scaling_family_n1"] = {"n_conformers": 10000, "pairs_per_step": int(s1[0]), "kernel_ms": k1,
+            out["scaling_family_n1"] = {"n_conformers": int(round(10000 * rehearsal_scale())), "pairs_per_step": int(s1[0]), "kernel_ms": k1,
                                         "ms_per_step": t1 / min(steps, 20), "value": v1,
                                         "note": "the N = 1 member of the family (BASELINE configs[1] itself), measured on rank 0 in "
                                                 "this run while the other ranks wait (device time, first launch to last)"}
@@ -782,7 +806,7 @@ def run_prune_line(ctx, workload, as_block=False):
     args, fc, _lib, syn = ctx["args"], ctx["fc"], ctx["_lib"], ctx["syn"]
     rank, world, barrier = ctx["rank"], ctx["world"], ctx["barrier"]
     n_atoms, seed = 80, 6
-    n_conf = int(round(100000 * np.sqrt(world / 8.0)))
+    n_conf = int(round(100000 * np.sqrt(world / 8.0) * rehearsal_scale()))
     steps = 20 if (args.steps is None or as_block) else args.steps
     warmup = 3 if (args.warmup is None or as_block) else args.warmup
     what = (f"{n_conf}-conformer x {n_atoms}-atom ensemble sharded over {world} GPU(s), all-pairs Kabsch RMSD + "
@@ -796,7 +820,7 @@ def run_prune_line(ctx, workload, as_block=False):
     if world > 1:
         if rank == 0:
             # the family's n_gpus = 1 member (same pairs per GPU), on rank 0 alone
-            n1 = int(round(100000 * np.sqrt(1 / 8.0)))
+            n1 = int(round(100000 * np.sqrt(1 / 8.0) * rehearsal_scale()))
             c1, _, a1 = syn.synthetic_ensemble(n1, n_atoms, seed=seed)
             with fc.DeviceEnsemble(c1, center=True) as e1:
                 e1.bench_prune(MAX_RMSD, 2 * MAX_RMSD, reps=2, want_mask=False)

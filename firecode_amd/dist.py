@@ -183,12 +183,25 @@ def comm_init_from_env(timeout_s=None):
             if time.monotonic() - t0 > timeout_s:
                 raise TimeoutError(f"rank {rank}: no RCCL unique id in {path} after {timeout_s:.0f} s")
             time.sleep(0.02)
-    _lib.comm_init(rank, world, uid)  # collective: returns once every rank has joined
+        # "rank `rank` has the id": rank 0 removes the id file only when every rank has said so
+        with open(f"{path}.ack.{rank}", "wb") as fh:
+            fh.write(b"1")
+    _lib.comm_init(rank, world, uid)  # collective with RCCL: returns once every rank has joined
     if world > 1 and rank == 0 and not hex_id:
-        try:
-            os.remove(_id_file())
-        except OSError:
-            pass
+        # ncclCommInitRank is collective, so every rank has read the id by now -- but that is the collective library's
+        # property, not this file's: the removal waits for the ranks' own acknowledgements (a stand-in collective whose
+        # init returned at once lost the id file under a slow rank, one run in twenty)
+        path, t0 = _id_file(), time.monotonic()
+        acks = [f"{path}.ack.{r}" for r in range(1, world)]
+        while not all(os.path.exists(a) for a in acks):
+            if time.monotonic() - t0 > timeout_s:
+                raise TimeoutError(f"rank 0: not every rank acknowledged the RCCL unique id in {path} after {timeout_s:.0f} s")
+            time.sleep(0.005)
+        for f in [path] + acks:
+            try:
+                os.remove(f)
+            except OSError:
+                pass
     return rank, world, local_rank
 
 

@@ -176,3 +176,29 @@ def test_bench_two_ranks_with_a_working_communicator(stub_lib):
     for blk in (line["prune_path"], line["cfg4_family"]):
         assert blk["survivor_count_ok"] and blk["survivors_are_last_cluster_members"], blk
         assert "all-gather" in blk["sharding"]
+
+
+def test_bench_four_ranks_rehearsal_and_failing_ranks(stub_lib):
+    """The launch the driver makes on an 8-GPU node, rehearsed as far as a one-GPU box allows (at most six processes may
+    use its card): `python bench.py --gpus 4` as typed, every rank on device 0, stand-in collective, conformer counts of
+    every family scaled by 0.3 (FC_BENCH_REHEARSAL_SCALE: stated in the line).  Four ranks seen, efficiency present, the
+    exchanging blocks checked against their known answers.  Then a rank that raises BEFORE and one that raises AFTER the
+    communicator is up: the launcher exits non-zero either way and ends the other ranks."""
+    import json
+
+    env = dict(os.environ, FC_BENCH_SAME_DEVICE="1", FC_RCCL_LIB=stub_lib, FC_BENCH_EXTRAS_TIMEOUT_S="600",
+               FC_BENCH_SETTLE_S="0.01", FC_BENCH_REHEARSAL_SCALE="0.3")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 4 and line["ranks_seen"] == 4 and "efficiency" in line
+    assert line["config"]["rehearsal_scale"] == 0.3
+    assert line["value_check"]["ok"] and line["value_check"]["all_ranks_ok"]
+    assert "RCCL communicator up" in line["rank_coordination"] and "extras_error" not in line
+    for blk in (line["prune_path"], line["cfg4_family"]):
+        assert blk["survivor_count_ok"], blk
+    for spec in ("2:before", "1:after"):
+        r = subprocess.run(cmd, env=dict(env, FC_BENCH_FAIL_RANK=spec, FC_COMM_TIMEOUT_S="20"), capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0, spec
+        assert "FC_BENCH_FAIL_RANK" in r.stderr, r.stderr[-2000:]
