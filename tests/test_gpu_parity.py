@@ -1198,11 +1198,14 @@ def test_sharded_scan_and_pose_grid_logical_ranks(fc):
 
 
 # ---------------------------------------------------------------- screen-kernel variants / odd shapes
-@pytest.mark.parametrize("n,a", [(2, 1), (3, 2), (70, 3), (130, 5), (200, 80), (150, 104), (140, 110), (90, 130), (150, 160), (130, 192), (100, 193)])
+@pytest.mark.parametrize("n,a", [(2, 1), (3, 2), (70, 3), (130, 5), (200, 80), (150, 104), (140, 110), (90, 130), (150, 160), (130, 192), (100, 193),
+                                 (110, 200), (100, 260), (90, 320)])
 def test_prune_odd_shapes_and_all_screen_variants(fc, n, a):
     """Every size class of the screens behind prune_by_rmsd: the split-half kernel with 1 ... 6 k-steps of 32 atoms (up to
     192 atoms; 4 and more: one workgroup per CU), the fp32 matrix pipe beyond (193), the fp64 kernels behind them
-    (mfma<4> up to 52 atoms, mfma<8> up to 104, the vector screen without an LDS tile above); tiny atom counts (K padded
+    (mfma<4> up to 52 atoms, mfma<8> up to 104, the vector screen without an LDS tile above: 200 atoms still have the
+    fp32 matrix pipe in front, 260 and 320 -- the poses of two or three docked molecules, firecode/embedder.py:1472-1474 --
+    go to the fp64 vector screen: the size class tools/shape_sweep.py reaches at 260 atoms); tiny atom counts (K padded
     to 4) and tiny N"""
     X, atoms, asg = syn.synthetic_ensemble(n, a, seed=90 + a, cluster_size=3)
     S0, R0, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
@@ -1431,6 +1434,22 @@ def test_rmsd_and_max_all_pairs_tiled_kernel(fc):
     assert np.all(np.abs(D[iu, ju] - d0) <= TOL + bound)
     assert (bound < TOL).mean() > 0.95
     assert R[4, 5] < 1e-12 and R[8, 9] < 1e-7
+
+
+@pytest.mark.parametrize("n,a", [(140, 104), (130, 105), (120, 160), (100, 260), (90, 320)])
+def test_rmsd_and_max_all_pairs_above_the_tiled_kernel(fc, n, a):
+    """the complete alignments of all pairs on both sides of the tiled kernel's last atom count (104: the 64-column
+    tile plus the kernel's own arrays fill the LDS) and at the sizes of docked poses -- k_matrix_exact takes over, same
+    1e-10 against the oracle"""
+    X, atoms, _ = syn.synthetic_ensemble(n, a, seed=500 + a, cluster_size=3)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        R, D, _ = ens.rmsd_and_max_all()
+    iu, ju = np.triu_indices(n, 1)
+    r0, d0 = o.rmsd_and_max_batch(X[iu], X[ju], center=True)
+    bound = o.rotation_error_bound_batch(X[iu], X[ju], center=True)
+    assert np.abs(R[iu, ju] - r0).max() < TOL
+    assert np.all(np.abs(D[iu, ju] - d0) <= TOL + bound) and (bound < TOL).mean() > 0.95
+    assert np.allclose(R, R.T) and np.all(np.diag(R) == 0)
 
 
 def test_context_lifecycle_and_threads(fc):
