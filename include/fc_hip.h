@@ -42,6 +42,19 @@ extern "C" {
 #define FC_E_HIP (-3)       /* HIP runtime error (message has the hipError)   */
 #define FC_E_NOMEM (-4)     /* device allocation failed                       */
 #define FC_E_LIMIT (-5)     /* size outside what a kernel supports            */
+/* FC_E_LIMIT as CONTRACT -- where the reference has no size regime and this library refuses (everything else is served at
+ * any size, more slowly beyond the tiled kernels: complete alignments above 104 atoms and prune screens above 192 atoms
+ * leave the matrix pipes, tests/test_gpu_parity.py checks them at 105 ... 320 atoms):
+ *   - per-structure clash / rotation / fitness kernels, torsion scan, embed pose grids (fc_clash_*, fc_rototranslate,
+ *     fc_fitness, fc_torsion_scan*, fc_embed_*): one structure (or pose table) lives in a workgroup's 160 KB of LDS --
+ *     A <= 1706 atoms per structure (4 x A x 24 B), for the pose grids the per-group bytes the message states;
+ *   - TFD (fc_tfd_simbits, fc_tfd_first_match, fc_torsion_scan_tfd*): Q <= 128 fingerprint entries -- np.sum switches to
+ *     pairwise summation above 128 addends (firecode/torsion_module.py:1064) and the kernels reproduce the plain order;
+ *   - cyclical embed: at most 85 distinct step angles per molecule and 2^31 poses per call (split the jobs);
+ *   - A <= 32767 atoms per conformer, bit matrices below 2^32 words, and the queue capacities stated with the entry
+ *     points that have one (they name the entry point to use instead).
+ * The TFD ladder has no size limit of its own: what exceeds a device capacity (components above 4096 nodes, last chunks
+ * that hold edges) is finished on the host from the device's flags (fc_tfd_ladder_from_first_match). */
 
 /* ---- lifecycle --------------------------------------------------------- */
 int fc_abi_version(void);
