@@ -932,7 +932,7 @@ def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_at
         legs["index_ms"].append(1e3 * (t4 - t3))
     out["host_in_mask_out_breakdown"] = {
         "what": "create = 12 MB through the library's pinned pieces (memmove 0.24 ms + DMA 0.22 ms at 54 GB/s, overlapped piece by "
-                "piece: tools/pin_probe.py) + the preparation kernel + one host wait; prune = one synchronous prune of the resident "
+                "piece: tools/attic/pin_probe.py) + the preparation kernel + one host wait; prune = one synchronous prune of the resident "
                 "ensemble (operand conversion, screen, refine, ladder, mask copy, host wait: nothing overlaps in a single call); "
                 "index = structures[mask] on the host.  min / median over 7 calls: the spread between runs and boxes is in the first leg "
                 "(host memory bandwidth, PCIe), not in the kernels",

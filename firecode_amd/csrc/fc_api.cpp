@@ -376,7 +376,7 @@ struct StageLease {  // one set of pinned pieces for the duration of one staged 
 
 bool staged_uploads() {
   static const bool on = [] {
-    // measured (cfg3 search, ten runs per process, tools/rescan_probe.py): with uploads on the runtime's own path one run
+    // measured (cfg3 search, ten runs per process, tools/attic/rescan_probe.py): with uploads on the runtime's own path one run
     // in three still lost 9-22 ms in the kernel behind the free of an uploaded array; with the pinned detour none did.
     // Price: memcpy + DMA instead of DMA from the caller's pages, +0.12 ms per 12 MB (FC_STAGED_UPLOADS=0: direct)
     const char *v = getenv("FC_STAGED_UPLOADS");
@@ -521,7 +521,7 @@ static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, c
 // Host arrays in (the drop-in call prune_by_rmsd(structures, ...)): the coordinates go through the pinned pieces like every
 // large upload from pageable memory (h2d_staged; fc_common.h says why the caller's pages are not handed to the runtime,
 // nor registered by the library for the duration of the copy).
-// What that costs and what was tried against it (round 4; tools/pin_probe.py, tools/hostin_breakdown.py; 12 MB):
+// What that costs and what was tried against it (round 4; tools/attic/pin_probe.py, tools/hostin_breakdown.py; 12 MB):
 // DMA from pinned memory 0.22 ms (54 GB/s), from the caller's pageable pages THE SAME 0.22 ms (the driver maps them; that
 // mapping is what later stalls the queues when the caller frees the array), memmove into pinned memory 0.24 ms on one
 // core -- piece by piece (3 x 4 MB, copy of piece k + 1 beside the DMA of piece k) 0.44 ms per ensemble with the
@@ -2684,7 +2684,7 @@ static int prune_pipeline(fc_ensemble *const *work, int64_t n, double max_rmsd, 
     if (timed) FC_HIP_TRY(hipEventRecord(ev[4 * r], scr));
     c.mark_after_screen = timed ? ev[4 * r + 1] : nullptr;  // the launcher records it right behind the screen kernel
     // with lanes the launcher itself moves to the tail stream behind its main kernel: verdict and gated fp64 screen
-    // run there (27 us between two screens on the screen stream otherwise: tools/step_gaps.py)
+    // run there (27 us between two screens on the screen stream otherwise: tools/attic/step_gaps.py)
     c.after_main_stream = lanes ? tail : nullptr;
     c.after_main_event = lanes ? dep[2 * r + 1] : nullptr;
     c.optimistic_screen = lanes;

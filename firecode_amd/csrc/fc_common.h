@@ -236,7 +236,7 @@ inline ArenaScope::~ArenaScope() {
 // pieces of the library's own (h2d_staged / d2h_staged: blocking): the runtime's path for such copies registers the
 // caller's pages with the driver, and when the caller later FREES that memory (a NumPy array, a std::vector: an munmap)
 // the process's queues stand still for 10-25 ms at a moment that has nothing to do with the copy (measured: every other
-// cfg3 search lost 22 ms in the kernel of the re-scan behind it; tools/rescan_probe.py).  Downloads showed it first, uploads
+// cfg3 search lost 22 ms in the kernel of the re-scan behind it; tools/attic/rescan_probe.py).  Downloads showed it first, uploads
 // less often (one run in three); FC_STAGED_UPLOADS=0 puts uploads back on the runtime's path (0.12 ms per 12 MB faster).
 // Pinned host memory (the pipelines' result slots) and small copies stay asynchronous.
 constexpr size_t kStagedCopyMin = (size_t)64 << 10;
@@ -269,8 +269,8 @@ inline int d2h(void *dst, const void *src, size_t n) {
 // 12 MB arrive in 0.29 ms instead of 0.37 and prune_by_rmsd(host arrays) takes 0.68-0.71 instead of 0.79 ms -- but memory
 // that has EVER been registered keeps the property that made the library copy in the first place: when the caller frees
 // it with an munmap, the next kernels wait 10-25 ms.  The cfg3 search, whose survivors' coordinates (4.6 MB) are a fresh
-// array per search, lost 12-25 ms in the re-scan of three searches out of ten; tools/hostin_fresh_probe.py does not show
-// it only because glibc stops returning a repeatedly allocated 12 MB block to the system.  tools/pin_probe_fresh.py.)
+// array per search, lost 12-25 ms in the re-scan of three searches out of ten; tools/attic/hostin_fresh_probe.py does not show
+// it only because glibc stops returning a repeatedly allocated 12 MB block to the system.  tools/attic/pin_probe_fresh.py.)
 inline int sync() {
   FC_HIP_TRY(hipStreamSynchronize(cur_stream()));
   return FC_OK;

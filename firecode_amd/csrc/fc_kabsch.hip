@@ -661,7 +661,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 #endif
   // One (row block, column tile) item per workgroup.  A persistent variant (grid = what the
   // chip holds, items drawn from a device counter) was built and measured with
-  // tools/timeline_probe.py: it removes the ~6 us dispatch gap between two 74 us workgroups
+  // tools/attic/timeline_probe.py: it removes the ~6 us dispatch gap between two 74 us workgroups
   // on a slot, but the 512 workgroups then run in lock-step -- all column tiles are fetched
   // in the same 12 us bursts (3.3 TB/s) instead of spread out -- and the loop-carried state
   // costs registers: 1.03 ms against 0.96 ms.  Not kept.
@@ -705,7 +705,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
     // (wave-uniform base) + 16 l, so each instruction fills one 1-KiB run of the swizzled
     // image -- run q = (sgrp*3 + c)*2 + (k>>1) holds [cs][k&1][16 columns] -- and the swizzle
     // is applied to the per-lane SOURCE address.  (Register staging took 4 dependent L2 round
-    // trips, 9.7 us of a 74 us workgroup: tools/timeline_probe.py.)
+    // trips, 9.7 us of a 74 us workgroup: tools/attic/timeline_probe.py.)
     const int n_runs = KS * 6;
     const int cs_l = lane >> 4, k1_l = (lane >> 3) & 1, c15_l = (lane & 7) * 2;
     for (int q = wv; q < n_runs; q += NW) {
@@ -1908,7 +1908,7 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
 
 // (Not kept: the same screen as RESIDENT workgroups -- grid = 3 per CU walking the item table with a stride, every
 // item taken as two 32-column halves so that the next half arrives by LDS-DMA in a second 24 KB buffer while this
-// one is computed: no wait for the column tile (16 % of a workgroup's 17 us, tools/h2_timeline_probe.py), no 1.4 us
+// one is computed: no wait for the column tile (16 % of a workgroup's 17 us, tools/attic/h2_timeline_probe.py), no 1.4 us
 // between two workgroups on a CU slot.  Same results; 0.25 ms per launch against 0.177 ms (0.22 ms with 2 or 4
 // workgroups per CU): statically dealt items leave the slower CUs behind, the four waves meet at a barrier per
 // half, and the loop-carried state costs 68 spilled SGPRs and 40 B of scratch.  The hardware's own dispatch of

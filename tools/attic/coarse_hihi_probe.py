@@ -1,4 +1,4 @@
-"""tools/coarse_hihi_probe.py -- would a hi x hi^T-only first pass of the split-half screen (18 instead of 54
+"""tools/attic/coarse_hihi_probe.py -- would a hi x hi^T-only first pass of the split-half screen (18 instead of 54
 MFMAs per 16 x 16 sub-tile, bounds widened by the 2^-10 s mass of the cross terms it leaves out) rule out whole
 sub-tiles of the bench ensembles?  CPU estimate in float64: the polynomial values P0 / s^4 and u / s^2 of sampled
 sub-tiles against the widened bounds of kabsch_f32_bounds with db = 2^-10 (1 + 2^-10) + the tight part."""

@@ -1,4 +1,4 @@
-"""tools/hostin_fresh_probe.py -- prune_by_rmsd on a NEW copy of the configs[1] ensemble every call, the copy dropped right
+"""tools/attic/hostin_fresh_probe.py -- prune_by_rmsd on a NEW copy of the configs[1] ensemble every call, the copy dropped right
 after the call, and a resident prune of a small ensemble behind each drop: does freeing an uploaded array stall the
 queues (round 3 saw 10-25 ms with the runtime's own upload path in the cfg3 search)?  min / median / max over 40 calls.
 (It does not show here: glibc stops returning a repeatedly allocated 12 MB block to the system, so the drop is no munmap.

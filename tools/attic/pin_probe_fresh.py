@@ -1,4 +1,4 @@
-"""tools/pin_probe_fresh.py -- the three ways to get a caller's pageable array to the device when the array is a NEW
+"""tools/attic/pin_probe_fresh.py -- the three ways to get a caller's pageable array to the device when the array is a NEW
 allocation every time and is FREED right after the call (what prune_by_rmsd sees from a caller that builds its ensemble,
 prunes it and drops it): (A) the runtime's own path (it pins the caller's pages and keeps them in a cache until the
 memory goes away), (B) hipHostRegister + DMA + hipHostUnregister, (C) memmove into the library's pinned pieces + DMA.

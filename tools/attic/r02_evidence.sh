@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 evidence: bench lines, rocprofv3 kernel stats and PMC passes.  Run on the GPU box from the repo root:
-#   bash tools/r02_evidence.sh      (writes gpurun_out/r02ev/; the summaries to keep are copied into profiles/ by hand)
+#   bash tools/attic/r02_evidence.sh      (writes gpurun_out/r02ev/; the summaries to keep are copied into profiles/ by hand)
 set -u
 O=gpurun_out/r02ev
 mkdir -p $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 evidence after the split-half screen (kind 16) became the default.  Run on the GPU box from the repo root:
-#   bash tools/r02_evidence_h2.sh      (writes gpurun_out/r02h2/; the summaries to keep are copied into profiles/ by hand)
+#   bash tools/attic/r02_evidence_h2.sh      (writes gpurun_out/r02h2/; the summaries to keep are copied into profiles/ by hand)
 set -u
 O=gpurun_out/r02h2
 mkdir -p $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# copies the summaries of gpurun_out/r03/ (tools/r03_evidence.sh) into profiles/ under round-3 names
+# copies the summaries of gpurun_out/r03/ (tools/attic/r03_evidence.sh) into profiles/ under round-3 names
 set -u
 S=gpurun_out/r03; D=profiles
 cp $S/bench_n1.json $D/r03_bench_n1.json

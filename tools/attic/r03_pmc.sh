@@ -1,4 +1,4 @@
-# tools/r03_pmc.sh OUTDIR TAG SCRIPT [ARGS...] -- rocprofv3 counter passes (one --pmc set per run, never mixed
+# tools/attic/r03_pmc.sh OUTDIR TAG SCRIPT [ARGS...] -- rocprofv3 counter passes (one --pmc set per run, never mixed
 # with tracing) + one --kernel-trace --stats run of `python3 SCRIPT ARGS`, summaries into OUTDIR.
 set -u
 O=$1; TAG=$2; shift 2

@@ -1,4 +1,4 @@
-"""tools/r03_pmc_json.py SUMMARY.txt KERNEL_SUBSTRING OUT.json key=value... -- one kernel's line of a
+"""tools/attic/r03_pmc_json.py SUMMARY.txt KERNEL_SUBSTRING OUT.json key=value... -- one kernel's line of a
 tools/pmc_summary.py file as a json record with the corrected fabric-side traffic (MI355X_MICROARCH.md, HBM:
 FETCH_SIZE counts wide coalesced reads at 1/2 -> doubled; WRITE_SIZE exact; both in KiB)."""
 import ast

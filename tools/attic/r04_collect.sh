@@ -1,5 +1,5 @@
 #!/bin/bash
-# copies the summaries of gpurun_out/r04/ (tools/r04_evidence.sh) into profiles/ under round-4 names
+# copies the summaries of gpurun_out/r04/ (tools/attic/r04_evidence.sh) into profiles/ under round-4 names
 set -u
 S=gpurun_out/r04; D=profiles
 cp $S/bench_n1.json $D/r04_bench_n1.json

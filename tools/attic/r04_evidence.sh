@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-4 evidence.  Run on the GPU box from the repo root:  bash tools/r04_evidence.sh [part ...]
+# Round-4 evidence.  Run on the GPU box from the repo root:  bash tools/attic/r04_evidence.sh [part ...]
 # (parts: pmc pmc80 refine bench cfg3 tests workloads hostin ranks).  Writes gpurun_out/r04/; the summaries to keep are
-# copied into profiles/ by tools/r04_collect.sh on the authoring side.  Counter passes never share a run with tracing.
+# copied into profiles/ by tools/attic/r04_collect.sh on the authoring side.  Counter passes never share a run with tracing.
 set -u
 O=gpurun_out/r04
 mkdir -p $O
@@ -11,24 +11,24 @@ parts="${*:-pmc pmc80 refine bench cfg3 tests workloads hostin ranks}"
 for part in $parts; do case $part in
 pmc)
   say "PMC passes: complete alignment kernel, BASELINE configs[1] (tools/time_complete.py 10000 50 5)"
-  bash tools/r03_pmc.sh $O/pmc_complete r04 tools/time_complete.py 10000 50 5 > $O/pmc_complete.log 2>&1
-  python3 tools/r03_pmc_json.py $O/pmc_complete/pmc_summary.txt "k_simbits_screen_mfma<4, 2>" $O/pmc_complete.json stats=$O/pmc_complete/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="BASELINE configs[1]: 10000 x 50, fc_bench_rmsd_and_max_all"
+  bash tools/attic/r03_pmc.sh $O/pmc_complete r04 tools/time_complete.py 10000 50 5 > $O/pmc_complete.log 2>&1
+  python3 tools/attic/r03_pmc_json.py $O/pmc_complete/pmc_summary.txt "k_simbits_screen_mfma<4, 2>" $O/pmc_complete.json stats=$O/pmc_complete/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="BASELINE configs[1]: 10000 x 50, fc_bench_rmsd_and_max_all"
   ;;
 pmc80)
   say "PMC passes: complete alignment kernel at the cfg4 shape (35355 x 80: the <8, 2> variant)"
-  bash tools/r03_pmc.sh $O/pmc_complete_a80 r04a80 tools/time_complete.py 35355 80 2 > $O/pmc_complete_a80.log 2>&1
-  python3 tools/r03_pmc_json.py $O/pmc_complete_a80/pmc_summary.txt "k_simbits_screen_mfma<8, 2>" $O/pmc_complete_a80.json stats=$O/pmc_complete_a80/kernel_stats.csv n_conformers=35355 n_atoms=80 workload="cfg4 family N = 1 member: 35355 x 80, fc_bench_rmsd_and_max_all"
+  bash tools/attic/r03_pmc.sh $O/pmc_complete_a80 r04a80 tools/time_complete.py 35355 80 2 > $O/pmc_complete_a80.log 2>&1
+  python3 tools/attic/r03_pmc_json.py $O/pmc_complete_a80/pmc_summary.txt "k_simbits_screen_mfma<8, 2>" $O/pmc_complete_a80.json stats=$O/pmc_complete_a80/kernel_stats.csv n_conformers=35355 n_atoms=80 workload="cfg4 family N = 1 member: 35355 x 80, fc_bench_rmsd_and_max_all"
   python3 tools/time_complete.py 35355 80 3 > $O/complete_a80.json 2>/dev/null
   python3 tools/time_complete.py 12000 80 5 >> $O/complete_a80.json 2>/dev/null
   ;;
 refine)
   say "PMC passes + stats: the long-queue refine on the continuous-RMSD ensemble (tools/refine_alone_probe.py)"
-  bash tools/r03_pmc.sh $O/pmc_refine r04ref tools/refine_alone_probe.py > $O/pmc_refine.log 2>&1
-  python3 tools/r03_pmc_json.py $O/pmc_refine/pmc_summary.txt "k_refine_buckets" $O/pmc_refine.json stats=$O/pmc_refine/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="continuous RMSD distribution, 945025 candidate pairs per launch"
+  bash tools/attic/r03_pmc.sh $O/pmc_refine r04ref tools/refine_alone_probe.py > $O/pmc_refine.log 2>&1
+  python3 tools/attic/r03_pmc_json.py $O/pmc_refine/pmc_summary.txt "k_refine_buckets" $O/pmc_refine.json stats=$O/pmc_refine/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="continuous RMSD distribution, 945025 candidate pairs per launch"
   python3 tools/refine_alone_probe.py > $O/refine_alone.json 2>/dev/null
   FC_REFINE_BUCKETS=0 FC_LADDER_MANY=0 python3 tools/refine_alone_probe.py > $O/refine_alone_round3_forms.json 2>/dev/null
-  python3 tools/ladder_many_probe.py > $O/ladder_many.json 2>/dev/null
-  FC_LADDER_MANY=0 python3 tools/ladder_many_probe.py > $O/ladder_one_workgroup.json 2>/dev/null
+  python3 tools/attic/ladder_many_probe.py > $O/ladder_many.json 2>/dev/null
+  FC_LADDER_MANY=0 python3 tools/attic/ladder_many_probe.py > $O/ladder_one_workgroup.json 2>/dev/null
   ;;
 bench)
   say "bench default"; python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
@@ -60,7 +60,7 @@ workloads)
   ;;
 hostin)
   say "host-in leg"
-  python tools/pin_probe.py > $O/pin_probe.json 2>/dev/null
+  python tools/attic/pin_probe.py > $O/pin_probe.json 2>/dev/null
   python tools/hostin_breakdown.py > $O/hostin_breakdown.json 2>/dev/null
   FC_STAGED_UPLOADS=0 python tools/hostin_breakdown.py > $O/hostin_breakdown_direct_uploads.json 2>/dev/null
   ;;

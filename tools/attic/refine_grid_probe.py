@@ -1,4 +1,4 @@
-"""tools/refine_grid_probe.py -- k_refine_pairs alone (fc_bench_refine) on the continuous-RMSD ensemble."""
+"""tools/attic/refine_grid_probe.py -- k_refine_pairs alone (fc_bench_refine) on the continuous-RMSD ensemble."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import firecode_amd as fc

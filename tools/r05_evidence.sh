@@ -35,5 +35,10 @@ bench)
   python bench.py --steps 20 --warmup 5 > $O/bench_n1_k20.json 2> $O/bench_n1_k20.err
   tail -c 600 $O/bench_n1_k20.json
   ;;
+laps)
+  say "cfg3 search with per-phase laps on stderr (FC_DEBUG FC_SCAN_LAPS)"
+  FC_DEBUG=1 FC_SCAN_LAPS=1 FC_CSEARCH_RUNS=4 timeout -k 10 300 python tools/bench_workloads.py csearch > $O/cfg3_laps.json 2> $O/cfg3_laps.err
+  grep -E "\[fc\]" $O/cfg3_laps.err | tail -24
+  ;;
 *) echo "unknown part $1"; exit 2 ;;
 esac
