@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/fc_hip.h"
+#include "fc_tuning.h"
 
 namespace fc {
 

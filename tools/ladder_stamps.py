@@ -1,4 +1,4 @@
-"""tools/ladder_stamps.py -- tuning build only (make BUILD=build_stamps OUT=../libfc_hip_stamps.so EXTRA=-DFC_TFD_STAMPS,
+"""tools/ladder_stamps.py -- tuning build only (make BUILD=build_stamps OUT=../libfc_hip_stamps.so EXTRA="-DFC_TUNING_BUILD -DFC_TFD_STAMPS",
 FC_LIB_PATH=firecode_amd/libfc_hip_stamps.so): cycles (s_memtime, 100 MHz ticks on gfx950) per phase of comp_group_first for the
 largest component of the cfg3 ladder"""
 import sys, ctypes as C
