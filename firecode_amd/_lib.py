@@ -71,6 +71,7 @@ _SIGNATURES = {
     "fc_alignment_matrices": [_p_f64, _p_f64, _i64, _i64, _p_f64],
     "fc_rmsd_simbits": [_ens, _f64, _f64, _p_f64, _f64, _i64, _i64, _p_u64, _p_i64],
     "fc_prune_rmsd": [_ens, _f64, _f64, _p_f64, _f64, _i64, _p_u8, _p_i64],
+    "fc_prune_rmsd_host": [_p_f64, _i64, _i64, _p_u8, C.c_int, _f64, _f64, _p_f64, _f64, _i64, _p_u8, _p_i64],
     "fc_greedy_prune_from_bits": [_p_u64, _i64, _i64, _p_u8],
     "fc_prune_rmsd_begin": [_ens, _f64, _f64, _p_f64, _f64, _i64, _i64, _i64, _p_i64],
     "fc_prune_level": [_ens, _i64, _p_u8, _p_u8],

@@ -992,7 +992,8 @@ int fc_kabsch_rmsd_pairs(const double *coords, int64_t N, int64_t A, const uint8
 // difference in the epilogue (k_simbits_screen_mfma<.., 2>); structures beyond the LDS column tile
 // (A > 104) take the one-wave-per-row kernel.  Outputs may both be NULL (timing only).
 static bool rmsd_and_max_tiled(const fc_ensemble *ens) {
-  const size_t lds_m = ((size_t)((ens->A + 3) / 4) * 4 * 3 * 64 + 64 + 128) * sizeof(double) + 1024;
+  // (a 64-column tile up to 104 atoms, 32 columns up to 208, 16 up to 416: launch_rmsd_values picks)
+  const size_t lds_m = ((size_t)(((ens->A + 3) / 4 + 1) / 2) * 384 + 16 + 128) * sizeof(double) + 1024;
   return lds_m <= (size_t)160 * 1024 && (uint64_t)((ens->A + 3) / 4 * 4) * 3 * (uint64_t)ens->Npad < (1ull << 32);
 }
 
@@ -1296,6 +1297,26 @@ int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const doubl
     stats[5] = survivors;
   }
   return FC_OK;
+}
+
+// prune_by_rmsd(host arrays) as ONE call (firecode/ensemble.py:230-235, firecode/embedder.py:1472-1474): upload, preparation,
+// prune, mask -- what a caller got from fc_ensemble_create + fc_prune_rmsd + fc_ensemble_destroy, under one lock and with
+// one crossing of the language boundary
+int fc_prune_rmsd_host(const double *coords, int64_t N, int64_t A, const uint8_t *atom_mask, int center, double max_rmsd,
+                       double max_dev, const double *energies, double max_dE, int64_t min_per_group, uint8_t *mask_out,
+                       int64_t *stats) {
+  FC_API_LOCK;
+  FC_REQUIRE(N >= 0 && A >= 1, "bad shape N=%lld A=%lld", (long long)N, (long long)A);
+  FC_REQUIRE(A <= 32767, "A=%lld exceeds 32767 atoms", (long long)A);
+  FC_REQUIRE(max_rmsd > 0.0 && max_dev > 0.0, "thresholds must be positive");
+  FC_REQUIRE(min_per_group >= 1, "min_per_group must be >= 1");
+  if (N == 0) return FC_OK;
+  FC_REQUIRE(coords != nullptr && mask_out != nullptr, "NULL pointer argument");
+  FC_TRY(ensure_init());
+  fc_ensemble e;
+  e.epoch = ctx().epoch;
+  FC_TRY(ensemble_build(coords, N, A, atom_mask, center, &e));
+  return fc_prune_rmsd(&e, max_rmsd, max_dev, energies, max_dE, min_per_group, mask_out, stats);
 }
 
 int fc_greedy_prune_from_bits(const uint64_t *bits, int64_t N, int64_t min_per_group,

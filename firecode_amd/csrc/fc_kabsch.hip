@@ -629,7 +629,10 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // eigenvalue (Newton) and stores rmsd(i, j) into a dense (N, N) matrix instead of
 // screening; pairs with rmsd below `A_thr2` (reused as the small-rmsd^2 * A limit)
 // are queued for the exact explicit-difference evaluation.
-template <int NW, int MODE = 0>
+// TC: conformers of the column tile held in LDS.  64 everywhere except the complete alignments of structures whose
+// 64-column tile no longer fits the CU's LDS: 105 ... 208 atoms take 32 columns, 209 ... 416 atoms 16 (MODE 2 only)
+// instead of leaving the tiled kernel for k_matrix_exact, 5.4 x slower per pair.
+template <int NW, int MODE = 0, int TC = 64>
 __global__ void __launch_bounds__(NW * 64, 2)
 k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N,
                       int64_t Npad, int A, double A_thr2, int IB, int64_t rank, int64_t world,
@@ -643,16 +646,22 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
   // mode takes one at a time -- its epilogue (four rotations, an atom pass) needs the registers the second
   // set of 36 accumulator doubles would hold (256 VGPRs + 220 B of scratch with two: 5.17 ms per 10^4 x 10^4)
   constexpr int NT = MODE == 2 ? 1 : 2;
-  constexpr int NU = 4 / NT;
+  static_assert(TC == 64 || ((TC == 32 || TC == 16) && MODE == 2), "column tiles: 64, or 32 / 16 for the complete alignments");
+  constexpr int NU = (TC / 16) / NT;
+  constexpr int KPR = TC == 64 ? 2 : 4;      // atoms of a k-group in one 1-KiB run of the LDS image (TC = 64: the other two in the next run)
+  constexpr int SST = 2048 / TC;             // doubles from one 16-column sub-tile to the next inside a run
+  constexpr int CST = TC == 64 ? 256 : 128;  // ... from one coordinate of a k-group to the next
+  // doubles in front of k-step sl: 12 TC per k-step -- TC = 16: a run holds TWO k-steps of one coordinate ([k-step][atom][16
+  // columns]), so k-steps come in pairs of three runs
+  auto koff = [](int sl) { return TC == 16 ? (sl >> 1) * 384 + (sl & 1) * 64 : sl * (12 * TC); };
   // behind a speculative fp32 screen: run only when k_screen_verdict asked for it
   if (gate != nullptr && *gate == 0ull) return;
   extern __shared__ double lds[];
-  constexpr int TC = 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int KS = (A + 3) >> 2;
-  double *__restrict__ ldsG = lds + KS * 12 * TC;  // [TC column sums | IB row sums]
+  double *__restrict__ ldsG = lds + (TC == 16 ? ((KS + 1) >> 1) * 384 : KS * 12 * TC);  // [TC column sums | IB row sums]
   uint64_t *__restrict__ stageQ = reinterpret_cast<uint64_t *>(ldsG + TC + IB);
   uint32_t *__restrict__ stageW = reinterpret_cast<uint32_t *>(stageQ + kStagePairs);
   unsigned *__restrict__ stageN = reinterpret_cast<unsigned *>(stageW + kStageWords);  // [pairs, words]
@@ -686,7 +695,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
     if (it & (1ull << 31)) it_last = IB >> 5;
     if (it & (1ull << 63)) it_first = IB >> 5;
   } else {
-    const int64_t NT = Npad >> 6;
+    const int64_t NT = Npad / TC;
     jt = (int64_t)(b % (unsigned long long)NT);
     lb = (int64_t)(b / (unsigned long long)NT);
   }
@@ -706,13 +715,19 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
     // image -- run q = (sgrp*3 + c)*2 + (k>>1) holds [cs][k&1][16 columns] -- and the swizzle
     // is applied to the per-lane SOURCE address.  (Register staging took 4 dependent L2 round
     // trips, 9.7 us of a 74 us workgroup: tools/attic/timeline_probe.py.)
-    const int n_runs = KS * 6;
-    const int cs_l = lane >> 4, k1_l = (lane >> 3) & 1, c15_l = (lane & 7) * 2;
+    // (TC = 32: a run holds [cs (2)][k (4)][16 columns] -- all four atoms of a k-group for one coordinate, three runs per
+    // k-step; TC = 16: [k-step of a pair (2)][k (4)][16 columns], three runs per PAIR of k-steps)
+    const int n_runs = TC == 64 ? KS * 6 : (TC == 32 ? KS * 3 : ((KS + 1) >> 1) * 3);
+    const int cs_l = TC == 64 ? lane >> 4 : lane >> 5, k1_l = TC == 64 ? (lane >> 3) & 1 : (lane >> 3) & 3, c15_l = (lane & 7) * 2;
     for (int q = wv; q < n_runs; q += NW) {
-      const int sc = q >> 1, kh = q & 1;  // sc = sgrp*3 + c
+      const int sc = TC == 64 ? q >> 1 : q, kh = TC == 64 ? q & 1 : 0;  // sc = sgrp*3 + c
       const int sg = sc / 3, c = sc - sg * 3;
-      const int a = sg * 4 + kh * 2 + k1_l;
-      const double *src = Xs + (int64_t)(a * 3 + c) * Npad + j0 + cs_l * 16 + c15_l;
+      int a = sg * 4 + kh * 2 + k1_l;
+      if (TC == 16) {  // (sg counts pairs of k-steps, cs_l picks the k-step; past the last atom row: any row, never read)
+        a = (sg * 2 + cs_l) * 4 + k1_l;
+        a = a < KS * 4 ? a : KS * 4 - 1;
+      }
+      const double *src = Xs + (int64_t)(a * 3 + c) * Npad + j0 + (TC == 16 ? 0 : cs_l * 16) + c15_l;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                        (__attribute__((address_space(3))) void *)(lds + q * 128), 16, 0, 0);
     }
@@ -737,7 +752,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
   // per lane (16 consecutive addresses per load instruction instead of four pairs of 4) and its four
   // column conformers in 32 consecutive bytes of the LDS tile (see the epilogue)
   const int lcol = MODE == 2 ? 4 * (l15 & 3) + (l15 >> 2) : l15;
-  const int boff = (kq >> 1) * (2 * TC) + (kq & 1) * 16 + lcol;
+  const int boff = (kq / KPR) * 128 + (kq % KPR) * 16 + lcol;
   uint16_t *bits16 = reinterpret_cast<uint16_t *>(bits);
 
   // Row operands of the first three k-steps of the NEXT unit (same rows for the second
@@ -790,7 +805,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
       // sets -- the set consumed by k-step s is refilled with k-step s+3 right
       // after its 18 MFMAs have issued, two full k-steps ahead of its use --
       // column operands (LDS) in two sets, one k-step ahead.
-      const double *__restrict__ lb0 = lds + cs0 * 32 + boff;
+      const double *__restrict__ lb0 = lds + cs0 * SST + boff;
       double b0[NT][3], b1[NT][3];
       const int KSe = KS;
       auto fetch_a = [&](double (&a)[3], int sx) {
@@ -798,11 +813,11 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
       };
       auto fetch_b = [&](double (&b)[NT][3], int sx) {
         const int sl = sx < KS ? sx : KS - 1;
-        const double *__restrict__ lb_s = lb0 + sl * (12 * TC);
+        const double *__restrict__ lb_s = lb0 + koff(sl);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) b[t][c] = lb_s[c * (4 * TC) + t * 32];
+          for (int c = 0; c < 3; ++c) b[t][c] = lb_s[c * CST + t * SST];
       };
       auto mma = [&](const double (&a)[3], const double (&b)[NT][3]) {
 #pragma unroll
@@ -898,7 +913,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
             }
           }
           typedef double d2_t __attribute__((ext_vector_type(2)));
-          const double *__restrict__ qcol = lds + cs * 32 + 4 * kq;
+          const double *__restrict__ qcol = lds + cs * SST + 4 * kq;
           const double *__restrict__ prow_u = Xs + ib;
           const unsigned l15u = (unsigned)l15;
           // Atoms in rounds of two (ping-pong register sets), two rounds per k-group of four atoms; the zero rows that
@@ -917,11 +932,11 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
           const double *__restrict__ qg = qcol;    // the current k-group of the LDS tile
           auto load_pq = [&](auto u_, double (&P)[3], d2_t (&Qv)[3][2]) {
             constexpr int u = decltype(u_)::value;  // position of the atom in its k-group
-            const double *__restrict__ ql = qg + ((u >> 1) & 1) * (2 * TC) + (u & 1) * 16;
+            const double *__restrict__ ql = qg + (u / KPR) * 128 + (u % KPR) * 16;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              Qv[c][0] = *reinterpret_cast<const d2_t *>(ql + c * (4 * TC));
-              Qv[c][1] = *reinterpret_cast<const d2_t *>(ql + c * (4 * TC) + 2);
+              Qv[c][0] = *reinterpret_cast<const d2_t *>(ql + c * CST);
+              Qv[c][1] = *reinterpret_cast<const d2_t *>(ql + c * CST + 2);
             }
             P[0] = pa0[l15u];
             P[1] = pa1[l15u];
@@ -966,7 +981,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
             __builtin_amdgcn_sched_barrier(0);
             accumulate(PA, QA);
             __builtin_amdgcn_sched_barrier(0);
-            qg += 12 * TC;
+            qg = TC == 16 ? qcol + koff(g + 1) : qg + 12 * TC;
             if (g + 1 < n_groups || odd_round) load_pq(U0{}, PA, QA);  // wave-uniform: nothing is read past the last atom row
             __builtin_amdgcn_sched_barrier(0);
             accumulate(PB, QB);
@@ -3220,15 +3235,15 @@ k_scatter_pairs(const uint64_t *__restrict__ pairs, int64_t n_pairs, int64_t N, 
 // triangle, in dispatch order (row blocks ascending, tiles left to right); built on the host
 // and kept on the device until N or the sharding changes.  Without it (row blocks that are not
 // a multiple of 64) the kernel enumerates all NT x n_lblocks pairs and skips the empty ones.
-static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks, bool halves = true) {
-  const int64_t rb_key = e->row_block * 2 + (halves ? 1 : 0);
+static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks, bool halves = true, int64_t tc = 64) {
+  const int64_t rb_key = (e->row_block * 2 + (halves ? 1 : 0)) * 128 + tc;
   if (e->item_key[0] == e->N && e->item_key[1] == e->rank && e->item_key[2] == e->world &&
       e->item_key[3] == rb_key)
     return FC_OK;
   e->item_total = 0;
   e->item_key[0] = e->N; e->item_key[1] = e->rank; e->item_key[2] = e->world; e->item_key[3] = rb_key;
-  if (e->row_block % 64 != 0) return FC_OK;
-  const int64_t r = e->row_block / 64;
+  if (e->row_block % tc != 0) return FC_OK;
+  const int64_t r = e->row_block / tc;
   std::vector<uint64_t> items;
   for (int64_t l = 0; l < n_lblocks; ++l) {
     const int64_t first = r * global_block(l, e->rank, e->world);
@@ -3265,11 +3280,17 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
                        int64_t world) {
   // rank / world: this launch covers the row blocks (of 128) dealt to `rank` in snake order -- the rows a
   // rank of the multi-GPU bench owns; (0, 1) = the whole upper triangle
-  const int64_t NT = e->Npad >> 6;
   const int64_t rb = 128;
   const int64_t n_lblocks = local_block_count(ceil_div(e->N, rb), rank, world);
   if (n_lblocks <= 0) return FC_OK;
-  const size_t lds_m = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)rb) * sizeof(double) + kStageBytes;
+  const size_t lds_64 = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)rb) * sizeof(double) + kStageBytes;
+  const size_t lds_32 = ((size_t)((e->A + 3) / 4) * 4 * 3 * 32 + 32 + (size_t)rb) * sizeof(double) + kStageBytes;
+  const size_t lds_16 = ((size_t)(((e->A + 3) / 4 + 1) / 2) * 384 + 16 + (size_t)rb) * sizeof(double) + kStageBytes;
+  // the 64-column tile no longer fits (105 atoms and more): the complete alignments go on with 32 columns, from 209 atoms with 16
+  const bool narrow = lds_64 > kLdsLimit && maxdev_dev != nullptr;
+  const int64_t tc = !narrow ? 64 : (lds_32 <= kLdsLimit ? 32 : 16);
+  const size_t lds_m = tc == 64 ? lds_64 : (tc == 32 ? lds_32 : lds_16);
+  const int64_t NT = e->Npad / tc;
   if (lds_m > kLdsLimit || NT == 0)
     return set_error(FC_E_LIMIT, "A=%lld atoms exceed the LDS column tile of the value kernel", (long long)e->A);
   const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32) &&
@@ -3278,7 +3299,9 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
   auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
   const bool two_blocks = 2 * lds_m <= kLdsLimit;
   const bool complete = maxdev_dev != nullptr;
-  const void *fn = complete ? (two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4, 2>)
+  const void *fn = narrow ? (tc == 32 ? reinterpret_cast<const void *>(k_simbits_screen_mfma<8, 2, 32>)
+                                      : reinterpret_cast<const void *>(k_simbits_screen_mfma<8, 2, 16>))
+                 : complete ? (two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4, 2>)
                                           : reinterpret_cast<const void *>(k_simbits_screen_mfma<8, 2>))
                             : (two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4, 1>)
                                           : reinterpret_cast<const void *>(k_simbits_screen_mfma<8, 1>));
@@ -3291,7 +3314,7 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
   // the world == 1 layout with its own row block, so it keeps its own table
   const int64_t saved_rank = e->rank, saved_world = e->world, saved_rb = e->row_block;
   e->rank = rank; e->world = world; e->row_block = rb;
-  const int rc_tbl = screen_item_table(e, NT, n_lblocks);
+  const int rc_tbl = screen_item_table(e, NT, n_lblocks, true, tc);
   e->rank = saved_rank; e->world = saved_world; e->row_block = saved_rb;
   e->item_key[3] = -1;  // the table was built for rb, not for the ensemble's own sharding
   if (rc_tbl != FC_OK) return rc_tbl;
@@ -3306,7 +3329,17 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
                      e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,   \
                      rank, world, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),                   \
                      (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev, nullptr, maxdev_dev)
-  if (complete) {
+  if (narrow && tc == 32) {
+    hipLaunchKernelGGL((k_simbits_screen_mfma<8, 2, 32>), grid, dim3(8 * 64), lds_m, ctx().stream, e->Xs.as<double>(),
+                       e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb, rank, world, nullptr, e->W, nullptr, cnt,
+                       e->pairq.as<uint64_t>(), (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev, nullptr,
+                       maxdev_dev);
+  } else if (narrow) {
+    hipLaunchKernelGGL((k_simbits_screen_mfma<8, 2, 16>), grid, dim3(8 * 64), lds_m, ctx().stream, e->Xs.as<double>(),
+                       e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb, rank, world, nullptr, e->W, nullptr, cnt,
+                       e->pairq.as<uint64_t>(), (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev, nullptr,
+                       maxdev_dev);
+  } else if (complete) {
     if (two_blocks) FC_LAUNCH_VALUES(4, 2);
     else FC_LAUNCH_VALUES(8, 2);
   } else {

@@ -84,10 +84,13 @@ def prune_by_rmsd(structures, atoms, max_rmsd=None, max_dev=None, energies=None,
     heavy = (atoms != "H") if heavy_atoms_only else np.ones(len(atoms), dtype=bool)
     order, en_sorted = _sorted_by_energy(structures, energies)
     X = structures if order is None else np.ascontiguousarray(structures[order])
-    with L.DeviceEnsemble(X, atom_mask=heavy, center=True) as ens:
-        mask_sorted, stats = ens.prune(max_rmsd, max_dev, energies=en_sorted, max_dE=max_dE,
-                                       min_per_group=min_per_group)
-    mask = _unsort(mask_sorted, order)
+    # one C call (fc_prune_rmsd_host): upload, preparation, prune, mask
+    m8 = np.zeros(N, dtype=np.uint8)
+    stats = np.zeros(6, dtype=np.int64)
+    hm = np.ascontiguousarray(heavy, dtype=np.uint8)
+    L.call("fc_prune_rmsd_host", L.pf(X), N, X.shape[1], L.pb(hm), 1, float(max_rmsd), float(max_dev),
+           L.pf(None if en_sorted is None else L.f64(en_sorted)), float(max_dE), int(min_per_group), L.pb(m8), L.pi(stats))
+    mask = _unsort(m8.view(np.bool_), order)
     if debugfunction is not None:
         debugfunction(
             f"DEBUG: prune_by_rmsd [gfx950] - {stats[0]} pairs screened, {stats[1]} refined, "

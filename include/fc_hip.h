@@ -147,6 +147,13 @@ int fc_rmsd_simbits(fc_ensemble *ens, double max_rmsd, double max_dev, const dou
                     int64_t *n_grey);
 int fc_prune_rmsd(fc_ensemble *ens, double max_rmsd, double max_dev, const double *energies,
                   double max_dE, int64_t min_per_group, uint8_t *mask_out, int64_t *stats);
+/* prism_pruner.pruner.prune_by_rmsd as FIRECODE calls it (firecode/ensemble.py:230-235, firecode/embedder.py:1472-1474:
+ * host arrays in, mask out) in ONE call: coords (N, A, 3), atom_mask (A bytes or NULL = all atoms), center as in
+ * fc_ensemble_create; the other arguments, mask_out (N bytes) and stats (6 values or NULL) as in fc_prune_rmsd.  Same
+ * mask as fc_ensemble_create + fc_prune_rmsd + fc_ensemble_destroy; nothing stays resident. */
+int fc_prune_rmsd_host(const double *coords, int64_t N, int64_t A, const uint8_t *atom_mask, int center, double max_rmsd,
+                       double max_dev, const double *energies, double max_dE, int64_t min_per_group, uint8_t *mask_out,
+                       int64_t *stats);
 /* One of the conventions of prism_pruner's pruner that the reference tree does not show (SURVEY.md
  * Appendix A) as a switch: 0 (default) = inside a chunk a structure is removed at the first LATER
  * similar one; 1 = the mirror rule (a structure falls to any earlier similar one of its chunk).

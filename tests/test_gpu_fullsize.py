@@ -113,15 +113,18 @@ def _check_against_oracle(X, iu, ju, r, d):
     return err_r, err_d, slack
 
 
-@pytest.mark.parametrize("n,n_atoms,seed", [(10000, 50, 2), (12010, 80, 4)])
+@pytest.mark.parametrize("n,n_atoms,seed", [(10000, 50, 2), (12010, 80, 4), (3050, 160, 6), (2570, 260, 7)])
 def test_complete_alignments_full_size_vs_oracle(fc, n, n_atoms, seed):
     """The bench's `value` kernel at the sizes it is timed at, both variants: k_simbits_screen_mfma<4, 2>
     (BASELINE configs[1]: 10 000 x 50, two workgroups per CU, half-row-block items at the end of the item table,
     16 columns in the last column tile) and <8, 2> (A = 80: one workgroup per CU; 12 010 conformers: 58 columns in
-    the last tile, 106 rows in the last row block).  Both (N, N) outputs are downloaded whole: > 28 000 sampled
+    the last tile, 106 rows in the last row block); and the narrow column tiles of larger structures: <8, 2, 32> at 160
+    atoms (105 ... 208: 32 columns), <8, 2, 16> at 260 atoms (209 ... 416: 16 columns, k-steps in pairs, an odd number
+    of them).  Both (N, N) outputs are downloaded whole: > 28 000 sampled
     pairs against the oracle's rmsd_and_max (firecode/utils.py:494-504), symmetry, exact-zero diagonal, and
     nothing outside what the kernel was asked for."""
-    X, atoms, asg = syn.synthetic_ensemble(n, n_atoms, seed=seed)
+    # (large structures: few cluster centres -- the generator redraws a centre until none of its atoms clash)
+    X, atoms, asg = syn.synthetic_ensemble(n, n_atoms, seed=seed, cluster_size=5 if n_atoms <= 100 else 50)
     rng = np.random.default_rng(100 + n_atoms)
     iu, ju = _headline_sample_pairs(n, rng)
     assert len(iu) > 28000
@@ -147,7 +150,7 @@ def test_complete_alignments_full_size_vs_oracle(fc, n, n_atoms, seed):
         assert np.array_equal((R[k:k + 2000] < 0.5) & (D[k:k + 2000] < 1.0), same[k:k + 2000])
 
 
-@pytest.mark.parametrize("n,n_atoms,seed,worlds", [(10000, 50, 2, (2, 3, 8)), (6000, 80, 4, (2, 3))])
+@pytest.mark.parametrize("n,n_atoms,seed,worlds", [(10000, 50, 2, (2, 3, 8)), (6000, 80, 4, (2, 3)), (2100, 160, 6, (2, 3)), (1700, 260, 7, (3,))])
 def test_complete_alignments_logical_ranks_equal_single_gpu(fc, n, n_atoms, seed, worlds):
     """What `bench.py --gpus N` measures: rank r computes the rows of the row blocks dealt to it in snake order
     (launch_rmsd_values(..., rank, world)).  Played on one GPU through fc_debug_comm_loopback, every rank's
@@ -156,7 +159,7 @@ def test_complete_alignments_logical_ranks_equal_single_gpu(fc, n, n_atoms, seed
     from firecode_amd import _lib
     from firecode_amd import dist as fdist
 
-    X, atoms, _ = syn.synthetic_ensemble(n, n_atoms, seed=seed)
+    X, atoms, _ = syn.synthetic_ensemble(n, n_atoms, seed=seed, cluster_size=5 if n_atoms <= 100 else 50)
     rng = np.random.default_rng(7 + n_atoms)
     iu, ju = _headline_sample_pairs(n, rng, n_random=12000)
     try:
