@@ -35,6 +35,14 @@ bench)
   python bench.py --steps 20 --warmup 5 > $O/bench_n1_k20.json 2> $O/bench_n1_k20.err
   tail -c 600 $O/bench_n1_k20.json
   ;;
+atoms)
+  say "complete alignments over the atom count (8 000 conformers): 64-, 32- and 16-column tiles, the exact kernel beyond"
+  : > $O/complete_over_atoms.jsonl
+  for a in 24 50 52 53 80 104 105 128 160 200 208 209 260 320 416 420; do
+    timeout -k 10 200 python tools/time_complete.py 8000 $a 3 2>/dev/null | tail -1 >> $O/complete_over_atoms.jsonl || exit 1
+  done
+  cat $O/complete_over_atoms.jsonl | cut -c1-160
+  ;;
 laps)
   say "cfg3 search with per-phase laps on stderr (FC_DEBUG FC_SCAN_LAPS)"
   FC_DEBUG=1 FC_SCAN_LAPS=1 FC_CSEARCH_RUNS=4 timeout -k 10 300 python tools/bench_workloads.py csearch > $O/cfg3_laps.json 2> $O/cfg3_laps.err
