@@ -1661,7 +1661,10 @@ constexpr int64_t kH2MaxKS2 = 6;
 // instruction mix the interleaved order takes 801 ns per sub-tile and SIMD at two waves per SIMD against 741 ns for
 // the phased order, and 667 against 629 ns at four: on gfx950 the vector work of a wave does not hide under its own
 // f16 MFMAs any better than under a sibling wave's; more resident waves is what helps.)
-template <int KS2, bool BITS>
+// TC: conformers of the column tile.  64; 32 for structures of 193 ... 416 atoms (7 ... 13 k-steps; lean launches only:
+// the bit-matrix layout is one 64-column word per tile) -- 12 KB of tile per k-step instead of 24, the row operands of
+// all k-steps still in registers (24 per k-step, one wavefront per SIMD has 512)
+template <int KS2, bool BITS, int TC = 64>
 __global__ void __launch_bounds__(256, (KS2 <= 2 ? FC_H2_WGS : KS2 <= 3 ? 2 : 1))  // (four k-steps and more: the column tile leaves one workgroup per CU anyway)
 k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__ G, int64_t N, int64_t Npad,
                          float half_A_thr2, float tiny_floor, float scale2, KabschF32Bounds bd, int IB, int64_t rank,
@@ -1669,7 +1672,8 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
                          unsigned long long *__restrict__ counters, uint64_t *__restrict__ pairq,
                          unsigned long long Q, const uint64_t *__restrict__ item_table, unsigned long long n_items) {
   extern __shared__ double lds_raw[];
-  constexpr int NW = 4, TC = 64;
+  static_assert(TC == 64 || (TC == 32 && !BITS), "32-column tiles: lean launches only");
+  constexpr int NW = 4;
   constexpr int n_runs = KS2 * 24;
   h8_t *__restrict__ lds8 = reinterpret_cast<h8_t *>(lds_raw);  // [run][64 columns]
   const int tid = threadIdx.x;
@@ -1698,7 +1702,7 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
     if (it & (1ull << 31)) it_last = IB >> 5;
     if (it & (1ull << 63)) it_first = IB >> 5;
   } else {
-    const int64_t NT = Npad >> 6;
+    const int64_t NT = Npad / TC;
     jt = (int64_t)(b % (unsigned long long)NT);
     lb = (int64_t)(b / (unsigned long long)NT);
   }
@@ -1733,10 +1737,18 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
   int it = it_first + wv;
   if (tile_exists(it)) fetch_rows(it);
   {  // column tile by LDS-DMA: one 1-KiB instruction per run
-    for (int q = wv; q < n_runs; q += NW) {
-      const h8_t *src = Xh + ((int64_t)q * Npad + j0 + lane);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)(lds8 + q * TC), 16, 0, 0);
+    if (TC == 64) {
+      for (int q = wv; q < n_runs; q += NW) {
+        const h8_t *src = Xh + ((int64_t)q * Npad + j0 + lane);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds8 + q * TC), 16, 0, 0);
+      }
+    } else {  // two runs of 32 columns per instruction: lanes 0..31 the even run, 32..63 the odd one
+      for (int q2 = wv; q2 < n_runs / 2; q2 += NW) {
+        const h8_t *src = Xh + ((int64_t)(2 * q2 + (lane >> 5)) * Npad + j0 + (lane & 31));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds8 + q2 * 64), 16, 0, 0);
+      }
     }
     for (int idx = tid; idx < TC + IB; idx += NW * 64) {
       const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
@@ -1761,7 +1773,7 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
     unsigned nz = 0;  // lanes 0..15: OR of the 16-bit pieces written for row ib + lane
     // one 16 x 16 sub-tile at a time: the row operands stay in registers, so a wider unit would share nothing
 #pragma unroll 1
-    for (int cs = 0; cs < 4; ++cs) {
+    for (int cs = 0; cs < TC / 16; ++cs) {
       if (j0 + (cs + 1) * 16 - 1 <= ib) {  // at or below the diagonal (never the last sub-tile)
         if (BITS && lane < 16 && ib + lane < N) bits16[((lrow0 + lane) * W + jt) * 4 + cs] = 0;
         continue;
@@ -1802,7 +1814,7 @@ k_simbits_screen_mfma_h2(const h8_t *__restrict__ Xh, const double *__restrict__
 #endif
       // the next row tile's operands are requested now: they land during the epilogue
 #ifndef FC_H2_ABLATE_ROWS  // timing experiment only (results are wrong): every row tile computed from the first one's operands
-      if (cs == 3 && tile_exists(it + NW)) fetch_rows(it + NW);
+      if (cs == TC / 16 - 1 && tile_exists(it + NW)) fetch_rows(it + NW);
 #endif
       // epilogue: lane owns pairs (ib + 4 kq + r, j0 + cs*16 + l15), r = 0..3.  The four polynomials in one
       // straight line; what is rare (a pair for the three-test form, a sub-tile on the diagonal or at the end
@@ -3484,10 +3496,10 @@ void screen_select(int kind) { g_screen_forced = kind; }
 int h2_model_ok(bool *ok);  // fc_h2_check.hip
 
 // makes e->Xh for the scale the split-half screen would use; scale_out = 0: the screen does not apply
-int ensure_h2_operands(fc_ensemble *e, double *scale_out) {
+static int ensure_h2_operands_upto(fc_ensemble *e, double *scale_out, int64_t max_ks2) {
   *scale_out = 0.0;
   const int64_t KS2 = (e->A + 31) / 32, A4 = (e->A + 3) / 4 * 4;
-  if (KS2 > kH2MaxKS2 || (uint64_t)(24 * KS2) * (uint64_t)e->Npad >= (1ull << 32)) return FC_OK;
+  if (KS2 > max_ks2 || (uint64_t)(24 * KS2) * (uint64_t)e->Npad >= (1ull << 32)) return FC_OK;
   if (!(e->g_max > 0.0) || !std::isfinite(e->g_max)) return FC_OK;
   // largest |coordinate| <= sqrt(g_max): scaled into [2^12, 2^13] (halfs reach 65504; s^4 stays in fp32)
   int ex = 0;
@@ -3504,6 +3516,7 @@ int ensure_h2_operands(fc_ensemble *e, double *scale_out) {
   *scale_out = scale;
   return FC_OK;
 }
+int ensure_h2_operands(fc_ensemble *e, double *scale_out) { return ensure_h2_operands_upto(e, scale_out, kH2MaxKS2); }
 
 int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   // Context::mark_after_screen: recorded once, right behind the main screen kernel of this launch
@@ -3531,6 +3544,83 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
   const char *cfg = getenv("FC_SCREEN_CFG");
   const bool want_valu = cfg && std::strncmp(cfg, "valu", 4) == 0;
   const bool alt = cfg && std::strcmp(cfg, "valu4x8") == 0;
+  // Structures of 193 ... 416 atoms (the poses of two or three docked molecules, firecode/embedder.py:1472-1474): the
+  // split-half screen with a 32-column tile, lean launches only.  Until round 5 they went to the fp32 matrix pipe up to
+  // 213 atoms (2.4 x the time per pair) and to the fp64 vector screen beyond (8 x).  No speculative mode here (no fp64
+  // matrix-pipe screen stands behind it at these sizes): the band rule decides alone, as for 105 ... 192 atoms.
+  {
+    const int64_t KS2n = (e->A + 31) / 32;
+    static const int h2_env_n = [] {
+      const char *v = getenv("FC_SCREEN_H2");
+      return v ? atoi(v) : 1;
+    }();
+    const char *f32_env_n = getenv("FC_SCREEN_F32");
+    const size_t lds_n = (size_t)KS2n * 24 * 512 + (32 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32;
+    if (!want_valu && e->lean && KS2n > kH2MaxKS2 && KS2n <= 13 && h2_env_n != 0 && (g_screen_forced == 0 || g_screen_forced == 16) &&
+        !(f32_env_n && f32_env_n[0] == '0') && e->row_block % 32 == 0 && lds_n <= kLdsLimit &&
+        (uint64_t)(24 * KS2n) * (uint64_t)e->Npad < (1ull << 32)) {
+      if (e->g_max < 0.0) {
+        auto *cnt_max = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
+        FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
+        hipLaunchKernelGGL(k_max_nonneg, dim3((unsigned)std::min<int64_t>(ceil_div(e->Npad, 256), 256)), dim3(256), 0, ctx().stream,
+                           e->G.as<double>(), e->Npad, cnt_max);
+        FC_TRY(check_launch("k_max_nonneg"));
+        unsigned long long bits_max = 0;
+        FC_TRY(d2h(&bits_max, cnt_max, sizeof bits_max));
+        FC_TRY(sync());
+        FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
+        std::memcpy(&e->g_max, &bits_max, sizeof(double));
+      }
+      bool model_ok = false;
+      FC_TRY(h2_model_ok(&model_ok));
+      double scale_n = 0.0;
+      if (model_ok) FC_TRY(ensure_h2_operands_upto(e, &scale_n, 13));
+      const KabschF32Bounds bdn = kabsch_h2_bounds(KS2n);
+      const double s2 = scale_n * scale_n;
+      const float hthr = (float)(0.5 * A_thr2 * s2);
+      static const double kBandMaxN = [] {
+        const char *v = getenv("FC_SCREEN_BAND_MAX");
+        const double x = v ? atof(v) : 4.0;
+        return x > 0.0 ? x : 4.0;
+      }();
+      const double band = (double)bdn.p0 * 2.0 * e->g_max / (double)e->A;
+      const bool band_ok = g_screen_forced == 16 || (f32_env_n && (f32_env_n[0] == '2' || f32_env_n[0] == '3')) || band <= kBandMaxN * thr2_margin;
+      if (scale_n > 0.0 && std::isfinite(hthr) && hthr > 0.f && band_ok) {
+        const int64_t NTn = e->Npad / 32;
+        FC_TRY(screen_item_table(e, NTn, n_lblocks, /*halves=*/false, 32));
+        unsigned long long n_items = (unsigned long long)NTn * (unsigned long long)n_lblocks;
+        const uint64_t *item_table_dev = nullptr;
+        if (e->item_total > 0) n_items = (unsigned long long)e->item_total, item_table_dev = e->item_table.as<uint64_t>();
+        if (n_items >= (1ull << 31)) return set_error(FC_E_LIMIT, "too many screen items for one launch");
+        auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
+        const float tiny_floor = std::max(4.0f * hthr, (float)e->A);
+#define FC_LAUNCH_H2N(KS2_)                                                                                                 \
+  do {                                                                                                                      \
+    const void *fn_ = reinterpret_cast<const void *>(k_simbits_screen_mfma_h2<KS2_, false, 32>);                            \
+    FC_HIP_TRY(hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));                           \
+    hipLaunchKernelGGL((k_simbits_screen_mfma_h2<KS2_, false, 32>), dim3((unsigned)n_items), dim3(256), lds_n, ctx().stream, \
+                       e->Xh.as<h8_t>(), e->G.as<double>(), e->N, e->Npad, hthr, tiny_floor, (float)s2, bdn, (int)e->row_block, \
+                       e->rank, e->world, nullptr, e->W, e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),              \
+                       (unsigned long long)e->pairq_cap, item_table_dev, n_items);                                          \
+  } while (0)
+        switch (KS2n) {
+          case 7: FC_LAUNCH_H2N(7); break;
+          case 8: FC_LAUNCH_H2N(8); break;
+          case 9: FC_LAUNCH_H2N(9); break;
+          case 10: FC_LAUNCH_H2N(10); break;
+          case 11: FC_LAUNCH_H2N(11); break;
+          case 12: FC_LAUNCH_H2N(12); break;
+          default: FC_LAUNCH_H2N(13); break;
+        }
+#undef FC_LAUNCH_H2N
+        FC_TRY(check_launch("k_simbits_screen_mfma_h2<narrow>"));
+        e->item_key[3] = -1;  // (the table holds 32-column items: the next launch of another screen rebuilds it)
+        g_last_screen = 16;
+        mark_main();
+        return FC_OK;
+      }
+    }
+  }
   {
     const size_t lds_m = ((size_t)((e->A + 3) / 4) * 4 * 3 * 64 + 64 + (size_t)e->row_block) * sizeof(double) + kStageBytes;
     const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32);

@@ -28,19 +28,33 @@ def synthetic_skeleton(n_atoms, rng, bond=1.5, min_dist=1.2):
     return np.array(pts)
 
 
-def synthetic_ensemble(n_conf, n_atoms, seed, cluster_size=5, sigma_cluster=0.6, sigma_conf=0.03):
+def compact_skeleton(n_atoms, rng, spacing=1.5):
+    """A globule instead of a walk: the n_atoms points of a cubic lattice (spacing 1.5 A) nearest to the origin, jittered
+    by 0.1 A -- the radius of gyration of a folded molecule or of docked poses (4.6 A at 260 atoms) where the
+    self-avoiding walk of synthetic_skeleton gives 15-21 A."""
+    m = int(np.ceil((n_atoms * 2) ** (1.0 / 3.0))) + 2
+    g = np.arange(-m, m + 1) * spacing
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3) + spacing / 3.0
+    pts = pts[np.argsort((pts ** 2).sum(axis=1), kind="stable")[:n_atoms]]
+    return pts + rng.normal(scale=0.1, size=pts.shape)
+
+
+def synthetic_ensemble(n_conf, n_atoms, seed, cluster_size=5, sigma_cluster=0.6, sigma_conf=0.03, compact=False):
     """K = n_conf / cluster_size cluster centres (skeleton + N(0, 0.6^2), no
     self-clash below 0.5 A), members = centre + N(0, 0.03^2), shuffled, each
     with a random proper rotation and a translation N(0, 5^2).  Intra-cluster
     RMSD ~0.07 A, inter-cluster ~1.5 A: no pair near the 0.5 A threshold.
     Returns (coords (N, A, 3), atoms (A,) all 'C', cluster id per conformer)."""
     rng = np.random.default_rng(seed)
-    skel = synthetic_skeleton(n_atoms, rng)
+    skel = compact_skeleton(n_atoms, rng) if compact else synthetic_skeleton(n_atoms, rng)
     K = max(1, n_conf // cluster_size)
     centres = np.empty((K, n_atoms, 3))
     for k in range(K):
         while True:
             c = skel + rng.normal(scale=sigma_cluster, size=skel.shape)
+            if compact:  # (a globule's many 1.5 A neighbours never all survive the noise: no clash rejection there)
+                centres[k] = c
+                break
             d = cdist(c, c)
             d[np.diag_indices(n_atoms)] = 10.0
             if d.min() >= 0.5:

@@ -52,6 +52,37 @@ def test_cfg2_full_prune_properties(fc):
     assert np.array_equal(S, expect) and grey == 0
 
 
+@pytest.mark.parametrize("n,a", [(7010, 224), (6000, 260), (4500, 320), (3000, 384)])
+def test_large_compact_structures_prune_properties(fc, n, a):
+    """The split-half screen's 32-column tile (193 ... 384 atoms; 7, 9, 10 and 12 k-steps here, the last three with row
+    operands partly in scratch) at sizes with many row blocks and a partial last column tile, on globules with the
+    radius of gyration of docked poses: one survivor per cluster, the LAST member of each, idempotent, and a band of
+    rows of the similarity bits against the cluster structure."""
+    X, atoms, asg = syn.synthetic_ensemble(n, a, seed=800 + a, cluster_size=5, compact=True)
+    pruned, mask = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    from firecode_amd import _lib
+
+    assert _lib.screen_last_kind() == 16
+    K = len(np.unique(asg))
+    assert mask.sum() == K and len(np.unique(asg[mask])) == K
+    last = np.zeros(K, dtype=np.int64)
+    last[asg] = np.arange(len(asg))
+    assert np.array_equal(np.sort(np.flatnonzero(mask)), np.sort(last))
+    _, m2 = fc.pruner.prune_by_rmsd(pruned, atoms, 0.5)
+    assert m2.all()
+    rng = np.random.default_rng(a)
+    iu, ju = rng.integers(0, n, 2000), rng.integers(0, n, 2000)
+    r, d = fc.rmsd.rmsd_and_max_batch(X, iu, ju, center=True)
+    r0, d0 = o.rmsd_and_max_batch(X[iu], X[ju], center=True)
+    assert np.abs(r - r0).max() < TOL and ((r < 0.5) == (asg[iu] == asg[ju])).all()
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        bits, grey = ens.simbits(0.5, 1.0, row_begin=n - 200, row_end=n - 136)
+    S = _lib.unpack_bits(bits, n)
+    rows = np.arange(n - 200, n - 136)
+    expect = (asg[rows, None] == asg[None, :]) & (np.arange(n)[None, :] > rows[:, None])
+    assert np.array_equal(S, expect) and grey == 0
+
+
 def test_cfg4_shape_80_atoms(fc):
     """the A = 80 kernel variant (one workgroup per CU) at a size the test can afford"""
     X, atoms, asg = syn.synthetic_ensemble(12000, 80, seed=4)

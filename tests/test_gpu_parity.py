@@ -1219,6 +1219,26 @@ def test_prune_odd_shapes_and_all_screen_variants(fc, n, a):
     assert np.array_equal(unpack_bits(bits, n), np.triu(S0, 1))
 
 
+@pytest.mark.parametrize("n,a", [(150, 193), (140, 224), (130, 260), (120, 320), (100, 384), (100, 416)])
+def test_prune_large_compact_structures(fc, n, a):
+    """Structures of 193 ... 384 atoms with the radius of gyration of folded molecules / docked poses (globules: 4.5-5.5 A;
+    the self-avoiding walks of the other tests have 15-20 A and a band too wide for a single-precision screen): the
+    split-half screen with its 32-column tile takes them (7 ... 12 k-steps of 32 atoms; 416 atoms: beyond its LDS tile).
+    Masks and similarity bits against the oracle."""
+    X, atoms, asg = syn.synthetic_ensemble(n, a, seed=700 + a, cluster_size=3, compact=True)
+    S0, R0, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    assert 0 < ref.sum() < n
+    _, mask = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    assert np.array_equal(mask, ref)
+    from firecode_amd import _lib
+
+    assert _lib.screen_last_kind() == (16 if a <= 384 else 1)
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        bits, grey = ens.simbits(0.5, 1.0)
+    assert np.array_equal(_lib.unpack_bits(bits, n), np.triu(S0, 1))
+
+
 @pytest.mark.parametrize("cfg", ["valu8x4", "valu4x8"])
 def test_valu_screen_kernels_still_agree(fc, cfg, monkeypatch):
     monkeypatch.setenv("FC_SCREEN_CFG", cfg)
