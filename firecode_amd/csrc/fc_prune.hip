@@ -850,6 +850,445 @@ k_tfd_first_match_merge(const unsigned long long *__restrict__ left_count, const
 }
 
 // ---------------------------------------------------------------------------
+// First match with 16-bit angles (round 5).  An angle becomes u = rint(a * 65536 / 360) mod 65536 -- the full circle
+// on the full range, so the wrap-around of the reference's delta (|d| or |d - 360|: torsion_module.py:1056-1067) is
+// the wrap-around of the 16-bit subtraction.  Eight angles of a structure are one 16-byte load (tfU[j]), the test
+// of a (row, column) pair is four v_pk_sub_i16 + four v_sad_u16 against the bias 0x8000 (the row is stored with
+// that bias, so that the column's angle lands at 0x8000 +- distance and the unsigned |x - 0x8000| is the circular
+// distance) where the fp32 pre-filter above spends ~45 vector instructions -- and the first-match kernels at
+// 1.7 M structures are bound by exactly those (1.5e9 pair tests in the look-ahead phase).
+//   Rounding: |u - a s| <= 0.5 per angle, <= 1 unit per distance, <= 8 units (0.044 deg) over eight angles.  So
+//   SAD <  floor(thresh s) - 10  => similar in exact arithmetic too  (only if ALL angles are in the eight: Q <= 8),
+//   SAD >= ceil(thresh s) + 10   => not similar (the eight are a lower bound of the sum for any Q),
+//   in between (never, on a systematic scan: its angles differ by whole steps) the fp64 sum in NumPy's order decides.
+// Valid while the reference's delta IS the circular distance: every |angle| <= 270 (|a - b| <= 540) and finite;
+// k_tfd_pack_u16 raises flags[kFmShards] otherwise, the kernels return at once and the host runs the fp32 kernels above.
+// ---------------------------------------------------------------------------
+typedef unsigned short fc_us2 __attribute__((ext_vector_type(2)));
+
+// The rows the dense phase leaves open go to kFmShards lists, eight consecutive row blocks to the same one: one list
+// means one returning atomic per workgroup on ONE address (2.6e4 of them: 0.3 ms by themselves), a list per block
+// means walk workgroups of 25 rows instead of 64.  List s holds at most fm_shard_cap(N) rows.
+constexpr int kFmShards = 16;
+__host__ __device__ inline int64_t fm_shard_cap(int64_t N) {
+  const int64_t blocks = (N + 63) / 64, groups = (blocks + 7) / 8;
+  return ((groups + kFmShards - 1) / kFmShards) * 8 * 64;
+}
+struct FmShards {
+  unsigned wg_begin[kFmShards + 1];  // walk workgroups [wg_begin[s], wg_begin[s + 1]) take list s
+  unsigned count[kFmShards];
+};
+
+
+__device__ __forceinline__ unsigned pk_sub_u16(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, (fc_us2)(__builtin_bit_cast(fc_us2, a) - __builtin_bit_cast(fc_us2, b)));
+}
+
+template <int ND>  // dwords that hold angles (two each)
+__device__ __forceinline__ unsigned sad_u16x8(const uint4 c, const uint4 row_biased) {
+  unsigned s = __builtin_amdgcn_sad_u16(pk_sub_u16(c.x, row_biased.x), 0x80008000u, 0u);
+  if (ND > 1) s = __builtin_amdgcn_sad_u16(pk_sub_u16(c.y, row_biased.y), 0x80008000u, s);
+  if (ND > 2) s = __builtin_amdgcn_sad_u16(pk_sub_u16(c.z, row_biased.z), 0x80008000u, s);
+  if (ND > 3) s = __builtin_amdgcn_sad_u16(pk_sub_u16(c.w, row_biased.w), 0x80008000u, s);
+  return s;
+}
+
+__global__ void __launch_bounds__(256)
+k_tfd_pack_u16(const double *__restrict__ tfT, int64_t N, int64_t Npad, int Q, uint4 *__restrict__ tfU,
+               unsigned long long *__restrict__ flags) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= Npad) return;
+  unsigned h[8];
+  bool bad = false;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double a = (q < Q && j < N) ? tfT[(int64_t)q * Npad + j] : 0.0;
+    if (!(fabs(a) <= 270.0)) bad = true;
+    h[q] = bad ? 0u : ((unsigned)(long long)rint(a * (65536.0 / 360.0)) & 0xffffu);
+  }
+  tfU[j] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+  if (bad) atomicOr(&flags[kFmShards], 1ull);
+}
+
+constexpr unsigned kFmOpen = 0xffffffffu;
+
+// The pairs of the undecided band take the fp64 sum out of line (never on a systematic scan; inlined at every test
+// it cost the kernels half their wavefronts per SIMD).  row / col: fingerprints with element strides rs / cs.
+__device__ __attribute__((noinline)) bool tfd_similar_exact(const double *row, int64_t rs, const double *col, int64_t cs,
+                                                            int Q, double thresh) {
+  return tfd_sum(row, rs, col, cs, Q) < thresh;
+}
+
+// Phase 1, dense: the columns right behind a block of 64 rows -- where half the rows of a systematic scan find their
+// match -- with LANES = ROWS: the column is the same for the whole wavefront (a scalar load of 16 bytes), every lane
+// tests its own row and keeps its first hit in a register.  No LDS reads, ballots or atomics per test: ~14 vector
+// instructions per column and 64 rows, where the lanes = columns form (k_tfd_first_match, and the walk below) pays
+// ~25 per OPEN row and 64 columns -- the better trade once fewer than ~35 of the 64 rows are open, i.e. past `ahead`
+// columns.  The four wavefronts take the columns in turns of four; what is open at the end goes to the leftover list.
+template <int QT>
+__global__ void __launch_bounds__(256)
+k_tfd_first_match_dense_u16(const double *__restrict__ tfT, const uint4 *__restrict__ tfU, int64_t N, int64_t Npad,
+                            int Qrt, double thresh, int t_lo, int t_hi, int64_t *__restrict__ first_match,
+                            int64_t ahead, unsigned long long *__restrict__ left_count,
+                            int64_t *__restrict__ left_rows, int64_t *__restrict__ left_from) {
+  const int Q = QT > 0 ? QT : Qrt;
+  constexpr int ND = QT > 0 ? (QT >= 7 ? 4 : (QT + 1) / 2) : 4;
+  if (left_count[kFmShards] != 0ull) return;  // (grid-uniform: angles the 16 bits cannot stand for)
+  __shared__ unsigned best[64];               // column - i0 of the first match
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t i0 = (int64_t)blockIdx.x * 64, i = i0 + lane;
+  const bool row = i < N;
+  uint4 rw = tfU[row ? i : N - 1];
+  rw = make_uint4(rw.x ^ 0x80008000u, rw.y ^ 0x80008000u, rw.z ^ 0x80008000u, rw.w ^ 0x80008000u);
+  if (tid < 64) best[tid] = row ? kFmOpen : 0u;
+  __syncthreads();
+  const int64_t e = i0 + 64 + ahead < N ? i0 + 64 + ahead : N;  // columns [i0 + 1, e)
+  const int e_rel = (int)(e - i0);
+  unsigned mine = row ? kFmOpen : 0u;
+  // (the columns of the next turn are requested before this turn's tests; the tests themselves without branches:
+  // the rare pair of the undecided band is noted and looked at after the turn)
+  uint4 cur[4], nxt[4];
+  int64_t j0 = i0 + 1 + 4 * wv;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) cur[u] = tfU[j0 + u < N ? j0 + u : N - 1];
+  for (; j0 < e; j0 += 16) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) nxt[u] = tfU[j0 + 16 + u < N ? j0 + 16 + u : N - 1];
+    const int jrel0 = (int)(j0 - i0);
+    unsigned und = 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int jrel = jrel0 + u;  // (uniform)
+      const int s = (int)sad_u16x8<ND>(cur[u], rw);
+      const bool valid = jrel > lane && jrel < e_rel;
+      const unsigned cand = (valid && s < t_lo) ? (unsigned)jrel : kFmOpen;
+      mine = mine < cand ? mine : cand;
+      und |= (valid && s >= t_lo && s < t_hi) ? 1u << u : 0u;
+    }
+    if (__ballot(und != 0u) != 0ull) {
+#pragma unroll 1
+      for (int u = 0; u < 4; ++u)
+        if (((und >> u) & 1u) && (unsigned)(jrel0 + u) < mine &&
+            tfd_similar_exact(tfT + i, Npad, tfT + j0 + u, Npad, Q, thresh))
+          mine = (unsigned)(jrel0 + u);
+    }
+    if (__ballot(mine == kFmOpen) == 0ull) break;  // every row has a match among this wavefront's columns
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+  }
+  if (row && mine != kFmOpen) atomicMin(&best[lane], mine);
+  __syncthreads();
+  if (tid < 64) {  // (the first wavefront, whole)
+    const bool open = row && best[tid] == kFmOpen;
+    if (row) first_match[i] = open ? -1 : i0 + (int64_t)best[tid];
+    const uint64_t lm = __ballot(open && e < N);
+    if (lm != 0ull) {
+      const int sh = (int)((blockIdx.x >> 3) & (kFmShards - 1));
+      unsigned long long base = 0ull;
+      if (tid == 0) base = atomicAdd(&left_count[sh], (unsigned long long)__popcll(lm));
+      base = __shfl(base, 0);
+      if ((lm >> tid) & 1ull) {
+        const int64_t slot = (int64_t)sh * fm_shard_cap(N) + (int64_t)base + __popcll(lm & ((1ull << tid) - 1ull));
+        left_rows[slot] = i;
+        left_from[slot] = e;
+      }
+    }
+  }
+}
+
+// Bounding boxes of the first (up to) eight angles over every window of 256 columns: wlo / whi[q * n_win + w]
+// and, for the walk's per-row test, as packed 16-bit (centre, half width + 2) per angle: wbu[2 w], wbu[2 w + 1] -- the
+// distance of a row's angle to the interval is then max(0, |a - c| - h) in the wrapping 16-bit arithmetic, five packed
+// instructions per two angles (the float form with its three wrapped copies: forty), rounded so that it never
+// exceeds the true one; a box of 359 degrees or more is the whole circle (h = 0x8000)
+__global__ void __launch_bounds__(256)
+k_tfd_window_bounds_f64(const double *__restrict__ tfT, int64_t N, int64_t Npad, int qf, int64_t n_win,
+                        float *__restrict__ wlo, float *__restrict__ whi, uint4 *__restrict__ wbu) {
+  __shared__ float slo[8][4], shi[8][4];
+  __shared__ unsigned sc[8], sh[8];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int64_t w = blockIdx.x, j = w * 256 + tid;
+  for (int q = 0; q < qf; ++q) {
+    double lo = 1e30, hi = -1e30;
+    if (j < N) lo = hi = tfT[(int64_t)q * Npad + j];
+    for (int off = 32; off > 0; off >>= 1) {
+      lo = fmin(lo, __shfl_xor(lo, off));
+      hi = fmax(hi, __shfl_xor(hi, off));
+    }
+    // outward in fp32: the box must hold every column's fp64 angle
+    if (lane == 0) slo[q][wv] = __double2float_rd(lo), shi[q][wv] = __double2float_ru(hi);
+  }
+  __syncthreads();
+  if (tid < 8) {
+    unsigned c = 0u, h = 0x8000u;  // (an angle the fingerprint does not have: every row is "inside")
+    if (tid < qf) {
+      const float lo = fminf(fminf(slo[tid][0], slo[tid][1]), fminf(slo[tid][2], slo[tid][3]));
+      const float hi = fmaxf(fmaxf(shi[tid][0], shi[tid][1]), fmaxf(shi[tid][2], shi[tid][3]));
+      wlo[(int64_t)tid * n_win + w] = lo;
+      whi[(int64_t)tid * n_win + w] = hi;
+      if (hi - lo < 359.f) {
+        c = (unsigned)(long long)rint(0.5 * ((double)lo + (double)hi) * (65536.0 / 360.0)) & 0xffffu;
+        h = (unsigned)ceil(0.5 * ((double)hi - (double)lo) * (65536.0 / 360.0)) + 2u;
+      }
+    }
+    sc[tid] = c;
+    sh[tid] = h;
+  }
+  __syncthreads();
+  if (tid == 0 && wbu != nullptr) {
+    wbu[2 * w] = make_uint4(sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16));
+    wbu[2 * w + 1] = make_uint4(sh[0] | (sh[1] << 16), sh[2] | (sh[3] << 16), sh[4] | (sh[5] << 16), sh[6] | (sh[7] << 16));
+  }
+}
+
+typedef short fc_s2 __attribute__((ext_vector_type(2)));
+// sum over two angles of max(0, |a - c| - h), 16-bit wrapping distance, saturating
+__device__ __forceinline__ fc_us2 box_gap_u16x2(unsigned a, unsigned c, unsigned h, fc_us2 acc) {
+  const fc_s2 d = __builtin_bit_cast(fc_s2, a) - __builtin_bit_cast(fc_s2, c);
+  const fc_s2 ad = __builtin_elementwise_max(d, (fc_s2)(0) - d);  // (|-32768| stays 0x8000: half the circle, unsigned)
+  const fc_us2 g = __builtin_elementwise_sub_sat(__builtin_bit_cast(fc_us2, ad), __builtin_bit_cast(fc_us2, h));
+  return __builtin_elementwise_add_sat(acc, g);
+}
+
+// distance of the intervals [alo, ahi] and [blo, bhi] on the circle of 360 (a lower bound of the reference's delta
+// between any member of one and any member of the other, for angles within [-270, 270])
+__device__ __forceinline__ float interval_gap_360(float alo, float ahi, float blo, float bhi) {
+  const float d0 = fmaxf(fmaxf(blo - ahi, alo - bhi), 0.f);
+  const float d1 = fmaxf(fmaxf(blo - (ahi + 360.f), (alo + 360.f) - bhi), 0.f);
+  const float d2 = fmaxf(fmaxf(blo - (ahi - 360.f), (alo - 360.f) - bhi), 0.f);
+  return fminf(d0, fminf(d1, d2));
+}
+
+#if defined(FC_TFD_STAMPS)
+// tuning build: ticks (s_memtime, 100 MHz) per phase of the walk, summed over workgroups by thread 0 (tools/fm_stamps.py)
+__device__ unsigned long long g_fm_stamps[16];
+#define FC_FM_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define FC_FM_ADD(k, v) do { if (threadIdx.x == 0) atomicAdd(&g_fm_stamps[k], (unsigned long long)(v)); } while (0)
+#define FC_FM_MAX(k, v) do { if (threadIdx.x == 0) atomicMax(&g_fm_stamps[k], (unsigned long long)(v)); } while (0)
+#define FC_FM_MIN(k, v) do { if (threadIdx.x == 0) atomicMin(&g_fm_stamps[k], (unsigned long long)(v)); } while (0)
+#else
+#define FC_FM_T(var) do { } while (0)
+#define FC_FM_ADD(k, v) do { } while (0)
+#define FC_FM_MAX(k, v) do { } while (0)
+#define FC_FM_MIN(k, v) do { } while (0)
+#endif
+
+// Phase 2, the walk: the rows the dense phase left open, 64 per workgroup in list order, against ALL later columns,
+// window by window of 256 columns IN ORDER -- a row retires at its first window with a match (the chunked
+// k_tfd_first_match_rest cannot stop: at 1.7 M structures it looked at 19 x the (row, window) pairs an ordered walk
+// needs, `tools/fm_probe.py`).  Windows are skipped by the bounding boxes of their angles twice: against the box of the
+// workgroup's rows (256 windows per step, one per thread), then per row.  In a systematic scan the angles vary like
+// the digits of a counter, so a window holds few values of the slow ones and most windows are far from a given row.
+// The windows that remain are taken FOUR at a time, one per wavefront (four columns per lane): a visit is one load
+// latency and two barriers whatever it tests, and a workgroup with a row that matches nowhere makes a hundred of
+// them -- one after the other they were the kernel (tools/fm_stamps.py).  A row that retires in the first window of
+// such a turn is still tested in the other three; the first match is the minimum either way.
+template <int QT>
+__global__ void __launch_bounds__(256)
+k_tfd_first_match_walk_u16(const double *__restrict__ tfT, const uint4 *__restrict__ tfU, int64_t N, int64_t Npad,
+                           int Qrt, double thresh, int t_lo, int t_hi, const FmShards sh,
+                           const int64_t *__restrict__ left_rows, const int64_t *__restrict__ left_from,
+                           const float *__restrict__ wlo, const float *__restrict__ whi,
+                           const uint4 *__restrict__ wbu, int64_t n_win, int64_t *__restrict__ first_match) {
+  const int Q = QT > 0 ? QT : Qrt;
+  constexpr int ND = QT > 0 ? (QT >= 7 ? 4 : (QT + 1) / 2) : 4;
+  constexpr int QB = 8, WIN = 256, WSH = 8;
+  extern __shared__ double rows[];  // [64][Q]
+  __shared__ uint4 rowsU[64];
+  __shared__ float rowsF[64][QB];
+  __shared__ long long row_i[64], row_from[64];
+  __shared__ unsigned long long lbest[64];  // first matching column so far, ~0: none
+  __shared__ float glo[QB], ghi[QB];
+  __shared__ long long from_min_s;
+  __shared__ int cand[256], act[256];
+  __shared__ uint4 cbox[256][2];  // the candidate windows' boxes in 16 bits: centres, half widths
+  __shared__ unsigned long long wmask[256];
+  __shared__ int wave_n[4];
+  __shared__ unsigned long long alive_s;
+  const int qb = QT > 0 ? (QT < QB ? QT : QB) : (Q < QB ? Q : QB);
+  const float lim = (float)thresh + 0.03f;  // (fp32 roundings of the boxes and of the wrapped copies: far below)
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int shard = 0;
+  while (shard + 1 < kFmShards && blockIdx.x >= sh.wg_begin[shard + 1]) ++shard;
+  const unsigned long long g0 = (unsigned long long)(blockIdx.x - sh.wg_begin[shard]) * 64ull, n_left = sh.count[shard];
+  left_rows += (int64_t)shard * fm_shard_cap(N);
+  left_from += (int64_t)shard * fm_shard_cap(N);
+  FC_FM_T(st0);
+  if (tid < 64) {
+    const bool on = g0 + tid < n_left;
+    const long long ri = on ? left_rows[g0 + tid] : -1;
+    const long long from = on ? left_from[g0 + tid] : (long long)N;
+    row_i[tid] = ri;
+    row_from[tid] = from;
+    lbest[tid] = ~0ull;
+    const uint4 a = tfU[on ? ri : 0];
+    rowsU[tid] = make_uint4(a.x ^ 0x80008000u, a.y ^ 0x80008000u, a.z ^ 0x80008000u, a.w ^ 0x80008000u);
+    long long fm_ = from;
+    for (int off = 32; off > 0; off >>= 1) {
+      const long long o = __shfl_xor(fm_, off);
+      fm_ = o < fm_ ? o : fm_;
+    }
+    const unsigned long long al = __ballot(on && from < (long long)N);
+    if (tid == 0) from_min_s = fm_, alive_s = al;
+  }
+  __syncthreads();
+  for (int k = tid; k < 64 * Q; k += 256) {
+    const int r = k / Q, q = k % Q;
+    const double v = row_i[r] >= 0 ? tfT[(int64_t)q * Npad + row_i[r]] : 0.0;
+    rows[k] = v;
+    if (q < QB) rowsF[r][q] = (float)v;
+  }
+  __syncthreads();
+  if (tid < 64) {  // the box of the workgroup's rows
+    const bool on = row_i[tid] >= 0;
+    for (int q = 0; q < qb; ++q) {
+      float lo = on ? rowsF[tid][q] : 1e30f, hi = on ? rowsF[tid][q] : -1e30f;
+      for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+      }
+      if (tid == 0) glo[q] = lo - 1e-3f, ghi[q] = hi + 1e-3f;  // ((float) of the fp64 angle: within 2e-5 of it)
+    }
+  }
+  __syncthreads();
+  unsigned long long alive = alive_s;
+  FC_FM_T(st1);
+  FC_FM_ADD(0, 1);
+  FC_FM_ADD(1, st1 - st0);
+  uint4 my_u = rowsU[lane];  // (lane = row in step (2))
+  my_u = make_uint4(my_u.x ^ 0x80008000u, my_u.y ^ 0x80008000u, my_u.z ^ 0x80008000u, my_u.w ^ 0x80008000u);
+  const long long my_from = row_from[lane];
+  for (int64_t wb = from_min_s >> WSH; wb < n_win && alive != 0ull; wb += 256) {
+    // (1) the windows of this step the workgroup's box comes near, compacted in order, their boxes kept in LDS
+    // (the loads of a window's sixteen numbers are issued together: one after the other, per angle and again per
+    // candidate and row, they were most of this kernel's time)
+    FC_FM_T(sa);
+    const int64_t w = wb + tid;
+    float wl[QB], wh[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const bool have = q < qb && w < n_win;
+      wl[q] = have ? wlo[(int64_t)q * n_win + w] : 0.f;
+      wh[q] = have ? whi[(int64_t)q * n_win + w] : 0.f;
+    }
+    const uint4 wc_u = wbu[2 * (w < n_win ? w : n_win - 1)], wh_u = wbu[2 * (w < n_win ? w : n_win - 1) + 1];
+    bool near = false;
+    if (w < n_win) {
+      float lb = 0.f;
+#pragma unroll
+      for (int q = 0; q < QB; ++q)
+        if (q < qb) lb += interval_gap_360(glo[q], ghi[q], wl[q], wh[q]);
+      near = lb < lim;
+    }
+    uint64_t nb = __ballot(near);
+    if (lane == 0) wave_n[wv] = __popcll(nb);
+    __syncthreads();
+    int base = 0, nc = 0;
+    for (int v = 0; v < 4; ++v) {
+      if (v < wv) base += wave_n[v];
+      nc += wave_n[v];
+    }
+    if (near) {
+      const int at = base + __popcll(nb & ((1ull << lane) - 1ull));
+      cand[at] = (int)(w - wb);
+      cbox[at][0] = wc_u;
+      cbox[at][1] = wh_u;
+    }
+    __syncthreads();
+    FC_FM_T(sb);
+    FC_FM_ADD(2, sb - sa);
+    FC_FM_ADD(5, 1);
+    FC_FM_ADD(6, nc);
+    // (2) per candidate window: the rows that come near it (lane = row)
+    for (int c = wv; c < nc; c += 4) {
+      const int64_t wc = wb + cand[c];
+      const int64_t w_end = (wc + 1) * WIN < N ? (wc + 1) * WIN : N;
+      // (a lower bound, in 16-bit units, of the TFD of the row to any column of the window: see k_tfd_window_bounds_f64)
+      const uint4 bc = cbox[c][0], bh = cbox[c][1];
+      fc_us2 acc = box_gap_u16x2(my_u.x, bc.x, bh.x, (fc_us2)(0));
+      acc = box_gap_u16x2(my_u.y, bc.y, bh.y, acc);
+      acc = box_gap_u16x2(my_u.z, bc.z, bh.z, acc);
+      acc = box_gap_u16x2(my_u.w, bc.w, bh.w, acc);
+      const int lbu = (int)acc.x + (int)acc.y;
+      const uint64_t m = __ballot(my_from < (long long)w_end && lbu < t_hi);
+      if (lane == 0) wmask[c] = m;
+    }
+    __syncthreads();
+    // ... and of those the ones that have a row (a few of two hundred), compacted in order: act
+    {
+      const bool has = tid < nc && (wmask[tid] & alive) != 0ull;
+      nb = __ballot(has);
+      if (lane == 0) wave_n[wv] = __popcll(nb);
+      __syncthreads();
+      int abase = 0;
+      for (int v = 0; v < wv; ++v) abase += wave_n[v];
+      if (has) act[abase + __popcll(nb & ((1ull << lane) - 1ull))] = tid;
+    }
+    __syncthreads();
+    const int na = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+    FC_FM_T(sc);
+    FC_FM_ADD(3, sc - sb);
+    // (3) the windows with rows, four per turn
+    for (int a0 = 0; a0 < na; a0 += 4) {
+      const int c = a0 + wv < na ? act[a0 + wv] : -1;  // (wave-uniform)
+      unsigned long long m = c >= 0 ? (wmask[c] & alive) : 0ull;
+      if (m != 0ull) {
+        FC_FM_ADD(7, 1);
+        const int64_t jb = (wb + cand[c]) * WIN;
+        uint4 cu[4];
+        int jrel[4];  // column - jb, -1: none
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t j = jb + u * 64 + lane;
+          const bool on = j < N;
+          cu[u] = tfU[on ? j : N - 1];
+          jrel[u] = on ? u * 64 + lane : -1;
+        }
+        while (m) {
+          const int r = __builtin_ctzll(m);
+          m &= m - 1ull;
+          // (columns before the row's `from` were looked at by the dense phase)
+          const long long fr = row_from[r] - jb - 1;
+          const int fr_rel = fr < -1 ? -1 : (int)fr;
+          const uint4 rw = rowsU[r];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            bool hit = false;
+            if (jrel[u] > fr_rel) {
+              const int s = (int)sad_u16x8<ND>(cu[u], rw);
+              hit = s < t_lo || (s < t_hi && tfd_similar_exact(rows + r * Q, 1, tfT + jb + jrel[u], Npad, Q, thresh));
+            }
+            const uint64_t b = __ballot(hit);  // columns increase with u, then with the lane: the first hit is the lowest
+            if (b != 0ull) {
+              if (lane == __builtin_ctzll(b)) atomicMin(&lbest[r], (unsigned long long)(jb + jrel[u]));
+              break;  // (uniform)
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const unsigned long long al = __ballot(lbest[tid] == ~0ull) & alive;
+        if (tid == 0) alive_s = al;
+      }
+      __syncthreads();
+      alive = alive_s;
+      if (alive == 0ull) break;
+    }
+    __syncthreads();  // (cand / wmask / act are rewritten by the next step)
+    FC_FM_T(sd);
+    FC_FM_ADD(4, sd - sc);
+  }
+  if (tid < 64 && row_i[tid] >= 0) first_match[row_i[tid]] = lbest[tid] == ~0ull ? -1 : (int64_t)lbest[tid];
+  FC_FM_T(se);
+  FC_FM_ADD(9, se - st0);
+  FC_FM_MAX(8, se - st0);
+  FC_FM_MIN(11, st0);
+  FC_FM_MAX(12, se);
+}
+
+// ---------------------------------------------------------------------------
 // Sequential "is_new_structure" filter of string_embed (embeds.py:59-84): a pose
 // that passed the clash test is kept iff its fingerprint is not TFD-similar to
 // any fingerprint KEPT so far (the cache is never trimmed).  Exact, chunked:
@@ -1267,13 +1706,6 @@ int launch_tfd_first_match(const double *tfT_dev, int64_t N, int64_t Npad, int64
     const char *v = getenv("FC_TFD_F32_COPY");
     return !(v && v[0] == '0');
   }();
-  if (use_copy && tfF_scratch != nullptr) {
-    const int64_t n = std::min<int64_t>(Q, 8) * Npad;
-    hipLaunchKernelGGL(k_tfd_prefilter_copy, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, tfT_dev, n,
-                       tfF_scratch);
-    FC_TRY(check_launch("k_tfd_prefilter_copy"));
-    tfF_dev = tfF_scratch;
-  }
   // two phases for long arrays: bounded look-ahead per row block, then the rows still open against column
   // chunks (FC_TFD_LOOKAHEAD: columns, 0 = one phase; needs the fp32 copy)
   // (measured at 1.7 M structures, whole call incl. the upload: one phase 59 ms; look-ahead 4 096: 11.7 ms,
@@ -1281,18 +1713,106 @@ int launch_tfd_first_match(const double *tfT_dev, int64_t N, int64_t Npad, int64
   int64_t lookahead_env = 4096;
   bool forced = false;
   if (const char *v = getenv("FC_TFD_LOOKAHEAD")) lookahead_env = (int64_t)std::strtoll(v, nullptr, 10), forced = true;  // (per call: test knob)
-  const bool two_phase = tfF_dev != nullptr && lookahead_env > 0 && (forced ? N > 8 * lookahead_env : N >= 65536);
+  const bool two_phase = tfF_scratch != nullptr && use_copy && lookahead_env > 0 && (forced ? N > 8 * lookahead_env : N >= 65536);
   const int64_t max_ahead = two_phase ? lookahead_env : 0;
-  DevBuf left;  // [count | rows x N | from x N | best x N]: released to the pool at return, reused in stream order
+  DevBuf left;  // [counts, flag | rows | from | best x N | boxes | 16-bit angles]: released to the pool at return
   unsigned long long *left_count = nullptr, *best_dev = nullptr;
   int64_t *left_rows = nullptr, *left_from = nullptr;
+  const int64_t n_win = ceil_div(N, 1024);
+  const int qf4 = (int)std::min<int64_t>(Q, 4);
+  float *wlo = nullptr, *whi = nullptr;
+  bool use_u16 = true;
+  if (const char *v = getenv("FC_TFD_U16")) use_u16 = v[0] != '0';  // 0: the fp32 pre-filter kernels (per call: test knob)
+  const bool u16 = two_phase && use_u16 && N < ((int64_t)1 << 31) - (1 << 20);
+  constexpr int kHead = 32;  // counters (one, or kFmShards) and the flag of the 16-bit path
+  const int64_t list_cap = u16 ? std::max<int64_t>(N, kFmShards * fm_shard_cap(N)) : N;
+  const int64_t n_winw = ceil_div(N, 256);
   if (two_phase) {
-    FC_TRY(left.reserve((size_t)(3 * N + 8) * sizeof(int64_t) + (size_t)(8 * ceil_div(N, 1024) + 16) * sizeof(float)));
+    const size_t boxes = (size_t)(16 * n_winw + 32) * sizeof(float) + (size_t)(2 * n_winw + 2) * sizeof(uint4);  // (those of the 16-bit walk)
+    FC_TRY(left.reserve((size_t)(2 * list_cap + N + kHead) * sizeof(int64_t) + boxes + (u16 ? (size_t)Npad * sizeof(uint4) + 16 : 0)));
     left_count = left.as<unsigned long long>();
-    left_rows = reinterpret_cast<int64_t *>(left_count + 8);
-    left_from = left_rows + N;
-    best_dev = reinterpret_cast<unsigned long long *>(left_from + N);
-    FC_HIP_TRY(hipMemsetAsync(left_count, 0, 8 * sizeof(unsigned long long), ctx().stream));
+    left_rows = reinterpret_cast<int64_t *>(left_count + kHead);
+    left_from = left_rows + list_cap;
+    best_dev = reinterpret_cast<unsigned long long *>(left_from + list_cap);
+    wlo = reinterpret_cast<float *>(best_dev + N), whi = wlo + 4 * n_win;
+    FC_HIP_TRY(hipMemsetAsync(left_count, 0, kHead * sizeof(unsigned long long), ctx().stream));
+  }
+  if (u16) {
+    // 16-bit angles (see k_tfd_pack_u16): a dense phase right behind every block of rows, then ONE ordered walk per
+    // 64 open rows over windows of 256 columns
+    // (dense phase of 32 / 64 / 128 / 256 columns at 1.7 M structures: 0.33 + 1.03 / 0.35 + 0.96 / 0.39 + 0.92 /
+    // 0.51 + 0.82 ms for the two kernels)
+    const int64_t ahead = forced ? lookahead_env : 128;
+    const int qf8 = (int)std::min<int64_t>(Q, 8);
+    float *blo = wlo, *bhi = blo + 8 * n_winw;
+    uint4 *wbu = reinterpret_cast<uint4 *>((reinterpret_cast<uintptr_t>(bhi + 8 * n_winw + 16) + 15) & ~(uintptr_t)15);
+    uint4 *tfU = wbu + 2 * n_winw;
+    hipLaunchKernelGGL(k_tfd_pack_u16, dim3((unsigned)ceil_div(Npad, 256)), block, 0, ctx().stream, tfT_dev, N, Npad, (int)Q,
+                       tfU, left_count);
+    FC_TRY(check_launch("k_tfd_pack_u16"));
+    hipLaunchKernelGGL(k_tfd_window_bounds_f64, dim3((unsigned)n_winw), block, 0, ctx().stream, tfT_dev, N, Npad, qf8, n_winw,
+                       blo, bhi, wbu);
+    FC_TRY(check_launch("k_tfd_window_bounds_f64"));
+    // thresholds in 16-bit units (the bounds are derived at k_tfd_pack_u16)
+    int t_lo = 0, t_hi = 0;
+    if (thresh > 0.0) {
+      const double ts = std::min(thresh * (65536.0 / 360.0), 300000.0);
+      t_hi = (int)std::ceil(ts) + 10;
+      t_lo = Q <= 8 ? std::max(0, (int)std::floor(ts) - 10) : 0;
+    }
+#define FC_FMU(QT)                                                                                                   \
+  case QT:                                                                                                           \
+    hipLaunchKernelGGL(k_tfd_first_match_dense_u16<QT>, grid, block, 0, ctx().stream, tfT_dev, tfU, N, Npad, (int)Q, \
+                       thresh, t_lo, t_hi, fm_dev, ahead, left_count, left_rows, left_from);                         \
+    break;
+    switch (Q) {
+      FC_FMU(1) FC_FMU(2) FC_FMU(3) FC_FMU(4) FC_FMU(5) FC_FMU(6) FC_FMU(7) FC_FMU(8)
+      default:
+        hipLaunchKernelGGL(k_tfd_first_match_dense_u16<0>, grid, block, 0, ctx().stream, tfT_dev, tfU, N, Npad, (int)Q,
+                           thresh, t_lo, t_hi, fm_dev, ahead, left_count, left_rows, left_from);
+    }
+#undef FC_FMU
+    FC_TRY(check_launch("k_tfd_first_match_dense_u16"));
+    unsigned long long head[kFmShards + 1] = {0};
+    FC_TRY(d2h(head, left_count, sizeof head));
+    FC_TRY(sync());
+    FmShards sh;
+    unsigned long long n_left = 0;
+    sh.wg_begin[0] = 0;
+    for (int k = 0; k < kFmShards; ++k) {
+      sh.count[k] = (unsigned)head[k];
+      sh.wg_begin[k + 1] = sh.wg_begin[k] + (unsigned)ceil_div((int64_t)head[k], 64);
+      n_left += head[k];
+    }
+    if (getenv("FC_DEBUG"))
+      fprintf(stderr, "[fc] tfd first match (16-bit angles%s): %llu of %lld rows open after the dense phase of %lld columns\n",
+              head[kFmShards] ? ": REFUSED, angles beyond +-270 or not finite" : "", n_left, (long long)N, (long long)ahead);
+    if (head[kFmShards] == 0ull) {
+      if (n_left == 0) return FC_OK;
+      const dim3 rgrid(sh.wg_begin[kFmShards]);
+#define FC_FMW(QT)                                                                                                      \
+  case QT:                                                                                                              \
+    hipLaunchKernelGGL(k_tfd_first_match_walk_u16<QT>, rgrid, block, lds, ctx().stream, tfT_dev, tfU, N, Npad, (int)Q,  \
+                       thresh, t_lo, t_hi, sh, left_rows, left_from, blo, bhi, wbu, n_winw, fm_dev);                         \
+    break;
+      switch (Q) {
+        FC_FMW(1) FC_FMW(2) FC_FMW(3) FC_FMW(4) FC_FMW(5) FC_FMW(6) FC_FMW(7) FC_FMW(8)
+        default:
+          hipLaunchKernelGGL(k_tfd_first_match_walk_u16<0>, rgrid, block, lds, ctx().stream, tfT_dev, tfU, N, Npad, (int)Q,
+                             thresh, t_lo, t_hi, sh, left_rows, left_from, blo, bhi, wbu, n_winw, fm_dev);
+      }
+#undef FC_FMW
+      return check_launch("k_tfd_first_match_walk_u16");
+    }
+    // refused: the fp32 kernels below redo the whole array
+    FC_HIP_TRY(hipMemsetAsync(left_count, 0, kHead * sizeof(unsigned long long), ctx().stream));
+  }
+  if (use_copy && tfF_scratch != nullptr) {
+    const int64_t n = std::min<int64_t>(Q, 8) * Npad;
+    hipLaunchKernelGGL(k_tfd_prefilter_copy, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, tfT_dev, n,
+                       tfF_scratch);
+    FC_TRY(check_launch("k_tfd_prefilter_copy"));
+    tfF_dev = tfF_scratch;
   }
 #define FC_FM(QT)                                                                                  \
   case QT:                                                                                         \
@@ -1318,9 +1838,6 @@ int launch_tfd_first_match(const double *tfT_dev, int64_t N, int64_t Npad, int64
   const int64_t chunk = 65536;
   const dim3 rgrid((unsigned)ceil_div((int64_t)n_left, 64), (unsigned)ceil_div(N, chunk));
   // bounding boxes of the pre-filter angles per window of 1024 columns (behind `best` in the same block)
-  const int64_t n_win = ceil_div(N, 1024);
-  const int qf4 = (int)std::min<int64_t>(Q, 4);
-  float *wlo = reinterpret_cast<float *>(best_dev + N), *whi = wlo + 4 * n_win;
   hipLaunchKernelGGL(k_tfd_window_bounds, dim3((unsigned)n_win), block, 0, ctx().stream, tfF_dev, N, Npad, qf4, n_win, wlo, whi);
   FC_TRY(check_launch("k_tfd_window_bounds"));
 #define FC_FMR(QT)                                                                                          \
@@ -1341,6 +1858,18 @@ int launch_tfd_first_match(const double *tfT_dev, int64_t N, int64_t Npad, int64
                      left_rows, best_dev, fm_dev);
   return check_launch("k_tfd_first_match_merge");
 }
+
+#if defined(FC_TFD_STAMPS)
+extern "C" int fc_debug_fm_stamps(unsigned long long *out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fm_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    z[11] = ~0ull;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fm_stamps), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 int launch_tfd_simbits(const double *tf_dev, int64_t N, int64_t Q, double thresh, int64_t row_begin,
                        int64_t row_end, uint64_t *bits_dev, int64_t W) {

@@ -617,7 +617,67 @@ def test_tfd_first_match_two_phases(fc, monkeypatch, q):
     assert (ref < 0).sum() > 100 and ((ref - np.arange(n))[ref >= 0] > 1000).sum() > 50
     # angles at the wrap-around (+-180) as well: the window boxes and the deltas have to agree there
     assert (np.abs(tf) > 175).any()
-    for look in ("0", "64", "640", None):
+    # (two phases: 16-bit angles -- a dense phase, then the ordered walk over windows -- or, FC_TFD_U16=0, the fp32
+    # pre-filter kernels with column chunks)
+    for u16 in (None, "0"):
+        if u16 is None:
+            monkeypatch.delenv("FC_TFD_U16", raising=False)
+        else:
+            monkeypatch.setenv("FC_TFD_U16", u16)
+        for look in ("0", "64", "640", None):
+            if look is None:
+                monkeypatch.delenv("FC_TFD_LOOKAHEAD", raising=False)
+            else:
+                monkeypatch.setenv("FC_TFD_LOOKAHEAD", look)
+            fm = np.zeros(n, dtype=np.int64)
+            L.call("fc_tfd_first_match", L.pf(np.ascontiguousarray(tf)), n, q, 10.0, L.pi(fm))
+            assert np.array_equal(fm, ref), (u16, look)
+
+
+def _first_match_numpy(tf, thresh):
+    n = len(tf)
+    ref = np.full(n, -1, dtype=np.int64)
+    for i in range(n - 1):
+        d = np.abs(tf[i + 1:] - tf[i])
+        d = np.abs(d - (d > 180) * 360)
+        hit = np.flatnonzero(d.sum(axis=1) < thresh)
+        if len(hit):
+            ref[i] = i + 1 + hit[0]
+    return ref
+
+
+@pytest.mark.parametrize("q", [3, 8, 9])
+def test_tfd_first_match_16bit_band_wrap_and_refusal(fc, monkeypatch, q):
+    """The 16-bit first-match kernels (k_tfd_first_match_dense_u16 / _walk_u16) decide a pair from the sum of absolute
+    differences of 16-bit angles only outside a band of +-10 units (0.055 deg) around the threshold: pairs planted AT
+    the threshold (sum = 10 -+ 1e-9 ... 0.07) must come out as the fp64 sum in NumPy's order says, next to the dense
+    phase (partners a few rows away), in the walk (thousands of rows away), across the +-180 wrap; fingerprints the
+    16 bits cannot stand for (an angle beyond +-270, a NaN) are refused by the kernels and redone by the fp32 ones
+    (reference: torsion_module.py:1056-1067 through `_first_match_numpy`)"""
+    from firecode_amd import _lib as L
+
+    rng = np.random.default_rng(900 + q)
+    n = 5000
+    tf = rng.uniform(-180, 180, size=(n, q))  # far from each other: no accidental partners
+    eps = [0.0, 1e-9, -1e-9, 3e-3, -3e-3, 0.02, -0.02, 0.05, -0.05, 0.07, -0.07, 0.5, -0.5]
+    rows = rng.choice(n - 4200, size=len(eps) * 3, replace=False)
+    planted = []
+    for k, i in enumerate(rows):
+        e = eps[k % len(eps)]
+        gap = (3, 700, 4100)[k // len(eps)]  # dense phase / a few windows on / many windows on
+        w = rng.dirichlet(np.ones(q)) * (10.0 + e)
+        sign = rng.choice([-1.0, 1.0], size=q)
+        j = i + gap
+        tf[j] = tf[i] + sign * w
+        planted.append((i, j))
+    # two planted pairs across the wrap
+    tf[100] = 179.0
+    tf[4000] = -179.5
+    tf[4000, 0] = -178.0  # sum = 1.5 (q - 1) + 3.0 < 10 only for small q: both outcomes occur over the parametrisation
+    tf = (tf + 180) % 360 - 180
+    ref = _first_match_numpy(tf, 10.0)
+    assert sum(ref[i] == j for i, j in planted) >= len(planted) // 3 and sum(ref[i] != j for i, j in planted) >= len(planted) // 4
+    for look in ("32", "512", None):  # (None: one phase at this size -- the fp32 kernel)
         if look is None:
             monkeypatch.delenv("FC_TFD_LOOKAHEAD", raising=False)
         else:
@@ -625,6 +685,23 @@ def test_tfd_first_match_two_phases(fc, monkeypatch, q):
         fm = np.zeros(n, dtype=np.int64)
         L.call("fc_tfd_first_match", L.pf(np.ascontiguousarray(tf)), n, q, 10.0, L.pi(fm))
         assert np.array_equal(fm, ref), look
+    # refusal: the reference's delta is not the circular distance beyond |a - b| = 540, and NaN is similar to nothing
+    monkeypatch.setenv("FC_TFD_LOOKAHEAD", "64")
+    for bad in (300.0, -512.0, np.nan):
+        tf2 = tf.copy()
+        tf2[1234, q - 1] = bad
+        tf2[10, 0] = 271.0 if np.isnan(bad) else tf2[10, 0]
+        with np.errstate(invalid="ignore"):
+            ref2 = _first_match_numpy(tf2, 10.0)
+        fm = np.zeros(n, dtype=np.int64)
+        L.call("fc_tfd_first_match", L.pf(np.ascontiguousarray(tf2)), n, q, 10.0, L.pi(fm))
+        assert np.array_equal(fm, ref2), bad
+    # thresholds beside the usual one, zero and negative included (nothing is similar)
+    for thr in (0.0, -1.0, 0.3, 40.0):
+        refT = _first_match_numpy(tf, thr)
+        fm = np.zeros(n, dtype=np.int64)
+        L.call("fc_tfd_first_match", L.pf(np.ascontiguousarray(tf)), n, q, float(thr), L.pi(fm))
+        assert np.array_equal(fm, refT), thr
 
 
 def test_scan_tfd_fused_equals_scan_then_prune(fc):
