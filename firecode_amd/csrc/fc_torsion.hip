@@ -78,6 +78,15 @@ __device__ __forceinline__ void rotate_masked(double *x, int A, const uint8_t *m
 // the only value the reference ever passes: torsion_module.py:827,838)
 // pre_r / pre_m (may be nullptr): the lane's (rest, moving) atom of the first kPrePairs rounds of 64 pairs, worked out once by
 // a caller that checks the same torsion again and again (k_ts_level: one torsion per launch)
+#if defined(FC_TFD_STAMPS)
+// tuning build: counters of the scan tree's last level (tools/ts_stamps.py)
+__device__ unsigned long long g_ts_stamps[16];
+#define FC_TS_ADD(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_ts_stamps[k], (unsigned long long)(v)); } while (0)
+#define FC_TS_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define FC_TS_ADD(k, v) do { } while (0)
+#define FC_TS_NOW() 0ull
+#endif
 constexpr int kPrePairs = 4;
 template <class IdxPtr>
 __device__ __forceinline__ bool comp_check(const double *x, IdxPtr mv, int nmv, IdxPtr rs, int nrs, double thr2, int lane,
@@ -121,25 +130,32 @@ __device__ __forceinline__ double dihedral_deg(const double *p0, const double *p
 
 // One torsion step of the scan (torsion_module.py:826-846): rotate by `angle`; on a clash step back by `backoff` degrees up
 // to angle // backoff times until the clash is gone.  Returns 1 when the bond ends up rotated.
+// sc_angle / sc_back (may be nullptr): {sin, cos} of half the angle / of half the back-off step, taken from a table by a
+// caller that meets the same few angles again and again (k_ts_level) -- half_angle_sincos of the same argument
 template <class MaskPtr, class IdxPtr>
 __device__ __forceinline__ int torsion_step(double *x, int A, MaskPtr mask, IdxPtr mv, int nm, IdxPtr rs, int nr, int i2, int i3,
                                             int angle, int backoff, double thr2, int lane, const int *pre_r = nullptr,
-                                            const int *pre_m = nullptr) {
+                                            const int *pre_m = nullptr, const double *sc_angle = nullptr,
+                                            const double *sc_back = nullptr) {
   double sn, cs;
-  half_angle_sincos((double)angle, sn, cs);
+  if (sc_angle != nullptr) sn = sc_angle[0], cs = sc_angle[1];
+  else half_angle_sincos((double)angle, sn, cs);
   rotate_masked_sc(x, A, mask, i2, i3, sn, cs, lane);
   if (comp_check(x, mv, nm, rs, nr, thr2, lane, pre_r, pre_m)) return 1;
   int steps = angle / backoff;  // Python floor division: range(angle // backoff)
   if ((angle % backoff != 0) && ((angle < 0) != (backoff < 0))) --steps;
   if (steps <= 0) return 0;
-  half_angle_sincos((double)(-backoff), sn, cs);  // once for all the steps
+  if (sc_back != nullptr) sn = sc_back[0], cs = sc_back[1];
+  else half_angle_sincos((double)(-backoff), sn, cs);  // once for all the steps
   if (!mask[i2] && !mask[i3]) {
     // the two axis atoms stay where they are, so every step applies the SAME matrix about the same point: built once
     // (from the same numbers by the same operations: the steps' coordinates keep their bits)
     const double cx = x[i3 * 3], cy = x[i3 * 3 + 1], cz = x[i3 * 3 + 2];
     double M[9];
     rot_from_axis_sincos(x[i2 * 3] - cx, x[i2 * 3 + 1] - cy, x[i2 * 3 + 2] - cz, sn, cs, M);
+    FC_TS_ADD(2, 1);
     for (int b = 0; b < steps; ++b) {
+      FC_TS_ADD(3, 1);
       __builtin_amdgcn_wave_barrier();
       for (int a = lane; a < A; a += 64) {
         if (mask[a]) {
@@ -469,6 +485,17 @@ k_ts_first(const uint8_t *__restrict__ d, const int *__restrict__ nid, int64_t S
   if (i == S - 1) first[nid[i]] = (int)S;
 }
 
+// LDS of k_ts_level beside the four conformers: the level's index lists and mask, a table of the half-angle sines and
+// cosines of the level's angles, and per wavefront the points of up to 64 dihedrals waiting for their turn
+constexpr int kTsScTab = 64;
+__host__ __device__ inline size_t ts_level_lds(int A) {
+  return (size_t)4 * A * 3 * sizeof(double)                // conformers
+         + (size_t)(kTsScTab + 1) * 2 * sizeof(double)     // sincos table, the back-off step's behind it
+         + (size_t)4 * 12 * 64 * sizeof(double)            // dihedral points [wave][12][64]
+         + (size_t)4 * 64 * 2 * sizeof(int)                // rows of the waiting conformers [wave][2][64]
+         + (size_t)A * 5 + 16;
+}
+
 __global__ void __launch_bounds__(256)
 k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ torsions, int T, int level,
            const uint8_t *__restrict__ rotmasks, const int16_t *__restrict__ mv_idx, const int16_t *__restrict__ rs_idx,
@@ -477,10 +504,13 @@ k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ t
            const int *__restrict__ nid, const int *__restrict__ first, const double *__restrict__ state_prev,
            const int *__restrict__ rot_prev, double *__restrict__ state, int *__restrict__ rot_out,
            double *__restrict__ out, int64_t *__restrict__ rotated, const int64_t *__restrict__ quads, int Q,
-           double *__restrict__ tf) {
+           double *__restrict__ tf, const unsigned *__restrict__ present, const uint16_t *__restrict__ rank, int n_angles) {
   extern __shared__ double s[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double *x = s + (size_t)wv * A * 3;
+  double *sc_tab = s + (size_t)4 * A * 3;                       // [kTsScTab + 1][2]
+  double *pts = sc_tab + (kTsScTab + 1) * 2 + (size_t)wv * 12 * 64;  // [12][64]
+  int *wait_rows = reinterpret_cast<int *>(sc_tab + (kTsScTab + 1) * 2 + (size_t)4 * 12 * 64) + wv * 128;  // [2][64]
   const int64_t M = nid[S - 1];  // inclusive scan: number of nodes of this level
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
   const int t = level;
@@ -488,13 +518,30 @@ k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ t
   const int nm = n_mv[t], nr = n_rs[t];
   // the level's ONE torsion: its rotation mask and its moving / rest index lists are read in every step of every
   // back-off loop (up to 60 per node) -- from LDS, not through the vector cache
-  int16_t *mv = reinterpret_cast<int16_t *>(s + (size_t)4 * A * 3);
+  int16_t *mv = reinterpret_cast<int16_t *>(wait_rows - wv * 128 + 4 * 128);
   int16_t *rs = mv + A;
   uint8_t *mask = reinterpret_cast<uint8_t *>(rs + A);
   for (int k = threadIdx.x; k < A; k += 256) {
     mv[k] = mv_idx[(size_t)t * A + k];
     rs[k] = rs_idx[(size_t)t * A + k];
     mask[k] = rotmasks[(size_t)t * A + k];
+  }
+  // the level's few angles (six in a six-fold scan) meet every node: sine and cosine of half of each once per
+  // workgroup instead of once per node, the back-off step's as well (same function, same argument: same bits)
+  const bool tab = n_angles <= kTsScTab;
+  if (tab)
+    for (int v = threadIdx.x; v < kAngleSpan; v += 256)
+      if ((present[t * kAngleWords + (v >> 5)] >> (v & 31)) & 1u) {
+        double sn, cs;
+        half_angle_sincos((double)(v - kAngleOffset), sn, cs);
+        sc_tab[2 * rank[t * kAngleSpan + v]] = sn;
+        sc_tab[2 * rank[t * kAngleSpan + v] + 1] = cs;
+      }
+  if (threadIdx.x == 0) {
+    double sn, cs;
+    half_angle_sincos((double)(-backoff), sn, cs);
+    sc_tab[2 * kTsScTab] = sn;
+    sc_tab[2 * kTsScTab + 1] = cs;
   }
   __syncthreads();
   int pre_r[kPrePairs], pre_m[kPrePairs];  // this lane's pairs of the first rounds of every clash check of the level
@@ -505,14 +552,39 @@ k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ t
     pre_m[q] = p < nm * nr ? mv[p % nm] : 0;
   }
   const bool last = level == T - 1;
+  // fingerprints of the last level: a conformer's Q dihedrals on Q lanes would run the long chain (two square roots,
+  // three divisions, atan2) at Q / 64 of the machine; the points of 64 / Q conformers wait in LDS instead and are
+  // turned into angles together
+  const int per_turn = (tf != nullptr && Q > 0 && Q <= 64) ? 64 / Q : 0;
+  int waiting = 0;
+  auto flush = [&]() {
+    __builtin_amdgcn_wave_barrier();
+    if (lane < waiting * Q) {
+      double p[12];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) p[c] = pts[c * 64 + lane];
+      const double d = dihedral_deg(p, p + 3, p + 6, p + 9);
+      const int slot = lane / Q, q = lane - slot * Q;
+      for (int ii = wait_rows[slot]; ii < wait_rows[64 + slot]; ++ii) tf[(int64_t)row[ii] * Q + q] = d;
+    }
+    __builtin_amdgcn_wave_barrier();
+    waiting = 0;
+  };
   for (int64_t node = wave0; node < M; node += nwaves) {
+    const unsigned long long ts0 = FC_TS_NOW();
     const int i = first[node];
     const double *src = level == 0 ? base : state_prev + (int64_t)(nid_prev[i] - 1) * A * 3;
     for (int k = lane; k < A * 3; k += 64) x[k] = src[k];
     __builtin_amdgcn_wave_barrier();
     int rot = level == 0 ? 0 : rot_prev[nid_prev[i] - 1];
     const int angle = (int)angles[(int64_t)row[i] * T + t];
-    if (angle != 0) rot += torsion_step(x, A, mask, mv, nm, rs, nr, i2, i3, angle, backoff, thr2, lane, pre_r, pre_m);
+    const unsigned long long ts1 = FC_TS_NOW();
+    if (last) { FC_TS_ADD(0, 1); FC_TS_ADD(4, ts1 - ts0); if (angle != 0) FC_TS_ADD(1, 1); }
+    if (angle != 0)
+      rot += torsion_step(x, A, mask, mv, nm, rs, nr, i2, i3, angle, backoff, thr2, lane, pre_r, pre_m,
+                          tab ? sc_tab + 2 * rank[t * kAngleSpan + angle + kAngleOffset] : nullptr, sc_tab + 2 * kTsScTab);
+    const unsigned long long ts2 = FC_TS_NOW();
+    if (last) FC_TS_ADD(5, ts2 - ts1);
     if (!last) {
       double *o = state + node * (int64_t)A * 3;
       for (int k = lane; k < A * 3; k += 64) o[k] = x[k];
@@ -525,16 +597,38 @@ k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ t
           double *o = out + r * (int64_t)A * 3;
           for (int k = lane; k < A * 3; k += 64) o[k] = x[k];
         }
-        if (tf != nullptr)
+        if (tf != nullptr && per_turn == 0)
           for (int q = lane; q < Q; q += 64)
             tf[r * (int64_t)Q + q] = dihedral_deg(x + quads[q * 4] * 3, x + quads[q * 4 + 1] * 3,
                                                   x + quads[q * 4 + 2] * 3, x + quads[q * 4 + 3] * 3);
         if (lane == 0) rotated[r] = rot;
       }
+      if (per_turn > 0) {
+        if (lane < Q) {
+          const int at = waiting * Q + lane;
+#pragma unroll
+          for (int c = 0; c < 12; ++c) pts[c * 64 + at] = x[quads[lane * 4 + c / 3] * 3 + c % 3];
+        }
+        if (lane == 0) wait_rows[waiting] = i, wait_rows[64 + waiting] = i_end;
+        if (++waiting == per_turn) flush();
+      }
     }
     __builtin_amdgcn_wave_barrier();
+    if (last) FC_TS_ADD(6, FC_TS_NOW() - ts2);
   }
+  if (waiting > 0) flush();
 }
+
+#if defined(FC_TFD_STAMPS)
+extern "C" int fc_debug_ts_stamps(unsigned long long *out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ts_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ts_stamps), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 // returns FC_OK when the tree did the scan, 1 when it does not apply (the caller runs k_torsion_scan)
 static int torsion_scan_tree(const double *base_dev, int64_t A, const int64_t *torsions_dev, int64_t T,
@@ -591,6 +685,10 @@ static int torsion_scan_tree(const double *base_dev, int64_t A, const int64_t *t
   FC_TRY(drotn[0].reserve((size_t)(max_state_nodes + 1) * 4));
   FC_TRY(drotn[1].reserve((size_t)(max_state_nodes + 1) * 4));
   const unsigned gb = (unsigned)ceil_div(S, 256);
+  if (ts_level_lds((int)A) > ((size_t)160 << 10)) return 1;
+  if (ts_level_lds((int)A) > ((size_t)64 << 10))
+    FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ts_level), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)ts_level_lds((int)A)));
   hipLaunchKernelGGL(k_ts_codes, dim3(gb), dim3(256), 0, st, angles_dev, S, (int)T, drank.as<uint16_t>(),
                      dmeta.as<ScanTreeMeta>(), dcode.as<uint64_t>(), drow.as<uint32_t>());
   FC_TRY(check_launch("k_ts_codes"));
@@ -616,11 +714,12 @@ static int torsion_scan_tree(const double *base_dev, int64_t A, const int64_t *t
                        dfirst.as<int>());
     const int64_t nodes = bound[(size_t)level];
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(nodes, 4), (int64_t)ctx().n_cu * 32));
-    hipLaunchKernelGGL(k_ts_level, dim3((unsigned)blocks), dim3(256), (size_t)4 * A * 3 * sizeof(double) + (size_t)A * 5 + 16, st, base_dev,
+    hipLaunchKernelGGL(k_ts_level, dim3((unsigned)blocks), dim3(256), ts_level_lds((int)A), st, base_dev,
                        (int)A, torsions_dev, (int)T, level, rotmasks_dev, mv_dev, rs_dev, nmv_dev, nrs_dev, angles_dev, S,
                        thr2, (int)backoff, drow2.as<uint32_t>(), nid_prev.as<int>(), nid.as<int>(), dfirst.as<int>(),
                        dstate[(level & 1) ^ 1].as<double>(), drotn[(level & 1) ^ 1].as<int>(), dstate[level & 1].as<double>(),
-                       drotn[level & 1].as<int>(), out_dev, rot_dev, quads_dev, (int)Q, tf_dev);
+                       drotn[level & 1].as<int>(), out_dev, rot_dev, quads_dev, (int)Q, tf_dev, dpres.as<unsigned>(),
+                       drank.as<uint16_t>(), meta.n[level]);
     FC_TRY(check_launch("k_ts_level"));
   }
   return sync();  // the temporaries above go back to the pool only after the kernels have used them
