@@ -82,7 +82,7 @@ __device__ __forceinline__ void rotate_masked(double *x, int A, const uint8_t *m
 // tuning build: counters of the scan tree's last level (tools/ts_stamps.py)
 __device__ unsigned long long g_ts_stamps[16];
 #define FC_TS_ADD(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_ts_stamps[k], (unsigned long long)(v)); } while (0)
-#define FC_TS_NOW() __builtin_amdgcn_s_memtime()
+#define FC_TS_NOW() wall_clock64()
 #else
 #define FC_TS_ADD(k, v) do { } while (0)
 #define FC_TS_NOW() 0ull
@@ -131,12 +131,14 @@ __device__ __forceinline__ double dihedral_deg(const double *p0, const double *p
 // One torsion step of the scan (torsion_module.py:826-846): rotate by `angle`; on a clash step back by `backoff` degrees up
 // to angle // backoff times until the clash is gone.  Returns 1 when the bond ends up rotated.
 // sc_angle / sc_back (may be nullptr): {sin, cos} of half the angle / of half the back-off step, taken from a table by a
-// caller that meets the same few angles again and again (k_ts_level) -- half_angle_sincos of the same argument
+// caller that meets the same few angles again and again (k_ts_level) -- half_angle_sincos of the same argument;
+// cs_steps (may be nullptr): {cos, sin} of b back-off angles, b = 1 .. kBackTab (see the closed form below)
+constexpr int kBackTab = 64;
 template <class MaskPtr, class IdxPtr>
 __device__ __forceinline__ int torsion_step(double *x, int A, MaskPtr mask, IdxPtr mv, int nm, IdxPtr rs, int nr, int i2, int i3,
                                             int angle, int backoff, double thr2, int lane, const int *pre_r = nullptr,
                                             const int *pre_m = nullptr, const double *sc_angle = nullptr,
-                                            const double *sc_back = nullptr) {
+                                            const double *sc_back = nullptr, const double *cs_steps = nullptr) {
   double sn, cs;
   if (sc_angle != nullptr) sn = sc_angle[0], cs = sc_angle[1];
   else half_angle_sincos((double)angle, sn, cs);
@@ -153,9 +155,93 @@ __device__ __forceinline__ int torsion_step(double *x, int A, MaskPtr mask, IdxP
     const double cx = x[i3 * 3], cy = x[i3 * 3 + 1], cz = x[i3 * 3 + 2];
     double M[9];
     rot_from_axis_sincos(x[i2 * 3] - cx, x[i2 * 3 + 1] - cy, x[i2 * 3 + 2] - cz, sn, cs, M);
-    FC_TS_ADD(2, 1);
+    // WHICH step ends the loop, without walking it.  A moving atom goes round a circle about the axis, so its squared
+    // distance to a resting atom after b steps is  c0 + c1 cos(b d) + c2 sin(b d)  (d = the back-off angle; R, P = the
+    // two atoms from the axis point, n the axis:  c0 = |R|^2 + |P|^2 - 2 (R.n)(P.n),  c1 = -2 (R.P - (R.n)(P.n)),
+    // c2 = 2 R.(n x P)  for the rotation by -d the matrix above makes).  Every lane holds its pairs' three numbers and
+    // tests step after step with two multiply-adds per pair -- against a rotation of the moving atoms through LDS
+    // and a clash check of all pairs per step (cfg3: 47 % of the 1.7 M leaves clash, 19 steps each: half the
+    // scan's time).  The closed form differs from the walked coordinates by roundings (<= 4e-14 (|R|^2 + |P|^2 + 1)
+    // over 60 steps, tools/ check in DESIGN 5.4); a pair within 1e-10 (|R|^2 + |P|^2 + 1) of the threshold at any step
+    // looked at sends the node to the loop below, which decides as before.  The step found, the moving atoms are
+    // turned that many times by the same operations as the loop's: same coordinates, bit for bit.
+    const int total_pairs = nm * nr;
+    if (pre_r != nullptr && cs_steps != nullptr && steps <= kBackTab && total_pairs <= kPrePairs * 64) {
+      const double ax = x[i2 * 3] - cx, ay = x[i2 * 3 + 1] - cy, az = x[i2 * 3 + 2] - cz;
+      const double nrm = sqrt((ax * ax + ay * ay) + az * az);
+      const double nx = ax / nrm, ny = ay / nrm, nz = az / nrm;
+      double c0[kPrePairs], c1[kPrePairs], c2[kPrePairs], gd[kPrePairs];
+#pragma unroll
+      for (int q = 0; q < kPrePairs; ++q) {
+        c0[q] = 1.0e300, c1[q] = 0.0, c2[q] = 0.0, gd[q] = 0.0;  // (no pair: never a clash, never near)
+        if (q * 64 + lane < total_pairs) {
+          const int r = pre_r[q], m = pre_m[q];
+          const double Rx = x[r * 3] - cx, Ry = x[r * 3 + 1] - cy, Rz = x[r * 3 + 2] - cz;
+          const double Px = x[m * 3] - cx, Py = x[m * 3 + 1] - cy, Pz = x[m * 3 + 2] - cz;
+          const double Rn = Rx * nx + Ry * ny + Rz * nz, Pn = Px * nx + Py * ny + Pz * nz;
+          const double RP = Rx * Px + Ry * Py + Rz * Pz, S = (Rx * Rx + Ry * Ry + Rz * Rz) + (Px * Px + Py * Py + Pz * Pz);
+          const double kx = ny * Pz - nz * Py, ky = nz * Px - nx * Pz, kz = nx * Py - ny * Px;
+          c0[q] = S - 2.0 * Rn * Pn;
+          c1[q] = -2.0 * (RP - Rn * Pn);
+          c2[q] = 2.0 * (Rx * kx + Ry * ky + Rz * kz);
+          gd[q] = 1.0e-10 * (S + 1.0);
+        }
+      }
+      const int rounds = (total_pairs + 63) >> 6;
+      int found = 0;  // the first step without a clash; -1: undecided (a pair too near the threshold)
+      // eight steps per turn: their sixteen table values requested together, the pairs' tests in one straight line (a
+      // step at a time the loop was a chain of LDS round trips and branches: 8 us per clashing node at two wavefronts
+      // per SIMD), then the steps' verdicts in order
+      for (int b0 = 1; b0 <= steps && found == 0; b0 += 8) {
+        double cb[8], sb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int at = (b0 + u <= kBackTab ? b0 + u : kBackTab) - 1;
+          cb[u] = cs_steps[2 * at], sb[u] = cs_steps[2 * at + 1];
+        }
+        unsigned clash = 0u, near = 0u;  // bit u: this lane's pairs at step b0 + u
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int q = 0; q < kPrePairs; ++q) {
+            if (q >= rounds) break;  // (uniform)
+            const double d2 = fma(c2[q], sb[u], fma(c1[q], cb[u], c0[q]));
+            clash |= (d2 < thr2 ? 1u : 0u) << u;
+            near |= (fabs(d2 - thr2) < gd[q] ? 1u : 0u) << u;
+          }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (b0 + u > steps) break;  // (uniform)
+          if (__any((near >> u) & 1u)) {
+            found = -1;
+            break;
+          }
+          if (!__any((clash >> u) & 1u)) {
+            found = b0 + u;
+            break;
+          }
+        }
+      }
+      if (found >= 0) {
+        const int turns = found > 0 ? found : steps;
+        __builtin_amdgcn_wave_barrier();
+        for (int a = lane; a < A; a += 64) {
+          if (mask[a]) {
+            double X0 = x[a * 3], X1 = x[a * 3 + 1], X2 = x[a * 3 + 2];
+            for (int b = 0; b < turns; ++b) {
+              const double px = X0 - cx, py = X1 - cy, pz = X2 - cz;
+              X0 = ((M[0] * px + M[1] * py) + M[2] * pz) + cx;
+              X1 = ((M[3] * px + M[4] * py) + M[5] * pz) + cy;
+              X2 = ((M[6] * px + M[7] * py) + M[8] * pz) + cz;
+            }
+            x[a * 3] = X0, x[a * 3 + 1] = X1, x[a * 3 + 2] = X2;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        return found > 0 ? 1 : 0;
+      }
+    }
     for (int b = 0; b < steps; ++b) {
-      FC_TS_ADD(3, 1);
       __builtin_amdgcn_wave_barrier();
       for (int a = lane; a < A; a += 64) {
         if (mask[a]) {
@@ -491,26 +577,72 @@ constexpr int kTsScTab = 64;
 __host__ __device__ inline size_t ts_level_lds(int A) {
   return (size_t)4 * A * 3 * sizeof(double)                // conformers
          + (size_t)(kTsScTab + 1) * 2 * sizeof(double)     // sincos table, the back-off step's behind it
+         + (size_t)kBackTab * 2 * sizeof(double)           // cos, sin of b back-off angles
          + (size_t)4 * 12 * 64 * sizeof(double)            // dihedral points [wave][12][64]
-         + (size_t)4 * 64 * 2 * sizeof(int)                // rows of the waiting conformers [wave][2][64]
+         + (size_t)4 * 64 * 3 * sizeof(int)                // rows of the waiting conformers [wave][3][64]: run begin, end, row[begin]
          + (size_t)A * 5 + 16;
 }
 
+// What a node of a level needs before its work can start, gathered by k_ts_nodes so that k_ts_level reads ONE record
+// per node instead of walking first -> nid_prev / row -> angles / rot_prev -> state: four dependent global round
+// trips per node, with sixteen wavefronts per CU to hide them, were the kernel (14.7 us per node and wavefront at the
+// last level of cfg3 whatever the arithmetic did: neither the closed form of the back-off loop nor the batched
+// dihedrals moved it)
+struct TsNode {
+  int i, i_end;   // the node's run of sorted rows
+  int par;        // node of the previous level it continues (state_prev, rot_prev)
+  int angle, rot; // the level's angle for this node; bonds rotated so far
+  int sc;         // place of the angle in the level's table of half-angle sines and cosines
+  unsigned row0;  // row[i]
+  int pad;
+};
+
 __global__ void __launch_bounds__(256)
+k_ts_nodes(const int *__restrict__ first, const int *__restrict__ nid_prev, const int *__restrict__ nid,
+           const uint32_t *__restrict__ row, const int64_t *__restrict__ angles, const int *__restrict__ rot_prev,
+           const uint16_t *__restrict__ rank, int64_t S, int T, int level, TsNode *__restrict__ nodes) {
+  const int64_t M = nid[S - 1];
+  const int64_t node = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (node >= M) return;
+  TsNode n;
+  n.i = first[node];
+  n.i_end = first[node + 1];
+  n.par = level == 0 ? 0 : nid_prev[n.i] - 1;
+  n.row0 = row[n.i];
+  n.angle = (int)angles[(int64_t)n.row0 * T + level];
+  n.rot = level == 0 ? 0 : rot_prev[n.par];
+  const int v = n.angle + kAngleOffset;
+  n.sc = (v >= 0 && v < kAngleSpan) ? (int)rank[level * kAngleSpan + v] : 0;
+  n.pad = 0;
+  nodes[node] = n;
+}
+
+#ifndef FC_TS_WGS
+#define FC_TS_WGS 4  // workgroups per CU the register budget is set for (128 registers, 272 B of scratch: 3.75 ms for cfg3's last level against 3.97 with three and 5.1 with two)
+#endif
+// (out of line: the rare fingerprints of more than 64 dihedrals must not cost the common path its registers)
+__device__ __attribute__((noinline)) double dihedral_deg_at(const double *x, const int64_t *__restrict__ quad) {
+  return dihedral_deg(x + quad[0] * 3, x + quad[1] * 3, x + quad[2] * 3, x + quad[3] * 3);
+}
+
+// kTsStateRounds: a node's state travels through registers, KR x 64 coordinates (3: 64 atoms, 6: 128 atoms; 0: not at all)
+template <int KR>
+__global__ void __launch_bounds__(256, FC_TS_WGS)
 k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ torsions, int T, int level,
            const uint8_t *__restrict__ rotmasks, const int16_t *__restrict__ mv_idx, const int16_t *__restrict__ rs_idx,
-           const int32_t *__restrict__ n_mv, const int32_t *__restrict__ n_rs, const int64_t *__restrict__ angles,
-           int64_t S, double thr2, int backoff, const uint32_t *__restrict__ row, const int *__restrict__ nid_prev,
-           const int *__restrict__ nid, const int *__restrict__ first, const double *__restrict__ state_prev,
-           const int *__restrict__ rot_prev, double *__restrict__ state, int *__restrict__ rot_out,
+           const int32_t *__restrict__ n_mv, const int32_t *__restrict__ n_rs, int64_t S, double thr2, int backoff,
+           const uint32_t *__restrict__ row, const int *__restrict__ nid, const TsNode *__restrict__ nodes,
+           const double *__restrict__ state_prev, double *__restrict__ state, int *__restrict__ rot_out,
            double *__restrict__ out, int64_t *__restrict__ rotated, const int64_t *__restrict__ quads, int Q,
-           double *__restrict__ tf, const unsigned *__restrict__ present, const uint16_t *__restrict__ rank, int n_angles) {
+           double *__restrict__ tf, const unsigned *__restrict__ present, const uint16_t *__restrict__ rank, int n_angles,
+           int closed_form) {
   extern __shared__ double s[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double *x = s + (size_t)wv * A * 3;
   double *sc_tab = s + (size_t)4 * A * 3;                       // [kTsScTab + 1][2]
-  double *pts = sc_tab + (kTsScTab + 1) * 2 + (size_t)wv * 12 * 64;  // [12][64]
-  int *wait_rows = reinterpret_cast<int *>(sc_tab + (kTsScTab + 1) * 2 + (size_t)4 * 12 * 64) + wv * 128;  // [2][64]
+  double *cs_steps = sc_tab + (kTsScTab + 1) * 2;              // [kBackTab][2]
+  double *pts = cs_steps + kBackTab * 2 + (size_t)wv * 12 * 64;  // [12][64]
+  int *wait_rows = reinterpret_cast<int *>(cs_steps + kBackTab * 2 + (size_t)4 * 12 * 64) + wv * 192;  // [3][64]
   const int64_t M = nid[S - 1];  // inclusive scan: number of nodes of this level
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
   const int t = level;
@@ -518,7 +650,7 @@ k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ t
   const int nm = n_mv[t], nr = n_rs[t];
   // the level's ONE torsion: its rotation mask and its moving / rest index lists are read in every step of every
   // back-off loop (up to 60 per node) -- from LDS, not through the vector cache
-  int16_t *mv = reinterpret_cast<int16_t *>(wait_rows - wv * 128 + 4 * 128);
+  int16_t *mv = reinterpret_cast<int16_t *>(wait_rows - wv * 192 + 4 * 192);
   int16_t *rs = mv + A;
   uint8_t *mask = reinterpret_cast<uint8_t *>(rs + A);
   for (int k = threadIdx.x; k < A; k += 256) {
@@ -543,6 +675,13 @@ k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ t
     sc_tab[2 * kTsScTab] = sn;
     sc_tab[2 * kTsScTab + 1] = cs;
   }
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + kBackTab) {
+    const int b = threadIdx.x - 64 + 1;
+    double sn, cs;
+    sincos((double)b * (double)backoff * (3.141592653589793 / 180.0), &sn, &cs);
+    cs_steps[2 * (b - 1)] = cs;
+    cs_steps[2 * (b - 1) + 1] = sn;
+  }
   __syncthreads();
   int pre_r[kPrePairs], pre_m[kPrePairs];  // this lane's pairs of the first rounds of every clash check of the level
 #pragma unroll
@@ -556,6 +695,10 @@ k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ t
   // three divisions, atan2) at Q / 64 of the machine; the points of 64 / Q conformers wait in LDS instead and are
   // turned into angles together
   const int per_turn = (tf != nullptr && Q > 0 && Q <= 64) ? 64 / Q : 0;
+  int qa[4] = {0, 0, 0, 0};  // this lane's dihedral (lane < Q): its four atoms, once per kernel
+  if (per_turn > 0 && lane < Q)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qa[c] = (int)quads[lane * 4 + c] * 3;
   int waiting = 0;
   auto flush = [&]() {
     __builtin_amdgcn_wave_barrier();
@@ -565,58 +708,98 @@ k_ts_level(const double *__restrict__ base, int A, const int64_t *__restrict__ t
       for (int c = 0; c < 12; ++c) p[c] = pts[c * 64 + lane];
       const double d = dihedral_deg(p, p + 3, p + 6, p + 9);
       const int slot = lane / Q, q = lane - slot * Q;
-      for (int ii = wait_rows[slot]; ii < wait_rows[64 + slot]; ++ii) tf[(int64_t)row[ii] * Q + q] = d;
+      const int ib = wait_rows[slot], ie = wait_rows[64 + slot];
+      tf[(int64_t)(unsigned)wait_rows[128 + slot] * Q + q] = d;
+      for (int ii = ib + 1; ii < ie; ++ii) tf[(int64_t)row[ii] * Q + q] = d;  // (duplicate angle-sets)
     }
     __builtin_amdgcn_wave_barrier();
     waiting = 0;
   };
-  for (int64_t node = wave0; node < M; node += nwaves) {
+  // Two nodes ahead: the record of node n + 2 and the state of node n + 1 (whose record came a turn earlier) travel
+  // while node n is worked on -- every global load of the loop is consumed a whole turn after it was issued.
+  const int n3 = A * 3;
+  constexpr int kTsStateRounds = KR > 0 ? KR : 1;
+  const bool regs_ok = KR > 0 && n3 <= KR * 64;
+  TsNode cur = {}, nxt = {};
+  double st_cur[kTsStateRounds], st_nxt[kTsStateRounds];
+  auto load_state = [&](const TsNode &nd, double (&st)[kTsStateRounds]) {
+    const double *src = level == 0 ? base : state_prev + (int64_t)nd.par * n3;
+#pragma unroll
+    for (int r = 0; r < kTsStateRounds; ++r) {
+      const int k = r * 64 + lane;
+      st[r] = k < n3 ? src[k] : 0.0;
+    }
+  };
+  int64_t node = wave0;
+  if (node < M) cur = nodes[node];
+  if (node + nwaves < M) nxt = nodes[node + nwaves];
+  if (node < M && regs_ok) load_state(cur, st_cur);
+  const unsigned long long tw0 = FC_TS_NOW();
+  unsigned long long acc_n = 0, acc_a = 0, acc_nz = 0, acc_b = 0, acc_c = 0;
+  for (; node < M; node += nwaves) {
     const unsigned long long ts0 = FC_TS_NOW();
-    const int i = first[node];
-    const double *src = level == 0 ? base : state_prev + (int64_t)(nid_prev[i] - 1) * A * 3;
-    for (int k = lane; k < A * 3; k += 64) x[k] = src[k];
+    TsNode nn = {};
+    if (node + 2 * nwaves < M) nn = nodes[node + 2 * nwaves];
+    if (regs_ok && node + nwaves < M) load_state(nxt, st_nxt);
+    if (regs_ok) {
+#pragma unroll
+      for (int r = 0; r < kTsStateRounds; ++r) {
+        const int k = r * 64 + lane;
+        if (k < n3) x[k] = st_cur[r];
+      }
+    } else {
+      const double *src = level == 0 ? base : state_prev + (int64_t)cur.par * n3;
+      for (int k = lane; k < n3; k += 64) x[k] = src[k];
+    }
     __builtin_amdgcn_wave_barrier();
-    int rot = level == 0 ? 0 : rot_prev[nid_prev[i] - 1];
-    const int angle = (int)angles[(int64_t)row[i] * T + t];
     const unsigned long long ts1 = FC_TS_NOW();
-    if (last) { FC_TS_ADD(0, 1); FC_TS_ADD(4, ts1 - ts0); if (angle != 0) FC_TS_ADD(1, 1); }
+    int rot = cur.rot;
+    const int angle = cur.angle;
+    acc_n += 1; acc_a += ts1 - ts0; acc_nz += angle != 0;
     if (angle != 0)
       rot += torsion_step(x, A, mask, mv, nm, rs, nr, i2, i3, angle, backoff, thr2, lane, pre_r, pre_m,
-                          tab ? sc_tab + 2 * rank[t * kAngleSpan + angle + kAngleOffset] : nullptr, sc_tab + 2 * kTsScTab);
+                          tab ? sc_tab + 2 * cur.sc : nullptr, sc_tab + 2 * kTsScTab, closed_form ? cs_steps : nullptr);
     const unsigned long long ts2 = FC_TS_NOW();
-    if (last) FC_TS_ADD(5, ts2 - ts1);
+    acc_b += ts2 - ts1;
     if (!last) {
-      double *o = state + node * (int64_t)A * 3;
-      for (int k = lane; k < A * 3; k += 64) o[k] = x[k];
+      double *o = state + node * (int64_t)n3;
+      for (int k = lane; k < n3; k += 64) o[k] = x[k];
       if (lane == 0) rot_out[node] = rot;
     } else {
-      const int i_end = first[node + 1];
-      for (int ii = i; ii < i_end; ++ii) {  // every row of the run (more than one only for duplicate angle-sets)
-        const int64_t r = row[ii];
+      for (int ii = cur.i; ii < cur.i_end; ++ii) {  // every row of the run (more than one only for duplicate angle-sets)
+        const int64_t r = ii == cur.i ? (int64_t)cur.row0 : (int64_t)row[ii];
         if (out != nullptr) {
-          double *o = out + r * (int64_t)A * 3;
-          for (int k = lane; k < A * 3; k += 64) o[k] = x[k];
+          double *o = out + r * (int64_t)n3;
+          for (int k = lane; k < n3; k += 64) o[k] = x[k];
         }
         if (tf != nullptr && per_turn == 0)
           for (int q = lane; q < Q; q += 64)
-            tf[r * (int64_t)Q + q] = dihedral_deg(x + quads[q * 4] * 3, x + quads[q * 4 + 1] * 3,
-                                                  x + quads[q * 4 + 2] * 3, x + quads[q * 4 + 3] * 3);
+            tf[r * (int64_t)Q + q] = dihedral_deg_at(x, quads + q * 4);
         if (lane == 0) rotated[r] = rot;
       }
       if (per_turn > 0) {
         if (lane < Q) {
           const int at = waiting * Q + lane;
 #pragma unroll
-          for (int c = 0; c < 12; ++c) pts[c * 64 + at] = x[quads[lane * 4 + c / 3] * 3 + c % 3];
+          for (int c = 0; c < 12; ++c) pts[c * 64 + at] = x[qa[c / 3] + c % 3];
         }
-        if (lane == 0) wait_rows[waiting] = i, wait_rows[64 + waiting] = i_end;
+        if (lane == 0) wait_rows[waiting] = cur.i, wait_rows[64 + waiting] = cur.i_end, wait_rows[128 + waiting] = (int)cur.row0;
         if (++waiting == per_turn) flush();
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (last) FC_TS_ADD(6, FC_TS_NOW() - ts2);
+    acc_c += FC_TS_NOW() - ts2;
+    cur = nxt;
+    nxt = nn;
+#pragma unroll
+    for (int r = 0; r < kTsStateRounds; ++r) st_cur[r] = st_nxt[r];
   }
   if (waiting > 0) flush();
+  if (last) {
+    FC_TS_ADD(8, FC_TS_NOW() - tw0); FC_TS_ADD(9, 1); FC_TS_ADD(0, acc_n); FC_TS_ADD(1, acc_nz); FC_TS_ADD(4, acc_a);
+    FC_TS_ADD(5, acc_b); FC_TS_ADD(6, acc_c);
+  }
+  (void)acc_n; (void)acc_a; (void)acc_nz; (void)acc_b; (void)acc_c; (void)tw0;
 }
 
 #if defined(FC_TFD_STAMPS)
@@ -684,11 +867,10 @@ static int torsion_scan_tree(const double *base_dev, int64_t A, const int64_t *t
   FC_TRY(dstate[1].reserve(std::max<size_t>(state_bytes, 8)));
   FC_TRY(drotn[0].reserve((size_t)(max_state_nodes + 1) * 4));
   FC_TRY(drotn[1].reserve((size_t)(max_state_nodes + 1) * 4));
+  DevBuf dnodes;
+  FC_TRY(dnodes.reserve((size_t)(*std::max_element(bound.begin(), bound.end()) + 1) * sizeof(TsNode)));
   const unsigned gb = (unsigned)ceil_div(S, 256);
   if (ts_level_lds((int)A) > ((size_t)160 << 10)) return 1;
-  if (ts_level_lds((int)A) > ((size_t)64 << 10))
-    FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ts_level), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)ts_level_lds((int)A)));
   hipLaunchKernelGGL(k_ts_codes, dim3(gb), dim3(256), 0, st, angles_dev, S, (int)T, drank.as<uint16_t>(),
                      dmeta.as<ScanTreeMeta>(), dcode.as<uint64_t>(), drow.as<uint32_t>());
   FC_TRY(check_launch("k_ts_codes"));
@@ -705,6 +887,8 @@ static int torsion_scan_tree(const double *base_dev, int64_t A, const int64_t *t
   hipLaunchKernelGGL(k_ts_firstdiff, dim3(gb), dim3(256), 0, st, dcode2.as<uint64_t>(), S, (int)T,
                      dmeta.as<ScanTreeMeta>(), dd.as<uint8_t>());
   FC_TRY(check_launch("k_ts_firstdiff"));
+  int closed_form = 1;  // FC_SCAN_CLOSED_FORM=0: every back-off loop walked step by step (A/B knob, per call)
+  if (const char *v = getenv("FC_SCAN_CLOSED_FORM")) closed_form = v[0] != '0';
   for (int level = 0; level < (int)T; ++level) {
     DevBuf &nid = dnid[level & 1], &nid_prev = dnid[(level & 1) ^ 1];
     hipLaunchKernelGGL(k_ts_flags, dim3(gb), dim3(256), 0, st, dd.as<uint8_t>(), S, level, dflag.as<int>());
@@ -713,13 +897,20 @@ static int torsion_scan_tree(const double *base_dev, int64_t A, const int64_t *t
     hipLaunchKernelGGL(k_ts_first, dim3(gb), dim3(256), 0, st, dd.as<uint8_t>(), nid.as<int>(), S, level,
                        dfirst.as<int>());
     const int64_t nodes = bound[(size_t)level];
+    hipLaunchKernelGGL(k_ts_nodes, dim3((unsigned)ceil_div(nodes, 256)), dim3(256), 0, st, dfirst.as<int>(), nid_prev.as<int>(),
+                       nid.as<int>(), drow2.as<uint32_t>(), angles_dev, drotn[(level & 1) ^ 1].as<int>(), drank.as<uint16_t>(), S,
+                       (int)T, level, dnodes.as<TsNode>());
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(nodes, 4), (int64_t)ctx().n_cu * 32));
-    hipLaunchKernelGGL(k_ts_level, dim3((unsigned)blocks), dim3(256), ts_level_lds((int)A), st, base_dev,
-                       (int)A, torsions_dev, (int)T, level, rotmasks_dev, mv_dev, rs_dev, nmv_dev, nrs_dev, angles_dev, S,
-                       thr2, (int)backoff, drow2.as<uint32_t>(), nid_prev.as<int>(), nid.as<int>(), dfirst.as<int>(),
-                       dstate[(level & 1) ^ 1].as<double>(), drotn[(level & 1) ^ 1].as<int>(), dstate[level & 1].as<double>(),
+    auto kfn = A * 3 <= 192 ? k_ts_level<3> : A * 3 <= 384 ? k_ts_level<6> : k_ts_level<0>;
+    if (level == 0 && ts_level_lds((int)A) > ((size_t)64 << 10))
+      FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)ts_level_lds((int)A)));
+    hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), ts_level_lds((int)A), st, base_dev,
+                       (int)A, torsions_dev, (int)T, level, rotmasks_dev, mv_dev, rs_dev, nmv_dev, nrs_dev, S,
+                       thr2, (int)backoff, drow2.as<uint32_t>(), nid.as<int>(), dnodes.as<TsNode>(),
+                       dstate[(level & 1) ^ 1].as<double>(), dstate[level & 1].as<double>(),
                        drotn[level & 1].as<int>(), out_dev, rot_dev, quads_dev, (int)Q, tf_dev, dpres.as<unsigned>(),
-                       drank.as<uint16_t>(), meta.n[level]);
+                       drank.as<uint16_t>(), meta.n[level], closed_form);
     FC_TRY(check_launch("k_ts_level"));
   }
   return sync();  // the temporaries above go back to the pool only after the kernels have used them

@@ -542,6 +542,79 @@ def test_torsion_scan_vs_oracle(fc):
     assert (rot0 < (angles != 0).sum(axis=1)).any()  # some back-off / failed rotations happened
 
 
+@pytest.mark.parametrize("thresh,backoff", [(1.5, 5), (2.0, 5), (2.0, 7), (1.5, 2)])
+def test_scan_back_off_closed_form_equals_the_walked_loop(fc, monkeypatch, thresh, backoff):
+    """The scan tree finds the step at which a back-off loop (torsion_module.py:831-842) ends from the closed form of
+    the pair distances under rotation and only then turns the atoms (fc_torsion.hip: torsion_step).  Same coordinates
+    bit for bit, same counts as the loop walked step by step (FC_SCAN_CLOSED_FORM=0) and as the one-wavefront-per-row
+    kernel (FC_SCAN_TREE=0), on scans where most nodes clash and a third to two thirds of the loops run out, with a
+    back-off that does not divide the angles (7) and with one that needs more steps than the kernel's table holds
+    (2 degrees: 150 steps, the loop); a sample against the oracle."""
+    base, tors, masks = _chain_case(40, 5, seed=72)
+    angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 5)  # 7 776 angle-sets: the tree takes them
+    runs = {}
+    for name, env in (("closed", {}), ("loop", {"FC_SCAN_CLOSED_FORM": "0"}), ("rows", {"FC_SCAN_TREE": "0"})):
+        for k in ("FC_SCAN_CLOSED_FORM", "FC_SCAN_TREE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if name == "rows":
+            runs[name] = fc.torsion_module.torsion_scan(base, tors, masks, angles, thresh=thresh, backoff=backoff)
+        else:
+            tf, rot, out = fc.torsion_module.torsion_scan_fingerprints(base, tors, masks, angles, tors, thresh=thresh,
+                                                                       backoff=backoff, want_coords=True)
+            runs[name] = (out, rot, tf)
+    for k in ("FC_SCAN_CLOSED_FORM", "FC_SCAN_TREE"):
+        monkeypatch.delenv(k, raising=False)
+    assert np.array_equal(runs["closed"][0], runs["loop"][0]) and np.array_equal(runs["closed"][1], runs["loop"][1])
+    assert np.array_equal(runs["closed"][2], runs["loop"][2])
+    assert np.array_equal(runs["closed"][0], runs["rows"][0]) and np.array_equal(runs["closed"][1], runs["rows"][1])
+    pick = np.random.default_rng(5).integers(0, len(angles), 120)
+    ref_c, ref_r = o.torsion_scan(base, tors, masks, angles[pick], thresh=thresh, backoff=backoff)
+    assert np.array_equal(runs["closed"][1][pick], ref_r)
+    assert np.abs(runs["closed"][0][pick] - ref_c).max() < TOL
+    nz = (angles != 0).sum(axis=1)
+    assert 0.1 < (runs["closed"][1] < nz).mean() < 0.9  # back-off loops that ran out, and loops that ended early
+
+
+def test_scan_back_off_threshold_exactly_on_a_distance(fc):
+    """A clash threshold EQUAL to a distance the back-off loop meets: the closed form cannot decide such a pair (its
+    value is within roundings of the threshold) and hands the node to the walked loop; counts as the oracle's
+    (`cdist < thresh`, strict), coordinates within 1e-10."""
+    from scipy.spatial.distance import cdist
+
+    base, tors, masks = _chain_case(40, 5, seed=74)
+    angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 5)
+    hit = 0
+    for t, angle, thr0 in [(t, a, h) for h in (2.0, 1.6, 2.4) for t in (4, 3, 2, 1, 0) for a in (120, 60, 180, 240, 300)]:
+        if hit == 3:
+            break
+        # walk this torsion's back-off by hand for the angle-set that turns only it, take a distance of step 2 as threshold
+        mask = masks[t].astype(bool)
+        temp = o.rotate_dihedral(base, tors[t], angle, mask)
+        if o.torsion_comp_check(temp, tors[t], mask, thr0):
+            continue  # (no clash to back off from)
+        for _ in range(2):
+            temp = o.rotate_dihedral(temp, tors[t], -5, mask)
+        anti = ~mask
+        anti[tors[t][1]] = anti[tors[t][2]] = False
+        d = cdist(temp[anti], temp[mask])
+        below = np.sort(d[d < thr0])
+        if len(below) == 0:
+            continue
+        thresh = float(below[0])  # the closest pair of step 2 sits exactly on the threshold
+        hit += 1
+        row = np.zeros(5, dtype=angles.dtype)
+        row[t] = angle
+        out, rot = fc.torsion_module.torsion_scan(base, tors, masks, angles, thresh=thresh)  # (tree: 7 776 rows)
+        pick = np.concatenate([[int(np.flatnonzero((angles == row).all(axis=1))[0])],
+                               np.random.default_rng(6).integers(0, len(angles), 40)])
+        ref_c, ref_r = o.torsion_scan(base, tors, masks, angles[pick], thresh=thresh)
+        assert np.array_equal(rot[pick], ref_r), (t, angle)
+        assert np.abs(out[pick] - ref_c).max() < TOL
+    assert hit >= 2
+
+
 def test_random_csearch_vs_oracle(fc):
     """random_csearch (torsion_module.py:436-571) with the shuffle fixed: same kept sets, same
     coordinates, including the max_tries quirk (the stop is only evaluated on a kept set)"""

@@ -23,4 +23,5 @@ for rep in range(2):
     v = [int(x) for x in out]
     n = max(v[0], 1)
     print({"nodes": v[0], "angle!=0": v[1], "nodes into back-off (all levels)": v[2], "back-off steps (all levels)": v[3],
-           "ticks load": v[4] / n, "ticks step": v[5] / n, "ticks output": v[6] / n})
+           "us per node: state to LDS": v[4] / n / 100, "torsion step": v[5] / n / 100, "outputs": v[6] / n / 100,
+           "closed form refused": v[7], "waves": v[9], "us per wave": v[8] / max(v[9], 1) / 100})
