@@ -360,7 +360,7 @@ struct StageLease {  // one set of pinned pieces for the duration of one staged 
       if (!set->pin[b] && hipHostMalloc(&set->pin[b], kStagePiece, hipHostMallocDefault) != hipSuccess)
         return set_error(FC_E_NOMEM, "pinned staging memory: hipHostMalloc failed");
     }
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < 2; ++b)
       if (!set->ev[b] && hipEventCreateWithFlags(&set->ev[b], hipEventDisableTiming) != hipSuccess)
         return set_error(FC_E_HIP, "hipEventCreate failed");
     return FC_OK;
@@ -2309,6 +2309,22 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
     FC_TRY(upload(dq, quads, (size_t)Q * 4));
     FC_TRY(dtf.reserve((size_t)S * Q * sizeof(double)));
   }
+  // The caller's fresh output arrays are touched for the first time by whoever writes them: 13 MB of counts at 1.7 M
+  // angle-sets are 3 300 page faults under the copy that brings them down (1.3 ms of this thread between the first
+  // match and the ladder, the device idle for half of it: tools/trace_phases.py).  A thread without any device call
+  // writes zeros to them while the scan runs; the copy then finds the pages in place (0.3 ms, beside the first-match walk).
+  std::thread prefault;
+  struct JoinGuard {
+    std::thread &t;
+    ~JoinGuard() {
+      if (t.joinable()) t.join();
+    }
+  } prefault_guard{prefault};
+  if (tfd_keep_out && S >= (1 << 17))
+    prefault = std::thread([rotated_bonds_out, tfd_keep_out, S] {
+      std::memset(rotated_bonds_out, 0, (size_t)S * sizeof(int64_t));
+      std::memset(tfd_keep_out, 0, (size_t)S + 1);
+    });
   FC_TRY(launch_torsion_scan(db.as<double>(), A, dt.as<int64_t>(), T, dmk.as<uint8_t>(),
                              dmv.as<int16_t>(), drs.as<int16_t>(), dnm.as<int32_t>(),
                              dnr.as<int32_t>(), da.as<int64_t>(), S, thresh, backoff_deg,
@@ -2348,10 +2364,13 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   DevBuf dtfF;
   FC_TRY(dtfF.reserve((size_t)std::min<int64_t>(Q, 8) * Npad * sizeof(float)));
   FC_TRY(launch_tfd_first_match(dT.as<double>(), N, Npad, Q, tfd_thresh, dfm.as<int64_t>(), dtfF.as<float>()));
-  {  // the counts, while the first-match kernels run (the copy into the caller's pageable array keeps this thread busy,
-     // the device is not waiting for it)
+  {  // the counts, while the first-match walk runs (the copy into the caller's pageable array keeps this thread busy, the
+     // device is not waiting for it: its pages are in place, see `prefault`)
     FC_TRY(side_streams());
-    FC_TRY(d2h_staged(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t), ctx().s_lane[0]));
+    const bool prefaulted = prefault.joinable();
+    if (prefaulted) prefault.join();
+    else std::memset(tfd_keep_out, 0, (size_t)S + 1);
+    FC_TRY(d2h_staged(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t), ctx().s_comm));
   }
   lap("first match enqueued, counts down");
   std::vector<uint8_t> mask((size_t)N);
@@ -2360,7 +2379,6 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   // keep flags: row r >= 1 of the TFD problem is the (r - 1)-th angle-set that rotated a bond, and the device still holds
   // that list (didx).  The survivors are few (thousands of 1.7 M): their rows go up, their angle-sets come down -- a
   // walk over all S counts on the host cost 0.7 ms
-  std::memset(tfd_keep_out, 0, (size_t)S + 1);
   tfd_keep_out[0] = mask[0];
   std::vector<int64_t> rows;
   {

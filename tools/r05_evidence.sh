@@ -13,6 +13,7 @@ cfg3)
   find $O/prof_cfg3 -name "*kernel_trace.csv" -exec cp {} $O/cfg3_kernel_trace.csv \;
   rm -rf $O/prof_cfg3
   python3 tools/trace_busy.py $O/cfg3_kernel_trace.csv k_angle_grid > $O/cfg3_device_busy.json
+  python3 tools/trace_phases.py $O/cfg3_kernel_trace.csv k_angle_grid > $O/cfg3_phases.txt
   rm -f $O/cfg3_kernel_trace.csv
   cat $O/cfg3_device_busy.json | head -12
   ;;
