@@ -898,14 +898,23 @@ def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_at
         sec["refine"] = {"kernel": "k_bucket_count + k_bucket_scan + k_bucket_scatter + k_refine_buckets (the whole refine of a long queue)",
                          "kernel_ms": r_ms, "candidates": int(n_cand),
                          "alignments_per_s": n_cand / (r_ms * 1e-3),
-                         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                      "algorithmic_bytes_per_alignment": bpa,
+                         # bound: the fp64 VECTOR peak (78.6 TFLOP/s on this chip, the same figure as the matrix pipe's) with
+                         # SURVEY 8d's flops of one complete alignment -- not the HBM roof: the 8d bytes of a candidate never leave
+                         # the L2 since the queue is ordered by bucket (`traffic`: what crosses the fabric, 12 x fewer), and an HBM
+                         # fraction computed from them (0.97 in round 4's line) says nothing
+                         "roofline": {"bound": "fp64", "achieved": n_cand * (53 * n_atoms + 600) / (r_ms * 1e-3) / 1e12,
+                                      "peak": PEAK_F64_MFMA, "unit": "TFLOP/s",
+                                      "frac": n_cand * (53 * n_atoms + 600) / (r_ms * 1e-3) / 1e12 / PEAK_F64_MFMA,
+                                      "flops_per_alignment": 53 * n_atoms + 600,
+                                      "algorithmic_bytes_per_alignment": bpa, "algorithmic_GBps": gbs,
                                       "traffic": pmc_traffic(("r04_pmc_refine.json",), n_conf, n_atoms)[0],
                                       "traffic_source": pmc_traffic(("r04_pmc_refine.json",), n_conf, n_atoms)[1],
-                                      "note": "the kernel north_star describes: one exact fp64 alignment (rotation, rmsd, max deviation) "
-                                              "per queued candidate pair; SURVEY 8d bytes (both conformers per pair) against 8 TB/s -- since "
-                                              "round 4 the queue is ordered by (1024-row, 64-column) bucket and the column tile is staged in LDS: "
-                                              "`traffic` is what actually crosses the fabric"}}
+                                      "note": "one exact fp64 alignment (rotation, rmsd, max deviation) per queued candidate pair, a lane per "
+                                              "pair, the queue ordered by (1024-row, 64-column) bucket with the column tile in LDS.  What holds "
+                                              "it at this fraction is the CU's vector-memory path, not arithmetic and not HBM: every lane gathers "
+                                              "its row conformer twice (2.5 KB per pair through the L1: ~14 cycles per 64-lane 8-byte load, "
+                                              "tuning build -DFC_RB_TIMELINE: per item of 512 pairs 8.7 us covariance pass, 8.3 us deviation "
+                                              "pass with twice the multiply-adds); DESIGN.md section 9"}}
     out["config"]["secondary"] = sec
     # (d) BASELINE's second metric as SURVEY 8d words it: host arrays in -> mask out, H2D / D2H included
     fc.pruner.prune_by_rmsd(coords[:2000], atoms, MAX_RMSD)
