@@ -211,23 +211,45 @@ k_chunk_front_block(const int64_t *__restrict__ fm, int64_t lo, int d, int64_t n
 // components one at a time (the records of the large chunks lie side by side: walked in place, a few hundred workgroups
 // got all the large components and the rest none)
 constexpr int kCompClasses = 4;
+constexpr int kCompListPer = 8;  // records per thread: ONE global atomic per class and 2 048 records (a wavefront's own
+                                 // atomics on the four counters -- 5e4 per launch on four addresses -- were 0.5 of the kernel's 0.63 ms)
 __global__ void __launch_bounds__(256)
 k_comp_lists(const CompRecord *__restrict__ rec, int64_t n_static, const uint32_t *__restrict__ n_dense, uint32_t *__restrict__ lists,
              int64_t list_cap, uint32_t *__restrict__ counts) {
+  __shared__ uint32_t s_cnt[kCompClasses], s_base[kCompClasses];
   const int64_t n_rec = n_static + (int64_t)*n_dense;
-  const int64_t ri = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint32_t n = ri < n_rec ? rec[ri].n : 0u;
-  const int cls = n <= (uint32_t)kTinyMax ? -1 : (n <= 76u ? 0 : (n <= 306u ? 1 : (n <= 1228u ? 2 : 3)));
   const int lane = (int)(threadIdx.x & 63);
+  if (threadIdx.x < kCompClasses) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  int cls[kCompListPer];
+  uint32_t at[kCompListPer];  // place inside the workgroup's share of its class
 #pragma unroll
-  for (int c = 0; c < kCompClasses; ++c) {
-    const unsigned long long b = __ballot(cls == c);
-    if (!b) continue;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&counts[c * 32], (uint32_t)__popcll(b));
-    base = __shfl(base, 0);
-    if (cls == c) lists[(int64_t)c * list_cap + base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)ri;
+  for (int k = 0; k < kCompListPer; ++k) {
+    const int64_t ri = ((int64_t)blockIdx.x * kCompListPer + k) * 256 + threadIdx.x;
+    const uint32_t n = ri < n_rec ? rec[ri].n : 0u;
+    cls[k] = n <= (uint32_t)kTinyMax ? -1 : (n <= 76u ? 0 : (n <= 306u ? 1 : (n <= 1228u ? 2 : 3)));
+    at[k] = 0u;
   }
+#pragma unroll
+  for (int k = 0; k < kCompListPer; ++k)
+#pragma unroll
+    for (int c = 0; c < kCompClasses; ++c) {
+      const unsigned long long b = __ballot(cls[k] == c);
+      if (!b) continue;  // (uniform)
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&s_cnt[c], (uint32_t)__popcll(b));
+      base = __shfl(base, 0);
+      if (cls[k] == c) at[k] = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    }
+  __syncthreads();
+  if (threadIdx.x < kCompClasses) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x * 32], s_cnt[threadIdx.x]) : 0u;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kCompListPer; ++k)
+    if (cls[k] >= 0) {
+      const int64_t ri = ((int64_t)blockIdx.x * kCompListPer + k) * 256 + threadIdx.x;
+      lists[(int64_t)cls[k] * list_cap + s_base[cls[k]] + at[k]] = (uint32_t)ri;
+    }
 }
 
 template <int CAP, int TBL, int CAP2>
@@ -995,7 +1017,7 @@ int tfd_ladder_device(const int64_t *fm_dev, const int64_t *fm_host, int64_t N, 
   {
     const int64_t n_rec_cap = n_static + dense_cap;
     uint32_t *lists = d_lists.as<uint32_t>(), *lcount = small + 640;  // (one counter per 128-byte line)
-    hipLaunchKernelGGL(k_comp_lists, dim3((unsigned)ceil_div(n_rec_cap, 256)), dim3(256), 0, st, rec, n_static, small, lists, n_rec_cap, lcount);
+    hipLaunchKernelGGL(k_comp_lists, dim3((unsigned)ceil_div(n_rec_cap, 256 * kCompListPer)), dim3(256), 0, st, rec, n_static, small, lists, n_rec_cap, lcount);
     FC_TRY(check_launch("k_comp_lists"));
     FC_HIP_TRY(hipEventRecord(evs[5], st));
     for (hipStream_t s2 : {sA, sB, sC}) FC_HIP_TRY(hipStreamWaitEvent(s2, evs[5], 0));
