@@ -464,7 +464,10 @@ int fc_tfd_simbits(const double *tf, int64_t N, int64_t Q, double thresh, int64_
                    int64_t row_end, uint64_t *bits_out);
 
 /* prune_conformers_tfd at any N (firecode/torsion_module.py:957-1043):
- * fc_tfd_first_match: first_out[i] = min{ j > i : TFD-similar(i, j) } or -1 (GPU);
+ * fc_tfd_first_match: first_out[i] = min{ j > i : TFD-similar(i, j) } or -1 (GPU).  From 65 536 structures on
+ * (and angles within +-270 degrees, all finite: the reference's delta is the circular distance exactly there) the
+ * pair tests run on 16-bit angles with the fp64 sum in NumPy's order for every pair within 0.055 degrees of the
+ * threshold -- same array as the fp32-filtered kernels, which serve every other input (FC_TFD_U16=0: always);
  * fc_tfd_ladder_from_first_match: the reference's k-ladder / match-graph /
  * "keep group[0]" bookkeeping replayed from that array -- bit-identical to the
  * reference under CPython >= 3.8 + networkx 3.x because it reproduces their set
