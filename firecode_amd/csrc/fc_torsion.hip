@@ -168,12 +168,14 @@ __device__ __forceinline__ int torsion_step(double *x, int A, MaskPtr mask, IdxP
     const int total_pairs = nm * nr;
     if (pre_r != nullptr && cs_steps != nullptr && steps <= kBackTab && total_pairs <= kPrePairs * 64) {
       const double ax = x[i2 * 3] - cx, ay = x[i2 * 3 + 1] - cy, az = x[i2 * 3 + 2] - cz;
-      const double nrm = sqrt((ax * ax + ay * ay) + az * az);
-      const double nx = ax / nrm, ny = ay / nrm, nz = az / nrm;
-      double c0[kPrePairs], c1[kPrePairs], c2[kPrePairs], gd[kPrePairs];
+      const double inv = 1.0 / sqrt((ax * ax + ay * ay) + az * az);  // (the closed form needs the axis to ~1e-15, not to the bit)
+      const double nx = ax * inv, ny = ay * inv, nz = az * inv;
+      // per pair: c0, c1, c2 and the threshold pulled down / pushed up by the guard: below `lo` a clash for certain,
+      // at or above `hi` none for certain
+      double c0[kPrePairs], c1[kPrePairs], c2[kPrePairs], lo[kPrePairs], hi[kPrePairs];
 #pragma unroll
       for (int q = 0; q < kPrePairs; ++q) {
-        c0[q] = 1.0e300, c1[q] = 0.0, c2[q] = 0.0, gd[q] = 0.0;  // (no pair: never a clash, never near)
+        c0[q] = 1.0e300, c1[q] = 0.0, c2[q] = 0.0, lo[q] = thr2, hi[q] = thr2;  // (no pair: never a clash, never in doubt)
         if (q * 64 + lane < total_pairs) {
           const int r = pre_r[q], m = pre_m[q];
           const double Rx = x[r * 3] - cx, Ry = x[r * 3 + 1] - cy, Rz = x[r * 3 + 2] - cz;
@@ -184,42 +186,51 @@ __device__ __forceinline__ int torsion_step(double *x, int A, MaskPtr mask, IdxP
           c0[q] = S - 2.0 * Rn * Pn;
           c1[q] = -2.0 * (RP - Rn * Pn);
           c2[q] = 2.0 * (Rx * kx + Ry * ky + Rz * kz);
-          gd[q] = 1.0e-10 * (S + 1.0);
+          const double gd = 1.0e-10 * (S + 1.0);
+          lo[q] = thr2 - gd, hi[q] = thr2 + gd;
         }
       }
       const int rounds = (total_pairs + 63) >> 6;
       int found = 0;  // the first step without a clash; -1: undecided (a pair too near the threshold)
-      // eight steps per turn: their sixteen table values requested together, the pairs' tests in one straight line (a
+      // A few steps per turn: their table values requested together, the pairs' tests in one straight line (a
       // step at a time the loop was a chain of LDS round trips and branches: 8 us per clashing node at two wavefronts
-      // per SIMD), then the steps' verdicts in order
-      for (int b0 = 1; b0 <= steps && found == 0; b0 += 8) {
-        double cb[8], sb[8];
+      // per SIMD).  A step at which SOME pair is below `lo` is a clash whatever the pairs near the threshold do: two
+      // multiply-adds and one compare (straight into a lane mask) per pair and step; only the first step without such
+      // a pair is looked at again -- every pair must be at or above `hi` there, or the node goes to the walked loop.
+#ifndef FC_TS_TURN
+#define FC_TS_TURN 4
+#endif
+      constexpr int kTurn = FC_TS_TURN;  // steps per turn (cfg3's last level: 3.20 ms with 4 or 2; with 8 -- 32 registers of table
+                                         // values, 352 B of scratch -- 4.25, slower than the per-pair doubt test it replaced: 3.75)
+      for (int b0 = 1; b0 <= steps && found == 0; b0 += kTurn) {
+        double cb[kTurn], sb[kTurn];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kTurn; ++u) {
           const int at = (b0 + u <= kBackTab ? b0 + u : kBackTab) - 1;
           cb[u] = cs_steps[2 * at], sb[u] = cs_steps[2 * at + 1];
         }
-        unsigned clash = 0u, near = 0u;  // bit u: this lane's pairs at step b0 + u
+        uint64_t sure[kTurn];  // per step: the lanes with a pair below `lo`
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < kTurn; ++u) {
+          sure[u] = 0ull;
 #pragma unroll
           for (int q = 0; q < kPrePairs; ++q) {
             if (q >= rounds) break;  // (uniform)
-            const double d2 = fma(c2[q], sb[u], fma(c1[q], cb[u], c0[q]));
-            clash |= (d2 < thr2 ? 1u : 0u) << u;
-            near |= (fabs(d2 - thr2) < gd[q] ? 1u : 0u) << u;
+            sure[u] |= __ballot(fma(c2[q], sb[u], fma(c1[q], cb[u], c0[q])) < lo[q]);
           }
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kTurn; ++u) {
           if (b0 + u > steps) break;  // (uniform)
-          if (__any((near >> u) & 1u)) {
-            found = -1;
-            break;
+          if (sure[u] != 0ull) continue;
+          bool doubt = false;  // no certain clash at this step: is every pair certainly clear?
+#pragma unroll
+          for (int q = 0; q < kPrePairs; ++q) {
+            if (q >= rounds) break;
+            doubt = doubt || fma(c2[q], sb[u], fma(c1[q], cb[u], c0[q])) < hi[q];
           }
-          if (!__any((clash >> u) & 1u)) {
-            found = b0 + u;
-            break;
-          }
+          found = __any(doubt) ? -1 : b0 + u;
+          break;
         }
       }
       if (found >= 0) {

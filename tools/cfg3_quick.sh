@@ -1,6 +1,9 @@
-for lib in libfc_hip.so libfc_hip_ts4.so; do
-FC_LIB_PATH=firecode_amd/$lib FC_CSEARCH_RUNS=4 rocprofv3 --kernel-trace --stats -d gpurun_out/q_$lib --output-format csv -- python3 tools/bench_workloads.py csearch > gpurun_out/q_$lib.json 2>/dev/null
-python - $lib <<'PY'
+# k_ts_level (sum of 32 launches, slowest launch, ns) and the search times of library builds side by side:
+#   bash tools/cfg3_quick.sh [suffix ...]     (firecode_amd/libfc_hip_<suffix>.so; the default library first)
+for lib in "" "$@"; do
+p=libfc_hip${lib:+_$lib}.so
+FC_LIB_PATH=firecode_amd/$p FC_CSEARCH_RUNS=4 rocprofv3 --kernel-trace --stats -d gpurun_out/q_$p --output-format csv -- python3 tools/bench_workloads.py csearch > gpurun_out/q_$p.json 2>/dev/null
+python - $p <<'PY'
 import csv,glob,sys,json
 f=glob.glob("gpurun_out/q_%s/**/*kernel_stats.csv"%sys.argv[1],recursive=True)[0]
 for r in csv.DictReader(open(f)):
