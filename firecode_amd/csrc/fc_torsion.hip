@@ -507,17 +507,40 @@ k_ts_presence(const int64_t *__restrict__ angles, int64_t S, int T, unsigned *__
     if (pres[k]) atomicOr(&present[k], pres[k]);
 }
 
+// rank[t][v]: number of present angle values below v; one wavefront per torsion (a single thread walking T x 1 441
+// values was 0.2 ms of every search), the counts per 32-value word by prefix sum over the wavefront
 __global__ void __launch_bounds__(64)
 k_ts_ranks(const unsigned *__restrict__ present, int T, uint16_t *__restrict__ rank, ScanTreeMeta *__restrict__ meta,
            const int *__restrict__ bad) {
-  if (threadIdx.x != 0) return;
+  __shared__ int s_n[kMaxTreeT];
+  const int lane = threadIdx.x;
+  for (int t = 0; t < T; ++t) {
+    int before = 0;  // present values in the words in front of this lane's
+    for (int w0 = 0; w0 < kAngleWords; w0 += 64) {
+      const int w = w0 + lane;
+      const unsigned bits = w < kAngleWords ? present[t * kAngleWords + w] : 0u;
+      int incl = __popc(bits);
+      const int mine = incl;
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+      }
+      int run = before + incl - mine;
+      if (w < kAngleWords)
+        for (int b = 0; b < 32; ++b) {
+          const int v = w * 32 + b;
+          if (v < kAngleSpan) rank[t * kAngleSpan + v] = (uint16_t)run;
+          run += (int)((bits >> b) & 1u);
+        }
+      before += __shfl(incl, 63);
+    }
+    if (lane == 0) s_n[t] = before;
+  }
+  __syncthreads();
+  if (lane != 0) return;
   int total = 0;
   for (int t = 0; t < T; ++t) {
-    int n = 0;
-    for (int v = 0; v < kAngleSpan; ++v) {
-      rank[t * kAngleSpan + v] = (uint16_t)n;
-      if ((present[t * kAngleWords + (v >> 5)] >> (v & 31)) & 1u) ++n;
-    }
+    const int n = s_n[t];
     int b = 1;
     while ((1 << b) < n) ++b;
     meta->n[t] = n;
