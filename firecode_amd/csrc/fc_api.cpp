@@ -2236,6 +2236,27 @@ int fc_string_embed(const double *m1, int64_t n1, int64_t A1, const double *cent
   return sync();
 }
 
+// First touch of freshly allocated host memory (a NumPy array the caller just made) on a thread of its own: one byte per
+// page, no device call.  Regions below 1 MB are not worth a thread.
+struct HostPrefault {
+  std::vector<std::pair<volatile char *, size_t>> regions;
+  std::thread t;
+  void add(void *p, size_t bytes) {
+    if (p != nullptr && bytes >= ((size_t)1 << 20)) regions.emplace_back(static_cast<volatile char *>(p), bytes);
+  }
+  void start() {
+    if (regions.empty()) return;
+    t = std::thread([r = regions] {
+      for (const auto &reg : r)
+        for (size_t off = 0; off < reg.second; off += 4096) reg.first[off] = 0;
+    });
+  }
+  void join() {
+    if (t.joinable()) t.join();
+  }
+  ~HostPrefault() { join(); }
+};
+
 // ---- a17-a20 -----------------------------------------------------------------------
 // tfd_keep_out != nullptr (fc_torsion_scan_tfd): the fingerprints never leave the device -- the list
 // [starting structure] + [scanned conformers with at least one rotated bond] is TFD-pruned at once.
@@ -2311,20 +2332,19 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   }
   // The caller's fresh output arrays are touched for the first time by whoever writes them: 13 MB of counts at 1.7 M
   // angle-sets are 3 300 page faults under the copy that brings them down (1.3 ms of this thread between the first
-  // match and the ladder, the device idle for half of it: tools/trace_phases.py).  A thread without any device call
-  // writes zeros to them while the scan runs; the copy then finds the pages in place (0.3 ms, beside the first-match walk).
-  std::thread prefault;
-  struct JoinGuard {
-    std::thread &t;
-    ~JoinGuard() {
-      if (t.joinable()) t.join();
-    }
-  } prefault_guard{prefault};
-  if (tfd_keep_out && S >= (1 << 17))
-    prefault = std::thread([rotated_bonds_out, tfd_keep_out, S] {
-      std::memset(rotated_bonds_out, 0, (size_t)S * sizeof(int64_t));
-      std::memset(tfd_keep_out, 0, (size_t)S + 1);
-    });
+  // match and the ladder, the device idle for half of it: tools/trace_phases.py); the 4.6 MB of the survivors' re-scan
+  // 0.65 ms where the DMA takes 0.09.  A thread without any device call writes one byte per page while the scan runs;
+  // the copies then find the pages in place.
+  HostPrefault prefault;
+  if (tfd_keep_out) {
+    prefault.add(rotated_bonds_out, (size_t)S * sizeof(int64_t));
+    prefault.add(tfd_keep_out, (size_t)S + 1);
+  } else {
+    prefault.add(coords_out, coords_out ? (size_t)S * A * 3 * sizeof(double) : 0);
+    prefault.add(tf_out, tf_out ? (size_t)S * Q * sizeof(double) : 0);
+    prefault.add(rotated_bonds_out, (size_t)S * sizeof(int64_t));
+  }
+  prefault.start();
   FC_TRY(launch_torsion_scan(db.as<double>(), A, dt.as<int64_t>(), T, dmk.as<uint8_t>(),
                              dmv.as<int16_t>(), drs.as<int16_t>(), dnm.as<int32_t>(),
                              dnr.as<int32_t>(), da.as<int64_t>(), S, thresh, backoff_deg,
@@ -2335,6 +2355,7 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
     (void)hipStreamSynchronize(ctx().stream);
     lap("scan kernels done");
   }
+  prefault.join();
   if (coords_out) FC_TRY(d2h(coords_out, dout.p, (size_t)S * A * 3 * sizeof(double)));
   lap("coords down");
   if (tf_out) FC_TRY(d2h(tf_out, dtf.p, (size_t)S * Q * sizeof(double)));
@@ -2367,9 +2388,8 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   {  // the counts, while the first-match walk runs (the copy into the caller's pageable array keeps this thread busy, the
      // device is not waiting for it: its pages are in place, see `prefault`)
     FC_TRY(side_streams());
-    const bool prefaulted = prefault.joinable();
-    if (prefaulted) prefault.join();
-    else std::memset(tfd_keep_out, 0, (size_t)S + 1);
+    prefault.join();
+    std::memset(tfd_keep_out, 0, (size_t)S + 1);
     FC_TRY(d2h_staged(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t), ctx().s_comm));
   }
   lap("first match enqueued, counts down");

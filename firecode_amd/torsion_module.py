@@ -5,11 +5,13 @@ import numpy as np
 from firecode_amd import _lib as L
 
 
-def torsion_scan(base, torsions, masks, angles, thresh=1.5, backoff=5):
+def torsion_scan(base, torsions, masks, angles, thresh=1.5, backoff=5, out=None):
     """Inner loops of ``clustered_csearch`` (firecode/torsion_module.py:812-856)
     for one starting structure: every row of ``angles`` (S, T) is applied to
     ``base`` (A, 3) with the clash test and the 5-degree back-off.
-    Returns (coords (S, A, 3), rotated_bonds (S,))."""
+    Returns (coords (S, A, 3), rotated_bonds (S,)).  ``out``: a C-contiguous float64 (S, A, 3) array (or view)
+    to write the conformers into -- a caller that puts the starting structure in front of them saves the copy
+    of ``np.concatenate``."""
     base = L.f64(base)
     tors = L.i64(torsions).reshape(-1, 4)
     msk = L.u8(np.asarray(masks, dtype=bool)).reshape(tors.shape[0], -1)
@@ -17,7 +19,10 @@ def torsion_scan(base, torsions, masks, angles, thresh=1.5, backoff=5):
     A, T, S = base.shape[0], tors.shape[0], ang.shape[0]
     if base.ndim != 2 or base.shape[1] != 3 or msk.shape[1] != A:
         raise L.FirecodeHipInputError(L.FC_E_INVALID, "base must be (A, 3) and masks (T, A)")
-    out = np.empty((S, A, 3))
+    if out is None:
+        out = np.empty((S, A, 3))
+    elif not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == (S, A, 3) and out.flags.c_contiguous):
+        raise L.FirecodeHipInputError(L.FC_E_INVALID, "out must be a C-contiguous float64 array of shape (S, A, 3)")
     rot = np.zeros(S, dtype=np.int64)
     L.call("fc_torsion_scan", L.pf(base), A, L.pi(tors), T, L.pb(msk), L.pi(ang), S, float(thresh),
            int(backoff), L.pf(out), L.pi(rot))
@@ -199,13 +204,15 @@ def clustered_csearch_core(coords, torsions, rotation_masks, n_out=100, thresh=1
     if logfunction is not None:
         logfunction(f"> Group 1/1 - {len(torsions)} bonds, {[int(t[4]) for t in torsions]} n-folds, "
                     f"1 starting point = {n_sets} conformers")
-    pruned = torsion_scan(base, quads, rotation_masks, cartesian_rows_at(values, np.flatnonzero(keep[1:])), thresh=thresh)[0]
-    if keep[0]:
-        pruned = np.concatenate([base[None], pruned])
-    output = list(pruned)
+    rows = np.flatnonzero(keep[1:])
+    first = 1 if keep[0] else 0
+    pruned = np.empty((first + len(rows),) + base.shape)  # the starting structure in front, the survivors written behind it
+    if first:
+        pruned[0] = base
+    torsion_scan(base, quads, rotation_masks, cartesian_rows_at(values, rows), thresh=thresh, out=pruned[first:])
     if n_new > n_out:
-        output = most_diverse_conformers(n_out, output, seed=seed)
-    return np.array(output)
+        return np.array(most_diverse_conformers(n_out, list(pruned), seed=seed))
+    return pruned
 
 
 N_FOLD_ANGLES = {2: (0, 180), 3: (0, 120, 240), 4: (0, 90, 180, 270), 6: (0, 60, 120, 180, 240, 300)}

@@ -79,9 +79,12 @@ def csearch():
             rot, keep = fc.torsion_module.torsion_scan_tfd_grid(base, torsions, masks, values, torsions, thresh=1.5, tfd_thresh=10)
         t_scan_tfd = time.perf_counter() - t0
         t1 = time.perf_counter()
-        surv = fc.torsion_module.torsion_scan(base, torsions, masks, fc.utils.cartesian_rows_at(values, np.flatnonzero(keep[1:])), thresh=1.5)[0]
-        if keep[0]:
-            surv = np.concatenate([base[None], surv])
+        rows = np.flatnonzero(keep[1:])  # (as clustered_csearch_core does it: the starting structure in front, the survivors written behind it)
+        first = 1 if keep[0] else 0
+        surv = np.empty((first + len(rows),) + base.shape)
+        if first:
+            surv[0] = base
+        fc.torsion_module.torsion_scan(base, torsions, masks, fc.utils.cartesian_rows_at(values, rows), thresh=1.5, out=surv[first:])
         t_regen = time.perf_counter() - t1
         t3 = time.perf_counter()
         _, rmask = fc.pruner.prune_by_rmsd(surv, atoms, 0.5)

@@ -21,7 +21,7 @@ for s, e, _ in last:
 busy += ce - cs
 per = {}
 for s, e, n in last:
-    k = n.split("(")[0][-48:]
+    k = n.replace("(anonymous namespace)::", "").split("(")[0][-48:]
     per[k] = per.get(k, 0) + (e - s)
 top = sorted(per.items(), key=lambda kv: -kv[1])[:12]
 print(json.dumps({"runs_in_trace": len(starts), "last_run_span_ms": (end - s0) / 1e6, "device_busy_ms": busy / 1e6,
