@@ -2246,10 +2246,13 @@ struct HostPrefault {
   }
   void start() {
     if (regions.empty()) return;
-    t = std::thread([r = regions] {
-      for (const auto &reg : r)
-        for (size_t off = 0; off < reg.second; off += 4096) reg.first[off] = 0;
-    });
+    try {
+      t = std::thread([r = regions] {
+        for (const auto &reg : r)
+          for (size_t off = 0; off < reg.second; off += 4096) reg.first[off] = 0;
+      });
+    } catch (...) {  // (no thread to be had: the copies fault the pages in themselves, as they always did)
+    }
   }
   void join() {
     if (t.joinable()) t.join();
