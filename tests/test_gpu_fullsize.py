@@ -371,3 +371,44 @@ def test_cfg4_full_size_eight_logical_ranks(fc):
     assert np.array_equal(np.flatnonzero(mask), np.sort(first))
     assert counts.max() <= cap and counts.max() - counts.min() < 0.1 * counts.mean()
     assert int(counts.sum()) == int(sum(c * (c - 1) // 2 for c in np.bincount(asg)))
+
+
+@pytest.mark.parametrize("q", [5, 12])
+def test_first_match_at_two_phase_size_without_structure(fc, q):
+    """fc_tfd_first_match at a size where the two-phase forms are the default (N >= 65 536) on fingerprints WITHOUT the
+    order of a systematic scan (random cluster centres, a third of the rows without any partner): the walk's window
+    boxes exclude little, rows stay open for tens of thousands of columns.  16-bit path == fp32 two-phase kernels ==
+    the one-phase kernel (Q = 12: the sixteen bits hold a lower bound only, every candidate takes the fp64 sum)."""
+    from firecode_amd import _lib as L
+
+    rng = np.random.default_rng(300 + q)
+    n = 70000
+    centres = rng.uniform(-180, 180, size=(9000, q))
+    tf = centres[rng.integers(0, len(centres), n)] + rng.normal(scale=1.2, size=(n, q))
+    tf[rng.integers(0, n, n // 3)] = rng.uniform(-180, 180, size=(n // 3, q))
+    tf = np.ascontiguousarray((tf + 180) % 360 - 180)
+    out = {}
+    for name, env in (("u16", {}), ("f32", {"FC_TFD_U16": "0"}), ("one", {"FC_TFD_LOOKAHEAD": "0"})):
+        for k in ("FC_TFD_U16", "FC_TFD_LOOKAHEAD"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        out[name] = np.zeros(n, dtype=np.int64)
+        L.call("fc_tfd_first_match", L.pf(tf), n, q, 10.0, L.pi(out[name]))
+    for k in ("FC_TFD_U16", "FC_TFD_LOOKAHEAD"):
+        os.environ.pop(k, None)
+    assert np.array_equal(out["u16"], out["one"]) and np.array_equal(out["f32"], out["one"])
+    gap = (out["one"] - np.arange(n))[out["one"] >= 0]
+    assert (out["one"] < 0).sum() > n // 4 and (gap > 20000).sum() > 100
+    # thresholds at which everything / nothing is similar, and one between two grid values of the sixteen bits
+    for thr in (5000.0, 1e-3, 10.0 + 1.0 / 364.0):
+        fm = np.zeros(n, dtype=np.int64)
+        L.call("fc_tfd_first_match", L.pf(tf), n, q, thr, L.pi(fm))
+        os.environ["FC_TFD_LOOKAHEAD"] = "0"
+        one = np.zeros(n, dtype=np.int64)
+        L.call("fc_tfd_first_match", L.pf(tf), n, q, thr, L.pi(one))
+        os.environ.pop("FC_TFD_LOOKAHEAD", None)
+        assert np.array_equal(fm, one), thr
+        if thr == 5000.0:
+            assert np.array_equal(fm[:-1], np.arange(1, n)) and fm[-1] == -1
+        if thr == 1e-3:
+            assert (fm < 0).all()

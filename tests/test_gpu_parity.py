@@ -577,6 +577,34 @@ def test_scan_back_off_closed_form_equals_the_walked_loop(fc, monkeypatch, thres
     assert 0.1 < (runs["closed"][1] < nz).mean() < 0.9  # back-off loops that ran out, and loops that ended early
 
 
+@pytest.mark.parametrize("n_atoms,n_quads", [(90, 5), (140, 5), (40, 70), (64, 33)])
+def test_scan_tree_size_classes_of_the_level_kernel(fc, monkeypatch, n_atoms, n_quads):
+    """k_ts_level's compile-time classes: a node's state through 3 x 64 registers (<= 64 atoms), 6 x 64 (<= 128) or read in
+    place (more); the last level's dihedrals 64 / Q conformers at a time (Q <= 64) or straight away (more); the closed
+    form of the back-off loop for <= 256 (rest, moving) pairs per torsion, the walked loop beyond (the early torsions
+    of a 90-atom chain have thousands).  Tree == one-wavefront-per-row kernel bit for bit (coordinates, counts,
+    fingerprints), a sample against the oracle."""
+    base, tors, masks = _chain_case(n_atoms, 5, seed=200 + n_atoms)
+    angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 5)
+    rng = np.random.default_rng(n_atoms + n_quads)
+    quads = tors if n_quads == 5 else np.array([rng.choice(n_atoms, 4, replace=False) for _ in range(n_quads)])
+    runs = {}
+    for name, env in (("tree", {}), ("rows", {"FC_SCAN_TREE": "0"})):
+        monkeypatch.delenv("FC_SCAN_TREE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tf, rot, out = fc.torsion_module.torsion_scan_fingerprints(base, tors, masks, angles, quads, thresh=1.6, want_coords=True)
+        runs[name] = (out, rot, tf)
+    monkeypatch.delenv("FC_SCAN_TREE", raising=False)
+    for a, b in zip(runs["tree"], runs["rows"]):
+        assert np.array_equal(a, b)
+    pick = rng.integers(0, len(angles), 60)
+    ref_c, ref_r = o.torsion_scan(base, tors, masks, angles[pick], thresh=1.6)
+    assert np.array_equal(runs["tree"][1][pick], ref_r)
+    assert np.abs(runs["tree"][0][pick] - ref_c).max() < TOL
+    assert np.abs(runs["tree"][2][pick] - o.get_tf_mat(ref_c, quads)).max() < 1e-8  # (arbitrary quadruplets: dihedrals near +-180 amplify)
+
+
 def test_scan_back_off_threshold_exactly_on_a_distance(fc):
     """A clash threshold EQUAL to a distance the back-off loop meets: the closed form cannot decide such a pair (its
     value is within roundings of the threshold) and hands the node to the walked loop; counts as the oracle's
