@@ -23,6 +23,7 @@
 #pragma once
 
 #include <cstdint>
+#include <type_traits>
 #include <cstdlib>
 
 #if defined(__HIPCC__)
@@ -326,30 +327,39 @@ FC_HD uint32_t tiny_first(const Acc &A, int n, uint32_t n_graph, uint8_t *scr) {
   }
   // the reference's orders: _plain_bfs from the earliest node over the neighbour lists in edge order ...
   uint8_t *q = scr, *frm = scr + 18, *tS = scr + 36, *tV = scr + 68;
+  uint32_t *keybuf = reinterpret_cast<uint32_t *>(scr + 36);  // (over tS / tV, which are filled behind the walk: 17 keys)
   q[0] = (uint8_t)src;
   frm[0] = 0xFF;
   int qt = 1;
   for (int qh = 0; qh < qt; ++qh) {
     const int v = q[qh], f = frm[qh];
-    const uint32_t xv = A.x(v), pv = A.par(v);
-    int64_t last = -1;
-    for (;;) {
-      uint32_t bkey = kNone;
-      int bk = -1;
-      for (int k = 0; k < n; ++k) {
-        if (k == v || k == f) continue;
-        uint32_t key;
-        if (A.par(k) == xv) key = A.slot(k);                   // a child of v: the edge is the child's
-        else if (pv != xv && A.x(k) == pv) key = A.slot(v);    // v's own first match
-        else continue;
-        if ((int64_t)key > last && key < bkey) bkey = key, bk = k;
+    const uint32_t xv = A.x(v), pv = A.par(v), sv = A.slot(v);
+    // ONE pass over the members per node: its neighbours go straight behind the queue's end, kept in the order of their
+    // edges by insertion (a node of a first-match forest has its one first match and a few children).  Every member's
+    // three numbers are requested whatever they turn out to be: with the look-ups behind branches -- and a pass per
+    // neighbour found -- the walk was a chain of dependent LDS round trips, ~350 cycles per member and pass on a
+    // wavefront that has its SIMD to itself (tools/cf_stamps.py).
+    int c = 0;
+#pragma unroll 6
+    for (int k = 0; k < n; ++k) {
+      const uint32_t pk = A.par(k), xk = A.x(k), sk = A.slot(k);
+      const bool child = pk == xv;                     // a child of v: the edge is the child's
+      const bool up = !child && pv != xv && xk == pv;  // v's own first match
+      if ((child || up) && k != v && k != f) {
+        const uint32_t key = child ? sk : sv;
+        int p = c;
+        while (p > 0 && keybuf[p - 1] > key) {
+          keybuf[p] = keybuf[p - 1];
+          q[qt + p] = q[qt + p - 1];
+          --p;
+        }
+        keybuf[p] = key;
+        q[qt + p] = (uint8_t)k;
+        ++c;
       }
-      if (bk < 0) break;
-      q[qt] = (uint8_t)bk;
-      frm[qt] = (uint8_t)v;
-      ++qt;
-      last = (int64_t)bkey;
     }
+    for (int j = 0; j < c; ++j) frm[qt + j] = (uint8_t)v;
+    qt += c;
   }
   // ... into a set of ints (hash(n) == n), then the set of that set's iteration (show_nodes), its first element
   auto place = [&](uint8_t *t, uint32_t mask, int k) {
@@ -877,11 +887,26 @@ struct ChunkExport {
 
 // fm: first-match array (absolute indices, -1: none); the chunk = structures [lo, lo + d); flags[x] = 1 for every
 // structure the chunk rejects (tiny components); the others go to ex.  Returns the number of exported components.
+#if defined(FC_TFD_STAMPS) && defined(__HIPCC__)
+static __device__ unsigned long long g_cf_stamps[48];
+#endif
+#if defined(FC_TFD_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+// tuning build: ticks per phase of chunk_front, one chunk in 64 sampled, slots [16 + 8 e + phase] by chunk-length class e
+#define FC_CF_BEGIN const bool cf_on_ = g.tid == 0 && ((t0 / (uint32_t)(d > 0 ? d : 1)) & 63u) == 0u; unsigned long long cf_t_ = cf_on_ ? wall_clock64() : 0ull; \
+  const int cf_e_ = d <= 19 ? 0 : d <= 77 ? 1 : d <= 307 ? 2 : d <= 1229 ? 3 : 4
+#define FC_CF(i) do { if (cf_on_) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_cf_stamps[cf_e_ * 8 + (i)], n_ - cf_t_); cf_t_ = n_; } } while (0)
+#define FC_CF_N(i, v) do { if (cf_on_) atomicAdd(&g_cf_stamps[cf_e_ * 8 + (i)], (unsigned long long)(v)); } while (0)
+#else
+#define FC_CF_BEGIN do { } while (0)
+#define FC_CF(i) do { } while (0)
+#define FC_CF_N(i, v) do { } while (0)
+#endif
 template <class G>
 FC_HD int chunk_front(G &g, const ChunkLocal &L, const int64_t *fm, int64_t lo, int d, uint32_t t0, uint8_t *flags,
                       const ChunkExport &ex) {
   const int dp = chunk_dpad(d);
   int m = 0;
+  FC_CF_BEGIN;
   {
     uint32_t carry = 0;
     for (int base = 0; base < d; base += g.size) {
@@ -900,6 +925,8 @@ FC_HD int chunk_front(G &g, const ChunkLocal &L, const int64_t *fm, int64_t lo, 
     m = (int)carry;
   }
   g.sync();
+  FC_CF(0);
+  FC_CF_N(7, 1);
   if (m == 0) return 0;
   // (1) the edge order: slots of the chunk's set of (i_rel, j_rel) tuples, filled in ascending i_rel
   if (m >= 2) {
@@ -908,6 +935,7 @@ FC_HD int chunk_front(G &g, const ChunkLocal &L, const int64_t *fm, int64_t lo, 
     for (int x = g.tid; x < d; x += g.size) L.pos[x] = 0;
     g.sync();
   }
+  FC_CF(1);
   // (2) tree roots by pointer jumping (a first-match graph is a forest: one edge per node, to a later one)
   for (int x = g.tid; x < d; x += g.size) L.root[x] = L.jr[x];
   g.sync();
@@ -919,6 +947,7 @@ FC_HD int chunk_front(G &g, const ChunkLocal &L, const int64_t *fm, int64_t lo, 
       g.sync();
     }
   }
+  FC_CF(2);
   // (3) graph nodes, component sizes, members grouped by component
   uint16_t *size = reinterpret_cast<uint16_t *>(L.table), *off = size + dp, *fill = off + dp, *lmem = L.rank;
   uint16_t *rlist = reinterpret_cast<uint16_t *>(L.mark);
@@ -970,6 +999,7 @@ FC_HD int chunk_front(G &g, const ChunkLocal &L, const int64_t *fm, int64_t lo, 
   g.sync();
   for (int c = g.tid; c < nr; c += g.size) rlist[c] = fill[c];
   g.sync();
+  FC_CF(3);
   // (4) components: the tiny ones here, one lane each; the others exported
   struct Acc {
     const uint16_t *lm, *jr, *pos;
@@ -977,26 +1007,44 @@ FC_HD int chunk_front(G &g, const ChunkLocal &L, const int64_t *fm, int64_t lo, 
     FC_HD uint32_t par(int k) const { return jr[lm[k]]; }
     FC_HD uint32_t slot(int k) const { return pos[lm[k]]; }
   };
-  uint16_t *biglist = fill;
-  int nexp = 0;
-  for (int base = 0; base < nr; base += g.size) {
-    const int ci = base + g.tid;
-    int r = 0, n = 0, o = 0;
-    if (ci < nr) r = rlist[ci], n = size[r], o = off[r];
-    const bool big = n > kTinyMax;
-    uint32_t tot;
-    const uint32_t pre = g.scan_excl(big ? 1u : 0u, tot);
-    g.sync();  // (biglist = fill: every lane has read its rlist / size / off entry)
-    if (big) biglist[nexp + (int)pre] = (uint16_t)r;
-    nexp += (int)tot;
-    if (n >= 2 && !big) {
-      const Acc A{lmem + o, L.jr, L.pos};
-      const uint32_t first = tiny_first(A, n, ng, L.tiny + (size_t)g.tid * kTinyScratch);
-      for (int k = 0; k < n; ++k)
-        if (lmem[o + k] != first) flags[lmem[o + k]] = 1;
-    }
+  // The components in the order of their size, largest first (a counting sort over 2 .. kTinyMax nodes and "larger"):
+  // a lane's walk costs ~n^2 steps and a wavefront waits for its slowest lane -- taken as they come, every wavefront of
+  // a chunk of thousands had a component of a dozen nodes among its 64 and the three in four that have 2 or 3 nodes
+  // waited for it (tools/cf_stamps.py: this phase was 73 % of the workgroup-per-chunk kernel, half of the others').
+  // sorted = root's array (the roots are in size / off / the member lists by now); the large ones come first: they are
+  // the export list.
+  // bins[0 .. kTinyMax]: count per size (index 0: larger), then the cursors -- in the first lane's scratch, which no walk uses yet
+  static_assert(kTinyScratch >= 2 * (2 * (kTinyMax + 1) + 2), "the size bins live in one lane's scratch");
+  uint16_t *sorted = L.root, *bins = reinterpret_cast<uint16_t *>(L.tiny);
+  constexpr int kBins = kTinyMax + 1;       // (index n for 2 <= n <= kTinyMax; 0: more than kTinyMax)
+  for (int k = g.tid; k < 2 * kBins + 2; k += g.size) bins[k] = 0;
+  g.sync();
+  for (int ci = g.tid; ci < nr; ci += g.size) {
+    const int n = size[rlist[ci]];
+    g.atomic_add16(bins, n > kTinyMax ? 0 : n, 1);
   }
   g.sync();
+  int nexp = bins[0];
+  for (int ci = g.tid; ci < nr; ci += g.size) {
+    const int r = rlist[ci], n = size[r], bin = n > kTinyMax ? 0 : n;
+    int start = 0;  // components in front of this size: the larger ones, then the sizes above
+    if (bin != 0) {
+      start = bins[0];
+      for (int q = kTinyMax; q > bin; --q) start += bins[q];
+    }
+    sorted[start + (int)g.atomic_add16(bins + kBins + 1, bin, 1)] = (uint16_t)r;
+  }
+  g.sync();
+  uint16_t *biglist = sorted;
+  for (int ci = nexp + g.tid; ci < nr; ci += g.size) {
+    const int r = sorted[ci], n = size[r], o = off[r];
+    const Acc A{lmem + o, L.jr, L.pos};
+    const uint32_t first = tiny_first(A, n, ng, L.tiny + (size_t)g.tid * kTinyScratch);
+    for (int k = 0; k < n; ++k)
+      if (lmem[o + k] != first) flags[lmem[o + k]] = 1;
+  }
+  g.sync();
+  FC_CF(4);
   for (int b = 0; b < nexp; ++b) {
     const int r = biglist[b], n = size[r], o = off[r];
     for (int k = g.tid; k < n; k += g.size) {
@@ -1007,6 +1055,7 @@ FC_HD int chunk_front(G &g, const ChunkLocal &L, const int64_t *fm, int64_t lo, 
     }
     if (g.tid == 0) ex.rec[b] = CompRecord{t0, ex.moff0 + (uint32_t)o, (uint32_t)n, ng};
   }
+  FC_CF(5);
   return nexp;
 }
 

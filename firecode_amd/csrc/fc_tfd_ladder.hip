@@ -1168,6 +1168,14 @@ int pyset_order_pairs_device(const int64_t *pairs_host, int64_t n, int64_t *orde
 }
 
 #if defined(FC_TFD_STAMPS)
+extern "C" int fc_debug_cf_stamps(unsigned long long *out48, int reset) {
+  if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(tfd::g_cf_stamps), 48 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[48] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(tfd::g_cf_stamps), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
 extern "C" int fc_debug_tfd_stamps(unsigned long long *out16, int reset) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(tfd::g_tfd_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
   if (reset) {
