@@ -305,25 +305,29 @@ template <class Acc>
 FC_HD uint32_t tiny_first(const Acc &A, int n, uint32_t n_graph, uint8_t *scr) {
   int src = 0;
   uint32_t best = kNone;
-  for (int k = 0; k < n; ++k)
-    if (A.par(k) != A.x(k) && A.slot(k) < best) best = A.slot(k), src = k;
+#pragma unroll 6
+  for (int k = 0; k < n; ++k) {
+    const uint32_t pk = A.par(k), xk = A.x(k), sk = A.slot(k);
+    const bool take = pk != xk && sk < best;
+    best = take ? sk : best;
+    src = take ? k : src;
+  }
   // networkx FilterAtlas: a component of at least half the graph is listed in the GRAPH's node order -- its earliest
   // node is the first endpoint of its earliest edge
   if (2u * (uint32_t)n >= n_graph) return A.x(src);
   const uint32_t fmask = n <= 4 ? 7u : 31u;
   {  // no two members in one home slot: every member sits at home whatever the order, the first is the smallest residue
-    uint32_t seen = 0, bestr = 64, bx = 0;
-    bool clean = true;
+    uint32_t seen = 0, twice = 0, bestr = 64, bx = 0;
+#pragma unroll 6
     for (int k = 0; k < n; ++k) {
-      const uint32_t r = A.x(k) & fmask;
-      if ((seen >> r) & 1u) {
-        clean = false;
-        break;
-      }
+      const uint32_t xk = A.x(k), r = xk & fmask;
+      twice |= seen & (1u << r);
       seen |= 1u << r;
-      if (r < bestr) bestr = r, bx = A.x(k);
+      const bool take = r < bestr;
+      bestr = take ? r : bestr;
+      bx = take ? xk : bx;
     }
-    if (clean) return bx;
+    if (twice == 0u) return bx;
   }
   // the reference's orders: _plain_bfs from the earliest node over the neighbour lists in edge order ...
   uint8_t *q = scr, *frm = scr + 18, *tS = scr + 36, *tV = scr + 68;
@@ -361,41 +365,43 @@ FC_HD uint32_t tiny_first(const Acc &A, int n, uint32_t n_graph, uint8_t *scr) {
     for (int j = 0; j < c; ++j) frm[qt + j] = (uint8_t)v;
     qt += c;
   }
-  // ... into a set of ints (hash(n) == n), then the set of that set's iteration (show_nodes), its first element
-  auto place = [&](uint8_t *t, uint32_t mask, int k) {
+  // ... into a set of ints (hash(n) == n), then the set of that set's iteration (show_nodes), its first element.
+  // Which slots are taken is a 32-bit mask in a register (a set of at most 18 ints has 8 or 32 slots): a probe is a few
+  // bit operations, not a byte read from LDS and a wait; the table itself is only written, and read once in slot order.
+  auto place = [&](uint8_t *t, uint32_t &occ, uint32_t mask, int k) {
     const uint64_t h = A.x(k);
     uint64_t perturb = h, i = h & mask;
     for (;;) {
-      const int lim = (i + 9 <= mask) ? 9 : 0;
-      for (int j = 0; j <= lim; ++j)
-        if (t[i + j] == 0xFF) {
-          t[i + j] = (uint8_t)k;
-          return;
-        }
+      const uint32_t w = (i + 9 <= mask) ? 0x3FFu : 1u;  // the linear window: ten slots, or this one
+      const uint32_t open = ~(occ >> (uint32_t)i) & w;
+      if (open != 0u) {
+        const uint32_t s = (uint32_t)i + (uint32_t)__builtin_ctz(open);
+        occ |= 1u << s;
+        t[s] = (uint8_t)k;
+        return;
+      }
       perturb >>= 5;
       i = (i * 5 + 1 + perturb) & mask;
     }
   };
-  uint32_t maskS = 7, maskV = 7;
-  auto add = [&](uint8_t *t, uint32_t &mask, int &fill, int k) {
-    place(t, mask, k);
+  auto add = [&](uint8_t *t, uint32_t &occ, uint32_t &mask, int &fill, int k) {
+    place(t, occ, mask, k);
     ++fill;
     if ((uint32_t)fill * 5u >= mask * 3u) {  // 8 -> 32 slots at the fifth key; 32 slots hold 18
       uint8_t old[8];
       for (int s = 0; s < 8; ++s) old[s] = t[s];
-      for (int s = 0; s < 32; ++s) t[s] = 0xFF;
+      const uint32_t was = occ;
+      occ = 0u;
       mask = 31;
       for (int s = 0; s < 8; ++s)
-        if (old[s] != 0xFF) place(t, mask, old[s]);
+        if ((was >> s) & 1u) place(t, occ, mask, old[s]);
     }
   };
-  for (int s = 0; s < 32; ++s) tS[s] = 0xFF, tV[s] = 0xFF;
+  uint32_t maskS = 7, maskV = 7, occS = 0u, occV = 0u;
   int fillS = 0, fillV = 0;
-  for (int i = 0; i < qt; ++i) add(tS, maskS, fillS, q[i]);
-  for (uint32_t s = 0; s <= maskS; ++s)
-    if (tS[s] != 0xFF) add(tV, maskV, fillV, tS[s]);
-  for (uint32_t s = 0; s <= maskV; ++s)
-    if (tV[s] != 0xFF) return A.x(tV[s]);
+  for (int i = 0; i < qt; ++i) add(tS, occS, maskS, fillS, q[i]);
+  for (uint32_t m = occS; m != 0u; m &= m - 1u) add(tV, occV, maskV, fillV, tS[__builtin_ctz(m)]);
+  if (occV != 0u) return A.x(tV[__builtin_ctz(occV)]);
   return A.x(src);
 }
 
