@@ -585,7 +585,20 @@ FC_HD void bfs_rank_euler(G &g, const CompLocal &L, int n, int src, uint16_t *ra
 // tuning build: cycles of the phases of the LARGEST component seen (tools/ladder_stamps.py reads g_tfd_stamps)
 static __device__ unsigned long long g_tfd_stamps[16];
 #endif
-#if defined(FC_TFD_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(FC_TFD_STAMPS) && defined(__HIP_DEVICE_COMPILE__) && defined(FC_TFD_STAMPS_SMALL)
+// (second form: the phases of the components of 19 ... 76 nodes, one in 64 sampled, ticks of 10 ns SUMMED; slot 11 counts them)
+#define FC_STAMP(i)                                                                                  \
+  do {                                                                                               \
+    if (g.tid == 0 && n <= 76 && (mx[0] & 63u) == 0u) {                                              \
+      const unsigned long long now_ = wall_clock64();                                                \
+      atomicAdd(&g_tfd_stamps[i], now_ - t_prev_);                                                   \
+      if ((i) == 0) atomicAdd(&g_tfd_stamps[11], 1ull);                                              \
+      t_prev_ = now_;                                                                                \
+    }                                                                                                \
+  } while (0)
+#define FC_STAMP_BEGIN unsigned long long t_prev_ = wall_clock64()
+#define FC_COUNT(i, v) do { } while (0)
+#elif defined(FC_TFD_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 #define FC_STAMP(i)                                                                                  \
   do {                                                                                               \
     if (g.tid == 0 && n >= 3000) {                                                                   \
