@@ -7,7 +7,8 @@
 //   timelines (s_memtime stamps into a side buffer; results unchanged, timing not):   FC_TIMELINE  FC_H2_TIMELINE  FC_RB_TIMELINE
 //     FC_TFD_STAMPS (cfg3's three steps: fc_tfd_core.h -- cycles per phase of the largest TFD component, tools/ladder_stamps.py;
 //       fc_prune.hip -- phases of the first-match walk per workgroup, tools/fm_stamps.py; fc_torsion.hip -- per-node phases of the
-//       scan tree's last level, tools/ts_stamps.py)
+//       scan tree's last level, tools/ts_stamps.py; with FC_TFD_STAMPS_SMALL the components of 19 ... 76 nodes instead of the
+//       largest, tools/comp_stamps_small.py; phases of chunk_front, tools/cf_stamps.py)
 //   ablations -- WRONG RESULTS (a phase of the kernel skipped):
 //     split-half / fp32 screens:  FC_H2_ABLATE_K  FC_H2_ABLATE_ROWS  FC_H2_ABLATE_POLY  FC_F32_ABLATE_K  FC_F32_ABLATE_POLY
 //     candidate staging:          FC_ABLATE_PUSH  FC_ABLATE_STAGE  FC_ABLATE_OVERFLOW  FC_ABLATE_REDO
@@ -18,7 +19,7 @@
 #pragma once
 
 #if !defined(FC_TUNING_BUILD) &&                                                                                             \
-    (defined(FC_TIMELINE) || defined(FC_H2_TIMELINE) || defined(FC_RB_TIMELINE) || defined(FC_TFD_STAMPS) || defined(FC_H2_ABLATE_K) ||   \
+    (defined(FC_TIMELINE) || defined(FC_H2_TIMELINE) || defined(FC_RB_TIMELINE) || defined(FC_TFD_STAMPS) || defined(FC_TFD_STAMPS_SMALL) || defined(FC_H2_ABLATE_K) ||   \
      defined(FC_H2_ABLATE_ROWS) || defined(FC_H2_ABLATE_POLY) || defined(FC_F32_ABLATE_K) || defined(FC_F32_ABLATE_POLY) ||  \
      defined(FC_ABLATE_PUSH) || defined(FC_ABLATE_STAGE) || defined(FC_ABLATE_OVERFLOW) || defined(FC_ABLATE_REDO) ||         \
      defined(FC_RB_NOSTAGE) || defined(FC_RB_NOPASS1) || defined(FC_RB_NOPASS2) || defined(FC_RB_NOJACOBI) ||                \
