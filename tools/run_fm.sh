@@ -3,7 +3,7 @@ set -e
 mkdir -p gpurun_out/fm
 timeout -k 10 200 python tools/fm_probe.py
 for ahead in 32 64 128 256; do
-  FC_TFD_DENSE_AHEAD=$ahead rocprofv3 --kernel-trace --stats -d gpurun_out/fm/prof_$ahead --output-format csv -- python3 tools/fm_probe.py > /dev/null 2>&1
+  FC_TFD_LOOKAHEAD=$ahead rocprofv3 --kernel-trace --stats -d gpurun_out/fm/prof_$ahead --output-format csv -- python3 tools/fm_probe.py > /dev/null 2>&1
   python - $ahead <<'PY'
 import csv,glob,sys
 f=glob.glob("gpurun_out/fm/prof_%s/**/*kernel_stats.csv"%(sys.argv[1]),recursive=True)[0]
