@@ -284,6 +284,9 @@ k_comp_block(const CompRecord *__restrict__ rec, const uint32_t *__restrict__ li
              uint8_t *__restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   __shared__ uint64_t red[40];
+  // The largest class (a few dozen components of thousands of nodes, one per workgroup) ends the component phase: its
+  // wavefronts share their SIMDs with the thousands of the other classes' kernels; they go first at the issue port.
+  if (CAP > 2048) __builtin_amdgcn_s_setprio(3);
   CompLocal L;
   comp_local_carve(lds_raw, CAP, TBL, CAP2, L);
   BlockGroup g(red);
