@@ -1158,7 +1158,9 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 // similar pairs (the bench) four units in five end after stage 1.
 // STAGED: the subset stage only (flagged units go to the unit queue); otherwise the full test only --
 // two kernels, so that neither carries the other's registers
-template <int NW, bool BITS = true, bool STAGED = false>
+// TC: conformers of the column tile: 64; 32 for structures whose 64-column tile does not fit the LDS (214 ... ~370 atoms: lean,
+// single-stage launches only) -- two runs of 32 columns per LDS-DMA instruction, one 16 x 32 unit per row tile
+template <int NW, bool BITS = true, bool STAGED = false, int TC = 64>
 __global__ void __launch_bounds__(NW * 64, FC_F32_WGS)
 k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restrict__ G, int64_t N,
                           int64_t Npad, int A, double A_thr2, KabschF32Bounds bd, int IB, int64_t rank,
@@ -1175,7 +1177,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
   if ((gate == 1 && counters[15] != 0ull) || (gate == 2 && counters[15] == 0ull)) return;
   extern __shared__ double lds_raw[];
   float *__restrict__ lds = reinterpret_cast<float *>(lds_raw);
-  constexpr int TC = 64;
+  static_assert(TC == 64 || (TC == 32 && !BITS && !STAGED), "32-column tiles: lean single-stage launches only");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1202,7 +1204,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
     if (it & (1ull << 31)) it_last = IB >> 5;
     if (it & (1ull << 63)) it_first = IB >> 5;
   } else {
-    const int64_t NT = Npad >> 6;
+    const int64_t NT = Npad / TC;
     jt = (int64_t)(b % (unsigned long long)NT);
     lb = (int64_t)(b / (unsigned long long)NT);
   }
@@ -1213,13 +1215,28 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
 
   {  // column tile by LDS-DMA: one 1-KiB instruction per (s, c) run
     const int n_runs = KS * 3;
-    const int kh_l = lane >> 5, cs_l = (lane >> 3) & 3, k1_l = (lane >> 2) & 1, c4_l = (lane & 3) * 4;
-    for (int q = wv; q < n_runs; q += NW) {
-      const int sg = q / 3, c = q - sg * 3;
-      const int a = sg * 4 + kh_l * 2 + k1_l;
-      const float *src = Xsf + (int64_t)(a * 3 + c) * Npad + j0 + cs_l * 16 + c4_l;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)(lds + q * 256), 16, 0, 0);
+    if (TC == 64) {
+      const int kh_l = lane >> 5, cs_l = (lane >> 3) & 3, k1_l = (lane >> 2) & 1, c4_l = (lane & 3) * 4;
+      for (int q = wv; q < n_runs; q += NW) {
+        const int sg = q / 3, c = q - sg * 3;
+        const int a = sg * 4 + kh_l * 2 + k1_l;
+        const float *src = Xsf + (int64_t)(a * 3 + c) * Npad + j0 + cs_l * 16 + c4_l;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds + q * 256), 16, 0, 0);
+      }
+    } else {  // a run = [kh][two sub-tiles][k1][16 columns] = 128 floats: lanes 0..31 the even run, 32..63 the odd one
+      const int l32 = lane & 31;
+      const int kh_l = l32 >> 4, cs_l = (l32 >> 3) & 1, k1_l = (l32 >> 2) & 1, c4_l = (l32 & 3) * 4;
+      for (int q2 = wv; 2 * q2 < n_runs; q2 += NW) {
+        const int q = 2 * q2 + (lane >> 5);
+        if (q < n_runs) {  // (an odd number of runs: the last instruction's upper half stays off)
+          const int sg = q / 3, c = q - sg * 3;
+          const int a = sg * 4 + kh_l * 2 + k1_l;
+          const float *src = Xsf + (int64_t)(a * 3 + c) * Npad + j0 + cs_l * 16 + c4_l;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                           (__attribute__((address_space(3))) void *)(lds + q2 * 256), 16, 0, 0);
+        }
+      }
     }
     for (int idx = tid; idx < TC + IB; idx += NW * 64) {
       const int64_t g = idx < TC ? j0 + idx : i0 + (idx - TC);
@@ -1402,7 +1419,7 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
     const int64_t lrow0 = lb * IB + (int64_t)it * 16;
     unsigned nz = 0;  // lanes 0..15: OR of the 16-bit pieces written for row ib + lane
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < TC / 32; ++half) {
       const int cs0 = half * 2;
       if (j0 + (cs0 + 2) * 16 - 1 <= ib) {  // both sub-tiles at or below the diagonal
         if (BITS && lane < 16 && ib + lane < N) {
@@ -1411,7 +1428,8 @@ k_simbits_screen_mfma_f32(const float *__restrict__ Xsf, const double *__restric
         }
         continue;
       }
-      const int nk = half == 0 ? ((it << 1) | 1) : (unit_exists(it + NW, 0) ? ((it + NW) << 1) : (unit_exists(it + NW, 1) ? (((it + NW) << 1) | 1) : -1));
+      const int nk = (TC == 64 && half == 0) ? ((it << 1) | 1)
+                                               : (unit_exists(it + NW, 0) ? ((it + NW) << 1) : ((TC == 64 && unit_exists(it + NW, 1)) ? (((it + NW) << 1) | 1) : -1));
       if constexpr (STAGED) {
         const bool any = run_unit(std::true_type{}, it, half, nk, nz);
         if (any && lane == 0) unit_list[atomicAdd(stageN + 2, 1u)] = (unsigned)((it << 1) | half);
@@ -3616,6 +3634,72 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
         FC_TRY(check_launch("k_simbits_screen_mfma_h2<narrow>"));
         e->item_key[3] = -1;  // (the table holds 32-column items: the next launch of another screen rebuilds it)
         g_last_screen = 16;
+        mark_main();
+        return FC_OK;
+      }
+    }
+  }
+  // Structures whose band is too wide for the split-half bound (extended ones: radius of gyration beyond ~11-14 A at these
+  // sizes) and whose 64-column fp32 tile does not fit the LDS (214 atoms and more): the fp32 matrix-pipe kernel with a
+  // 32-column tile, lean single-stage launches, up to the size at which its own bound stops being small (p0 < 2e-3:
+  // ~370 atoms).  They went to the fp64 vector screen (8-12 ms per 7.2e7 pairs at 224 ... 384 atoms).
+  {
+    const int64_t A4n = (e->A + 3) / 4 * 4;
+    const char *f32_env_n = getenv("FC_SCREEN_F32");
+    const size_t lds_wide = (size_t)A4n * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32;
+    const size_t lds_n = (size_t)A4n * 3 * 32 * sizeof(float) + (32 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32;
+    const KabschF32Bounds bfn = kabsch_f32_bounds(A4n);
+    if (!want_valu && e->lean && lds_wide > kLdsLimit && lds_n <= kLdsLimit && (g_screen_forced == 0 || g_screen_forced == 32) &&
+        !(f32_env_n && f32_env_n[0] == '0') && e->row_block % 32 == 0 && bfn.p0 < 2.0e-3f &&
+        (uint64_t)A4n * 3 * (uint64_t)e->Npad < (1ull << 32)) {
+      if (e->g_max < 0.0) {
+        auto *cnt_max = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
+        FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
+        hipLaunchKernelGGL(k_max_nonneg, dim3((unsigned)std::min<int64_t>(ceil_div(e->Npad, 256), 256)), dim3(256), 0, ctx().stream,
+                           e->G.as<double>(), e->Npad, cnt_max);
+        FC_TRY(check_launch("k_max_nonneg"));
+        unsigned long long bits_max = 0;
+        FC_TRY(d2h(&bits_max, cnt_max, sizeof bits_max));
+        FC_TRY(sync());
+        FC_HIP_TRY(hipMemsetAsync(cnt_max, 0, sizeof(unsigned long long), ctx().stream));
+        std::memcpy(&e->g_max, &bits_max, sizeof(double));
+      }
+      static const double kBandMaxF = [] {
+        const char *v = getenv("FC_SCREEN_BAND_MAX");
+        const double x = v ? atof(v) : 4.0;
+        return x > 0.0 ? x : 4.0;
+      }();
+      const double band_f = (double)bfn.p0 * 2.0 * e->g_max / (double)e->A;
+      const bool band_ok = g_screen_forced == 32 || (f32_env_n && (f32_env_n[0] == '2' || f32_env_n[0] == '3')) || band_f <= kBandMaxF * thr2_margin;
+      if (band_ok && std::isfinite(e->g_max)) {
+        if (!e->xsf_valid) {
+          const int64_t n = A4n * 3 * e->Npad;
+          FC_TRY(e->Xsf.reserve((size_t)n * sizeof(float)));
+          hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, e->Xs.as<double>(), n,
+                             e->Xsf.as<float>());
+          FC_TRY(check_launch("k_f64_to_f32"));
+          FC_TRY(e->sub.reserve((size_t)e->Npad * 8 * sizeof(float)));
+          hipLaunchKernelGGL(k_subset_stats, dim3((unsigned)ceil_div(e->Npad, 256)), dim3(256), 0, ctx().stream, e->Xs.as<double>(),
+                             e->Npad, (int)e->A, e->sub.as<float>());
+          FC_TRY(check_launch("k_subset_stats"));
+          e->xsf_valid = true;
+        }
+        const int64_t NTn = e->Npad / 32;
+        FC_TRY(screen_item_table(e, NTn, n_lblocks, /*halves=*/false, 32));
+        unsigned long long n_items = (unsigned long long)NTn * (unsigned long long)n_lblocks;
+        const uint64_t *item_table_dev = nullptr;
+        if (e->item_total > 0) n_items = (unsigned long long)e->item_total, item_table_dev = e->item_table.as<uint64_t>();
+        if (n_items >= (1ull << 31)) return set_error(FC_E_LIMIT, "too many screen items for one launch");
+        auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
+        const void *fn_ = reinterpret_cast<const void *>(k_simbits_screen_mfma_f32<4, false, false, 32>);
+        FC_HIP_TRY(hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));
+        hipLaunchKernelGGL((k_simbits_screen_mfma_f32<4, false, false, 32>), dim3((unsigned)n_items), dim3(256), lds_n, ctx().stream,
+                           e->Xsf.as<float>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_thr2, bfn, (int)e->row_block, e->rank,
+                           e->world, nullptr, e->W, e->cand.as<uint32_t>(), cnt, e->pairq.as<uint64_t>(),
+                           (unsigned long long)e->pairq_cap, item_table_dev, n_items, nullptr, bfn, 0.f, nullptr, 0, 0);
+        FC_TRY(check_launch("k_simbits_screen_mfma_f32<narrow>"));
+        e->item_key[3] = -1;  // (the table holds 32-column items: the next launch of another screen rebuilds it)
+        g_last_screen = 32;
         mark_main();
         return FC_OK;
       }

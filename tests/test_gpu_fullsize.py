@@ -83,6 +83,31 @@ def test_large_compact_structures_prune_properties(fc, n, a):
     assert np.array_equal(S, expect) and grey == 0
 
 
+@pytest.mark.parametrize("n,a,seed", [(6010, 224, 2), (5000, 260, 2), (4000, 288, 2)])
+def test_large_extended_structures_prune_properties(fc, n, a, seed):
+    """The fp32 matrix-pipe screen's 32-column tile (214 ... 360 atoms, where the split-half bound's band is too wide:
+    self-avoiding walks with a radius of gyration of 15-16 A) at sizes with many row blocks and a partial last column
+    tile: the default selection takes it; one survivor per cluster, the LAST member of each, idempotent, sampled values
+    against the oracle."""
+    from firecode_amd import _lib
+
+    X, atoms, asg = syn.synthetic_ensemble(n, a, seed=seed, cluster_size=50)
+    pruned, mask = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    assert _lib.screen_last_kind() == 32
+    K = len(np.unique(asg))
+    assert mask.sum() == K and len(np.unique(asg[mask])) == K
+    last = np.zeros(K, dtype=np.int64)
+    last[asg] = np.arange(len(asg))
+    assert np.array_equal(np.sort(np.flatnonzero(mask)), np.sort(last))
+    _, m2 = fc.pruner.prune_by_rmsd(pruned, atoms, 0.5)
+    assert m2.all()
+    rng = np.random.default_rng(a)
+    iu, ju = rng.integers(0, n, 1500), rng.integers(0, n, 1500)
+    r, d = fc.rmsd.rmsd_and_max_batch(X, iu, ju, center=True)
+    r0, d0 = o.rmsd_and_max_batch(X[iu], X[ju], center=True)
+    assert np.abs(r - r0).max() < TOL and ((r < 0.5) == (asg[iu] == asg[ju])).all()
+
+
 def test_cfg4_shape_80_atoms(fc):
     """the A = 80 kernel variant (one workgroup per CU) at a size the test can afford"""
     X, atoms, asg = syn.synthetic_ensemble(12000, 80, seed=4)

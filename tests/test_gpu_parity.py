@@ -1417,6 +1417,39 @@ def test_prune_large_compact_structures(fc, n, a):
     assert np.array_equal(_lib.unpack_bits(bits, n), np.triu(S0, 1))
 
 
+@pytest.mark.parametrize("n,a,seed", [(140, 214, 2), (130, 224, 2), (120, 260, 2), (110, 288, 2), (100, 329, 4), (90, 360, 2)])
+def test_prune_large_extended_structures_on_the_fp32_pipe(fc, n, a, seed):
+    """Extended structures (the generator's self-avoiding walks: radius of gyration 15-20 A) of 214 ... 360 atoms: the band
+    of the split-half bound is too wide for them and the fp32 kernel's 64-column tile does not fit the LDS -- the fp32
+    matrix-pipe screen with a 32-column tile (odd numbers of 12-row runs included: 329 atoms = 83 k-steps, 249 runs).
+    Selected here whatever the band (fc_screen_select(32)); masks against the oracle, and the default selection must
+    give the same mask whichever screen it takes."""
+    from firecode_amd import _lib
+
+    X, atoms, asg = syn.synthetic_ensemble(n, a, seed=seed, cluster_size=3)
+    S0, R0, _ = o.rmsd_similarity_matrix(X, atoms, 0.5)
+    ref = o.greedy_prune_from_matrix(S0)
+    assert 0 < ref.sum() < n
+    try:
+        _lib.screen_select(32)
+        _, mask = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+        kind = _lib.screen_last_kind()
+    finally:
+        _lib.screen_select(0)
+    assert kind == 32
+    assert np.array_equal(mask, ref)
+    _, mask2 = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    assert np.array_equal(mask2, ref)
+    # the pairs the screen lets through hold every similar pair (it is a filter): the exact refine's count of similar pairs
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        try:
+            _lib.screen_select(32)
+            tk, ts, m3, st = ens.bench_prune(0.5, 1.0, reps=2, want_mask=True)
+        finally:
+            _lib.screen_select(0)
+    assert np.array_equal(m3.astype(bool), ref) and int(st[2]) == int(np.triu(S0, 1).sum())
+
+
 @pytest.mark.parametrize("cfg", ["valu8x4", "valu4x8"])
 def test_valu_screen_kernels_still_agree(fc, cfg, monkeypatch):
     monkeypatch.setenv("FC_SCREEN_CFG", cfg)
