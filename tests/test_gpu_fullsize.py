@@ -347,20 +347,24 @@ def test_bench_multi_gpu_sizes_with_logical_ranks(fc, world):
     assert counts.max() - counts.min() < 0.1 * counts.mean()  # the snake deal balances the pairs too
 
 
-def test_large_compact_structures_sharded_with_logical_ranks(fc):
-    """the sharded prune of 260-atom globules (the split-half screen's 32-column items dealt to three logical ranks in snake
-    order): the replayed ladder gives the single-GPU mask, every similar pair is found by exactly one rank"""
+@pytest.mark.parametrize("compact,kind,seed", [(True, 16, 31), (False, 32, 2)])
+def test_large_compact_structures_sharded_with_logical_ranks(fc, compact, kind, seed):
+    """the sharded prune of 260-atom structures -- globules (the split-half screen's 32-column items) and extended ones (the
+    fp32 matrix-pipe screen's) -- dealt to three logical ranks in snake order: every rank takes the narrow-tile screen,
+    the replayed ladder gives the single-GPU mask, every similar pair is found by exactly one rank"""
     from firecode_amd import _lib
 
     n, world = 4200, 3
-    X, atoms, asg = syn.synthetic_ensemble(n, 260, seed=31, cluster_size=5, compact=True)
+    X, atoms, asg = syn.synthetic_ensemble(n, 260, seed=seed, cluster_size=5, compact=compact)
     counts = []
     try:
         with fc.DeviceEnsemble(X, center=True) as ens:
             ref, stats0 = ens.prune(0.5, 1.0)
+            assert _lib.screen_last_kind() == kind
             for r in list(range(1, world)) + [0]:
                 _lib.call("fc_debug_comm_loopback", r, world)
                 mask, stats = ens.prune_sharded(0.5, 1.0)
+                assert _lib.screen_last_kind() == kind
                 counts.append(int(stats[2]))
     finally:
         _lib.call("fc_debug_comm_loopback", -1, 0)
