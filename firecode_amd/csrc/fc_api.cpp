@@ -2237,25 +2237,34 @@ int fc_string_embed(const double *m1, int64_t n1, int64_t A1, const double *cent
 }
 
 // First touch of freshly allocated host memory (a NumPy array the caller just made) on a thread of its own: one byte per
-// page, no device call.  Regions below 1 MB are not worth a thread.
+// page, no device call.  The touch is an atomic OR of zero -- it brings the page in for writing and leaves whatever is
+// there -- so a copy into the same array may run beside it (2 GB of coordinates: the copy must not wait for 5e5 faults
+// it would otherwise take itself, piece by piece, under the DMA).  Regions below 1 MB are not worth a thread.
 struct HostPrefault {
-  std::vector<std::pair<volatile char *, size_t>> regions;
+  std::vector<std::pair<unsigned char *, size_t>> regions;
   std::thread t;
   void add(void *p, size_t bytes) {
-    if (p != nullptr && bytes >= ((size_t)1 << 20)) regions.emplace_back(static_cast<volatile char *>(p), bytes);
+    if (p != nullptr && bytes >= ((size_t)1 << 20)) regions.emplace_back(static_cast<unsigned char *>(p), bytes);
   }
   void start() {
     if (regions.empty()) return;
     try {
       t = std::thread([r = regions] {
         for (const auto &reg : r)
-          for (size_t off = 0; off < reg.second; off += 4096) reg.first[off] = 0;
+          for (size_t off = 0; off < reg.second; off += 4096) (void)__atomic_fetch_or(reg.first + off, (unsigned char)0, __ATOMIC_RELAXED);
       });
     } catch (...) {  // (no thread to be had: the copies fault the pages in themselves, as they always did)
     }
   }
   void join() {
     if (t.joinable()) t.join();
+  }
+  // in front of a copy into the regions: wait when the touches are a matter of a millisecond (they run beside a kernel
+  // the copy has to wait for anyway), let a long one carry on beside the copy
+  void join_if_short() {
+    size_t total = 0;
+    for (const auto &reg : regions) total += reg.second;
+    if (total <= ((size_t)64 << 20)) join();
   }
   ~HostPrefault() { join(); }
 };
@@ -2358,7 +2367,7 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
     (void)hipStreamSynchronize(ctx().stream);
     lap("scan kernels done");
   }
-  prefault.join();
+  prefault.join_if_short();
   if (coords_out) FC_TRY(d2h(coords_out, dout.p, (size_t)S * A * 3 * sizeof(double)));
   lap("coords down");
   if (tf_out) FC_TRY(d2h(tf_out, dtf.p, (size_t)S * Q * sizeof(double)));
