@@ -2236,39 +2236,6 @@ int fc_string_embed(const double *m1, int64_t n1, int64_t A1, const double *cent
   return sync();
 }
 
-// First touch of freshly allocated host memory (a NumPy array the caller just made) on a thread of its own: one byte per
-// page, no device call.  The touch is an atomic OR of zero -- it brings the page in for writing and leaves whatever is
-// there -- so a copy into the same array may run beside it (2 GB of coordinates: the copy must not wait for 5e5 faults
-// it would otherwise take itself, piece by piece, under the DMA).  Regions below 1 MB are not worth a thread.
-struct HostPrefault {
-  std::vector<std::pair<unsigned char *, size_t>> regions;
-  std::thread t;
-  void add(void *p, size_t bytes) {
-    if (p != nullptr && bytes >= ((size_t)1 << 20)) regions.emplace_back(static_cast<unsigned char *>(p), bytes);
-  }
-  void start() {
-    if (regions.empty()) return;
-    try {
-      t = std::thread([r = regions] {
-        for (const auto &reg : r)
-          for (size_t off = 0; off < reg.second; off += 4096) (void)__atomic_fetch_or(reg.first + off, (unsigned char)0, __ATOMIC_RELAXED);
-      });
-    } catch (...) {  // (no thread to be had: the copies fault the pages in themselves, as they always did)
-    }
-  }
-  void join() {
-    if (t.joinable()) t.join();
-  }
-  // in front of a copy into the regions: wait when the touches are a matter of a millisecond (they run beside a kernel
-  // the copy has to wait for anyway), let a long one carry on beside the copy
-  void join_if_short() {
-    size_t total = 0;
-    for (const auto &reg : regions) total += reg.second;
-    if (total <= ((size_t)64 << 20)) join();
-  }
-  ~HostPrefault() { join(); }
-};
-
 // ---- a17-a20 -----------------------------------------------------------------------
 // tfd_keep_out != nullptr (fc_torsion_scan_tfd): the fingerprints never leave the device -- the list
 // [starting structure] + [scanned conformers with at least one rotated bond] is TFD-pruned at once.
@@ -2342,21 +2309,6 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
     FC_TRY(upload(dq, quads, (size_t)Q * 4));
     FC_TRY(dtf.reserve((size_t)S * Q * sizeof(double)));
   }
-  // The caller's fresh output arrays are touched for the first time by whoever writes them: 13 MB of counts at 1.7 M
-  // angle-sets are 3 300 page faults under the copy that brings them down (1.3 ms of this thread between the first
-  // match and the ladder, the device idle for half of it: tools/trace_phases.py); the 4.6 MB of the survivors' re-scan
-  // 0.65 ms where the DMA takes 0.09.  A thread without any device call writes one byte per page while the scan runs;
-  // the copies then find the pages in place.
-  HostPrefault prefault;
-  if (tfd_keep_out) {
-    prefault.add(rotated_bonds_out, (size_t)S * sizeof(int64_t));
-    prefault.add(tfd_keep_out, (size_t)S + 1);
-  } else {
-    prefault.add(coords_out, coords_out ? (size_t)S * A * 3 * sizeof(double) : 0);
-    prefault.add(tf_out, tf_out ? (size_t)S * Q * sizeof(double) : 0);
-    prefault.add(rotated_bonds_out, (size_t)S * sizeof(int64_t));
-  }
-  prefault.start();
   FC_TRY(launch_torsion_scan(db.as<double>(), A, dt.as<int64_t>(), T, dmk.as<uint8_t>(),
                              dmv.as<int16_t>(), drs.as<int16_t>(), dnm.as<int32_t>(),
                              dnr.as<int32_t>(), da.as<int64_t>(), S, thresh, backoff_deg,
@@ -2367,7 +2319,6 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
     (void)hipStreamSynchronize(ctx().stream);
     lap("scan kernels done");
   }
-  prefault.join_if_short();
   if (coords_out) FC_TRY(d2h(coords_out, dout.p, (size_t)S * A * 3 * sizeof(double)));
   lap("coords down");
   if (tf_out) FC_TRY(d2h(tf_out, dtf.p, (size_t)S * Q * sizeof(double)));
@@ -2397,10 +2348,11 @@ static int torsion_scan_impl(const double *base, int64_t A, const int64_t *torsi
   DevBuf dtfF;
   FC_TRY(dtfF.reserve((size_t)std::min<int64_t>(Q, 8) * Npad * sizeof(float)));
   FC_TRY(launch_tfd_first_match(dT.as<double>(), N, Npad, Q, tfd_thresh, dfm.as<int64_t>(), dtfF.as<float>()));
-  {  // the counts, while the first-match walk runs (the copy into the caller's pageable array keeps this thread busy, the
-     // device is not waiting for it: its pages are in place, see `prefault`)
+  {  // the counts, while the first-match walk runs (the copy into the caller's pageable array keeps this thread busy for
+     // 0.3 ms when the array's pages are in place and 1.3 ms when they are fresh from the kernel -- which of the two
+     // depends on the caller's allocator, not on this library: a pre-faulting helper thread was built and brought
+     // nothing measurable, FC_PREFAULT A/B over 4 x 10 searches)
     FC_TRY(side_streams());
-    prefault.join();
     std::memset(tfd_keep_out, 0, (size_t)S + 1);
     FC_TRY(d2h_staged(rotated_bonds_out, drot.p, (size_t)S * sizeof(int64_t), ctx().s_comm));
   }
