@@ -925,6 +925,23 @@ def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_at
         ts.append(time.perf_counter() - t1)
     out["pruned_ensembles_per_s_host_in_mask_out"] = 1.0 / min(ts)
     out["host_in_mask_out_ms"] = 1e3 * min(ts)
+    # ... and the same call on an ensemble that lives in page-locked host memory (firecode_amd.pinned_empty: an integrator that
+    # can choose where its coordinate arrays live; the upload is then a direct DMA, the staging copy is skipped).  Reported
+    # BESIDE host_in_mask_out_ms, which stays the ordinary-array call FIRECODE makes today
+    try:
+        cp = fc.pinned_empty(coords.shape)
+        cp[...] = coords
+        fc.pruner.prune_by_rmsd(cp[:2000], atoms, MAX_RMSD)
+        tp = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            _, m_p = fc.pruner.prune_by_rmsd(cp, atoms, MAX_RMSD)
+            tp.append(time.perf_counter() - t1)
+        out["host_in_mask_out_pinned_ms"] = 1e3 * min(tp)
+        del cp
+    except Exception as ex:  # (reported, never fatal: the contract line does not depend on it)
+        out["host_in_mask_out_pinned_ms"] = None
+        out["host_in_mask_out_pinned_error"] = str(ex)[:200]
     # where that time goes (the same three steps prune_by_rmsd performs, timed apart; min / median of 7)
     legs = {"create_ms": [], "prune_ms": [], "index_ms": []}
     for _ in range(7):

@@ -17,6 +17,7 @@ from firecode_amd._lib import (  # noqa: F401
     device_count,
     device_info,
     init,
+    pinned_empty,
     shutdown,
 )
 from firecode_amd import (  # noqa: F401,E402

@@ -893,6 +893,28 @@ int fc_memory_trim(void) {
   return FC_OK;
 }
 
+int fc_host_alloc_pinned(int64_t bytes, void **out) {
+  FC_API_LOCK;
+  FC_REQUIRE(out != nullptr && bytes >= 0, "bad arguments");
+  *out = nullptr;
+  if (bytes == 0) return FC_OK;
+  FC_TRY(ensure_init());
+  void *p = nullptr;
+  if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return set_error(FC_E_NOMEM, "hipHostMalloc of %lld bytes failed", (long long)bytes);
+  }
+  *out = p;
+  return FC_OK;
+}
+
+int fc_host_free_pinned(void *p) {
+  FC_API_LOCK;
+  if (p == nullptr) return FC_OK;
+  if (hipHostFree(p) != hipSuccess) return set_error(FC_E_HIP, "hipHostFree failed: %s", hipGetErrorString(hipGetLastError()));
+  return FC_OK;
+}
+
 int fc_stream_set(void *hip_stream) {
   FC_API_LOCK;
   FC_TRY(ensure_init());

@@ -79,6 +79,13 @@ int fc_stream_use(void *hip_stream);
  * and reused; FC_POOL_MB caps what is kept, default 8192, 0 disables).  fc_memory_trim returns
  * the kept blocks to the HIP runtime; fc_shutdown does the same. */
 int fc_memory_trim(void);
+/* Page-locked host memory for a caller that can choose where its coordinate arrays live (FIRECODE's Ensemble holds one
+ * (N, A, 3) float64 array per ensemble: firecode/ensemble.py:58-98).  An upload from such memory is a direct DMA -- the
+ * library's staging copy for pageable arrays (0.24 ms per 12 MB) is skipped, nothing else changes:
+ * every entry point takes either kind of pointer.  fc_host_free_pinned releases a block; blocks still alive at
+ * fc_shutdown stay valid host memory and must still be freed by their owner. */
+int fc_host_alloc_pinned(int64_t bytes, void **out);
+int fc_host_free_pinned(void *p);
 /* name, CU count and bytes of HBM of the active device (diagnostics) */
 int fc_device_info(char *name, int64_t name_len, int64_t *n_cu, int64_t *hbm_bytes);
 

@@ -532,6 +532,37 @@ def _chain_case(n_atoms, n_tors, seed):
     return skel, np.array(torsions), np.array(masks)
 
 
+def test_pinned_host_arrays_are_taken_like_any_other(fc):
+    """fc_host_alloc_pinned behind ``firecode_amd.pinned_empty``: an ensemble built into page-locked memory is uploaded by
+    direct DMA (no staging copy) and pruned to the same mask as from an ordinary array; views keep the block alive, the
+    last one frees it; a zero-size request is an ordinary empty array."""
+    import gc
+
+    X, atoms, asg = syn.synthetic_ensemble(3000, 50, seed=12)
+    _, ref = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    P = fc.pinned_empty(X.shape)
+    assert P.shape == X.shape and P.dtype == np.float64 and P.flags.c_contiguous and P.flags.writeable
+    P[...] = X
+    view = P[100:200]
+    _, mask = fc.pruner.prune_by_rmsd(P, atoms, 0.5)
+    assert np.array_equal(mask, ref)
+    del P
+    gc.collect()
+    assert np.array_equal(view, X[100:200])  # (the view still owns the block)
+    _, m2 = fc.pruner.prune_by_rmsd(np.ascontiguousarray(view), atoms, 0.5)
+    assert m2.shape == (100,)
+    del view
+    gc.collect()
+    assert fc.pinned_empty((0, 5, 3)).shape == (0, 5, 3)
+    for _ in range(20):  # (blocks come and go: nothing accumulates, nothing is freed twice)
+        Q = fc.pinned_empty((64, 50, 3))
+        Q[...] = X[:64]
+        del Q
+    gc.collect()
+    _, m3 = fc.pruner.prune_by_rmsd(X, atoms, 0.5)
+    assert np.array_equal(m3, ref)
+
+
 def test_torsion_scan_vs_oracle(fc):
     base, tors, masks = _chain_case(30, 4, seed=31)
     angles = o.cartesian_product(*[(0, 60, 120, 180, 240, 300)] * 4)[::5]
