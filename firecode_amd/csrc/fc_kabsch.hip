@@ -764,13 +764,20 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
   auto row_offsets = [&](int it_, unsigned (&vo)[3]) {
     const int64_t ib_ = i0 + (int64_t)it_ * 16;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) vo[c] = (unsigned)((int64_t)(kq * 3 + c) * Npad + ib_ + l15);
+    for (int c = 0; c < 3; ++c) vo[c] = (unsigned)(((int64_t)(kq * 3 + c) * Npad + ib_ + l15) * 8);  // BYTES inside a k-step
   };
-  auto fetch_a_at = [&](double (&a)[3], const unsigned (&vo)[3], int sx) {
+  auto fetch_a_at = [&](double (&a)[3], unsigned (&vo)[3], int sx) {
     const int sl = sx < KS ? sx : KS - 1;  // fewer than 3 k-steps: harmless re-read
-    const double *__restrict__ xs_s = Xs + (int64_t)sl * 12 * Npad;  // wave-uniform base
+    // wave-uniform base + the lane's 32-bit BYTE offset: one addressing mode of the load (with element offsets the compiler
+    // formed a 64-bit address per load: three vector instructions per k-step beside nine matrix ones)
+    const char *__restrict__ xs_s = reinterpret_cast<const char *>(Xs + (int64_t)sl * 12 * Npad);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) a[c] = xs_s[vo[c]];
+    for (int c = 0; c < 3; ++c) {
+      // (the offset passes through an empty asm in place: that keeps its zero-extension next to the load -- hoisted out of the
+      // K loop it is a 64-bit add per load again -- and costs no copy)
+      asm volatile("" : "+v"(vo[c]));
+      a[c] = *reinterpret_cast<const double *>(xs_s + vo[c]);
+    }
   };
 
   for (int it = it_first + wv; it < it_last; it += NW) {
@@ -794,11 +801,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
         }
         continue;
       }
-      d4_t acc[NT][9];
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int e = 0; e < 9; ++e) acc[t][e] = d4_t{0.0, 0.0, 0.0, 0.0};
+      d4_t acc[NT][9];  // (written by the first k-step, whose third operand is the constant zero: no 36 moves per sub-tile)
 
       // Operand sets rotate through the K loop so that no register copies are
       // needed: row operands (L2 / Infinity Cache, ~1 us under load) in three
@@ -819,16 +822,18 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
 #pragma unroll
           for (int c = 0; c < 3; ++c) b[t][c] = lb_s[c * CST + t * SST];
       };
-      auto mma = [&](const double (&a)[3], const double (&b)[NT][3]) {
+      auto mma = [&](const double (&a)[3], const double (&b)[NT][3], auto first_) {
+        constexpr bool first = decltype(first_)::value;
 #pragma unroll
         for (int x = 0; x < 3; ++x)
 #pragma unroll
           for (int y = 0; y < 3; ++y)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-              acc[t][x * 3 + y] = MODE == 2
-                  ? __builtin_amdgcn_mfma_f64_16x16x4f64(b[t][y], a[x], acc[t][x * 3 + y], 0, 0, 0)
-                  : __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[t][y], acc[t][x * 3 + y], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) {
+              const d4_t c_in = first ? d4_t{0.0, 0.0, 0.0, 0.0} : acc[t][x * 3 + y];
+              acc[t][x * 3 + y] = MODE == 2 ? __builtin_amdgcn_mfma_f64_16x16x4f64(b[t][y], a[x], c_in, 0, 0, 0)
+                                            : __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[t][y], c_in, 0, 0, 0);
+            }
       };
       if (pre_it != it) {  // first unit of the wave, or the prediction below missed
         fetch_a_at(a0, voff, 0);
@@ -839,17 +844,20 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
       fetch_b(b1, 1);
 #define FC_KSTEP(AX, BX, U)             \
   if (sgrp + (U) < KSe) {               \
-    mma(AX, BX);                        \
+    mma(AX, BX, std::false_type{});     \
     fetch_a(AX, sgrp + (U) + 3);        \
     fetch_b(BX, sgrp + (U) + 2);        \
   }
-      for (int sgrp = 0; sgrp < KSe; sgrp += 6) {
-        FC_KSTEP(a0, b0, 0)
-        FC_KSTEP(a1, b1, 1)
-        FC_KSTEP(a2, b0, 2)
-        FC_KSTEP(a0, b1, 3)
-        FC_KSTEP(a1, b0, 4)
-        FC_KSTEP(a2, b1, 5)
+      mma(a0, b0, std::true_type{});  // k-step 0 (there is always one)
+      fetch_a(a0, 3);
+      fetch_b(b0, 2);
+      for (int sgrp = 1; sgrp < KSe; sgrp += 6) {
+        FC_KSTEP(a1, b1, 0)
+        FC_KSTEP(a2, b0, 1)
+        FC_KSTEP(a0, b1, 2)
+        FC_KSTEP(a1, b0, 3)
+        FC_KSTEP(a2, b1, 4)
+        FC_KSTEP(a0, b0, 5)
       }
 #undef FC_KSTEP
       {  // request the next unit's first three k-steps now; they land during the epilogue
@@ -3324,7 +3332,7 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
   if (lds_m > kLdsLimit || NT == 0)
     return set_error(FC_E_LIMIT, "A=%lld atoms exceed the LDS column tile of the value kernel", (long long)e->A);
   const bool fits32 = (uint64_t)((e->A + 3) / 4 * 4) * 3 * (uint64_t)e->Npad < (1ull << 32) &&
-                      (2 * (uint64_t)e->Npad + 16) * 8 < (1ull << 32);  // (the atom pass of MODE 2: byte offsets of three rows)
+                      96 * (uint64_t)e->Npad < (1ull << 32);  // (byte offsets inside one k-step; the atom pass of MODE 2: of three rows)
   if (!fits32) return set_error(FC_E_LIMIT, "ensemble too large for 32-bit operand offsets");
   auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
   const bool two_blocks = 2 * lds_m <= kLdsLimit;
@@ -3712,7 +3720,8 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
     // the fp64 matrix-pipe screen needs its column tile in LDS (up to ~100 atoms); the single-precision
     // screens reach further (fp32 tile: half the bytes; split-half: 128 atoms) and then run without the
     // fp64 screen behind them -- no speculative mode, and a band too wide for them means the VALU screen
-    const bool mfma64_ok = fits32 && lds_m <= kLdsLimit && e->row_block % (two_blocks_fit ? 64 : 128) == 0;
+    const bool mfma64_ok = fits32 && 96 * (uint64_t)e->Npad < (1ull << 32) /* row operands by 32-bit byte offsets */ &&
+                           lds_m <= kLdsLimit && e->row_block % (two_blocks_fit ? 64 : 128) == 0;
     const int64_t A4s = (e->A + 3) / 4 * 4, KS2s = (e->A + 31) / 32;
     const bool single_ok = fits32 && e->row_block % 64 == 0 &&
                            ((size_t)A4s * 3 * 64 * sizeof(float) + (64 + (size_t)e->row_block) * sizeof(float) + kStageBytesF32 <= kLdsLimit ||
