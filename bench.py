@@ -556,11 +556,11 @@ def main():
 def complete_roofline(kernel_ms, owned_pairs, n_conf, n_atoms, world):
     fl = FLOPS_PER_ALIGNMENT(n_atoms)
     tflops = owned_pairs * fl / (kernel_ms * 1e-3) / 1e12
-    traffic, src = pmc_traffic(("r04_pmc_complete.json", "r03_pmc_complete.json"), n_conf, n_atoms, world)
+    traffic, src = pmc_traffic(("r05_pmc_complete.json", "r04_pmc_complete.json", "r03_pmc_complete.json"), n_conf, n_atoms, world)
     return {"bound": "mfma", "kernel": "k_simbits_screen_mfma<4, 2>", "achieved": tflops, "peak": PEAK_F64_MFMA,
             "unit": "TFLOP/s", "frac": tflops / PEAK_F64_MFMA, "traffic": traffic, "traffic_source": src,
             "kernel_ms": kernel_ms, "flops_per_alignment": fl, "dtype": "f64",
-            "clock": pmc_held_clock(("r04_pmc_complete.json", "r03_pmc_complete.json"), n_conf, n_atoms, tflops / PEAK_F64_MFMA, world),
+            "clock": pmc_held_clock(("r05_pmc_complete.json", "r04_pmc_complete.json", "r03_pmc_complete.json"), n_conf, n_atoms, tflops / PEAK_F64_MFMA, world),
             "note": "achieved = SURVEY 8d's algorithmic flops of one complete alignment (53 A + 600) x pairs of one launch / the "
                     "kernel's mean HIP-event duration; peak = the fp64 rate of the matrix pipe, which on this chip is also the "
                     "fp64 vector rate -- the kernel runs its covariance on the first and rotation + deviation pass on the second",

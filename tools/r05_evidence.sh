@@ -49,5 +49,36 @@ laps)
   FC_DEBUG=1 FC_SCAN_LAPS=1 FC_CSEARCH_RUNS=4 timeout -k 10 300 python tools/bench_workloads.py csearch > $O/cfg3_laps.json 2> $O/cfg3_laps.err
   grep -E "\[fc\]" $O/cfg3_laps.err | tail -24
   ;;
+benchprof)
+  say "bench under rocprofv3 (kernel trace + stats; the timed region only)"
+  cd /tmp && cd "$GRAFT_REPO_ROOT"
+  rocprofv3 --kernel-trace --stats -d $O/prof_bench --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras > $O/bench_n1_under_rocprof.json 2> $O/prof_bench.err || exit 1
+  find $O/prof_bench -name "*kernel_stats.csv" -exec cp {} $O/bench_n1_kernel_stats.csv \;
+  rm -rf $O/prof_bench
+  head -4 $O/bench_n1_kernel_stats.csv | cut -c1-200
+  ;;
+pmc)
+  say "PMC passes: complete alignment kernel, BASELINE configs[1] (tools/time_complete.py 10000 50 5)"
+  bash tools/attic/r03_pmc.sh $O/pmc_complete r05 tools/time_complete.py 10000 50 5 > $O/pmc_complete.log 2>&1 || exit 1
+  python3 tools/attic/r03_pmc_json.py $O/pmc_complete/pmc_summary.txt "k_simbits_screen_mfma<4, 2, 64>" $O/pmc_complete.json stats=$O/pmc_complete/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="BASELINE configs[1]: 10000 x 50, fc_bench_rmsd_and_max_all"
+  cp $O/pmc_complete/pmc_summary.txt $O/pmc_complete.txt
+  rm -rf $O/pmc_complete/pmc_* $O/pmc_complete/trace
+  cut -c1-400 $O/pmc_complete.json
+  ;;
+hostin)
+  say "host arrays in -> mask out: breakdown, A/B against the staged DMA, device timeline of one call"
+  python tools/hostin_breakdown.py > $O/hostin_breakdown.json 2>$O/hostin.err || exit 1
+  FC_HOSTIN_PULL=0 python tools/hostin_breakdown.py > $O/hostin_breakdown_staged_dma.json 2>>$O/hostin.err || exit 1
+  python tools/hostin_breakdown.py >> $O/hostin_breakdown.json 2>>$O/hostin.err || exit 1
+  FC_HOSTIN_PULL=0 python tools/hostin_breakdown.py >> $O/hostin_breakdown_staged_dma.json 2>>$O/hostin.err || exit 1
+  : > $O/hostin_pieces.txt
+  for kb in 512 1024 4096; do echo "piece_kb $kb" >> $O/hostin_pieces.txt; FC_HOSTIN_PIECE_KB=$kb python tools/hostin_breakdown.py >> $O/hostin_pieces.txt 2>>$O/hostin.err; done
+  cd /tmp && cd "$GRAFT_REPO_ROOT"
+  rocprofv3 --kernel-trace --memory-copy-trace -d $O/prof_hostin --output-format csv -- python3 tools/hostin_timeline.py > $O/hostin_calls.json 2>>$O/hostin.err || exit 1
+  python3 tools/hostin_timeline.py $O/prof_hostin > $O/hostin_timeline.txt
+  rm -rf $O/prof_hostin
+  FC_TIMELINE_PINNED=1 python3 tools/hostin_timeline.py > $O/hostin_calls_pinned.json 2>>$O/hostin.err
+  cat $O/hostin_breakdown.json $O/hostin_breakdown_staged_dma.json $O/hostin_pieces.txt $O/hostin_calls.json $O/hostin_calls_pinned.json; cat $O/hostin_timeline.txt
+  ;;
 *) echo "unknown part $1"; exit 2 ;;
 esac
