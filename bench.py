@@ -9,7 +9,7 @@ The line's top-level fields are the reference-precision measurement in SURVEY.md
         over EVERY pair of the HBM-resident ensemble (fc_bench_rmsd_and_max_all: covariance tiles on the fp64
         matrix pipe, rotation and deviation pass per pair, two dense (N, N) fp64 outputs that stay in HBM).
         K steps enqueued back to back, one host wait, bracketed by barrier + device synchronisation.
-        `roofline` = that pass's dominant kernel, k_simbits_screen_mfma<4, 2>, HIP events on its stream around
+        `roofline` = that pass's dominant kernel, k_simbits_screen_mfma<4, 2, 64, true>, HIP events on its stream around
         every launch of the timed region, against the fp64 peak by 8d's 53 A + 600 flop per alignment.
 
 Extra blocks of the same line (each with its own device timing, outside the timed region):
@@ -557,13 +557,15 @@ def complete_roofline(kernel_ms, owned_pairs, n_conf, n_atoms, world):
     fl = FLOPS_PER_ALIGNMENT(n_atoms)
     tflops = owned_pairs * fl / (kernel_ms * 1e-3) / 1e12
     traffic, src = pmc_traffic(("r05_pmc_complete.json", "r04_pmc_complete.json", "r03_pmc_complete.json"), n_conf, n_atoms, world)
-    return {"bound": "mfma", "kernel": "k_simbits_screen_mfma<4, 2>", "achieved": tflops, "peak": PEAK_F64_MFMA,
+    return {"bound": "mfma", "kernel": "k_simbits_screen_mfma<4, 2, 64, true>", "achieved": tflops, "peak": PEAK_F64_MFMA,
             "unit": "TFLOP/s", "frac": tflops / PEAK_F64_MFMA, "traffic": traffic, "traffic_source": src,
             "kernel_ms": kernel_ms, "flops_per_alignment": fl, "dtype": "f64",
             "clock": pmc_held_clock(("r05_pmc_complete.json", "r04_pmc_complete.json", "r03_pmc_complete.json"), n_conf, n_atoms, tflops / PEAK_F64_MFMA, world),
             "note": "achieved = SURVEY 8d's algorithmic flops of one complete alignment (53 A + 600) x pairs of one launch / the "
                     "kernel's mean HIP-event duration; peak = the fp64 rate of the matrix pipe, which on this chip is also the "
-                    "fp64 vector rate -- the kernel runs its covariance on the first and rotation + deviation pass on the second",
+                    "fp64 vector rate -- the kernel runs its covariance on the first and rotation + deviation pass on the second; "
+                    "the flops are the algorithmic ones whatever the kernel issues (round 5: the rmsd comes from the eigenvalue, "
+                    "one add per atom and pair less than 8d counts)",
             "kernel_ms_source": "HIP events on the kernel's stream around every launch of the timed region"
                                 + ("" if world == 1 else "; rank 0's launches")}
 
@@ -680,7 +682,7 @@ def run_alignments(ctx):
         out["roofline"] = complete_roofline(k_ms, owned, n_conf, n_atoms, world)
         bytes_per_alignment = 2 * n_atoms * 24 + 16
         achieved = owned * bytes_per_alignment / (k_ms * 1e-3) / 1e9
-        out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_simbits_screen_mfma<4, 2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_simbits_screen_mfma<4, 2, 64, true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": out["roofline"]["traffic"],
                                "algorithmic_bytes_per_alignment": bytes_per_alignment,
                                "compulsory_bytes": n_conf * n_atoms * 24 + 16 * owned,

@@ -34,7 +34,7 @@ int launch_prep_tiles(const double *, int64_t, int64_t, const int32_t *, int64_t
 int launch_pairs_exact(const fc_ensemble *, const int64_t *, const int64_t *, int64_t, double *,
                        double *, double *);
 int launch_matrix_exact(const fc_ensemble *, double *, double *);
-int launch_rmsd_values(fc_ensemble *, double, double *, double *, int64_t rank = 0, int64_t world = 1);
+int launch_rmsd_values(fc_ensemble *, double, double *, double *, int64_t rank = 0, int64_t world = 1, bool explicit_sum = false);
 int launch_mirror_upper(double *m_dev, int64_t N);
 int launch_gather_matrix_pairs(const double *, const double *, int64_t, const int64_t *, const int64_t *, int64_t,
                                double *, double *);
@@ -1049,6 +1049,14 @@ static int rmsd_and_max_all(fc_ensemble *ens, double *rmsd_out, double *maxdev_o
     float ms = 0.f;
     FC_HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
     *ms_kernel = ms;
+  }
+  if (tiled && cnt[6] > (unsigned long long)ens->pairq_cap) {
+    // more pairs for the fix-up than its queue holds.  Near-duplicates first (the eigenvalue form of the rmsd declines pairs
+    // closer than ~1e-3 A): the same kernel with the running sum
+    FC_HIP_TRY(hipMemsetAsync(ens->counters.p, 0, 16 * sizeof(uint64_t), c.stream));
+    FC_TRY(launch_rmsd_values(ens, 0.0, dr.as<double>(), dm.as<double>(), 0, 1, /*explicit_sum=*/true));
+    FC_TRY(d2h(cnt, ens->counters.p, sizeof cnt));
+    FC_TRY(sync());
   }
   if (tiled && cnt[6] > (unsigned long long)ens->pairq_cap) {
     // more degenerate pairs than the fix-up queue holds (planar or collinear structures: every pair): the plain kernel

@@ -632,7 +632,13 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // TC: conformers of the column tile held in LDS.  64 everywhere except the complete alignments of structures whose
 // 64-column tile no longer fits the CU's LDS: 105 ... 208 atoms take 32 columns, 209 ... 416 atoms 16 (MODE 2 only)
 // instead of leaving the tiled kernel for k_matrix_exact, 5.4 x slower per pair.
-template <int NW, int MODE = 0, int TC = 64>
+// EIG (MODE 2): the rmsd of a pair from its largest eigenvalue -- sum |p - R q|^2 = (Gp + Gq) - 2 lambda for the optimal
+// rotation, lambda as the Newton iteration left it -- instead of a running sum in the atom pass (one fp64 instruction per
+// atom and pair less, 50 of ~1 100 per pair at 50 atoms; the maximum deviation still comes from the explicit rotated
+// difference).  The difference carries ~u (Gp + Gq) of rounding, so it holds 5e-11 in the rmsd only for pairs further
+// apart than ~1e-3 A (msd A > 2e-10 (Gp + Gq)^2 / A): closer pairs go to the fix-up kernel like the pairs whose rotation
+// was declined.  EIG = false (the launcher's retry when the fix-up queue overflowed: an ensemble of near-duplicates): the sum.
+template <int NW, int MODE = 0, int TC = 64, bool EIG = false>
 __global__ void __launch_bounds__(NW * 64, 2)
 k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ G, int64_t N,
                       int64_t Npad, int A, double A_thr2, int IB, int64_t rank, int64_t world,
@@ -641,6 +647,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
                       unsigned long long Q, const uint64_t *__restrict__ item_table, unsigned long long n_items,
                       double *__restrict__ rmsd_out = nullptr, const unsigned long long *__restrict__ gate = nullptr,
                       double *__restrict__ maxdev_out = nullptr) {
+  static_assert(!EIG || MODE == 2, "EIG: the complete alignments");
   constexpr bool VALUES = MODE != 0;  // 1: rmsd values (Newton), 2: (rmsd, maxdev) by explicit difference
   // sub-tiles (16 columns) per unit: two share the row operands in the screens; the complete-alignment
   // mode takes one at a time -- its epilogue (four rotations, an atom pass) needs the registers the second
@@ -903,16 +910,26 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
           const double Gp = ldsG[TC + it * 16 + l15];
           double nR[4][9];
           bool ok4[4];
+          double msdA4[4] = {0.0, 0.0, 0.0, 0.0};  // EIG: (Gp + Gq) - 2 lambda
           {  // the four Newton iterations in one loop (independent chains side by side: 2.71 -> 2.66 ms per 10^4 x 10^4
              // against one pair after the other), -R straight from the adjugate column (no normalisation of q)
-            double B4[4][9], GG[4], Q44[4][4], nq4[4];
+            double B4[4][9], GG[4], Q44[4][4], nq4[4], lam4[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               GG[r] = Gp + ldsG[cs * 16 + 4 * kq + r];
 #pragma unroll
               for (int e = 0; e < 9; ++e) B4[r][e] = acc[t][e][r];
             }
-            kabsch_quaternion_qcp_lean4(B4, GG, Q44, nq4, ok4);
+            kabsch_quaternion_qcp_lean4(B4, GG, Q44, nq4, ok4, EIG ? lam4 : nullptr);
+            if constexpr (EIG) {
+              const double k_small = 2e-10 / (double)A;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                msdA4[r] = GG[r] - 2.0 * lam4[r];
+                // too close for the difference (also NaN): a declined pair, the fix-up kernel's explicit sum decides
+                if (!(msdA4[r] > k_small * GG[r] * GG[r])) ok4[r] = false, msdA4[r] = 0.0;
+              }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               // (NaN must not reach the stores: the fix-up overwrites what a declined pair leaves)
@@ -962,7 +979,7 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
               const double dy = fma(nR[r][3], qx, fma(nR[r][4], qy, fma(nR[r][5], qz, P[1])));
               const double dz = fma(nR[r][6], qx, fma(nR[r][7], qy, fma(nR[r][8], qz, P[2])));
               const double s2 = fma(dz, dz, fma(dy, dy, dx * dx));
-              ssq[r] += s2;
+              if constexpr (!EIG) ssq[r] += s2;
               // (fmax() first re-quiets its loop-carried operand: one more instruction per pair and atom)
               asm("v_max_f64 %0, %1, %2" : "=v"(mx[r]) : "v"(mx[r]), "v"(s2));
             }
@@ -1001,6 +1018,10 @@ k_simbits_screen_mfma(const double *__restrict__ Xs, const double *__restrict__ 
             accumulate(PA, QA);
             __builtin_amdgcn_sched_barrier(0);
             accumulate(PB, QB);
+          }
+          if constexpr (EIG) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ssq[r] = msdA4[r];
           }
           const bool row_in = i < n32;
           double *__restrict__ ro = rmsd_out + (int64_t)i * N + jb;
@@ -3314,8 +3335,27 @@ static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks, bool
 // all-pairs RMSD values on the matrix pipe (world == 1 layout); rmsd_dev: (N, N), pre-zeroed.
 // maxdev_dev != nullptr: the complete alignment of every pair -- (rmsd, maxdev) from the explicit
 // rotated difference (MODE 2 of the kernel); pairs it could not rotate are redone by the fix-up.
+// one instantiation of the complete-alignment kernel: LDS attribute + launch
+template <int NW, int TC, bool EIG>
+static int launch_complete_variant(fc_ensemble *e, dim3 grid, size_t lds_m, double A_small, int64_t rb, int64_t rank, int64_t world,
+                                   unsigned long long *cnt, const uint64_t *item_table_dev, unsigned long long n_items,
+                                   double *rmsd_dev, double *maxdev_dev) {
+  if (lds_m > 64 * 1024) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_simbits_screen_mfma<NW, 2, TC, EIG>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+    if (err != hipSuccess) return set_error(FC_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
+  }
+  hipLaunchKernelGGL((k_simbits_screen_mfma<NW, 2, TC, EIG>), grid, dim3(NW * 64), lds_m, ctx().stream, e->Xs.as<double>(),
+                     e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb, rank, world, nullptr, e->W, nullptr, cnt,
+                     e->pairq.as<uint64_t>(), (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev, nullptr,
+                     maxdev_dev);
+  return FC_OK;
+}
+
+// explicit_sum (complete alignments only): the rmsd from the running sum of the atom pass instead of the eigenvalue -- the
+// caller's retry when the eigenvalue form sent more near-duplicate pairs to the fix-up than its queue holds
 int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, double *maxdev_dev, int64_t rank,
-                       int64_t world) {
+                       int64_t world, bool explicit_sum) {
   // rank / world: this launch covers the row blocks (of 128) dealt to `rank` in snake order -- the rows a
   // rank of the multi-GPU bench owns; (0, 1) = the whole upper triangle
   const int64_t rb = 128;
@@ -3337,13 +3377,9 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
   auto *cnt = reinterpret_cast<unsigned long long *>(e->counters.p);
   const bool two_blocks = 2 * lds_m <= kLdsLimit;
   const bool complete = maxdev_dev != nullptr;
-  const void *fn = narrow ? (tc == 32 ? reinterpret_cast<const void *>(k_simbits_screen_mfma<8, 2, 32>)
-                                      : reinterpret_cast<const void *>(k_simbits_screen_mfma<8, 2, 16>))
-                 : complete ? (two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4, 2>)
-                                          : reinterpret_cast<const void *>(k_simbits_screen_mfma<8, 2>))
-                            : (two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4, 1>)
-                                          : reinterpret_cast<const void *>(k_simbits_screen_mfma<8, 1>));
-  if (lds_m > 64 * 1024) {
+  const void *fn = two_blocks ? reinterpret_cast<const void *>(k_simbits_screen_mfma<4, 1>)
+                              : reinterpret_cast<const void *>(k_simbits_screen_mfma<8, 1>);
+  if (!complete && lds_m > 64 * 1024) {
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
     if (err != hipSuccess) return set_error(FC_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
   }
@@ -3367,23 +3403,25 @@ int launch_rmsd_values(fc_ensemble *e, double small_rmsd, double *rmsd_dev, doub
                      e->Xs.as<double>(), e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb,   \
                      rank, world, nullptr, e->W, nullptr, cnt, e->pairq.as<uint64_t>(),                   \
                      (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev, nullptr, maxdev_dev)
+  const char *eig_env = getenv("FC_COMPLETE_EIG");  // 0: always the running sum (read per call: the tests compare both forms)
+  const bool eig = complete && !(eig_env && atoi(eig_env) == 0) && !explicit_sum;
+#define FC_LAUNCH_COMPLETE(NW_, TC_)                                                                                        \
+  FC_TRY((eig ? launch_complete_variant<NW_, TC_, true>(e, grid, lds_m, A_small, rb, rank, world, cnt, item_table_dev, n_items, \
+                                                       rmsd_dev, maxdev_dev)                                               \
+              : launch_complete_variant<NW_, TC_, false>(e, grid, lds_m, A_small, rb, rank, world, cnt, item_table_dev,     \
+                                                        n_items, rmsd_dev, maxdev_dev)))
   if (narrow && tc == 32) {
-    hipLaunchKernelGGL((k_simbits_screen_mfma<8, 2, 32>), grid, dim3(8 * 64), lds_m, ctx().stream, e->Xs.as<double>(),
-                       e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb, rank, world, nullptr, e->W, nullptr, cnt,
-                       e->pairq.as<uint64_t>(), (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev, nullptr,
-                       maxdev_dev);
+    FC_LAUNCH_COMPLETE(8, 32);
   } else if (narrow) {
-    hipLaunchKernelGGL((k_simbits_screen_mfma<8, 2, 16>), grid, dim3(8 * 64), lds_m, ctx().stream, e->Xs.as<double>(),
-                       e->G.as<double>(), e->N, e->Npad, (int)e->A, A_small, (int)rb, rank, world, nullptr, e->W, nullptr, cnt,
-                       e->pairq.as<uint64_t>(), (unsigned long long)e->pairq_cap, item_table_dev, n_items, rmsd_dev, nullptr,
-                       maxdev_dev);
+    FC_LAUNCH_COMPLETE(8, 16);
   } else if (complete) {
-    if (two_blocks) FC_LAUNCH_VALUES(4, 2);
-    else FC_LAUNCH_VALUES(8, 2);
+    if (two_blocks) FC_LAUNCH_COMPLETE(4, 64);
+    else FC_LAUNCH_COMPLETE(8, 64);
   } else {
     if (two_blocks) FC_LAUNCH_VALUES(4, 1);
     else FC_LAUNCH_VALUES(8, 1);
   }
+#undef FC_LAUNCH_COMPLETE
 #undef FC_LAUNCH_VALUES
   FC_TRY(check_launch("k_simbits_screen_mfma<values>"));
   if (ctx().mark_after_screen) (void)hipEventRecord(ctx().mark_after_screen, ctx().stream);  // bench hook: end of the tiled kernel

@@ -666,8 +666,10 @@ __host__ __device__ __forceinline__ bool kabsch_quaternion_qcp_lean(const double
 
 // four pairs of one lane: the Newton iterations of all four in one wave-uniform loop; the quaternions come back
 // NOT normalised with their squared lengths (neg_rotation_from_raw_quaternion divides once)
+// lam_out (optional): the converged eigenvalues -- sum |p - R q|^2 = (Gp + Gq) - 2 lambda for the optimal rotation
 __host__ __device__ __forceinline__ void kabsch_quaternion_qcp_lean4(const double (&B)[4][9], const double (&GpGq)[4],
-                                                                     double (&Q)[4][4], double (&nq)[4], bool (&ok)[4]) {
+                                                                     double (&Q)[4][4], double (&nq)[4], bool (&ok)[4],
+                                                                     double *lam_out = nullptr) {
   QcpLeanPoly P[4];
   double x[4], delta[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -687,6 +689,10 @@ __host__ __device__ __forceinline__ void kabsch_quaternion_qcp_lean4(const doubl
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) ok[r] = qcp_lean_quaternion_raw(B[r], P[r], x[r], delta[r], Q[r], nq[r]);
+  if (lam_out != nullptr) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lam_out[r] = x[r];
+  }
 }
 
 // R (row-major) from a unit quaternion, same formulas as kabsch_rotation

@@ -1714,6 +1714,75 @@ def test_rmsd_and_max_all_pairs_above_the_tiled_kernel(fc, n, a):
     assert np.allclose(R, R.T) and np.all(np.diag(R) == 0)
 
 
+@pytest.mark.parametrize("n,a,kind", [(700, 50, "clusters"), (600, 23, "continuous"), (500, 64, "continuous"), (400, 80, "clusters"),
+                                      (300, 130, "clusters"), (200, 260, "clusters"), (500, 40, "duplicates"), (400, 24, "mirror"),
+                                      (450, 30, "far"), (420, 32, "large")])
+def test_complete_alignments_rmsd_from_the_eigenvalue_equals_the_running_sum(fc, monkeypatch, n, a, kind):
+    """The tiled kernel's rmsd comes from the largest eigenvalue, (Gp + Gq) - 2 lambda (k_simbits_screen_mfma<.., EIG>);
+    FC_COMPLETE_EIG=0 keeps the atom pass's running sum.  Both forms on clusters, continuous ensembles, exact and 1e-5 A
+    duplicates (closer than ~1e-3 A: the eigenvalue form hands the pair to the fix-up kernel), a mirror-symmetric
+    structure, coordinates far from the origin and 40 x larger, at every column-tile width (64 / 32 / 16): rmsd within 1e-11
+    of each other (2e-11 x the scale for the large coordinates) and within 1e-10 of the oracle, the maximum deviation --
+    the explicit rotated difference in both -- bit for bit equal except where the fix-up kernel took the pair."""
+    rng = np.random.default_rng(1000 + n + a)
+    if kind == "clusters":
+        X = syn.synthetic_ensemble(n, a, seed=n + a, cluster_size=4)[0]
+    elif kind in ("continuous", "far", "large"):
+        X = syn.continuous_ensemble(n, a, seed=n + a)
+        if kind == "far":
+            X = X + np.array([250.0, -90.0, 40.0])
+        if kind == "large":
+            X = X * 40.0
+    elif kind == "duplicates":
+        X = syn.continuous_ensemble(n, a, seed=n + a)
+        X[200:350] = X[:150]
+        X[350:] = X[:150] + rng.normal(scale=1e-5, size=(150, a, 3))
+    else:  # atoms that tie for the largest deviation
+        base = rng.normal(scale=2.0, size=(a // 2, 3))
+        X = np.repeat(np.concatenate([base, base * np.array([1.0, 1.0, -1.0])])[None], n, axis=0).copy()
+        amp = rng.normal(scale=0.3, size=(n, a // 2, 3))
+        X[:, : a // 2] += amp
+        X[:, a // 2:] += amp * np.array([1.0, 1.0, -1.0])
+    scale = 40.0 if kind == "large" else 1.0
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        R1, D1, _ = ens.rmsd_and_max_all()
+        _, _, st1 = ens.bench_rmsd_and_max_all(1)
+        monkeypatch.setenv("FC_COMPLETE_EIG", "0")
+        R0, D0, _ = ens.rmsd_and_max_all()
+        _, _, st0 = ens.bench_rmsd_and_max_all(1)
+        monkeypatch.delenv("FC_COMPLETE_EIG")
+    iu, ju = np.triu_indices(n, 1)
+    assert np.abs(R1 - R0)[iu, ju].max() < 1e-11 * scale * scale
+    same = D1[iu, ju] == D0[iu, ju]
+    assert np.abs(D1 - D0)[iu, ju].max() < 1e-11 * scale and (~same).sum() <= int(st1[1]) + int(st0[1])
+    assert int(st1[1]) >= int(st0[1])
+    if kind == "duplicates":
+        assert int(st1[1]) >= 150 + 150 and R1[0, 200] < 1e-12 and 0 < R1[0, 350] < 1e-4
+    else:
+        assert int(st1[1]) <= 5
+    sel = rng.choice(len(iu), size=3000, replace=False)
+    r0, d0 = o.rmsd_and_max_batch(X[iu[sel]], X[ju[sel]], center=True)
+    bound = o.rotation_error_bound_batch(X[iu[sel]], X[ju[sel]], center=True)
+    assert np.abs(R1[iu[sel], ju[sel]] - r0).max() < TOL * scale
+    assert np.all(np.abs(D1[iu[sel], ju[sel]] - d0) <= TOL * scale + bound)
+
+
+def test_complete_alignments_of_near_duplicates_beyond_the_fix_up_queue(fc, monkeypatch):
+    """An ensemble of copies: every pair is closer than the eigenvalue form of the rmsd can resolve and the fix-up queue
+    (here cut to 1 000 entries) overflows -- fc_ensemble_rmsd_and_max_all then runs the tiled kernel again with the
+    running sum, which declines no pair of these."""
+    rng = np.random.default_rng(5)
+    base = syn.continuous_ensemble(1, 40, seed=3)[0]
+    X = base[None] + rng.normal(scale=2e-6, size=(300, 40, 3))
+    monkeypatch.setenv("FC_PAIRQ_CAP", "1000")
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        R, D, _ = ens.rmsd_and_max_all()
+    iu, ju = np.triu_indices(300, 1)
+    r0, d0 = o.rmsd_and_max_batch(X[iu], X[ju], center=True)
+    assert np.abs(R[iu, ju] - r0).max() < TOL and np.abs(D[iu, ju] - d0).max() < TOL
+    assert r0.max() < 1e-4 and np.allclose(R, R.T) and np.all(np.diag(R) == 0)
+
+
 def test_context_lifecycle_and_threads(fc):
     """fc_shutdown / fc_init: streams, events and staging are rebuilt, ensembles of the old context
     are refused (never used), pipelined prunes work again; two host threads may call the library

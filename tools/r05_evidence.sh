@@ -60,7 +60,7 @@ benchprof)
 pmc)
   say "PMC passes: complete alignment kernel, BASELINE configs[1] (tools/time_complete.py 10000 50 5)"
   bash tools/attic/r03_pmc.sh $O/pmc_complete r05 tools/time_complete.py 10000 50 5 > $O/pmc_complete.log 2>&1 || exit 1
-  python3 tools/attic/r03_pmc_json.py $O/pmc_complete/pmc_summary.txt "k_simbits_screen_mfma<4, 2, 64>" $O/pmc_complete.json stats=$O/pmc_complete/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="BASELINE configs[1]: 10000 x 50, fc_bench_rmsd_and_max_all"
+  python3 tools/attic/r03_pmc_json.py $O/pmc_complete/pmc_summary.txt "k_simbits_screen_mfma<4, 2, 64, true>" $O/pmc_complete.json stats=$O/pmc_complete/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="BASELINE configs[1]: 10000 x 50, fc_bench_rmsd_and_max_all"
   cp $O/pmc_complete/pmc_summary.txt $O/pmc_complete.txt
   rm -rf $O/pmc_complete/pmc_* $O/pmc_complete/trace
   cut -c1-400 $O/pmc_complete.json
