@@ -28,6 +28,7 @@ namespace fc {
 // ---- launchers implemented in the .hip translation units --------------------
 int launch_prep(const double *, int64_t, int64_t, const int32_t *, int64_t, int, fc_ensemble *, const int32_t *);
 int launch_prep_begin(fc_ensemble *);
+int prebuild_screen_items(fc_ensemble *);
 bool prep_by_tiles(int64_t);
 int launch_prep_tiles(const double *, int64_t, int64_t, const int32_t *, int64_t, int, fc_ensemble *, const int32_t *, int64_t,
                       int64_t);
@@ -271,6 +272,8 @@ static void context_teardown() {
   c.stream = c.own_stream = nullptr;
   if (c.pinned) (void)hipHostFree(c.pinned);
   c.pinned = nullptr;
+  if (c.pinned_word) (void)hipHostFree(c.pinned_word);
+  c.pinned_word = nullptr;
   c.pinned_bytes = 0;
   for (auto &set : c.stage)
     for (int b = 0; b < 2; ++b) {
@@ -485,9 +488,22 @@ static int make_selection(const uint8_t *atom_mask, int64_t A_all, std::vector<i
 
 // prepared layout of N conformers taken from device-resident raw coordinates (all atoms, AoS):
 // conformer n is raw[conf_idx[n]] (conf_idx_dev == nullptr: raw[n])
+// defer_wait: return with the preparation kernel and the copy of the largest G still in flight -- the caller does host
+// work that does not need them (fc_prune_rmsd_host: the prune's reserves and item table) and then calls
+// ensemble_build_finish
+static int ensemble_build_finish(fc_ensemble *e) {
+  if (!e->g_max_pending) return FC_OK;
+  e->g_max_pending = false;
+  FC_TRY(sync());
+  std::memcpy(&e->g_max, ctx().pinned_word, sizeof(double));
+  auto *gmax_dev = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
+  FC_HIP_TRY(hipMemsetAsync(gmax_dev, 0, sizeof(unsigned long long), ctx().stream));
+  return FC_OK;
+}
+
 static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, const uint8_t *atom_mask,
-                              int center, const int32_t *conf_idx_dev, fc_ensemble *e) {
-  std::vector<int32_t> sel;
+                              int center, const int32_t *conf_idx_dev, fc_ensemble *e, bool defer_wait = false) {
+  std::vector<int32_t> &sel = e->sel_host;
   FC_TRY(make_selection(atom_mask, A_all, sel));
   e->N = N;
   e->A = (int64_t)sel.size();
@@ -511,6 +527,18 @@ static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, c
   // the largest G (left by the prep kernel in the last counter word) comes back behind the same wait
   unsigned long long gmax_bits = 0;
   auto *gmax_dev = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
+  if (defer_wait) {
+    Context &c = ctx();
+    if (!c.pinned_word && hipHostMalloc(&c.pinned_word, 64, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      c.pinned_word = nullptr;
+    }
+    if (c.pinned_word) {
+      FC_HIP_TRY(hipMemcpyAsync(c.pinned_word, gmax_dev, sizeof gmax_bits, hipMemcpyDeviceToHost, c.stream));
+      e->g_max_pending = true;
+      return FC_OK;  // (dsel returns to the pool: its next user is ordered behind the kernel on this stream)
+    }
+  }
   FC_TRY(d2h(&gmax_bits, gmax_dev, sizeof gmax_bits));
   FC_TRY(sync());  // (also keeps `sel` / dsel alive until the kernel has read them)
   std::memcpy(&e->g_max, &gmax_bits, sizeof(double));
@@ -531,10 +559,10 @@ static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, c
 // (0.53 ms); the copy of each 4 MB piece split between this thread and a helper thread (0.41 ms: a thread per call
 // for 0.03 ms).
 static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const uint8_t *atom_mask,
-                          int center, fc_ensemble *e) {
+                          int center, fc_ensemble *e, bool defer_wait = false) {
   DevBuf raw;
   FC_TRY(upload(raw, coords, (size_t)N * A_all * 3));
-  return ensemble_build_dev(raw.as<double>(), N, A_all, atom_mask, center, nullptr, e);
+  return ensemble_build_dev(raw.as<double>(), N, A_all, atom_mask, center, nullptr, e, defer_wait);
 }
 
 // (re)shape the bit-matrix workspace for a given sharding
@@ -1345,7 +1373,16 @@ int fc_prune_rmsd_host(const double *coords, int64_t N, int64_t A, const uint8_t
   FC_TRY(ensure_init());
   fc_ensemble e;
   e.epoch = ctx().epoch;
-  FC_TRY(ensemble_build(coords, N, A, atom_mask, center, &e));
+  // the last piece's DMA and the preparation kernel are still running when ensemble_build returns: the prune's reserves and
+  // the screen's item table (host work + one small copy) go under them instead of behind the wait for the largest G
+  int rc = ensemble_build(coords, N, A, atom_mask, center, &e, /*defer_wait=*/true);
+  if (rc == FC_OK) rc = ensemble_shard(&e, 0, 1, default_row_block());
+  if (rc == FC_OK) rc = prebuild_screen_items(&e);
+  const int rc_fin = ensemble_build_finish(&e);  // (always: nothing of `e` may be in flight when it goes out of scope)
+  if (rc != FC_OK || rc_fin != FC_OK) {
+    (void)hipStreamSynchronize(cur_stream());
+    return rc != FC_OK ? rc : rc_fin;
+  }
   return fc_prune_rmsd(&e, max_rmsd, max_dev, energies, max_dE, min_per_group, mask_out, stats);
 }
 

@@ -71,6 +71,7 @@ struct Context {
   // pinned host staging for small device->host results (truly asynchronous copies)
   void *pinned = nullptr;
   size_t pinned_bytes = 0;
+  void *pinned_word = nullptr;  // 64 page-locked bytes: the largest G of a fresh ensemble comes back here without a host wait
   // pinned pieces + events of the staged copies (d2h_staged / h2d_staged): one set per concurrent caller (the TFD
   // ladder's helper threads copy side by side), handed out under stage_mu
   struct StageSet {
@@ -329,6 +330,8 @@ struct fc_ensemble {
   bool xh_valid = false;
   double xh_scale = 0.0;       // the power of two Xh was made with
   double g_max = -1.0;         // largest G (host copy, found on first use): sizes the fp32 screen's band
+  bool g_max_pending = false;  // the copy of the largest G into Context::pinned_word is still in flight (ensemble_build_finish)
+  std::vector<int32_t> sel_host;  // the atom selection: source of an asynchronous upload
   // prune workspace (allocated on first use, kept for later calls)
   fc::DevBuf bits;             // rows_local * W uint64
   fc::DevBuf cand;             // rows_local * W uint32: queue of words to refine

@@ -3332,6 +3332,14 @@ static int screen_item_table(fc_ensemble *e, int64_t NT, int64_t n_lblocks, bool
   return FC_OK;
 }
 
+// the item table the default screens of a prune will ask for (64-column tiles, half items at the tail), built and sent
+// ahead of the launch; a screen that wants another table rebuilds it
+int prebuild_screen_items(fc_ensemble *e) {
+  const int64_t n_lblocks = local_block_count(ceil_div(e->N, e->row_block), e->rank, e->world);
+  if (n_lblocks <= 0 || (e->Npad >> 6) == 0) return FC_OK;
+  return screen_item_table(e, e->Npad >> 6, n_lblocks, /*halves=*/true, 64);
+}
+
 // all-pairs RMSD values on the matrix pipe (world == 1 layout); rmsd_dev: (N, N), pre-zeroed.
 // maxdev_dev != nullptr: the complete alignment of every pair -- (rmsd, maxdev) from the explicit
 // rotated difference (MODE 2 of the kernel); pairs it could not rotate are redone by the fix-up.

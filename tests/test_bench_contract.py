@@ -39,7 +39,7 @@ def _check_headline(d, steps, warmup):
     # the headline is the reference-precision measurement: complete fp64 alignments, fp64 peak
     assert d["dtype"] == "f64"
     r = d["roofline"]
-    assert r["dtype"] == "f64" and r["peak"] == 78.6 and r["kernel"] == "k_simbits_screen_mfma<4, 2>"
+    assert r["dtype"] == "f64" and r["peak"] == 78.6 and r["kernel"] == "k_simbits_screen_mfma<4, 2, 64, true>"
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1.5 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["flops_per_alignment"] == 53 * 50 + 600
     assert r["traffic"] is None or r["traffic_source"].startswith("from_file")
