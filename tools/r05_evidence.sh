@@ -80,5 +80,14 @@ hostin)
   FC_TIMELINE_PINNED=1 python3 tools/hostin_timeline.py > $O/hostin_calls_pinned.json 2>>$O/hostin.err
   cat $O/hostin_breakdown.json $O/hostin_breakdown_staged_dma.json $O/hostin_pieces.txt $O/hostin_calls.json $O/hostin_calls_pinned.json; cat $O/hostin_timeline.txt
   ;;
+pmc80)
+  say "PMC passes: complete alignment kernel at the cfg4 shape (35355 x 80: the <8, 2, 64, true> variant)"
+  bash tools/attic/r03_pmc.sh $O/pmc_complete_a80 r05a80 tools/time_complete.py 35355 80 2 > $O/pmc_complete_a80.log 2>&1 || exit 1
+  python3 tools/attic/r03_pmc_json.py $O/pmc_complete_a80/pmc_summary.txt "k_simbits_screen_mfma<8, 2, 64, true>" $O/pmc_complete_a80.json stats=$O/pmc_complete_a80/kernel_stats.csv n_conformers=35355 n_atoms=80 workload="cfg4 family N = 1 member: 35355 x 80, fc_bench_rmsd_and_max_all"
+  cp $O/pmc_complete_a80/pmc_summary.txt $O/pmc_complete_a80.txt
+  rm -rf $O/pmc_complete_a80/pmc_* $O/pmc_complete_a80/trace
+  python3 tools/time_complete.py 35355 80 3 > $O/complete_a80.json 2>/dev/null
+  cat $O/complete_a80.json
+  ;;
 *) echo "unknown part $1"; exit 2 ;;
 esac
