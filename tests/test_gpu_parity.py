@@ -1767,6 +1767,24 @@ def test_complete_alignments_rmsd_from_the_eigenvalue_equals_the_running_sum(fc,
     assert np.all(np.abs(D1[iu[sel], ju[sel]] - d0) <= TOL * scale + bound)
 
 
+@pytest.mark.parametrize("n,a", [(2, 1), (5, 1), (70, 2), (130, 3), (65, 4), (200, 5), (3, 50), (129, 7)])
+def test_complete_alignments_of_tiny_structures(fc, n, a):
+    """one to seven atoms, two conformers: rank-deficient covariances (every pair of a one- or two-atom structure goes to the
+    fix-up kernel), a single row tile, a single pair -- the tiled kernel's outputs against the oracle, no NaN anywhere"""
+    rng = np.random.default_rng(3 * n + a)
+    X = rng.normal(scale=2.0, size=(n, a, 3))
+    with fc.DeviceEnsemble(X, center=True) as ens:
+        R, D, _ = ens.rmsd_and_max_all()
+    iu, ju = np.triu_indices(n, 1)
+    r0, d0 = o.rmsd_and_max_batch(X[iu], X[ju], center=True)
+    bound = o.rotation_error_bound_batch(X[iu], X[ju], center=True)
+    assert not np.isnan(R).any() and not np.isnan(D).any()
+    assert np.abs(R[iu, ju] - r0).max() < TOL
+    fin = np.isfinite(bound)
+    assert np.all(np.abs(D[iu, ju] - d0)[fin] <= TOL + bound[fin])
+    assert np.allclose(R, R.T) and np.all(np.diag(R) == 0)
+
+
 def test_complete_alignments_of_near_duplicates_beyond_the_fix_up_queue(fc, monkeypatch):
     """An ensemble of copies: every pair is closer than the eigenvalue form of the rmsd can resolve and the fix-up queue
     (here cut to 1 000 entries) overflows -- fc_ensemble_rmsd_and_max_all then runs the tiled kernel again with the
