@@ -234,7 +234,7 @@ def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, wo
         flops = 3 * 2 * 9 * a32
         tflops = owned_pairs * flops / (kernel_ms * 1e-3) / 1e12
         eq = owned_pairs * 2 * 9 * ((n_atoms + 3) // 4 * 4) / (kernel_ms * 1e-3) / 1e12
-        traffic, src = pmc_traffic(("r03_pmc_screen_h2.json", "r03_pmc_screen_h2_cfg4_member.json"), n_conf if traffic_file else None,
+        traffic, src = pmc_traffic(("r05_pmc_screen_h2.json", "r05_pmc_screen_h2_cfg4_member.json", "r03_pmc_screen_h2.json", "r03_pmc_screen_h2_cfg4_member.json"), n_conf if traffic_file else None,
                                    n_atoms, world)
         return {"bound": "mfma", "kernel": "k_simbits_screen_mfma_h2", "achieved": tflops, "peak": PEAK_F16_MFMA,
                 "unit": "TFLOP/s", "frac": tflops / PEAK_F16_MFMA, "traffic": traffic, "traffic_source": src,
@@ -247,12 +247,12 @@ def screen_roofline(_lib, kernel_ms, owned_pairs, n_atoms, traffic_file=True, wo
                                "achieved_tera_lane_instr_per_s": owned_pairs * 75 / (kernel_ms * 1e-3) / 1e12,
                                "peak": PEAK_F32_MFMA / 2, "frac": owned_pairs * 75 / (kernel_ms * 1e-3) / 1e12 / (PEAK_F32_MFMA / 2)},
                 "two_stage": None,
-                "clock": pmc_held_clock(("r03_pmc_screen_h2.json", "r03_pmc_screen_h2_cfg4_member.json"), n_conf if traffic_file else None,
+                "clock": pmc_held_clock(("r05_pmc_screen_h2.json", "r05_pmc_screen_h2_cfg4_member.json", "r03_pmc_screen_h2.json", "r03_pmc_screen_h2_cfg4_member.json"), n_conf if traffic_file else None,
                                         n_atoms, tflops / PEAK_F16_MFMA, world),
                 "issue_model": {"what": "tools/ubench_issue_model.hip (profiles/r03_issue_model_f16mfma_valu*.txt): one SIMD issues a "
                                         "v_mfma_f32_16x16x32_f16 in 8 and an fp32 vector instruction in ~4 of its cycles, whichever "
                                         "waves they come from and however they are interleaved; the matrix pipe is busy 16 per MFMA",
-                                "cycles_per_16x16_subtile": pmc_issue_cycles(("r03_pmc_screen_h2.json", "r03_pmc_screen_h2_cfg4_member.json"),
+                                "cycles_per_16x16_subtile": pmc_issue_cycles(("r05_pmc_screen_h2.json", "r05_pmc_screen_h2_cfg4_member.json", "r03_pmc_screen_h2.json", "r03_pmc_screen_h2_cfg4_member.json"),
                                                                              n_conf if traffic_file else None, n_atoms, world)},
                 "note": "frac = f16 flops issued to the matrix pipe (3 products x 2 x 9 x atoms padded to 32 per pair) / time / "
                         "2.5 PFLOP/s; the kernel is bound by the sum of that and of the vector epilogue (valu_share)"}

@@ -28,6 +28,7 @@ namespace fc {
 // ---- launchers implemented in the .hip translation units --------------------
 int launch_prep(const double *, int64_t, int64_t, const int32_t *, int64_t, int, fc_ensemble *, const int32_t *);
 int launch_prep_begin(fc_ensemble *);
+int launch_prep_body(const double *, int64_t, int64_t, const int32_t *, int64_t, int, fc_ensemble *, const int32_t *);
 int prebuild_screen_items(fc_ensemble *);
 bool prep_by_tiles(int64_t);
 int launch_prep_tiles(const double *, int64_t, int64_t, const int32_t *, int64_t, int, fc_ensemble *, const int32_t *, int64_t,
@@ -274,6 +275,8 @@ static void context_teardown() {
   c.pinned = nullptr;
   if (c.pinned_word) (void)hipHostFree(c.pinned_word);
   c.pinned_word = nullptr;
+  if (c.ladder_all) (void)hipFree(c.ladder_all);
+  c.ladder_all = nullptr;
   c.pinned_bytes = 0;
   for (auto &set : c.stage)
     for (int b = 0; b < 2; ++b) {
@@ -501,8 +504,11 @@ static int ensemble_build_finish(fc_ensemble *e) {
   return FC_OK;
 }
 
-static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, const uint8_t *atom_mask,
-                              int center, const int32_t *conf_idx_dev, fc_ensemble *e, bool defer_wait = false) {
+// Two halves: what does not need the coordinates on the device (selection, reserves, the selection's upload, the reset of the
+// largest-G word) and the preparation launch behind them -- ensemble_build issues the first half in FRONT of the upload, so
+// that nothing but the launch itself stands between the last piece's DMA and the kernel (the trace of one
+// prune_by_rmsd(host arrays) call showed 39 us there).
+static int ensemble_build_prepare(int64_t N, int64_t A_all, const uint8_t *atom_mask, fc_ensemble *e, DevBuf &dsel) {
   std::vector<int32_t> &sel = e->sel_host;
   FC_TRY(make_selection(atom_mask, A_all, sel));
   e->N = N;
@@ -521,9 +527,13 @@ static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, c
   FC_TRY(e->G.reserve((size_t)e->Npad * sizeof(double)));
   FC_TRY(e->Xa.reserve((size_t)std::max<int64_t>(N, 1) * e->A * 3 * sizeof(double)));
   FC_TRY(e->counters.reserve(kCounters * sizeof(uint64_t)));
-  DevBuf dsel;
   FC_TRY(upload(dsel, sel.data(), sel.size()));
-  FC_TRY(launch_prep(raw_dev, N, A_all, dsel.as<int32_t>(), e->A, center, e, conf_idx_dev));
+  return launch_prep_begin(e);
+}
+
+static int ensemble_build_launch(const double *raw_dev, int64_t N, int64_t A_all, int center, const int32_t *conf_idx_dev,
+                                 fc_ensemble *e, DevBuf &dsel, bool defer_wait) {
+  FC_TRY(launch_prep_body(raw_dev, N, A_all, dsel.as<int32_t>(), e->A, center, e, conf_idx_dev));
   // the largest G (left by the prep kernel in the last counter word) comes back behind the same wait
   unsigned long long gmax_bits = 0;
   auto *gmax_dev = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
@@ -546,6 +556,13 @@ static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, c
   return FC_OK;
 }
 
+static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, const uint8_t *atom_mask,
+                              int center, const int32_t *conf_idx_dev, fc_ensemble *e, bool defer_wait = false) {
+  DevBuf dsel;
+  FC_TRY(ensemble_build_prepare(N, A_all, atom_mask, e, dsel));
+  return ensemble_build_launch(raw_dev, N, A_all, center, conf_idx_dev, e, dsel, defer_wait);
+}
+
 // Host arrays in (the drop-in call prune_by_rmsd(structures, ...)): the coordinates go through the pinned pieces like every
 // large upload from pageable memory (h2d_staged; fc_common.h says why the caller's pages are not handed to the runtime,
 // nor registered by the library for the duration of the copy).
@@ -560,9 +577,10 @@ static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, c
 // for 0.03 ms).
 static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const uint8_t *atom_mask,
                           int center, fc_ensemble *e, bool defer_wait = false) {
-  DevBuf raw;
+  DevBuf dsel, raw;
+  FC_TRY(ensemble_build_prepare(N, A_all, atom_mask, e, dsel));
   FC_TRY(upload(raw, coords, (size_t)N * A_all * 3));
-  return ensemble_build_dev(raw.as<double>(), N, A_all, atom_mask, center, nullptr, e, defer_wait);
+  return ensemble_build_launch(raw.as<double>(), N, A_all, center, nullptr, e, dsel, defer_wait);
 }
 
 // (re)shape the bit-matrix workspace for a given sharding
@@ -692,7 +710,30 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
   const bool lds_ok = (size_t)2 * W * sizeof(uint64_t) <= 60 * 1024;
   if (pairs_dev != nullptr && lds_ok) {
     // sparse similarity (the usual case): the whole ladder is ONE launch over the pair list
-    if (e->ladder_k_n != n_lv || e->ladder_k_mpg != min_per_group) {
+    // the values that can run at this N are a suffix of kLadder: they sit on the device once per context (a launch of
+    // k_store_ladder_ks per fresh ensemble -- every drop-in call -- was 5 us of an otherwise empty device)
+    const int64_t *ks_dev = nullptr;
+    {
+      bool suffix = n_lv >= 1 && n_lv <= n_ladder;
+      for (int q = 0; suffix && q < n_lv; ++q) suffix = ks[(size_t)q] == kLadder[n_ladder - n_lv + q];
+      Context &c = ctx();
+      if (suffix && c.ladder_all == nullptr) {
+        if (hipMalloc(reinterpret_cast<void **>(&c.ladder_all), sizeof kLadder) == hipSuccess) {
+          // (a blocking copy, once per context: the first ladder may run on a lane of a pipeline, whose other lanes must not
+          // find the values still in flight)
+          if (hipMemcpy(c.ladder_all, kLadder, sizeof kLadder, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(c.ladder_all);
+            c.ladder_all = nullptr;
+          }
+        } else {
+          (void)hipGetLastError();
+          c.ladder_all = nullptr;
+        }
+      }
+      if (suffix && c.ladder_all != nullptr) ks_dev = c.ladder_all + (n_ladder - n_lv);
+    }
+    if (ks_dev == nullptr && (e->ladder_k_n != n_lv || e->ladder_k_mpg != min_per_group)) {
       // the source of the (asynchronous) copy lives with the ensemble: no host wait here -- a wait at this point sat
       // between the refine and the ladder of every drop-in call (each creates its ensemble) and cost it ~45 us
       // (the values travel as kernel arguments: an asynchronous copy out of a pageable vector could be overtaken by the next
@@ -720,12 +761,12 @@ static int ladder_single(fc_ensemble *e, const uint64_t *bits_dev, int64_t min_p
     if (many_ok && n_lv >= 2 && e->last_similar > ((int64_t)1 << 17))
       FC_TRY(launch_ladder_pairs_many(pairs_dev, e->levelmask.as<uint64_t>(), cnt + 2, pairs_are_final ? nullptr : cnt + 6,
                                       (unsigned long long)e->pairq_cap, ladder_cap, N, W, min_per_group,
-                                      e->ladder_k.as<int64_t>(), ks.data(), n_lv, mb, mb + (size_t)n_lv * W, cnt));
+                                      ks_dev ? ks_dev : e->ladder_k.as<int64_t>(), ks.data(), n_lv, mb, mb + (size_t)n_lv * W, cnt));
     else
       FC_TRY(launch_ladder_pairs(pairs_dev, e->levelmask.as<uint64_t>(), cnt + 2,
                                  pairs_are_final ? nullptr : cnt + 6,
                                  (unsigned long long)e->pairq_cap, ladder_cap, N, W, min_per_group,
-                                 e->ladder_k.as<int64_t>(), n_lv, mb + (size_t)n_lv * W, cnt));
+                                 ks_dev ? ks_dev : e->ladder_k.as<int64_t>(), n_lv, mb + (size_t)n_lv * W, cnt));
     // mask words and the 16 counters behind them (written by the kernel): one copy
     FC_TRY(d2h(words, mb + (size_t)n_lv * W, (size_t)(W + 16) * sizeof(uint64_t)));
     if (defer_slot >= 0) return FC_OK;

@@ -71,6 +71,7 @@ struct Context {
   // pinned host staging for small device->host results (truly asynchronous copies)
   void *pinned = nullptr;
   size_t pinned_bytes = 0;
+  int64_t *ladder_all = nullptr;  // the 18 ladder values on the device, once per context (an ensemble's list is a suffix of them)
   void *pinned_word = nullptr;  // 64 page-locked bytes: the largest G of a fresh ensemble comes back here without a host wait
   // pinned pieces + events of the staged copies (d2h_staged / h2d_staged): one set per concurrent caller (the TFD
   // ladder's helper threads copy side by side), handed out under stage_mu

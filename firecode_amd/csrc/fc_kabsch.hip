@@ -85,57 +85,80 @@ k_prep(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_
   if (g == g) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(g));
 }
 
-// k_prep_tile: the same preparation for 64 conformers per workgroup through LDS -- the input
-// block of 64 conformers (64 x A_all x 3 doubles, contiguous) is read with coalesced loads and
-// every output is written coalesced too: Xs across the 64 conformers of a column, Xa as the
+// k_prep_tile: the same preparation for TILE conformers per workgroup through LDS -- the input
+// block of TILE conformers (TILE x A_all x 3 doubles, contiguous) is read with coalesced loads and
+// every output is written coalesced too: Xs across the TILE conformers of a column, Xa as the
 // contiguous image of the tile.  (k_prep reads with a 1200-byte stride between lanes and keeps
 // 40 CUs busy at 10^4 conformers: 75 us against ~15 us.)  Same arithmetic, same order.
+// Round 5 (the trace of one prune_by_rmsd(host arrays) call showed this kernel at 40 us for 10 000 x 50: 157 workgroups of
+// 64 conformers on 256 CUs, each a chain of ~110 loop turns with 64-bit divisions and one serial pass of 64 lanes): 32
+// conformers per workgroup (twice the workgroups, half the turns), 32-bit index arithmetic, 16-byte loads where the source
+// allows, the Xs phase without a division (a wavefront per coordinate row), the centroid as three lanes per conformer -- one
+// per coordinate, each the SAME running sum over the atoms in the same order.
+constexpr int kPrepTile = 32;
+template <int TILE>
 __global__ void __launch_bounds__(256)
 k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const int32_t *__restrict__ sel,
             int64_t A, int center, int64_t Npad, double *__restrict__ Xs, double *__restrict__ G,
             double *__restrict__ Xa, unsigned long long *__restrict__ gmax_bits,
             const int32_t *__restrict__ conf_idx,  // conf_idx != nullptr: gather (the survivors of an earlier stage)
             int64_t tile0) {                       // first tile of this launch (an upload arrives in pieces)
-  extern __shared__ double tile[];  // [64][A_all*3 + 1] (the +1 spreads the conformers over the banks)
-  __shared__ double cen[64][3];
+  static_assert(TILE == 32 || TILE == 64, "a tile is one or half a wavefront of conformers");
+  extern __shared__ double tile[];  // [TILE][A_all*3 + 1] (the +1 spreads the conformers over the banks)
+  __shared__ double cen[TILE][3];
   const int tid = threadIdx.x;
-  const int64_t n0 = ((int64_t)blockIdx.x + tile0) * 64;
-  const int64_t row = A_all * 3, ld = row + 1;
-  const int64_t n_here = (N - n0 < 64) ? (N - n0 > 0 ? N - n0 : 0) : 64;
+  const int64_t n0 = ((int64_t)blockIdx.x + tile0) * TILE;
+  const uint32_t row = (uint32_t)(A_all * 3), ld = row + 1u;
+  const int64_t left = N - n0;
+  const uint32_t n_here = left < TILE ? (left > 0 ? (uint32_t)left : 0u) : (uint32_t)TILE;
+  const uint32_t cnt = n_here * row;
   if (conf_idx == nullptr) {
-    const double *src = coords + n0 * row;
-    for (int64_t k = tid; k < n_here * row; k += 256) tile[(k / row) * ld + (k % row)] = src[k];
+    const double *__restrict__ src = coords + n0 * (int64_t)row;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      typedef double dbl2_t __attribute__((ext_vector_type(2)));
+      const dbl2_t *__restrict__ src2 = reinterpret_cast<const dbl2_t *>(src);
+      const uint32_t n2 = cnt >> 1;
+      for (uint32_t k = (uint32_t)tid; k < n2; k += 256u) {
+        const dbl2_t v = src2[k];
+        const uint32_t k0 = 2u * k, l0 = k0 / row, l1 = (k0 + 1u) / row;
+        tile[l0 * ld + (k0 - l0 * row)] = v[0];
+        tile[l1 * ld + (k0 + 1u - l1 * row)] = v[1];
+      }
+      if ((cnt & 1u) && tid == 0) tile[((cnt - 1u) / row) * ld + ((cnt - 1u) % row)] = src[cnt - 1u];
+    } else {
+      for (uint32_t k = (uint32_t)tid; k < cnt; k += 256u) tile[(k / row) * ld + (k % row)] = src[k];
+    }
   } else {
-    for (int64_t k = tid; k < n_here * row; k += 256) {
-      const int64_t l = k / row, r = k - l * row;
-      tile[l * ld + r] = coords[(int64_t)conf_idx[n0 + l] * row + r];
+    for (uint32_t k = (uint32_t)tid; k < cnt; k += 256u) {
+      const uint32_t l = k / row, r = k - l * row;
+      tile[l * ld + r] = coords[(int64_t)conf_idx[n0 + l] * (int64_t)row + r];
     }
   }
   __syncthreads();
-  if (tid < 64) {
-    double cx = 0.0, cy = 0.0, cz = 0.0, g = 0.0;
-    if (tid < n_here) {
-      const double *t = tile + (int64_t)tid * ld;
-      if (center) {
-        // same order as numpy's mean(axis=0): running sum over atoms, then / A
-        for (int64_t a = 0; a < A; ++a) {
-          const double *r = t + (int64_t)sel[a] * 3;
-          cx += r[0];
-          cy += r[1];
-          cz += r[2];
-        }
-        cx /= (double)A;
-        cy /= (double)A;
-        cz /= (double)A;
-      }
+  // centroid: lane (conformer l, coordinate c) -- same order as numpy's mean(axis=0): running sum over atoms, then / A
+  if (tid < TILE * 3) {
+    const uint32_t l = (uint32_t)tid / 3u, c = (uint32_t)tid - 3u * l;
+    double sum = 0.0;
+    if (center && l < n_here) {
+      const double *__restrict__ t = tile + l * ld + c;
+      for (int64_t a = 0; a < A; ++a) sum += t[(uint32_t)sel[a] * 3u];
+      sum /= (double)A;
+    }
+    cen[l][c] = sum;
+  }
+  __syncthreads();
+  if (tid < 64) {  // (a whole wavefront: the reduction below shuffles across 64 lanes)
+    double g = 0.0;
+    if (tid < TILE && (uint32_t)tid < n_here) {
+      const double *__restrict__ t = tile + (uint32_t)tid * ld;
+      const double cx = cen[tid][0], cy = cen[tid][1], cz = cen[tid][2];
       for (int64_t a = 0; a < A; ++a) {
-        const double *r = t + (int64_t)sel[a] * 3;
+        const double *__restrict__ r = t + (uint32_t)sel[a] * 3u;
         const double x = r[0] - cx, y = r[1] - cy, z = r[2] - cz;
         g += x * x + y * y + z * z;
       }
     }
-    cen[tid][0] = cx, cen[tid][1] = cy, cen[tid][2] = cz;
-    if (n0 + tid < Npad) G[n0 + tid] = g;
+    if (tid < TILE && n0 + tid < Npad) G[n0 + tid] = g;
     // largest G (sizes the single-precision screen's band): one atomic per workgroup
     double gm = (g == g) ? g : 0.0;
     for (int off = 32; off > 0; off >>= 1) {
@@ -144,21 +167,34 @@ k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const i
     }
     if (tid == 0) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(gm));
   }
-  __syncthreads();
-  // Xs: element (a, c) of 64 consecutive conformers is one coalesced 512-byte store; rows A..A4-1 are zero
-  const int64_t A4 = (A + 3) & ~(int64_t)3;
-  for (int64_t k = tid; k < A4 * 3 * 64; k += 256) {
-    const int64_t ac = k >> 6, l = k & 63;
-    const int64_t a = ac / 3, c = ac - a * 3;
-    double v = 0.0;
-    if (a < A && l < n_here) v = tile[l * ld + (int64_t)sel[a] * 3 + c] - cen[l][c];
-    if (n0 + l < Npad) Xs[ac * Npad + n0 + l] = v;
+  // Xs: element (a, c) of TILE consecutive conformers is one coalesced store; rows A..A4-1 are zero.  256 / TILE
+  // coordinate rows per turn, no division: (a, c) advance with the row
+  {
+    constexpr uint32_t kRowsPerTurn = 256u / TILE;
+    const uint32_t l = (uint32_t)tid % TILE, r0 = (uint32_t)tid / TILE;
+    const uint32_t A4x3 = (uint32_t)(((A + 3) & ~(int64_t)3) * 3), Ax3 = (uint32_t)(A * 3);
+    uint32_t a = r0 / 3u, c = r0 - 3u * a;
+    const bool lane_in = l < n_here, col_in = n0 + l < Npad;
+    const double *__restrict__ tl = tile + l * ld;
+    const double c0 = cen[l][0], c1 = cen[l][1], c2 = cen[l][2];
+    for (uint32_t ac = r0; ac < A4x3; ac += kRowsPerTurn) {
+      double v = 0.0;
+      if (ac < Ax3 && lane_in) v = tl[(uint32_t)sel[a] * 3u + c] - (c == 0u ? c0 : (c == 1u ? c1 : c2));
+      if (col_in) Xs[(int64_t)ac * Npad + n0 + l] = v;
+      c += kRowsPerTurn % 3u;
+      a += kRowsPerTurn / 3u;
+      if (c >= 3u) c -= 3u, ++a;
+    }
   }
   // Xa: [n][a][c], contiguous for the tile
-  for (int64_t k = tid; k < n_here * A * 3; k += 256) {
-    const int64_t l = k / (A * 3), rest = k - l * (A * 3);
-    const int64_t a = rest / 3, c = rest - a * 3;
-    Xa[(n0 + l) * A * 3 + rest] = tile[l * ld + (int64_t)sel[a] * 3 + c] - cen[l][c];
+  {
+    const uint32_t Ax3 = (uint32_t)(A * 3), tot = n_here * Ax3;
+    double *__restrict__ xa = Xa + n0 * (int64_t)Ax3;
+    for (uint32_t k = (uint32_t)tid; k < tot; k += 256u) {
+      const uint32_t l = k / Ax3, rest = k - l * Ax3;
+      const uint32_t a = rest / 3u, c = rest - a * 3u;
+      xa[k] = tile[l * ld + (uint32_t)sel[a] * 3u + c] - cen[l][c];
+    }
   }
 }
 
@@ -3040,32 +3076,58 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
       const uint64_t e = on ? pairq[p_own] : 0ull;
       double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       double Gs = 0.0;  // sum of squares of both structures: start value of the eigenvalue iteration
-#pragma unroll FC_REFINE_UNROLL
+      // The rounds side by side (round 5): every step of the atom loop requests the atoms of ALL rounds' pairs before it
+      // uses any -- kRounds x 6 loads in flight instead of 6, the loop's chain of exposed latencies kRounds times shorter
+      // (a short queue leaves most of the chip empty: the kernel's time is that chain).  Per pair and lane the same atoms in
+      // the same order into the same accumulators: same bits.  A group without a pair reads conformer 0 and its sums are
+      // never taken.
+      const double *__restrict__ ppr[kRounds], *__restrict__ qqr[kRounds];
+#pragma unroll
       for (int round = 0; round < kRounds; ++round) {
         const uint64_t eg = __shfl(e, round * 8 + slot);  // the pair of this 8-lane group
         const bool og = base + round * 8 + slot < (int64_t)n_pairs;
-        double Bg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        double gg = 0.0;
-        if (og) {
-          const double *__restrict__ pp = Xa + (int64_t)(eg >> 32) * (int64_t)A * 3;
-          const double *__restrict__ qq = Xa + (int64_t)(eg & 0xffffffffull) * (int64_t)A * 3;
-          for (int a = sub; a < A; a += 8) {
-            const double px = pp[a * 3], py = pp[a * 3 + 1], pz = pp[a * 3 + 2];
-            const double qx = qq[a * 3], qy = qq[a * 3 + 1], qz = qq[a * 3 + 2];
-            Bg[0] = fma(px, qx, Bg[0]); Bg[1] = fma(px, qy, Bg[1]); Bg[2] = fma(px, qz, Bg[2]);
-            Bg[3] = fma(py, qx, Bg[3]); Bg[4] = fma(py, qy, Bg[4]); Bg[5] = fma(py, qz, Bg[5]);
-            Bg[6] = fma(pz, qx, Bg[6]); Bg[7] = fma(pz, qy, Bg[7]); Bg[8] = fma(pz, qz, Bg[8]);
-            gg += (px * px + py * py + pz * pz) + (qx * qx + qy * qy + qz * qz);
+        ppr[round] = Xa + (og ? (int64_t)(eg >> 32) * (int64_t)A * 3 : 0);
+        qqr[round] = Xa + (og ? (int64_t)(eg & 0xffffffffull) * (int64_t)A * 3 : 0);
+      }
+      {
+        double Bg[kRounds][9], gg[kRounds];
+#pragma unroll
+        for (int round = 0; round < kRounds; ++round) {
+          gg[round] = 0.0;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Bg[round][k] = 0.0;
+        }
+        for (int a = sub; a < A; a += 8) {
+          double P[kRounds][3], Qv[kRounds][3];
+#pragma unroll
+          for (int round = 0; round < kRounds; ++round)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              P[round][c] = ppr[round][a * 3 + c];
+              Qv[round][c] = qqr[round][a * 3 + c];
+            }
+#pragma unroll
+          for (int round = 0; round < kRounds; ++round) {
+            const double px = P[round][0], py = P[round][1], pz = P[round][2];
+            const double qx = Qv[round][0], qy = Qv[round][1], qz = Qv[round][2];
+            double(&Bq)[9] = Bg[round];
+            Bq[0] = fma(px, qx, Bq[0]); Bq[1] = fma(px, qy, Bq[1]); Bq[2] = fma(px, qz, Bq[2]);
+            Bq[3] = fma(py, qx, Bq[3]); Bq[4] = fma(py, qy, Bq[4]); Bq[5] = fma(py, qz, Bq[5]);
+            Bq[6] = fma(pz, qx, Bq[6]); Bq[7] = fma(pz, qy, Bq[7]); Bq[8] = fma(pz, qz, Bq[8]);
+            gg[round] += (px * px + py * py + pz * pz) + (qx * qx + qy * qy + qz * qz);
           }
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const double tot = group8_sum(Bg[k]);
-          const double mine = __shfl(tot, sub * 8);  // group `sub` holds the pair lane 8*round+sub owns
-          if (slot == round) B[k] = mine;
+        for (int round = 0; round < kRounds; ++round) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            const double tot = group8_sum(Bg[round][k]);
+            const double mine = __shfl(tot, sub * 8);  // group `sub` holds the pair lane 8*round+sub owns
+            if (slot == round) B[k] = mine;
+          }
+          const double gmine = __shfl(group8_sum(gg[round]), sub * 8);
+          if (slot == round) Gs = gmine;
         }
-        const double gmine = __shfl(group8_sum(gg), sub * 8);
-        if (slot == round) Gs = gmine;
       }
       // The fp64 screen polynomial on this exact covariance first: the single-precision screen
       // passes dissimilar pairs inside its band, and what the fp64 screen would have dropped
@@ -3081,32 +3143,44 @@ k_simbits_refine(const double *__restrict__ Xs, const double *__restrict__ Xa, i
         if (may && !fast) (void)kabsch_rotation(B, R);
       }
       double ssq_own = 0.0, mx_own = 0.0;
-#pragma unroll FC_REFINE_UNROLL
-      for (int round = 0; any_may && round < kRounds; ++round) {
-        const uint64_t eg = __shfl(e, round * 8 + slot);
-        const bool og = base + round * 8 + slot < (int64_t)n_pairs;
-        double Rg[9];
+      if (any_may) {  // (the deviation pass the same way: all rounds' atoms requested before any is used)
+        double Rg[kRounds][9], ssq[kRounds], mx[kRounds];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rg[k] = __shfl(R[k], round * 8 + slot);
-        double ssq = 0.0, mx = 0.0;
-        if (og) {
-          const double *__restrict__ pp = Xa + (int64_t)(eg >> 32) * (int64_t)A * 3;
-          const double *__restrict__ qq = Xa + (int64_t)(eg & 0xffffffffull) * (int64_t)A * 3;
-          for (int a = sub; a < A; a += 8) {
-            const double px = pp[a * 3], py = pp[a * 3 + 1], pz = pp[a * 3 + 2];
-            const double qx = qq[a * 3], qy = qq[a * 3 + 1], qz = qq[a * 3 + 2];
-            const double dx = px - (Rg[0] * qx + Rg[1] * qy + Rg[2] * qz);
-            const double dy = py - (Rg[3] * qx + Rg[4] * qy + Rg[5] * qz);
-            const double dz = pz - (Rg[6] * qx + Rg[7] * qy + Rg[8] * qz);
+        for (int round = 0; round < kRounds; ++round) {
+          ssq[round] = 0.0;
+          mx[round] = 0.0;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rg[round][k] = __shfl(R[k], round * 8 + slot);
+        }
+        for (int a = sub; a < A; a += 8) {
+          double P[kRounds][3], Qv[kRounds][3];
+#pragma unroll
+          for (int round = 0; round < kRounds; ++round)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              P[round][c] = ppr[round][a * 3 + c];
+              Qv[round][c] = qqr[round][a * 3 + c];
+            }
+#pragma unroll
+          for (int round = 0; round < kRounds; ++round) {
+            const double px = P[round][0], py = P[round][1], pz = P[round][2];
+            const double qx = Qv[round][0], qy = Qv[round][1], qz = Qv[round][2];
+            const double(&Rq)[9] = Rg[round];
+            const double dx = px - (Rq[0] * qx + Rq[1] * qy + Rq[2] * qz);
+            const double dy = py - (Rq[3] * qx + Rq[4] * qy + Rq[5] * qz);
+            const double dz = pz - (Rq[6] * qx + Rq[7] * qy + Rq[8] * qz);
             const double sq = dx * dx + dy * dy + dz * dz;
-            ssq += sq;
-            mx = fmax(mx, sq);
+            ssq[round] += sq;
+            mx[round] = fmax(mx[round], sq);
           }
         }
-        const double ts = __shfl(group8_sum(ssq), sub * 8), tm = __shfl(group8_max(mx), sub * 8);
-        if (slot == round) {
-          ssq_own = ts;
-          mx_own = tm;
+#pragma unroll
+        for (int round = 0; round < kRounds; ++round) {
+          const double ts = __shfl(group8_sum(ssq[round]), sub * 8), tm = __shfl(group8_max(mx[round]), sub * 8);
+          if (slot == round) {
+            ssq_own = ts;
+            mx_own = tm;
+          }
         }
       }
       bool sim = false, grey = false;
@@ -3510,26 +3584,36 @@ int launch_prep_begin(fc_ensemble *e) {
 }
 // whether the tile kernel (64 conformers per workgroup through LDS) applies: only it can take a range of tiles
 bool prep_by_tiles(int64_t A_all) {
-  const size_t lds_tile = (size_t)64 * (size_t)(A_all * 3 + 1) * sizeof(double);
-  return lds_tile + 2048 <= kLdsLimit && !getenv("FC_PREP_LANES");  // FC_PREP_LANES=1: the one-lane-per-conformer kernel
+  const size_t lds_tile = (size_t)kPrepTile * (size_t)(A_all * 3 + 1) * sizeof(double);
+  return lds_tile + 2048 <= kLdsLimit && (uint64_t)kPrepTile * (uint64_t)(A_all * 3 + 1) < (1ull << 31) &&
+         !getenv("FC_PREP_LANES");  // FC_PREP_LANES=1: the one-lane-per-conformer kernel
 }
 // tiles [tile0, tile0 + n_tiles) of 64 conformers (behind launch_prep_begin)
 int launch_prep_tiles(const double *coords_dev, int64_t N, int64_t A_all, const int32_t *sel_dev, int64_t A, int center,
                       fc_ensemble *e, const int32_t *conf_idx_dev, int64_t tile0, int64_t n_tiles) {
   if (n_tiles <= 0) return FC_OK;
   auto *gmax_bits = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
-  const size_t lds_tile = (size_t)64 * (size_t)(A_all * 3 + 1) * sizeof(double);
+  // (tile0, n_tiles count 64-conformer tiles; the kernel takes kPrepTile conformers per workgroup)
+  constexpr int64_t kPer64 = 64 / kPrepTile;
+  const size_t lds_tile = (size_t)kPrepTile * (size_t)(A_all * 3 + 1) * sizeof(double);
   if (lds_tile > 64 * 1024)
-    FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_tile),
+    FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_tile<kPrepTile>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
-  hipLaunchKernelGGL(k_prep_tile, dim3((unsigned)n_tiles), dim3(256), lds_tile, ctx().stream, coords_dev, N, A_all,
-                     sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(), e->Xa.as<double>(), gmax_bits,
-                     conf_idx_dev, tile0);
+  hipLaunchKernelGGL(k_prep_tile<kPrepTile>, dim3((unsigned)(n_tiles * kPer64)), dim3(256), lds_tile, ctx().stream, coords_dev, N,
+                     A_all, sel_dev, A, center, e->Npad, e->Xs.as<double>(), e->G.as<double>(), e->Xa.as<double>(), gmax_bits,
+                     conf_idx_dev, tile0 * kPer64);
   return check_launch("k_prep_tile");
 }
+int launch_prep_body(const double *coords_dev, int64_t N, int64_t A_all, const int32_t *sel_dev, int64_t A, int center,
+                     fc_ensemble *e, const int32_t *conf_idx_dev);
 int launch_prep(const double *coords_dev, int64_t N, int64_t A_all, const int32_t *sel_dev,
                 int64_t A, int center, fc_ensemble *e, const int32_t *conf_idx_dev) {
   FC_TRY(launch_prep_begin(e));
+  return launch_prep_body(coords_dev, N, A_all, sel_dev, A, center, e, conf_idx_dev);
+}
+// (behind launch_prep_begin)
+int launch_prep_body(const double *coords_dev, int64_t N, int64_t A_all, const int32_t *sel_dev, int64_t A, int center,
+                     fc_ensemble *e, const int32_t *conf_idx_dev) {
   if (prep_by_tiles(A_all))
     return launch_prep_tiles(coords_dev, N, A_all, sel_dev, A, center, e, conf_idx_dev, 0, e->Npad / 64);
   auto *gmax_bits = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);

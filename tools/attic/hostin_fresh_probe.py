@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import firecode_amd as fc  # noqa: E402
 from firecode_amd import synthetic as syn  # noqa: E402
 

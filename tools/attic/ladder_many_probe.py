@@ -1,7 +1,7 @@
 """The ladder of a long similar-pair list alone: one prune of the continuous-RMSD ensemble after another (no pipeline), kernel
 times from rocprofv3 are what to read; prints the synchronous prune time."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import firecode_amd as fc
 from firecode_amd import synthetic as syn
 fc.init(0)

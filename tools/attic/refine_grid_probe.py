@@ -1,6 +1,6 @@
 """tools/attic/refine_grid_probe.py -- k_refine_pairs alone (fc_bench_refine) on the continuous-RMSD ensemble."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import firecode_amd as fc
 from firecode_amd import synthetic as syn
 fc.init(0)

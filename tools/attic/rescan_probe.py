@@ -1,7 +1,7 @@
 """Why the re-scan of the survivors of a cfg3 search sometimes takes 25 ms instead of 1: times two identical torsion_scan calls
 behind every fc_torsion_scan_tfd_grid call."""
 import sys, time, json, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import firecode_amd as fc
 from firecode_amd import synthetic as syn

@@ -1,7 +1,7 @@
 """Repeats the device-built TFD ladder (three levels in flight, arena blocks, compact downloads) against the all-host ladder
 on changing first-match arrays in ONE process: a race between the helper streams would show as a mask that differs."""
 import os, sys, json, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import firecode_amd as fc

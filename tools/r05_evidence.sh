@@ -89,5 +89,17 @@ pmc80)
   python3 tools/time_complete.py 35355 80 3 > $O/complete_a80.json 2>/dev/null
   cat $O/complete_a80.json
   ;;
+screenpmc)
+  say "PMC passes + stats: the split-half screen on the prune path, cfg4 N = 1 member (35355 x 80) and BASELINE configs[1]"
+  bash tools/attic/r03_pmc.sh $O/pmc_cfg4 r05cfg4 tools/attic/prune_probe.py 35355 80 6 20 > $O/pmc_cfg4.log 2>&1 || exit 1
+  python3 tools/attic/r03_pmc_json.py $O/pmc_cfg4/pmc_summary.txt "k_simbits_screen_mfma_h2" $O/pmc_screen_h2_cfg4_member.json stats=$O/pmc_cfg4/kernel_stats.csv n_conformers=35355 n_atoms=80 workload="cfg4 family, n_gpus = 1 member"
+  cp $O/pmc_cfg4/pmc_summary.txt $O/pmc_cfg4_member.txt; cp $O/pmc_cfg4/kernel_stats.csv $O/cfg4_member_kernel_stats.csv
+  rm -rf $O/pmc_cfg4/pmc_* $O/pmc_cfg4/trace
+  bash tools/attic/r03_pmc.sh $O/pmc_prune r05prune tools/attic/prune_probe.py 10000 50 2 100 > $O/pmc_prune.log 2>&1 || exit 1
+  python3 tools/attic/r03_pmc_json.py $O/pmc_prune/pmc_summary.txt "k_simbits_screen_mfma_h2" $O/pmc_screen_h2.json stats=$O/pmc_prune/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="BASELINE configs[1], prune path"
+  cp $O/pmc_prune/pmc_summary.txt $O/pmc_prune.txt; cp $O/pmc_prune/kernel_stats.csv $O/prune_kernel_stats.csv
+  rm -rf $O/pmc_prune/pmc_* $O/pmc_prune/trace
+  cut -c1-300 $O/pmc_screen_h2_cfg4_member.json; cut -c1-300 $O/pmc_screen_h2.json
+  ;;
 *) echo "unknown part $1"; exit 2 ;;
 esac
