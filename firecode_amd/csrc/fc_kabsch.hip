@@ -103,7 +103,7 @@ k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const i
             double *__restrict__ Xa, unsigned long long *__restrict__ gmax_bits,
             const int32_t *__restrict__ conf_idx,  // conf_idx != nullptr: gather (the survivors of an earlier stage)
             int64_t tile0) {                       // first tile of this launch (an upload arrives in pieces)
-  static_assert(TILE == 32 || TILE == 64, "a tile is one or half a wavefront of conformers");
+  static_assert(TILE == 16 || TILE == 32 || TILE == 64, "a tile is a wavefront of conformers, a half or a quarter");
   extern __shared__ double tile[];  // [TILE][A_all*3 + 1] (the +1 spreads the conformers over the banks)
   __shared__ double cen[TILE][3];
   const int tid = threadIdx.x;
@@ -437,9 +437,6 @@ __device__ __forceinline__ void push_pairs(uint64_t m, bool may, unsigned i, uns
 #endif
 #ifndef FC_V2_ALIGN
 #define FC_V2_ALIGN 1
-#endif
-#ifndef FC_REFINE_UNROLL
-#define FC_REFINE_UNROLL 1
 #endif
 constexpr int kStagePairs = 48;  // uint64 entries per workgroup
 constexpr int kStageWords = 24;  // uint32 entries per workgroup

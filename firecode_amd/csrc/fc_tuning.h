@@ -15,7 +15,7 @@
 //     bucket refine:              FC_RB_NOSTAGE  FC_RB_NOPASS1  FC_RB_NOPASS2  FC_RB_NOJACOBI  FC_RB_NOCOMPUTE  FC_RB_ROWS_FROM_LDS
 //                                 FC_RB_SAMEROW
 //   shapes (results unchanged):   FC_RB_ROWS  FC_RB_COLSHIFT  FC_RB_WPS  FC_RB_AHEAD  FC_RB_CHUNK  FC_H2_WGS  FC_F32_WGS
-//                                 FC_REFINE_UNROLL  FC_REFINE_ROUNDS  FC_V2_ALIGN  FC_STAGE_PAIRS_F32  FC_TS_WGS  FC_TS_TURN
+//                                 FC_REFINE_ROUNDS  FC_V2_ALIGN  FC_STAGE_PAIRS_F32  FC_TS_WGS  FC_TS_TURN
 #pragma once
 
 #if !defined(FC_TUNING_BUILD) &&                                                                                             \
@@ -24,7 +24,6 @@
      defined(FC_ABLATE_PUSH) || defined(FC_ABLATE_STAGE) || defined(FC_ABLATE_OVERFLOW) || defined(FC_ABLATE_REDO) ||         \
      defined(FC_RB_NOSTAGE) || defined(FC_RB_NOPASS1) || defined(FC_RB_NOPASS2) || defined(FC_RB_NOJACOBI) ||                \
      defined(FC_RB_NOCOMPUTE) || defined(FC_RB_ROWS_FROM_LDS) || defined(FC_RB_SAMEROW) || defined(FC_RB_WPS) ||              \
-     defined(FC_RB_AHEAD) || defined(FC_RB_CHUNK) || defined(FC_H2_WGS) || defined(FC_F32_WGS) || defined(FC_REFINE_UNROLL) || \
-     defined(FC_REFINE_ROUNDS) || defined(FC_V2_ALIGN) || defined(FC_STAGE_PAIRS_F32) || defined(FC_TS_WGS) || defined(FC_TS_TURN))
+     defined(FC_RB_AHEAD) || defined(FC_RB_CHUNK) || defined(FC_H2_WGS) || defined(FC_F32_WGS) || defined(FC_REFINE_ROUNDS) || defined(FC_V2_ALIGN) || defined(FC_STAGE_PAIRS_F32) || defined(FC_TS_WGS) || defined(FC_TS_TURN))
 #error "a tuning switch (FC_*TIMELINE / FC_*ABLATE* / FC_RB_* / FC_TFD_STAMPS ...) without -DFC_TUNING_BUILD: see fc_tuning.h"
 #endif
