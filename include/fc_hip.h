@@ -115,9 +115,15 @@ int fc_ensemble_rmsd_pairs(fc_ensemble *ens, const int64_t *pair_i, const int64_
 /* all pairs: rmsd_out / maxdev_out are (N, N) row-major, symmetric, 0 diagonal */
 int fc_ensemble_rmsd_matrix(fc_ensemble *ens, double *rmsd_out, double *maxdev_out);
 /* The complete alignment of ALL pairs, timed on the device: rmsd_and_max's two outputs (RMSD and
- * max per-atom deviation, both from the explicit rotated difference) for every i < j --
- * covariance tiles on the fp64 matrix pipe, rotation (Newton eigenvalue + adjugate column;
- * Jacobi sweeps where the eigenvalue is not clearly simple) and one atom pass in the epilogue.
+ * max per-atom deviation; firecode/utils.py:499) for every i < j -- covariance tiles on the fp64
+ * matrix pipe, rotation (Newton eigenvalue + adjugate column; Jacobi sweeps where the eigenvalue is
+ * not clearly simple) and one atom pass in the epilogue.  The max deviation is taken from the explicit
+ * rotated difference p - R q; the rmsd from the largest eigenvalue of the pair's quaternion matrix,
+ * sqrt(((Gp + Gq) - 2 lambda) / A) -- the sum of squares of that same difference under the optimal
+ * rotation, equal to it within 1e-11 on everything tested (tests/test_complete_eig_bound.py pins the
+ * bound) -- except for pairs closer than ~1e-3 A, where that difference of large numbers no longer
+ * holds 1e-10: those, like pairs with a declined rotation, are recomputed by a fix-up kernel from the
+ * explicit sum.  FC_COMPLETE_EIG=0: the explicit running sum for every pair (the form of rounds 2-4).
  * rmsd_out / maxdev_out (N, N) symmetric with 0 diagonal, either may be NULL (timing only);
  * ms_kernel (may be NULL) = HIP-event time of the kernels.  fc_ensemble_rmsd_matrix is this
  * call with both outputs required. */
