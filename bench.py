@@ -5,7 +5,7 @@ The line's top-level fields are the reference-precision measurement in SURVEY.md
 
   value / ms_per_step / dtype "f64" / roofline
         COMPLETE fp64 alignments per second: a step = one pass of `rmsd_and_max` (firecode/utils.py:499:
-        two conformers in -> Kabsch RMSD AND max per-atom deviation of the explicit rotated difference out)
+        two conformers in -> Kabsch RMSD (from the largest eigenvalue) AND max per-atom deviation of the explicit rotated difference out)
         over EVERY pair of the HBM-resident ensemble (fc_bench_rmsd_and_max_all: covariance tiles on the fp64
         matrix pipe, rotation and deviation pass per pair, two dense (N, N) fp64 outputs that stay in HBM).
         K steps enqueued back to back, one host wait, bracketed by barrier + device synchronisation.
@@ -669,7 +669,9 @@ def run_alignments(ctx):
             "config": {"workload": what, "baseline_config": "configs[1]", "n_conformers": n_conf, "n_atoms": n_atoms,
                        "pairs_per_step": pairs_total, "pairs_per_step_rank0": owned,
                        "value_counts": "complete alignments: for EVERY conformer pair of the step the optimal rotation (Kabsch), the "
-                                       "RMSD and the max per-atom deviation from the explicit rotated difference, all fp64 -- "
+                                       "max per-atom deviation from the explicit rotated difference and the RMSD from the pair's largest "
+                                       "eigenvalue ((Gp + Gq) - 2 lambda: the sum of squares of that difference under the optimal rotation; "
+                                       "pairs closer than ~1e-3 A from the explicit sum), all fp64 -- "
                                        "the (rmsd, maxdev) contract of rmsd_and_max (firecode/utils.py:499); outputs: two dense "
                                        "(N, N) fp64 matrices in HBM",
                        "sharding": (f"row blocks of 128 of the pair matrix dealt in snake order over {world} ranks, every rank "
