@@ -911,8 +911,8 @@ def extras_single_gpu(args, out, fc, _lib, syn, ens, coords, atoms, n_conf, n_at
                                       "frac": n_cand * (53 * n_atoms + 600) / (r_ms * 1e-3) / 1e12 / PEAK_F64_MFMA,
                                       "flops_per_alignment": 53 * n_atoms + 600,
                                       "algorithmic_bytes_per_alignment": bpa, "algorithmic_GBps": gbs,
-                                      "traffic": pmc_traffic(("r04_pmc_refine.json",), n_conf, n_atoms)[0],
-                                      "traffic_source": pmc_traffic(("r04_pmc_refine.json",), n_conf, n_atoms)[1],
+                                      "traffic": pmc_traffic(("r05_pmc_refine.json", "r04_pmc_refine.json"), n_conf, n_atoms)[0],
+                                      "traffic_source": pmc_traffic(("r05_pmc_refine.json", "r04_pmc_refine.json"), n_conf, n_atoms)[1],
                                       "note": "one exact fp64 alignment (rotation, rmsd, max deviation) per queued candidate pair, a lane per "
                                               "pair, the queue ordered by (1024-row, 64-column) bucket with the column tile in LDS.  What holds "
                                               "it at this fraction is the CU's vector-memory path, not arithmetic and not HBM: every lane gathers "

@@ -101,5 +101,14 @@ screenpmc)
   rm -rf $O/pmc_prune/pmc_* $O/pmc_prune/trace
   cut -c1-300 $O/pmc_screen_h2_cfg4_member.json; cut -c1-300 $O/pmc_screen_h2.json
   ;;
+refine)
+  say "PMC passes + stats: the long-queue refine on the continuous-RMSD ensemble (tools/refine_alone_probe.py)"
+  bash tools/attic/r03_pmc.sh $O/pmc_refine r05ref tools/refine_alone_probe.py > $O/pmc_refine.log 2>&1 || exit 1
+  python3 tools/attic/r03_pmc_json.py $O/pmc_refine/pmc_summary.txt "k_refine_buckets" $O/pmc_refine.json stats=$O/pmc_refine/kernel_stats.csv n_conformers=10000 n_atoms=50 workload="continuous RMSD distribution, 945025 candidate pairs per launch"
+  cp $O/pmc_refine/pmc_summary.txt $O/pmc_refine.txt
+  rm -rf $O/pmc_refine/pmc_* $O/pmc_refine/trace
+  python3 tools/refine_alone_probe.py > $O/refine_alone.json 2>/dev/null
+  cut -c1-300 $O/pmc_refine.json; cat $O/refine_alone.json
+  ;;
 *) echo "unknown part $1"; exit 2 ;;
 esac
