@@ -433,7 +433,7 @@ __device__ __forceinline__ void push_pairs(uint64_t m, bool may, unsigned i, uns
 // 4 % of the kernel at 10^4 conformers, 17 % at 5*10^3).  A ballot that does not fit
 // goes straight to the global queue; the slots it reserved stay at the "empty" marker.
 #ifndef FC_REFINE_ROUNDS
-#define FC_REFINE_ROUNDS 4  // measured: 8 -> 66 us, 4 -> 53 us, 2 -> 59 us, 1 (all redundant) -> 82 us
+#define FC_REFINE_ROUNDS 4  // measured: 8 -> 66 us, 4 -> 53 us, 2 -> 59 us, 1 (all redundant) -> 82 us; with the rounds' loads side by side (round 5): 2 -> 44, 4 -> 34, 8 -> 70 us (scratch)
 #endif
 #ifndef FC_V2_ALIGN
 #define FC_V2_ALIGN 1
