@@ -66,19 +66,15 @@ pmc)
   cut -c1-400 $O/pmc_complete.json
   ;;
 hostin)
-  say "host arrays in -> mask out: breakdown, A/B against the staged DMA, device timeline of one call"
-  python tools/hostin_breakdown.py > $O/hostin_breakdown.json 2>$O/hostin.err || exit 1
-  FC_HOSTIN_PULL=0 python tools/hostin_breakdown.py > $O/hostin_breakdown_staged_dma.json 2>>$O/hostin.err || exit 1
-  python tools/hostin_breakdown.py >> $O/hostin_breakdown.json 2>>$O/hostin.err || exit 1
-  FC_HOSTIN_PULL=0 python tools/hostin_breakdown.py >> $O/hostin_breakdown_staged_dma.json 2>>$O/hostin.err || exit 1
-  : > $O/hostin_pieces.txt
-  for kb in 512 1024 4096; do echo "piece_kb $kb" >> $O/hostin_pieces.txt; FC_HOSTIN_PIECE_KB=$kb python tools/hostin_breakdown.py >> $O/hostin_pieces.txt 2>>$O/hostin.err; done
+  say "host arrays in -> mask out: breakdown (four runs), device timeline of one call, the same from a page-locked source"
+  : > $O/hostin_breakdown.json
+  for i in 1 2 3 4; do python tools/hostin_breakdown.py >> $O/hostin_breakdown.json 2>>$O/hostin.err || exit 1; done
   cd /tmp && cd "$GRAFT_REPO_ROOT"
   rocprofv3 --kernel-trace --memory-copy-trace -d $O/prof_hostin --output-format csv -- python3 tools/hostin_timeline.py > $O/hostin_calls.json 2>>$O/hostin.err || exit 1
   python3 tools/hostin_timeline.py $O/prof_hostin > $O/hostin_timeline.txt
   rm -rf $O/prof_hostin
   FC_TIMELINE_PINNED=1 python3 tools/hostin_timeline.py > $O/hostin_calls_pinned.json 2>>$O/hostin.err
-  cat $O/hostin_breakdown.json $O/hostin_breakdown_staged_dma.json $O/hostin_pieces.txt $O/hostin_calls.json $O/hostin_calls_pinned.json; cat $O/hostin_timeline.txt
+  cat $O/hostin_breakdown.json $O/hostin_calls.json $O/hostin_calls_pinned.json; cat $O/hostin_timeline.txt
   ;;
 pmc80)
   say "PMC passes: complete alignment kernel at the cfg4 shape (35355 x 80: the <8, 2, 64, true> variant)"
