@@ -1785,6 +1785,49 @@ def test_complete_alignments_of_tiny_structures(fc, n, a):
     assert np.allclose(R, R.T) and np.all(np.diag(R) == 0)
 
 
+def test_complete_alignments_random_shapes_both_forms(fc, monkeypatch):
+    """A seeded sweep over shapes the directed cases do not name one by one: 2 - 700 conformers, 1 - 300 atoms (all three tile
+    widths and the exact kernel's side of 416), clustered / continuous / unrelated / duplicated / planar / mirrored structures
+    with random rigid motions -- the eigenvalue form against the running sum (1e-11), both against the oracle on a sample."""
+    rng = np.random.default_rng(20261005)
+    for case in range(30):
+        n = int(rng.choice([2, 3, 17, 64, 65, 129, 200, 257, 400, 700]))
+        a = int(rng.choice([1, 2, 3, 4, 7, 16, 33, 50, 52, 53, 80, 104, 105, 140, 208, 209, 300]))
+        if n * n * a > 6e7:
+            n = 129
+        kind = str(rng.choice(["clusters", "continuous", "random", "duplicates", "planar", "mirror"]))
+        seed = int(rng.integers(1 << 30))
+        if kind == "clusters" and a >= 3:
+            X = syn.synthetic_ensemble(max(n, 5), a, seed=seed, cluster_size=3 if a > 100 else 5)[0][:n]
+        elif kind == "continuous" and a >= 3:
+            X = syn.continuous_ensemble(n, a, seed=seed)
+        else:
+            X = rng.normal(scale=1.5, size=(n, a, 3))
+            if kind == "duplicates":
+                X[n // 2:] = X[: n - n // 2] + rng.normal(scale=10.0 ** rng.uniform(-7, -2), size=(n - n // 2, a, 3))
+            elif kind == "planar":
+                X[:, :, 2] = 0.0
+            elif kind == "mirror":
+                X[1::2] = X[0::2][: len(X[1::2])] * np.array([1.0, 1.0, -1.0])
+        X = np.einsum("nij,naj->nai", np.array([_rot(rng) for _ in range(n)]), X) + rng.normal(scale=3.0, size=(n, 1, 3))
+        with fc.DeviceEnsemble(X, center=True) as ens:
+            R1, D1, _ = ens.rmsd_and_max_all()
+            monkeypatch.setenv("FC_COMPLETE_EIG", "0")
+            R0, D0, _ = ens.rmsd_and_max_all()
+            monkeypatch.delenv("FC_COMPLETE_EIG")
+        iu, ju = np.triu_indices(n, 1)
+        where = (case, n, a, kind)
+        assert not np.isnan(R1).any() and not np.isnan(D1).any(), where
+        assert np.abs(R1 - R0)[iu, ju].max() < 1e-11, where
+        sel = rng.choice(len(iu), size=min(len(iu), 1500), replace=False)
+        r0, d0 = o.rmsd_and_max_batch(X[iu[sel]], X[ju[sel]], center=True)
+        bound = o.rotation_error_bound_batch(X[iu[sel]], X[ju[sel]], center=True)
+        assert np.abs(R1[iu[sel], ju[sel]] - r0).max() < TOL, where
+        fin = np.isfinite(bound)
+        assert np.all(np.abs(D1[iu[sel], ju[sel]] - d0)[fin] <= TOL + bound[fin]), where
+        assert np.all(np.abs(D0[iu[sel], ju[sel]] - d0)[fin] <= TOL + bound[fin]), where
+
+
 def test_complete_alignments_of_near_duplicates_beyond_the_fix_up_queue(fc, monkeypatch):
     """An ensemble of copies: every pair is closer than the eigenvalue form of the rmsd can resolve and the fix-up queue
     (here cut to 1 000 entries) overflows -- fc_ensemble_rmsd_and_max_all then runs the tiled kernel again with the
