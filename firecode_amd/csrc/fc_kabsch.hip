@@ -104,11 +104,16 @@ k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const i
             const int32_t *__restrict__ conf_idx,  // conf_idx != nullptr: gather (the survivors of an earlier stage)
             int64_t tile0) {                       // first tile of this launch (an upload arrives in pieces)
   static_assert(TILE == 16 || TILE == 32 || TILE == 64, "a tile is a wavefront of conformers, a half or a quarter");
-  extern __shared__ double tile[];  // [TILE][A_all*3 + 1] (the +1 spreads the conformers over the banks)
+  extern __shared__ double tile[];  // [TILE][A_all*3 + 1] (the +1 spreads the conformers over the banks), then the selection
   __shared__ double cen[TILE][3];
   const int tid = threadIdx.x;
   const int64_t n0 = ((int64_t)blockIdx.x + tile0) * TILE;
   const uint32_t row = (uint32_t)(A_all * 3), ld = row + 1u;
+  // the atom selection in LDS for the serial loops below.  Phases of one workgroup at 10^4 x 50 by wall-clock stamps: load
+  // 4.6 us, centroid 1.0, G 2.6, Xs 3.2, Xa 2.2 = 13.5 us of the kernel's 23 (17 us for the ten workgroups of a 300-conformer
+  // ensemble: the chain of one workgroup is what the kernel costs at any size)
+  int *__restrict__ s_sel = reinterpret_cast<int *>(tile + (size_t)TILE * ld);
+  for (uint32_t a = (uint32_t)tid; a < (uint32_t)A; a += 256u) s_sel[a] = sel[a];
   const int64_t left = N - n0;
   const uint32_t n_here = left < TILE ? (left > 0 ? (uint32_t)left : 0u) : (uint32_t)TILE;
   const uint32_t cnt = n_here * row;
@@ -141,7 +146,7 @@ k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const i
     double sum = 0.0;
     if (center && l < n_here) {
       const double *__restrict__ t = tile + l * ld + c;
-      for (int64_t a = 0; a < A; ++a) sum += t[(uint32_t)sel[a] * 3u];
+      for (int64_t a = 0; a < A; ++a) sum += t[(uint32_t)s_sel[a] * 3u];
       sum /= (double)A;
     }
     cen[l][c] = sum;
@@ -153,7 +158,7 @@ k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const i
       const double *__restrict__ t = tile + (uint32_t)tid * ld;
       const double cx = cen[tid][0], cy = cen[tid][1], cz = cen[tid][2];
       for (int64_t a = 0; a < A; ++a) {
-        const double *__restrict__ r = t + (uint32_t)sel[a] * 3u;
+        const double *__restrict__ r = t + (uint32_t)s_sel[a] * 3u;
         const double x = r[0] - cx, y = r[1] - cy, z = r[2] - cz;
         g += x * x + y * y + z * z;
       }
@@ -179,7 +184,7 @@ k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const i
     const double c0 = cen[l][0], c1 = cen[l][1], c2 = cen[l][2];
     for (uint32_t ac = r0; ac < A4x3; ac += kRowsPerTurn) {
       double v = 0.0;
-      if (ac < Ax3 && lane_in) v = tl[(uint32_t)sel[a] * 3u + c] - (c == 0u ? c0 : (c == 1u ? c1 : c2));
+      if (ac < Ax3 && lane_in) v = tl[(uint32_t)s_sel[a] * 3u + c] - (c == 0u ? c0 : (c == 1u ? c1 : c2));
       if (col_in) Xs[(int64_t)ac * Npad + n0 + l] = v;
       c += kRowsPerTurn % 3u;
       a += kRowsPerTurn / 3u;
@@ -193,7 +198,7 @@ k_prep_tile(const double *__restrict__ coords, int64_t N, int64_t A_all, const i
     for (uint32_t k = (uint32_t)tid; k < tot; k += 256u) {
       const uint32_t l = k / Ax3, rest = k - l * Ax3;
       const uint32_t a = rest / 3u, c = rest - a * 3u;
-      xa[k] = tile[l * ld + (uint32_t)sel[a] * 3u + c] - cen[l][c];
+      xa[k] = tile[l * ld + (uint32_t)s_sel[a] * 3u + c] - cen[l][c];
     }
   }
 }
@@ -3581,7 +3586,7 @@ int launch_prep_begin(fc_ensemble *e) {
 }
 // whether the tile kernel (64 conformers per workgroup through LDS) applies: only it can take a range of tiles
 bool prep_by_tiles(int64_t A_all) {
-  const size_t lds_tile = (size_t)kPrepTile * (size_t)(A_all * 3 + 1) * sizeof(double);
+  const size_t lds_tile = (size_t)kPrepTile * (size_t)(A_all * 3 + 1) * sizeof(double) + (size_t)A_all * sizeof(int) + 8;
   return lds_tile + 2048 <= kLdsLimit && (uint64_t)kPrepTile * (uint64_t)(A_all * 3 + 1) < (1ull << 31) &&
          !getenv("FC_PREP_LANES");  // FC_PREP_LANES=1: the one-lane-per-conformer kernel
 }
@@ -3592,7 +3597,7 @@ int launch_prep_tiles(const double *coords_dev, int64_t N, int64_t A_all, const 
   auto *gmax_bits = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
   // (tile0, n_tiles count 64-conformer tiles; the kernel takes kPrepTile conformers per workgroup)
   constexpr int64_t kPer64 = 64 / kPrepTile;
-  const size_t lds_tile = (size_t)kPrepTile * (size_t)(A_all * 3 + 1) * sizeof(double);
+  const size_t lds_tile = (size_t)kPrepTile * (size_t)(A_all * 3 + 1) * sizeof(double) + (size_t)A_all * sizeof(int) + 8;  // tile + selection
   if (lds_tile > 64 * 1024)
     FC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_tile<kPrepTile>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));

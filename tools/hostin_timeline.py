@@ -1,7 +1,8 @@
 """Device-side timeline of ONE prune_by_rmsd(host arrays) call at BASELINE configs[1] (10 000 x 50).
 
   run:     rocprofv3 --kernel-trace --memory-copy-trace -d DIR --output-format csv -- python3 tools/hostin_timeline.py
-           (prints the host-side wall time of each call as JSON)
+           (prints the host-side wall time of each call as JSON; FC_TIMELINE_N / FC_TIMELINE_A: another shape,
+           FC_TIMELINE_PINNED=1: the ensemble in page-locked memory)
   report:  python3 tools/hostin_timeline.py DIR      (kernels and copies of the LAST call, microseconds from its first one)
 """
 import csv
@@ -20,7 +21,8 @@ def run():
     from firecode_amd import synthetic as syn
 
     fc.init(0)
-    X, atoms, _ = syn.synthetic_ensemble(10000, 50, seed=2)
+    n_conf, n_atoms = int(os.environ.get("FC_TIMELINE_N", "10000")), int(os.environ.get("FC_TIMELINE_A", "50"))
+    X, atoms, _ = syn.synthetic_ensemble(n_conf, n_atoms, seed=2)
     pinned = os.environ.get("FC_TIMELINE_PINNED") == "1"
     if pinned:
         P = fc.pinned_empty(X.shape)
