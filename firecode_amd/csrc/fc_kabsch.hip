@@ -3995,7 +3995,11 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
           return x > 0.0 ? x : 4.0;
         }();
         use_f32 = band <= kBandMax * thr2_margin;
-        speculative = band > 0.1 * thr2_margin;  // narrow band: not worth the verdict's ~10 us
+        // narrow band: not worth the verdict's ~10 us.  Nor is a small ensemble (all its pairs fit the short candidate queue,
+        // N <= 512): whatever the band holds costs the exact refine less than the verdict and the gated launch behind it cost
+        // every call (9 of the 150-180 us of a drop-in prune at FIRECODE's own sizes)
+        const bool worth_verdict = (double)e->N * (double)e->N > 2.0 * (double)kRefineLanesMin;
+        speculative = band > 0.1 * thr2_margin && worth_verdict;
         if (!use_f32 && use_h2 && g_screen_forced != 16 && lds_f32_tile <= kLdsLimit) {
           // the split-half bound is about twice the fp32 kernel's (66 u per 32 atoms against one u per atom): where its band
           // is too wide and the fp32 kernel's is not -- 160 stretched atoms -- the fp32 matrix pipe is still 2.5 x faster
@@ -4006,7 +4010,7 @@ int launch_simbits_screen(fc_ensemble *e, double thr2_margin) {
             use_h2 = false;
             bd = bf;
             use_f32 = true;
-            speculative = band_f > 0.1 * thr2_margin;
+            speculative = band_f > 0.1 * thr2_margin && worth_verdict;
           }
         }
       }
