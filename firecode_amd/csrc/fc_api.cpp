@@ -568,8 +568,9 @@ static int ensemble_build_prepare(int64_t N, int64_t A_all, const uint8_t *atom_
 }
 
 static int ensemble_build_launch(const double *raw_dev, int64_t N, int64_t A_all, int center, const int32_t *conf_idx_dev,
-                                 fc_ensemble *e, DevBuf &dsel, bool defer_wait) {
+                                 fc_ensemble *e, DevBuf &dsel, bool defer_wait, bool host_gmax = false) {
   FC_TRY(launch_prep_body(raw_dev, N, A_all, dsel.as<int32_t>(), e->A, center, e, conf_idx_dev));
+  if (host_gmax) return FC_OK;  // (the caller computes the largest G from its array: fc_prune_rmsd_host on small ensembles)
   // the largest G (left by the prep kernel in the last counter word) comes back behind the same wait
   unsigned long long gmax_bits = 0;
   auto *gmax_dev = reinterpret_cast<unsigned long long *>(e->counters.p) + (kCounters - 1);
@@ -612,11 +613,11 @@ static int ensemble_build_dev(const double *raw_dev, int64_t N, int64_t A_all, c
 // (0.53 ms); the copy of each 4 MB piece split between this thread and a helper thread (0.41 ms: a thread per call
 // for 0.03 ms).
 static int ensemble_build(const double *coords, int64_t N, int64_t A_all, const uint8_t *atom_mask,
-                          int center, fc_ensemble *e, bool defer_wait = false) {
+                          int center, fc_ensemble *e, bool defer_wait = false, bool host_gmax = false) {
   DevBuf dsel, raw;
   FC_TRY(ensemble_build_prepare(N, A_all, atom_mask, e, dsel));
   FC_TRY(upload(raw, coords, (size_t)N * A_all * 3));
-  return ensemble_build_launch(raw.as<double>(), N, A_all, center, nullptr, e, dsel, defer_wait);
+  return ensemble_build_launch(raw.as<double>(), N, A_all, center, nullptr, e, dsel, defer_wait, host_gmax);
 }
 
 // (re)shape the bit-matrix workspace for a given sharding
@@ -1452,15 +1453,13 @@ int fc_prune_rmsd_host(const double *coords, int64_t N, int64_t A, const uint8_t
   e.epoch = ctx().epoch;
   // the last piece's DMA and the preparation kernel are still running when ensemble_build returns: the prune's reserves and
   // the screen's item table (host work + one small copy) go under them instead of behind the wait for the largest G
-  int rc = ensemble_build(coords, N, A, atom_mask, center, &e, /*defer_wait=*/true);
-  if (rc == FC_OK && e.g_max_pending && N * A * 3 <= kHostGmaxDoubles) {
-    // a small ensemble: no wait for the device's largest G (its copy into the page-locked word lands unread; the counters
-    // are reset in front of the screen)
+  // a small ensemble: the largest G from the caller's array, no copy of the device's and no wait for it (the counters are
+  // reset in front of the screen)
+  const bool host_gmax = N * A * 3 <= kHostGmaxDoubles;
+  int rc = ensemble_build(coords, N, A, atom_mask, center, &e, /*defer_wait=*/true, host_gmax);
+  if (rc == FC_OK && host_gmax) {
     const double g = host_largest_g(coords, N, A, e.sel_host, center);
-    if (std::isfinite(g)) {
-      e.g_max = g * (1.0 + 1e-12);
-      e.g_max_pending = false;
-    }
+    e.g_max = std::isfinite(g) ? g * (1.0 + 1e-12) : g;  // (not finite: every screen that needs it declines, as with the device's)
   }
   if (rc == FC_OK) rc = ensemble_shard(&e, 0, 1, default_row_block());
   if (rc == FC_OK) rc = prebuild_screen_items(&e);

@@ -4301,7 +4301,9 @@ int launch_simbits_refine(fc_ensemble *e, double max_rmsd, double max_dev, const
                        (unsigned long long)e->pairq_cap, geom, bk, off, e->bk_list.as<int>(), st_off, xoff, n_st, x_stride,
                        e->sortq.as<uint64_t>(), e->simq.as<uint64_t>());
     FC_TRY(check_launch("k_refine_buckets"));
-  } else if (lanes) {
+  } else if (lanes && (double)e->N * (double)(e->N - 1) * 0.5 > (double)kRefineLanesMin) {
+    // (an ensemble whose WHOLE pair matrix fits the short queue -- N <= 512 -- never has a long one: no launch that finds
+    // nothing to do; k_simbits_refine below takes every queue of up to kRefineLanesMin pairs either way)
     static const int per_cu = [] {
       // workgroups per CU (tuning knob).  The kernel waits for the memory system, not for lanes: alone it takes 0.45 / 0.49 /
       // 0.47 ms for 9.45e5 pairs with 16 / 2 / 1 workgroups per CU; beside a screen, two per CU leave the screen the
